@@ -1,0 +1,248 @@
+"""Straight-line code emission for an ODE right-hand side and its derivatives.
+
+Given ``f : R^N -> R^n`` (N = n+1+m+p, the ODE input ``[x,t,u,p]``) as a DAG, build
+
+* ``J[k,i]  = d f_k / d y_i``                    (forward derivatives on the DAG)
+* ``g[i]    = sum_k lam_k d f_k / d y_i``         (one reverse sweep of ``lam . f``)
+* ``H[i,j]  = sum_k lam_k d2 f_k / d y_i d y_j``  (forward derivative of ``g``; lower triangle)
+
+and print them as one fully inlined function per "level" (value / value+J /
+value+J+g+H).  These three levels are exactly the three entry points the reference
+calls on a user ODE from the collocation defects -- ``compute``, ``compute_jacobian``,
+``compute_jacobian_adjointgradient_adjointhessian``
+(/root/reference/src/OptimalControl/LGLDefects.h:74,148,366-367,383-384).
+
+Two printers share the same node schedule:
+
+* :func:`emit_hip_functor`  -- a ``struct`` of ``__host__ __device__`` templates writing
+  through accessor objects, so a kernel can route results straight into LDS tiles /
+  registers with its own layout (no intermediate dense arrays).
+* :func:`emit_c`            -- plain C with pointer arguments (row-major J, full symmetric H).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Sequence, Tuple
+
+from .functions import VectorFunction
+from .ir import GRAPH as G
+from .ir import Node, topo_order
+
+
+@dataclass
+class OdeDerivatives:
+    name: str
+    xv: int
+    uv: int
+    pv: int
+    f: List[Node]
+    J: List[List[Node]]      # [n][N]
+    g: List[Node]            # [N]
+    H: List[List[Node]]      # [N][N], only j<=i filled (lower), mirrored on request
+
+    @property
+    def nin(self) -> int:
+        return self.xv + 1 + self.uv + self.pv
+
+    def stats(self) -> Dict[str, int]:
+        def count(roots):
+            return sum(1 for n in topo_order(roots) if n.args)
+        z = G.zero
+        return {
+            "ops_f": count(self.f),
+            "ops_fj": count(self.f + [e for r in self.J for e in r]),
+            "ops_fjgh": count(self.f + [e for r in self.J for e in r] + self.g
+                              + [self.H[i][j] for i in range(self.nin) for j in range(i + 1)]),
+            "nnz_J": sum(1 for r in self.J for e in r if e is not z),
+            "nnz_H_lower": sum(1 for i in range(self.nin) for j in range(i + 1) if self.H[i][j] is not z),
+        }
+
+
+def differentiate(name: str, ode: VectorFunction, xv: int, uv: int, pv: int) -> OdeDerivatives:
+    N = xv + 1 + uv + pv
+    if ode.IRows() != N:
+        raise ValueError(f"ODE input size {ode.IRows()} != XV+1+UV+PV = {N}")
+    if ode.ORows() != xv:
+        raise ValueError(f"ODE output size {ode.ORows()} != XV = {xv}")
+    ys = [G.var(i) for i in range(N)]
+    lams = [G.lam(k) for k in range(xv)]
+    f = list(ode.outs)
+    J = [[G.d(fk, y) for y in ys] for fk in f]
+    s = G.dot(lams, f)
+    g = G.grad(s, ys)
+    H = [[G.zero] * N for _ in range(N)]
+    for i in range(N):
+        for j in range(i + 1):
+            H[i][j] = G.d(g[i], ys[j])
+    return OdeDerivatives(name, xv, uv, pv, f, J, g, H)
+
+
+# --------------------------------------------------------------------------- printing
+
+def _cnum(v: float) -> str:
+    s = repr(float(v))
+    if s in ("inf", "-inf", "nan"):
+        raise ValueError("non-finite constant in ODE expression")
+    if "e" not in s and "." not in s:
+        s += ".0"
+    return f"({s})" if v < 0 else s
+
+
+class _Printer:
+    """Schedules reachable interior nodes into temporaries t0,t1,..."""
+
+    def __init__(self, roots: Sequence[Node], yname="y{}", lname="l{}"):
+        self.names: Dict[int, str] = {}
+        self.lines: List[str] = []
+        self.used_y = set()
+        self.used_l = set()
+        self.yname, self.lname = yname, lname
+        for n in topo_order(roots):
+            if n.op == "var":
+                self.used_y.add(n.value)
+            elif n.op == "lam":
+                self.used_l.add(n.value)
+            if n.args:
+                nm = f"t{len(self.lines)}"
+                self.lines.append(f"const double {nm} = {self._expr(n)};")
+                self.names[n.id] = nm
+
+    def ref(self, n: Node) -> str:
+        if n.op == "const":
+            return _cnum(n.value)
+        if n.op == "var":
+            return self.yname.format(n.value)
+        if n.op == "lam":
+            return self.lname.format(n.value)
+        return self.names[n.id]
+
+    def _expr(self, n: Node) -> str:
+        a = [self.ref(x) for x in n.args]
+        op = n.op
+        if op == "add":
+            return f"{a[0]} + {a[1]}"
+        if op == "sub":
+            return f"{a[0]} - {a[1]}"
+        if op == "mul":
+            return f"{a[0]} * {a[1]}"
+        if op == "div":
+            return f"{a[0]} / {a[1]}"
+        if op == "neg":
+            return f"-{a[0]}"
+        if op == "powi":
+            return _powi_expr(a[0], n.value)
+        if op == "powr":
+            return f"pow({a[0]}, {_cnum(n.value)})"
+        if op == "atan2":
+            return f"atan2({a[0]}, {a[1]})"
+        if op == "abs":
+            return f"fabs({a[0]})"
+        if op == "sign":
+            return f"(double)(({a[0]} > 0.0) - ({a[0]} < 0.0))"
+        return f"{op}({a[0]})"
+
+
+def _powi_expr(x: str, n: int) -> str:
+    """x**n (n>=3) by binary powering, written out as products."""
+    assert n >= 3
+    terms = []
+    sq = x
+    k = n
+    # square-and-multiply on strings; depth is tiny for the exponents ODEs use
+    while k:
+        if k & 1:
+            terms.append(sq)
+        k >>= 1
+        if k:
+            sq = f"({sq} * {sq})"
+    return " * ".join(terms)
+
+
+def _level_roots(d: OdeDerivatives, level: int) -> List[Node]:
+    roots = list(d.f)
+    if level >= 1:
+        roots += [e for r in d.J for e in r]
+    if level >= 2:
+        roots += d.g + [d.H[i][j] for i in range(d.nin) for j in range(i + 1)]
+    return roots
+
+
+def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
+    """HIP/C++ functor.  Accessor contracts:
+
+    ``in.y(i)`` / ``in.lam(k)`` return doubles; ``out.f(k,v)``, ``out.J(k,i,v)``, ``out.g(i,v)``,
+    ``out.H(i,j,v)`` (called once per lower-triangle entry, j<=i) receive every entry
+    including structural zeros, so the caller never has to pre-clear.
+    """
+    N, n = d.nin, d.xv
+    o: List[str] = []
+    o.append(f"// generated by asset_asrl_amd/vf/codegen.py -- ODE '{d.name}'  (XV={d.xv}, UV={d.uv}, PV={d.pv})")
+    st = d.stats()
+    o.append(f"// ops: f={st['ops_f']} f+J={st['ops_fj']} f+J+g+H={st['ops_fjgh']}  "
+             f"nnz(J)={st['nnz_J']}/{n * N}  nnz(H lower)={st['nnz_H_lower']}/{N * (N + 1) // 2}")
+    o.append(f"struct {struct_name} {{")
+    o.append(f"  static constexpr int XV = {d.xv}, UV = {d.uv}, PV = {d.pv}, NIN = {N};")
+    o.append(f"  static constexpr int NNZ_J = {st['nnz_J']}, NNZ_H = {st['nnz_H_lower']};")
+    o.append(f"  static constexpr const char* name() {{ return \"{d.name}\"; }}")
+    sigs = [
+        ("f", "template <class In, class Out> __host__ __device__ static inline void f(const In& in, Out& out)"),
+        ("fj", "template <class In, class Out> __host__ __device__ static inline void fj(const In& in, Out& out)"),
+        ("fjgh", "template <class In, class Out> __host__ __device__ static inline void fjgh(const In& in, Out& out)"),
+    ]
+    for level, (_, sig) in enumerate(sigs):
+        p = _Printer(_level_roots(d, level))
+        o.append(f"  {sig} {{")
+        for i in sorted(p.used_y):
+            o.append(f"    const double y{i} = in.y({i});")
+        for k in sorted(p.used_l):
+            o.append(f"    const double l{k} = in.lam({k});")
+        o += ["    " + ln for ln in p.lines]
+        for k in range(n):
+            o.append(f"    out.f({k}, {p.ref(d.f[k])});")
+        if level >= 1:
+            for k in range(n):
+                for i in range(N):
+                    o.append(f"    out.J({k}, {i}, {p.ref(d.J[k][i])});")
+        if level >= 2:
+            for i in range(N):
+                o.append(f"    out.g({i}, {p.ref(d.g[i])});")
+            for i in range(N):
+                for j in range(i + 1):
+                    o.append(f"    out.H({i}, {j}, {p.ref(d.H[i][j])});")
+        o.append("  }")
+    o.append("};")
+    return "\n".join(o) + "\n"
+
+
+def emit_c(d: OdeDerivatives, prefix: str) -> str:
+    """Plain C: ``<prefix>_f``, ``<prefix>_fj`` (J row-major n x N), ``<prefix>_fjgh`` (H full N x N)."""
+    N, n = d.nin, d.xv
+    o: List[str] = ["#include <math.h>",
+                    f"/* generated by asset_asrl_amd/vf/codegen.py -- ODE '{d.name}' */"]
+    sigs = [
+        f"void {prefix}_f(const double* y, double* f)",
+        f"void {prefix}_fj(const double* y, double* f, double* J)",
+        f"void {prefix}_fjgh(const double* y, const double* lam, double* f, double* J, double* g, double* H)",
+    ]
+    for level, sig in enumerate(sigs):
+        p = _Printer(_level_roots(d, level), yname="y[{}]", lname="lam[{}]")
+        o.append(sig + " {")
+        o += ["  " + ln for ln in p.lines]
+        for k in range(n):
+            o.append(f"  f[{k}] = {p.ref(d.f[k])};")
+        if level >= 1:
+            for k in range(n):
+                for i in range(N):
+                    o.append(f"  J[{k * N + i}] = {p.ref(d.J[k][i])};")
+        if level >= 2:
+            for i in range(N):
+                o.append(f"  g[{i}] = {p.ref(d.g[i])};")
+            for i in range(N):
+                for j in range(i + 1):
+                    r = p.ref(d.H[i][j])
+                    o.append(f"  H[{i * N + j}] = {r};")
+                    if i != j:
+                        o.append(f"  H[{j * N + i}] = {r};")
+        o.append("}")
+    o.append(f"const int {prefix}_sizes[3] = {{{d.xv}, {d.uv}, {d.pv}}};")
+    return "\n".join(o) + "\n"

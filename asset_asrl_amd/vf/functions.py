@@ -1,0 +1,380 @@
+"""Python-visible VectorFunction surface (subset) over the expression DAG.
+
+Mirrors the *names and argument meaning* of the reference's ``asset.VectorFunctions``
+objects that ODE definitions use (``Arguments``, ``head/tail/segment``, ``norm``,
+``normalized``, ``normalized_power3``, ``cross``, ``dot``, ``stack``, ``sum``,
+``sin``/``cos``/..., operator overloads, ``F(G)`` composition, ``RowMatrix``) --
+see /root/reference/src/VectorFunctions/DenseFunctionBase.h:1644-2101 (operator and
+method binds) and /root/reference/asset_asrl/VectorFunctions/__init__.py:7-58.
+The objects here do not evaluate anything on the CPU hot path: they only build the
+DAG that codegen.py turns into HIP device code.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Union
+
+import numpy as np
+
+from .ir import GRAPH as G
+from .ir import Node, evaluate
+
+Number = Union[int, float, np.floating, np.integer]
+
+
+def _is_num(x) -> bool:
+    return isinstance(x, (int, float, np.floating, np.integer))
+
+
+class VectorFunction:
+    """A map R^irows -> R^orows given as DAG roots over the leaves var0..var{irows-1}."""
+
+    __array_ufunc__ = None  # numpy arrays defer to our reflected operators
+
+    def __init__(self, irows: int, outs: Sequence[Node]):
+        self._irows = int(irows)
+        self.outs: List[Node] = list(outs)
+
+    # ---- sizes (reference names) ---------------------------------------------------
+    def IRows(self) -> int:
+        return self._irows
+
+    def ORows(self) -> int:
+        return len(self.outs)
+
+    def name(self) -> str:
+        return f"VectorFunction<{self._irows},{len(self.outs)}>"
+
+    def is_scalar(self) -> bool:
+        return len(self.outs) == 1
+
+    # ---- construction helpers ------------------------------------------------------
+    def _like(self, outs: Sequence[Node]) -> "VectorFunction":
+        return VectorFunction(self._irows, outs)
+
+    def _coerce(self, other, n: int) -> List[Node]:
+        """Broadcast a python number / numpy vector / function to n DAG nodes."""
+        if isinstance(other, VectorFunction):
+            if other._irows != self._irows:
+                raise ValueError("Functions must have the same input size")
+            if other.ORows() == n:
+                return other.outs
+            if other.ORows() == 1:
+                return other.outs * n
+            raise ValueError("Output sizes do not match")
+        if _is_num(other):
+            return [G.const(other)] * n
+        arr = np.asarray(other, dtype=float).ravel()
+        if arr.size != n:
+            raise ValueError("Vector size does not match function output size")
+        return [G.const(v) for v in arr]
+
+    # ---- indexing ------------------------------------------------------------------
+    def segment(self, start: int, size: int) -> "VectorFunction":
+        if start < 0 or size < 0 or start + size > self.ORows():
+            raise ValueError("Segment index out of bounds")
+        return self._like(self.outs[start:start + size])
+
+    def head(self, n: int) -> "VectorFunction":
+        return self.segment(0, n)
+
+    def tail(self, n: int) -> "VectorFunction":
+        return self.segment(self.ORows() - n, n)
+
+    def head2(self):
+        return self.head(2)
+
+    def head3(self):
+        return self.head(3)
+
+    def tail2(self):
+        return self.tail(2)
+
+    def tail3(self):
+        return self.tail(3)
+
+    def segment2(self, start: int):
+        return self.segment(start, 2)
+
+    def segment3(self, start: int):
+        return self.segment(start, 3)
+
+    def coeff(self, i: int) -> "VectorFunction":
+        return self.segment(i, 1)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self._like(self.outs[i])
+        if i < 0:
+            i += self.ORows()
+        return self.coeff(i)
+
+    def tolist(self, spec=None):
+        """Scalar components, or sub-vectors for a list of (start,size) pairs."""
+        if spec is None:
+            return [self.coeff(i) for i in range(self.ORows())]
+        return [self.segment(s, n) for (s, n) in spec]
+
+    # ---- composition ---------------------------------------------------------------
+    def eval(self, inner: "VectorFunction") -> "VectorFunction":
+        """self(inner(x)) -- the reference's ``F.eval(G)`` / ``F(G)``."""
+        if inner.ORows() != self._irows:
+            raise ValueError("Inner function output size does not match outer input size")
+        outs = G.substitute(self.outs, {i: n for i, n in enumerate(inner.outs)})
+        return VectorFunction(inner._irows, outs)
+
+    def __call__(self, arg):
+        if isinstance(arg, VectorFunction):
+            return self.eval(arg)
+        return self.compute(arg)
+
+    # ---- host-side numeric evaluation (set-up / tests only) ------------------------
+    def compute(self, x) -> np.ndarray:
+        x = np.asarray(x, dtype=float).ravel()
+        if x.size != self._irows:
+            raise ValueError("Input vector has incorrect size")
+        return np.array(evaluate(self.outs, x))
+
+    # ---- arithmetic ----------------------------------------------------------------
+    def _bin(self, other, fn, swap=False):
+        n = self.ORows()
+        if isinstance(other, VectorFunction) and other.ORows() != n and n == 1:
+            n = other.ORows()
+        a = self._coerce(self, n)
+        b = self._coerce(other, n)
+        if swap:
+            a, b = b, a
+        return self._like([fn(x, y) for x, y in zip(a, b)])
+
+    def __add__(self, o):
+        return self._bin(o, G.add)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._bin(o, G.sub)
+
+    def __rsub__(self, o):
+        return self._bin(o, G.sub, swap=True)
+
+    def __mul__(self, o):
+        return self._bin(o, G.mul)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        return self._bin(o, G.div)
+
+    def __rtruediv__(self, o):
+        return self._bin(o, G.div, swap=True)
+
+    def __neg__(self):
+        return self._like([G.neg(x) for x in self.outs])
+
+    def __pow__(self, p):
+        if not _is_num(p):
+            raise TypeError("only constant exponents are supported")
+        return self._like([G.powr(x, float(p)) for x in self.outs])
+
+    def _map(self, op: str):
+        return self._like([G.unary(op, x) for x in self.outs])
+
+    def squared(self):
+        return self * self
+
+    def sqrt(self):
+        return self._map("sqrt")
+
+    def exp(self):
+        return self._map("exp")
+
+    def log(self):
+        return self._map("log")
+
+    def sin(self):
+        return self._map("sin")
+
+    def cos(self):
+        return self._map("cos")
+
+    def tan(self):
+        return self._map("tan")
+
+    def tanh(self):
+        return self._map("tanh")
+
+    # ---- vector algebra ------------------------------------------------------------
+    def sum(self):
+        return self._like([G.sum(self.outs)])
+
+    def dot(self, other):
+        b = self._coerce(other, self.ORows())
+        return self._like([G.dot(self.outs, b)])
+
+    def squared_norm(self):
+        return self._like([G.dot(self.outs, self.outs)])
+
+    def norm(self):
+        return self._like([G.unary("sqrt", G.dot(self.outs, self.outs))])
+
+    def inverse_norm(self):
+        return self._like([G.div(G.one, G.unary("sqrt", G.dot(self.outs, self.outs)))])
+
+    def cubed_norm(self):
+        n = G.unary("sqrt", G.dot(self.outs, self.outs))
+        return self._like([G.powi(n, 3)])
+
+    def normalized(self):
+        n = G.unary("sqrt", G.dot(self.outs, self.outs))
+        return self._like([G.div(x, n) for x in self.outs])
+
+    def _normalized_power(self, k: int):
+        n = G.unary("sqrt", G.dot(self.outs, self.outs))
+        nk = G.powi(n, k)
+        return self._like([G.div(x, nk) for x in self.outs])
+
+    def normalized_power2(self):
+        return self._normalized_power(2)
+
+    def normalized_power3(self):
+        return self._normalized_power(3)
+
+    def normalized_power4(self):
+        return self._normalized_power(4)
+
+    def normalized_power5(self):
+        return self._normalized_power(5)
+
+    def cross(self, other):
+        if self.ORows() != 3:
+            raise ValueError("cross requires 3-vectors")
+        a = self.outs
+        b = self._coerce(other, 3)
+        return self._like([
+            G.sub(G.mul(a[1], b[2]), G.mul(a[2], b[1])),
+            G.sub(G.mul(a[2], b[0]), G.mul(a[0], b[2])),
+            G.sub(G.mul(a[0], b[1]), G.mul(a[1], b[0])),
+        ])
+
+    def cwiseProduct(self, other):
+        return self * other
+
+    def cwiseQuotient(self, other):
+        return self / other
+
+
+class MatrixFunction:
+    """Row/Col-major matrix view of a VectorFunction (``vf.RowMatrix`` / ``vf.ColMatrix``)."""
+
+    def __init__(self, f: VectorFunction, rows: int, cols: int, rowmajor: bool):
+        if f.ORows() != rows * cols:
+            raise ValueError("matrix dimensions do not match function output size")
+        self.f, self.rows, self.cols, self.rowmajor = f, rows, cols, rowmajor
+
+    def _elem(self, r, c) -> Node:
+        k = r * self.cols + c if self.rowmajor else c * self.rows + r
+        return self.f.outs[k]
+
+    def __mul__(self, v):
+        b = self.f._coerce(v, self.cols)
+        outs = [G.sum(G.mul(self._elem(r, c), b[c]) for c in range(self.cols)) for r in range(self.rows)]
+        return self.f._like(outs)
+
+
+# --------------------------------------------------------------------------- free functions
+
+def Arguments(n: int) -> VectorFunction:
+    return VectorFunction(n, [G.var(i) for i in range(n)])
+
+
+def Segment(irows: int, size: int, start: int) -> VectorFunction:
+    return Arguments(irows).segment(start, size)
+
+
+def Element(irows: int, i: int) -> VectorFunction:
+    return Arguments(irows).coeff(i)
+
+
+def _flatten(args) -> List:
+    if len(args) == 1 and isinstance(args[0], (list, tuple)):
+        return list(args[0])
+    return list(args)
+
+
+def stack(*args) -> VectorFunction:
+    fs = _flatten(args)
+    ir = next(f._irows for f in fs if isinstance(f, VectorFunction))
+    outs: List[Node] = []
+    for f in fs:
+        if isinstance(f, VectorFunction):
+            if f._irows != ir:
+                raise ValueError("Functions must have the same input size")
+            outs.extend(f.outs)
+        elif _is_num(f):
+            outs.append(G.const(f))
+        else:
+            outs.extend(G.const(v) for v in np.asarray(f, dtype=float).ravel())
+    return VectorFunction(ir, outs)
+
+
+Stack = stack
+stack_scalar = stack
+
+
+def sum(*args) -> VectorFunction:  # noqa: A001  (reference name)
+    fs = _flatten(args)
+    acc = fs[0]
+    for f in fs[1:]:
+        acc = acc + f
+    return acc
+
+
+Sum = sum
+
+
+def _u(op):
+    def fn(f: VectorFunction) -> VectorFunction:
+        return f._map(op)
+    fn.__name__ = op
+    return fn
+
+
+sin, cos, tan, exp, log, sqrt, tanh = (_u(o) for o in ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh"))
+sinh, cosh = _u("sinh"), _u("cosh")
+arcsin, arccos, arctan = _u("asin"), _u("acos"), _u("atan")
+abs = _u("abs")  # noqa: A001
+
+
+def arctan2(y: VectorFunction, x: VectorFunction) -> VectorFunction:
+    return y._like([G.atan2(a, b) for a, b in zip(y.outs, x.outs)])
+
+
+def dot(a: VectorFunction, b) -> VectorFunction:
+    return a.dot(b)
+
+
+def cross(a: VectorFunction, b) -> VectorFunction:
+    return a.cross(b)
+
+
+def cwiseProduct(a, b):
+    return a * b
+
+
+def cwiseQuotient(a, b):
+    return a / b
+
+
+def RowMatrix(f: VectorFunction, rows: int, cols: int) -> MatrixFunction:
+    return MatrixFunction(f, rows, cols, True)
+
+
+def ColMatrix(f: VectorFunction, rows: int, cols: int) -> MatrixFunction:
+    return MatrixFunction(f, rows, cols, False)
+
+
+def ConstantVector(irows: int, v) -> VectorFunction:
+    return VectorFunction(irows, [G.const(x) for x in np.asarray(v, dtype=float).ravel()])
+
+
+def ConstantScalar(irows: int, v: float) -> VectorFunction:
+    return VectorFunction(irows, [G.const(v)])

@@ -1,0 +1,210 @@
+"""ORACLE (test infrastructure): ctypes bindings to liboracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TRAPEZOIDAL, LGL3, LGL5, LGL7 = 1, 2, 3, 4
+MODES = {"Trapezoidal": 1, "LGL3": 2, "LGL5": 3, "LGL7": 4}
+CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS = range(5)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class OdeStruct(C.Structure):
+    _fields_ = [("xv", C.c_int), ("uv", C.c_int), ("pv", C.c_int),
+                ("f", C.c_void_p), ("fj", C.c_void_p), ("fjgh", C.c_void_p), ("ctx", C.c_void_p)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.oracle_get_ode.argtypes = [C.c_char_p, C.c_int, C.POINTER(OdeStruct)]
+        L.oracle_set_synthetic32.argtypes = [_dp]
+        L.oracle_defect_sizes.argtypes = [C.c_int] * 5 + [_ip, _ip]
+        L.oracle_defect_compute.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, _dp, _dp]
+        L.oracle_defect_jacobian.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, _dp, _dp, _dp]
+        L.oracle_defect_all.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.oracle_lgl_table.argtypes = [C.c_int, C.c_char_p]
+        L.oracle_lgl_table.restype = _dp
+        L.oracle_phase_num_vars.argtypes = [C.c_int] * 7
+        L.oracle_phase_defect_index.argtypes = [C.c_int] * 9 + [_ip, _ip]
+        L.oracle_nlp_create.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int,
+                                        C.c_int]
+        L.oracle_nlp_create.restype = C.c_void_p
+        L.oracle_nlp_destroy.argtypes = [C.c_void_p]
+        for fn in ("oracle_nlp_kkt_dim", "oracle_nlp_nnz", "oracle_nlp_num_user_kkt"):
+            getattr(L, fn).argtypes = [C.c_void_p]
+        L.oracle_nlp_csr.argtypes = [C.c_void_p, _ip, _ip]
+        L.oracle_nlp_kkt_locations.argtypes = [C.c_void_p, _ip]
+        L.oracle_nlp_kkt_coords.argtypes = [C.c_void_p, _ip, _ip]
+        L.oracle_nlp_eval.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.oracle_nlp_eval_blocks.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def synthetic32_coeffs(n: int = 32, seed: int = 32) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return np.concatenate([rng.uniform(0.5, 1.5, n) for _ in range(3)])
+
+
+def get_ode(name: str, provider: int = 0) -> OdeStruct:
+    o = OdeStruct()
+    if name == "synthetic32":
+        abc = np.ascontiguousarray(synthetic32_coeffs())
+        lib().oracle_set_synthetic32(_d(abc))
+    rc = lib().oracle_get_ode(name.encode(), provider, C.byref(o))
+    if rc:
+        raise KeyError(f"oracle ODE {name!r} provider {provider}: rc={rc}")
+    return o
+
+
+def lgl_table(cs: int, which: str) -> np.ndarray:
+    p = lib().oracle_lgl_table(cs, which.encode())
+    K = cs - 1
+    shape = {"tc": (cs,), "s": (K,), "E": (K,)}.get(which)
+    if shape is not None:
+        return np.array([p[i] for i in range(shape[0])])
+    return np.array([[p[i * 4 + j] for j in range(cs)] for i in range(K)])
+
+
+def defect_sizes(mode: int, ode: OdeStruct, blocked: bool = False):
+    ir, orr = C.c_int(), C.c_int()
+    rc = lib().oracle_defect_sizes(mode, ode.xv, ode.uv, ode.pv, int(blocked), C.byref(ir), C.byref(orr))
+    if rc:
+        raise ValueError("bad mode")
+    return ir.value, orr.value
+
+
+def defect_compute(ode, mode, x, blocked=False):
+    ir, orr = defect_sizes(mode, ode, blocked)
+    x = np.ascontiguousarray(x, dtype=float)
+    assert x.size == ir
+    fx = np.zeros(orr)
+    lib().oracle_defect_compute(C.byref(ode), mode, int(blocked), _d(x), _d(fx))
+    return fx
+
+
+def defect_jacobian(ode, mode, x, blocked=False):
+    ir, orr = defect_sizes(mode, ode, blocked)
+    x = np.ascontiguousarray(x, dtype=float)
+    fx, jx = np.zeros(orr), np.zeros((ir, orr))
+    lib().oracle_defect_jacobian(C.byref(ode), mode, int(blocked), _d(x), _d(fx), _d(jx))
+    return fx, jx.T.copy()
+
+
+def defect_all(ode, mode, x, lam, blocked=False):
+    """(fx, jx[OR,IR], gx, hx[IR,IR]) -- the reference's ``computeall(x,l)`` tuple."""
+    ir, orr = defect_sizes(mode, ode, blocked)
+    x = np.ascontiguousarray(x, dtype=float)
+    lam = np.ascontiguousarray(lam, dtype=float)
+    assert x.size == ir and lam.size == orr
+    fx, jx, gx, hx = np.zeros(orr), np.zeros((ir, orr)), np.zeros(ir), np.zeros((ir, ir))
+    lib().oracle_defect_all(C.byref(ode), mode, int(blocked), _d(x), _d(lam), _d(fx), _d(jx), _d(gx), _d(hx))
+    return fx, jx.T.copy(), gx, hx.T.copy()
+
+
+def phase_num_vars(xv, uv, pv, spv, cs, nd, blocked):
+    return lib().oracle_phase_num_vars(xv, uv, pv, spv, cs, nd, int(blocked))
+
+
+def phase_defect_index(xv, uv, pv, spv, cs, nd, blocked, var_offset=0, con_offset=0):
+    if blocked:
+        ir = cs * (xv + 1) + uv + pv
+    else:
+        ir = cs * (xv + 1 + uv) + pv
+    orr = (cs - 1) * xv
+    V = np.zeros((nd, ir), dtype=np.int32)
+    Cx = np.zeros((nd, orr), dtype=np.int32)
+    got = lib().oracle_phase_defect_index(xv, uv, pv, spv, cs, nd, int(blocked), var_offset, con_offset, _i(V), _i(Cx))
+    assert got == ir
+    return V, Cx  # row V = application V (i.e. transposed w.r.t. the reference's column-per-application)
+
+
+class Nlp:
+    def __init__(self, ode, mode, blocked, vindex, cindex, primal, equal, threads=1):
+        self.ode = ode
+        self.vindex = np.ascontiguousarray(vindex, dtype=np.int32)
+        self.cindex = np.ascontiguousarray(cindex, dtype=np.int32)
+        self.nappl, self.ir = self.vindex.shape
+        self.orr = self.cindex.shape[1]
+        self.primal, self.equal = primal, equal
+        self.h = lib().oracle_nlp_create(C.byref(ode), mode, int(blocked), self.nappl, _i(self.vindex),
+                                         _i(self.cindex), primal, equal, threads)
+        if not self.h:
+            raise ValueError("oracle_nlp_create failed")
+        self.kkt_dim = lib().oracle_nlp_kkt_dim(self.h)
+        self.nnz = lib().oracle_nlp_nnz(self.h)
+        self.num_user_kkt = lib().oracle_nlp_num_user_kkt(self.h)
+        self.nkkt = self.num_user_kkt // max(self.nappl, 1)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_nlp_destroy(self.h)
+            self.h = None
+
+    def csr(self):
+        outer = np.zeros(self.kkt_dim + 1, dtype=np.int32)
+        inner = np.zeros(self.nnz, dtype=np.int32)
+        lib().oracle_nlp_csr(self.h, _i(outer), _i(inner))
+        return outer, inner
+
+    def kkt_locations(self):
+        locs = np.zeros(self.num_user_kkt + self.kkt_dim, dtype=np.int32)
+        lib().oracle_nlp_kkt_locations(self.h, _i(locs))
+        return locs
+
+    def kkt_coords(self):
+        r = np.zeros(self.num_user_kkt + self.kkt_dim, dtype=np.int32)
+        c = np.zeros_like(r)
+        lib().oracle_nlp_kkt_coords(self.h, _i(r), _i(c))
+        return r, c
+
+    def eval(self, what, X, LE=None):
+        X = np.ascontiguousarray(X, dtype=float)
+        LE = None if LE is None else np.ascontiguousarray(LE, dtype=float)
+        FXE = np.zeros(self.equal)
+        AGX = np.zeros(self.primal)
+        vals = np.zeros(self.nnz) if what >= JAC else None
+        rc = lib().oracle_nlp_eval(self.h, what, _d(X), _d(LE), _d(FXE), _d(AGX), _d(vals))
+        if rc:
+            raise RuntimeError(f"oracle_nlp_eval rc={rc}")
+        return FXE, AGX, vals
+
+    def eval_blocks(self, what, X, LE=None):
+        X = np.ascontiguousarray(X, dtype=float)
+        LE = None if LE is None else np.ascontiguousarray(LE, dtype=float)
+        fx = np.zeros((self.nappl, self.orr))
+        agx = np.zeros((self.nappl, self.ir))
+        kkt = np.zeros((self.nappl, self.nkkt)) if what >= JAC else None
+        rc = lib().oracle_nlp_eval_blocks(self.h, what, _d(X), _d(LE), _d(fx), _d(agx), _d(kkt))
+        if rc:
+            raise RuntimeError(f"oracle_nlp_eval_blocks rc={rc}")
+        return fx, agx, kkt

@@ -1,0 +1,109 @@
+// ORACLE (test infrastructure, never shipped or imported by the product path).
+//
+// ODE registry.  Provider 0 ("ad2") derives df/dy and lam^T d2f/dy2 from the templated right-hand
+// sides in odes.h with the AD2 scalar -- independent of the product's code generator and used for
+// every parity check.  Provider 1 ("gen") links the plain-C analytic derivatives printed by the
+// product's generator (oracle/gen/odes_gen.c, made by oracle/gen_odes.py); it exists only so that
+// bench.py's cpu_baseline is not handicapped by AD2's O(N^2)-per-operation cost, and is itself
+// checked against provider 0 in tests/test_oracle.py.
+#include <cstring>
+
+#include "odes.h"
+#include "oracle.h"
+
+namespace {
+
+double g_synth32[96];
+
+template <int XV, int NIN, void (*FD)(const double*, double*, const void*),
+          void (*FA)(const AD2<NIN>*, AD2<NIN>*, const void*)>
+struct Ad2Provider {
+  static void f(const double* y, double* fx, const void* ctx) { FD(y, fx, ctx); }
+  static void run(const double* y, AD2<NIN>* out, const void* ctx) {
+    AD2<NIN> in[NIN];
+    for (int i = 0; i < NIN; i++) in[i] = AD2<NIN>::variable(y[i], i);
+    FA(in, out, ctx);
+  }
+  static void fj(const double* y, double* fx, double* J, const void* ctx) {
+    AD2<NIN> out[XV];
+    run(y, out, ctx);
+    for (int k = 0; k < XV; k++) {
+      fx[k] = out[k].v;
+      for (int i = 0; i < NIN; i++) J[k * NIN + i] = out[k].g[i];
+    }
+  }
+  static void fjgh(const double* y, const double* lam, double* fx, double* J, double* g, double* H, const void* ctx) {
+    AD2<NIN> out[XV];
+    run(y, out, ctx);
+    for (int i = 0; i < NIN; i++) g[i] = 0.0;
+    for (int i = 0; i < NIN * NIN; i++) H[i] = 0.0;
+    for (int k = 0; k < XV; k++) {
+      fx[k] = out[k].v;
+      for (int i = 0; i < NIN; i++) {
+        J[k * NIN + i] = out[k].g[i];
+        g[i] += lam[k] * out[k].g[i];
+      }
+      for (int i = 0; i < NIN * NIN; i++) H[i] += lam[k] * out[k].h[i];
+    }
+  }
+};
+
+#define AD2_ODE(NAME, XV, UV, PV)                                                                      \
+  using P_##NAME = Ad2Provider<XV, XV + 1 + UV + PV, &oracle_odes::NAME<double>,                       \
+                               &oracle_odes::NAME<AD2<XV + 1 + UV + PV>>>;
+
+AD2_ODE(brachistochrone, 3, 1, 0)
+AD2_ODE(reentry, 5, 2, 0)
+AD2_ODE(twobody_lt, 6, 3, 0)
+AD2_ODE(betts_lowthrust, 7, 3, 1)
+AD2_ODE(synthetic32, 32, 0, 0)
+
+}  // namespace
+
+// generated analytic C (optional at link time)
+#define GEN_DECL(NAME)                                                                                  \
+  extern "C" void ode_##NAME##_f(const double*, double*) __attribute__((weak));                         \
+  extern "C" void ode_##NAME##_fj(const double*, double*, double*) __attribute__((weak));               \
+  extern "C" void ode_##NAME##_fjgh(const double*, const double*, double*, double*, double*, double*)   \
+      __attribute__((weak));                                                                            \
+  namespace {                                                                                           \
+  void gen_##NAME##_f(const double* y, double* f, const void*) { ode_##NAME##_f(y, f); }                \
+  void gen_##NAME##_fj(const double* y, double* f, double* J, const void*) { ode_##NAME##_fj(y, f, J); } \
+  void gen_##NAME##_fjgh(const double* y, const double* l, double* f, double* J, double* g, double* H,  \
+                         const void*) {                                                                 \
+    ode_##NAME##_fjgh(y, l, f, J, g, H);                                                                \
+  }                                                                                                     \
+  }
+GEN_DECL(brachistochrone)
+GEN_DECL(reentry)
+GEN_DECL(twobody_lt)
+GEN_DECL(betts_lowthrust)
+GEN_DECL(synthetic32)
+
+extern "C" {
+
+void oracle_set_synthetic32(const double* abc) { std::memcpy(g_synth32, abc, sizeof g_synth32); }
+
+#define TRY(NAME, XV, UV, PV, CTX)                                                  \
+  if (!std::strcmp(name, #NAME)) {                                                  \
+    out->xv = XV, out->uv = UV, out->pv = PV, out->ctx = CTX;                       \
+    if (provider == 0) {                                                            \
+      out->f = &P_##NAME::f, out->fj = &P_##NAME::fj, out->fjgh = &P_##NAME::fjgh;  \
+      return 0;                                                                     \
+    }                                                                               \
+    if (provider == 1 && ode_##NAME##_fjgh) {                                       \
+      out->f = &gen_##NAME##_f, out->fj = &gen_##NAME##_fj, out->fjgh = &gen_##NAME##_fjgh; \
+      return 0;                                                                     \
+    }                                                                               \
+    return -2;                                                                      \
+  }
+
+int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
+  TRY(brachistochrone, 3, 1, 0, nullptr)
+  TRY(reentry, 5, 2, 0, nullptr)
+  TRY(twobody_lt, 6, 3, 0, nullptr)
+  TRY(betts_lowthrust, 7, 3, 1, nullptr)
+  TRY(synthetic32, 32, 0, 0, g_synth32)
+  return -1;
+}
+}

@@ -1,0 +1,221 @@
+// ORACLE (test infrastructure, never shipped or imported by the product path).
+//
+// Right-hand sides of the BASELINE.json config ODEs, written as templates over the scalar type so
+// the same text yields values (S=double) and exact derivatives (S=AD2<N>).  Each function restates
+// the dynamics of a reference example script (input layout y = [x, t, u, p]):
+//   brachistochrone  /root/reference/examples/Brachistochrone.py:15-33
+//   reentry          /root/reference/examples/Reentry.py:14-97
+//   twobody_lt       /root/reference/examples/MultiSpacecraftOptimization.py:17-34
+//   betts_lowthrust  /root/reference/examples/BettsLowThrust.py:22-48,212-400
+//   synthetic32      SURVEY.md section 8(d) (defined by this build)
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "ad2.h"
+
+namespace oracle_odes {
+
+using std::cos;
+using std::exp;
+using std::sin;
+using std::sqrt;
+using std::tan;
+
+// ------------------------------------------------------------------ brachistochrone (3,1,0)
+template <class S>
+void brachistochrone(const S* y, S* f, const void*) {
+  const double g = 9.81;
+  const S& v = y[2];
+  const S& theta = y[4];
+  f[0] = sin(theta) * v;
+  f[1] = -1.0 * cos(theta) * v;
+  f[2] = g * cos(theta);
+}
+
+// ------------------------------------------------------------------ shuttle reentry (5,2,0)
+template <class S>
+void reentry(const S* y, S* f, const void*) {
+  const double g0 = 32.2, W = 203000.0;
+  const double Lstar = 100000.0, Tstar = 60.0, Mstar = W / g0;
+  const double Rhostar = Mstar / (Lstar * Lstar * Lstar);
+  const double Mustar = (Lstar * Lstar * Lstar) / (Tstar * Tstar);
+  const double Re = 20902900.0 / Lstar;
+  const double Sref = 2690.0 / (Lstar * Lstar);
+  const double m = (W / g0) / Mstar;
+  const double mu = 0.140765e17 / Mustar;
+  const double rho0 = 0.002378 / Rhostar;
+  const double h_ref = 23800.0 / Lstar;
+  const double a0 = -0.20704, a1 = 0.029244;
+  const double b0 = 0.07854, b1 = -0.61592e-2, b2 = 0.621408e-3;
+
+  const S &h = y[0], &theta = y[1], &v = y[2], &gamma = y[3], &psi = y[4];
+  const S &alpha = y[6], &beta = y[7];
+
+  S alphadeg = (180.0 / M_PI) * alpha;
+  S CL = a0 + a1 * alphadeg;
+  S CD = b0 + b1 * alphadeg + b2 * (alphadeg * alphadeg);
+  S rho = rho0 * exp(-h / h_ref);
+  S r = h + Re;
+  S L = 0.5 * CL * Sref * rho * (v * v);
+  S D = 0.5 * CD * Sref * rho * (v * v);
+  S g = mu / (r * r);
+  S sgam = sin(gamma), cgam = cos(gamma);
+  S sbet = sin(beta), cbet = cos(beta);
+  S spsi = sin(psi), cpsi = cos(psi);
+  S tantheta = tan(theta);
+
+  f[0] = v * sgam;
+  f[1] = (v / r) * cgam * cpsi;
+  f[2] = -D / m - g * sgam;
+  f[3] = (L / (m * v)) * cbet + cgam * (v / r - g / v);
+  f[4] = L * sbet / (m * v * cgam) + (v / r) * cgam * spsi * tantheta;
+}
+
+// ------------------------------------------------------------------ two-body + low-thrust (6,3,0)
+template <class S>
+void twobody_lt(const S* y, S* f, const void*) {
+  const double P1mu = 1.0, ltacc = 0.01;
+  S r2 = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+  S rn = sqrt(r2);
+  S r3 = rn * rn * rn;
+  for (int i = 0; i < 3; i++) {
+    f[i] = y[3 + i];
+    f[3 + i] = (y[i] / r3) * (-P1mu) + y[7 + i] * ltacc;
+  }
+}
+
+// ------------------------------------------------------------------ Betts low thrust MEE (7,3,1)
+struct BettsConsts {
+  double Re, mu, Thrust, Isp, gs, J2, J3, J4;
+  BettsConsts() {
+    const double g0 = 32.174, W = 1.0, mu_e = 1.407645794e16, Lstar = 20925662.73;
+    const double Tstar = Lstar / std::sqrt(mu_e / Lstar);
+    const double Mstar = W / g0;
+    const double Fstar = Mstar * Lstar / (Tstar * Tstar);
+    const double Astar = Lstar / (Tstar * Tstar);
+    const double Mustar = (Lstar * Lstar * Lstar) / (Tstar * Tstar);
+    Re = 20925662.73 / Lstar;
+    mu = mu_e / Mustar;
+    Thrust = 4.446618e-3 / Fstar;
+    Isp = 450.0 / Tstar;
+    gs = g0 / Astar;
+    J2 = 1082.639e-6;
+    J3 = -2.565e-6;
+    J4 = -1.608e-6;
+  }
+};
+
+template <class S>
+static inline S norm3(const S* a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+template <class S>
+static inline void cross3(const S* a, const S* b, S* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <class S>
+static inline void normalize3(const S* a, S* out) {
+  S n = norm3(a);
+  for (int i = 0; i < 3; i++) out[i] = a[i] / n;
+}
+
+template <class S>
+void betts_lowthrust(const S* y, S* f, const void*) {
+  static const BettsConsts c;
+  const double mu = c.mu;
+  const S &p = y[0], &ff = y[1], &g = y[2], &h = y[3], &k = y[4], &L = y[5], &ww = y[6];
+  const S* Uraw = y + 8;
+  const S& tau = y[11];
+
+  // MEE -> Cartesian position/velocity (BettsLowThrust.py:212-238)
+  S sinL = sin(L), cosL = cos(L);
+  S sqmp = sqrt(mu / p);
+  S w = 1.0 + ff * cosL + g * sinL;
+  S s2 = 1.0 + h * h + k * k;
+  S a2 = h * h - k * k;
+  S r = p / w;
+  S r_s2 = r / s2;
+  S subs2 = 1.0 / s2;
+  S R[3], V[3];
+  R[0] = r_s2 * (cosL + a2 * cosL + 2.0 * h * k * sinL);
+  R[1] = r_s2 * (sinL - a2 * sinL + 2.0 * h * k * cosL);
+  R[2] = r_s2 * (2.0 * (h * sinL - k * cosL));
+  S vs = -subs2 * sqmp;
+  V[0] = vs * (sinL + a2 * sinL - 2.0 * h * k * cosL + g - 2.0 * ff * h * k + a2 * g);
+  V[1] = vs * (-cosL + a2 * cosL + 2.0 * h * k * sinL - ff + 2.0 * g * h * k + a2 * ff);
+  V[2] = vs * (-2.0 * (h * cosL + k * sinL + ff * h + g * k));
+
+  // zonal gravity J2..J4 in RTN (BettsLowThrust.py:250-304)
+  S rn = norm3(R);
+  S Ir[3];
+  normalize3(R, Ir);
+  S IrN = Ir[2];  // Ir . North, North = (0,0,1)
+  S Inraw[3] = {0.0 - Ir[0] * IrN, 0.0 - Ir[1] * IrN, 1.0 - Ir[2] * IrN};
+  S In[3];
+  normalize3(Inraw, In);
+  S sphi = Ir[2];
+  S cphi = sqrt(1.0 - sphi * sphi);
+  S sphi2 = sphi * sphi, sphi3 = sphi2 * sphi, sphi4 = sphi2 * sphi2;
+  S P2 = 0.5 * (3.0 * sphi2 - 1.0);
+  S P3 = 0.5 * (5.0 * sphi3 - 3.0 * sphi);
+  S P4 = (35.0 / 8.0) * sphi4 - (30.0 / 8.0) * sphi2 + 3.0 / 8.0;
+  S D2 = 3.0 * sphi;
+  S D3 = 0.5 * (15.0 * sphi2 - 3.0);
+  S D4 = (35.0 / 2.0) * sphi3 - (30.0 / 4.0) * sphi;
+  S Rr = c.Re / rn;
+  S Rr2 = Rr * Rr, Rr3 = Rr2 * Rr, Rr4 = Rr2 * Rr2;
+  S gn = (D2 * c.J2 * Rr2 + D3 * c.J3 * Rr3 + D4 * c.J4 * Rr4) * cphi;
+  S gr = (3.0 * P2 * c.J2) * Rr2 + (4.0 * P3 * c.J3) * Rr3 + (5.0 * P4 * c.J4) * Rr4;
+  S gsc = -mu / (R[0] * R[0] + R[1] * R[1] + R[2] * R[2]);
+  S Gcart[3];
+  for (int i = 0; i < 3; i++) Gcart[i] = (gn * In[i] - gr * Ir[i]) * gsc;
+  // RTN basis rows: Rhat, That = (Nhat x R)^, Nhat = (R x V)^
+  S Nraw[3], Nhat[3], Traw[3], That[3];
+  cross3(R, V, Nraw);
+  normalize3(Nraw, Nhat);
+  cross3(Nhat, R, Traw);
+  normalize3(Traw, That);
+  S accJ[3];
+  accJ[0] = Ir[0] * Gcart[0] + Ir[1] * Gcart[1] + Ir[2] * Gcart[2];
+  accJ[1] = That[0] * Gcart[0] + That[1] * Gcart[1] + That[2] * Gcart[2];
+  accJ[2] = Nhat[0] * Gcart[0] + Nhat[1] * Gcart[1] + Nhat[2] * Gcart[2];
+
+  // thrust acceleration (BettsLowThrust.py:381-387)
+  S Uhat[3];
+  normalize3(Uraw, Uhat);
+  S thr = c.gs * c.Thrust * (1.0 + 0.01 * tau);
+  S ur = thr * Uhat[0] / ww + accJ[0];
+  S ut = thr * Uhat[1] / ww + accJ[1];
+  S un = thr * Uhat[2] / ww + accJ[2];
+
+  // MEE dynamics (BettsLowThrust.py:337-363)
+  S sqp = sqrt(p) / std::sqrt(mu);
+  S hs = h * sinL - k * cosL;
+  f[0] = (2.0 * (p / w) * ut) * sqp;
+  f[1] = (ur * sinL + ((w + 1.0) * cosL + ff) * (ut / w) - hs * (g * un / w)) * sqp;
+  f[2] = (-ur * cosL + ((w + 1.0) * sinL + g) * (ut / w) + hs * (ff * un / w)) * sqp;
+  S hk = (s2 * un / w) / 2.0;
+  f[3] = (cosL * hk) * sqp;
+  f[4] = (sinL * hk) * sqp;
+  f[5] = (mu * (w / p) * (w / p) + (1.0 / w) * hs * un) * sqp;
+  f[6] = S(-c.Thrust) * (1.0 + 0.01 * tau) / c.Isp;
+}
+
+// ------------------------------------------------------------------ synthetic-32 (32,0,0)
+// Coefficients a,b,c ~ U(0.5,1.5) are supplied by the caller (ctx -> 3*32 doubles) so that the
+// python test harness and the product share one numpy.random.default_rng(32) draw.
+template <class S>
+void synthetic32(const S* y, S* f, const void* ctx) {
+  const int n = 32;
+  const double* a = static_cast<const double*>(ctx);
+  const double* b = a + n;
+  const double* c = b + n;
+  const S& t = y[n];
+  S ct = cos(t);
+  for (int k = 0; k < n; k++) {
+    f[k] = (-a[k]) * y[k] + b[k] * sin(y[(k + 1) % n]) * y[(k + 5) % n] + c[k] * ct;
+  }
+}
+
+}  // namespace oracle_odes
