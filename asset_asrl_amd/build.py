@@ -1,0 +1,147 @@
+"""Build libasset_hip.so: generate the ODE functors, compile every kernel TU for gfx950, link.
+
+``python -m asset_asrl_amd.build`` (or ``__graft_entry__.build()``).  hipcc cross-compiles without a GPU.
+The shared object is written in-tree (asset_asrl_amd/libasset_hip.so) so it travels with the snapshot.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+GEN = os.path.join(CSRC, "gen")
+OBJ = os.path.join(CSRC, "obj")
+LIB = os.path.join(HERE, "libasset_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+LDS_BUDGET = 160 * 1024
+LDS_TARGET = 40 * 1024          # keep >= 4 single-wave workgroups per CU when the sizes allow it
+
+
+def dims(xv, uv, pv, cs, blocked):
+    """Mirror of ``Dims<>`` in csrc/defect_kernels.h (sizes + LDS plan)."""
+    n = xv
+    m, p = (0, uv + pv) if blocked else (uv, pv)
+    K = cs - 1
+    q = n + 1 + m
+    N = q + p
+    IR, OR = cs * q + p, K * n
+    NKKT = IR * (IR + 1) // 2 + OR * IR
+    NH = N * (N + 1) // 2
+    IRP, ORP = (IR + 15) // 16 * 16, (OR + 15) // 16 * 16
+    KT = (K * N + 3) // 4 * 4
+    LDD = IRP + 16 if IRP % 32 == 0 else IRP
+    LDJ = ORP + 16 if ORP % 32 == 0 else ORP
+    SLOT = IR + OR + cs * n + cs * n * N + cs * N + cs * NH + K * n + K * n * N + K * N + K * NH
+    REGION = max(IRP * (IRP + ORP), 2 * KT * LDD)
+    SCRATCH = REGION + KT * LDJ + IRP
+
+    def lds_bytes(G):
+        return (G * SLOT + SCRATCH) * 8 + (NKKT + 3) // 4 * 4 * 2
+    return dict(n=n, m=m, p=p, q=q, N=N, IR=IR, OR=OR, NKKT=NKKT, lds_bytes=lds_bytes)
+
+
+def pick_group(xv, uv, pv, cs, blocked):
+    d = dims(xv, uv, pv, cs, blocked)
+    for G in (4, 2, 1):
+        if d["lds_bytes"](G) <= LDS_TARGET:
+            return G
+    for G in (2, 1):
+        if d["lds_bytes"](G) <= LDS_BUDGET:
+            return G
+    return 0
+
+
+def _struct_name(name: str) -> str:
+    return "Ode" + "".join(w.capitalize() for w in name.split("_"))
+
+
+def generate(verbose=True):
+    """Write csrc/gen/ode_<name>.h and csrc/gen/tu_<name>.hip for every library ODE."""
+    from .ode import ODE_LIBRARY
+    from .vf.codegen import emit_hip_functor
+    os.makedirs(GEN, exist_ok=True)
+    tus = []
+    for name, cls in ODE_LIBRARY.items():
+        ode = cls()
+        sn = _struct_name(name)
+        hdr = "#pragma once\n#include <math.h>\n" + emit_hip_functor(ode.derivatives(), sn)
+        _write_if_changed(os.path.join(GEN, f"ode_{name}.h"), hdr)
+        lines = [f'#include "ode_{name}.h"', '#include "../registry.h"']
+        xv, uv, pv = ode.XVars(), ode.UVars(), ode.PVars()
+        for cs in (2, 3, 4):
+            for blocked in ((0, 1) if uv > 0 else (0,)):
+                G = pick_group(xv, uv, pv, cs, bool(blocked))
+                if G == 0:
+                    lines.append(f"// LGL cs={cs} blocked={blocked}: working set exceeds one CU's LDS -- not instantiated")
+                    continue
+                lines.append(f"ASSET_REGISTER_LGL({sn}, {cs}, {blocked}, {G})")
+        tu = os.path.join(GEN, f"tu_{name}.hip")
+        _write_if_changed(tu, "\n".join(lines) + "\n")
+        tus.append(tu)
+        if verbose:
+            print(f"[asset_hip] generated {name}: {ode.derivatives().stats()}", flush=True)
+    return tus
+
+
+def _write_if_changed(path, text):
+    if os.path.exists(path) and open(path).read() == text:
+        return
+    with open(path, "w") as f:
+        f.write(text)
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(open(p, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    os.makedirs(OBJ, exist_ok=True)
+    obj = os.path.join(OBJ, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    inc = os.path.join(GEN, os.path.basename(src).replace("tu_", "ode_").replace(".hip", ".h"))
+    if os.path.exists(inc):
+        deps.append(inc)
+    deps.append(os.path.join(HERE, "..", "include", "asset_hip.h"))
+    stamp = obj + ".sha"
+    dg = _digest(deps)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as f:
+        f.write(dg)
+    return obj, True
+
+
+def build(verbose=True, jobs=None) -> str:
+    tus = generate(verbose)
+    srcs = tus + [os.path.join(CSRC, "capi.hip")]
+    jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
+    with ThreadPoolExecutor(jobs) as ex:
+        res = list(ex.map(_compile, srcs))
+    objs = [o for o, _ in res]
+    if any(ch for _, ch in res) or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    if verbose:
+        print(f"[asset_hip] {LIB} ({os.path.getsize(LIB) // 1024} KiB)", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    sys.exit(0 if build() else 1)

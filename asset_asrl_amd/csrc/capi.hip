@@ -1,0 +1,284 @@
+// C ABI of libasset_hip.so (see include/asset_hip.h for the contract and the reference interfaces replaced).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/asset_hip.h"
+#include "registry.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hipfail(hipError_t e, const char* where) {
+  g_err = std::string(where) + ": " + hipGetErrorString(e);
+  return int(e) > 0 ? int(e) : ASSET_HIP_ENODEV;
+}
+#define HIP_TRY(expr)                                     \
+  do {                                                    \
+    hipError_t _e = (expr);                               \
+    if (_e != hipSuccess) return hipfail(_e, #expr);      \
+  } while (0)
+
+const asset_hip::KernelEntry* find_entry(const char* ode, int mode, int blocked) {
+  for (auto* e = asset_hip::registry_head(); e; e = e->next)
+    if (!std::strcmp(e->ode, ode) && e->mode == mode && e->blocked == (blocked ? 1 : 0)) return e;
+  return nullptr;
+}
+
+int level_of(int what) {
+  switch (what) {
+    case ASSET_HIP_CON: return 0;
+    case ASSET_HIP_CON_ADJGRAD:
+    case ASSET_HIP_JAC:
+    case ASSET_HIP_JAC_ADJGRAD: return 1;
+    case ASSET_HIP_JAC_ADJGRAD_HESS: return 2;
+  }
+  return -1;
+}
+
+}  // namespace
+
+struct asset_hip_defect {
+  const asset_hip::KernelEntry* ke = nullptr;
+  int nseg = 0, n_primal = 0, n_equal = 0, device = 0;
+  bool mfma = true;
+  int grid = 0;
+  int* d_vindex = nullptr;
+  int* d_cindex = nullptr;
+  // staging for the host-pointer entry point (allocated lazily)
+  double *d_X = nullptr, *d_L = nullptr, *d_fx = nullptr, *d_agx = nullptr, *d_kkt = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+const char* asset_hip_last_error(void) { return g_err.c_str(); }
+const char* asset_hip_version(void) { return "asset_hip 0.1 (gfx950)"; }
+
+int asset_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int asset_hip_num_odes(void) {
+  int n = 0;
+  for (auto* e = asset_hip::registry_head(); e; e = e->next) {
+    bool first = true;
+    for (auto* f = e->next; f; f = f->next)
+      if (!std::strcmp(f->ode, e->ode)) first = false;
+    n += first;
+  }
+  return n;
+}
+
+const char* asset_hip_ode_name(int i) {
+  int n = 0;
+  for (auto* e = asset_hip::registry_head(); e; e = e->next) {
+    bool first = true;
+    for (auto* f = e->next; f; f = f->next)
+      if (!std::strcmp(f->ode, e->ode)) first = false;
+    if (first && n++ == i) return e->ode;
+  }
+  return nullptr;
+}
+
+int asset_hip_ode_sizes(const char* ode, int* xv, int* uv, int* pv) {
+  if (!ode) return fail(ASSET_HIP_EINVAL, "null ode name");
+  for (auto* e = asset_hip::registry_head(); e; e = e->next)
+    if (!std::strcmp(e->ode, ode)) {
+      if (xv) *xv = e->xv;
+      if (uv) *uv = e->uv;
+      if (pv) *pv = e->pv;
+      return 0;
+    }
+  return fail(ASSET_HIP_ENOODE, std::string("unknown ODE '") + ode + "'");
+}
+
+int asset_hip_has_kernel(const char* ode, int mode, int blocked) {
+  return (ode && find_entry(ode, mode, blocked)) ? 1 : 0;
+}
+
+int asset_hip_lgl_table(int cs, const char* which, double* out, int cap) {
+  if (cs < 2 || cs > 4 || !which || !out) return fail(ASSET_HIP_EINVAL, "bad lgl table query");
+  const asset_hip::LglTab& t = asset_hip::h_lgl_tab[cs - 2];
+  const int K = cs - 1;
+  const double* src = nullptr;
+  int rows = 1, cols = 0;
+  if (!std::strcmp(which, "tc")) src = t.tc, cols = cs;
+  else if (!std::strcmp(which, "s")) src = t.s, cols = K;
+  else if (!std::strcmp(which, "E")) src = t.E, cols = K;
+  else {
+    rows = K, cols = cs;
+    if (!std::strcmp(which, "A")) src = &t.A[0][0];
+    else if (!std::strcmp(which, "B")) src = &t.B[0][0];
+    else if (!std::strcmp(which, "U")) src = &t.U[0][0];
+    else if (!std::strcmp(which, "C")) src = &t.C[0][0];
+    else if (!std::strcmp(which, "D")) src = &t.D[0][0];
+    else return fail(ASSET_HIP_EINVAL, "unknown table name");
+  }
+  if (cap < rows * cols) return fail(ASSET_HIP_EINVAL, "output buffer too small");
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) out[i * cols + j] = (rows == 1) ? src[j] : src[i * 4 + j];
+  return rows * cols;
+}
+
+int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* out) {
+  if (!d || !out) return fail(ASSET_HIP_EINVAL, "null descriptor / output");
+  *out = nullptr;
+  if (!d->ode || !d->vindex || !d->cindex || d->nseg <= 0 || d->n_primal <= 0 || d->n_equal <= 0)
+    return fail(ASSET_HIP_EINVAL, "descriptor fields missing or non-positive");
+  const asset_hip::KernelEntry* ke = find_entry(d->ode, d->mode, d->blocked);
+  if (!ke) {
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "no device code compiled for ode='%s' mode=%d blocked=%d", d->ode, d->mode,
+                  d->blocked);
+    return fail(ASSET_HIP_ENOODE, buf);
+  }
+  // bounds-check the index tables once, on the host (the kernels trust them)
+  const size_t nv = size_t(ke->ir) * d->nseg, nc = size_t(ke->orr) * d->nseg;
+  for (size_t i = 0; i < nv; i++)
+    if (d->vindex[i] < 0 || d->vindex[i] >= d->n_primal) return fail(ASSET_HIP_ERANGE, "vindex entry out of range");
+  for (size_t i = 0; i < nc; i++)
+    if (d->cindex[i] < 0 || d->cindex[i] >= d->n_equal) return fail(ASSET_HIP_ERANGE, "cindex entry out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(ASSET_HIP_ENODEV, "no HIP device visible: the evaluator has no CPU fallback");
+  if (d->device < 0 || d->device >= ndev) return fail(ASSET_HIP_EINVAL, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(d->device));
+  asset_hip_defect* h = new (std::nothrow) asset_hip_defect;
+  if (!h) return fail(ASSET_HIP_EINVAL, "out of host memory");
+  h->ke = ke, h->nseg = d->nseg, h->n_primal = d->n_primal, h->n_equal = d->n_equal, h->device = d->device;
+  h->mfma = d->use_mfma != 0;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, d->device);
+  const int cus = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  const int ngroups = (d->nseg + ke->seg_per_group - 1) / ke->seg_per_group;
+  const int per_cu = int((160 * 1024) / (ke->lds_bytes ? ke->lds_bytes : 1));
+  const int resident = cus * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+  h->grid = ngroups < resident ? ngroups : resident;  // persistent waves, grid-stride over groups
+  auto bail = [&](hipError_t err, const char* w) {
+    int rc = hipfail(err, w);
+    asset_hip_defect_destroy(h);
+    return rc;
+  };
+  if ((e = hipMalloc(&h->d_vindex, nv * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(vindex)");
+  if ((e = hipMalloc(&h->d_cindex, nc * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(cindex)");
+  if ((e = hipMemcpy(h->d_vindex, d->vindex, nv * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess)
+    return bail(e, "hipMemcpy(vindex)");
+  if ((e = hipMemcpy(h->d_cindex, d->cindex, nc * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess)
+    return bail(e, "hipMemcpy(cindex)");
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+  if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+  *out = h;
+  return 0;
+}
+
+void asset_hip_defect_destroy(asset_hip_defect_t h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : {(void*)h->d_vindex, (void*)h->d_cindex, (void*)h->d_X, (void*)h->d_L, (void*)h->d_fx,
+                  (void*)h->d_agx, (void*)h->d_kkt})
+    if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int asset_hip_defect_sizes(asset_hip_defect_t h, int* irows, int* orows, int* nkkt) {
+  if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
+  if (irows) *irows = h->ke->ir;
+  if (orows) *orows = h->ke->orr;
+  if (nkkt) *nkkt = h->ke->nkkt;
+  return 0;
+}
+
+static int launch(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx, double* dagx,
+                  double* dkkt, hipStream_t st) {
+  const int level = level_of(what);
+  if (level < 0) return fail(ASSET_HIP_EINVAL, "unknown evaluation kind");
+  if (!dX) return fail(ASSET_HIP_EINVAL, "X is null");
+  const bool needs_l = (what == ASSET_HIP_CON_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD_HESS);
+  if (needs_l && !dL) return fail(ASSET_HIP_EINVAL, "L is null for an evaluation kind that contracts with multipliers");
+  asset_hip::EvalArgs a;
+  a.nseg = h->nseg;
+  a.X = dX;
+  a.L = needs_l ? dL : nullptr;
+  a.vindex = h->d_vindex;
+  a.cindex = h->d_cindex;
+  a.FX = dfx;
+  a.AGX = (what == ASSET_HIP_CON || what == ASSET_HIP_JAC) ? nullptr : dagx;
+  a.KKT = (what >= ASSET_HIP_JAC) ? dkkt : nullptr;
+  hipError_t e = h->ke->launch(level, h->mfma, a, h->grid, st);
+  if (e != hipSuccess) return hipfail(e, "kernel launch");
+  return 0;
+}
+
+int asset_hip_defect_eval_device(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx,
+                                 double* dagx, double* dkkt, void* stream) {
+  if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  return launch(h, what, dX, dL, dfx, dagx, dkkt, stream ? static_cast<hipStream_t>(stream) : h->stream);
+}
+
+int asset_hip_defect_time_device(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx,
+                                 double* dagx, double* dkkt, int warmup, int iters, float* ms_per_launch) {
+  if (!h || !ms_per_launch || iters <= 0) return fail(ASSET_HIP_EINVAL, "bad timing arguments");
+  HIP_TRY(hipSetDevice(h->device));
+  for (int i = 0; i < warmup; i++) {
+    int rc = launch(h, what, dX, dL, dfx, dagx, dkkt, h->stream);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < iters; i++) {
+    int rc = launch(h, what, dX, dL, dfx, dagx, dkkt, h->stream);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_per_launch = ms / float(iters);
+  return 0;
+}
+
+int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const double* L, double* fx, double* agx,
+                          double* kkt) {
+  if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
+  if (!X) return fail(ASSET_HIP_EINVAL, "X is null");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nfx = size_t(h->nseg) * h->ke->orr, nagx = size_t(h->nseg) * h->ke->ir,
+               nkkt = size_t(h->nseg) * h->ke->nkkt;
+  if (!h->d_X) HIP_TRY(hipMalloc(&h->d_X, sizeof(double) * h->n_primal));
+  if (!h->d_L) HIP_TRY(hipMalloc(&h->d_L, sizeof(double) * h->n_equal));
+  if (fx && !h->d_fx) HIP_TRY(hipMalloc(&h->d_fx, sizeof(double) * nfx));
+  if (agx && !h->d_agx) HIP_TRY(hipMalloc(&h->d_agx, sizeof(double) * nagx));
+  if (kkt && !h->d_kkt) HIP_TRY(hipMalloc(&h->d_kkt, sizeof(double) * nkkt));
+  HIP_TRY(hipMemcpyAsync(h->d_X, X, sizeof(double) * h->n_primal, hipMemcpyHostToDevice, h->stream));
+  if (L) HIP_TRY(hipMemcpyAsync(h->d_L, L, sizeof(double) * h->n_equal, hipMemcpyHostToDevice, h->stream));
+  int rc = launch(h, what, h->d_X, L ? h->d_L : nullptr, fx ? h->d_fx : nullptr, agx ? h->d_agx : nullptr,
+                  kkt ? h->d_kkt : nullptr, h->stream);
+  if (rc) return rc;
+  const int level = level_of(what);
+  if (fx) HIP_TRY(hipMemcpyAsync(fx, h->d_fx, sizeof(double) * nfx, hipMemcpyDeviceToHost, h->stream));
+  if (agx && what != ASSET_HIP_CON && what != ASSET_HIP_JAC)
+    HIP_TRY(hipMemcpyAsync(agx, h->d_agx, sizeof(double) * nagx, hipMemcpyDeviceToHost, h->stream));
+  if (kkt && level >= 1 && what >= ASSET_HIP_JAC)
+    HIP_TRY(hipMemcpyAsync(kkt, h->d_kkt, sizeof(double) * nkkt, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// LGL3 / LGL5 / LGL7 collocation weights used by the defect kernels (device __constant__ + host copy).
+//
+// Same quantities as the reference's LGLCoeffs<CS> tables
+// (/root/reference/src/OptimalControl/LGLCoeffs.h:15-56, 62-162, 169-393); the literals are kept
+// digit-for-digit because the parity bar (1e-10 on residuals) is tighter than the spread between
+// 15-digit and exact coefficients would otherwise allow to ignore.  Layout is this build's own:
+// one POD per scheme, rows = interior point, columns = cardinal node.
+//   s  InteriorSpacings     tc CardinalSpacings
+//   A  x-interpolation      B  xdot-interpolation (times h)     U  control polynomial
+//   C  x defect weights     D  cardinal xdot defect weights (times h)     E  interior xdot defect weight (times h)
+#pragma once
+
+namespace asset_hip {
+
+struct LglTab {
+  double tc[4];
+  double s[3];
+  double A[3][4];
+  double B[3][4];
+  double U[3][4];
+  double C[3][4];
+  double D[3][4];
+  double E[3];
+};
+
+#define ASSET_SQ21 4.58257569495584
+#define ASSET_I686 (1.0 / 686.0)
+#define ASSET_I360 (1.0 / 360)
+#define ASSET_I360D (1.0 / 360.0)
+
+// clang-format off
+#define ASSET_LGL_TABLE_INIT                                                                                   \
+  {                                                                                                            \
+    { /* CS=2, LGL3 */                                                                                         \
+      {0.0, 1.0}, {0.5},                                                                                       \
+      {{0.5, 0.5}}, {{0.125, -0.125}}, {{0.5, 0.5}},                                                           \
+      {{1.0, -1.0}}, {{1.0 / 6.0, 1.0 / 6.0}}, {4.0 / 6.0}                                                     \
+    },                                                                                                         \
+    { /* CS=3, LGL5 */                                                                                         \
+      {0.0, 0.5, 1.0}, {0.172673164646011, 0.827326835353989},                                                 \
+      {{(39.0 * ASSET_SQ21 + 231.0) * ASSET_I686, 224.0 * ASSET_I686, (-39.0 * ASSET_SQ21 + 231.0) * ASSET_I686}, \
+       {(-39.0 * ASSET_SQ21 + 231.0) * ASSET_I686, 224.0 * ASSET_I686, (39.0 * ASSET_SQ21 + 231.0) * ASSET_I686}}, \
+      {{(3.0 * ASSET_SQ21 + 21.0) * ASSET_I686, (-16.0 * ASSET_SQ21) * ASSET_I686, (3.0 * ASSET_SQ21 - 21.0) * ASSET_I686}, \
+       {(-3.0 * ASSET_SQ21 + 21.0) * ASSET_I686, (16.0 * ASSET_SQ21) * ASSET_I686, (-3.0 * ASSET_SQ21 - 21.0) * ASSET_I686}}, \
+      {{0.541612549639704, 0.571428571428571, -0.113041121068274},                                             \
+       {-0.113041121068274, 0.571428571428571, 0.541612549639704}},                                            \
+      {{(32.0 * ASSET_SQ21 + 180.0) * ASSET_I360, -64.0 * ASSET_SQ21 * ASSET_I360, (32.0 * ASSET_SQ21 - 180.0) * ASSET_I360}, \
+       {(-32.0 * ASSET_SQ21 + 180.0) * ASSET_I360D, 64.0 * ASSET_SQ21 * ASSET_I360D, (-32.0 * ASSET_SQ21 - 180.0) * ASSET_I360D}}, \
+      {{(9.0 + ASSET_SQ21) * ASSET_I360, 64.0 * ASSET_I360, (9.0 - ASSET_SQ21) * ASSET_I360},                  \
+       {(9.0 - ASSET_SQ21) * ASSET_I360D, 64.0 * ASSET_I360D, (9.0 + ASSET_SQ21) * ASSET_I360D}},              \
+      {98.0 * ASSET_I360, 98.0 * ASSET_I360D}                                                                  \
+    },                                                                                                         \
+    { /* CS=4, LGL7 */                                                                                         \
+      {+0.00000000000000, +2.65575603264643e-1, +7.34424396735357e-1, +1.00000000000000},                      \
+      {+8.48880518607166e-2, +0.50000000000000, +9.15111948139283e-1},                                         \
+      {{+6.18612232711785e-1, +3.34253095933642e-1, +1.52679626438851e-2, +3.18667087106879e-2},               \
+       {+1.41445282326366e-1, +3.58554717673634e-1, +3.58554717673634e-1, +1.41445282326366e-1},               \
+       {+3.18667087106879e-2, +1.52679626438851e-2, +3.34253095933642e-1, +6.18612232711785e-1}},              \
+      {{+2.57387738427162e-2, -5.50098654524528e-2, -1.53026046503702e-2, -2.38759243962924e-3},               \
+       {+9.92317607754556e-3, +9.62835932121973e-2, -9.62835932121973e-2, -9.92317607754556e-3},               \
+       {+2.38759243962924e-3, +1.53026046503702e-2, +5.50098654524528e-2, -2.57387738427162e-2}},              \
+      {{0.550643660407289, 0.551767574740443, -0.153490305524281, 0.0510790703765507},                         \
+       {-0.140877081724073, 0.640877081724073, 0.640877081724073, -0.140877081724073},                         \
+       {0.0510790703765507, -0.153490305524281, 0.551767574740443, 0.550643660407289}},                        \
+      {{+8.84260109348311e-1, -8.23622559094327e-1, -2.35465327970606e-2, -3.70910174569208e-2},               \
+       {+7.86488731947674e-2, +8.00076026297266e-1, -8.00076026297266e-1, -7.86488731947674e-2},               \
+       {+3.70910174569208e-2, +2.35465327970606e-2, +8.23622559094327e-1, -8.84260109348311e-1}},              \
+      {{+1.62213410652341e-2, +9.71662045547156e-2, +1.85682012187242e-2, +2.74945307600086e-3},               \
+       {+4.83872966828888e-3, +1.00138284831491e-1, +1.00138284831491e-1, +4.83872966828888e-3},               \
+       {+2.74945307600086e-3, +1.85682012187242e-2, +9.71662045547156e-2, +1.62213410652341e-2}},              \
+      {+1.38413023680783e-1, +2.43809523809524e-1, +1.38413023680783e-1}                                       \
+    }                                                                                                          \
+  }
+// clang-format on
+
+static const LglTab h_lgl_tab[3] = ASSET_LGL_TABLE_INIT;  // host copy (C-ABI table query, set-up code)
+
+}  // namespace asset_hip

@@ -1,0 +1,114 @@
+"""``DefectEvaluator`` -- thin Python handle over the C ABI (one phase shard on one GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, MODES  # noqa: F401
+
+
+def _dptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class DefectEvaluator:
+    """Evaluates the defect constraint of ``nseg`` mesh segments on a HIP device.
+
+    ``vindex[nseg, IR]`` / ``cindex[nseg, OR]`` are the application-major index tables
+    (see indexing.PhaseIndexer.make_defect_Vindex_Cindex).
+    """
+
+    def __init__(self, ode: str, mode, blocked: bool, vindex, cindex, n_primal: int, n_equal: int,
+                 device: int = 0, use_mfma: bool = True):
+        L = _lib.lib()
+        self.ode = ode
+        self.mode = MODES[mode] if isinstance(mode, str) else int(mode)
+        self.blocked = bool(blocked)
+        self.vindex = np.ascontiguousarray(vindex, dtype=np.int32)
+        self.cindex = np.ascontiguousarray(cindex, dtype=np.int32)
+        if self.vindex.ndim != 2 or self.cindex.ndim != 2 or self.vindex.shape[0] != self.cindex.shape[0]:
+            raise ValueError("vindex/cindex must be [nseg, IR] / [nseg, OR]")
+        self.nseg = self.vindex.shape[0]
+        self.n_primal, self.n_equal = int(n_primal), int(n_equal)
+        desc = _lib.DefectDesc(self.mode, int(self.blocked), ode.encode(), self.nseg,
+                               self.vindex.ctypes.data_as(C.POINTER(C.c_int32)),
+                               self.cindex.ctypes.data_as(C.POINTER(C.c_int32)),
+                               self.n_primal, self.n_equal, int(device), int(use_mfma))
+        self._h = C.c_void_p()
+        _lib.check(L.asset_hip_defect_create(C.byref(desc), C.byref(self._h)), "asset_hip_defect_create")
+        ir, orr, nk = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(L.asset_hip_defect_sizes(self._h, C.byref(ir), C.byref(orr), C.byref(nk)))
+        self.IR, self.OR, self.NKKT = ir.value, orr.value, nk.value
+        if self.vindex.shape[1] != self.IR or self.cindex.shape[1] != self.OR:
+            self.close()
+            raise ValueError(f"index tables are [{self.vindex.shape[1]}],[{self.cindex.shape[1]}] wide, "
+                             f"the defect needs IR={self.IR}, OR={self.OR}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().asset_hip_defect_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def IRows(self):
+        return self.IR
+
+    def ORows(self):
+        return self.OR
+
+    def numKKTEles(self, dojac: bool = True, dohess: bool = True):
+        return (self.IR * (self.IR + 1) // 2 if dohess else 0) + (self.OR * self.IR if dojac else 0)
+
+    # ---- host-pointer evaluation -----------------------------------------------------------
+    def eval(self, what: int, X, L=None):
+        """Returns (fx[nseg,OR], agx[nseg,IR] or None, kkt[nseg,NKKT] or None)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.size != self.n_primal:
+            raise ValueError(f"X has {X.size} entries, expected {self.n_primal}")
+        if L is not None:
+            L = np.ascontiguousarray(L, dtype=np.float64)
+            if L.size != self.n_equal:
+                raise ValueError(f"L has {L.size} entries, expected {self.n_equal}")
+        fx = np.empty((self.nseg, self.OR))
+        agx = np.empty((self.nseg, self.IR)) if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+        kkt = np.empty((self.nseg, self.NKKT)) if what >= JAC else None
+        _lib.check(_lib.lib().asset_hip_defect_eval(self._h, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx),
+                                                    _dptr(kkt)), "asset_hip_defect_eval")
+        return fx, agx, kkt
+
+    # ---- device-pointer evaluation (torch tensors or raw ints) ------------------------------
+    @staticmethod
+    def _p(t):
+        if t is None:
+            return None
+        return C.c_void_p(t if isinstance(t, int) else t.data_ptr())
+
+    def eval_device(self, what: int, X, L, fx, agx, kkt, stream=None):
+        st = None if stream is None else C.c_void_p(stream if isinstance(stream, int) else stream.cuda_stream)
+        _lib.check(_lib.lib().asset_hip_defect_eval_device(self._h, what, self._p(X), self._p(L), self._p(fx),
+                                                           self._p(agx), self._p(kkt), st),
+                   "asset_hip_defect_eval_device")
+
+    def time_device(self, what: int, X, L, fx, agx, kkt, warmup: int = 3, iters: int = 20) -> float:
+        ms = C.c_float()
+        _lib.check(_lib.lib().asset_hip_defect_time_device(self._h, what, self._p(X), self._p(L), self._p(fx),
+                                                           self._p(agx), self._p(kkt), warmup, iters, C.byref(ms)),
+                   "asset_hip_defect_time_device")
+        return float(ms.value)
+
+
+def unpack_kkt_block(blk: np.ndarray, IR: int, OR: int):
+    """Block slot order -> (H lower-triangular filled symmetric [IR,IR], J [OR,IR])."""
+    H = np.zeros((IR, IR))
+    J = np.zeros((OR, IR))
+    k = 0
+    for i in range(IR):
+        H[i:, i] = blk[k:k + IR - i]
+        k += IR - i
+        J[:, i] = blk[k:k + OR]
+        k += OR
+    H = H + np.tril(H, -1).T
+    return H, J

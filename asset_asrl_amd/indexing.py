@@ -1,0 +1,151 @@
+"""Phase variable layout and the defect constraint's index tables (host side, set-up time).
+
+Mirror of the parts of the reference's ``PhaseIndexer`` / ``SolverIndexingData`` that the batched
+defect evaluator needs (/root/reference/src/OptimalControl/PhaseIndexer.h:63-99,168-197,
+PhaseIndexer.cpp:132-189,361-391,412-488; /root/reference/src/VectorFunctions/IndexingData.h:30-210):
+
+* non-blocked  X = [node_0(q) ... node_{S-1}(q) ; P(p) ; StaticP],  q = Xv+1+Uv,  S = (CS-1)*D + 1
+* blocked      X = [node_0(Xv+1) ... node_{S-1}(Xv+1) ; u_seg0(Uv) ... u_seg{D-1}(Uv) ; P ; StaticP]
+* DefectPath column V = nodes V*(CS-1) ... V*(CS-1)+CS-1 then P; Cindex column V = OR consecutive rows.
+
+Index arrays are int32 and stored application-major (row V = application V), which is the reference's
+column-major [rows x applications] matrix seen from C.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+
+
+class PhaseIndexer:
+    def __init__(self, Xv: int, Uv: int = 0, OPv: int = 0, SPv: int = 0):
+        self.xv, self.uv, self.pv, self.spv = int(Xv), int(Uv), int(OPv), int(SPv)
+        self.numDefects = 0
+        self.DefectCardinalStates = 0
+        self.BlockedControls = False
+        self.var_offset = 0
+        self.con_offset = 0
+
+    # ---- sizes ---------------------------------------------------------------------
+    def XVars(self):
+        return self.xv
+
+    def UVars(self):
+        return self.uv
+
+    def PVars(self):
+        return self.pv
+
+    def StatPVars(self):
+        return self.spv
+
+    def XtVars(self):
+        return self.xv + 1
+
+    def XtUVars(self):
+        return self.xv + 1 + self.uv
+
+    def set_dimensions(self, DCS: int, Dnum: int, BlockCon: bool):
+        if DCS < 2 or Dnum < 1:
+            raise ValueError("need at least 2 cardinal states and 1 defect")
+        self.numDefects = int(Dnum)
+        self.DefectCardinalStates = int(DCS)
+        self.numStates = (DCS - 1) * Dnum + 1
+        self.BlockedControls = bool(BlockCon) and self.uv > 0
+        if self.BlockedControls:
+            self.numPhaseVars = self.numStates * self.XtVars() + Dnum * self.uv + self.pv + self.spv
+        else:
+            self.numPhaseVars = self.numStates * self.XtUVars() + self.pv + self.spv
+        self.ODEParamLoc0 = self.numPhaseVars - self.pv - self.spv
+        self.StaticParamLoc0 = self.numPhaseVars - self.spv
+        self.numPhaseEqCons = (DCS - 1) * self.xv * Dnum
+
+    def begin_indexing(self, var_offset: int = 0, con_offset: int = 0):
+        self.var_offset, self.con_offset = int(var_offset), int(con_offset)
+
+    def getXTUVarLoc(self, vloc: int, State: int, Defect: int | None = None) -> int:
+        o = self.var_offset
+        if self.BlockedControls:
+            if vloc < self.XtVars():
+                return o + vloc + State * self.XtVars()
+            if Defect is None:
+                Defect = min(State // (self.DefectCardinalStates - 1), self.numDefects - 1)
+            return o + self.XtVars() * self.numStates + (vloc - self.XtVars()) + Defect * self.uv
+        return o + vloc + State * self.XtUVars()
+
+    # ---- defect constraint tables -------------------------------------------------------
+    def defect_sizes(self):
+        cs = self.DefectCardinalStates
+        ir = cs * self.XtVars() + self.uv + self.pv if self.BlockedControls else cs * self.XtUVars() + self.pv
+        return ir, (cs - 1) * self.xv
+
+    def make_defect_Vindex_Cindex(self):
+        """(Vindex[nseg, IR], Cindex[nseg, OR]) for DefectPath / BlockDefectPath."""
+        cs, D = self.DefectCardinalStates, self.numDefects
+        ir, orr = self.defect_sizes()
+        o = self.var_offset
+        seg = np.arange(D, dtype=np.int64)[:, None]
+        p0 = o + self.ODEParamLoc0
+        if self.BlockedControls:
+            xt = self.XtVars()
+            nodes = o + (seg * (cs - 1)) * xt + np.arange(cs * xt)[None, :]
+            u = o + xt * self.numStates + seg * self.uv + np.arange(self.uv)[None, :]
+            par = np.broadcast_to(p0 + np.arange(self.pv)[None, :], (D, self.pv))
+            V = np.concatenate([nodes, u, par], axis=1)
+        else:
+            xtu = self.XtUVars()
+            nodes = o + (seg * (cs - 1)) * xtu + np.arange(cs * xtu)[None, :]
+            par = np.broadcast_to(p0 + np.arange(self.pv)[None, :], (D, self.pv))
+            V = np.concatenate([nodes, par], axis=1)
+        Cx = self.con_offset + seg * orr + np.arange(orr)[None, :]
+        assert V.shape == (D, ir)
+        return np.ascontiguousarray(V, dtype=np.int32), np.ascontiguousarray(Cx, dtype=np.int32)
+
+    # ---- trajectory <-> solver vector ------------------------------------------------------
+    def makeSolverInput(self, ActiveTraj: Sequence[np.ndarray], ActiveStaticParams=None) -> np.ndarray:
+        T = np.asarray(ActiveTraj, dtype=float)
+        if T.shape[0] != self.numStates:
+            raise ValueError(f"trajectory has {T.shape[0]} states, phase needs {self.numStates}")
+        V = np.zeros(self.numPhaseVars)
+        cs, D = self.DefectCardinalStates, self.numDefects
+        if self.BlockedControls:
+            xt = self.XtVars()
+            V[: self.numStates * xt] = T[:, :xt].ravel()
+            u0 = self.numStates * xt
+            V[u0:u0 + D * self.uv] = T[0:(cs - 1) * D:(cs - 1), xt:xt + self.uv].ravel()
+        else:
+            xtu = self.XtUVars()
+            V[: self.numStates * xtu] = T[:, :xtu].ravel()
+        if self.pv:
+            V[self.ODEParamLoc0:self.ODEParamLoc0 + self.pv] = T[0, -self.pv:]
+        if self.spv:
+            V[self.StaticParamLoc0:] = np.asarray(ActiveStaticParams, dtype=float)
+        return V
+
+    def collectSolverOutput(self, Vars: np.ndarray):
+        cs, D = self.DefectCardinalStates, self.numDefects
+        out = np.zeros((self.numStates, self.XtUVars() + self.pv))
+        if self.BlockedControls:
+            xt = self.XtVars()
+            out[:, :xt] = Vars[: self.numStates * xt].reshape(self.numStates, xt)
+            U = Vars[self.numStates * xt: self.numStates * xt + D * self.uv].reshape(D, self.uv)
+            unum = np.minimum(np.arange(self.numStates) // (cs - 1), D - 1)
+            out[:, xt:xt + self.uv] = U[unum]
+        else:
+            xtu = self.XtUVars()
+            out[:, :xtu] = Vars[: self.numStates * xtu].reshape(self.numStates, xtu)
+        if self.pv:
+            out[:, -self.pv:] = Vars[self.ODEParamLoc0:self.ODEParamLoc0 + self.pv]
+        return out, Vars[self.StaticParamLoc0:self.StaticParamLoc0 + self.spv].copy()
+
+
+def thread_split(nappl: int, parts: int):
+    """Contiguous ByApplication split (IndexingData.h:117-146): list of (start, count)."""
+    per, rem = divmod(nappl, parts)
+    out, start = [], 0
+    for i in range(parts if per > 0 else rem):
+        cnt = per + (1 if i < rem else 0)
+        out.append((start, cnt))
+        start += cnt
+    return out

@@ -1,0 +1,111 @@
+/* asset_hip.h -- C ABI of the MI355X collocation-defect evaluator (libasset_hip.so).
+ *
+ * This is the drop-in boundary for the one accelerated path: the phase's defect equality constraint as
+ * the solver sees it.  The reference has no C ABI (templates + pybind11); every entry point below names
+ * the reference interface it stands in for, relative to /root/reference/src/:
+ *
+ *   asset_hip_defect_create   <- LGLDefects<DODE,CS>/TrapezoidalDefects<DODE> construction + registration
+ *                                OptimalControl/ODEPhase.h:218-341 (transcribe_dynamics) with the index data of
+ *                                OptimalControl/PhaseIndexer.cpp:3-17,361-391 (addEquality, DefectPath /
+ *                                BlockDefectPath Vindex/Cindex) and Solvers/ConstraintFunction.h:31-62
+ *   asset_hip_defect_eval*    <- the five evaluation methods of SolverConstraintSpec::Concept,
+ *                                VectorFunctions/VectorFunctionTypeErasure/SolverInterfaceSpecs.h:41-92:
+ *                                  ASSET_HIP_CON               constraints(X,FX,data)
+ *                                  ASSET_HIP_CON_ADJGRAD       constraints_adjointgradient(X,L,FX,AGX,data)
+ *                                  ASSET_HIP_JAC               constraints_jacobian(X,FX,KKTmat,...)
+ *                                  ASSET_HIP_JAC_ADJGRAD       constraints_jacobian_adjointgradient(X,L,FX,AGX,KKTmat,...)
+ *                                  ASSET_HIP_JAC_ADJGRAD_HESS  constraints_jacobian_adjointgradient_adjointhessian(...)
+ *                                (bodies: VectorFunctions/ComputableBase.h:246-335, DenseFunctionBase.h:1145-1391)
+ *   asset_hip_defect_sizes    <- SizableSpec IRows/ORows (VectorFunctionTypeErasure/SizingSpecs.h:29-39) and
+ *                                numKKTEles(dojac,dohess) (DenseFunctionBase.h:1070-1088)
+ *   asset_hip_defect_destroy  <- destructor of the ConstraintFunction holding the defect
+ *
+ * Block layouts (what the reference's scatter consumes, so a host shim can do its indexed += unchanged):
+ *   FX  [nseg][OR]     rows of application V   = InnerConstraintStarts[V] + 0..OR   (ComputableBase.h:256-259)
+ *   AGX [nseg][IR]     rows of application V   = InnerGradientStarts[V] + 0..IR     (ComputableBase.h:327-331)
+ *   KKT [nseg][NKKT]   for i in 0..IR-1: { H(j,i), j=i..IR-1 ; J(j,i), j=0..OR-1 }  (DenseFunctionBase.h:1112-1123)
+ *                      NKKT = IR(IR+1)/2 + OR*IR.  For JAC / JAC_ADJGRAD the H slots are written as 0.
+ *
+ * Conventions: every function returns 0 on success or a negative ASSET_HIP_E* / positive hipError_t code and
+ * never throws; asset_hip_last_error() gives text for the calling thread.  A handle is thread-compatible
+ * (one evaluation at a time per handle).  Pointers are caller-owned and only read/written during the call.
+ */
+#ifndef ASSET_HIP_H
+#define ASSET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ASSET_HIP_TRAPEZOIDAL = 1, ASSET_HIP_LGL3 = 2, ASSET_HIP_LGL5 = 3, ASSET_HIP_LGL7 = 4 };
+
+enum {
+  ASSET_HIP_CON = 0,
+  ASSET_HIP_CON_ADJGRAD = 1,
+  ASSET_HIP_JAC = 2,
+  ASSET_HIP_JAC_ADJGRAD = 3,
+  ASSET_HIP_JAC_ADJGRAD_HESS = 4
+};
+
+enum {
+  ASSET_HIP_EINVAL = -1,      /* bad argument / null pointer / size mismatch          */
+  ASSET_HIP_ENOODE = -2,      /* no device code for this (ode, mode, blocked) triple  */
+  ASSET_HIP_ENODEV = -3,      /* no usable HIP device                                  */
+  ASSET_HIP_ERANGE = -4       /* an index in vindex/cindex is outside [0,n)            */
+};
+
+typedef struct asset_hip_defect* asset_hip_defect_t;
+
+typedef struct asset_hip_defect_desc {
+  int mode;               /* ASSET_HIP_TRAPEZOIDAL / LGL3 / LGL5 / LGL7 (TranscriptionModes)                    */
+  int blocked;            /* 1 = BlockConstant control (Blocked_ODE_Wrapper), 0 otherwise                        */
+  const char* ode;        /* name of a compiled-in ODE functor, see asset_hip_ode_name()                         */
+  int nseg;               /* number of applications (= mesh segments of the phase shard)                          */
+  const int32_t* vindex;  /* [IR x nseg] column-major, indices into X  (SolverIndexingData::Vindex)               */
+  const int32_t* cindex;  /* [OR x nseg] column-major, indices into L  (SolverIndexingData::Cindex)               */
+  int n_primal;           /* length of X (bounds check + staging size for the host-pointer entry point)           */
+  int n_equal;            /* length of L                                                                          */
+  int device;             /* HIP device ordinal                                                                   */
+  int use_mfma;           /* 1 = matrix-core congruence (default path), 0 = plain FMA cross-check path             */
+} asset_hip_defect_desc;
+
+int asset_hip_defect_create(const asset_hip_defect_desc* desc, asset_hip_defect_t* out);
+void asset_hip_defect_destroy(asset_hip_defect_t h);
+
+/* IRows, ORows, per-application KKT slots */
+int asset_hip_defect_sizes(asset_hip_defect_t h, int* irows, int* orows, int* nkkt);
+
+/* Host-pointer evaluation: X[n_primal], L[n_equal] (may be NULL for CON/JAC) are copied in, the requested
+ * block arrays (any may be NULL) are copied out.  Synchronous. */
+int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const double* L, double* fx_blocks,
+                          double* agx_blocks, double* kkt_blocks);
+
+/* Device-pointer evaluation: everything already resident in HBM; enqueued on `stream` (a hipStream_t, NULL =
+ * the handle's own stream) and NOT synchronised. */
+int asset_hip_defect_eval_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
+                                 double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_blocks, void* stream);
+
+/* Measures the evaluation kernel itself: `iters` back-to-back device evaluations on the handle's stream
+ * bracketed by HIP events (after `warmup` untimed ones); *ms_per_launch = elapsed / iters. */
+int asset_hip_defect_time_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
+                                 double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_blocks, int warmup,
+                                 int iters, float* ms_per_launch);
+
+/* ---- introspection ---- */
+int asset_hip_num_odes(void);
+const char* asset_hip_ode_name(int i);                           /* NULL when i is out of range            */
+int asset_hip_ode_sizes(const char* ode, int* xv, int* uv, int* pv);
+int asset_hip_has_kernel(const char* ode, int mode, int blocked);
+/* collocation weight tables: which in {"tc","s","A","B","U","C","D","E"}; out receives cs or (cs-1) or
+ * (cs-1)*cs doubles (row = interior point).  Returns the count written or <0. */
+int asset_hip_lgl_table(int cs, const char* which, double* out, int cap);
+int asset_hip_device_count(void);
+const char* asset_hip_last_error(void);
+const char* asset_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASSET_HIP_H */

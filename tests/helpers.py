@@ -1,0 +1,40 @@
+"""Shared workload construction for the parity tests (oracle side lives in oracle/, product in asset_asrl_amd/)."""
+from __future__ import annotations
+
+import numpy as np
+
+from asset_asrl_amd import synth
+from asset_asrl_amd.indexing import PhaseIndexer
+
+
+class Workload:
+    """A synthetic phase: solver vector X, multipliers L and the defect index tables."""
+
+    def __init__(self, ode: str, mode: str, nseg: int, blocked: bool = False, seed: int = synth.SEED,
+                 var_offset: int = 0, con_offset: int = 0, extra_vars: int = 0):
+        xv, uv, pv = synth.ODE_SIZES[ode]
+        self.ode, self.mode, self.nseg, self.blocked = ode, mode, nseg, bool(blocked) and uv > 0
+        self.cs = synth.MODE_CS[mode]
+        self.traj = synth.make_traj(ode, mode, nseg, seed=seed)
+        ix = PhaseIndexer(xv, uv, pv, 0)
+        ix.set_dimensions(self.cs, nseg, self.blocked)
+        ix.begin_indexing(var_offset, con_offset)
+        self.indexer = ix
+        self.vindex, self.cindex = ix.make_defect_Vindex_Cindex()
+        self.IR, self.OR = ix.defect_sizes()
+        self.n_primal = var_offset + ix.numPhaseVars + extra_vars
+        self.n_equal = con_offset + ix.numPhaseEqCons
+        rng = np.random.default_rng(seed + 7)
+        self.X = rng.uniform(-1, 1, self.n_primal)
+        self.X[var_offset:var_offset + ix.numPhaseVars] = ix.makeSolverInput(self.traj)
+        self.L = synth.make_multipliers(self.n_equal, seed=seed + 1)
+        self.NKKT = self.IR * (self.IR + 1) // 2 + self.OR * self.IR
+
+    def oracle_nlp(self, ob, threads: int = 1, provider: int = 0):
+        return ob.Nlp(ob.get_ode(self.ode, provider), ob.MODES[self.mode], self.blocked, self.vindex, self.cindex,
+                      self.n_primal, self.n_equal, threads)
+
+
+def rel_err(a, b, floor=1.0):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(floor, float(np.max(np.abs(b)))))

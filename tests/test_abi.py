@@ -1,0 +1,60 @@
+"""CPU tests of the drop-in boundary: libasset_hip.so loads, exports every symbol include/asset_hip.h declares,
+answers the introspection calls, and refuses to evaluate without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from asset_asrl_amd import _lib, synth
+from asset_asrl_amd.build import dims
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "asset_hip.h")).read()
+    declared = set(re.findall(r"\b(asset_hip_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"asset_hip_defect_eval"} - {"asset_hip_defect_eval"}  # keep all
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_introspection_matches_survey_sizes():
+    assert set(_lib.ode_names()) >= {"brachistochrone", "reentry", "twobody_lt", "betts_lowthrust", "synthetic32"}
+    for name, sizes in synth.ODE_SIZES.items():
+        assert _lib.ode_sizes(name) == sizes
+    # SURVEY.md section 8 size table
+    for ode, cs, blocked, IR, OR, NKKT in [("brachistochrone", 2, False, 10, 3, 85), ("betts_lowthrust", 3, False, 34, 14, 1071),
+                                           ("reentry", 4, False, 32, 15, 1008), ("twobody_lt", 3, True, 24, 12, 588),
+                                           ("synthetic32", 4, False, 132, 96, 21450)]:
+        d = dims(*synth.ODE_SIZES[ode], cs, blocked)
+        assert (d["IR"], d["OR"], d["NKKT"]) == (IR, OR, NKKT)
+    assert _lib.has_kernel("reentry", _lib.LGL7, False)
+    assert _lib.has_kernel("twobody_lt", _lib.LGL5, True)
+    assert not _lib.has_kernel("nonexistent", _lib.LGL3, False)
+
+
+def test_lgl_tables_bitwise_equal_to_oracle(oracle):
+    for cs in (2, 3, 4):
+        for which in ("tc", "s", "A", "B", "U", "C", "D", "E"):
+            np.testing.assert_array_equal(_lib.lgl_table(cs, which), oracle.lgl_table(cs, which))
+        np.testing.assert_array_equal(_lib.lgl_table(cs, "tc"), synth._TC[cs])
+
+
+def test_create_rejects_bad_arguments_and_has_no_cpu_fallback():
+    from asset_asrl_amd.evaluator import DefectEvaluator
+    from helpers import Workload
+    w = Workload("brachistochrone", "LGL3", 4)
+    with pytest.raises(_lib.AssetHipError, match="no device code"):
+        DefectEvaluator("nonexistent", "LGL3", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    bad = w.vindex.copy()
+    bad[2, 3] = w.n_primal
+    with pytest.raises(_lib.AssetHipError, match="out of range"):
+        DefectEvaluator("brachistochrone", "LGL3", False, bad, w.cindex, w.n_primal, w.n_equal)
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.AssetHipError, match="no HIP device"):
+            DefectEvaluator("brachistochrone", "LGL3", False, w.vindex, w.cindex, w.n_primal, w.n_equal)

@@ -1,0 +1,128 @@
+"""GPU parity tests proper: the HIP path through the C ABI against the oracle on the same seeded inputs, and
+against the committed golden vectors.  Tolerances are the north-star's: 1e-10 relative on residuals (relative
+to the magnitude of the terms), 1e-8 relative on derivatives."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from asset_asrl_amd import _lib
+from asset_asrl_amd.evaluator import (CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, DefectEvaluator,
+                                      unpack_kkt_block)
+from helpers import Workload, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_RES, TOL_DER = 1e-10, 1e-8
+
+
+def _check_blocks(got, ref, w, what):
+    fx, agx, kkt = got
+    rfx, ragx, rkkt = ref
+    scale = max(1.0, float(np.abs(w.X).max()))
+    assert np.abs(fx - rfx).max() / scale < TOL_RES
+    if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS):
+        assert rel_err(agx, ragx) < TOL_DER
+    if what >= JAC:
+        assert kkt.shape == rkkt.shape
+        assert rel_err(kkt, rkkt) < TOL_DER
+        # per-entry check relative to the block's own scale (catches a wrong small entry hidden by a big one)
+        bs = np.maximum(1.0, np.abs(rkkt).max(axis=1, keepdims=True))
+        assert (np.abs(kkt - rkkt) / bs).max() < TOL_DER
+
+
+CONFIGS = [
+    ("brachistochrone", "LGL3", 40, False),      # BASELINE config 0
+    ("betts_lowthrust", "LGL5", 100, False),     # config 1 shape (1000 segments in test_gpu_full_size)
+    ("reentry", "LGL7", 257, False),             # config 2 shape, ragged vs the group size
+    ("twobody_lt", "LGL5", 75, True),            # config 3: BlockConstant
+    ("reentry", "LGL3", 64, False),
+    ("reentry", "LGL5", 31, False),
+    ("twobody_lt", "LGL7", 33, False),
+    ("betts_lowthrust", "LGL3", 17, True),
+    ("brachistochrone", "LGL7", 5, True),
+    ("synthetic32", "LGL3", 9, False),
+]
+
+
+@pytest.mark.parametrize("ode,mode,nseg,blocked", CONFIGS)
+@pytest.mark.parametrize("use_mfma", [True, False], ids=["mfma", "fma"])
+def test_all_evaluation_kinds_match_oracle(oracle, ode, mode, nseg, blocked, use_mfma):
+    w = Workload(ode, mode, nseg, blocked, var_offset=3, con_offset=2, extra_vars=4)
+    nlp = w.oracle_nlp(oracle, threads=4)
+    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal, use_mfma=use_mfma)
+    assert (ev.IR, ev.OR, ev.NKKT) == (w.IR, w.OR, w.NKKT)
+    for what in (JAC_ADJGRAD_HESS, CON, CON_ADJGRAD, JAC, JAC_ADJGRAD):
+        ref = nlp.eval_blocks(what, w.X, w.L)
+        got = ev.eval(what, w.X, w.L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
+        if what in (JAC, JAC_ADJGRAD):   # Hessian slots are written as zero in Jacobian-only kinds
+            H, _ = unpack_kkt_block(got[2][0], w.IR, w.OR)
+            assert np.abs(H).max() == 0.0
+        _check_blocks(got, ref, w, what)
+    ev.close()
+
+
+@pytest.mark.parametrize("nseg", [1, 2, 3, 4, 5, 63, 64, 65])
+def test_ragged_segment_counts(oracle, nseg):
+    w = Workload("reentry", "LGL7", nseg)
+    ev = DefectEvaluator("reentry", "LGL7", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    _check_blocks(ev.eval(JAC_ADJGRAD_HESS, w.X, w.L), w.oracle_nlp(oracle).eval_blocks(oracle.JAC_ADJGRAD_HESS, w.X, w.L),
+                  w, JAC_ADJGRAD_HESS)
+
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_hip_matches_golden(path):
+    g = np.load(path)
+    ode, mode, blocked = str(g["ode"]), str(g["mode"]), bool(g["blocked"])
+    if not _lib.has_kernel(ode, _lib.MODES[mode], blocked):
+        pytest.skip("no device kernel for this size yet")
+    ns, IR = g["x"].shape
+    OR = g["lam"].shape[1]
+    X, L = g["x"].ravel(), g["lam"].ravel()
+    V = np.arange(ns * IR, dtype=np.int32).reshape(ns, IR)
+    Cx = np.arange(ns * OR, dtype=np.int32).reshape(ns, OR)
+    ev = DefectEvaluator(ode, mode, blocked, V, Cx, X.size, L.size)
+    fx, agx, kkt = ev.eval(JAC_ADJGRAD_HESS, X, L)
+    for s in range(ns):
+        H, J = unpack_kkt_block(kkt[s], IR, OR)
+        assert np.abs(fx[s] - g["fx"][s]).max() / max(1.0, np.abs(g["x"][s]).max()) < TOL_RES
+        assert rel_err(J, g["jx"][s]) < TOL_DER
+        assert rel_err(agx[s], g["gx"][s]) < TOL_DER
+        assert rel_err(H, g["hx"][s]) < TOL_DER
+
+
+def test_gpu_full_size_properties(oracle):
+    """BASELINE sizes: 10k-segment LGL7 phase.  Oracle on a strided sample + size-independent properties:
+    J^T lam == adjoint gradient for every segment, shifting all node times leaves the autonomous reentry
+    defects unchanged, and the evaluation is idempotent (bitwise repeatable)."""
+    w = Workload("reentry", "LGL7", 10000)
+    ev = DefectEvaluator("reentry", "LGL7", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    fx, agx, kkt = ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    fx2, agx2, kkt2 = ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    assert np.array_equal(fx, fx2) and np.array_equal(agx, agx2) and np.array_equal(kkt, kkt2)
+    o = oracle.get_ode("reentry", 0)
+    for V in range(0, 10000, 397):
+        rfx, rjx, rgx, rhx = oracle.defect_all(o, oracle.LGL7, w.X[w.vindex[V]], w.L[w.cindex[V]])
+        H, J = unpack_kkt_block(kkt[V], w.IR, w.OR)
+        assert np.abs(fx[V] - rfx).max() / max(1.0, np.abs(w.X).max()) < TOL_RES
+        assert rel_err(J, rjx) < TOL_DER and rel_err(H, rhx) < TOL_DER and rel_err(agx[V], rgx) < TOL_DER
+    # J^T lam identity on every segment (reference recipe, 1e-12 -> here relative 1e-10 over 10k segments)
+    lam = w.L[w.cindex]                                    # [nseg, OR]
+    k = 0
+    JT = np.zeros((w.nseg, w.IR, w.OR))
+    for i in range(w.IR):
+        k += w.IR - i
+        JT[:, i, :] = kkt[:, k:k + w.OR]
+        k += w.OR
+    g2 = np.einsum("sio,so->si", JT, lam)
+    assert rel_err(agx, g2) < 1e-12
+    # time-shift invariance (reentry has no explicit time dependence)
+    X2 = w.X.copy()
+    tidx = w.vindex[:, [w.indexer.xv + j * w.indexer.XtUVars() for j in range(w.cs)]]
+    X2[np.unique(tidx)] += 0.25
+    fx3, _, _ = ev.eval(CON, X2)
+    assert np.abs(fx3 - fx).max() < 1e-9
