@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libasset_hip.so")
+LIB_PATH = os.environ.get("ASSET_HIP_LIB") or os.path.join(_HERE, "libasset_hip.so")  # env override: kernel experiments
 
 TRAPEZOIDAL, LGL3, LGL5, LGL7 = 1, 2, 3, 4
 MODES = {"Trapezoidal": TRAPEZOIDAL, "LGL3": LGL3, "LGL5": LGL5, "LGL7": LGL7}
@@ -24,7 +24,7 @@ _ip = C.POINTER(C.c_int32)
 class DefectDesc(C.Structure):
     _fields_ = [("mode", C.c_int), ("blocked", C.c_int), ("ode", C.c_char_p), ("nseg", C.c_int),
                 ("vindex", _ip), ("cindex", _ip), ("n_primal", C.c_int), ("n_equal", C.c_int),
-                ("device", C.c_int), ("use_mfma", C.c_int)]
+                ("device", C.c_int)]
 
 
 # every symbol include/asset_hip.h declares: name -> (restype, argtypes)

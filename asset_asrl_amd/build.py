@@ -35,25 +35,37 @@ def dims(xv, uv, pv, cs, blocked):
     NKKT = IR * (IR + 1) // 2 + OR * IR
     NH = N * (N + 1) // 2
     IRP, ORP = (IR + 15) // 16 * 16, (OR + 15) // 16 * 16
-    KT = (K * N + 3) // 4 * 4
-    LDD = IRP + 16 if IRP % 32 == 0 else IRP
-    LDJ = ORP + 16 if ORP % 32 == 0 else ORP
+    NP = (N + 3) // 4 * 4
     SLOT = IR + OR + cs * n + cs * n * N + cs * N + cs * NH + K * n + K * n * N + K * N + K * NH
-    REGION = max(IRP * (IRP + ORP), 2 * KT * LDD)
-    SCRATCH = REGION + KT * LDJ + IRP
+    SCRATCH = K * NP * IRP + IRP * (K * NP + 1) + OR * IRP + 3 * IRP
+    DENSE = SLOT + SCRATCH
+    STG_LD = (n * N + NH) | 1
+    budget = 40 * 1024
+    staged = (16 * STG_LD <= DENSE or 16 * STG_LD * 8 <= budget)
+    LC = 64 if (not staged or 64 * STG_LD <= DENSE or 64 * STG_LD * 8 <= budget) else (
+        32 if (32 * STG_LD <= DENSE or 32 * STG_LD * 8 <= budget) else 16)
+    BODY = max(LC * STG_LD, DENSE) if staged else DENSE
 
-    def lds_bytes(G):
-        return (G * SLOT + SCRATCH) * 8 + (NKKT + 3) // 4 * 4 * 2
-    return dict(n=n, m=m, p=p, q=q, N=N, IR=IR, OR=OR, NKKT=NKKT, lds_bytes=lds_bytes)
+    def lds_bytes(G=0):
+        return (70 + BODY) * 8
+    return dict(n=n, m=m, p=p, q=q, N=N, IR=IR, OR=OR, NKKT=NKKT, SLOT=SLOT, LC=LC, lds_bytes=lds_bytes)
 
 
 def pick_group(xv, uv, pv, cs, blocked):
     d = dims(xv, uv, pv, cs, blocked)
-    for G in (4, 2, 1):
-        if d["lds_bytes"](G) <= LDS_TARGET:
-            return G
-    for G in (2, 1):
-        if d["lds_bytes"](G) <= LDS_BUDGET:
+    return 64 // cs if d["lds_bytes"]() <= LDS_BUDGET else 0
+
+
+def pick_trap_group(xv, uv, pv, blocked):
+    n = xv
+    m, p = (0, uv + pv) if blocked else (uv, pv)
+    q = n + 1 + m
+    N = q + p
+    IR, OR = 2 * q + p, n
+    slot = IR + OR + 2 * n + 2 * n * N + 2 * N + N * (N + 1)
+    nkkt = IR * (IR + 1) // 2 + OR * IR
+    for G in (32, 16, 8, 4, 2, 1):
+        if G * slot * 8 + (nkkt + 3) // 4 * 4 * 2 <= (32 if G > 1 else 60) * 1024:
             return G
     return 0
 
@@ -82,6 +94,10 @@ def generate(verbose=True):
                     lines.append(f"// LGL cs={cs} blocked={blocked}: working set exceeds one CU's LDS -- not instantiated")
                     continue
                 lines.append(f"ASSET_REGISTER_LGL({sn}, {cs}, {blocked}, {G})")
+        for blocked in ((0, 1) if uv > 0 else (0,)):
+            G = pick_trap_group(xv, uv, pv, bool(blocked))
+            if G:
+                lines.append(f"ASSET_REGISTER_TRAP({sn}, {blocked}, {G})")
         tu = os.path.join(GEN, f"tu_{name}.hip")
         _write_if_changed(tu, "\n".join(lines) + "\n")
         tus.append(tu)

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -49,12 +50,12 @@ int level_of(int what) {
 struct asset_hip_defect {
   const asset_hip::KernelEntry* ke = nullptr;
   int nseg = 0, n_primal = 0, n_equal = 0, device = 0;
-  bool mfma = true;
   int grid = 0;
   int* d_vindex = nullptr;
   int* d_cindex = nullptr;
   // staging for the host-pointer entry point (allocated lazily)
   double *d_X = nullptr, *d_L = nullptr, *d_fx = nullptr, *d_agx = nullptr, *d_kkt = nullptr;
+  double* d_work = nullptr;  // per-workgroup ODE result slots
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -158,14 +159,17 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
   asset_hip_defect* h = new (std::nothrow) asset_hip_defect;
   if (!h) return fail(ASSET_HIP_EINVAL, "out of host memory");
   h->ke = ke, h->nseg = d->nseg, h->n_primal = d->n_primal, h->n_equal = d->n_equal, h->device = d->device;
-  h->mfma = d->use_mfma != 0;
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, d->device);
   const int cus = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  const int ngroups = (d->nseg + ke->seg_per_group - 1) / ke->seg_per_group;
   const int per_cu = int((160 * 1024) / (ke->lds_bytes ? ke->lds_bytes : 1));
   const int resident = cus * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
-  h->grid = ngroups < resident ? ngroups : resident;  // persistent waves, grid-stride over groups
+  // persistent single-wave workgroups; each takes a contiguous, balanced share of the segments
+  h->grid = d->nseg < resident ? d->nseg : resident;
+  if (const char* g = std::getenv("ASSET_HIP_GRID")) {   // tuning experiments only
+    const int gv = std::atoi(g);
+    if (gv > 0) h->grid = gv < d->nseg ? gv : d->nseg;
+  }
   auto bail = [&](hipError_t err, const char* w) {
     int rc = hipfail(err, w);
     asset_hip_defect_destroy(h);
@@ -177,6 +181,10 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
     return bail(e, "hipMemcpy(vindex)");
   if ((e = hipMemcpy(h->d_cindex, d->cindex, nc * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess)
     return bail(e, "hipMemcpy(cindex)");
+  if (ke->work_doubles) {
+    if ((e = hipMalloc(&h->d_work, size_t(h->grid) * ke->work_doubles * sizeof(double))) != hipSuccess)
+      return bail(e, "hipMalloc(workspace)");
+  }
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -189,7 +197,7 @@ void asset_hip_defect_destroy(asset_hip_defect_t h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->d_vindex, (void*)h->d_cindex, (void*)h->d_X, (void*)h->d_L, (void*)h->d_fx,
-                  (void*)h->d_agx, (void*)h->d_kkt})
+                  (void*)h->d_agx, (void*)h->d_kkt, (void*)h->d_work})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -221,7 +229,8 @@ static int launch(asset_hip_defect_t h, int what, const double* dX, const double
   a.FX = dfx;
   a.AGX = (what == ASSET_HIP_CON || what == ASSET_HIP_JAC) ? nullptr : dagx;
   a.KKT = (what >= ASSET_HIP_JAC) ? dkkt : nullptr;
-  hipError_t e = h->ke->launch(level, h->mfma, a, h->grid, st);
+  a.work = h->d_work;
+  hipError_t e = h->ke->launch(level, a, h->grid, st);
   if (e != hipSuccess) return hipfail(e, "kernel launch");
   return 0;
 }

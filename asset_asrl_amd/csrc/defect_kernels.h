@@ -1,4 +1,4 @@
-// Batched LGL collocation-defect kernels for gfx950 (CDNA4).  HIP only -- no CUDA path.
+// Batched collocation-defect kernels for gfx950 (CDNA4).  HIP only -- no CUDA path.
 //
 // What is computed, per mesh segment (SURVEY.md section 8 "Mathematical statement"):
 //   value      d_i = sum_j (C_ij x_j + h D_ij f_j) + h E_i f(x^_i, tau_i, u^_i, P)          i = 0..K-1
@@ -11,15 +11,18 @@
 // (/root/reference/src/VectorFunctions/DenseFunctionBase.h:1097-1129, 1276-1391).
 //
 // Execution shape (one 64-lane wavefront per workgroup, grid-stride over groups of G segments):
-//   phase P0  gather z = X[Vindex], lam = L[Cindex] for G segments into LDS (index reads coalesced)
-//   phase P1  lane <-> (segment, cardinal node):   f_j                      (ODE value)
-//   phase P2  lane <-> (segment, interior point):  x^,tau,u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
-//   phase P3  lane <-> (segment, cardinal node):   w_j ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f
-//   phase P4  all 64 lanes on ONE segment at a time: stack DI = d(x^,tau,u^,P)/dz for the K interiors
-//             into a (K*N) x IR LDS tile, M = (h E_i H^_i) DI, then the lower triangle of
-//             H = DI^T M and J^T = DI^T (h E J^)^T as 16x16x4 f64 MFMA tiles out of LDS; the result tile
-//             is staged in LDS, the sparse cardinal / time-column terms are added there, and the finished
-//             block is streamed to HBM with fully coalesced 8-byte stores in the reference's slot order.
+//   P0  gather z = X[Vindex], lam = L[Cindex] for G segments into LDS (index reads coalesced)
+//   P1  lane <-> (segment, cardinal node):   f_j                               (ODE value)
+//   P2  lane <-> (segment, interior point):  x^,tau,u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
+//   P3  lane <-> (segment, cardinal node):   w_j ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f
+//   P4  all 64 lanes on ONE segment at a time.  With DI_i = d(x^_i,tau_i,u^_i,P)/dz (N x IR):
+//         M_i^T   = DI_i^T [hE_i H^_i | E_i g^_i]        16x16x4 f64 MFMA, A = DI_i^T tiles from LDS
+//         H      += DI_i^T M_i   (lower-triangle tiles)  same A fragments, B = M_i from LDS
+//         J^T    += DI_i^T (hE_i J^_i)^T                  same A fragments
+//       The remaining terms are sparse (cardinal diagonal blocks, the two time columns/rows, C/D weights):
+//       each lane adds them to the accumulator entries it owns, then stores its entries straight to the
+//       KKT block in HBM -- no staging tile, no slot map.  For a fixed accumulator register, lanes 0..15 hold 16
+//       consecutive rows of one block column, i.e. 128 contiguous bytes of the reference's slot order.
 // The ODE is an inlined generated functor (asset_asrl_amd/vf/codegen.py), so P1-P3 are straight-line
 // register code; the only HBM traffic is the gather and the block stores.
 #pragma once
@@ -28,6 +31,10 @@
 #include <cstdint>
 
 #include "lgl_tables.h"
+
+#ifndef ASSET_WAVES_PER_SIMD
+#define ASSET_WAVES_PER_SIMD 1
+#endif
 
 namespace asset_hip {
 
@@ -42,6 +49,7 @@ struct EvalArgs {
   double* FX;          // [nseg x OR] blocks or null
   double* AGX;         // [nseg x IR] blocks or null
   double* KKT;         // [nseg x NKKT] blocks or null
+  double* work;        // [grid][G][SLOT] per-workgroup ODE result slots (L2-resident scratch in HBM)
 };
 
 // ---------------------------------------------------------------------------------------------- sizes
@@ -62,17 +70,14 @@ struct Dims {
   static constexpr int NH = N * (N + 1) / 2;                          // packed lower ODE Hessian
   static constexpr int IRP = (IR + 15) / 16 * 16;
   static constexpr int ORP = (OR + 15) / 16 * 16;
-  static constexpr int KT = (K * N + 3) / 4 * 4;                      // stacked contraction depth, MFMA k=4
-  // LDS leading dimensions (doubles).  Operand tiles are read as 16 consecutive doubles per 16-lane
-  // group with consecutive groups one row apart: stride = 16 (mod 32) doubles keeps ds_read_b64 conflict-free.
-  static constexpr int LDD = (IRP % 32 == 0) ? IRP + 16 : IRP;        // DI / M tiles
-  static constexpr int LDJ = (ORP % 32 == 0) ? ORP + 16 : ORP;        // (hE J^)^T tile
-  static constexpr int LDO = IRP;                                     // staged output: H part  [IRP][LDO]
-  static constexpr int LDOJ = ORP;                                    //                J^T part [IRP][LDOJ]
+  static constexpr int NP = (N + 3) / 4 * 4;                          // rows of one interior's DI tile (MFMA k = 4)
+  static constexpr int KS = NP / 4;                                   // k-steps per interior
+  static constexpr int MT = (N + 1 + 15) / 16;                        // 16-wide column tiles of [hE H^ | E g^]
   static constexpr int TI = IRP / 16, TJ = ORP / 16;
-  static constexpr int NACC = TI * (TI + 1) / 2 + TI * TJ;            // accumulator tiles per lane
+  static constexpr int NTH = TI * (TI + 1) / 2;                       // lower-triangle H tiles
+  static constexpr int CW = IRP <= 16 ? 16 : (IRP <= 32 ? 32 : 64);   // lanes per DI row pass (power of two)
 
-  // ---- LDS map (in doubles) : per in-flight segment slot
+  // ---- LDS map (in doubles): per in-flight segment slot
   static constexpr int o_z = 0;
   static constexpr int o_lam = o_z + IR;
   static constexpr int o_Cf = o_lam + OR;
@@ -85,20 +90,33 @@ struct Dims {
   static constexpr int o_IH = o_Ig + K * N;
   static constexpr int SLOT = o_IH + K * NH;
   // ---- dense scratch (one segment at a time)
-  static constexpr int OUTSZ = IRP * (LDO + LDOJ);
-  static constexpr int OPSZ = 2 * KT * LDD;
-  static constexpr int s_DI = 0;                 // DI tile   [KT][LDD]
-  static constexpr int s_M = KT * LDD;           // M tile    [KT][LDD]
-  static constexpr int s_OUT = 0;                // output staging aliases DI/M (MFMA path, after a barrier)
-  static constexpr int REGION = OUTSZ > OPSZ ? OUTSZ : OPSZ;
-  static constexpr int s_LJ = REGION;            // (hE J^)^T [KT][LDJ]
-  static constexpr int s_HT = s_LJ + KT * LDJ;   // HTpar [IRP]
-  static constexpr int SCRATCH = s_HT + IRP;
+  static constexpr int s_DI = 0;                       // DI tiles   [K][NP][IRP]   (rows >= n are per-kernel constants)
+  static constexpr int s_M = s_DI + K * NP * IRP;      // M^T        [IRP][K*NP+1]
+  static constexpr int s_DC = s_M + IRP * (K * NP + 1);  // cardinal part of J, rows = defect rows  [OR][IRP]
+  static constexpr int s_R2 = s_DC + OR * IRP;         // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar
+  static constexpr int s_HI = s_R2 + 2 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
+  static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
+  static constexpr int SCRATCH = s_HI + IRP;
+  static constexpr int LDM = K * NP + 1;               // M is stored column-major [IRP][LDM]: conflict-free MFMA write-back
 
-  template <int G>
-  static constexpr int lds_doubles() { return G * SLOT + SCRATCH; }
-  template <int G>
-  static constexpr size_t lds_bytes() { return size_t(lds_doubles<G>()) * 8 + size_t((NKKT + 3) / 4 * 4) * 2; }
+  // ---- ODE-phase staging: every evaluating lane writes its dense J (n x N) and packed H into an LDS row, the wave
+  //      then copies the rows to the workspace with coalesced stores.  Row stride is odd: conflict-free ds_write.
+  static constexpr int NSTG = n * N + NH;
+  static constexpr int STG_LD = NSTG | 1;
+  static constexpr int DENSE = SLOT + SCRATCH;         // slot buffer + dense scratch (staging aliases both)
+  // lanes per ODE pass: as many as fit in the LDS the dense phase needs anyway (occupancy is LDS-bound)
+#ifndef ASSET_LC_BUDGET
+#define ASSET_LC_BUDGET (40 * 1024)
+#endif
+  // very wide ODEs: no LDS row fits -> the evaluating lanes write J/H straight to the workspace (uncoalesced, correct)
+  static constexpr bool STAGED = (16 * STG_LD <= DENSE || 16 * STG_LD * 8 <= ASSET_LC_BUDGET);
+  static constexpr int LC = !STAGED ? 64
+                            : (64 * STG_LD <= DENSE || 64 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 64
+                            : ((32 * STG_LD <= DENSE || 32 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 32 : 16);
+  static constexpr int s_TAB0 = 0;                     // weight tables live in front of the aliased region
+  static constexpr int BODY = (STAGED && LC * STG_LD > DENSE) ? LC * STG_LD : DENSE;
+  static constexpr int lds_doubles() { return TABSZ + BODY; }
+  static constexpr size_t lds_bytes() { return size_t(lds_doubles()) * 8; }
 };
 
 using d4 = __attribute__((ext_vector_type(4))) double;
@@ -131,414 +149,769 @@ struct OdeOut {  // routes every derivative entry to its LDS slot (J row-major n
   __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
 };
 
+template <class D>
+struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H -> this lane's LDS staging row [J row-major | H packed]
+  double* f_;
+  double* g_;
+  double* J_;
+  double* H_;
+  __device__ void f(int k, double v) { f_[k] = v; }
+  __device__ void J(int k, int i, double v) { J_[k * D::N + i] = v; }
+  __device__ void g(int i, double v) { g_[i] = v; }
+  __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
+};
+
 __device__ inline double hsym(const double* Hp, int a, int b) {
   return a >= b ? Hp[a * (a + 1) / 2 + b] : Hp[b * (b + 1) / 2 + a];
 }
 
+// true when block columns [16ct,16ct+16) and rows [16rt,16rt+16) can hold a cardinal diagonal / parameter entry
+template <class D>
+__device__ constexpr bool tiles_share_node(int ct, int rt) {
+  const int c0 = 16 * ct, c1 = (16 * ct + 15 < D::IR - 1) ? 16 * ct + 15 : D::IR - 1;
+  const int r0 = 16 * rt, r1 = (16 * rt + 15 < D::IR - 1) ? 16 * rt + 15 : D::IR - 1;
+  if (c0 > c1 || r0 > r1) return false;
+  if (D::p > 0 && r1 >= D::P0) return true;                 // parameter rows couple to every column
+  const int jc0 = c0 / D::q, jc1 = c1 / D::q, jr0 = r0 / D::q, jr1 = r1 / D::q;
+  return !(jr1 < jc0 || jc1 < jr0);
+}
+
+// One wave per workgroup: the barrier only orders this wave's own LDS traffic.
+__device__ inline void wave_lds_sync() { __syncthreads(); }
+
+// ---------------------------------------------------------------------------------------------- ODE phases
+// Kept out of line: each is a long straight-line generated body, and separating their register allocation from
+// the dense phase keeps the latter's accumulators and fragments in registers.
+template <class Ode, class D, int LEVEL>
+__device__ __attribute__((noinline)) void interior_eval(double* S, int i, const LglTab* tabp, double* row) {
+  constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, CS = D::CS;
+  const LglTab& tab = *tabp;
+  const double* z = S + D::o_z;
+  const double h = z[D::TF] - z[T];
+  double y[N];
+  double li[n > 0 ? n : 1];
+#pragma unroll
+  for (int k = 0; k < n; k++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * S[D::o_Cf + j * n + k]);
+    y[k] = acc;
+  }
+  y[T] = z[T] + h * tab.s[i];
+#pragma unroll
+  for (int k = 0; k < m; k++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < CS; j++) acc += tab.U[i][j] * z[j * q + n + 1 + k];
+    y[n + 1 + k] = acc;
+  }
+#pragma unroll
+  for (int k = 0; k < p; k++) y[q + k] = z[D::P0 + k];
+#pragma unroll
+  for (int k = 0; k < n; k++) li[k] = (LEVEL >= 2) ? S[D::o_lam + i * n + k] : 0.0;
+  RegIn<D> in{y, li};
+  OdeOutStaged<D> out{S + D::o_If + i * n, S + D::o_Ig + i * N,
+                      D::STAGED ? row : S + D::o_IJ + i * n * N, D::STAGED ? row + n * N : S + D::o_IH + i * D::NH};
+  (void)K;
+  if constexpr (LEVEL == 0) Ode::f(in, out);
+  else if constexpr (LEVEL == 1) Ode::fj(in, out);
+  else Ode::fjgh(in, out);
+}
+
+template <class Ode, class D>
+__device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const LglTab* tabp, double* row) {
+  constexpr int K = D::K, n = D::n, N = D::N, T = D::T, CS = D::CS;
+  const LglTab& tab = *tabp;
+  const double* z = S + D::o_z;
+  const double h = z[D::TF] - z[T];
+  double w[n > 0 ? n : 1];
+#pragma unroll
+  for (int k = 0; k < n; k++) {  // C_AVS[j]  (LGLDefects.h:369-374)
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      acc += S[D::o_Ig + i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
+      acc += S[D::o_lam + i * n + k] * (tab.D[i][j] * h);
+    }
+    w[k] = acc;
+  }
+  CardIn<D> in{z, w, j};
+  OdeOutStaged<D> out{S + D::o_Cf + j * n, S + D::o_Cg + j * N,
+                      D::STAGED ? row : S + D::o_CJ + j * n * N, D::STAGED ? row + n * N : S + D::o_CH + j * D::NH};
+  Ode::fjgh(in, out);
+}
+
+template <class Ode, class D, int LEVEL>
+__device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, double* row) {
+  CardIn<D> in{S + D::o_z, nullptr, j};
+  OdeOutStaged<D> out{S + D::o_Cf + j * D::n, nullptr, D::STAGED ? row : S + D::o_CJ + j * D::n * D::N, nullptr};
+  if constexpr (LEVEL == 1) Ode::fj(in, out);
+  else Ode::f(in, out);
+}
+
 // ---------------------------------------------------------------------------------------------- kernel
 // LEVEL 0: value only (constraints).  LEVEL 1: value + Jacobian (+ J^T lam).  LEVEL 2: + adjoint Hessian.
-// MFMA: use v_mfma_f64_16x16x4_f64 for the congruence; false = plain FMA loops (cross-check / fallback sizes).
-template <class Ode, int CS, bool BLOCKED, int G, int LEVEL, bool MFMA>
-__global__ __launch_bounds__(64) void lgl_defect_kernel(EvalArgs a) {
+template <class Ode, int CS, bool BLOCKED, int G, int LEVEL>
+__global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
   using D = Dims<Ode, CS, BLOCKED>;
-  constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T;
-  constexpr int IR = D::IR, OR = D::OR;
+  constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0;
+  constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, ORP = D::ORP, NP = D::NP, KS = D::KS;
+  constexpr int LC = D::LC, NSTG = D::NSTG, STG_LD = D::STG_LD;
   static_assert(N == Ode::NIN, "ODE input size mismatch");
-  const LglTab& tab = d_lgl_tab[CS - 2];
+  static_assert(G * CS <= 64 * 8, "group too large");
+  (void)m; (void)p; (void)ORP;
 
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* slots = lds;
-  double* scr = lds + G * D::SLOT;
-  unsigned short* kmap = reinterpret_cast<unsigned short*>(lds + D::template lds_doubles<G>());
+  double* tabL = lds;                       // weight tables (persistent)
+  double* body = lds + D::TABSZ;            // [slot buffer | dense scratch], aliased by the ODE staging rows
+  double* slotb = body;
+  double* scr = body + D::SLOT;
+  double* stage = body;
   const int lane = threadIdx.x;
+  const int lr = lane & 15, lk = lane >> 4;
+  // the scheme's weight tables are read with lane-dependent indices all over the kernel: keep them in LDS
+  for (int e = lane; e < D::TABSZ; e += 64) tabL[e] = reinterpret_cast<const double*>(&d_lgl_tab[CS - 2])[e];
+  wave_lds_sync();
+  const LglTab& tab = *reinterpret_cast<const LglTab*>(tabL);
 
-  // ---- slot order of the KKT block -> offset in the staged output tile (DenseFunctionBase.h:1112-1123)
-  if constexpr (LEVEL >= 1) {
-    for (int k = lane; k < D::NKKT; k += 64) {
-      // column i owns (IR - i) Hessian slots then OR Jacobian slots; start(i) = i*(IR+OR) - i(i-1)/2
-      int i = 0;
-      int lo = 0, hi = IR - 1;
-      while (lo < hi) {  // largest i with start(i) <= k
-        const int mid = (lo + hi + 1) >> 1;
-        const int st = mid * (IR + OR) - mid * (mid - 1) / 2;
-        if (st <= k) lo = mid; else hi = mid - 1;
-      }
-      i = lo;
-      const int r = k - (i * (IR + OR) - i * (i - 1) / 2);
-      const int off = (r < IR - i) ? (i * D::LDO + (i + r)) : (D::IRP * D::LDO + i * D::LDOJ + (r - (IR - i)));
-      kmap[k] = static_cast<unsigned short>(off);
-    }
-  }
-  __syncthreads();
+  // this workgroup's share of the mesh: contiguous, balanced (same rule as IndexingData.h:117-146)
+  const int per = a.nseg / int(gridDim.x), rem = a.nseg % int(gridDim.x);
+  const int wg_first = int(blockIdx.x) * per + min(int(blockIdx.x), rem);
+  const int wg_count = per + (int(blockIdx.x) < rem ? 1 : 0);
+  double* Wg = a.work + size_t(blockIdx.x) * G * D::SLOT;   // ODE result slots of the current group (HBM / L2)
 
-  const int ngroups = (a.nseg + G - 1) / G;
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int seg0 = grp * G;
-    const int gcount = min(G, a.nseg - seg0);
+#if defined(ASSET_TIMING)
+  long long tstamp[24];
+  int nts = 0;
+#define TS() do { if (nts < 24) tstamp[nts++] = clock64(); } while (0)
+#else
+#define TS() do {} while (0)
+#endif
+  for (int g0 = 0; g0 < wg_count; g0 += G) {
+    const int seg0 = wg_first + g0;
+    TS();
+    const int gcount = min(G, wg_count - g0);
 
-    // ------------------------------------------------------------------ P0: gather
+    // ------------------------------------------------------------------ P0: gather z = X[Vindex], lam = L[Cindex]
     for (int e = lane; e < gcount * IR; e += 64) {
       const int g = e / IR, r = e - g * IR;
-      slots[g * D::SLOT + D::o_z + r] = a.X[a.vindex[size_t(seg0 + g) * IR + r]];
+      Wg[g * D::SLOT + D::o_z + r] = a.X[a.vindex[size_t(seg0 + g) * IR + r]];
     }
     if constexpr (LEVEL >= 1) {
       for (int e = lane; e < gcount * OR; e += 64) {
         const int g = e / OR, r = e - g * OR;
-        slots[g * D::SLOT + D::o_lam + r] = a.L ? a.L[a.cindex[size_t(seg0 + g) * OR + r]] : 0.0;
+        Wg[g * D::SLOT + D::o_lam + r] = a.L ? a.L[a.cindex[size_t(seg0 + g) * OR + r]] : 0.0;
       }
     }
-    __syncthreads();
+    wave_lds_sync();
 
+    TS();
     // ------------------------------------------------------------------ P1: cardinal ODE values (and J for LEVEL 1)
-    for (int e = lane; e < gcount * CS; e += 64) {
-      const int g = e / CS, j = e - g * CS;
-      double* S = slots + g * D::SLOT;
-      CardIn<D> in{S + D::o_z, nullptr, j};
-      OdeOut<D> out{S + D::o_Cf + j * n, S + D::o_CJ + j * n * N, nullptr, nullptr};
-      if constexpr (LEVEL == 1) Ode::fj(in, out);
-      else Ode::f(in, out);
+    for (int e0 = 0; e0 < gcount * CS; e0 += LC) {
+      const int e = e0 + lane;
+      if (lane < LC && e < gcount * CS) {
+        const int g = e / CS, j = e - g * CS;
+        cardinal_eval1<Ode, D, LEVEL>(Wg + g * D::SLOT, j, stage + lane * STG_LD);
+      }
+      if constexpr (LEVEL == 1 && D::STAGED) {
+        wave_lds_sync();
+        const int npt = min(LC, gcount * CS - e0);
+        for (int idx = lane; idx < npt * (n * N); idx += 64) {
+          const int row = idx / (n * N), k = idx - row * (n * N);
+          const int ee = e0 + row, g = ee / CS, j = ee - g * CS;
+          Wg[g * D::SLOT + D::o_CJ + j * n * N + k] = stage[row * STG_LD + k];
+        }
+        wave_lds_sync();
+      }
+    }
+    wave_lds_sync();
+
+    TS();
+    // ------------------------------------------------------------------ P2: interior points
+    for (int e0 = 0; e0 < gcount * K; e0 += LC) {
+      const int e = e0 + lane;
+      if (lane < LC && e < gcount * K) {
+        const int g = e / K, i = e - g * K;
+        interior_eval<Ode, D, LEVEL>(Wg + g * D::SLOT, i, &tab, stage + lane * STG_LD);
+      }
+      if constexpr (LEVEL >= 1 && D::STAGED) {
+        wave_lds_sync();
+        const int npt = min(LC, gcount * K - e0);
+        constexpr int NC = (LEVEL >= 2) ? NSTG : n * N;   // LEVEL 1 has no Hessian part
+        for (int idx = lane; idx < npt * NC; idx += 64) {
+          const int row = idx / NC, k = idx - row * NC;
+          const int ee = e0 + row, g = ee / K, i = ee - g * K;
+          double* dstp = Wg + g * D::SLOT + ((k < n * N) ? (D::o_IJ + i * n * N + k) : (D::o_IH + i * D::NH + (k - n * N)));
+          *dstp = stage[row * STG_LD + k];
+        }
+        wave_lds_sync();
+      }
+    }
+    wave_lds_sync();
+
+    TS();
+    // ------------------------------------------------------------------ P3: cardinal second derivatives
+    if constexpr (LEVEL >= 2) {
+      for (int e0 = 0; e0 < gcount * CS; e0 += LC) {
+        const int e = e0 + lane;
+        if (lane < LC && e < gcount * CS) {
+          const int g = e / CS, j = e - g * CS;
+          cardinal_eval2<Ode, D>(Wg + g * D::SLOT, j, &tab, stage + lane * STG_LD);
+        }
+        wave_lds_sync();
+        const int npt = D::STAGED ? min(LC, gcount * CS - e0) : 0;
+        for (int idx = lane; idx < npt * NSTG; idx += 64) {
+          const int row = idx / NSTG, k = idx - row * NSTG;
+          const int ee = e0 + row, g = ee / CS, j = ee - g * CS;
+          double* dstp = Wg + g * D::SLOT + ((k < n * N) ? (D::o_CJ + j * n * N + k) : (D::o_CH + j * D::NH + (k - n * N)));
+          *dstp = stage[row * STG_LD + k];
+        }
+        wave_lds_sync();
+      }
+    }
+
+    if constexpr (LEVEL == 0) {
+      // ---- value only: lanes over (segment, defect row); everything needed is in the workspace slots
+      if (a.FX) {
+        for (int e = lane; e < gcount * OR; e += 64) {
+          const int g = e / OR, jr = e - g * OR;
+          const int i = jr / n, k = jr - i * n;
+          const double* S = Wg + g * D::SLOT;
+          const double* z = S + D::o_z;
+          const double h = z[TF] - z[T];
+          double fxv = 0.0;
+#pragma unroll
+          for (int j = 0; j < CS; j++) fxv += (tab.C[i][j] * z[j * q + k] + (tab.D[i][j] * h) * S[D::o_Cf + j * n + k]);
+          fxv += (h * tab.E[i]) * S[D::o_If + i * n + k];
+          a.FX[size_t(seg0 + g) * OR + jr] = fxv;
+        }
+      }
+      wave_lds_sync();
+      continue;
+    }
+
+    TS();
+    // (the first slot's loads are issued below, right after this initialisation, and overlap nothing -- one per group)
+    // ---- per-group constants of the dense scratch (the staging rows aliased it): the rows of DI_i that do not
+    //      depend on the segment (tau row, control-interpolation rows, parameter identity rows, zero padding;
+    //      LGLDefects.h:417-458), the rank-2 direction d = e_TF - e_T, zero padding of M and DC
+    for (int e = lane; e < K * NP * IRP; e += 64) {
+      const int i = e / (NP * IRP), rem2 = e - i * NP * IRP;
+      const int r = rem2 / IRP, c = rem2 - r * IRP;
+      double v = 0.0;
+      if (c < IR) {
+        if (r == T) v = (c == T) ? (1.0 - tab.s[i]) : ((c == TF) ? tab.s[i] : 0.0);
+        else if (r > T && r < q) { if (c < P0 && (c % q) == r) v = tab.U[i][c / q]; }
+        else if (r >= q && r < N) { if (c == P0 + (r - q)) v = 1.0; }
+      }
+      scr[D::s_DI + e] = v;
+    }
+    for (int e = lane; e < IRP; e += 64) scr[D::s_R2 + e] = (e == TF) ? 1.0 : ((e == T) ? -1.0 : 0.0);
+    for (int e = lane; e < OR * IRP; e += 64) scr[D::s_DC + e] = 0.0;
+    for (int e = lane; e < IRP * D::LDM; e += 64) scr[D::s_M + e] = 0.0;
+    wave_lds_sync();
+
+    TS();
+    // ------------------------------------------------------------------ P4: per-segment dense phase
+    constexpr int NPRE = (D::SLOT + 63) / 64;
+    double pre[NPRE];                      // next segment's slot, in flight while the current one is processed
+#pragma unroll
+    for (int t = 0; t < NPRE; t++) pre[t] = (lane + 64 * t < D::SLOT) ? Wg[lane + 64 * t] : 0.0;
+    for (int g = 0; g < gcount; g++) {
+      // slot: workspace -> LDS (coalesced); the loads were issued one segment ago
+#pragma unroll
+      for (int t = 0; t < NPRE; t++)
+        if (lane + 64 * t < D::SLOT) slotb[lane + 64 * t] = pre[t];
+      wave_lds_sync();
+      if (g + 1 < gcount) {
+#pragma unroll
+        for (int t = 0; t < NPRE; t++) pre[t] = (lane + 64 * t < D::SLOT) ? Wg[(g + 1) * D::SLOT + lane + 64 * t] : 0.0;
+      }
+      if (g == 0) TS();
+      const double* S = slotb;
+      const double* z = S + D::o_z;
+      const double* lam = S + D::o_lam;
+      const double h = z[TF] - z[T];
+      const size_t seg = size_t(seg0 + g);
+
+      if constexpr (LEVEL == 0) continue;
+
+      double* DI = scr + D::s_DI;
+      double* Mt = scr + D::s_M;
+      double* DC = scr + D::s_DC;
+      double* R2 = scr + D::s_R2;
+      double* HI = scr + D::s_HI;
+
+      if (g == 0) TS();
+      // ---- D1: one pass over (interior i, state row r, block column c) builds, from a single read of dfdy_j:
+      //        DI_i[r][c]  = A_ij [cc==r] + h B_ij J_j[r][cc]        (LGLDefects.h:430-444)
+      //        DC[(i,r)][c] = C_ij [cc==r] + h D_ij J_j[r][cc]        (LGLDefects.h:467-482)  -- cardinal part of J
+      {
+        constexpr int RPW = 64 / D::CW;                 // rows written per wave pass
+        const int c = lane & (D::CW - 1), rsub = lane / D::CW;
+        const bool cok = c < IR;
+        const int j = (c < P0) ? c / q : 0, cc = (c < P0) ? c - j * q : 0;
+        constexpr int ROWS = K * n;
+#pragma unroll
+        for (int t = 0; t < (ROWS + RPW - 1) / RPW; t++) {
+          const int row = t * RPW + rsub;               // (i, r), r < n
+          if (row < ROWS && cok) {
+            const int i = row / n, r = row - i * n;
+            double vi, vc;
+            if (c < P0) {
+              const double jv = S[D::o_CJ + (j * n + r) * N + cc];
+              vi = (tab.B[i][j] * h) * jv;
+              vc = (tab.D[i][j] * h) * jv;
+              if (cc == r) { vi += tab.A[i][j]; vc += tab.C[i][j]; }
+            } else {
+              vi = 0.0, vc = 0.0;
+#pragma unroll
+              for (int jj = 0; jj < CS; jj++) {
+                const double jv = S[D::o_CJ + (jj * n + r) * N + q + (c - P0)];
+                vi += (tab.B[i][jj] * h) * jv;
+                vc += (tab.D[i][jj] * h) * jv;
+              }
+            }
+            DI[(i * NP + r) * IRP + c] = vi;
+            DC[row * IRP + c] = vc;
+          }
+        }
+        if constexpr (IRP > 64) {                       // wider than one pass: remaining columns
+          for (int e = lane; e < ROWS * (IRP - 64); e += 64) {
+            const int row = e / (IRP - 64), c2 = 64 + e - row * (IRP - 64);
+            if (c2 < IR) {
+              const int i = row / n, r = row - i * n;
+              double vi = 0.0, vc = 0.0;
+              if (c2 < P0) {
+                const int j2 = c2 / q, cc2 = c2 - j2 * q;
+                const double jv = S[D::o_CJ + (j2 * n + r) * N + cc2];
+                vi = (tab.B[i][j2] * h) * jv;
+                vc = (tab.D[i][j2] * h) * jv;
+                if (cc2 == r) { vi += tab.A[i][j2]; vc += tab.C[i][j2]; }
+              } else {
+                for (int jj = 0; jj < CS; jj++) {
+                  const double jv = S[D::o_CJ + (jj * n + r) * N + q + (c2 - P0)];
+                  vi += (tab.B[i][jj] * h) * jv;
+                  vc += (tab.D[i][jj] * h) * jv;
+                }
+              }
+              DI[(i * NP + r) * IRP + c2] = vi;
+              DC[row * IRP + c2] = vc;
+            }
+          }
+        }
+      }
+      wave_lds_sync();
+      if (g == 0) TS();
+      // time columns: DI rows -+ sum_j B_ij f_j (LGLDefects.h:446-450), DC rows -+ (sum_j D_ij f_j + E_i f^_i) (:484-500)
+      for (int e = lane; e < K * n; e += 64) {
+        const int i = e / n, r = e - i * n;
+        double sb = 0.0, sd = tab.E[i] * S[D::o_If + i * n + r];
+#pragma unroll
+        for (int jj = 0; jj < CS; jj++) {
+          sb += tab.B[i][jj] * S[D::o_Cf + jj * n + r];
+          sd += tab.D[i][jj] * S[D::o_Cf + jj * n + r];
+        }
+        DI[(i * NP + r) * IRP + T] -= sb;
+        DI[(i * NP + r) * IRP + TF] += sb;
+        DC[e * IRP + T] -= sd;
+        DC[e * IRP + TF] += sd;
+        if (a.FX) {                                      // defect value of row (i,r)  (LGLDefects.h:96-103)
+          double fxv = h * sd;
+#pragma unroll
+          for (int jj = 0; jj < CS; jj++) fxv += tab.C[i][jj] * z[jj * q + r];
+          a.FX[seg * OR + e] = fxv;
+        }
+      }
+      wave_lds_sync();
+
+      if (g == 0) TS();
+      // ---- D2: A fragments (DI_i^T tiles) for every tile row, reused by all three products
+      double av[D::TI][K][KS];
+#pragma unroll
+      for (int ct = 0; ct < D::TI; ct++)
+#pragma unroll
+        for (int i = 0; i < K; i++)
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++) av[ct][i][kk] = DI[(i * NP + 4 * kk + lk) * IRP + 16 * ct + lr];
+
+      // ---- D3: M_i^T = DI_i^T [hE_i H^_i | E_i g^_i]; column N of the product is sum_b E_i g^_i[b] DI_i[b,c]
+      if constexpr (LEVEL >= 2) {
+        double hi_acc[D::TI][4];
+#pragma unroll
+        for (int ct = 0; ct < D::TI; ct++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) hi_acc[ct][v] = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+          const double he = h * tab.E[i];
+          const double* Hp = S + D::o_IH + i * D::NH;
+#pragma unroll
+          for (int mt = 0; mt < D::MT; mt++) {
+            const int acol = 16 * mt + lr;               // column of [hE H^ | E g^]
+            double bv[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) {
+              const int b = 4 * kk + lk;
+              double v = 0.0;
+              if (b < N) {
+                if (acol < N) v = hsym(Hp, b, acol) * he;
+                else if (acol == N) v = S[D::o_Ig + i * N + b] * tab.E[i];
+              }
+              bv[kk] = v;
+            }
+#pragma unroll
+            for (int ct = 0; ct < D::TI; ct++) {
+              d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bv[kk], acc, 0, 0, 0);
+              // acc[v] = (M_i^T)[c = 16ct + lk + 4v][acol]
+              if (acol < N) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + i * NP + acol] = acc[v];
+              } else if (acol == N) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) hi_acc[ct][v] += acc[v];
+              }
+            }
+          }
+        }
+        if ((N & 15) == lr) {                            // the lanes that own column N
+#pragma unroll
+          for (int ct = 0; ct < D::TI; ct++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) HI[16 * ct + lk + 4 * v] = hi_acc[ct][v];
+        }
+        wave_lds_sync();
+        // full time-partial vector HTpar (LGLDefects.h:403-411, 504-505) -> rank-2 rows:
+        //   H += d HT^T + HT d^T  with d = e_TF - e_T   (the four updates of LGLDefects.h:508-511)
+        const double ih = 1.0 / h;
+        for (int c = lane; c < IRP; c += 64) {
+          double v = 0.0;
+          if (c < IR) {
+            v = HI[c];
+            if (c < P0) {
+              const int j = c / q, cc = c - j * q;
+              v += S[D::o_Cg + j * N + cc] * ih;
+            } else {
+#pragma unroll
+              for (int j = 0; j < CS; j++) v += S[D::o_Cg + j * N + q + (c - P0)] * ih;
+            }
+          }
+          R2[IRP + c] = v;          // A-side row 1 / B-side row 0 share this copy
+        }
+        wave_lds_sync();
+      }
+
+      if (g == 0) TS();
+      // ---- D4: H (lower-triangle tiles) and J^T
+      d4 accH[LEVEL >= 2 ? D::NTH : 1];
+      d4 accJ[D::TI * D::TJ];
+      if constexpr (LEVEL >= 2) {
+        // rank-2 time fragments: k=0 -> (A: d, B: HT), k=1 -> (A: HT, B: d), k=2,3 -> 0
+        double a2[D::TI], b2[D::TI];
+#pragma unroll
+        for (int t = 0; t < D::TI; t++) {
+          const double dv = R2[16 * t + lr], hv = R2[IRP + 16 * t + lr];
+          a2[t] = (lk == 0) ? dv : ((lk == 1) ? hv : 0.0);
+          b2[t] = (lk == 0) ? hv : ((lk == 1) ? dv : 0.0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < D::TI; rt++) {
+          double bm[K][KS];
+#pragma unroll
+          for (int i = 0; i < K; i++)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) bm[i][kk] = Mt[(16 * rt + lr) * D::LDM + i * NP + 4 * kk + lk];
+#pragma unroll
+          for (int ct = 0; ct <= rt; ct++) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            // cardinal diagonal / parameter blocks (LGLDefects.h:386-402) enter as the initial accumulator value
+            if (tiles_share_node<D>(ct, rt)) {
+#pragma unroll
+              for (int v = 0; v < 4; v++) {
+                const int c = 16 * ct + lk + 4 * v, r = 16 * rt + lr;
+                double val = 0.0;
+                if (c < IR && r < IR && r >= c) {
+                  if (c < P0) {
+                    const int jn = c / q, cc = c - jn * q;
+                    if (r < P0) {
+                      if (r / q == jn) val = hsym(S + D::o_CH + jn * D::NH, r - jn * q, cc);
+                    } else {
+                      val = hsym(S + D::o_CH + jn * D::NH, q + (r - P0), cc);
+                    }
+                  } else {
+#pragma unroll
+                    for (int j = 0; j < CS; j++) val += hsym(S + D::o_CH + j * D::NH, q + (r - P0), q + (c - P0));
+                  }
+                }
+                acc[v] = val;
+              }
+            }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[ct], b2[rt], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < K; i++)
+#pragma unroll
+              for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bm[i][kk], acc, 0, 0, 0);
+            accH[rt * (rt + 1) / 2 + ct] = acc;
+          }
+        }
+      }
+      if (g == 0) TS();
+#pragma unroll
+      for (int jt = 0; jt < D::TJ; jt++) {
+        const int jr = 16 * jt + lr;
+        const int ji = (jr < OR) ? jr / n : K, jk = (jr < OR) ? jr - ji * n : 0;
+        double bj[K][KS];
+#pragma unroll
+        for (int i = 0; i < K; i++)
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++) {
+            const int aa = 4 * kk + lk;                  // (hE_i J^_i)^T[aa][jr], non-zero only on interior i's rows
+            bj[i][kk] = (ji == i && aa < N) ? (h * tab.E[i]) * S[D::o_IJ + (i * n + jk) * N + aa] : 0.0;
+          }
+#pragma unroll
+        for (int ct = 0; ct < D::TI; ct++) {
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int i = 0; i < K; i++)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bj[i][kk], acc, 0, 0, 0);
+          // + cardinal part: DC^T * I, k runs over the 16 defect rows of this tile
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            const int kr = 16 * jt + 4 * kk + lk;
+            const double adc = (kr < OR) ? DC[kr * IRP + 16 * ct + lr] : 0.0;
+            const double bid = (4 * kk + lk == lr) ? 1.0 : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(adc, bid, acc, 0, 0, 0);
+          }
+          accJ[ct * D::TJ + jt] = acc;
+        }
+      }
+
+      if (g == 0) TS();
+      // ---- D5: adjoint gradient  g = J^T lam  without touching the J tile:
+      //      interior part  h * sum_i E_i g^_i^T DI_i  (= h * HI), cardinal part = DC^T lam
+      if (a.AGX) {
+        for (int c = lane; c < IR; c += 64) {
+          double v = 0.0;
+          if constexpr (LEVEL >= 2) {
+            v = h * HI[c];
+          } else {                                       // no Hessian pass: interior part from J^ directly
+            for (int i = 0; i < K; i++)
+              for (int k = 0; k < n; k++) {
+                double dj = 0.0;
+                for (int b = 0; b < N; b++) dj += S[D::o_IJ + (i * n + k) * N + b] * DI[(i * NP + b) * IRP + c];
+                v += lam[i * n + k] * ((h * tab.E[i]) * dj);
+              }
+          }
+#pragma unroll
+          for (int jr = 0; jr < OR; jr++) v += lam[jr] * DC[jr * IRP + c];
+          a.AGX[seg * IR + c] = v;
+        }
+      }
+
+      if (g == 0) TS();
+      // ---- D6: store.  Entry (v) of a tile held by this lane: block column c = 16*ct + lk + 4v,
+      //      row (H) r = 16*rt + lr or (J) jr = 16*jt + lr; 16 consecutive lanes cover 128 contiguous bytes.
+      if (a.KKT) {
+        double* dst = a.KKT + seg * size_t(D::NKKT);
+#pragma unroll
+        for (int ct = 0; ct < D::TI; ct++) {
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            const int c = 16 * ct + lk + 4 * v;
+            const int cst = c * (IR + OR) - c * (c - 1) / 2;   // first slot of block column c
+            if (c < IR) {
+#pragma unroll
+              for (int rt = ct; rt < D::TI; rt++) {
+                const int r = 16 * rt + lr;
+                if (r >= c && r < IR) dst[cst + (r - c)] = (LEVEL >= 2) ? accH[rt * (rt + 1) / 2 + ct][v] : 0.0;
+              }
+#pragma unroll
+              for (int jt = 0; jt < D::TJ; jt++) {
+                const int jr = 16 * jt + lr;
+                if (jr < OR) dst[cst + (IR - c) + jr] = accJ[ct * D::TJ + jt][v];
+              }
+            }
+          }
+        }
+      }
+      if (g == 0) TS();
+      wave_lds_sync();  // the next segment rewrites the DI / M / DC tiles
+    }
+    TS();
+  }
+#if defined(ASSET_TIMING)
+  if (blockIdx.x == 7 && lane == 0 && a.FX)
+    for (int t = 0; t + 1 < nts; t++) a.FX[size_t(wg_first) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
+#endif
+#undef TS
+}
+
+}  // namespace asset_hip
+
+// =============================================================================================== Trapezoidal
+// d = -[(x1 - x0) - (h/2)(f0 + f1)], its Jacobian, adjoint gradient and adjoint Hessian
+// (/root/reference/src/OptimalControl/TrapezoidalDefects.h:146-184, 186-260, 263-435).  No interior point and
+// no congruence product: every block entry is a closed form of the two cardinal ODE evaluations, so the kernel
+// is two phases -- lane <-> (segment, node) for the ODE, then lanes stride over the block slots of each segment
+// and store straight to HBM (coalesced, reference slot order).
+namespace asset_hip {
+
+template <class Ode, bool BLOCKED_>
+struct TrapDims {
+  static constexpr int n = Ode::XV;
+  static constexpr int m = BLOCKED_ ? 0 : Ode::UV;
+  static constexpr int p = BLOCKED_ ? Ode::UV + Ode::PV : Ode::PV;
+  static constexpr int q = n + 1 + m;
+  static constexpr int N = q + p;
+  static constexpr int T = n, TF = q + n, P0 = 2 * q;
+  static constexpr int IR = 2 * q + p, OR = n;
+  static constexpr int NKKT = IR * (IR + 1) / 2 + OR * IR;
+  static constexpr int NH = N * (N + 1) / 2;
+  static constexpr int o_z = 0, o_lam = o_z + IR, o_F = o_lam + OR, o_J = o_F + 2 * n, o_G = o_J + 2 * n * N,
+                       o_H = o_G + 2 * N, SLOT = o_H + 2 * NH;
+  static_assert(IR + OR < 256, "slot map packs the row index in 8 bits");
+  template <int G>
+  static constexpr size_t lds_bytes() { return size_t(G) * SLOT * 8 + size_t((NKKT + 3) / 4 * 4) * 2; }
+};
+
+template <class D>
+struct TrapIn {
+  const double* z;
+  const double* l;
+  int j;
+  __device__ double y(int i) const { return i < D::q ? z[j * D::q + i] : z[D::P0 + (i - D::q)]; }
+  __device__ double lam(int k) const { return l[k]; }
+};
+template <class D>
+struct TrapOut {
+  double* f_;
+  double* J_;
+  double* g_;
+  double* H_;
+  __device__ void f(int k, double v) { f_[k] = v; }
+  __device__ void J(int k, int i, double v) { J_[k * D::N + i] = v; }
+  __device__ void g(int i, double v) { g_[i] = v; }
+  __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
+};
+
+template <class Ode, bool BLOCKED, int G, int LEVEL>
+__global__ __launch_bounds__(64) void trap_defect_kernel(EvalArgs a) {
+  using D = TrapDims<Ode, BLOCKED>;
+  constexpr int n = D::n, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0, IR = D::IR, OR = D::OR;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  unsigned short* kmap = reinterpret_cast<unsigned short*>(lds + G * D::SLOT);
+  const int lane = threadIdx.x;
+  if constexpr (LEVEL >= 1) {
+    for (int k = lane; k < D::NKKT; k += 64) {
+      int lo = 0, hi = IR - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (mid * (IR + OR) - mid * (mid - 1) / 2 <= k) lo = mid; else hi = mid - 1;
+      }
+      const int r = k - (lo * (IR + OR) - lo * (lo - 1) / 2);
+      kmap[k] = static_cast<unsigned short>((lo << 8) | (r < IR - lo ? lo + r : IR + (r - (IR - lo))));
+    }
+  }
+  __syncthreads();
+  const int ngroups = (a.nseg + G - 1) / G;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int seg0 = grp * G, gcount = min(G, a.nseg - seg0);
+    for (int e = lane; e < gcount * IR; e += 64) {
+      const int g = e / IR, r = e - g * IR;
+      lds[g * D::SLOT + D::o_z + r] = a.X[a.vindex[size_t(seg0 + g) * IR + r]];
+    }
+    if constexpr (LEVEL >= 1) {
+      for (int e = lane; e < gcount * OR; e += 64) {
+        const int g = e / OR, r = e - g * OR;
+        lds[g * D::SLOT + D::o_lam + r] = a.L ? a.L[a.cindex[size_t(seg0 + g) * OR + r]] : 0.0;
+      }
     }
     __syncthreads();
-
-    // ------------------------------------------------------------------ P2: interior points
-    for (int e = lane; e < gcount * K; e += 64) {
-      const int g = e / K, i = e - g * K;
-      double* S = slots + g * D::SLOT;
-      const double* z = S + D::o_z;
-      const double h = z[D::TF] - z[T];
-      double y[N];
-      double li[n > 0 ? n : 1];
-#pragma unroll
-      for (int k = 0; k < n; k++) {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * S[D::o_Cf + j * n + k]);
-        y[k] = acc;
-      }
-      y[T] = z[T] + h * tab.s[i];
-#pragma unroll
-      for (int k = 0; k < m; k++) {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < CS; j++) acc += tab.U[i][j] * z[j * q + n + 1 + k];
-        y[n + 1 + k] = acc;
-      }
-#pragma unroll
-      for (int k = 0; k < p; k++) y[q + k] = z[D::P0 + k];
-#pragma unroll
-      for (int k = 0; k < n; k++) li[k] = (LEVEL >= 2) ? S[D::o_lam + i * n + k] : 0.0;
-      RegIn<D> in{y, li};
-      OdeOut<D> out{S + D::o_If + i * n, S + D::o_IJ + i * n * N, S + D::o_Ig + i * N, S + D::o_IH + i * D::NH};
+    for (int e = lane; e < gcount * 2; e += 64) {
+      const int g = e >> 1, j = e & 1;
+      double* S = lds + g * D::SLOT;
+      TrapIn<D> in{S + D::o_z, S + D::o_lam, j};
+      TrapOut<D> out{S + D::o_F + j * n, S + D::o_J + j * n * N, S + D::o_G + j * N, S + D::o_H + j * D::NH};
       if constexpr (LEVEL == 0) Ode::f(in, out);
       else if constexpr (LEVEL == 1) Ode::fj(in, out);
       else Ode::fjgh(in, out);
     }
     __syncthreads();
-
-    // ------------------------------------------------------------------ P3: cardinal second derivatives
-    if constexpr (LEVEL >= 2) {
-      for (int e = lane; e < gcount * CS; e += 64) {
-        const int g = e / CS, j = e - g * CS;
-        double* S = slots + g * D::SLOT;
-        const double* z = S + D::o_z;
-        const double h = z[D::TF] - z[T];
-        double w[n > 0 ? n : 1];
-#pragma unroll
-        for (int k = 0; k < n; k++) {  // C_AVS[j]  (LGLDefects.h:369-374)
-          double acc = 0.0;
-#pragma unroll
-          for (int i = 0; i < K; i++) {
-            acc += S[D::o_Ig + i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
-            acc += S[D::o_lam + i * n + k] * (tab.D[i][j] * h);
-          }
-          w[k] = acc;
-        }
-        CardIn<D> in{z, w, j};
-        OdeOut<D> out{S + D::o_Cf + j * n, S + D::o_CJ + j * n * N, S + D::o_Cg + j * N, S + D::o_CH + j * D::NH};
-        Ode::fjgh(in, out);
-      }
-      __syncthreads();
-    }
-
-    // ------------------------------------------------------------------ P4: per-segment dense phase
     for (int g = 0; g < gcount; g++) {
-      const double* S = slots + g * D::SLOT;
+      const double* S = lds + g * D::SLOT;
       const double* z = S + D::o_z;
       const double* lam = S + D::o_lam;
-      const double h = z[D::TF] - z[T];
+      const double* F0 = S + D::o_F;
+      const double* F1 = F0 + n;
+      const double* J0 = S + D::o_J;
+      const double* J1 = J0 + n * N;
+      const double* G0 = S + D::o_G;
+      const double* G1 = G0 + N;
+      const double* H0 = S + D::o_H;
+      const double* H1 = H0 + D::NH;
+      const double h = z[TF] - z[T];
+      const double mh2 = -h / 2.0;
       const size_t seg = size_t(seg0 + g);
-
-      // ---- value (every level): lanes over (i,k)
-      if (a.FX) {
-        for (int e = lane; e < OR; e += 64) {
-          const int i = e / n, k = e - i * n;
-          double acc = 0.0;
-#pragma unroll
-          for (int j = 0; j < CS; j++) acc += (tab.C[i][j] * z[j * q + k] + (tab.D[i][j] * h) * S[D::o_Cf + j * n + k]);
-          acc += (h * tab.E[i]) * S[D::o_If + i * n + k];
-          a.FX[seg * OR + e] = acc;
-        }
-      }
+      if (a.FX)
+        for (int k = lane; k < OR; k += 64)
+          a.FX[seg * OR + k] = -((z[q + k] - z[k]) - (h / 2.0) * (F0[k] + F1[k]));
       if constexpr (LEVEL == 0) continue;
-
-      double* DI = scr + D::s_DI;
-      double* Mt = scr + D::s_M;
-      double* LJ = scr + D::s_LJ;
-      double* HT = scr + D::s_HT;
-      double* OH = scr + D::s_OUT;
-      double* OJ = OH + D::IRP * D::LDO;
-
-      // ---- D1: DI tile (stacked over interiors) and (hE J^)^T tile
-      for (int e = lane; e < D::KT * D::IRP; e += 64) {
-        const int kk = e / D::IRP, c = e - kk * D::IRP;
-        double v = 0.0;
-        if (kk < K * N && c < IR) {
-          const int i = kk / N, r = kk - i * N;
-          if (r < n) {
-            if (c < D::P0) {
-              const int j = c / q, cc = c - j * q;
-              v = (tab.B[i][j] * h) * S[D::o_CJ + (j * n + r) * N + cc];
-              if (cc == r) v += tab.A[i][j];
-              if (cc == T && (j == 0 || j == CS - 1)) {
-                double sf = 0.0;
-#pragma unroll
-                for (int jj = 0; jj < CS; jj++) sf += tab.B[i][jj] * S[D::o_Cf + jj * n + r];
-                v += (j == 0 && CS > 1) ? -sf : sf;
-              }
-            } else {
-              const int cp = c - D::P0;
-#pragma unroll
-              for (int jj = 0; jj < CS; jj++) v += (tab.B[i][jj] * h) * S[D::o_CJ + (jj * n + r) * N + q + cp];
-            }
-          } else if (r == T) {
-            v = (c == T) ? (1.0 - tab.s[i]) : ((c == D::TF) ? tab.s[i] : 0.0);
-          } else if (r < q) {
-            const int ku = r - (n + 1);
-            if (c < D::P0) {
-              const int j = c / q, cc = c - j * q;
-              if (cc == n + 1 + ku) v = tab.U[i][j];
-            }
-          } else {
-            if (c == D::P0 + (r - q)) v = 1.0;
-          }
-        }
-        DI[kk * D::LDD + c] = v;
-      }
-      for (int e = lane; e < D::KT * D::ORP; e += 64) {
-        const int kk = e / D::ORP, jr = e - kk * D::ORP;
-        double v = 0.0;
-        if (kk < K * N && jr < OR) {
-          const int i = kk / N, r = kk - i * N;
-          const int i2 = jr / n, k2 = jr - i2 * n;
-          if (i2 == i) v = (h * tab.E[i]) * S[D::o_IJ + (i * n + k2) * N + r];
-        }
-        LJ[kk * D::LDJ + jr] = v;
-      }
-      __syncthreads();
-
-      // ---- D2: M = (hE_i H^_i) DI_i ; time-partial vector HTpar
-      if constexpr (LEVEL >= 2) {
-        for (int e = lane; e < D::KT * D::IRP; e += 64) {
-          const int kk = e / D::IRP, c = e - kk * D::IRP;
-          double v = 0.0;
-          if (kk < K * N && c < IR) {
-            const int i = kk / N, r = kk - i * N;
-            const double* Hp = S + D::o_IH + i * D::NH;
-            const double he = h * tab.E[i];
-#pragma unroll
-            for (int b = 0; b < N; b++) v += (hsym(Hp, r, b) * he) * DI[(i * N + b) * D::LDD + c];
-          }
-          Mt[kk * D::LDD + c] = v;
-        }
-        for (int c = lane; c < D::IRP; c += 64) {
-          double v = 0.0;
-          if (c < IR) {
-            const double ih = 1.0 / h;
-            if (c < D::P0) {
-              const int j = c / q, cc = c - j * q;
-              v = S[D::o_Cg + j * N + cc] * ih;
-            } else {
-#pragma unroll
-              for (int j = 0; j < CS; j++) v += S[D::o_Cg + j * N + q + (c - D::P0)] * ih;
-            }
-#pragma unroll
-            for (int i = 0; i < K; i++) {
-              double acc = 0.0;
-#pragma unroll
-              for (int r = 0; r < N; r++) acc += (S[D::o_Ig + i * N + r] * tab.E[i]) * DI[(i * N + r) * D::LDD + c];
-              v += acc;
-            }
-          }
-          HT[c] = v;
-        }
-        __syncthreads();
-      }
-
-      // ---- D3/D4: congruence products into the staged output tile
-      if constexpr (MFMA) {
-        d4 acc[D::NACC];
-#pragma unroll
-        for (int t = 0; t < D::NACC; t++) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-        const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-        for (int ct = 0; ct < D::TI; ct++) {
-          const int tb = ct * (D::TI + D::TJ) - ct * (ct - 1) / 2;  // first accumulator tile of this tile-row
-          double av[D::KT / 4];
-#pragma unroll
-          for (int kk = 0; kk < D::KT / 4; kk++) av[kk] = DI[(4 * kk + lk) * D::LDD + 16 * ct + lr];
-          if constexpr (LEVEL >= 2) {
-#pragma unroll
-            for (int rt = ct; rt < D::TI; rt++) {
-#pragma unroll
-              for (int kk = 0; kk < D::KT / 4; kk++) {
-                const double bv = Mt[(4 * kk + lk) * D::LDD + 16 * rt + lr];
-                acc[tb + rt - ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv, acc[tb + rt - ct], 0, 0, 0);
-              }
-            }
-          }
-#pragma unroll
-          for (int jt = 0; jt < D::TJ; jt++) {
-#pragma unroll
-            for (int kk = 0; kk < D::KT / 4; kk++) {
-              const double bv = LJ[(4 * kk + lk) * D::LDJ + 16 * jt + lr];
-              acc[tb + D::TI - ct + jt] =
-                  __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv, acc[tb + D::TI - ct + jt], 0, 0, 0);
-            }
-          }
-        }
-        __syncthreads();  // every lane has finished reading DI / M: the staging tile may overwrite them
-#pragma unroll
-        for (int ct = 0; ct < D::TI; ct++) {
-          const int tb = ct * (D::TI + D::TJ) - ct * (ct - 1) / 2;
-#pragma unroll
-          for (int rt = ct; rt < D::TI; rt++) {
-#pragma unroll
-            for (int v = 0; v < 4; v++) OH[(16 * ct + lk + 4 * v) * D::LDO + 16 * rt + lr] = acc[tb + rt - ct][v];
-          }
-#pragma unroll
-          for (int jt = 0; jt < D::TJ; jt++) {
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-              OJ[(16 * ct + lk + 4 * v) * D::LDOJ + 16 * jt + lr] = acc[tb + D::TI - ct + jt][v];
-          }
-        }
-      } else {
-        // plain FMA reference path: each lane owns output elements and keeps them in registers until the barrier
-        constexpr int NE_H = D::IRP * D::IRP, NE_J = D::IRP * D::ORP;
-        constexpr int PER = (NE_H + NE_J + 63) / 64;
-        double accv[PER];
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-          const int e = lane + 64 * u;
-          double v = 0.0;
-          if (e < NE_H) {
-            const int c = e / D::IRP, r = e - c * D::IRP;
-            if (LEVEL >= 2 && r >= c)
-              for (int kk = 0; kk < K * N; kk++) v += DI[kk * D::LDD + c] * Mt[kk * D::LDD + r];
-          } else if (e < NE_H + NE_J) {
-            const int e2 = e - NE_H;
-            const int c = e2 / D::ORP, jr = e2 - c * D::ORP;
-            for (int kk = 0; kk < K * N; kk++) v += DI[kk * D::LDD + c] * LJ[kk * D::LDJ + jr];
-          }
-          accv[u] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-          const int e = lane + 64 * u;
-          if (e < NE_H) {
-            const int c = e / D::IRP, r = e - c * D::IRP;
-            OH[c * D::LDO + r] = accv[u];
-          } else if (e < NE_H + NE_J) {
-            const int e2 = e - NE_H;
-            const int c = e2 / D::ORP, jr = e2 - c * D::ORP;
-            OJ[c * D::LDOJ + jr] = accv[u];
-          }
-        }
-      }
-      __syncthreads();
-
-      // ---- D5: sparse terms.  Jacobian: cardinal blocks + time columns (LGLDefects.h:467-500)
-      for (int e = lane; e < OR * IR; e += 64) {
-        const int c = e / OR, jr = e - c * OR;
-        const int i = jr / n, k = jr - i * n;
-        double v = 0.0;
-        if (c < D::P0) {
-          const int j = c / q, cc = c - j * q;
-          v = (tab.D[i][j] * h) * S[D::o_CJ + (j * n + k) * N + cc];
-          if (cc == k) v += tab.C[i][j];
-          if (cc == T && (j == 0 || j == CS - 1)) {
-            double sf = 0.0;
-#pragma unroll
-            for (int jj = 0; jj < CS; jj++) sf += tab.D[i][jj] * S[D::o_Cf + jj * n + k];
-            sf += tab.E[i] * S[D::o_If + i * n + k];
-            v += (j == 0) ? -sf : sf;
-          }
+      // final (already negated) Jacobian entry
+      auto jac = [&](int k, int c) -> double {
+        double v;
+        if (c < q) {
+          v = mh2 * J0[k * N + c];
+          if (c == k) v += -1.0;
+          if (c == T) v -= -0.5 * (F0[k] + F1[k]);
+        } else if (c < P0) {
+          const int cc = c - q;
+          v = mh2 * J1[k * N + cc];
+          if (cc == k) v += 1.0;
+          if (cc == T) v += -0.5 * (F0[k] + F1[k]);
         } else {
-#pragma unroll
-          for (int jj = 0; jj < CS; jj++) v += (tab.D[i][jj] * h) * S[D::o_CJ + (jj * n + k) * N + q + (c - D::P0)];
+          v = mh2 * (J0[k * N + q + (c - P0)] + J1[k * N + q + (c - P0)]);
         }
-        OJ[c * D::LDOJ + jr] += v;
-      }
-      if constexpr (LEVEL >= 2) {
-        // Hessian: cardinal diagonal / parameter blocks (LGLDefects.h:386-402), lower triangle only (r >= c)
-        for (int e = lane; e < CS * q * q; e += 64) {
-          const int j = e / (q * q), rem = e - j * q * q;
-          const int aa = rem / q, bb = rem - aa * q;  // H(jq+aa, jq+bb), keep aa >= bb
-          if (aa >= bb) OH[(j * q + bb) * D::LDO + (j * q + aa)] += S[D::o_CH + j * D::NH + aa * (aa + 1) / 2 + bb];
-        }
-        if constexpr (p > 0) {
-          for (int e = lane; e < CS * q * p; e += 64) {
-            const int j = e / (q * p), rem = e - j * q * p;
-            const int aa = rem / p, bb = rem - aa * p;  // row P0+bb, col jq+aa
-            OH[(j * q + aa) * D::LDO + (D::P0 + bb)] += hsym(S + D::o_CH + j * D::NH, q + bb, aa);
-          }
-          for (int e = lane; e < p * p; e += 64) {
-            const int aa = e / p, bb = e - aa * p;  // row P0+aa, col P0+bb, aa >= bb
-            if (aa >= bb) {
-              double v = 0.0;
-#pragma unroll
-              for (int j = 0; j < CS; j++) v += hsym(S + D::o_CH + j * D::NH, q + aa, q + bb);
-              OH[(D::P0 + bb) * D::LDO + (D::P0 + aa)] += v;
-            }
-          }
-        }
-      }
-      __syncthreads();
-
-      // ---- D6/D7: rank-2 time update (LGLDefects.h:508-511) and adjoint gradient (:512)
-      if constexpr (LEVEL >= 2) {
-        for (int r = lane; r < IR; r += 64) {  // columns T and TF, rows r >= column
-          if (r >= T) OH[T * D::LDO + r] -= HT[r];
-          if (r >= D::TF) OH[D::TF * D::LDO + r] += HT[r];
-        }
-        __syncthreads();
-        for (int c = lane; c < IR; c += 64) {  // rows T and TF, columns c <= row
-          if (c <= T) OH[c * D::LDO + T] -= HT[c];
-          if (c <= D::TF) OH[c * D::LDO + D::TF] += HT[c];
-        }
-      }
-      if (a.AGX) {
+        return -v;
+      };
+      auto htpar = [&](int c) -> double {
+        if (c < q) return -G0[c] * 0.5;
+        if (c < P0) return -G1[c - q] * 0.5;
+        return -G0[q + (c - P0)] * 0.5 + -G1[q + (c - P0)] * 0.5;
+      };
+      auto hess = [&](int r, int c) -> double {  // r >= c, final sign
+        double v = 0.0;
+        if (r < q) v = mh2 * hsym(H0, r, c);
+        else if (r < P0) { if (c >= q) v = mh2 * hsym(H1, r - q, c - q); }
+        else if (c >= P0) v = mh2 * (hsym(H0, q + r - P0, q + c - P0) + hsym(H1, q + r - P0, q + c - P0));
+        else if (c < q) v = mh2 * hsym(H0, q + r - P0, c);
+        else v = mh2 * hsym(H1, q + r - P0, c - q);
+        if (c == T) v -= htpar(r);
+        if (c == TF) v += htpar(r);
+        if (r == T) v -= htpar(c);
+        if (r == TF) v += htpar(c);
+        return -v;
+      };
+      if (a.AGX)
         for (int c = lane; c < IR; c += 64) {
           double acc = 0.0;
-          for (int r = 0; r < OR; r++) acc += lam[r] * OJ[c * D::LDOJ + r];
+          for (int k = 0; k < OR; k++) acc += lam[k] * jac(k, c);
           a.AGX[seg * IR + c] = acc;
         }
-      }
-      __syncthreads();
-
-      // ---- D8: stream the finished block, reference slot order, coalesced
       if (a.KKT) {
         double* dst = a.KKT + seg * size_t(D::NKKT);
         for (int k = lane; k < D::NKKT; k += 64) {
-          const int off = kmap[k];
-          double v = scr[D::s_OUT + off];
-          if (LEVEL < 2 && off < D::IRP * D::LDO) v = 0.0;
+          const int code = kmap[k], c = code >> 8, r = code & 255;
+          double v;
+          if (r < IR) v = (LEVEL >= 2) ? hess(r, c) : 0.0;
+          else v = jac(r - IR, c);
           dst[k] = v;
         }
       }
-      __syncthreads();
     }
+    __syncthreads();
   }
 }
 

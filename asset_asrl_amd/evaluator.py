@@ -21,7 +21,7 @@ class DefectEvaluator:
     """
 
     def __init__(self, ode: str, mode, blocked: bool, vindex, cindex, n_primal: int, n_equal: int,
-                 device: int = 0, use_mfma: bool = True):
+                 device: int = 0):
         L = _lib.lib()
         self.ode = ode
         self.mode = MODES[mode] if isinstance(mode, str) else int(mode)
@@ -35,7 +35,7 @@ class DefectEvaluator:
         desc = _lib.DefectDesc(self.mode, int(self.blocked), ode.encode(), self.nseg,
                                self.vindex.ctypes.data_as(C.POINTER(C.c_int32)),
                                self.cindex.ctypes.data_as(C.POINTER(C.c_int32)),
-                               self.n_primal, self.n_equal, int(device), int(use_mfma))
+                               self.n_primal, self.n_equal, int(device))
         self._h = C.c_void_p()
         _lib.check(L.asset_hip_defect_create(C.byref(desc), C.byref(self._h)), "asset_hip_defect_create")
         ir, orr, nk = C.c_int(), C.c_int(), C.c_int()

@@ -87,7 +87,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="reentry_lgl7_10k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fma", action="store_true", help="use the plain-FMA congruence path instead of MFMA")
     a = ap.parse_args()
 
     import numpy as np
@@ -112,8 +111,7 @@ def main():
 
     ode, mode, nseg, blocked = WORKLOADS[a.workload]
     w = Workload(ode, mode, nseg, blocked, seed=20260723 + rank)
-    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal, device=local_rank,
-                         use_mfma=not a.fma)
+    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal, device=local_rank)
     dev = torch.device("cuda", local_rank)
     X = torch.from_numpy(w.X).to(dev)
     L = torch.from_numpy(w.L).to(dev)
@@ -167,7 +165,7 @@ def main():
                                    f"{', BlockConstant control' if w.blocked else ''}; evalKKT-equivalent "
                                    "(value + adjoint gradient + Jacobian + adjoint-Hessian blocks), inputs resident in HBM",
                        "name": a.workload, "IR": ev.IR, "OR": ev.OR, "kkt_slots_per_segment": ev.NKKT,
-                       "congruence": "fma" if a.fma else "mfma_f64_16x16x4",
+                       "congruence": "mfma_f64_16x16x4",
                        "sharding": f"{world} x {nseg} independent segments, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

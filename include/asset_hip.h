@@ -68,7 +68,6 @@ typedef struct asset_hip_defect_desc {
   int n_primal;           /* length of X (bounds check + staging size for the host-pointer entry point)           */
   int n_equal;            /* length of L                                                                          */
   int device;             /* HIP device ordinal                                                                   */
-  int use_mfma;           /* 1 = matrix-core congruence (default path), 0 = plain FMA cross-check path             */
 } asset_hip_defect_desc;
 
 int asset_hip_defect_create(const asset_hip_defect_desc* desc, asset_hip_defect_t* out);

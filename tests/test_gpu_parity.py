@@ -43,15 +43,39 @@ CONFIGS = [
     ("betts_lowthrust", "LGL3", 17, True),
     ("brachistochrone", "LGL7", 5, True),
     ("synthetic32", "LGL3", 9, False),
+    ("reentry", "Trapezoidal", 130, False),
+    ("twobody_lt", "Trapezoidal", 33, True),
+    ("betts_lowthrust", "Trapezoidal", 21, False),
+    ("synthetic32", "Trapezoidal", 5, False),
 ]
 
 
+def _all_kernels():
+    out = []
+    for ode in ("brachistochrone", "reentry", "twobody_lt", "betts_lowthrust"):
+        for mode in ("Trapezoidal", "LGL3", "LGL5", "LGL7"):
+            for blocked in (False, True):
+                out.append((ode, mode, blocked))
+    return out
+
+
+@pytest.mark.parametrize("ode,mode,blocked", _all_kernels())
+def test_every_compiled_instantiation(oracle, ode, mode, blocked):
+    """One small full evaluation per (ODE, transcription, control mode) kernel instantiation."""
+    if not _lib.has_kernel(ode, _lib.MODES[mode], blocked):
+        pytest.skip("not instantiated")
+    w = Workload(ode, mode, 19, blocked, seed=7)
+    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    _check_blocks(ev.eval(JAC_ADJGRAD_HESS, w.X, w.L), w.oracle_nlp(oracle, threads=2).eval_blocks(oracle.JAC_ADJGRAD_HESS, w.X, w.L),
+                  w, JAC_ADJGRAD_HESS)
+    ev.close()
+
+
 @pytest.mark.parametrize("ode,mode,nseg,blocked", CONFIGS)
-@pytest.mark.parametrize("use_mfma", [True, False], ids=["mfma", "fma"])
-def test_all_evaluation_kinds_match_oracle(oracle, ode, mode, nseg, blocked, use_mfma):
+def test_all_evaluation_kinds_match_oracle(oracle, ode, mode, nseg, blocked):
     w = Workload(ode, mode, nseg, blocked, var_offset=3, con_offset=2, extra_vars=4)
     nlp = w.oracle_nlp(oracle, threads=4)
-    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal, use_mfma=use_mfma)
+    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
     assert (ev.IR, ev.OR, ev.NKKT) == (w.IR, w.OR, w.NKKT)
     for what in (JAC_ADJGRAD_HESS, CON, CON_ADJGRAD, JAC, JAC_ADJGRAD):
         ref = nlp.eval_blocks(what, w.X, w.L)
