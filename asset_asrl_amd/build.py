@@ -85,22 +85,23 @@ def generate(verbose=True):
         sn = _struct_name(name)
         hdr = "#pragma once\n#include <math.h>\n" + emit_hip_functor(ode.derivatives(), sn)
         _write_if_changed(os.path.join(GEN, f"ode_{name}.h"), hdr)
-        lines = [f'#include "ode_{name}.h"', '#include "../registry.h"']
         xv, uv, pv = ode.XVars(), ode.UVars(), ode.PVars()
+        # one translation unit per (transcription, control mode): they compile in parallel
+        units = []
         for cs in (2, 3, 4):
             for blocked in ((0, 1) if uv > 0 else (0,)):
                 G = pick_group(xv, uv, pv, cs, bool(blocked))
                 if G == 0:
-                    lines.append(f"// LGL cs={cs} blocked={blocked}: working set exceeds one CU's LDS -- not instantiated")
-                    continue
-                lines.append(f"ASSET_REGISTER_LGL({sn}, {cs}, {blocked}, {G})")
+                    continue  # working set exceeds one CU's LDS -- not instantiated (asset_hip_has_kernel says so)
+                units.append((f"lgl{cs}_{blocked}", f"ASSET_REGISTER_LGL({sn}, {cs}, {blocked}, {G})"))
         for blocked in ((0, 1) if uv > 0 else (0,)):
             G = pick_trap_group(xv, uv, pv, bool(blocked))
             if G:
-                lines.append(f"ASSET_REGISTER_TRAP({sn}, {blocked}, {G})")
-        tu = os.path.join(GEN, f"tu_{name}.hip")
-        _write_if_changed(tu, "\n".join(lines) + "\n")
-        tus.append(tu)
+                units.append((f"trap_{blocked}", f"ASSET_REGISTER_TRAP({sn}, {blocked}, {G})"))
+        for tag, line in units:
+            tu = os.path.join(GEN, f"tu_{name}_{tag}.hip")
+            _write_if_changed(tu, f'#include "ode_{name}.h"\n#include "../registry.h"\n{line}\n')
+            tus.append(tu)
         if verbose:
             print(f"[asset_hip] generated {name}: {ode.derivatives().stats()}", flush=True)
     return tus
@@ -125,9 +126,9 @@ def _compile(src):
     os.makedirs(OBJ, exist_ok=True)
     obj = os.path.join(OBJ, os.path.basename(src).rsplit(".", 1)[0] + ".o")
     deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    inc = os.path.join(GEN, os.path.basename(src).replace("tu_", "ode_").replace(".hip", ".h"))
-    if os.path.exists(inc):
-        deps.append(inc)
+    for f in os.listdir(GEN):
+        if f.startswith("ode_") and f.endswith(".h") and f'#include "{f}"' in open(src).read():
+            deps.append(os.path.join(GEN, f))
     deps.append(os.path.join(HERE, "..", "include", "asset_hip.h"))
     stamp = obj + ".sha"
     dg = _digest(deps)
@@ -144,8 +145,16 @@ def _compile(src):
 
 def build(verbose=True, jobs=None) -> str:
     tus = generate(verbose)
+    keep = {os.path.basename(t) for t in tus}
+    for f in os.listdir(GEN):       # drop translation units of an older layout
+        if f.startswith("tu_") and f not in keep:
+            os.remove(os.path.join(GEN, f))
+    if os.path.isdir(OBJ):
+        for f in os.listdir(OBJ):
+            if f.startswith("tu_") and f.split(".")[0] + ".hip" not in keep:
+                os.remove(os.path.join(OBJ, f))
     srcs = tus + [os.path.join(CSRC, "capi.hip")]
-    jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
+    jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2)))
     with ThreadPoolExecutor(jobs) as ex:
         res = list(ex.map(_compile, srcs))
     objs = [o for o, _ in res]

@@ -797,6 +797,16 @@ struct TrapOut {
   __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
 };
 
+// out of line for the same reason as the LGL ODE phases: a long generated body with its own register allocation
+template <class Ode, class D, int LEVEL>
+__device__ __attribute__((noinline)) void trap_node_eval(double* S, int j) {
+  TrapIn<D> in{S + D::o_z, S + D::o_lam, j};
+  TrapOut<D> out{S + D::o_F + j * D::n, S + D::o_J + j * D::n * D::N, S + D::o_G + j * D::N, S + D::o_H + j * D::NH};
+  if constexpr (LEVEL == 0) Ode::f(in, out);
+  else if constexpr (LEVEL == 1) Ode::fj(in, out);
+  else Ode::fjgh(in, out);
+}
+
 template <class Ode, bool BLOCKED, int G, int LEVEL>
 __global__ __launch_bounds__(64) void trap_defect_kernel(EvalArgs a) {
   using D = TrapDims<Ode, BLOCKED>;
@@ -830,15 +840,7 @@ __global__ __launch_bounds__(64) void trap_defect_kernel(EvalArgs a) {
       }
     }
     __syncthreads();
-    for (int e = lane; e < gcount * 2; e += 64) {
-      const int g = e >> 1, j = e & 1;
-      double* S = lds + g * D::SLOT;
-      TrapIn<D> in{S + D::o_z, S + D::o_lam, j};
-      TrapOut<D> out{S + D::o_F + j * n, S + D::o_J + j * n * N, S + D::o_G + j * N, S + D::o_H + j * D::NH};
-      if constexpr (LEVEL == 0) Ode::f(in, out);
-      else if constexpr (LEVEL == 1) Ode::fj(in, out);
-      else Ode::fjgh(in, out);
-    }
+    for (int e = lane; e < gcount * 2; e += 64) trap_node_eval<Ode, D, LEVEL>(lds + (e >> 1) * D::SLOT, e & 1);
     __syncthreads();
     for (int g = 0; g < gcount; g++) {
       const double* S = lds + g * D::SLOT;
