@@ -163,8 +163,17 @@ def build(verbose=True, jobs=None) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    # host-side C++ shim (plain g++; links against the C ABI only)
+    host_src = os.path.join(HERE, "host", "batched_defect_constraint.cpp")
+    host_lib = os.path.join(HERE, "libasset_host.so")
+    if (not os.path.exists(host_lib) or os.path.getmtime(host_lib) < max(os.path.getmtime(host_src), os.path.getmtime(LIB))):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", host_src, "-o", host_lib, "-L" + HERE, "-lasset_hip",
+               "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host shim build failed:\n" + r.stderr[-4000:])
     if verbose:
-        print(f"[asset_hip] {LIB} ({os.path.getsize(LIB) // 1024} KiB)", flush=True)
+        print(f"[asset_hip] {LIB} ({os.path.getsize(LIB) // 1024} KiB), {host_lib}", flush=True)
     return LIB
 
 

@@ -1,0 +1,79 @@
+// Host-side shim: a phase's defect equality constraint, evaluated for all of its applications at once on an
+// MI355X through the C ABI (include/asset_hip.h), exposing the method set of the reference's constraint
+// plug-in interface so that it can stand where the threaded CPU evaluator stood.
+//
+// Interface mirrored (names, argument meaning, accumulate-vs-overwrite semantics), relative to /root/reference/src:
+//   SolverConstraintSpec::Concept          VectorFunctions/VectorFunctionTypeErasure/SolverInterfaceSpecs.h:41-92
+//   SizableSpec  name/IRows/ORows/thread_safe   VectorFunctions/VectorFunctionTypeErasure/SizingSpecs.h:29-39
+//   SolverIndexingData                     VectorFunctions/IndexingData.h:30-210
+// Differences forced by the absence of Eigen in this tree: vectors are plain pointers, the KKT matrix is
+// its CSR value array (what `KKTmat.valuePtr()` is in the reference), and the per-column mutex table
+// (KKTClashes / KKTLocks) is not taken: the shim evaluates every application in one device call and scatters
+// on the calling thread, i.e. it is meant to be registered with ThreadMode = MainThread
+// (Solvers/NonLinearProgram.cpp:86-104), as SURVEY.md section 8(b) prescribes.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/asset_hip.h"
+
+namespace asset_hip_host {
+
+struct SolverIndexingData {
+  int input_size = 0, output_size = 0, num_funcappl = 0;
+  std::vector<int> Vindex;   // [input_size x num_funcappl] column-major
+  std::vector<int> Cindex;   // [output_size x num_funcappl] column-major
+  std::vector<int> InnerConstraintStarts, InnerGradientStarts, InnerKKTStarts;
+  int NumAppl() const { return num_funcappl; }
+  int VLoc(int loc, int col) const { return Vindex[size_t(col) * input_size + loc]; }
+  int CLoc(int loc, int col) const { return Cindex[size_t(col) * output_size + loc]; }
+  // IndexingData.h:96-115
+  void getGradientSpace(int* GXrows, int& freeloc);
+  void getConstraintSpace(int* FXrows, int& freeloc);
+};
+
+class BatchedDefectConstraint {
+ public:
+  // mode: ASSET_HIP_LGL3/5/7 or ASSET_HIP_TRAPEZOIDAL; throws std::invalid_argument / std::runtime_error
+  BatchedDefectConstraint(const std::string& ode, int mode, bool blocked, const SolverIndexingData& data,
+                          int primal_vars, int equal_cons, int device = 0);
+  ~BatchedDefectConstraint();
+  BatchedDefectConstraint(const BatchedDefectConstraint&) = delete;
+  BatchedDefectConstraint& operator=(const BatchedDefectConstraint&) = delete;
+
+  std::string name() const;
+  int IRows() const { return ir_; }
+  int ORows() const { return or_; }
+  bool thread_safe() const { return false; }  // one evaluation at a time per handle
+
+  // DenseFunctionBase.h:1070-1088 / 1097-1129 (every Jacobian and lower-triangle Hessian entry is structural)
+  int numKKTEles(bool dojac, bool dohess) const;
+  void getKKTSpace(int* KKTrows, int* KKTcols, int& freeloc, int conoffset, bool dojac, bool dohess,
+                   SolverIndexingData& data) const;
+
+  // ComputableBase.h:246-335, DenseFunctionBase.h:1145-1391.  FX/AGX slots are overwritten, KKT values accumulated.
+  void constraints(const double* X, double* FX, const SolverIndexingData& data);
+  void constraints_adjointgradient(const double* X, const double* L, double* FX, double* AGX,
+                                   const SolverIndexingData& data);
+  void constraints_jacobian(const double* X, double* FX, double* KKTvals, const int* KKTLocations,
+                            const SolverIndexingData& data);
+  void constraints_jacobian_adjointgradient(const double* X, const double* L, double* FX, double* AGX,
+                                            double* KKTvals, const int* KKTLocations, const SolverIndexingData& data);
+  void constraints_jacobian_adjointgradient_adjointhessian(const double* X, const double* L, double* FX, double* AGX,
+                                                           double* KKTvals, const int* KKTLocations,
+                                                           const SolverIndexingData& data);
+
+  // block scatter (public so it can be checked on its own): KKTFillAll / KKTFillJac, DenseFunctionBase.h:1413-1523
+  static void scatter_kkt(const double* kkt_blocks, int nkkt, int ir, int orr, bool dohess, double* KKTvals,
+                          const int* KKTLocations, const SolverIndexingData& data);
+
+ private:
+  void eval(int what, const double* X, const double* L, double* FX, double* AGX, double* KKTvals,
+            const int* KKTLocations, const SolverIndexingData& data);
+  asset_hip_defect_t h_ = nullptr;
+  std::string ode_;
+  int mode_, ir_ = 0, or_ = 0, nkkt_ = 0, nappl_ = 0;
+  std::vector<double> fx_, agx_, kkt_;
+};
+
+}  // namespace asset_hip_host

@@ -1,0 +1,201 @@
+"""``Phase`` -- the slice of the reference's ODEPhase API that reaches the accelerated path.
+
+Kept names / argument meaning (host orchestration only; nothing here is timed):
+  ``ode.phase(mode, traj, nsegs)``, ``setTraj``, ``setControlMode``, ``switchTranscriptionMode``, ``transcribe``,
+  ``get_defect`` (-> object with ``IRows/ORows/compute/jacobian/adjointgradient/adjointhessian/computeall``),
+  ``test_threads(i, j, n)`` and ``returnTraj``
+(/root/reference/src/OptimalControl/ODEPhaseBase.cpp:536-670,1364-1441; ODEPhase.h:165-341,687-717;
+ /root/reference/src/VectorFunctions/DenseFunctionBase.h:1546-1631).
+Constraints, objectives, PSIOPT and mesh refinement stay with the host solver and are out of scope here
+(SURVEY.md section 8): a Phase in this package carries only the dynamics (defect) constraint.
+"""
+from __future__ import annotations
+
+import time
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib, synth
+from .evaluator import (CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, DefectEvaluator, unpack_kkt_block)
+from .indexing import PhaseIndexer
+
+_MODES = ("LGL3", "LGL5", "LGL7", "Trapezoidal")
+_CONTROL_MODES = ("HighestOrderSpline", "FirstOrderSpline", "NoSpline", "BlockConstant")
+
+
+class DefectFunction:
+    """The phase's defect as a VectorFunction of one segment: z[IR] -> d[OR] (``phase.get_defect()``)."""
+
+    def __init__(self, ode_name: str, mode: str, blocked: bool, device: int = 0):
+        self._ode, self._mode, self._blocked, self._device = ode_name, mode, blocked, device
+        xv, uv, pv = _lib.ode_sizes(ode_name)
+        ix = PhaseIndexer(xv, uv, pv, 0)
+        ix.set_dimensions(synth.MODE_CS[mode], 1, blocked)
+        self._ir, self._or = ix.defect_sizes()
+        self._ev = None
+
+    def IRows(self):
+        return self._ir
+
+    def ORows(self):
+        return self._or
+
+    def name(self):
+        return f"{self._mode}Defects<{self._ode}>"
+
+    def _eval(self, what, x, l=None):
+        x = np.asarray(x, dtype=float).ravel()
+        if x.size != self._ir:
+            raise ValueError(f"Input vector has incorrect size: {x.size} != IRows {self._ir}")
+        if l is not None:
+            l = np.asarray(l, dtype=float).ravel()
+            if l.size != self._or:
+                raise ValueError(f"Multiplier vector has incorrect size: {l.size} != ORows {self._or}")
+        if self._ev is None:
+            V = np.arange(self._ir, dtype=np.int32)[None, :]
+            Cx = np.arange(self._or, dtype=np.int32)[None, :]
+            self._ev = DefectEvaluator(self._ode, self._mode, self._blocked, V, Cx, self._ir, self._or, self._device)
+        fx, agx, kkt = self._ev.eval(what, x, l)
+        H = J = None
+        if kkt is not None:
+            H, J = unpack_kkt_block(kkt[0], self._ir, self._or)
+        return fx[0], J, (None if agx is None else agx[0]), H
+
+    def compute(self, x):
+        return self._eval(CON, x)[0]
+
+    __call__ = compute
+
+    def jacobian(self, x):
+        return self._eval(JAC, x)[1]
+
+    def adjointgradient(self, x, l):
+        return self._eval(CON_ADJGRAD, x, l)[2]
+
+    def adjointhessian(self, x, l):
+        return self._eval(JAC_ADJGRAD_HESS, x, l)[3]
+
+    def computeall(self, x, l):
+        """(fx, jx, gx, hx) -- the reference's ``computeall(x, l)`` tuple."""
+        return self._eval(JAC_ADJGRAD_HESS, x, l)
+
+
+class Phase:
+    def __init__(self, ode, mode: str = "LGL3", device: int = 0):
+        self.ode = ode
+        self.device = device
+        self.TranscriptionMode = None
+        self.ControlMode = "HighestOrderSpline"
+        self.switchTranscriptionMode(mode)
+        self.ActiveTraj = None
+        self.numDefects = 0
+        self._ev = None
+        self._indexer = None
+
+    # ---- configuration ---------------------------------------------------------------------
+    def switchTranscriptionMode(self, mode: str):
+        if mode not in _MODES:
+            raise ValueError("Invalid Transcription Method")   # ODEPhase.h:209
+        self.TranscriptionMode = mode
+        self._ev = None
+
+    setTranscriptionMode = switchTranscriptionMode
+
+    def setControlMode(self, mode: str):
+        if mode not in _CONTROL_MODES:
+            raise ValueError(f"Unrecognized control mode: {mode}")
+        self.ControlMode = mode
+        self._ev = None
+
+    def _blocked(self) -> bool:
+        return self.ControlMode == "BlockConstant" and self.ode.UVars() > 0
+
+    # ---- trajectory -------------------------------------------------------------------------
+    def setTraj(self, traj: Sequence, nsegs: int):
+        """Resample `traj` (rows [x,t,u,p]) onto `nsegs` equal segments with the scheme's cardinal spacing
+        (linear interpolation in time, as the reference's default LerpIG does)."""
+        T = np.asarray(traj, dtype=float)
+        if T.ndim != 2 or T.shape[1] != self.ode.XtUPVars():
+            raise ValueError(f"Input trajectory states must have {self.ode.XtUPVars()} columns")
+        if not np.all(np.isfinite(T)):
+            raise ValueError("NaN or Inf detected in input trajectory")   # ODEPhaseBase.cpp:560-564
+        if nsegs < 1:
+            raise ValueError("Number of segments must be positive")
+        tcol = self.ode.TVar()
+        t = T[:, tcol]
+        if np.any(np.diff(t) <= 0) and np.any(np.diff(t) >= 0):
+            raise ValueError("Trajectory time must be strictly monotonic")
+        cs = synth.MODE_CS[self.TranscriptionMode]
+        tc = _lib.lgl_table(cs, "tc")
+        K = cs - 1
+        edges = np.linspace(t[0], t[-1], nsegs + 1)
+        nodes = np.empty(K * nsegs + 1)
+        for j in range(K):
+            nodes[j:-1:K] = edges[:-1] + tc[j] * (edges[1:] - edges[:-1])
+        nodes[-1] = t[-1]
+        order = np.argsort(t)
+        out = np.column_stack([np.interp(nodes, t[order], T[order, c]) for c in range(T.shape[1])])
+        out[:, tcol] = nodes
+        self.ActiveTraj = out
+        self.numDefects = int(nsegs)
+        self._ev = None
+
+    def returnTraj(self):
+        return [row.copy() for row in self.ActiveTraj]
+
+    # ---- transcription ------------------------------------------------------------------------
+    def transcribe(self):
+        if self.ActiveTraj is None:
+            raise RuntimeError("No trajectory set: call setTraj first")
+        name = self.ode.ode_name
+        mode_id = _lib.MODES[self.TranscriptionMode]
+        if not _lib.has_kernel(name, mode_id, self._blocked()):
+            raise _lib.AssetHipError(
+                f"no device code for ODE '{name}' with {self.TranscriptionMode}"
+                f"{' BlockConstant' if self._blocked() else ''}: only the ODE functors compiled into libasset_hip.so "
+                f"are available ({_lib.ode_names()}); there is no CPU fallback")
+        ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
+        ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
+        ix.begin_indexing(0, 0)
+        V, Cx = ix.make_defect_Vindex_Cindex()
+        self._indexer = ix
+        self._ev = DefectEvaluator(name, self.TranscriptionMode, self._blocked(), V, Cx, ix.numPhaseVars,
+                                   ix.numPhaseEqCons, self.device)
+        return self
+
+    def solver_input(self) -> np.ndarray:
+        if self._indexer is None:
+            self.transcribe()
+        return self._indexer.makeSolverInput(self.ActiveTraj)
+
+    @property
+    def evaluator(self) -> DefectEvaluator:
+        if self._ev is None:
+            self.transcribe()
+        return self._ev
+
+    def get_defect(self) -> DefectFunction:
+        return DefectFunction(self.ode.ode_name, self.TranscriptionMode, self._blocked(), self.device)
+
+    # ---- the reference's built-in benchmark of the path ---------------------------------------------
+    def test_threads(self, i: int = 1, j: int = 1, n: int = 100, verbose: bool = True):
+        """NLPTest analogue (NonLinearProgram.cpp:686-820): n x {evalKKT, evalOCC} of the defect constraint with
+        multipliers 100*U(-1,1); prints mean ms per call.  The thread counts are accepted for signature
+        compatibility; the device evaluates all segments in one launch."""
+        ev = self.evaluator
+        X = self.solver_input()
+        rng = np.random.default_rng(0)
+        t_kkt = t_occ = 0.0
+        for _ in range(n):
+            L = 100.0 * rng.uniform(-1, 1, ev.n_equal)
+            t0 = time.perf_counter()
+            ev.eval(JAC_ADJGRAD_HESS, X, L)
+            t_kkt += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ev.eval(CON, X)
+            t_occ += time.perf_counter() - t0
+        res = {"evalKKT_ms": 1e3 * t_kkt / n, "evalOCC_ms": 1e3 * t_occ / n, "segments": ev.nseg}
+        if verbose:
+            print(f"{res['evalKKT_ms']} ms\n{res['evalOCC_ms']} ms")
+        return res

@@ -147,6 +147,14 @@ def main():
     bseg = algorithmic_bytes_per_segment(ev.IR, ev.OR)
     achieved = nseg * bseg / (ms_kernel * 1e-3) / 1e9
 
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", f"r1_{a.workload}_pmc.json")
+    if os.path.exists(prof):  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+        try:
+            traffic = json.load(open(prof))["hbm"]["bytes_per_launch"]
+        except Exception:
+            traffic = None
+
     if rank == 0:
         out = {
             "metric": "NLP func+Jacobian+Hessian eval throughput (mesh segments/s)",
@@ -168,7 +176,7 @@ def main():
                        "congruence": "mfma_f64_16x16x4",
                        "sharding": f"{world} x {nseg} independent segments, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "lgl_defect_kernel", "kernel_ms": ms_kernel,
                          "algorithmic_bytes_per_segment": bseg},
         }

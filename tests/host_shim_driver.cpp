@@ -1,0 +1,49 @@
+// Test driver for the C++ host shim (asset_asrl_amd/host/batched_defect_constraint.h): builds the index data the way
+// NonLinearProgram::getMATSpace/getRHSSpace do for a single-thread NLP, runs one evaluation kind through the shim's
+// Concept-style methods and returns the scattered results.  Compiled by tests/test_gpu_host_shim.py.
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "../asset_asrl_amd/host/batched_defect_constraint.h"
+
+using namespace asset_hip_host;
+
+extern "C" int shim_run(const char* ode, int mode, int blocked, int ir, int orr, int nappl, const int* vindex,
+                        const int* cindex, int primal, int equal, int what, const double* X, const double* L,
+                        const int* kkt_locations, int* kkt_rows_out, int* kkt_cols_out, double* kkt_vals,
+                        double* FXE, double* AGX, char* err, int errcap) {
+  try {
+    SolverIndexingData data;
+    data.input_size = ir, data.output_size = orr, data.num_funcappl = nappl;
+    data.Vindex.assign(vindex, vindex + size_t(ir) * nappl);
+    data.Cindex.assign(cindex, cindex + size_t(orr) * nappl);
+    BatchedDefectConstraint con(ode, mode, blocked != 0, data, primal, equal, 0);
+    std::vector<int> gxrows(size_t(ir) * nappl), fxrows(size_t(orr) * nappl);
+    int gfree = 0, cfree = 0, kfree = 0;
+    data.getGradientSpace(gxrows.data(), gfree);
+    data.getConstraintSpace(fxrows.data(), cfree);
+    con.getKKTSpace(kkt_rows_out, kkt_cols_out, kfree, primal, true, true, data);
+    if (kfree != con.numKKTEles(true, true) * nappl) throw std::runtime_error("KKT space count mismatch");
+    std::vector<double> fxc(size_t(orr) * nappl, 0.0), agxc(size_t(ir) * nappl, 0.0);
+    switch (what) {
+      case ASSET_HIP_CON: con.constraints(X, fxc.data(), data); break;
+      case ASSET_HIP_CON_ADJGRAD: con.constraints_adjointgradient(X, L, fxc.data(), agxc.data(), data); break;
+      case ASSET_HIP_JAC: con.constraints_jacobian(X, fxc.data(), kkt_vals, kkt_locations, data); break;
+      case ASSET_HIP_JAC_ADJGRAD:
+        con.constraints_jacobian_adjointgradient(X, L, fxc.data(), agxc.data(), kkt_vals, kkt_locations, data);
+        break;
+      default:
+        con.constraints_jacobian_adjointgradient_adjointhessian(X, L, fxc.data(), agxc.data(), kkt_vals,
+                                                                kkt_locations, data);
+    }
+    // fillRHS (NonLinearProgram.h:401-407)
+    for (size_t i = 0; i < fxc.size(); i++) FXE[fxrows[i]] += fxc[i];
+    for (size_t i = 0; i < agxc.size(); i++) AGX[gxrows[i]] += agxc[i];
+    return 0;
+  } catch (const std::exception& e) {
+    std::strncpy(err, e.what(), errcap - 1);
+    err[errcap - 1] = 0;
+    return 1;
+  }
+}

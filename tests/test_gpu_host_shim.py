@@ -1,0 +1,53 @@
+"""GPU test of the C++ host shim: the Concept-style methods scatter into the same CSR values / RHS vectors as the
+oracle's NonLinearProgram restatement."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import Workload, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    pk = os.path.join(ROOT, "asset_asrl_amd")
+    so = str(tmp_path_factory.mktemp("shim") / "shim_driver.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "host_shim_driver.cpp"),
+                           "-o", so, "-L" + pk, "-lasset_host", "-lasset_hip", "-Wl,-rpath," + pk])
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("ode,mode,blocked,nseg", [("reentry", "LGL7", False, 37), ("twobody_lt", "LGL5", True, 20),
+                                                   ("betts_lowthrust", "LGL3", False, 9), ("reentry", "Trapezoidal", False, 11)])
+def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg):
+    w = Workload(ode, mode, nseg, blocked, var_offset=2, con_offset=1, extra_vars=3)
+    nlp = w.oracle_nlp(oracle, threads=1)
+    locs = nlp.kkt_locations()
+    rows_ref, cols_ref = nlp.kkt_coords()
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    for what in (oracle.JAC_ADJGRAD_HESS, oracle.CON, oracle.CON_ADJGRAD, oracle.JAC, oracle.JAC_ADJGRAD):
+        FXE, AGX, vals = np.zeros(w.n_equal), np.zeros(w.n_primal), np.zeros(nlp.nnz)
+        rows = np.zeros(nlp.num_user_kkt, dtype=np.int32)
+        cols = np.zeros(nlp.num_user_kkt, dtype=np.int32)
+        err = C.create_string_buffer(512)
+        rc = shim.shim_run(ode.encode(), oracle.MODES[mode], int(w.blocked), w.IR, w.OR, w.nseg,
+                           w.vindex.ctypes.data_as(ip), w.cindex.ctypes.data_as(ip), w.n_primal, w.n_equal, what,
+                           w.X.ctypes.data_as(dp), w.L.ctypes.data_as(dp), locs.ctypes.data_as(ip),
+                           rows.ctypes.data_as(ip), cols.ctypes.data_as(ip), vals.ctypes.data_as(dp),
+                           FXE.ctypes.data_as(dp), AGX.ctypes.data_as(dp), err, 512)
+        assert rc == 0, err.value
+        # analyzeSparsity keeps every slot as (row >= col) and files it in CSR row `col` (NonLinearProgram.cpp:282-307)
+        lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+        np.testing.assert_array_equal(hi, rows_ref[: nlp.num_user_kkt])
+        np.testing.assert_array_equal(lo, cols_ref[: nlp.num_user_kkt])
+        rFXE, rAGX, rvals = nlp.eval(what, w.X, w.L)
+        assert np.abs(FXE - rFXE).max() / max(1.0, np.abs(w.X).max()) < 1e-10
+        if what in (oracle.CON_ADJGRAD, oracle.JAC_ADJGRAD, oracle.JAC_ADJGRAD_HESS):
+            assert rel_err(AGX, rAGX) < 1e-8
+        if what >= oracle.JAC:
+            assert rel_err(vals, rvals) < 1e-8
