@@ -40,11 +40,10 @@ def dims(xv, uv, pv, cs, blocked):
     SCRATCH = K * NP * IRP + IRP * (K * NP + 1) + OR * IRP + 3 * IRP
     DENSE = SLOT + SCRATCH
     STG_LD = (n * N + NH) | 1
-    budget = 40 * 1024
-    staged = (16 * STG_LD <= DENSE or 16 * STG_LD * 8 <= budget)
-    LC = 64 if (not staged or 64 * STG_LD <= DENSE or 64 * STG_LD * 8 <= budget) else (
-        32 if (32 * STG_LD <= DENSE or 32 * STG_LD * 8 <= budget) else 16)
-    BODY = max(LC * STG_LD, DENSE) if staged else DENSE
+    budget = 64 * 1024
+    staged = 16 * STG_LD * 8 <= budget
+    LC = 64 if (not staged or 64 * STG_LD * 8 <= budget) else (32 if 32 * STG_LD * 8 <= budget else 16)
+    BODY = max(LC * STG_LD if staged else 0, DENSE)
 
     def lds_bytes(G=0):
         return (70 + BODY) * 8

@@ -50,7 +50,7 @@ int level_of(int what) {
 struct asset_hip_defect {
   const asset_hip::KernelEntry* ke = nullptr;
   int nseg = 0, n_primal = 0, n_equal = 0, device = 0;
-  int grid = 0;
+  int cus = 256;
   int* d_vindex = nullptr;
   int* d_cindex = nullptr;
   // staging for the host-pointer entry point (allocated lazily)
@@ -162,14 +162,7 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, d->device);
   const int cus = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  const int per_cu = int((160 * 1024) / (ke->lds_bytes ? ke->lds_bytes : 1));
-  const int resident = cus * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
-  // persistent single-wave workgroups; each takes a contiguous, balanced share of the segments
-  h->grid = d->nseg < resident ? d->nseg : resident;
-  if (const char* g = std::getenv("ASSET_HIP_GRID")) {   // tuning experiments only
-    const int gv = std::atoi(g);
-    if (gv > 0) h->grid = gv < d->nseg ? gv : d->nseg;
-  }
+  h->cus = cus;
   auto bail = [&](hipError_t err, const char* w) {
     int rc = hipfail(err, w);
     asset_hip_defect_destroy(h);
@@ -182,7 +175,7 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
   if ((e = hipMemcpy(h->d_cindex, d->cindex, nc * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess)
     return bail(e, "hipMemcpy(cindex)");
   if (ke->work_doubles) {
-    if ((e = hipMalloc(&h->d_work, size_t(h->grid) * ke->work_doubles * sizeof(double))) != hipSuccess)
+    if ((e = hipMalloc(&h->d_work, size_t(h->nseg) * ke->work_doubles * sizeof(double))) != hipSuccess)
       return bail(e, "hipMalloc(workspace)");
   }
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
@@ -230,7 +223,7 @@ static int launch(asset_hip_defect_t h, int what, const double* dX, const double
   a.AGX = (what == ASSET_HIP_CON || what == ASSET_HIP_JAC) ? nullptr : dagx;
   a.KKT = (what >= ASSET_HIP_JAC) ? dkkt : nullptr;
   a.work = h->d_work;
-  hipError_t e = h->ke->launch(level, a, h->grid, st);
+  hipError_t e = h->ke->launch(level, a, h->cus, st);
   if (e != hipSuccess) return hipfail(e, "kernel launch");
   return 0;
 }

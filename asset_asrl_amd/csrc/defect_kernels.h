@@ -32,8 +32,8 @@
 
 #include "lgl_tables.h"
 
-#ifndef ASSET_WAVES_PER_SIMD
-#define ASSET_WAVES_PER_SIMD 1
+#ifndef ASSET_DENSE_WAVES_PER_SIMD
+#define ASSET_DENSE_WAVES_PER_SIMD 2  // register budget of the dense-phase kernel: 512 / 2 = 256 per lane
 #endif
 
 namespace asset_hip {
@@ -106,17 +106,16 @@ struct Dims {
   static constexpr int DENSE = SLOT + SCRATCH;         // slot buffer + dense scratch (staging aliases both)
   // lanes per ODE pass: as many as fit in the LDS the dense phase needs anyway (occupancy is LDS-bound)
 #ifndef ASSET_LC_BUDGET
-#define ASSET_LC_BUDGET (40 * 1024)
+#define ASSET_LC_BUDGET (64 * 1024)
 #endif
   // very wide ODEs: no LDS row fits -> the evaluating lanes write J/H straight to the workspace (uncoalesced, correct)
-  static constexpr bool STAGED = (16 * STG_LD <= DENSE || 16 * STG_LD * 8 <= ASSET_LC_BUDGET);
+  static constexpr bool STAGED = (16 * STG_LD * 8 <= ASSET_LC_BUDGET);
   static constexpr int LC = !STAGED ? 64
-                            : (64 * STG_LD <= DENSE || 64 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 64
-                            : ((32 * STG_LD <= DENSE || 32 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 32 : 16);
-  static constexpr int s_TAB0 = 0;                     // weight tables live in front of the aliased region
-  static constexpr int BODY = (STAGED && LC * STG_LD > DENSE) ? LC * STG_LD : DENSE;
-  static constexpr int lds_doubles() { return TABSZ + BODY; }
-  static constexpr size_t lds_bytes() { return size_t(lds_doubles()) * 8; }
+                            : (64 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 64 : ((32 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 32 : 16);
+  // LDS of the two launches: [weight tables | staging rows] and [weight tables | slot buffer | dense scratch]
+  static constexpr size_t lds_bytes_ode() { return size_t(TABSZ + (STAGED ? LC * STG_LD : 0)) * 8; }
+  static constexpr size_t lds_bytes_dense() { return size_t(TABSZ + DENSE) * 8; }
+  static constexpr size_t lds_bytes() { return lds_bytes_ode() > lds_bytes_dense() ? lds_bytes_ode() : lds_bytes_dense(); }
 };
 
 using d4 = __attribute__((ext_vector_type(4))) double;
@@ -176,8 +175,12 @@ __device__ constexpr bool tiles_share_node(int ct, int rt) {
   return !(jr1 < jc0 || jc1 < jr0);
 }
 
-// One wave per workgroup: the barrier only orders this wave's own LDS traffic.
-__device__ inline void wave_lds_sync() { __syncthreads(); }
+// One wave per workgroup.  LDS instructions of a wave execute in issue order, so LDS hand-offs between lanes only
+// need the compiler kept from reordering (and the reads returned); crucially this does NOT wait for outstanding
+// global stores the way __syncthreads() (vmcnt(0)) does -- the block stores of a segment drain behind the next one.
+__device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Hand-offs through the global workspace (same wave writes, then reads): wait for the stores as well.
+__device__ inline void wave_mem_sync() { __syncthreads(); }
 
 // ---------------------------------------------------------------------------------------------- ODE phases
 // Kept out of line: each is a long straight-line generated body, and separating their register allocation from
@@ -251,8 +254,11 @@ __device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, doubl
 
 // ---------------------------------------------------------------------------------------------- kernel
 // LEVEL 0: value only (constraints).  LEVEL 1: value + Jacobian (+ J^T lam).  LEVEL 2: + adjoint Hessian.
-template <class Ode, int CS, bool BLOCKED, int G, int LEVEL>
-__global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
+// STAGE 1: ODE phases only (P0-P3; results -> workspace slot of every segment).  STAGE 2: dense phase only (P4).
+// They are separate launches because their resource shapes differ: the ODE bodies need ~250 VGPRs and wide LDS
+// staging rows, the dense phase needs few registers and 23 KiB of LDS, so it runs at a higher occupancy.
+template <class Ode, int CS, bool BLOCKED, int G, int LEVEL, int STAGE>
+__global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) void lgl_defect_kernel(EvalArgs a) {
   using D = Dims<Ode, CS, BLOCKED>;
   constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0;
   constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, ORP = D::ORP, NP = D::NP, KS = D::KS;
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(Ev
   const int per = a.nseg / int(gridDim.x), rem = a.nseg % int(gridDim.x);
   const int wg_first = int(blockIdx.x) * per + min(int(blockIdx.x), rem);
   const int wg_count = per + (int(blockIdx.x) < rem ? 1 : 0);
-  double* Wg = a.work + size_t(blockIdx.x) * G * D::SLOT;   // ODE result slots of the current group (HBM / L2)
+  (void)G;
 
 #if defined(ASSET_TIMING)
   long long tstamp[24];
@@ -291,7 +297,9 @@ __global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(Ev
     const int seg0 = wg_first + g0;
     TS();
     const int gcount = min(G, wg_count - g0);
+    double* Wg = a.work + size_t(seg0) * D::SLOT;   // ODE result slots of this group's segments (HBM / L2)
 
+    if constexpr (STAGE == 1) {
     // ------------------------------------------------------------------ P0: gather z = X[Vindex], lam = L[Cindex]
     for (int e = lane; e < gcount * IR; e += 64) {
       const int g = e / IR, r = e - g * IR;
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(Ev
         Wg[g * D::SLOT + D::o_lam + r] = a.L ? a.L[a.cindex[size_t(seg0 + g) * OR + r]] : 0.0;
       }
     }
-    wave_lds_sync();
+    wave_mem_sync();
 
     TS();
     // ------------------------------------------------------------------ P1: cardinal ODE values (and J for LEVEL 1)
@@ -314,17 +322,17 @@ __global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(Ev
         cardinal_eval1<Ode, D, LEVEL>(Wg + g * D::SLOT, j, stage + lane * STG_LD);
       }
       if constexpr (LEVEL == 1 && D::STAGED) {
-        wave_lds_sync();
+        wave_mem_sync();
         const int npt = min(LC, gcount * CS - e0);
         for (int idx = lane; idx < npt * (n * N); idx += 64) {
           const int row = idx / (n * N), k = idx - row * (n * N);
           const int ee = e0 + row, g = ee / CS, j = ee - g * CS;
           Wg[g * D::SLOT + D::o_CJ + j * n * N + k] = stage[row * STG_LD + k];
         }
-        wave_lds_sync();
+        wave_mem_sync();
       }
     }
-    wave_lds_sync();
+    wave_mem_sync();
 
     TS();
     // ------------------------------------------------------------------ P2: interior points
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(Ev
         interior_eval<Ode, D, LEVEL>(Wg + g * D::SLOT, i, &tab, stage + lane * STG_LD);
       }
       if constexpr (LEVEL >= 1 && D::STAGED) {
-        wave_lds_sync();
+        wave_mem_sync();
         const int npt = min(LC, gcount * K - e0);
         constexpr int NC = (LEVEL >= 2) ? NSTG : n * N;   // LEVEL 1 has no Hessian part
         for (int idx = lane; idx < npt * NC; idx += 64) {
@@ -344,10 +352,10 @@ __global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(Ev
           double* dstp = Wg + g * D::SLOT + ((k < n * N) ? (D::o_IJ + i * n * N + k) : (D::o_IH + i * D::NH + (k - n * N)));
           *dstp = stage[row * STG_LD + k];
         }
-        wave_lds_sync();
+        wave_mem_sync();
       }
     }
-    wave_lds_sync();
+    wave_mem_sync();
 
     TS();
     // ------------------------------------------------------------------ P3: cardinal second derivatives
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(Ev
           const int g = e / CS, j = e - g * CS;
           cardinal_eval2<Ode, D>(Wg + g * D::SLOT, j, &tab, stage + lane * STG_LD);
         }
-        wave_lds_sync();
+        wave_mem_sync();
         const int npt = D::STAGED ? min(LC, gcount * CS - e0) : 0;
         for (int idx = lane; idx < npt * NSTG; idx += 64) {
           const int row = idx / NSTG, k = idx - row * NSTG;
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(Ev
           double* dstp = Wg + g * D::SLOT + ((k < n * N) ? (D::o_CJ + j * n * N + k) : (D::o_CH + j * D::NH + (k - n * N)));
           *dstp = stage[row * STG_LD + k];
         }
-        wave_lds_sync();
+        wave_mem_sync();
       }
     }
 
@@ -386,9 +394,10 @@ __global__ __launch_bounds__(64, ASSET_WAVES_PER_SIMD) void lgl_defect_kernel(Ev
           a.FX[size_t(seg0 + g) * OR + jr] = fxv;
         }
       }
-      wave_lds_sync();
-      continue;
+      wave_mem_sync();
     }
+    }  // STAGE == 1
+    if constexpr (STAGE == 1 || LEVEL == 0) continue;
 
     TS();
     // (the first slot's loads are issued below, right after this initialisation, and overlap nothing -- one per group)

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "defect_kernels.h"
@@ -17,9 +18,9 @@ struct KernelEntry {
   int ir, orr, nkkt;
   int seg_per_group;      // segments whose ODE results one workgroup keeps in its workspace at a time
   size_t lds_bytes;
-  size_t work_doubles;    // workspace doubles per workgroup
+  size_t work_doubles;    // workspace doubles per segment (ODE result slot)
   // level 0/1/2 ; returns hipError_t
-  hipError_t (*launch)(int level, const EvalArgs& a, int grid, hipStream_t st);
+  hipError_t (*launch)(int level, const EvalArgs& a, int cus, hipStream_t st);
   KernelEntry* next;
 };
 
@@ -36,32 +37,46 @@ struct Registrar {
 };
 
 template <class Ode, int CS, bool BLOCKED, int G>
-hipError_t launch_lgl(int level, const EvalArgs& a, int grid, hipStream_t st) {
+hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   using D = Dims<Ode, CS, BLOCKED>;
-  constexpr size_t bytes = D::lds_bytes();
-  static_assert(bytes <= 160 * 1024, "per-workgroup LDS exceeds the 160 KiB of a gfx950 CU");
-#define ASSET_LAUNCH(LV)                                                                                          \
+  constexpr size_t bytes_ode = D::lds_bytes_ode(), bytes_dense = D::lds_bytes_dense();
+  static_assert(bytes_ode <= 160 * 1024 && bytes_dense <= 160 * 1024, "per-workgroup LDS exceeds the 160 KiB of a gfx950 CU");
+  // ODE launch: one group of G segments (= 64 evaluation points of the widest phase) per workgroup where possible
+  const int groups = (a.nseg + G - 1) / G;
+  const int per_cu_a = int((160 * 1024) / bytes_ode) < 1 ? 1 : (int((160 * 1024) / bytes_ode) > 8 ? 8 : int((160 * 1024) / bytes_ode));
+  const int grid_a = groups < cus * per_cu_a ? groups : cus * per_cu_a;
+  // dense launch: persistent single-wave workgroups, as many as the LDS lets be resident
+  // (an even number of waves per CU spreads evenly over the 4 SIMDs; 7 per CU measured 30% slower than 6)
+  int per_cu_b = int((160 * 1024) / bytes_dense);
+  per_cu_b = per_cu_b < 1 ? 1 : (per_cu_b >= 8 ? 8 : (per_cu_b >= 6 ? 6 : (per_cu_b >= 4 ? 4 : per_cu_b)));
+  int grid_b = a.nseg < cus * per_cu_b ? a.nseg : cus * per_cu_b;
+  static const int env_b = std::getenv("ASSET_HIP_GRID_B") ? std::atoi(std::getenv("ASSET_HIP_GRID_B")) : 0;  // tuning only
+  if (env_b > 0) grid_b = env_b < a.nseg ? env_b : a.nseg;
+#define ASSET_LAUNCH(LV, STG, GRID, BYTES)                                                                        \
   do {                                                                                                            \
-    auto kern = lgl_defect_kernel<Ode, CS, BLOCKED, G, LV>;                                                       \
-    if (bytes > 64 * 1024) {                                                                                      \
+    auto kern = lgl_defect_kernel<Ode, CS, BLOCKED, G, LV, STG>;                                                  \
+    if (BYTES > 64 * 1024) {                                                                                      \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(BYTES));                 \
       if (e != hipSuccess) return e;                                                                              \
     }                                                                                                             \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), bytes, st, a);                                                 \
-    return hipGetLastError();                                                                                     \
+    hipLaunchKernelGGL(kern, dim3(GRID), dim3(64), BYTES, st, a);                                                 \
+    hipError_t e2 = hipGetLastError();                                                                            \
+    if (e2 != hipSuccess) return e2;                                                                              \
   } while (0)
   switch (level) {
-    case 0: ASSET_LAUNCH(0);
-    case 1: ASSET_LAUNCH(1);
-    case 2: ASSET_LAUNCH(2);
+    case 0: ASSET_LAUNCH(0, 1, grid_a, bytes_ode); return hipSuccess;
+    case 1: ASSET_LAUNCH(1, 1, grid_a, bytes_ode); ASSET_LAUNCH(1, 2, grid_b, bytes_dense); return hipSuccess;
+    case 2: ASSET_LAUNCH(2, 1, grid_a, bytes_ode); ASSET_LAUNCH(2, 2, grid_b, bytes_dense); return hipSuccess;
   }
 #undef ASSET_LAUNCH
   return hipErrorInvalidValue;
 }
 
 template <class Ode, bool BLOCKED, int G>
-hipError_t launch_trap(int level, const EvalArgs& a, int grid, hipStream_t st) {
+hipError_t launch_trap(int level, const EvalArgs& a, int cus, hipStream_t st) {
+  const int ngroups = (a.nseg + G - 1) / G;
+  const int grid = ngroups < cus * 8 ? ngroups : cus * 8;
   using D = TrapDims<Ode, BLOCKED>;
   constexpr size_t bytes = D::template lds_bytes<G>();
   static_assert(bytes <= 64 * 1024, "trapezoidal group does not fit the default dynamic LDS window");
@@ -89,7 +104,7 @@ hipError_t launch_trap(int level, const EvalArgs& a, int grid, hipStream_t st) {
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::IR, ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::OR,                   \
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::NKKT, G,                                                           \
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::lds_bytes(),                                                       \
-      size_t(G) * ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::SLOT,                                                  \
+      size_t(::asset_hip::Dims<ODE, CSV, (BLK != 0)>::SLOT),                                                      \
       &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr};                                                \
   static ::asset_hip::Registrar reg_##ODE##_##CSV##_##BLK(&entry_##ODE##_##CSV##_##BLK);
 
