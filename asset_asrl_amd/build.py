@@ -24,7 +24,7 @@ LDS_BUDGET = 160 * 1024
 LDS_TARGET = 40 * 1024          # keep >= 4 single-wave workgroups per CU when the sizes allow it
 
 
-def dims(xv, uv, pv, cs, blocked):
+def dims(xv, uv, pv, cs, blocked, nsave=0):
     """Mirror of ``Dims<>`` in csrc/defect_kernels.h (sizes + LDS plan)."""
     n = xv
     m, p = (0, uv + pv) if blocked else (uv, pv)
@@ -36,7 +36,7 @@ def dims(xv, uv, pv, cs, blocked):
     NH = N * (N + 1) // 2
     IRP, ORP = (IR + 15) // 16 * 16, (OR + 15) // 16 * 16
     NP = (N + 3) // 4 * 4
-    SLOT = IR + OR + cs * n + cs * n * N + cs * N + cs * NH + K * n + K * n * N + K * N + K * NH
+    SLOT = IR + OR + cs * n + cs * n * N + cs * N + cs * NH + K * n + K * n * N + K * N + K * NH + cs * nsave
     SCRATCH = K * NP * IRP + IRP * (K * NP + 1) + OR * IRP + 3 * IRP
     DENSE = SLOT + SCRATCH
     STG_LD = (n * N + NH) | 1
@@ -50,8 +50,8 @@ def dims(xv, uv, pv, cs, blocked):
     return dict(n=n, m=m, p=p, q=q, N=N, IR=IR, OR=OR, NKKT=NKKT, SLOT=SLOT, LC=LC, lds_bytes=lds_bytes)
 
 
-def pick_group(xv, uv, pv, cs, blocked):
-    d = dims(xv, uv, pv, cs, blocked)
+def pick_group(xv, uv, pv, cs, blocked, nsave=0):
+    d = dims(xv, uv, pv, cs, blocked, nsave)
     return 64 // cs if d["lds_bytes"]() <= LDS_BUDGET else 0
 
 
@@ -76,7 +76,7 @@ def _struct_name(name: str) -> str:
 def generate(verbose=True):
     """Write csrc/gen/ode_<name>.h and csrc/gen/tu_<name>.hip for every library ODE."""
     from .ode import ODE_LIBRARY
-    from .vf.codegen import emit_hip_functor
+    from .vf.codegen import emit_hip_functor, saved_nodes
     os.makedirs(GEN, exist_ok=True)
     tus = []
     for name, cls in ODE_LIBRARY.items():
@@ -89,7 +89,7 @@ def generate(verbose=True):
         units = []
         for cs in (2, 3, 4):
             for blocked in ((0, 1) if uv > 0 else (0,)):
-                G = pick_group(xv, uv, pv, cs, bool(blocked))
+                G = pick_group(xv, uv, pv, cs, bool(blocked), len(saved_nodes(ode.derivatives())))
                 if G == 0:
                     continue  # working set exceeds one CU's LDS -- not instantiated (asset_hip_has_kernel says so)
                 units.append((f"lgl{cs}_{blocked}", f"ASSET_REGISTER_LGL({sn}, {cs}, {blocked}, {G})"))

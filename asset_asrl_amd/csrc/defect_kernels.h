@@ -88,7 +88,8 @@ struct Dims {
   static constexpr int o_IJ = o_If + K * n;
   static constexpr int o_Ig = o_IJ + K * n * N;
   static constexpr int o_IH = o_Ig + K * N;
-  static constexpr int SLOT = o_IH + K * NH;
+  static constexpr int o_SV = o_IH + K * NH;            // transcendental values of f at the cardinal nodes (P1 -> P3)
+  static constexpr int SLOT = o_SV + CS * Ode::NSAVE;
   // ---- dense scratch (one segment at a time)
   static constexpr int s_DI = 0;                       // DI tiles   [K][NP][IRP]   (rows >= n are per-kernel constants)
   static constexpr int s_M = s_DI + K * NP * IRP;      // M^T        [IRP][K*NP+1]
@@ -122,12 +123,14 @@ using d4 = __attribute__((ext_vector_type(4))) double;
 
 // ---------------------------------------------------------------------------------------------- ODE accessors
 template <class D>
-struct CardIn {  // y = [z_j (q), P (p)] read from the LDS copy of z; lam = adjoint weights in registers
+struct CardIn {  // y = [z_j (q), P (p)] read from the slot's copy of z; lam = adjoint weights in registers
   const double* z;
   const double* w;
   int j;
+  const double* sv = nullptr;  // saved transcendental values of f at this node (fjgh_load)
   __device__ double y(int i) const { return i < D::q ? z[j * D::q + i] : z[D::P0 + (i - D::q)]; }
   __device__ double lam(int k) const { return w[k]; }
+  __device__ double saved(int k) const { return sv[k]; }
 };
 template <class D>
 struct RegIn {
@@ -154,10 +157,12 @@ struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H -> this lan
   double* g_;
   double* J_;
   double* H_;
+  double* sv_ = nullptr;
   __device__ void f(int k, double v) { f_[k] = v; }
   __device__ void J(int k, int i, double v) { J_[k * D::N + i] = v; }
   __device__ void g(int i, double v) { g_[i] = v; }
   __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
+  __device__ void save(int k, double v) { sv_[k] = v; }
 };
 
 __device__ inline double hsym(const double* Hp, int a, int b) {
@@ -238,17 +243,19 @@ __device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const
     }
     w[k] = acc;
   }
-  CardIn<D> in{z, w, j};
+  CardIn<D> in{z, w, j, S + D::o_SV + j * Ode::NSAVE};
   OdeOutStaged<D> out{S + D::o_Cf + j * n, S + D::o_Cg + j * N,
                       D::STAGED ? row : S + D::o_CJ + j * n * N, D::STAGED ? row + n * N : S + D::o_CH + j * D::NH};
-  Ode::fjgh(in, out);
+  Ode::fjgh_load(in, out);   // the transcendental sub-expressions of f at this node were stored by P1
 }
 
 template <class Ode, class D, int LEVEL>
 __device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, double* row) {
   CardIn<D> in{S + D::o_z, nullptr, j};
-  OdeOutStaged<D> out{S + D::o_Cf + j * D::n, nullptr, D::STAGED ? row : S + D::o_CJ + j * D::n * D::N, nullptr};
+  OdeOutStaged<D> out{S + D::o_Cf + j * D::n, nullptr, D::STAGED ? row : S + D::o_CJ + j * D::n * D::N, nullptr,
+                      S + D::o_SV + j * Ode::NSAVE};
   if constexpr (LEVEL == 1) Ode::fj(in, out);
+  else if constexpr (LEVEL == 2) Ode::f_save(in, out);
   else Ode::f(in, out);
 }
 

@@ -41,10 +41,11 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   using D = Dims<Ode, CS, BLOCKED>;
   constexpr size_t bytes_ode = D::lds_bytes_ode(), bytes_dense = D::lds_bytes_dense();
   static_assert(bytes_ode <= 160 * 1024 && bytes_dense <= 160 * 1024, "per-workgroup LDS exceeds the 160 KiB of a gfx950 CU");
-  // ODE launch: one group of G segments (= 64 evaluation points of the widest phase) per workgroup where possible
-  const int groups = (a.nseg + G - 1) / G;
-  const int per_cu_a = int((160 * 1024) / bytes_ode) < 1 ? 1 : (int((160 * 1024) / bytes_ode) > 8 ? 8 : int((160 * 1024) / bytes_ode));
-  const int grid_a = groups < cus * per_cu_a ? groups : cus * per_cu_a;
+  // ODE launch: the three ODE phases are latency chains, so spread the segments over every resident wave (fewest
+  // passes per wave); a workgroup walks its share in groups of at most G segments (= 64 points of the widest phase)
+  int per_cu_a = int((160 * 1024) / bytes_ode);
+  per_cu_a = per_cu_a < 1 ? 1 : (per_cu_a >= 8 ? 8 : (per_cu_a >= 4 ? 4 : per_cu_a));
+  const int grid_a = a.nseg < cus * per_cu_a ? a.nseg : cus * per_cu_a;
   // dense launch: persistent single-wave workgroups, as many as the LDS lets be resident
   // (an even number of waves per CU spreads evenly over the 4 SIMDs; 7 per CU measured 30% slower than 6)
   int per_cu_b = int((160 * 1024) / bytes_dense);

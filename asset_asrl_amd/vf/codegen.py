@@ -88,24 +88,106 @@ def _cnum(v: float) -> str:
     return f"({s})" if v < 0 else s
 
 
-class _Printer:
-    """Schedules reachable interior nodes into temporaries t0,t1,..."""
+TRANSCENDENTAL = ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "asin", "acos", "atan",
+                  "atan2", "powr")
 
-    def __init__(self, roots: Sequence[Node], yname="y{}", lname="l{}"):
+
+def lower_reciprocals(roots: Sequence[Node]) -> List[Node]:
+    """a/d -> a*(1/d) for every denominator d that divides at least twice: one division instead of many.
+
+    Costs at most one extra rounding per quotient (the reference is built with -ffast-math, which licenses the
+    same rewrite); both printers apply it, so the CPU baseline and the device evaluate the same expression."""
+    order = topo_order(roots)
+    uses: Dict[int, int] = {}
+    for n in order:
+        if n.op == "div" and not n.args[1].is_const():
+            uses[n.args[1].id] = uses.get(n.args[1].id, 0) + 1
+    memo: Dict[int, Node] = {}
+    rcp: Dict[int, Node] = {}
+    for n in order:
+        if not n.args:
+            memo[n.id] = n
+            continue
+        args = [memo[a.id] for a in n.args]
+        if n.op == "div" and uses.get(n.args[1].id, 0) >= 2:
+            d = args[1]
+            r = rcp.get(d.id)
+            if r is None:
+                r = rcp[d.id] = G._mk("div", (G.one, d))
+            memo[n.id] = G.mul(args[0], r)
+        else:
+            memo[n.id] = G.rebuild(n, args)
+    return [memo[r.id] for r in roots]
+
+
+def _topo_stop(roots: Sequence[Node], stop) -> List[Node]:
+    """topo order of what is reachable from roots without descending below the nodes in `stop`."""
+    if not stop:
+        return topo_order(roots)
+    seen, out = set(), []
+    for r in roots:
+        stack = [(r, 0)]
+        while stack:
+            n, i = stack.pop()
+            if i == 0:
+                if n.id in seen:
+                    continue
+                seen.add(n.id)
+            kids = () if n.id in stop else n.args
+            if i < len(kids):
+                stack.append((n, i + 1))
+                if kids[i].id not in seen:
+                    stack.append((kids[i], 0))
+            else:
+                out.append(n)
+    return out
+
+
+class _Printer:
+    """Schedules reachable interior nodes into temporaries t0,t1,...
+
+    ``loaded``: {node id: expression} -- nodes whose value is supplied (not recomputed; nothing below them is scheduled
+    unless needed elsewhere).  ``pair_sincos``: emit one ``sincos`` for a sin/cos pair on the same argument (device)."""
+
+    def __init__(self, roots: Sequence[Node], yname="y{}", lname="l{}", loaded=None, pair_sincos=False):
         self.names: Dict[int, str] = {}
         self.lines: List[str] = []
         self.used_y = set()
         self.used_l = set()
         self.yname, self.lname = yname, lname
-        for n in topo_order(roots):
+        loaded = loaded or {}
+        order = _topo_stop(roots, set(loaded))
+        partner: Dict[int, Node] = {}
+        if pair_sincos:
+            by_arg: Dict[int, Dict[str, Node]] = {}
+            for n in order:
+                if n.op in ("sin", "cos") and n.id not in loaded:
+                    by_arg.setdefault(n.args[0].id, {})[n.op] = n
+            for pr in by_arg.values():
+                if len(pr) == 2:
+                    partner[pr["sin"].id] = pr["cos"]
+                    partner[pr["cos"].id] = pr["sin"]
+        for n in order:
             if n.op == "var":
                 self.used_y.add(n.value)
             elif n.op == "lam":
                 self.used_l.add(n.value)
-            if n.args:
-                nm = f"t{len(self.lines)}"
-                self.lines.append(f"const double {nm} = {self._expr(n)};")
-                self.names[n.id] = nm
+            if n.id in loaded:
+                self.names[n.id] = loaded[n.id]
+                continue
+            if not n.args or n.id in self.names:
+                continue
+            if n.id in partner:
+                other = partner[n.id]
+                k = len(self.lines)
+                sn, cn = f"t{k}s", f"t{k}c"
+                self.lines.append(f"double {sn}, {cn}; sincos({self.ref(n.args[0])}, &{sn}, &{cn});")
+                self.names[n.id] = sn if n.op == "sin" else cn
+                self.names[other.id] = cn if n.op == "sin" else sn
+                continue
+            nm = f"t{len(self.lines)}"
+            self.lines.append(f"const double {nm} = {self._expr(n)};")
+            self.names[n.id] = nm
 
     def ref(self, n: Node) -> str:
         if n.op == "const":
@@ -189,8 +271,12 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
         ("fj", "template <class In, class Out> __host__ __device__ static inline void fj(const In& in, Out& out)"),
         ("fjgh", "template <class In, class Out> __host__ __device__ static inline void fjgh(const In& in, Out& out)"),
     ]
+    saved = saved_nodes(d)
+    o.insert(-1, f"  static constexpr int NSAVE = {len(saved)};   // transcendental values f_save() hands to fjgh_load()")
     for level, (_, sig) in enumerate(sigs):
-        p = _Printer(_level_roots(d, level))
+        low = lower_reciprocals(_level_roots(d, level))
+        p = _Printer(low, pair_sincos=True)
+        it = iter(low)
         o.append(f"  {sig} {{")
         for i in sorted(p.used_y):
             o.append(f"    const double y{i} = in.y({i});")
@@ -198,20 +284,64 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
             o.append(f"    const double l{k} = in.lam({k});")
         o += ["    " + ln for ln in p.lines]
         for k in range(n):
-            o.append(f"    out.f({k}, {p.ref(d.f[k])});")
+            o.append(f"    out.f({k}, {p.ref(next(it))});")
         if level >= 1:
             for k in range(n):
                 for i in range(N):
-                    o.append(f"    out.J({k}, {i}, {p.ref(d.J[k][i])});")
+                    o.append(f"    out.J({k}, {i}, {p.ref(next(it))});")
         if level >= 2:
             for i in range(N):
-                o.append(f"    out.g({i}, {p.ref(d.g[i])});")
+                o.append(f"    out.g({i}, {p.ref(next(it))});")
             for i in range(N):
                 for j in range(i + 1):
-                    o.append(f"    out.H({i}, {j}, {p.ref(d.H[i][j])});")
+                    o.append(f"    out.H({i}, {j}, {p.ref(next(it))});")
         o.append("  }")
+    # ---- f_save / fjgh_load: the value pass stores every transcendental sub-expression of f; the second-derivative
+    #      pass at the SAME point (cardinal nodes: LGLDefects.h:336 then :383-384) loads them instead of recomputing
+    sv_ids = {nd.id: k for k, nd in enumerate(saved)}
+    roots0 = _level_roots(d, 0) + saved
+    p = _Printer(lower_reciprocals(roots0), pair_sincos=True)
+    low0 = lower_reciprocals(roots0)
+    o.append("  template <class In, class Out> __host__ __device__ static inline void f_save(const In& in, Out& out) {")
+    for i in sorted(p.used_y):
+        o.append(f"    const double y{i} = in.y({i});")
+    o += ["    " + ln for ln in p.lines]
+    for k in range(n):
+        o.append(f"    out.f({k}, {p.ref(low0[k])});")
+    for k in range(len(saved)):
+        o.append(f"    out.save({k}, {p.ref(low0[n + k])});")
+    o.append("  }")
+    roots2 = _level_roots(d, 2)
+    low2 = lower_reciprocals(roots2 + saved)          # lowering rebuilds nodes: locate the saved ones afterwards
+    loaded = {low2[len(roots2) + k].id: f"s{k}" for k in range(len(saved))}
+    p = _Printer(low2[:len(roots2)], loaded=loaded, pair_sincos=True)
+    o.append("  template <class In, class Out> __host__ __device__ static inline void fjgh_load(const In& in, Out& out) {")
+    for i in sorted(p.used_y):
+        o.append(f"    const double y{i} = in.y({i});")
+    for k in sorted(p.used_l):
+        o.append(f"    const double l{k} = in.lam({k});")
+    for k in range(len(saved)):
+        o.append(f"    const double s{k} = in.saved({k});")
+    o += ["    " + ln for ln in p.lines]
+    it = iter(low2[:len(roots2)])
+    for k in range(n):
+        o.append(f"    out.f({k}, {p.ref(next(it))});")
+    for k in range(n):
+        for i in range(N):
+            o.append(f"    out.J({k}, {i}, {p.ref(next(it))});")
+    for i in range(N):
+        o.append(f"    out.g({i}, {p.ref(next(it))});")
+    for i in range(N):
+        for j in range(i + 1):
+            o.append(f"    out.H({i}, {j}, {p.ref(next(it))});")
+    o.append("  }")
     o.append("};")
     return "\n".join(o) + "\n"
+
+
+def saved_nodes(d: OdeDerivatives) -> List[Node]:
+    """Transcendental sub-expressions of the value function f (in schedule order)."""
+    return [nd for nd in topo_order(d.f) if nd.op in TRANSCENDENTAL]
 
 
 def emit_c(d: OdeDerivatives, prefix: str) -> str:
@@ -225,21 +355,23 @@ def emit_c(d: OdeDerivatives, prefix: str) -> str:
         f"void {prefix}_fjgh(const double* y, const double* lam, double* f, double* J, double* g, double* H)",
     ]
     for level, sig in enumerate(sigs):
-        p = _Printer(_level_roots(d, level), yname="y[{}]", lname="lam[{}]")
+        low = lower_reciprocals(_level_roots(d, level))
+        p = _Printer(low, yname="y[{}]", lname="lam[{}]")
+        it = iter(low)
         o.append(sig + " {")
         o += ["  " + ln for ln in p.lines]
         for k in range(n):
-            o.append(f"  f[{k}] = {p.ref(d.f[k])};")
+            o.append(f"  f[{k}] = {p.ref(next(it))};")
         if level >= 1:
             for k in range(n):
                 for i in range(N):
-                    o.append(f"  J[{k * N + i}] = {p.ref(d.J[k][i])};")
+                    o.append(f"  J[{k * N + i}] = {p.ref(next(it))};")
         if level >= 2:
             for i in range(N):
-                o.append(f"  g[{i}] = {p.ref(d.g[i])};")
+                o.append(f"  g[{i}] = {p.ref(next(it))};")
             for i in range(N):
                 for j in range(i + 1):
-                    r = p.ref(d.H[i][j])
+                    r = p.ref(next(it))
                     o.append(f"  H[{i * N + j}] = {r};")
                     if i != j:
                         o.append(f"  H[{j * N + i}] = {r};")
