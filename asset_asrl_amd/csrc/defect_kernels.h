@@ -293,6 +293,96 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
   const int wg_count = per + (int(blockIdx.x) < rem ? 1 : 0);
   (void)G;
 
+  // ---- per-lane constants of the dense phase, computed once per launch: every index decode, table lookup and
+  //      store offset below depends only on the lane, never on the segment
+  constexpr int CW = D::CW, RPW = 64 / CW, ROWS = K * n;
+  constexpr bool BOTH = (RPW == 1);                        // one lane builds the DI and the DC entry of its column
+  constexpr int CMAIN = (P0 < CW) ? P0 : CW;               // block columns handled by the structured pass
+  const int d1c = lane & (CW - 1), d1h = lane / CW;        // column; role 0 -> DI row, 1 -> DC row (when RPW >= 2)
+  const bool d1ok = (d1c < CMAIN) && (BOTH || d1h < 2);
+  const int d1j = d1ok ? d1c / q : 0, d1cc = d1ok ? d1c - d1j * q : 0;
+  double wa[K], wb[K], wa2[BOTH ? K : 1], wb2[BOTH ? K : 1];
+  int bo[D::MT][KS];                                       // B fragment of [hE H^ | E g^]: >=0 packed-H index, -1 zero, <=-2 g^ row
+  int cho[LEVEL >= 2 ? D::NTH : 1][4];                     // cardinal Hessian entry feeding accumulator (tile, v)
+  int jo[D::TJ][K][KS];                                    // (hE J^)^T fragment: slot offset or -1
+  int hst[LEVEL >= 2 ? D::NTH : 1][4], jst[D::TI * D::TJ][4];   // KKT slot of accumulator entry (tile, v) or -1
+  double tB[CS], tD[CS], tC[CS], tE = 0.0;                 // weights of the row (i,r) this lane owns in the time-column pass
+  if constexpr (STAGE == 2 && LEVEL >= 1) {
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      const bool dcrole = (!BOTH && d1h == 1);
+      wa[i] = dcrole ? tab.C[i][d1j] : tab.A[i][d1j];
+      wb[i] = dcrole ? tab.D[i][d1j] : tab.B[i][d1j];
+      if constexpr (BOTH) { wa2[i] = tab.C[i][d1j]; wb2[i] = tab.D[i][d1j]; }
+    }
+    {
+      const int e = (lane < ROWS) ? lane : 0, i = e / n;
+#pragma unroll
+      for (int jj = 0; jj < CS; jj++) { tB[jj] = tab.B[i][jj]; tD[jj] = tab.D[i][jj]; tC[jj] = tab.C[i][jj]; }
+      tE = tab.E[i];
+    }
+#pragma unroll
+    for (int mt = 0; mt < D::MT; mt++)
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) {
+        const int b = 4 * kk + lk, acol = 16 * mt + lr;
+        int v = -1;
+        if (b < N) {
+          if (acol < N) v = (b >= acol) ? b * (b + 1) / 2 + acol : acol * (acol + 1) / 2 + b;
+          else if (acol == N) v = -2 - b;
+        }
+        bo[mt][kk] = v;
+      }
+#pragma unroll
+    for (int jt = 0; jt < D::TJ; jt++) {
+      const int jr = 16 * jt + lr;
+      const int ji = (jr < OR) ? jr / n : K, jk = (jr < OR) ? jr - ji * n : 0;
+#pragma unroll
+      for (int i = 0; i < K; i++)
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+          const int aa = 4 * kk + lk;
+          jo[jt][i][kk] = (ji == i && aa < N) ? D::o_IJ + (i * n + jk) * N + aa : -1;
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < D::TI; ct++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int c = 16 * ct + lk + 4 * v;
+        const int cst = c * (IR + OR) - c * (c - 1) / 2;   // first slot of block column c
+#pragma unroll
+        for (int jt = 0; jt < D::TJ; jt++) {
+          const int jr = 16 * jt + lr;
+          jst[ct * D::TJ + jt][v] = (c < IR && jr < OR) ? cst + (IR - c) + jr : -1;
+        }
+        if constexpr (LEVEL >= 2) {
+#pragma unroll
+          for (int rt = ct; rt < D::TI; rt++) {
+            const int r = 16 * rt + lr, tix = rt * (rt + 1) / 2 + ct;
+            const bool ok = (c < IR && r < IR && r >= c);
+            hst[tix][v] = ok ? cst + (r - c) : -1;
+            int ch = -1;
+            if (ok) {
+              if (c < P0) {
+                const int jn = c / q, cc = c - jn * q;
+                if (r < P0) {
+                  if (r / q == jn) { const int rr = r - jn * q; ch = D::o_CH + jn * D::NH + rr * (rr + 1) / 2 + cc; }
+                } else {
+                  const int rr = q + (r - P0);
+                  ch = D::o_CH + jn * D::NH + rr * (rr + 1) / 2 + cc;
+                }
+              } else {
+                const int rr = q + (r - P0), c2 = q + (c - P0);
+                ch = -2 - (rr * (rr + 1) / 2 + c2);        // parameter-parameter: summed over the cardinal nodes
+              }
+            }
+            cho[tix][v] = ch;
+          }
+        }
+      }
+  }
+
 #if defined(ASSET_TIMING)
   long long tstamp[24];
   int nts = 0;
@@ -443,7 +533,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
 #pragma unroll
         for (int t = 0; t < NPRE; t++) pre[t] = (lane + 64 * t < D::SLOT) ? Wg[(g + 1) * D::SLOT + lane + 64 * t] : 0.0;
       }
-      if (g == 0) TS();
       const double* S = slotb;
       const double* z = S + D::o_z;
       const double* lam = S + D::o_lam;
@@ -458,75 +547,67 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
       double* R2 = scr + D::s_R2;
       double* HI = scr + D::s_HI;
 
-      if (g == 0) TS();
-      // ---- D1: one pass over (interior i, state row r, block column c) builds, from a single read of dfdy_j:
+      // ---- D1: one pass over (interior i, state row r) builds, from a single read of dfdy_j per block column c:
       //        DI_i[r][c]  = A_ij [cc==r] + h B_ij J_j[r][cc]        (LGLDefects.h:430-444)
       //        DC[(i,r)][c] = C_ij [cc==r] + h D_ij J_j[r][cc]        (LGLDefects.h:467-482)  -- cardinal part of J
-      {
-        constexpr int RPW = 64 / D::CW;                 // rows written per wave pass
-        const int c = lane & (D::CW - 1), rsub = lane / D::CW;
-        const bool cok = c < IR;
-        const int j = (c < P0) ? c / q : 0, cc = (c < P0) ? c - j * q : 0;
-        constexpr int ROWS = K * n;
+      //      lanes [0,CW) write the DI row, lanes [CW,2CW) the DC row of the same (i,r); row indices are compile-time
+      if (d1ok) {
+        double wbh[K], wb2h[BOTH ? K : 1];
 #pragma unroll
-        for (int t = 0; t < (ROWS + RPW - 1) / RPW; t++) {
-          const int row = t * RPW + rsub;               // (i, r), r < n
-          if (row < ROWS && cok) {
-            const int i = row / n, r = row - i * n;
-            double vi, vc;
-            if (c < P0) {
-              const double jv = S[D::o_CJ + (j * n + r) * N + cc];
-              vi = (tab.B[i][j] * h) * jv;
-              vc = (tab.D[i][j] * h) * jv;
-              if (cc == r) { vi += tab.A[i][j]; vc += tab.C[i][j]; }
-            } else {
-              vi = 0.0, vc = 0.0;
-#pragma unroll
-              for (int jj = 0; jj < CS; jj++) {
-                const double jv = S[D::o_CJ + (jj * n + r) * N + q + (c - P0)];
-                vi += (tab.B[i][jj] * h) * jv;
-                vc += (tab.D[i][jj] * h) * jv;
-              }
-            }
-            DI[(i * NP + r) * IRP + c] = vi;
-            DC[row * IRP + c] = vc;
-          }
+        for (int i = 0; i < K; i++) {
+          wbh[i] = wb[i] * h;
+          if constexpr (BOTH) wb2h[i] = wb2[i] * h;
         }
-        if constexpr (IRP > 64) {                       // wider than one pass: remaining columns
-          for (int e = lane; e < ROWS * (IRP - 64); e += 64) {
-            const int row = e / (IRP - 64), c2 = 64 + e - row * (IRP - 64);
-            if (c2 < IR) {
-              const int i = row / n, r = row - i * n;
-              double vi = 0.0, vc = 0.0;
-              if (c2 < P0) {
-                const int j2 = c2 / q, cc2 = c2 - j2 * q;
-                const double jv = S[D::o_CJ + (j2 * n + r) * N + cc2];
-                vi = (tab.B[i][j2] * h) * jv;
-                vc = (tab.D[i][j2] * h) * jv;
-                if (cc2 == r) { vi += tab.A[i][j2]; vc += tab.C[i][j2]; }
-              } else {
-                for (int jj = 0; jj < CS; jj++) {
-                  const double jv = S[D::o_CJ + (jj * n + r) * N + q + (c2 - P0)];
-                  vi += (tab.B[i][jj] * h) * jv;
-                  vc += (tab.D[i][jj] * h) * jv;
-                }
-              }
-              DI[(i * NP + r) * IRP + c2] = vi;
-              DC[row * IRP + c2] = vc;
-            }
+        const double* cj = S + D::o_CJ + d1j * n * N + d1cc;
+        const bool dcrole = (!BOTH && d1h == 1);
+        double* dstb = (dcrole ? DC : DI) + d1c;
+#pragma unroll
+        for (int row = 0; row < ROWS; row++) {
+          const int i = row / n, r = row - i * n;
+          const double jv = cj[r * N];
+          double v = wbh[i] * jv;
+          if (d1cc == r) v += wa[i];
+          dstb[dcrole ? row * IRP : (i * NP + r) * IRP] = v;
+          if constexpr (BOTH) {
+            double v2 = wb2h[i] * jv;
+            if (d1cc == r) v2 += wa2[i];
+            DC[row * IRP + d1c] = v2;
           }
         }
       }
+      if constexpr (CMAIN < IR) {                        // parameter columns and columns beyond one wave pass
+        for (int e = lane; e < ROWS * (IR - CMAIN); e += 64) {
+          const int row = e / (IR - CMAIN), c2 = CMAIN + e - row * (IR - CMAIN);
+          const int i = row / n, r = row - i * n;
+          double vi = 0.0, vc = 0.0;
+          if (c2 < P0) {
+            const int j2 = c2 / q, cc2 = c2 - j2 * q;
+            const double jv = S[D::o_CJ + (j2 * n + r) * N + cc2];
+            vi = (tab.B[i][j2] * h) * jv;
+            vc = (tab.D[i][j2] * h) * jv;
+            if (cc2 == r) { vi += tab.A[i][j2]; vc += tab.C[i][j2]; }
+          } else {
+            for (int jj = 0; jj < CS; jj++) {
+              const double jv = S[D::o_CJ + (jj * n + r) * N + q + (c2 - P0)];
+              vi += (tab.B[i][jj] * h) * jv;
+              vc += (tab.D[i][jj] * h) * jv;
+            }
+          }
+          DI[(i * NP + r) * IRP + c2] = vi;
+          DC[row * IRP + c2] = vc;
+        }
+      }
       wave_lds_sync();
-      if (g == 0) TS();
       // time columns: DI rows -+ sum_j B_ij f_j (LGLDefects.h:446-450), DC rows -+ (sum_j D_ij f_j + E_i f^_i) (:484-500)
-      for (int e = lane; e < K * n; e += 64) {
+      for (int e = lane; e < ROWS; e += 64) {
         const int i = e / n, r = e - i * n;
-        double sb = 0.0, sd = tab.E[i] * S[D::o_If + i * n + r];
+        const bool own = (e == lane);                    // first pass: weights are the precomputed per-lane ones
+        double sb = 0.0, sd = (own ? tE : tab.E[i]) * S[D::o_If + i * n + r];
 #pragma unroll
         for (int jj = 0; jj < CS; jj++) {
-          sb += tab.B[i][jj] * S[D::o_Cf + jj * n + r];
-          sd += tab.D[i][jj] * S[D::o_Cf + jj * n + r];
+          const double fv = S[D::o_Cf + jj * n + r];
+          sb += (own ? tB[jj] : tab.B[i][jj]) * fv;
+          sd += (own ? tD[jj] : tab.D[i][jj]) * fv;
         }
         DI[(i * NP + r) * IRP + T] -= sb;
         DI[(i * NP + r) * IRP + TF] += sb;
@@ -535,13 +616,12 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         if (a.FX) {                                      // defect value of row (i,r)  (LGLDefects.h:96-103)
           double fxv = h * sd;
 #pragma unroll
-          for (int jj = 0; jj < CS; jj++) fxv += tab.C[i][jj] * z[jj * q + r];
+          for (int jj = 0; jj < CS; jj++) fxv += (own ? tC[jj] : tab.C[i][jj]) * z[jj * q + r];
           a.FX[seg * OR + e] = fxv;
         }
       }
       wave_lds_sync();
 
-      if (g == 0) TS();
       // ---- D2: A fragments (DI_i^T tiles) for every tile row, reused by all three products
       double av[D::TI][K][KS];
 #pragma unroll
@@ -568,13 +648,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
             double bv[KS];
 #pragma unroll
             for (int kk = 0; kk < KS; kk++) {
-              const int b = 4 * kk + lk;
-              double v = 0.0;
-              if (b < N) {
-                if (acol < N) v = hsym(Hp, b, acol) * he;
-                else if (acol == N) v = S[D::o_Ig + i * N + b] * tab.E[i];
-              }
-              bv[kk] = v;
+              const int o = bo[mt][kk];
+              bv[kk] = (o >= 0) ? Hp[o] * he : ((o <= -2) ? S[D::o_Ig + i * N + (-2 - o)] * tab.E[i] : 0.0);
             }
 #pragma unroll
             for (int ct = 0; ct < D::TI; ct++) {
@@ -619,7 +694,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         wave_lds_sync();
       }
 
-      if (g == 0) TS();
       // ---- D4: H (lower-triangle tiles) and J^T
       d4 accH[LEVEL >= 2 ? D::NTH : 1];
       d4 accJ[D::TI * D::TJ];
@@ -646,20 +720,13 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
             if (tiles_share_node<D>(ct, rt)) {
 #pragma unroll
               for (int v = 0; v < 4; v++) {
-                const int c = 16 * ct + lk + 4 * v, r = 16 * rt + lr;
+                const int o = cho[rt * (rt + 1) / 2 + ct][v];
                 double val = 0.0;
-                if (c < IR && r < IR && r >= c) {
-                  if (c < P0) {
-                    const int jn = c / q, cc = c - jn * q;
-                    if (r < P0) {
-                      if (r / q == jn) val = hsym(S + D::o_CH + jn * D::NH, r - jn * q, cc);
-                    } else {
-                      val = hsym(S + D::o_CH + jn * D::NH, q + (r - P0), cc);
-                    }
-                  } else {
+                if (o >= 0) {
+                  val = S[o];
+                } else if (p > 0 && o <= -2) {
 #pragma unroll
-                    for (int j = 0; j < CS; j++) val += hsym(S + D::o_CH + j * D::NH, q + (r - P0), q + (c - P0));
-                  }
+                  for (int j = 0; j < CS; j++) val += S[D::o_CH + j * D::NH + (-2 - o)];
                 }
                 acc[v] = val;
               }
@@ -673,18 +740,15 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
           }
         }
       }
-      if (g == 0) TS();
 #pragma unroll
       for (int jt = 0; jt < D::TJ; jt++) {
-        const int jr = 16 * jt + lr;
-        const int ji = (jr < OR) ? jr / n : K, jk = (jr < OR) ? jr - ji * n : 0;
-        double bj[K][KS];
+        double bj[K][KS];                                // (hE_i J^_i)^T[aa][jr], non-zero only on interior i's rows
 #pragma unroll
         for (int i = 0; i < K; i++)
 #pragma unroll
           for (int kk = 0; kk < KS; kk++) {
-            const int aa = 4 * kk + lk;                  // (hE_i J^_i)^T[aa][jr], non-zero only on interior i's rows
-            bj[i][kk] = (ji == i && aa < N) ? (h * tab.E[i]) * S[D::o_IJ + (i * n + jk) * N + aa] : 0.0;
+            const int o = jo[jt][i][kk];
+            bj[i][kk] = (o >= 0) ? (h * tab.E[i]) * S[o] : 0.0;
           }
 #pragma unroll
         for (int ct = 0; ct < D::TI; ct++) {
@@ -705,7 +769,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         }
       }
 
-      if (g == 0) TS();
       // ---- D5: adjoint gradient  g = J^T lam  without touching the J tile:
       //      interior part  h * sum_i E_i g^_i^T DI_i  (= h * HI), cardinal part = DC^T lam
       if (a.AGX) {
@@ -727,7 +790,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         }
       }
 
-      if (g == 0) TS();
       // ---- D6: store.  Entry (v) of a tile held by this lane: block column c = 16*ct + lk + 4v,
       //      row (H) r = 16*rt + lr or (J) jr = 16*jt + lr; 16 consecutive lanes cover 128 contiguous bytes.
       if (a.KKT) {
@@ -736,24 +798,32 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         for (int ct = 0; ct < D::TI; ct++) {
 #pragma unroll
           for (int v = 0; v < 4; v++) {
-            const int c = 16 * ct + lk + 4 * v;
-            const int cst = c * (IR + OR) - c * (c - 1) / 2;   // first slot of block column c
-            if (c < IR) {
+            if constexpr (LEVEL >= 2) {
 #pragma unroll
               for (int rt = ct; rt < D::TI; rt++) {
-                const int r = 16 * rt + lr;
-                if (r >= c && r < IR) dst[cst + (r - c)] = (LEVEL >= 2) ? accH[rt * (rt + 1) / 2 + ct][v] : 0.0;
+                const int tix = rt * (rt + 1) / 2 + ct;
+                const int o = hst[tix][v];
+                if (o >= 0) dst[o] = accH[tix][v];
               }
+            }
 #pragma unroll
-              for (int jt = 0; jt < D::TJ; jt++) {
-                const int jr = 16 * jt + lr;
-                if (jr < OR) dst[cst + (IR - c) + jr] = accJ[ct * D::TJ + jt][v];
-              }
+            for (int jt = 0; jt < D::TJ; jt++) {
+              const int o = jst[ct * D::TJ + jt][v];
+              if (o >= 0) dst[o] = accJ[ct * D::TJ + jt][v];
             }
           }
         }
+        if constexpr (LEVEL < 2) {                       // Jacobian-only kinds: the Hessian slots are written as zero
+          for (int k = lane; k < D::NKKT; k += 64) {
+            int lo = 0, hi = IR - 1;
+            while (lo < hi) {
+              const int mid = (lo + hi + 1) >> 1;
+              if (mid * (IR + OR) - mid * (mid - 1) / 2 <= k) lo = mid; else hi = mid - 1;
+            }
+            if (k - (lo * (IR + OR) - lo * (lo - 1) / 2) < IR - lo) dst[k] = 0.0;
+          }
+        }
       }
-      if (g == 0) TS();
       wave_lds_sync();  // the next segment rewrites the DI / M / DC tiles
     }
     TS();
