@@ -249,9 +249,19 @@ __device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const
   Ode::fjgh_load(in, out);   // the transcendental sub-expressions of f at this node were stored by P1
 }
 
+template <class D>
+struct GatherIn {  // y = X[Vindex(node j, component i)]: the first ODE phase reads the solver vector directly
+  const double* X;
+  const int* vi;   // this segment's Vindex column
+  int j;
+  __device__ double y(int i) const { return X[i < D::q ? vi[j * D::q + i] : vi[D::P0 + (i - D::q)]]; }
+  __device__ double lam(int) const { return 0.0; }
+  __device__ double saved(int) const { return 0.0; }
+};
+
 template <class Ode, class D, int LEVEL>
-__device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, double* row) {
-  CardIn<D> in{S + D::o_z, nullptr, j};
+__device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, double* row, const double* X, const int* vi) {
+  GatherIn<D> in{X, vi, j};
   OdeOutStaged<D> out{S + D::o_Cf + j * D::n, nullptr, D::STAGED ? row : S + D::o_CJ + j * D::n * D::N, nullptr,
                       S + D::o_SV + j * Ode::NSAVE};
   if constexpr (LEVEL == 1) Ode::fj(in, out);
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         Wg[g * D::SLOT + D::o_lam + r] = a.L ? a.L[a.cindex[size_t(seg0 + g) * OR + r]] : 0.0;
       }
     }
-    wave_mem_sync();
+    // (no wait here: P1 reads X itself; the barrier after P1 also covers these stores before P2 reads the slots)
 
     TS();
     // ------------------------------------------------------------------ P1: cardinal ODE values (and J for LEVEL 1)
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
       const int e = e0 + lane;
       if (lane < LC && e < gcount * CS) {
         const int g = e / CS, j = e - g * CS;
-        cardinal_eval1<Ode, D, LEVEL>(Wg + g * D::SLOT, j, stage + lane * STG_LD);
+        cardinal_eval1<Ode, D, LEVEL>(Wg + g * D::SLOT, j, stage + lane * STG_LD, a.X, a.vindex + size_t(seg0 + g) * IR);
       }
       if constexpr (LEVEL == 1 && D::STAGED) {
         wave_mem_sync();

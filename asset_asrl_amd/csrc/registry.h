@@ -53,6 +53,7 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   int grid_b = a.nseg < cus * per_cu_b ? a.nseg : cus * per_cu_b;
   static const int env_b = std::getenv("ASSET_HIP_GRID_B") ? std::atoi(std::getenv("ASSET_HIP_GRID_B")) : 0;  // tuning only
   if (env_b > 0) grid_b = env_b < a.nseg ? env_b : a.nseg;
+  static const bool skip_dense = std::getenv("ASSET_HIP_SKIP_DENSE") != nullptr;                               // tuning only
 #define ASSET_LAUNCH(LV, STG, GRID, BYTES)                                                                        \
   do {                                                                                                            \
     auto kern = lgl_defect_kernel<Ode, CS, BLOCKED, G, LV, STG>;                                                  \
@@ -67,8 +68,8 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   } while (0)
   switch (level) {
     case 0: ASSET_LAUNCH(0, 1, grid_a, bytes_ode); return hipSuccess;
-    case 1: ASSET_LAUNCH(1, 1, grid_a, bytes_ode); ASSET_LAUNCH(1, 2, grid_b, bytes_dense); return hipSuccess;
-    case 2: ASSET_LAUNCH(2, 1, grid_a, bytes_ode); ASSET_LAUNCH(2, 2, grid_b, bytes_dense); return hipSuccess;
+    case 1: ASSET_LAUNCH(1, 1, grid_a, bytes_ode); if (!skip_dense) ASSET_LAUNCH(1, 2, grid_b, bytes_dense); return hipSuccess;
+    case 2: ASSET_LAUNCH(2, 1, grid_a, bytes_ode); if (!skip_dense) ASSET_LAUNCH(2, 2, grid_b, bytes_dense); return hipSuccess;
   }
 #undef ASSET_LAUNCH
   return hipErrorInvalidValue;
