@@ -177,7 +177,8 @@ def main():
                        "sharding": f"{world} x {nseg} independent segments, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "lgl_defect_kernel", "kernel_ms": ms_kernel,
+                         "kernel": "lgl_defect_kernel: one evaluation = ODE-stage launch + dense-stage launch (both timed)",
+                         "kernel_ms": ms_kernel,
                          "algorithmic_bytes_per_segment": bseg},
         }
         if world == 1 and not a.no_cpu_baseline:
