@@ -91,9 +91,15 @@ struct Dims {
   static constexpr int o_SV = o_IH + K * NH;            // transcendental values of f at the cardinal nodes (P1 -> P3)
   static constexpr int SLOT = o_SV + CS * Ode::NSAVE;
   // ---- dense scratch (one segment at a time)
-  static constexpr int s_DI = 0;                       // DI tiles   [K][NP][IRP]   (rows >= n are per-kernel constants)
-  static constexpr int s_M = s_DI + K * NP * IRP;      // M^T        [IRP][K*NP+1]
-  static constexpr int s_DC = s_M + IRP * (K * NP + 1);  // cardinal part of J, rows = defect rows  [OR][IRP]
+  // DI_i is kept as two tiles: state rows (r < n), rewritten for every segment, and the remaining rows (tau / control
+  // / parameter / padding), constant per launch.  M^T is produced after every A fragment has been read into
+  // registers, so it re-uses the state-row tile's memory.
+  static constexpr int NCR = NP - n;                   // constant rows per interior
+  static constexpr int s_DIx = 0;                      // [K][n][IRP]
+  static constexpr int s_M = 0;                        // M^T [IRP][K*NP+1]  (aliases s_DIx)
+  static constexpr int XM = (K * n * IRP > IRP * (K * NP + 1)) ? K * n * IRP : IRP * (K * NP + 1);
+  static constexpr int s_DIc = XM;                     // [K][NCR][IRP]
+  static constexpr int s_DC = s_DIc + K * (NP - n) * IRP;  // cardinal part of J, rows = defect rows  [OR][IRP]
   static constexpr int s_R2 = s_DC + OR * IRP;         // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar
   static constexpr int s_HI = s_R2 + 2 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
   static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
@@ -511,20 +517,20 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
     // ---- per-group constants of the dense scratch (the staging rows aliased it): the rows of DI_i that do not
     //      depend on the segment (tau row, control-interpolation rows, parameter identity rows, zero padding;
     //      LGLDefects.h:417-458), the rank-2 direction d = e_TF - e_T, zero padding of M and DC
-    for (int e = lane; e < K * NP * IRP; e += 64) {
-      const int i = e / (NP * IRP), rem2 = e - i * NP * IRP;
-      const int r = rem2 / IRP, c = rem2 - r * IRP;
+    for (int e = lane; e < K * D::NCR * IRP; e += 64) {
+      const int i = e / (D::NCR * IRP), rem2 = e - i * D::NCR * IRP;
+      const int r = n + rem2 / IRP, c = rem2 % IRP;
       double v = 0.0;
       if (c < IR) {
         if (r == T) v = (c == T) ? (1.0 - tab.s[i]) : ((c == TF) ? tab.s[i] : 0.0);
         else if (r > T && r < q) { if (c < P0 && (c % q) == r) v = tab.U[i][c / q]; }
         else if (r >= q && r < N) { if (c == P0 + (r - q)) v = 1.0; }
       }
-      scr[D::s_DI + e] = v;
+      scr[D::s_DIc + e] = v;
     }
+    for (int e = lane; e < K * n * IRP; e += 64) scr[D::s_DIx + e] = 0.0;   // padding columns of the state rows
     for (int e = lane; e < IRP; e += 64) scr[D::s_R2 + e] = (e == TF) ? 1.0 : ((e == T) ? -1.0 : 0.0);
     for (int e = lane; e < OR * IRP; e += 64) scr[D::s_DC + e] = 0.0;
-    for (int e = lane; e < IRP * D::LDM; e += 64) scr[D::s_M + e] = 0.0;
     wave_lds_sync();
 
     TS();
@@ -551,7 +557,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
 
       if constexpr (LEVEL == 0) continue;
 
-      double* DI = scr + D::s_DI;
+      double* DIx = scr + D::s_DIx;
+      const double* DIc = scr + D::s_DIc;
       double* Mt = scr + D::s_M;
       double* DC = scr + D::s_DC;
       double* R2 = scr + D::s_R2;
@@ -570,14 +577,14 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         }
         const double* cj = S + D::o_CJ + d1j * n * N + d1cc;
         const bool dcrole = (!BOTH && d1h == 1);
-        double* dstb = (dcrole ? DC : DI) + d1c;
+        double* dstb = (dcrole ? DC : DIx) + d1c;
 #pragma unroll
         for (int row = 0; row < ROWS; row++) {
           const int i = row / n, r = row - i * n;
           const double jv = cj[r * N];
           double v = wbh[i] * jv;
           if (d1cc == r) v += wa[i];
-          dstb[dcrole ? row * IRP : (i * NP + r) * IRP] = v;
+          dstb[row * IRP] = v;
           if constexpr (BOTH) {
             double v2 = wb2h[i] * jv;
             if (d1cc == r) v2 += wa2[i];
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
               vc += (tab.D[i][jj] * h) * jv;
             }
           }
-          DI[(i * NP + r) * IRP + c2] = vi;
+          DIx[row * IRP + c2] = vi;
           DC[row * IRP + c2] = vc;
         }
       }
@@ -619,8 +626,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
           sb += (own ? tB[jj] : tab.B[i][jj]) * fv;
           sd += (own ? tD[jj] : tab.D[i][jj]) * fv;
         }
-        DI[(i * NP + r) * IRP + T] -= sb;
-        DI[(i * NP + r) * IRP + TF] += sb;
+        DIx[e * IRP + T] -= sb;
+        DIx[e * IRP + TF] += sb;
         DC[e * IRP + T] -= sd;
         DC[e * IRP + TF] += sd;
         if (a.FX) {                                      // defect value of row (i,r)  (LGLDefects.h:96-103)
@@ -639,7 +646,10 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
 #pragma unroll
         for (int i = 0; i < K; i++)
 #pragma unroll
-          for (int kk = 0; kk < KS; kk++) av[ct][i][kk] = DI[(i * NP + 4 * kk + lk) * IRP + 16 * ct + lr];
+          for (int kk = 0; kk < KS; kk++) {
+            const int r = 4 * kk + lk;
+            av[ct][i][kk] = (r < n) ? DIx[(i * n + r) * IRP + 16 * ct + lr] : DIc[(i * D::NCR + (r - n)) * IRP + 16 * ct + lr];
+          }
 
       // ---- D3: M_i^T = DI_i^T [hE_i H^_i | E_i g^_i]; column N of the product is sum_b E_i g^_i[b] DI_i[b,c]
       if constexpr (LEVEL >= 2) {
@@ -667,12 +677,13 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
 #pragma unroll
               for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bv[kk], acc, 0, 0, 0);
               // acc[v] = (M_i^T)[c = 16ct + lk + 4v][acol]
-              if (acol < N) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + i * NP + acol] = acc[v];
-              } else if (acol == N) {
+              if (acol == N) {
 #pragma unroll
                 for (int v = 0; v < 4; v++) hi_acc[ct][v] += acc[v];
+              }
+              if (acol < NP) {                           // columns N..NP-1 are k-padding of the next product: keep them zero
+#pragma unroll
+                for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + i * NP + acol] = (acol < N) ? acc[v] : 0.0;
               }
             }
           }
@@ -790,7 +801,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
             for (int i = 0; i < K; i++)
               for (int k = 0; k < n; k++) {
                 double dj = 0.0;
-                for (int b = 0; b < N; b++) dj += S[D::o_IJ + (i * n + k) * N + b] * DI[(i * NP + b) * IRP + c];
+                for (int b = 0; b < N; b++)
+                  dj += S[D::o_IJ + (i * n + k) * N + b] * ((b < n) ? DIx[(i * n + b) * IRP + c] : DIc[(i * D::NCR + (b - n)) * IRP + c]);
                 v += lam[i * n + k] * ((h * tab.E[i]) * dj);
               }
           }
