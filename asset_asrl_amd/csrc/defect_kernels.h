@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "lgl_tables.h"
 
@@ -157,12 +158,16 @@ struct OdeOut {  // routes every derivative entry to its LDS slot (J row-major n
   __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
 };
 
+// LDS-address-space pointer: stores through it are ds_write (tracked by lgkmcnt only), never flat
+typedef __attribute__((address_space(3))) double lds_double;
+
 template <class D>
 struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H -> this lane's LDS staging row [J row-major | H packed]
+  using JP = std::conditional_t<D::STAGED, lds_double*, double*>;
   double* f_;
   double* g_;
-  double* J_;
-  double* H_;
+  JP J_;
+  JP H_;
   double* sv_ = nullptr;
   __device__ void f(int k, double v) { f_[k] = v; }
   __device__ void J(int k, int i, double v) { J_[k * D::N + i] = v; }
@@ -170,6 +175,11 @@ struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H -> this lan
   __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
   __device__ void save(int k, double v) { sv_[k] = v; }
 };
+
+template <class D>
+__device__ inline auto stage_or(lds_double* row, double* slot) {
+  if constexpr (D::STAGED) { (void)slot; return row; } else { (void)row; return slot; }
+}
 
 __device__ inline double hsym(const double* Hp, int a, int b) {
   return a >= b ? Hp[a * (a + 1) / 2 + b] : Hp[b * (b + 1) / 2 + a];
@@ -197,7 +207,7 @@ __device__ inline void wave_mem_sync() { __syncthreads(); }
 // Kept out of line: each is a long straight-line generated body, and separating their register allocation from
 // the dense phase keeps the latter's accumulators and fragments in registers.
 template <class Ode, class D, int LEVEL>
-__device__ __attribute__((noinline)) void interior_eval(double* S, int i, const LglTab* tabp, double* row) {
+__device__ __attribute__((noinline)) void interior_eval(double* S, int i, const LglTab* tabp, lds_double* row) {
   constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
   const double* z = S + D::o_z;
@@ -224,8 +234,8 @@ __device__ __attribute__((noinline)) void interior_eval(double* S, int i, const 
 #pragma unroll
   for (int k = 0; k < n; k++) li[k] = (LEVEL >= 2) ? S[D::o_lam + i * n + k] : 0.0;
   RegIn<D> in{y, li};
-  OdeOutStaged<D> out{S + D::o_If + i * n, S + D::o_Ig + i * N,
-                      D::STAGED ? row : S + D::o_IJ + i * n * N, D::STAGED ? row + n * N : S + D::o_IH + i * D::NH};
+  OdeOutStaged<D> out{S + D::o_If + i * n, S + D::o_Ig + i * N, stage_or<D>(row, S + D::o_IJ + i * n * N),
+                      stage_or<D>(row + n * N, S + D::o_IH + i * D::NH)};
   (void)K;
   if constexpr (LEVEL == 0) Ode::f(in, out);
   else if constexpr (LEVEL == 1) Ode::fj(in, out);
@@ -233,7 +243,7 @@ __device__ __attribute__((noinline)) void interior_eval(double* S, int i, const 
 }
 
 template <class Ode, class D>
-__device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const LglTab* tabp, double* row) {
+__device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const LglTab* tabp, lds_double* row) {
   constexpr int K = D::K, n = D::n, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
   const double* z = S + D::o_z;
@@ -250,8 +260,8 @@ __device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const
     w[k] = acc;
   }
   CardIn<D> in{z, w, j, S + D::o_SV + j * Ode::NSAVE};
-  OdeOutStaged<D> out{S + D::o_Cf + j * n, S + D::o_Cg + j * N,
-                      D::STAGED ? row : S + D::o_CJ + j * n * N, D::STAGED ? row + n * N : S + D::o_CH + j * D::NH};
+  OdeOutStaged<D> out{S + D::o_Cf + j * n, S + D::o_Cg + j * N, stage_or<D>(row, S + D::o_CJ + j * n * N),
+                      stage_or<D>(row + n * N, S + D::o_CH + j * D::NH)};
   Ode::fjgh_load(in, out);   // the transcendental sub-expressions of f at this node were stored by P1
 }
 
@@ -266,9 +276,9 @@ struct GatherIn {  // y = X[Vindex(node j, component i)]: the first ODE phase re
 };
 
 template <class Ode, class D, int LEVEL>
-__device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, double* row, const double* X, const int* vi) {
+__device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, lds_double* row, const double* X, const int* vi) {
   GatherIn<D> in{X, vi, j};
-  OdeOutStaged<D> out{S + D::o_Cf + j * D::n, nullptr, D::STAGED ? row : S + D::o_CJ + j * D::n * D::N, nullptr,
+  OdeOutStaged<D> out{S + D::o_Cf + j * D::n, nullptr, stage_or<D>(row, S + D::o_CJ + j * D::n * D::N), nullptr,
                       S + D::o_SV + j * Ode::NSAVE};
   if constexpr (LEVEL == 1) Ode::fj(in, out);
   else if constexpr (LEVEL == 2) Ode::f_save(in, out);
@@ -432,17 +442,17 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
       const int e = e0 + lane;
       if (lane < LC && e < gcount * CS) {
         const int g = e / CS, j = e - g * CS;
-        cardinal_eval1<Ode, D, LEVEL>(Wg + g * D::SLOT, j, stage + lane * STG_LD, a.X, a.vindex + size_t(seg0 + g) * IR);
+        cardinal_eval1<Ode, D, LEVEL>(Wg + g * D::SLOT, j, (lds_double*)(stage + lane * STG_LD), a.X, a.vindex + size_t(seg0 + g) * IR);
       }
       if constexpr (LEVEL == 1 && D::STAGED) {
-        wave_mem_sync();
+        wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
         const int npt = min(LC, gcount * CS - e0);
         for (int idx = lane; idx < npt * (n * N); idx += 64) {
           const int row = idx / (n * N), k = idx - row * (n * N);
           const int ee = e0 + row, g = ee / CS, j = ee - g * CS;
           Wg[g * D::SLOT + D::o_CJ + j * n * N + k] = stage[row * STG_LD + k];
         }
-        wave_mem_sync();
+        wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
       }
     }
     wave_mem_sync();
@@ -453,10 +463,10 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
       const int e = e0 + lane;
       if (lane < LC && e < gcount * K) {
         const int g = e / K, i = e - g * K;
-        interior_eval<Ode, D, LEVEL>(Wg + g * D::SLOT, i, &tab, stage + lane * STG_LD);
+        interior_eval<Ode, D, LEVEL>(Wg + g * D::SLOT, i, &tab, (lds_double*)(stage + lane * STG_LD));
       }
       if constexpr (LEVEL >= 1 && D::STAGED) {
-        wave_mem_sync();
+        wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
         const int npt = min(LC, gcount * K - e0);
         constexpr int NC = (LEVEL >= 2) ? NSTG : n * N;   // LEVEL 1 has no Hessian part
         for (int idx = lane; idx < npt * NC; idx += 64) {
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
           double* dstp = Wg + g * D::SLOT + ((k < n * N) ? (D::o_IJ + i * n * N + k) : (D::o_IH + i * D::NH + (k - n * N)));
           *dstp = stage[row * STG_LD + k];
         }
-        wave_mem_sync();
+        wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
       }
     }
     wave_mem_sync();
@@ -477,9 +487,9 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         const int e = e0 + lane;
         if (lane < LC && e < gcount * CS) {
           const int g = e / CS, j = e - g * CS;
-          cardinal_eval2<Ode, D>(Wg + g * D::SLOT, j, &tab, stage + lane * STG_LD);
+          cardinal_eval2<Ode, D>(Wg + g * D::SLOT, j, &tab, (lds_double*)(stage + lane * STG_LD));
         }
-        wave_mem_sync();
+        wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
         const int npt = D::STAGED ? min(LC, gcount * CS - e0) : 0;
         for (int idx = lane; idx < npt * NSTG; idx += 64) {
           const int row = idx / NSTG, k = idx - row * NSTG;
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
           double* dstp = Wg + g * D::SLOT + ((k < n * N) ? (D::o_CJ + j * n * N + k) : (D::o_CH + j * D::NH + (k - n * N)));
           *dstp = stage[row * STG_LD + k];
         }
-        wave_mem_sync();
+        wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
       }
     }
 

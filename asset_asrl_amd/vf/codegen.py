@@ -88,6 +88,8 @@ def _cnum(v: float) -> str:
     return f"({s})" if v < 0 else s
 
 
+LEVEL_ORDER = True   # device functors: breadth-first statement order (see _Printer)
+
 TRANSCENDENTAL = ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "asin", "acos", "atan",
                   "atan2", "powr")
 
@@ -149,7 +151,8 @@ class _Printer:
     ``loaded``: {node id: expression} -- nodes whose value is supplied (not recomputed; nothing below them is scheduled
     unless needed elsewhere).  ``pair_sincos``: emit one ``sincos`` for a sin/cos pair on the same argument (device)."""
 
-    def __init__(self, roots: Sequence[Node], yname="y{}", lname="l{}", loaded=None, pair_sincos=False):
+    def __init__(self, roots: Sequence[Node], yname="y{}", lname="l{}", loaded=None, pair_sincos=False,
+                 level_order=False):
         self.names: Dict[int, str] = {}
         self.lines: List[str] = []
         self.used_y = set()
@@ -157,6 +160,13 @@ class _Printer:
         self.yname, self.lname = yname, lname
         loaded = loaded or {}
         order = _topo_stop(roots, set(loaded))
+        if level_order:
+            # breadth-first schedule: a node is emitted after everything of smaller depth, so neighbouring statements
+            # are independent and a single wave can overlap their latencies (a depth-first order is one long chain)
+            depth: Dict[int, int] = {}
+            for n in order:
+                depth[n.id] = 0 if (not n.args or n.id in loaded) else 1 + max(depth[a.id] for a in n.args)
+            order = sorted(order, key=lambda n: depth[n.id])
         partner: Dict[int, Node] = {}
         if pair_sincos:
             by_arg: Dict[int, Dict[str, Node]] = {}
@@ -275,7 +285,7 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     o.insert(-1, f"  static constexpr int NSAVE = {len(saved)};   // transcendental values f_save() hands to fjgh_load()")
     for level, (_, sig) in enumerate(sigs):
         low = lower_reciprocals(_level_roots(d, level))
-        p = _Printer(low, pair_sincos=True)
+        p = _Printer(low, pair_sincos=True, level_order=LEVEL_ORDER)
         it = iter(low)
         o.append(f"  {sig} {{")
         for i in sorted(p.used_y):
@@ -300,7 +310,7 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     #      pass at the SAME point (cardinal nodes: LGLDefects.h:336 then :383-384) loads them instead of recomputing
     sv_ids = {nd.id: k for k, nd in enumerate(saved)}
     roots0 = _level_roots(d, 0) + saved
-    p = _Printer(lower_reciprocals(roots0), pair_sincos=True)
+    p = _Printer(lower_reciprocals(roots0), pair_sincos=True, level_order=LEVEL_ORDER)
     low0 = lower_reciprocals(roots0)
     o.append("  template <class In, class Out> __host__ __device__ static inline void f_save(const In& in, Out& out) {")
     for i in sorted(p.used_y):
@@ -314,7 +324,7 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     roots2 = _level_roots(d, 2)
     low2 = lower_reciprocals(roots2 + saved)          # lowering rebuilds nodes: locate the saved ones afterwards
     loaded = {low2[len(roots2) + k].id: f"s{k}" for k in range(len(saved))}
-    p = _Printer(low2[:len(roots2)], loaded=loaded, pair_sincos=True)
+    p = _Printer(low2[:len(roots2)], loaded=loaded, pair_sincos=True, level_order=LEVEL_ORDER)
     o.append("  template <class In, class Out> __host__ __device__ static inline void fjgh_load(const In& in, Out& out) {")
     for i in sorted(p.used_y):
         o.append(f"    const double y{i} = in.y({i});")
