@@ -33,6 +33,9 @@
 
 #include "lgl_tables.h"
 
+#ifndef ASSET_ODE_WAVES_PER_SIMD
+#define ASSET_ODE_WAVES_PER_SIMD 1    // register budget of the ODE-stage kernel
+#endif
 #ifndef ASSET_DENSE_WAVES_PER_SIMD
 #define ASSET_DENSE_WAVES_PER_SIMD 2  // register budget of the dense-phase kernel: 512 / 2 = 256 per lane
 #endif
@@ -100,11 +103,12 @@ struct Dims {
   static constexpr int s_M = 0;                        // M^T [IRP][K*NP+1]  (aliases s_DIx)
   static constexpr int XM = (K * n * IRP > IRP * (K * NP + 1)) ? K * n * IRP : IRP * (K * NP + 1);
   static constexpr int s_DIc = XM;                     // [K][NCR][IRP]
-  static constexpr int s_DC = s_DIc + K * (NP - n) * IRP;  // cardinal part of J, rows = defect rows  [OR][IRP]
-  static constexpr int s_R2 = s_DC + OR * IRP;         // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar
+  static constexpr int s_DC = s_DIc + K * (NP - n) * IRP;  // cardinal part of J, rows = defect rows  [ORP][IRP], padding rows zero
+  static constexpr int s_R2 = s_DC + ORP * IRP;        // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar
   static constexpr int s_HI = s_R2 + 2 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
+  static constexpr int s_Z0 = s_HI + IRP;              // a cell that always holds 0.0: target of every "no entry" offset
   static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
-  static constexpr int SCRATCH = s_HI + IRP;
+  static constexpr int SCRATCH = s_Z0 + 2;
   static constexpr int LDM = K * NP + 1;               // M is stored column-major [IRP][LDM]: conflict-free MFMA write-back
 
   // ---- ODE-phase staging: every evaluating lane writes its dense J (n x N) and packed H into an LDS row, the wave
@@ -291,7 +295,7 @@ __device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, lds_d
 // They are separate launches because their resource shapes differ: the ODE bodies need ~250 VGPRs and wide LDS
 // staging rows, the dense phase needs few registers and 23 KiB of LDS, so it runs at a higher occupancy.
 template <class Ode, int CS, bool BLOCKED, int G, int LEVEL, int STAGE>
-__global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) void lgl_defect_kernel(EvalArgs a) {
+__global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET_ODE_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
   using D = Dims<Ode, CS, BLOCKED>;
   constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0;
   constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, ORP = D::ORP, NP = D::NP, KS = D::KS;
@@ -328,9 +332,14 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
   const bool d1ok = (d1c < CMAIN) && (BOTH || d1h < 2);
   const int d1j = d1ok ? d1c / q : 0, d1cc = d1ok ? d1c - d1j * q : 0;
   double wa[K], wb[K], wa2[BOTH ? K : 1], wb2[BOTH ? K : 1];
-  int bo[D::MT][KS];                                       // B fragment of [hE H^ | E g^]: >=0 packed-H index, -1 zero, <=-2 g^ row
+  // Offsets below are relative to the slot base S and always readable: "no entry" points at the zero cell, so the
+  // per-segment loads need no branch (a conditional LDS load costs a full exposed latency each).
+  constexpr int ZERO = D::SLOT + D::s_Z0;
+  int bo[D::MT][KS], bst[D::MT][KS];                       // B fragment of [hE H^ | E g^]: offset for i = 0 and stride in i
   int cho[LEVEL >= 2 ? D::NTH : 1][4];                     // cardinal Hessian entry feeding accumulator (tile, v)
-  int jo[D::TJ][K][KS];                                    // (hE J^)^T fragment: slot offset or -1
+  int chp[(LEVEL >= 2 && p > 0) ? D::NTH : 1][4];          // parameter-parameter entry (summed over the cardinal nodes) or -1
+  int jo[D::TJ][K][KS];                                    // (hE J^)^T fragment
+  int avb[KS], avs[KS];                                    // DI_i^T fragment: offset in the dense scratch for i = 0, stride in i
   int hst[LEVEL >= 2 ? D::NTH : 1][4], jst[D::TI * D::TJ][4];   // KKT slot of accumulator entry (tile, v) or -1
   double tB[CS], tD[CS], tC[CS], tE = 0.0;                 // weights of the row (i,r) this lane owns in the time-column pass
   if constexpr (STAGE == 2 && LEVEL >= 1) {
@@ -352,13 +361,20 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
 #pragma unroll
       for (int kk = 0; kk < KS; kk++) {
         const int b = 4 * kk + lk, acol = 16 * mt + lr;
-        int v = -1;
+        int v = ZERO, st = 0;
         if (b < N) {
-          if (acol < N) v = (b >= acol) ? b * (b + 1) / 2 + acol : acol * (acol + 1) / 2 + b;
-          else if (acol == N) v = -2 - b;
+          if (acol < N) { v = D::o_IH + ((b >= acol) ? b * (b + 1) / 2 + acol : acol * (acol + 1) / 2 + b); st = D::NH; }
+          else if (acol == N) { v = D::o_Ig + b; st = N; }   // stride N marks a g^ row (scaled by E_i, not h E_i)
         }
         bo[mt][kk] = v;
+        bst[mt][kk] = st;
       }
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+      const int r = 4 * kk + lk;
+      avb[kk] = ((r < n) ? D::s_DIx + r * IRP : D::s_DIc + (r - n) * IRP) + lr;
+      avs[kk] = ((r < n) ? n : D::NCR) * IRP;
+    }
 #pragma unroll
     for (int jt = 0; jt < D::TJ; jt++) {
       const int jr = 16 * jt + lr;
@@ -368,7 +384,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) {
           const int aa = 4 * kk + lk;
-          jo[jt][i][kk] = (ji == i && aa < N) ? D::o_IJ + (i * n + jk) * N + aa : -1;
+          jo[jt][i][kk] = (ji == i && aa < N) ? D::o_IJ + (i * n + jk) * N + aa : ZERO;
         }
     }
 #pragma unroll
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
             const int r = 16 * rt + lr, tix = rt * (rt + 1) / 2 + ct;
             const bool ok = (c < IR && r < IR && r >= c);
             hst[tix][v] = ok ? cst + (r - c) : -1;
-            int ch = -1;
+            int ch = ZERO, cp = -1;
             if (ok) {
               if (c < P0) {
                 const int jn = c / q, cc = c - jn * q;
@@ -400,10 +416,11 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
                 }
               } else {
                 const int rr = q + (r - P0), c2 = q + (c - P0);
-                ch = -2 - (rr * (rr + 1) / 2 + c2);        // parameter-parameter: summed over the cardinal nodes
+                cp = rr * (rr + 1) / 2 + c2;               // parameter-parameter: summed over the cardinal nodes
               }
             }
             cho[tix][v] = ch;
+            if constexpr (p > 0) chp[tix][v] = cp;
           }
         }
       }
@@ -424,14 +441,31 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
 
     if constexpr (STAGE == 1) {
     // ------------------------------------------------------------------ P0: gather z = X[Vindex], lam = L[Cindex]
-    for (int e = lane; e < gcount * IR; e += 64) {
-      const int g = e / IR, r = e - g * IR;
-      Wg[g * D::SLOT + D::o_z + r] = a.X[a.vindex[size_t(seg0 + g) * IR + r]];
-    }
-    if constexpr (LEVEL >= 1) {
-      for (int e = lane; e < gcount * OR; e += 64) {
-        const int g = e / OR, r = e - g * OR;
-        Wg[g * D::SLOT + D::o_lam + r] = a.L ? a.L[a.cindex[size_t(seg0 + g) * OR + r]] : 0.0;
+    // Two dependent HBM round trips (index, then value): every index load is issued before the first value load,
+    // so the whole gather costs two latencies instead of two per 64 elements.
+    {
+      constexpr int NZ = (G * IR + 63) / 64, NL = (LEVEL >= 1) ? (G * OR + 63) / 64 : 0;
+      const int* vseg = a.vindex + size_t(seg0) * IR;      // this group's Vindex / Cindex columns are contiguous
+      const int* cseg = a.cindex + size_t(seg0) * OR;
+      int vi[NZ], ci[NL > 0 ? NL : 1];
+#pragma unroll
+      for (int t = 0; t < NZ; t++) vi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : -1;
+#pragma unroll
+      for (int t = 0; t < NL; t++) ci[t] = (a.L && lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : -1;
+      double zv[NZ], lv[NL > 0 ? NL : 1];
+#pragma unroll
+      for (int t = 0; t < NZ; t++) zv[t] = (vi[t] >= 0) ? a.X[vi[t]] : 0.0;
+#pragma unroll
+      for (int t = 0; t < NL; t++) lv[t] = (ci[t] >= 0) ? a.L[ci[t]] : 0.0;
+#pragma unroll
+      for (int t = 0; t < NZ; t++) {
+        const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
+        if (e < gcount * IR) Wg[g * D::SLOT + D::o_z + r] = zv[t];
+      }
+#pragma unroll
+      for (int t = 0; t < NL; t++) {
+        const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
+        if (e < gcount * OR) Wg[g * D::SLOT + D::o_lam + r] = lv[t];
       }
     }
     // (no wait here: P1 reads X itself; the barrier after P1 also covers these stores before P2 reads the slots)
@@ -540,7 +574,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
     }
     for (int e = lane; e < K * n * IRP; e += 64) scr[D::s_DIx + e] = 0.0;   // padding columns of the state rows
     for (int e = lane; e < IRP; e += 64) scr[D::s_R2 + e] = (e == TF) ? 1.0 : ((e == T) ? -1.0 : 0.0);
-    for (int e = lane; e < OR * IRP; e += 64) scr[D::s_DC + e] = 0.0;
+    for (int e = lane; e < ORP * IRP; e += 64) scr[D::s_DC + e] = 0.0;
+    if (lane < 2) scr[D::s_Z0 + lane] = 0.0;
     wave_lds_sync();
 
     TS();
@@ -548,16 +583,17 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
     constexpr int NPRE = (D::SLOT + 63) / 64;
     double pre[NPRE];                      // next segment's slot, in flight while the current one is processed
 #pragma unroll
-    for (int t = 0; t < NPRE; t++) pre[t] = (lane + 64 * t < D::SLOT) ? Wg[lane + 64 * t] : 0.0;
+    for (int t = 0; t < NPRE; t++) pre[t] = (t + 1 < NPRE || lane + 64 * t < D::SLOT) ? Wg[lane + 64 * t] : 0.0;
     for (int g = 0; g < gcount; g++) {
       // slot: workspace -> LDS (coalesced); the loads were issued one segment ago
 #pragma unroll
       for (int t = 0; t < NPRE; t++)
-        if (lane + 64 * t < D::SLOT) slotb[lane + 64 * t] = pre[t];
+        if (t + 1 < NPRE || lane + 64 * t < D::SLOT) slotb[lane + 64 * t] = pre[t];   // only the last row is partial
       wave_lds_sync();
       if (g + 1 < gcount) {
 #pragma unroll
-        for (int t = 0; t < NPRE; t++) pre[t] = (lane + 64 * t < D::SLOT) ? Wg[(g + 1) * D::SLOT + lane + 64 * t] : 0.0;
+        for (int t = 0; t < NPRE; t++)
+          pre[t] = (t + 1 < NPRE || lane + 64 * t < D::SLOT) ? Wg[(g + 1) * D::SLOT + lane + 64 * t] : 0.0;
       }
       const double* S = slotb;
       const double* z = S + D::o_z;
@@ -626,9 +662,9 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
       }
       wave_lds_sync();
       // time columns: DI rows -+ sum_j B_ij f_j (LGLDefects.h:446-450), DC rows -+ (sum_j D_ij f_j + E_i f^_i) (:484-500)
-      for (int e = lane; e < ROWS; e += 64) {
+      auto time_columns = [&](int e, auto own_) {
+        constexpr bool own = decltype(own_)::value;      // first pass: the weights are the precomputed per-lane ones
         const int i = e / n, r = e - i * n;
-        const bool own = (e == lane);                    // first pass: weights are the precomputed per-lane ones
         double sb = 0.0, sd = (own ? tE : tab.E[i]) * S[D::o_If + i * n + r];
 #pragma unroll
         for (int jj = 0; jj < CS; jj++) {
@@ -646,6 +682,10 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
           for (int jj = 0; jj < CS; jj++) fxv += (own ? tC[jj] : tab.C[i][jj]) * z[jj * q + r];
           a.FX[seg * OR + e] = fxv;
         }
+      };
+      if (lane < ROWS) time_columns(lane, std::true_type{});
+      if constexpr (ROWS > 64) {
+        for (int e = lane + 64; e < ROWS; e += 64) time_columns(e, std::false_type{});
       }
       wave_lds_sync();
 
@@ -656,10 +696,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
 #pragma unroll
         for (int i = 0; i < K; i++)
 #pragma unroll
-          for (int kk = 0; kk < KS; kk++) {
-            const int r = 4 * kk + lk;
-            av[ct][i][kk] = (r < n) ? DIx[(i * n + r) * IRP + 16 * ct + lr] : DIc[(i * D::NCR + (r - n)) * IRP + 16 * ct + lr];
-          }
+          for (int kk = 0; kk < KS; kk++)
+            av[ct][i][kk] = scr[avb[kk] + i * avs[kk] + 16 * ct];
 
       // ---- D3: M_i^T = DI_i^T [hE_i H^_i | E_i g^_i]; column N of the product is sum_b E_i g^_i[b] DI_i[b,c]
       if constexpr (LEVEL >= 2) {
@@ -671,15 +709,13 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
 #pragma unroll
         for (int i = 0; i < K; i++) {
           const double he = h * tab.E[i];
-          const double* Hp = S + D::o_IH + i * D::NH;
 #pragma unroll
           for (int mt = 0; mt < D::MT; mt++) {
             const int acol = 16 * mt + lr;               // column of [hE H^ | E g^]
             double bv[KS];
 #pragma unroll
             for (int kk = 0; kk < KS; kk++) {
-              const int o = bo[mt][kk];
-              bv[kk] = (o >= 0) ? Hp[o] * he : ((o <= -2) ? S[D::o_Ig + i * N + (-2 - o)] * tab.E[i] : 0.0);
+              bv[kk] = S[bo[mt][kk] + i * bst[mt][kk]] * ((bst[mt][kk] == N) ? tab.E[i] : he);
             }
 #pragma unroll
             for (int ct = 0; ct < D::TI; ct++) {
@@ -709,13 +745,10 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         //   H += d HT^T + HT d^T  with d = e_TF - e_T   (the four updates of LGLDefects.h:508-511)
         const double ih = 1.0 / h;
         for (int c = lane; c < IRP; c += 64) {
-          double v = 0.0;
-          if (c < IR) {
-            v = HI[c];
-            if (c < P0) {
-              const int j = c / q, cc = c - j * q;
-              v += S[D::o_Cg + j * N + cc] * ih;
-            } else {
+          const int jn = c / q;
+          double v = HI[c] + S[(c < P0) ? D::o_Cg + jn * N + (c - jn * q) : ZERO] * ih;   // HI is zero on padding columns
+          if constexpr (p > 0) {
+            if (c >= P0 && c < IR) {
 #pragma unroll
               for (int j = 0; j < CS; j++) v += S[D::o_Cg + j * N + q + (c - P0)] * ih;
             }
@@ -751,13 +784,13 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
             if (tiles_share_node<D>(ct, rt)) {
 #pragma unroll
               for (int v = 0; v < 4; v++) {
-                const int o = cho[rt * (rt + 1) / 2 + ct][v];
-                double val = 0.0;
-                if (o >= 0) {
-                  val = S[o];
-                } else if (p > 0 && o <= -2) {
+                double val = S[cho[rt * (rt + 1) / 2 + ct][v]];
+                if constexpr (p > 0) {
+                  const int o = chp[rt * (rt + 1) / 2 + ct][v];
+                  if (o >= 0) {
 #pragma unroll
-                  for (int j = 0; j < CS; j++) val += S[D::o_CH + j * D::NH + (-2 - o)];
+                    for (int j = 0; j < CS; j++) val += S[D::o_CH + j * D::NH + o];
+                  }
                 }
                 acc[v] = val;
               }
@@ -778,8 +811,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
         for (int i = 0; i < K; i++)
 #pragma unroll
           for (int kk = 0; kk < KS; kk++) {
-            const int o = jo[jt][i][kk];
-            bj[i][kk] = (o >= 0) ? (h * tab.E[i]) * S[o] : 0.0;
+            bj[i][kk] = (h * tab.E[i]) * S[jo[jt][i][kk]];
           }
 #pragma unroll
         for (int ct = 0; ct < D::TI; ct++) {
@@ -791,8 +823,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : 1) vo
           // + cardinal part: DC^T * I, k runs over the 16 defect rows of this tile
 #pragma unroll
           for (int kk = 0; kk < 4; kk++) {
-            const int kr = 16 * jt + 4 * kk + lk;
-            const double adc = (kr < OR) ? DC[kr * IRP + 16 * ct + lr] : 0.0;
+            const double adc = DC[(16 * jt + 4 * kk + lk) * IRP + 16 * ct + lr];   // rows >= OR are zero padding
             const double bid = (4 * kk + lk == lr) ? 1.0 : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(adc, bid, acc, 0, 0, 0);
           }

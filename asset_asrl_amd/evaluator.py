@@ -47,9 +47,9 @@ class DefectEvaluator:
                              f"the defect needs IR={self.IR}, OR={self.OR}")
 
     def close(self):
-        if getattr(self, "_h", None):
-            _lib.lib().asset_hip_defect_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None and getattr(_lib, "lib", None) is not None:   # module globals vanish at interpreter exit
+            _lib.lib().asset_hip_defect_destroy(h)
 
     __del__ = close
 

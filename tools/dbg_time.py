@@ -1,3 +1,4 @@
+"""Prints the clock64() deltas a -DASSET_TIMING build leaves in FX (workgroup 7).  usage: dbg_time.py <grid>"""
 import sys, os, numpy as np
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
@@ -9,6 +10,4 @@ for rep in range(3):
     fx,agx,kkt=ev.eval(4,w.X,w.L)
 G=int(sys.argv[1]) if len(sys.argv)>1 else 1536; per=10000//G; rem=10000%G
 first=7*per+min(7,rem)
-print('cycles [P0, P1, P2, P3, init, dense(all segs)]:', fx.ravel()[first*15:first*15+6])
-big=np.argwhere(np.abs(fx.ravel())>1000).ravel()
-print("large", list(fx.ravel()[big[:24]]))
+print('segs per wg', per, 'deltas:', fx.ravel()[first*15:first*15+23].astype(int))
