@@ -37,8 +37,8 @@ def dims(xv, uv, pv, cs, blocked, nsave=0):
     IRP, ORP = (IR + 15) // 16 * 16, (OR + 15) // 16 * 16
     NP = (N + 3) // 4 * 4
     SLOT = IR + OR + cs * n + cs * n * N + cs * N + cs * NH + K * n + K * n * N + K * N + K * NH + cs * nsave
-    SCRATCH = max(K * n * IRP, IRP * (K * NP + 1)) + K * (NP - n) * IRP + ORP * IRP + 3 * IRP + 2
-    DENSE = SLOT + SCRATCH
+    SCRATCH = max(K * n * IRP, IRP * (K * NP + 1)) + K * (NP - n) * IRP + ORP * (IRP + 4) + 3 * IRP + 2
+    DENSE = SLOT - cs * nsave + SCRATCH
     STG_LD = (n * N + NH) | 1
     budget = 64 * 1024
     staged = 16 * STG_LD * 8 <= budget

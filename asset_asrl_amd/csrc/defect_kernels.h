@@ -94,6 +94,7 @@ struct Dims {
   static constexpr int o_IH = o_Ig + K * N;
   static constexpr int o_SV = o_IH + K * NH;            // transcendental values of f at the cardinal nodes (P1 -> P3)
   static constexpr int SLOT = o_SV + CS * Ode::NSAVE;
+  static constexpr int SLOTD = o_SV;                    // what the dense stage reads of a slot (the saved values are P1 -> P3 only)
   // ---- dense scratch (one segment at a time)
   // DI_i is kept as two tiles: state rows (r < n), rewritten for every segment, and the remaining rows (tau / control
   // / parameter / padding), constant per launch.  M^T is produced after every A fragment has been read into
@@ -104,7 +105,8 @@ struct Dims {
   static constexpr int XM = (K * n * IRP > IRP * (K * NP + 1)) ? K * n * IRP : IRP * (K * NP + 1);
   static constexpr int s_DIc = XM;                     // [K][NCR][IRP]
   static constexpr int s_DC = s_DIc + K * (NP - n) * IRP;  // cardinal part of J, rows = defect rows  [ORP][IRP], padding rows zero
-  static constexpr int s_R2 = s_DC + ORP * IRP;        // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar
+  static constexpr int LDC = IRP + 4;                  // DC row stride: row- and column-wise fragment reads both conflict-free
+  static constexpr int s_R2 = s_DC + ORP * LDC;        // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar
   static constexpr int s_HI = s_R2 + 2 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
   static constexpr int s_Z0 = s_HI + IRP;              // a cell that always holds 0.0: target of every "no entry" offset
   static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
@@ -115,7 +117,7 @@ struct Dims {
   //      then copies the rows to the workspace with coalesced stores.  Row stride is odd: conflict-free ds_write.
   static constexpr int NSTG = n * N + NH;
   static constexpr int STG_LD = NSTG | 1;
-  static constexpr int DENSE = SLOT + SCRATCH;         // slot buffer + dense scratch (staging aliases both)
+  static constexpr int DENSE = SLOTD + SCRATCH;         // slot buffer + dense scratch (staging aliases both)
   // lanes per ODE pass: as many as fit in the LDS the dense phase needs anyway (occupancy is LDS-bound)
 #ifndef ASSET_LC_BUDGET
 #define ASSET_LC_BUDGET (64 * 1024)
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
   double* tabL = lds;                       // weight tables (persistent)
   double* body = lds + D::TABSZ;            // [slot buffer | dense scratch], aliased by the ODE staging rows
   double* slotb = body;
-  double* scr = body + D::SLOT;
+  double* scr = body + D::SLOTD;
   double* stage = body;
   const int lane = threadIdx.x;
   const int lr = lane & 15, lk = lane >> 4;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
   double wa[K], wb[K], wa2[BOTH ? K : 1], wb2[BOTH ? K : 1];
   // Offsets below are relative to the slot base S and always readable: "no entry" points at the zero cell, so the
   // per-segment loads need no branch (a conditional LDS load costs a full exposed latency each).
-  constexpr int ZERO = D::SLOT + D::s_Z0;
+  constexpr int ZERO = D::SLOTD + D::s_Z0;
   int bo[D::MT][KS], bst[D::MT][KS];                       // B fragment of [hE H^ | E g^]: offset for i = 0 and stride in i
   int cho[LEVEL >= 2 ? D::NTH : 1][4];                     // cardinal Hessian entry feeding accumulator (tile, v)
   int chp[(LEVEL >= 2 && p > 0) ? D::NTH : 1][4];          // parameter-parameter entry (summed over the cardinal nodes) or -1
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
         int v = ZERO, st = 0;
         if (b < N) {
           if (acol < N) { v = D::o_IH + ((b >= acol) ? b * (b + 1) / 2 + acol : acol * (acol + 1) / 2 + b); st = D::NH; }
-          else if (acol == N) { v = D::o_Ig + b; st = N; }   // stride N marks a g^ row (scaled by E_i, not h E_i)
+          else if (acol == N) { v = D::o_Ig + b; st = N; }   // the g^ column is scaled by E_i, the others by h E_i
         }
         bo[mt][kk] = v;
         bst[mt][kk] = st;
@@ -557,7 +559,11 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
     if constexpr (STAGE == 1 || LEVEL == 0) continue;
 
     TS();
-    // (the first slot's loads are issued below, right after this initialisation, and overlap nothing -- one per group)
+    constexpr int NPRE = (D::SLOTD + 63) / 64;
+    double pre[NPRE];                      // next segment's slot, in flight while the current one is processed
+#pragma unroll
+    for (int t = 0; t < NPRE; t++) pre[t] = (t + 1 < NPRE || lane + 64 * t < D::SLOTD) ? Wg[lane + 64 * t] : 0.0;
+    // (the first slot's loads fly while the constant tiles below are built)
     // ---- per-group constants of the dense scratch (the staging rows aliased it): the rows of DI_i that do not
     //      depend on the segment (tau row, control-interpolation rows, parameter identity rows, zero padding;
     //      LGLDefects.h:417-458), the rank-2 direction d = e_TF - e_T, zero padding of M and DC
@@ -574,26 +580,22 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
     }
     for (int e = lane; e < K * n * IRP; e += 64) scr[D::s_DIx + e] = 0.0;   // padding columns of the state rows
     for (int e = lane; e < IRP; e += 64) scr[D::s_R2 + e] = (e == TF) ? 1.0 : ((e == T) ? -1.0 : 0.0);
-    for (int e = lane; e < ORP * IRP; e += 64) scr[D::s_DC + e] = 0.0;
+    for (int e = lane; e < ORP * D::LDC; e += 64) scr[D::s_DC + e] = 0.0;
     if (lane < 2) scr[D::s_Z0 + lane] = 0.0;
     wave_lds_sync();
 
     TS();
     // ------------------------------------------------------------------ P4: per-segment dense phase
-    constexpr int NPRE = (D::SLOT + 63) / 64;
-    double pre[NPRE];                      // next segment's slot, in flight while the current one is processed
-#pragma unroll
-    for (int t = 0; t < NPRE; t++) pre[t] = (t + 1 < NPRE || lane + 64 * t < D::SLOT) ? Wg[lane + 64 * t] : 0.0;
     for (int g = 0; g < gcount; g++) {
       // slot: workspace -> LDS (coalesced); the loads were issued one segment ago
 #pragma unroll
       for (int t = 0; t < NPRE; t++)
-        if (t + 1 < NPRE || lane + 64 * t < D::SLOT) slotb[lane + 64 * t] = pre[t];   // only the last row is partial
+        if (t + 1 < NPRE || lane + 64 * t < D::SLOTD) slotb[lane + 64 * t] = pre[t];   // only the last row is partial
       wave_lds_sync();
       if (g + 1 < gcount) {
 #pragma unroll
         for (int t = 0; t < NPRE; t++)
-          pre[t] = (t + 1 < NPRE || lane + 64 * t < D::SLOT) ? Wg[(g + 1) * D::SLOT + lane + 64 * t] : 0.0;
+          pre[t] = (t + 1 < NPRE || lane + 64 * t < D::SLOTD) ? Wg[(g + 1) * D::SLOT + lane + 64 * t] : 0.0;
       }
       const double* S = slotb;
       const double* z = S + D::o_z;
@@ -624,17 +626,21 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
         const double* cj = S + D::o_CJ + d1j * n * N + d1cc;
         const bool dcrole = (!BOTH && d1h == 1);
         double* dstb = (dcrole ? DC : DIx) + d1c;
+        const int dld = dcrole ? D::LDC : IRP;
+        double jvr[n];                                   // every LDS read is issued before the first write: the compiler
+#pragma unroll                                           // cannot reorder them itself (it must assume the tiles alias the slot)
+        for (int r = 0; r < n; r++) jvr[r] = cj[r * N];
 #pragma unroll
         for (int row = 0; row < ROWS; row++) {
           const int i = row / n, r = row - i * n;
-          const double jv = cj[r * N];
+          const double jv = jvr[r];
           double v = wbh[i] * jv;
           if (d1cc == r) v += wa[i];
-          dstb[row * IRP] = v;
+          dstb[row * dld] = v;
           if constexpr (BOTH) {
             double v2 = wb2h[i] * jv;
             if (d1cc == r) v2 += wa2[i];
-            DC[row * IRP + d1c] = v2;
+            DC[row * D::LDC + d1c] = v2;
           }
         }
       }
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
             }
           }
           DIx[row * IRP + c2] = vi;
-          DC[row * IRP + c2] = vc;
+          DC[row * D::LDC + c2] = vc;
         }
       }
       wave_lds_sync();
@@ -665,21 +671,25 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
       auto time_columns = [&](int e, auto own_) {
         constexpr bool own = decltype(own_)::value;      // first pass: the weights are the precomputed per-lane ones
         const int i = e / n, r = e - i * n;
-        double sb = 0.0, sd = (own ? tE : tab.E[i]) * S[D::o_If + i * n + r];
+        double fv[CS], zv[CS];
+        const double fi = S[D::o_If + i * n + r];
+#pragma unroll
+        for (int jj = 0; jj < CS; jj++) { fv[jj] = S[D::o_Cf + jj * n + r]; zv[jj] = z[jj * q + r]; }
+        const double dit = DIx[e * IRP + T], ditf = DIx[e * IRP + TF], dct = DC[e * D::LDC + T], dctf = DC[e * D::LDC + TF];
+        double sb = 0.0, sd = (own ? tE : tab.E[i]) * fi;
 #pragma unroll
         for (int jj = 0; jj < CS; jj++) {
-          const double fv = S[D::o_Cf + jj * n + r];
-          sb += (own ? tB[jj] : tab.B[i][jj]) * fv;
-          sd += (own ? tD[jj] : tab.D[i][jj]) * fv;
+          sb += (own ? tB[jj] : tab.B[i][jj]) * fv[jj];
+          sd += (own ? tD[jj] : tab.D[i][jj]) * fv[jj];
         }
-        DIx[e * IRP + T] -= sb;
-        DIx[e * IRP + TF] += sb;
-        DC[e * IRP + T] -= sd;
-        DC[e * IRP + TF] += sd;
+        DIx[e * IRP + T] = dit - sb;
+        DIx[e * IRP + TF] = ditf + sb;
+        DC[e * D::LDC + T] = dct - sd;
+        DC[e * D::LDC + TF] = dctf + sd;
         if (a.FX) {                                      // defect value of row (i,r)  (LGLDefects.h:96-103)
           double fxv = h * sd;
 #pragma unroll
-          for (int jj = 0; jj < CS; jj++) fxv += (own ? tC[jj] : tab.C[i][jj]) * z[jj * q + r];
+          for (int jj = 0; jj < CS; jj++) fxv += (own ? tC[jj] : tab.C[i][jj]) * zv[jj];
           a.FX[seg * OR + e] = fxv;
         }
       };
@@ -706,6 +716,13 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
         for (int ct = 0; ct < D::TI; ct++)
 #pragma unroll
           for (int v = 0; v < 4; v++) hi_acc[ct][v] = 0.0;
+        double bvall[K][D::MT][KS];                      // all B operands are read before the first M^T write-back
+#pragma unroll
+        for (int i = 0; i < K; i++)
+#pragma unroll
+          for (int mt = 0; mt < D::MT; mt++)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) bvall[i][mt][kk] = S[bo[mt][kk] + i * bst[mt][kk]];
 #pragma unroll
         for (int i = 0; i < K; i++) {
           const double he = h * tab.E[i];
@@ -714,23 +731,22 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
             const int acol = 16 * mt + lr;               // column of [hE H^ | E g^]
             double bv[KS];
 #pragma unroll
-            for (int kk = 0; kk < KS; kk++) {
-              bv[kk] = S[bo[mt][kk] + i * bst[mt][kk]] * ((bst[mt][kk] == N) ? tab.E[i] : he);
-            }
+            for (int kk = 0; kk < KS; kk++) bv[kk] = bvall[i][mt][kk] * ((acol == N) ? tab.E[i] : he);
 #pragma unroll
             for (int ct = 0; ct < D::TI; ct++) {
               d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
               for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bv[kk], acc, 0, 0, 0);
-              // acc[v] = (M_i^T)[c = 16ct + lk + 4v][acol]
-              if (acol == N) {
+              // acc[v] = (M_i^T)[c = 16ct + lk + 4v][acol].  Every lane accumulates and writes, so there is no branch:
+              // only the lanes owning column N publish hi_acc, and lanes beyond the k-padding write the spare column
+              // K*NP of their row (it exists for bank spreading and is never read).
+              if (mt == N / 16) {
 #pragma unroll
                 for (int v = 0; v < 4; v++) hi_acc[ct][v] += acc[v];
               }
-              if (acol < NP) {                           // columns N..NP-1 are k-padding of the next product: keep them zero
+              const int mcol = (acol < NP) ? i * NP + acol : K * NP;
 #pragma unroll
-                for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + i * NP + acol] = (acol < N) ? acc[v] : 0.0;
-              }
+              for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + mcol] = (acol < N) ? acc[v] : 0.0;
             }
           }
         }
@@ -804,6 +820,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
           }
         }
       }
+      {
 #pragma unroll
       for (int jt = 0; jt < D::TJ; jt++) {
         double bj[K][KS];                                // (hE_i J^_i)^T[aa][jr], non-zero only on interior i's rows
@@ -815,20 +832,17 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
           }
 #pragma unroll
         for (int ct = 0; ct < D::TI; ct++) {
-          d4 acc = {0.0, 0.0, 0.0, 0.0};
+          // cardinal part of J^T (DC^T) is the initial accumulator value: entry v is (c = 16ct + lk + 4v, jr = 16jt + lr)
+          d4 acc;
+#pragma unroll
+          for (int v = 0; v < 4; v++) acc[v] = DC[(16 * jt + lr) * D::LDC + 16 * ct + lk + 4 * v];   // rows >= OR: zero padding
 #pragma unroll
           for (int i = 0; i < K; i++)
 #pragma unroll
             for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bj[i][kk], acc, 0, 0, 0);
-          // + cardinal part: DC^T * I, k runs over the 16 defect rows of this tile
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) {
-            const double adc = DC[(16 * jt + 4 * kk + lk) * IRP + 16 * ct + lr];   // rows >= OR are zero padding
-            const double bid = (4 * kk + lk == lr) ? 1.0 : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(adc, bid, acc, 0, 0, 0);
-          }
           accJ[ct * D::TJ + jt] = acc;
         }
+      }
       }
 
       // ---- D5: adjoint gradient  g = J^T lam  without touching the J tile:
@@ -848,7 +862,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
               }
           }
 #pragma unroll
-          for (int jr = 0; jr < OR; jr++) v += lam[jr] * DC[jr * IRP + c];
+          for (int jr = 0; jr < OR; jr++) v += lam[jr] * DC[jr * D::LDC + c];
           a.AGX[seg * IR + c] = v;
         }
       }
@@ -857,24 +871,44 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
       //      row (H) r = 16*rt + lr or (J) jr = 16*jt + lr; 16 consecutive lanes cover 128 contiguous bytes.
       if (a.KKT) {
         double* dst = a.KKT + seg * size_t(D::NKKT);
+        // Lanes are grouped by the condition that makes their entry a KKT slot, so a handful of branches cover all
+        // stores: off-diagonal H tiles are complete, a diagonal tile's entry v is kept when r >= c (lr >= lk + 4v),
+        // a J tile's when its defect row exists (lr < OR - 16jt); padded sizes add the c < IR / r < IR tests.
+        constexpr bool CFULL = (IR == IRP);
+        if constexpr (LEVEL >= 2) {
 #pragma unroll
-        for (int ct = 0; ct < D::TI; ct++) {
+          for (int rt = 0; rt < D::TI; rt++)
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
-            if constexpr (LEVEL >= 2) {
+            for (int ct = 0; ct < rt; ct++) {
+              const int tix = rt * (rt + 1) / 2 + ct;
+              if (CFULL || 16 * rt + lr < IR) {            // columns of a tile left of the diagonal are always < IR
 #pragma unroll
-              for (int rt = ct; rt < D::TI; rt++) {
-                const int tix = rt * (rt + 1) / 2 + ct;
-                const int o = hst[tix][v];
-                if (o >= 0) dst[o] = accH[tix][v];
+                for (int v = 0; v < 4; v++) dst[hst[tix][v]] = accH[tix][v];
               }
             }
 #pragma unroll
-            for (int jt = 0; jt < D::TJ; jt++) {
-              const int o = jst[ct * D::TJ + jt][v];
-              if (o >= 0) dst[o] = accJ[ct * D::TJ + jt][v];
+          for (int v = 0; v < 4; v++) {
+            if (lr >= lk + 4 * v) {
+#pragma unroll
+              for (int t = 0; t < D::TI; t++) {
+                const int tix = t * (t + 1) / 2 + t;
+                if (CFULL || t + 1 < D::TI || 16 * t + lr < IR) dst[hst[tix][v]] = accH[tix][v];
+              }
             }
           }
+        }
+        {
+#pragma unroll
+        for (int jt = 0; jt < D::TJ; jt++) {
+          if (16 * jt + lr < OR) {
+#pragma unroll
+            for (int ct = 0; ct < D::TI; ct++)
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+                if (CFULL || ct + 1 < D::TI || 16 * ct + lk + 4 * v < IR)
+                  dst[jst[ct * D::TJ + jt][v]] = accJ[ct * D::TJ + jt][v];
+          }
+        }
         }
         if constexpr (LEVEL < 2) {                       // Jacobian-only kinds: the Hessian slots are written as zero
           for (int k = lane; k < D::NKKT; k += 64) {
