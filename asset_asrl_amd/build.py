@@ -24,8 +24,9 @@ LDS_BUDGET = 160 * 1024
 LDS_TARGET = 40 * 1024          # keep >= 4 single-wave workgroups per CU when the sizes allow it
 
 
-def dims(xv, uv, pv, cs, blocked, nsave=0):
-    """Mirror of ``Dims<>`` in csrc/defect_kernels.h (sizes + LDS plan)."""
+def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
+    """Mirror of ``Dims<>`` in csrc/defect_kernels.h (sizes + LDS plan).  ``nzj`` / ``nzh`` are the structural
+    non-zero counts of the ODE Jacobian / packed-lower Hessian (dense when omitted)."""
     n = xv
     m, p = (0, uv + pv) if blocked else (uv, pv)
     K = cs - 1
@@ -34,12 +35,15 @@ def dims(xv, uv, pv, cs, blocked, nsave=0):
     IR, OR = cs * q + p, K * n
     NKKT = IR * (IR + 1) // 2 + OR * IR
     NH = N * (N + 1) // 2
+    nzj = n * N if nzj is None else nzj
+    nzh = NH if nzh is None else nzh
     IRP, ORP = (IR + 15) // 16 * 16, (OR + 15) // 16 * 16
     NP = (N + 3) // 4 * 4
-    SLOT = IR + OR + cs * n + cs * n * N + cs * N + cs * NH + K * n + K * n * N + K * N + K * NH + cs * nsave
+    WSLOTD = IR + OR + cs * n + cs * nzj + cs * N + cs * nzh + K * n + K * nzj + K * N + K * nzh
+    WSLOT = WSLOTD + cs * nsave
     SCRATCH = max(K * n * IRP, IRP * (K * NP + 1)) + K * (NP - n) * IRP + ORP * (IRP + 4) + 3 * IRP + 2
-    DENSE = SLOT - cs * nsave + SCRATCH
-    STG_LD = (n * N + NH) | 1
+    DENSE = WSLOTD + SCRATCH
+    STG_LD = (nzj + nzh) | 1
     budget = 64 * 1024
     staged = 16 * STG_LD * 8 <= budget
     LC = 64 if (not staged or 64 * STG_LD * 8 <= budget) else (32 if 32 * STG_LD * 8 <= budget else 16)
@@ -47,11 +51,12 @@ def dims(xv, uv, pv, cs, blocked, nsave=0):
 
     def lds_bytes(G=0):
         return (70 + BODY) * 8
-    return dict(n=n, m=m, p=p, q=q, N=N, IR=IR, OR=OR, NKKT=NKKT, SLOT=SLOT, LC=LC, lds_bytes=lds_bytes)
+    return dict(n=n, m=m, p=p, q=q, N=N, IR=IR, OR=OR, NKKT=NKKT, SLOT=WSLOT, LC=LC, lds_bytes=lds_bytes,
+                lds_bytes_ode=(70 + (LC * STG_LD if staged else 0)) * 8, lds_bytes_dense=(70 + DENSE) * 8)
 
 
-def pick_group(xv, uv, pv, cs, blocked, nsave=0):
-    d = dims(xv, uv, pv, cs, blocked, nsave)
+def pick_group(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
+    d = dims(xv, uv, pv, cs, blocked, nsave, nzj, nzh)
     return 64 // cs if d["lds_bytes"]() <= LDS_BUDGET else 0
 
 
@@ -89,7 +94,9 @@ def generate(verbose=True):
         units = []
         for cs in (2, 3, 4):
             for blocked in ((0, 1) if uv > 0 else (0,)):
-                G = pick_group(xv, uv, pv, cs, bool(blocked), len(saved_nodes(ode.derivatives())))
+                st = ode.derivatives().stats()
+                G = pick_group(xv, uv, pv, cs, bool(blocked), len(saved_nodes(ode.derivatives())), st["nnz_J"],
+                               st["nnz_H_lower"])
                 if G == 0:
                     continue  # working set exceeds one CU's LDS -- not instantiated (asset_hip_has_kernel says so)
                 units.append((f"lgl{cs}_{blocked}", f"ASSET_REGISTER_LGL({sn}, {cs}, {blocked}, {G})"))

@@ -81,20 +81,24 @@ struct Dims {
   static constexpr int NTH = TI * (TI + 1) / 2;                       // lower-triangle H tiles
   static constexpr int CW = IRP <= 16 ? 16 : (IRP <= 32 ? 32 : 64);   // lanes per DI row pass (power of two)
 
-  // ---- LDS map (in doubles): per in-flight segment slot
-  static constexpr int o_z = 0;
-  static constexpr int o_lam = o_z + IR;
-  static constexpr int o_Cf = o_lam + OR;
-  static constexpr int o_CJ = o_Cf + CS * n;
-  static constexpr int o_Cg = o_CJ + CS * n * N;
-  static constexpr int o_CH = o_Cg + CS * N;
-  static constexpr int o_If = o_CH + CS * NH;
-  static constexpr int o_IJ = o_If + K * n;
-  static constexpr int o_Ig = o_IJ + K * n * N;
-  static constexpr int o_IH = o_Ig + K * N;
-  static constexpr int o_SV = o_IH + K * NH;            // transcendental values of f at the cardinal nodes (P1 -> P3)
-  static constexpr int SLOT = o_SV + CS * Ode::NSAVE;
-  static constexpr int SLOTD = o_SV;                    // what the dense stage reads of a slot (the saved values are P1 -> P3 only)
+  // ---- per-segment slot of ODE results (in doubles): workspace layout in HBM, copied verbatim into LDS by the dense
+  //      stage.  J and H blocks hold only their structural non-zeros, in Ode::JIDX / HIDX order (Ode::JPOS / HPOS
+  //      give the position of a dense entry or -1); readers point "no entry" at a zero cell instead.
+  using ode_t = Ode;
+  static constexpr int NZJ = Ode::NNZ_J, NZH = Ode::NNZ_H;
+  static constexpr int w_z = 0;
+  static constexpr int w_lam = w_z + IR;
+  static constexpr int w_Cf = w_lam + OR;
+  static constexpr int w_CJ = w_Cf + CS * n;
+  static constexpr int w_Cg = w_CJ + CS * NZJ;
+  static constexpr int w_CH = w_Cg + CS * N;
+  static constexpr int w_If = w_CH + CS * NZH;
+  static constexpr int w_IJ = w_If + K * n;
+  static constexpr int w_Ig = w_IJ + K * NZJ;
+  static constexpr int w_IH = w_Ig + K * N;
+  static constexpr int w_SV = w_IH + K * NZH;           // transcendental values of f at the cardinal nodes (P1 -> P3)
+  static constexpr int WSLOT = w_SV + CS * Ode::NSAVE;
+  static constexpr int WSLOTD = w_SV;                   // what the dense stage reads of a slot
   // ---- dense scratch (one segment at a time)
   // DI_i is kept as two tiles: state rows (r < n), rewritten for every segment, and the remaining rows (tau / control
   // / parameter / padding), constant per launch.  M^T is produced after every A fragment has been read into
@@ -115,9 +119,9 @@ struct Dims {
 
   // ---- ODE-phase staging: every evaluating lane writes its dense J (n x N) and packed H into an LDS row, the wave
   //      then copies the rows to the workspace with coalesced stores.  Row stride is odd: conflict-free ds_write.
-  static constexpr int NSTG = n * N + NH;
+  static constexpr int NSTG = NZJ + NZH;               // a staging row holds one point's non-zeros [J | H]
   static constexpr int STG_LD = NSTG | 1;
-  static constexpr int DENSE = SLOTD + SCRATCH;         // slot buffer + dense scratch (staging aliases both)
+  static constexpr int DENSE = WSLOTD + SCRATCH;         // slot buffer + dense scratch (staging aliases both)
   // lanes per ODE pass: as many as fit in the LDS the dense phase needs anyway (occupancy is LDS-bound)
 #ifndef ASSET_LC_BUDGET
 #define ASSET_LC_BUDGET (64 * 1024)
@@ -168,7 +172,7 @@ struct OdeOut {  // routes every derivative entry to its LDS slot (J row-major n
 typedef __attribute__((address_space(3))) double lds_double;
 
 template <class D>
-struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H -> this lane's LDS staging row [J row-major | H packed]
+struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H non-zeros -> this lane's LDS staging row [J | H]
   using JP = std::conditional_t<D::STAGED, lds_double*, double*>;
   double* f_;
   double* g_;
@@ -176,9 +180,15 @@ struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H -> this lan
   JP H_;
   double* sv_ = nullptr;
   __device__ void f(int k, double v) { f_[k] = v; }
-  __device__ void J(int k, int i, double v) { J_[k * D::N + i] = v; }
+  __device__ void J(int k, int i, double v) {          // (k, i) are literals in the generated bodies: the lookup folds
+    const int c = D::ode_t::JPOS[k * D::N + i];
+    if (c >= 0) J_[c] = v;
+  }
   __device__ void g(int i, double v) { g_[i] = v; }
-  __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
+  __device__ void H(int i, int j, double v) {
+    const int c = D::ode_t::HPOS[i * (i + 1) / 2 + j];
+    if (c >= 0) H_[c] = v;
+  }
   __device__ void save(int k, double v) { sv_[k] = v; }
 };
 
@@ -216,7 +226,7 @@ template <class Ode, class D, int LEVEL>
 __device__ __attribute__((noinline)) void interior_eval(double* S, int i, const LglTab* tabp, lds_double* row) {
   constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
-  const double* z = S + D::o_z;
+  const double* z = S + D::w_z;
   const double h = z[D::TF] - z[T];
   double y[N];
   double li[n > 0 ? n : 1];
@@ -224,7 +234,7 @@ __device__ __attribute__((noinline)) void interior_eval(double* S, int i, const 
   for (int k = 0; k < n; k++) {
     double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * S[D::o_Cf + j * n + k]);
+    for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * S[D::w_Cf + j * n + k]);
     y[k] = acc;
   }
   y[T] = z[T] + h * tab.s[i];
@@ -238,10 +248,10 @@ __device__ __attribute__((noinline)) void interior_eval(double* S, int i, const 
 #pragma unroll
   for (int k = 0; k < p; k++) y[q + k] = z[D::P0 + k];
 #pragma unroll
-  for (int k = 0; k < n; k++) li[k] = (LEVEL >= 2) ? S[D::o_lam + i * n + k] : 0.0;
+  for (int k = 0; k < n; k++) li[k] = (LEVEL >= 2) ? S[D::w_lam + i * n + k] : 0.0;
   RegIn<D> in{y, li};
-  OdeOutStaged<D> out{S + D::o_If + i * n, S + D::o_Ig + i * N, stage_or<D>(row, S + D::o_IJ + i * n * N),
-                      stage_or<D>(row + n * N, S + D::o_IH + i * D::NH)};
+  OdeOutStaged<D> out{S + D::w_If + i * n, S + D::w_Ig + i * N, stage_or<D>(row, S + D::w_IJ + i * D::NZJ),
+                      stage_or<D>(row + D::NZJ, S + D::w_IH + i * D::NZH)};
   (void)K;
   if constexpr (LEVEL == 0) Ode::f(in, out);
   else if constexpr (LEVEL == 1) Ode::fj(in, out);
@@ -252,7 +262,7 @@ template <class Ode, class D>
 __device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const LglTab* tabp, lds_double* row) {
   constexpr int K = D::K, n = D::n, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
-  const double* z = S + D::o_z;
+  const double* z = S + D::w_z;
   const double h = z[D::TF] - z[T];
   double w[n > 0 ? n : 1];
 #pragma unroll
@@ -260,14 +270,14 @@ __device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < K; i++) {
-      acc += S[D::o_Ig + i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
-      acc += S[D::o_lam + i * n + k] * (tab.D[i][j] * h);
+      acc += S[D::w_Ig + i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
+      acc += S[D::w_lam + i * n + k] * (tab.D[i][j] * h);
     }
     w[k] = acc;
   }
-  CardIn<D> in{z, w, j, S + D::o_SV + j * Ode::NSAVE};
-  OdeOutStaged<D> out{S + D::o_Cf + j * n, S + D::o_Cg + j * N, stage_or<D>(row, S + D::o_CJ + j * n * N),
-                      stage_or<D>(row + n * N, S + D::o_CH + j * D::NH)};
+  CardIn<D> in{z, w, j, S + D::w_SV + j * Ode::NSAVE};
+  OdeOutStaged<D> out{S + D::w_Cf + j * n, S + D::w_Cg + j * N, stage_or<D>(row, S + D::w_CJ + j * D::NZJ),
+                      stage_or<D>(row + D::NZJ, S + D::w_CH + j * D::NZH)};
   Ode::fjgh_load(in, out);   // the transcendental sub-expressions of f at this node were stored by P1
 }
 
@@ -284,11 +294,38 @@ struct GatherIn {  // y = X[Vindex(node j, component i)]: the first ODE phase re
 template <class Ode, class D, int LEVEL>
 __device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, lds_double* row, const double* X, const int* vi) {
   GatherIn<D> in{X, vi, j};
-  OdeOutStaged<D> out{S + D::o_Cf + j * D::n, nullptr, stage_or<D>(row, S + D::o_CJ + j * D::n * D::N), nullptr,
-                      S + D::o_SV + j * Ode::NSAVE};
+  OdeOutStaged<D> out{S + D::w_Cf + j * D::n, nullptr, stage_or<D>(row, S + D::w_CJ + j * D::NZJ), nullptr,
+                      S + D::w_SV + j * Ode::NSAVE};
   if constexpr (LEVEL == 1) Ode::fj(in, out);
   else if constexpr (LEVEL == 2) Ode::f_save(in, out);
   else Ode::f(in, out);
+}
+
+// Coalesced copy of `npt` LDS staging rows (NC doubles each) to the workspace: element idx = row*NC + k goes to
+// dst_of(e0 + row, k).  Four elements per lane are in flight (all LDS reads of a batch are issued before its stores;
+// one read-wait-store per trip exposes a full LDS latency each time) and (row, k) advance incrementally.
+template <int NC, class F>
+__device__ inline void copy_rows(const double* stage, int stg_ld, int npt, int e0, int lane, F&& dst_of) {
+  constexpr int RSTEP = 64 / NC, KSTEP = 64 % NC;
+  int row = lane / NC, k = lane - row * NC;
+  const int total = npt * NC;
+  for (int base = 0; base < total; base += 256) {
+    double v[4];
+    double* d[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      ok[u] = base + 64 * u + lane < total;
+      v[u] = stage[ok[u] ? row * stg_ld + k : 0];
+      d[u] = dst_of(e0 + row, k);
+      row += RSTEP;
+      k += KSTEP;
+      if (k >= NC) { k -= NC; row++; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (ok[u]) *d[u] = v[u];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- kernel
@@ -310,7 +347,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
   double* tabL = lds;                       // weight tables (persistent)
   double* body = lds + D::TABSZ;            // [slot buffer | dense scratch], aliased by the ODE staging rows
   double* slotb = body;
-  double* scr = body + D::SLOTD;
+  double* scr = body + D::WSLOTD;
   double* stage = body;
   const int lane = threadIdx.x;
   const int lr = lane & 15, lk = lane >> 4;
@@ -336,12 +373,17 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
   double wa[K], wb[K], wa2[BOTH ? K : 1], wb2[BOTH ? K : 1];
   // Offsets below are relative to the slot base S and always readable: "no entry" points at the zero cell, so the
   // per-segment loads need no branch (a conditional LDS load costs a full exposed latency each).
-  constexpr int ZERO = D::SLOTD + D::s_Z0;
+  constexpr int ZERO = D::WSLOTD + D::s_Z0;
+  // slot offset of dfdy_j[r][cc] / dfdy^_i[k][b] for run-time indices (the rare paths; table lookups)
+  auto cj_at = [](int j, int r, int cc) { const int jp = Ode::JPOS[r * N + cc]; return jp >= 0 ? D::w_CJ + j * D::NZJ + jp : ZERO; };
+  auto ij_at = [](int i, int k, int b) { const int jp = Ode::JPOS[k * N + b]; return jp >= 0 ? D::w_IJ + i * D::NZJ + jp : ZERO; };
+  (void)cj_at; (void)ij_at;
   int bo[D::MT][KS], bst[D::MT][KS];                       // B fragment of [hE H^ | E g^]: offset for i = 0 and stride in i
   int cho[LEVEL >= 2 ? D::NTH : 1][4];                     // cardinal Hessian entry feeding accumulator (tile, v)
   int chp[(LEVEL >= 2 && p > 0) ? D::NTH : 1][4];          // parameter-parameter entry (summed over the cardinal nodes) or -1
   int jo[D::TJ][K][KS];                                    // (hE J^)^T fragment
   int avb[KS], avs[KS];                                    // DI_i^T fragment: offset in the dense scratch for i = 0, stride in i
+  int cjo[n];                                              // dfdy_j[r][cc] of this lane's block column (D1)
   int hst[LEVEL >= 2 ? D::NTH : 1][4], jst[D::TI * D::TJ][4];   // KKT slot of accumulator entry (tile, v) or -1
   double tB[CS], tD[CS], tC[CS], tE = 0.0;                 // weights of the row (i,r) this lane owns in the time-column pass
   if constexpr (STAGE == 2 && LEVEL >= 1) {
@@ -365,12 +407,19 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
         const int b = 4 * kk + lk, acol = 16 * mt + lr;
         int v = ZERO, st = 0;
         if (b < N) {
-          if (acol < N) { v = D::o_IH + ((b >= acol) ? b * (b + 1) / 2 + acol : acol * (acol + 1) / 2 + b); st = D::NH; }
-          else if (acol == N) { v = D::o_Ig + b; st = N; }   // the g^ column is scaled by E_i, the others by h E_i
+          if (acol < N) {
+            const int hp = Ode::HPOS[(b >= acol) ? b * (b + 1) / 2 + acol : acol * (acol + 1) / 2 + b];
+            if (hp >= 0) { v = D::w_IH + hp; st = D::NZH; }
+          } else if (acol == N) { v = D::w_Ig + b; st = N; }   // the g^ column is scaled by E_i, the others by h E_i
         }
         bo[mt][kk] = v;
         bst[mt][kk] = st;
       }
+#pragma unroll
+    for (int r = 0; r < n; r++) {
+      const int jp = Ode::JPOS[r * N + d1cc];
+      cjo[r] = (d1ok && jp >= 0) ? D::w_CJ + d1j * D::NZJ + jp : ZERO;
+    }
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) {
       const int r = 4 * kk + lk;
@@ -386,7 +435,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) {
           const int aa = 4 * kk + lk;
-          jo[jt][i][kk] = (ji == i && aa < N) ? D::o_IJ + (i * n + jk) * N + aa : ZERO;
+          const int jp = (ji == i && aa < N) ? Ode::JPOS[jk * N + aa] : -1;
+          jo[jt][i][kk] = (jp >= 0) ? D::w_IJ + i * D::NZJ + jp : ZERO;
         }
     }
 #pragma unroll
@@ -411,14 +461,14 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
               if (c < P0) {
                 const int jn = c / q, cc = c - jn * q;
                 if (r < P0) {
-                  if (r / q == jn) { const int rr = r - jn * q; ch = D::o_CH + jn * D::NH + rr * (rr + 1) / 2 + cc; }
+                  if (r / q == jn) { const int rr = r - jn * q, hp = Ode::HPOS[rr * (rr + 1) / 2 + cc]; if (hp >= 0) ch = D::w_CH + jn * D::NZH + hp; }
                 } else {
-                  const int rr = q + (r - P0);
-                  ch = D::o_CH + jn * D::NH + rr * (rr + 1) / 2 + cc;
+                  const int rr = q + (r - P0), hp = Ode::HPOS[rr * (rr + 1) / 2 + cc];
+                  if (hp >= 0) ch = D::w_CH + jn * D::NZH + hp;
                 }
               } else {
                 const int rr = q + (r - P0), c2 = q + (c - P0);
-                cp = rr * (rr + 1) / 2 + c2;               // parameter-parameter: summed over the cardinal nodes
+                cp = Ode::HPOS[rr * (rr + 1) / 2 + c2];    // parameter-parameter: summed over the cardinal nodes
               }
             }
             cho[tix][v] = ch;
@@ -439,7 +489,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
     const int seg0 = wg_first + g0;
     TS();
     const int gcount = min(G, wg_count - g0);
-    double* Wg = a.work + size_t(seg0) * D::SLOT;   // ODE result slots of this group's segments (HBM / L2)
+    double* Wg = a.work + size_t(seg0) * D::WSLOT;  // ODE result slots of this group's segments (HBM / L2)
 
     if constexpr (STAGE == 1) {
     // ------------------------------------------------------------------ P0: gather z = X[Vindex], lam = L[Cindex]
@@ -462,12 +512,12 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
 #pragma unroll
       for (int t = 0; t < NZ; t++) {
         const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
-        if (e < gcount * IR) Wg[g * D::SLOT + D::o_z + r] = zv[t];
+        if (e < gcount * IR) Wg[g * D::WSLOT + D::w_z + r] = zv[t];
       }
 #pragma unroll
       for (int t = 0; t < NL; t++) {
         const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
-        if (e < gcount * OR) Wg[g * D::SLOT + D::o_lam + r] = lv[t];
+        if (e < gcount * OR) Wg[g * D::WSLOT + D::w_lam + r] = lv[t];
       }
     }
     // (no wait here: P1 reads X itself; the barrier after P1 also covers these stores before P2 reads the slots)
@@ -478,16 +528,15 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
       const int e = e0 + lane;
       if (lane < LC && e < gcount * CS) {
         const int g = e / CS, j = e - g * CS;
-        cardinal_eval1<Ode, D, LEVEL>(Wg + g * D::SLOT, j, (lds_double*)(stage + lane * STG_LD), a.X, a.vindex + size_t(seg0 + g) * IR);
+        cardinal_eval1<Ode, D, LEVEL>(Wg + g * D::WSLOT, j, (lds_double*)(stage + lane * STG_LD), a.X, a.vindex + size_t(seg0 + g) * IR);
       }
       if constexpr (LEVEL == 1 && D::STAGED) {
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
         const int npt = min(LC, gcount * CS - e0);
-        for (int idx = lane; idx < npt * (n * N); idx += 64) {
-          const int row = idx / (n * N), k = idx - row * (n * N);
-          const int ee = e0 + row, g = ee / CS, j = ee - g * CS;
-          Wg[g * D::SLOT + D::o_CJ + j * n * N + k] = stage[row * STG_LD + k];
-        }
+        copy_rows<(D::NZJ > 0 ? D::NZJ : 1)>(stage, STG_LD, D::NZJ > 0 ? npt : 0, e0, lane, [&](int ee, int k) {
+          const int g = ee / CS, j = ee - g * CS;
+          return Wg + g * D::WSLOT + D::w_CJ + j * D::NZJ + k;
+        });
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
       }
     }
@@ -499,18 +548,16 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
       const int e = e0 + lane;
       if (lane < LC && e < gcount * K) {
         const int g = e / K, i = e - g * K;
-        interior_eval<Ode, D, LEVEL>(Wg + g * D::SLOT, i, &tab, (lds_double*)(stage + lane * STG_LD));
+        interior_eval<Ode, D, LEVEL>(Wg + g * D::WSLOT, i, &tab, (lds_double*)(stage + lane * STG_LD));
       }
       if constexpr (LEVEL >= 1 && D::STAGED) {
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
         const int npt = min(LC, gcount * K - e0);
-        constexpr int NC = (LEVEL >= 2) ? NSTG : n * N;   // LEVEL 1 has no Hessian part
-        for (int idx = lane; idx < npt * NC; idx += 64) {
-          const int row = idx / NC, k = idx - row * NC;
-          const int ee = e0 + row, g = ee / K, i = ee - g * K;
-          double* dstp = Wg + g * D::SLOT + ((k < n * N) ? (D::o_IJ + i * n * N + k) : (D::o_IH + i * D::NH + (k - n * N)));
-          *dstp = stage[row * STG_LD + k];
-        }
+        constexpr int NC = (LEVEL >= 2) ? NSTG : D::NZJ;   // LEVEL 1 has no Hessian part
+        copy_rows<(NC > 0 ? NC : 1)>(stage, STG_LD, NC > 0 ? npt : 0, e0, lane, [&](int ee, int k) {
+          const int g = ee / K, i = ee - g * K;
+          return Wg + g * D::WSLOT + ((k < D::NZJ) ? (D::w_IJ + i * D::NZJ + k) : (D::w_IH + i * D::NZH + (k - D::NZJ)));
+        });
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
       }
     }
@@ -523,16 +570,14 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
         const int e = e0 + lane;
         if (lane < LC && e < gcount * CS) {
           const int g = e / CS, j = e - g * CS;
-          cardinal_eval2<Ode, D>(Wg + g * D::SLOT, j, &tab, (lds_double*)(stage + lane * STG_LD));
+          cardinal_eval2<Ode, D>(Wg + g * D::WSLOT, j, &tab, (lds_double*)(stage + lane * STG_LD));
         }
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
         const int npt = D::STAGED ? min(LC, gcount * CS - e0) : 0;
-        for (int idx = lane; idx < npt * NSTG; idx += 64) {
-          const int row = idx / NSTG, k = idx - row * NSTG;
-          const int ee = e0 + row, g = ee / CS, j = ee - g * CS;
-          double* dstp = Wg + g * D::SLOT + ((k < n * N) ? (D::o_CJ + j * n * N + k) : (D::o_CH + j * D::NH + (k - n * N)));
-          *dstp = stage[row * STG_LD + k];
-        }
+        copy_rows<(NSTG > 0 ? NSTG : 1)>(stage, STG_LD, NSTG > 0 ? npt : 0, e0, lane, [&](int ee, int k) {
+          const int g = ee / CS, j = ee - g * CS;
+          return Wg + g * D::WSLOT + ((k < D::NZJ) ? (D::w_CJ + j * D::NZJ + k) : (D::w_CH + j * D::NZH + (k - D::NZJ)));
+        });
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
       }
     }
@@ -543,13 +588,13 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
         for (int e = lane; e < gcount * OR; e += 64) {
           const int g = e / OR, jr = e - g * OR;
           const int i = jr / n, k = jr - i * n;
-          const double* S = Wg + g * D::SLOT;
-          const double* z = S + D::o_z;
+          const double* S = Wg + g * D::WSLOT;
+          const double* z = S + D::w_z;
           const double h = z[TF] - z[T];
           double fxv = 0.0;
 #pragma unroll
-          for (int j = 0; j < CS; j++) fxv += (tab.C[i][j] * z[j * q + k] + (tab.D[i][j] * h) * S[D::o_Cf + j * n + k]);
-          fxv += (h * tab.E[i]) * S[D::o_If + i * n + k];
+          for (int j = 0; j < CS; j++) fxv += (tab.C[i][j] * z[j * q + k] + (tab.D[i][j] * h) * S[D::w_Cf + j * n + k]);
+          fxv += (h * tab.E[i]) * S[D::w_If + i * n + k];
           a.FX[size_t(seg0 + g) * OR + jr] = fxv;
         }
       }
@@ -559,10 +604,10 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
     if constexpr (STAGE == 1 || LEVEL == 0) continue;
 
     TS();
-    constexpr int NPRE = (D::SLOTD + 63) / 64;
+    constexpr int NPRE = (D::WSLOTD + 63) / 64;
     double pre[NPRE];                      // next segment's slot, in flight while the current one is processed
 #pragma unroll
-    for (int t = 0; t < NPRE; t++) pre[t] = (t + 1 < NPRE || lane + 64 * t < D::SLOTD) ? Wg[lane + 64 * t] : 0.0;
+    for (int t = 0; t < NPRE; t++) pre[t] = (t + 1 < NPRE || lane + 64 * t < D::WSLOTD) ? Wg[lane + 64 * t] : 0.0;
     // (the first slot's loads fly while the constant tiles below are built)
     // ---- per-group constants of the dense scratch (the staging rows aliased it): the rows of DI_i that do not
     //      depend on the segment (tau row, control-interpolation rows, parameter identity rows, zero padding;
@@ -590,16 +635,16 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
       // slot: workspace -> LDS (coalesced); the loads were issued one segment ago
 #pragma unroll
       for (int t = 0; t < NPRE; t++)
-        if (t + 1 < NPRE || lane + 64 * t < D::SLOTD) slotb[lane + 64 * t] = pre[t];   // only the last row is partial
+        if (t + 1 < NPRE || lane + 64 * t < D::WSLOTD) slotb[lane + 64 * t] = pre[t];   // only the last row is partial
       wave_lds_sync();
       if (g + 1 < gcount) {
 #pragma unroll
         for (int t = 0; t < NPRE; t++)
-          pre[t] = (t + 1 < NPRE || lane + 64 * t < D::SLOTD) ? Wg[(g + 1) * D::SLOT + lane + 64 * t] : 0.0;
+          pre[t] = (t + 1 < NPRE || lane + 64 * t < D::WSLOTD) ? Wg[(g + 1) * D::WSLOT + lane + 64 * t] : 0.0;
       }
       const double* S = slotb;
-      const double* z = S + D::o_z;
-      const double* lam = S + D::o_lam;
+      const double* z = S + D::w_z;
+      const double* lam = S + D::w_lam;
       const double h = z[TF] - z[T];
       const size_t seg = size_t(seg0 + g);
 
@@ -623,13 +668,12 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
           wbh[i] = wb[i] * h;
           if constexpr (BOTH) wb2h[i] = wb2[i] * h;
         }
-        const double* cj = S + D::o_CJ + d1j * n * N + d1cc;
         const bool dcrole = (!BOTH && d1h == 1);
         double* dstb = (dcrole ? DC : DIx) + d1c;
         const int dld = dcrole ? D::LDC : IRP;
         double jvr[n];                                   // every LDS read is issued before the first write: the compiler
 #pragma unroll                                           // cannot reorder them itself (it must assume the tiles alias the slot)
-        for (int r = 0; r < n; r++) jvr[r] = cj[r * N];
+        for (int r = 0; r < n; r++) jvr[r] = S[cjo[r]];
 #pragma unroll
         for (int row = 0; row < ROWS; row++) {
           const int i = row / n, r = row - i * n;
@@ -651,13 +695,13 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
           double vi = 0.0, vc = 0.0;
           if (c2 < P0) {
             const int j2 = c2 / q, cc2 = c2 - j2 * q;
-            const double jv = S[D::o_CJ + (j2 * n + r) * N + cc2];
+            const double jv = S[cj_at(j2, r, cc2)];
             vi = (tab.B[i][j2] * h) * jv;
             vc = (tab.D[i][j2] * h) * jv;
             if (cc2 == r) { vi += tab.A[i][j2]; vc += tab.C[i][j2]; }
           } else {
             for (int jj = 0; jj < CS; jj++) {
-              const double jv = S[D::o_CJ + (jj * n + r) * N + q + (c2 - P0)];
+              const double jv = S[cj_at(jj, r, q + (c2 - P0))];
               vi += (tab.B[i][jj] * h) * jv;
               vc += (tab.D[i][jj] * h) * jv;
             }
@@ -672,9 +716,9 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
         constexpr bool own = decltype(own_)::value;      // first pass: the weights are the precomputed per-lane ones
         const int i = e / n, r = e - i * n;
         double fv[CS], zv[CS];
-        const double fi = S[D::o_If + i * n + r];
+        const double fi = S[D::w_If + i * n + r];
 #pragma unroll
-        for (int jj = 0; jj < CS; jj++) { fv[jj] = S[D::o_Cf + jj * n + r]; zv[jj] = z[jj * q + r]; }
+        for (int jj = 0; jj < CS; jj++) { fv[jj] = S[D::w_Cf + jj * n + r]; zv[jj] = z[jj * q + r]; }
         const double dit = DIx[e * IRP + T], ditf = DIx[e * IRP + TF], dct = DC[e * D::LDC + T], dctf = DC[e * D::LDC + TF];
         double sb = 0.0, sd = (own ? tE : tab.E[i]) * fi;
 #pragma unroll
@@ -762,11 +806,11 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
         const double ih = 1.0 / h;
         for (int c = lane; c < IRP; c += 64) {
           const int jn = c / q;
-          double v = HI[c] + S[(c < P0) ? D::o_Cg + jn * N + (c - jn * q) : ZERO] * ih;   // HI is zero on padding columns
+          double v = HI[c] + S[(c < P0) ? D::w_Cg + jn * N + (c - jn * q) : ZERO] * ih;   // HI is zero on padding columns
           if constexpr (p > 0) {
             if (c >= P0 && c < IR) {
 #pragma unroll
-              for (int j = 0; j < CS; j++) v += S[D::o_Cg + j * N + q + (c - P0)] * ih;
+              for (int j = 0; j < CS; j++) v += S[D::w_Cg + j * N + q + (c - P0)] * ih;
             }
           }
           R2[IRP + c] = v;          // A-side row 1 / B-side row 0 share this copy
@@ -805,7 +849,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
                   const int o = chp[rt * (rt + 1) / 2 + ct][v];
                   if (o >= 0) {
 #pragma unroll
-                    for (int j = 0; j < CS; j++) val += S[D::o_CH + j * D::NH + o];
+                    for (int j = 0; j < CS; j++) val += S[D::w_CH + j * D::NZH + o];
                   }
                 }
                 acc[v] = val;
@@ -857,7 +901,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
               for (int k = 0; k < n; k++) {
                 double dj = 0.0;
                 for (int b = 0; b < N; b++)
-                  dj += S[D::o_IJ + (i * n + k) * N + b] * ((b < n) ? DIx[(i * n + b) * IRP + c] : DIc[(i * D::NCR + (b - n)) * IRP + c]);
+                  dj += S[ij_at(i, k, b)] * ((b < n) ? DIx[(i * n + b) * IRP + c] : DIc[(i * D::NCR + (b - n)) * IRP + c]);
                 v += lam[i * n + k] * ((h * tab.E[i]) * dj);
               }
           }

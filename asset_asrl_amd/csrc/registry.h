@@ -106,7 +106,7 @@ hipError_t launch_trap(int level, const EvalArgs& a, int cus, hipStream_t st) {
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::IR, ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::OR,                   \
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::NKKT, G,                                                           \
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::lds_bytes(),                                                       \
-      size_t(::asset_hip::Dims<ODE, CSV, (BLK != 0)>::SLOT),                                                      \
+      size_t(::asset_hip::Dims<ODE, CSV, (BLK != 0)>::WSLOT),                                                      \
       &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr};                                                \
   static ::asset_hip::Registrar reg_##ODE##_##CSV##_##BLK(&entry_##ODE##_##CSV##_##BLK);
 

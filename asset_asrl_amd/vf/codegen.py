@@ -276,6 +276,20 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     o.append(f"  static constexpr int XV = {d.xv}, UV = {d.uv}, PV = {d.pv}, NIN = {N};")
     o.append(f"  static constexpr int NNZ_J = {st['nnz_J']}, NNZ_H = {st['nnz_H_lower']};")
     o.append(f"  static constexpr const char* name() {{ return \"{d.name}\"; }}")
+    # structural sparsity: compact position of every J (row-major) / H (packed lower) entry or -1, and its inverse.
+    # The LGL workspace stores only the non-zeros; the dense accessors ignore these tables.
+    z = G.zero
+    jnz = [k * N + i for k in range(n) for i in range(N) if d.J[k][i] is not z]
+    hnz = [i * (i + 1) // 2 + j for i in range(N) for j in range(i + 1) if d.H[i][j] is not z]
+    jpos = {e: c for c, e in enumerate(jnz)}
+    hpos = {e: c for c, e in enumerate(hnz)}
+    def arr(name, vals):
+        vals = list(vals) or [0]
+        return f"  static constexpr short {name}[{len(vals)}] = {{{', '.join(str(v) for v in vals)}}};"
+    o.append(arr("JPOS", [jpos.get(e, -1) for e in range(n * N)]))
+    o.append(arr("HPOS", [hpos.get(e, -1) for e in range(N * (N + 1) // 2)]))
+    o.append(arr("JIDX", jnz))
+    o.append(arr("HIDX", hnz))
     sigs = [
         ("f", "template <class In, class Out> __host__ __device__ static inline void f(const In& in, Out& out)"),
         ("fj", "template <class In, class Out> __host__ __device__ static inline void fj(const In& in, Out& out)"),
