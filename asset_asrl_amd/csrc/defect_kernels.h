@@ -171,7 +171,7 @@ struct OdeOut {  // routes every derivative entry to its LDS slot (J row-major n
 // LDS-address-space pointer: stores through it are ds_write (tracked by lgkmcnt only), never flat
 typedef __attribute__((address_space(3))) double lds_double;
 
-template <class D>
+template <class D, bool ACCG = false>
 struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H non-zeros -> this lane's LDS staging row [J | H]
   using JP = std::conditional_t<D::STAGED, lds_double*, double*>;
   double* f_;
@@ -179,10 +179,15 @@ struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H non-zeros -
   JP J_;
   JP H_;
   double* sv_ = nullptr;
+  const double* lamv_ = nullptr;                       // ACCG: multipliers of this point's defect rows ...
+  double gacc_[ACCG ? D::N : 1];                       // ... and g^ = J^^T lam accumulated while J is emitted (fj has no g)
   __device__ void f(int k, double v) { f_[k] = v; }
   __device__ void J(int k, int i, double v) {          // (k, i) are literals in the generated bodies: the lookup folds
     const int c = D::ode_t::JPOS[k * D::N + i];
-    if (c >= 0) J_[c] = v;
+    if (c >= 0) {
+      J_[c] = v;
+      if constexpr (ACCG) gacc_[i] += lamv_[k] * v;
+    }
   }
   __device__ void g(int i, double v) { g_[i] = v; }
   __device__ void H(int i, int j, double v) {
@@ -248,14 +253,18 @@ __device__ __attribute__((noinline)) void interior_eval(double* S, int i, const 
 #pragma unroll
   for (int k = 0; k < p; k++) y[q + k] = z[D::P0 + k];
 #pragma unroll
-  for (int k = 0; k < n; k++) li[k] = (LEVEL >= 2) ? S[D::w_lam + i * n + k] : 0.0;
+  for (int k = 0; k < n; k++) li[k] = (LEVEL >= 1) ? S[D::w_lam + i * n + k] : 0.0;
   RegIn<D> in{y, li};
-  OdeOutStaged<D> out{S + D::w_If + i * n, S + D::w_Ig + i * N, stage_or<D>(row, S + D::w_IJ + i * D::NZJ),
-                      stage_or<D>(row + D::NZJ, S + D::w_IH + i * D::NZH)};
+  OdeOutStaged<D, LEVEL == 1> out{S + D::w_If + i * n, S + D::w_Ig + i * N, stage_or<D>(row, S + D::w_IJ + i * D::NZJ),
+                                  stage_or<D>(row + D::NZJ, S + D::w_IH + i * D::NZH)};
   (void)K;
   if constexpr (LEVEL == 0) Ode::f(in, out);
-  else if constexpr (LEVEL == 1) Ode::fj(in, out);
-  else Ode::fjgh(in, out);
+  else if constexpr (LEVEL == 1) {
+    out.lamv_ = li;
+    Ode::fj(in, out);
+#pragma unroll
+    for (int b = 0; b < N; b++) S[D::w_Ig + i * N + b] = out.gacc_[b];   // adjoint gradient of the point, for D5
+  } else Ode::fjgh(in, out);
 }
 
 template <class Ode, class D>
@@ -352,8 +361,19 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
   const int lane = threadIdx.x;
   const int lr = lane & 15, lk = lane >> 4;
   // the scheme's weight tables are read with lane-dependent indices all over the kernel: keep them in LDS
-  for (int e = lane; e < D::TABSZ; e += 64) tabL[e] = reinterpret_cast<const double*>(&d_lgl_tab[CS - 2])[e];
-  wave_lds_sync();
+  // (ODE stage: the copy is finished just before its first use in P2, so its latency hides behind P0 / P1)
+  constexpr int NTAB = (D::TABSZ + 63) / 64;
+  double tabv[NTAB];
+#pragma unroll
+  for (int t = 0; t < NTAB; t++)
+    tabv[t] = (lane + 64 * t < D::TABSZ) ? reinterpret_cast<const double*>(&d_lgl_tab[CS - 2])[lane + 64 * t] : 0.0;
+  auto publish_tables = [&]() {
+#pragma unroll
+    for (int t = 0; t < NTAB; t++)
+      if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
+    wave_lds_sync();
+  };
+  if constexpr (STAGE != 1) publish_tables();
   const LglTab& tab = *reinterpret_cast<const LglTab*>(tabL);
 
   // this workgroup's share of the mesh: contiguous, balanced (same rule as IndexingData.h:117-146)
@@ -376,15 +396,14 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
   constexpr int ZERO = D::WSLOTD + D::s_Z0;
   // slot offset of dfdy_j[r][cc] / dfdy^_i[k][b] for run-time indices (the rare paths; table lookups)
   auto cj_at = [](int j, int r, int cc) { const int jp = Ode::JPOS[r * N + cc]; return jp >= 0 ? D::w_CJ + j * D::NZJ + jp : ZERO; };
-  auto ij_at = [](int i, int k, int b) { const int jp = Ode::JPOS[k * N + b]; return jp >= 0 ? D::w_IJ + i * D::NZJ + jp : ZERO; };
-  (void)cj_at; (void)ij_at;
+  (void)cj_at;
   int bo[D::MT][KS], bst[D::MT][KS];                       // B fragment of [hE H^ | E g^]: offset for i = 0 and stride in i
   int cho[LEVEL >= 2 ? D::NTH : 1][4];                     // cardinal Hessian entry feeding accumulator (tile, v)
   int chp[(LEVEL >= 2 && p > 0) ? D::NTH : 1][4];          // parameter-parameter entry (summed over the cardinal nodes) or -1
   int jo[D::TJ][K][KS];                                    // (hE J^)^T fragment
   int avb[KS], avs[KS];                                    // DI_i^T fragment: offset in the dense scratch for i = 0, stride in i
   int cjo[n];                                              // dfdy_j[r][cc] of this lane's block column (D1)
-  int hst[LEVEL >= 2 ? D::NTH : 1][4], jst[D::TI * D::TJ][4];   // KKT slot of accumulator entry (tile, v) or -1
+  int hst[D::NTH][4], jst[D::TI * D::TJ][4];   // KKT slot of accumulator entry (tile, v) or -1
   double tB[CS], tD[CS], tC[CS], tE = 0.0;                 // weights of the row (i,r) this lane owns in the time-column pass
   if constexpr (STAGE == 2 && LEVEL >= 1) {
 #pragma unroll
@@ -450,12 +469,12 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
           const int jr = 16 * jt + lr;
           jst[ct * D::TJ + jt][v] = (c < IR && jr < OR) ? cst + (IR - c) + jr : -1;
         }
-        if constexpr (LEVEL >= 2) {
 #pragma unroll
-          for (int rt = ct; rt < D::TI; rt++) {
-            const int r = 16 * rt + lr, tix = rt * (rt + 1) / 2 + ct;
-            const bool ok = (c < IR && r < IR && r >= c);
-            hst[tix][v] = ok ? cst + (r - c) : -1;
+        for (int rt = ct; rt < D::TI; rt++) {
+          const int r = 16 * rt + lr, tix = rt * (rt + 1) / 2 + ct;
+          const bool ok = (c < IR && r < IR && r >= c);
+          hst[tix][v] = ok ? cst + (r - c) : -1;
+          if constexpr (LEVEL >= 2) {
             int ch = ZERO, cp = -1;
             if (ok) {
               if (c < P0) {
@@ -543,6 +562,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
     wave_mem_sync();
 
     TS();
+    if (g0 == 0) publish_tables();
     // ------------------------------------------------------------------ P2: interior points
     for (int e0 = 0; e0 < gcount * K; e0 += LC) {
       const int e = e0 + lane;
@@ -896,14 +916,13 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
           double v = 0.0;
           if constexpr (LEVEL >= 2) {
             v = h * HI[c];
-          } else {                                       // no Hessian pass: interior part from J^ directly
+          } else {                                       // no M product: g^_i = J^_i^T lam_i comes from the ODE stage
+#pragma unroll
             for (int i = 0; i < K; i++)
-              for (int k = 0; k < n; k++) {
-                double dj = 0.0;
-                for (int b = 0; b < N; b++)
-                  dj += S[ij_at(i, k, b)] * ((b < n) ? DIx[(i * n + b) * IRP + c] : DIc[(i * D::NCR + (b - n)) * IRP + c]);
-                v += lam[i * n + k] * ((h * tab.E[i]) * dj);
-              }
+#pragma unroll
+              for (int b = 0; b < N; b++)
+                v += ((h * tab.E[i]) * S[D::w_Ig + i * N + b]) *
+                     ((b < n) ? DIx[(i * n + b) * IRP + c] : DIc[(i * D::NCR + (b - n)) * IRP + c]);
           }
 #pragma unroll
           for (int jr = 0; jr < OR; jr++) v += lam[jr] * DC[jr * D::LDC + c];
@@ -919,7 +938,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
         // stores: off-diagonal H tiles are complete, a diagonal tile's entry v is kept when r >= c (lr >= lk + 4v),
         // a J tile's when its defect row exists (lr < OR - 16jt); padded sizes add the c < IR / r < IR tests.
         constexpr bool CFULL = (IR == IRP);
-        if constexpr (LEVEL >= 2) {
+        auto hval = [&](int tix, int v) { if constexpr (LEVEL >= 2) return accH[tix][v]; else return 0.0; };
+        {                                                  // Jacobian-only kinds write the Hessian slots as zero
 #pragma unroll
           for (int rt = 0; rt < D::TI; rt++)
 #pragma unroll
@@ -927,7 +947,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
               const int tix = rt * (rt + 1) / 2 + ct;
               if (CFULL || 16 * rt + lr < IR) {            // columns of a tile left of the diagonal are always < IR
 #pragma unroll
-                for (int v = 0; v < 4; v++) dst[hst[tix][v]] = accH[tix][v];
+                for (int v = 0; v < 4; v++) dst[hst[tix][v]] = hval(tix, v);
               }
             }
 #pragma unroll
@@ -936,7 +956,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
 #pragma unroll
               for (int t = 0; t < D::TI; t++) {
                 const int tix = t * (t + 1) / 2 + t;
-                if (CFULL || t + 1 < D::TI || 16 * t + lr < IR) dst[hst[tix][v]] = accH[tix][v];
+                if (CFULL || t + 1 < D::TI || 16 * t + lr < IR) dst[hst[tix][v]] = hval(tix, v);
               }
             }
           }
@@ -953,16 +973,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
                   dst[jst[ct * D::TJ + jt][v]] = accJ[ct * D::TJ + jt][v];
           }
         }
-        }
-        if constexpr (LEVEL < 2) {                       // Jacobian-only kinds: the Hessian slots are written as zero
-          for (int k = lane; k < D::NKKT; k += 64) {
-            int lo = 0, hi = IR - 1;
-            while (lo < hi) {
-              const int mid = (lo + hi + 1) >> 1;
-              if (mid * (IR + OR) - mid * (mid - 1) / 2 <= k) lo = mid; else hi = mid - 1;
-            }
-            if (k - (lo * (IR + OR) - lo * (lo - 1) / 2) < IR - lo) dst[k] = 0.0;
-          }
         }
       }
       wave_lds_sync();  // the next segment rewrites the DI / M / DC tiles

@@ -21,6 +21,7 @@ Two printers share the same node schedule:
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Sequence, Tuple
 
@@ -88,7 +89,7 @@ def _cnum(v: float) -> str:
     return f"({s})" if v < 0 else s
 
 
-LEVEL_ORDER = True   # device functors: breadth-first statement order (see _Printer)
+LEVEL_ORDER = os.environ.get("ASSET_LEVEL_ORDER", "1") == "1"   # breadth-first statement schedule (experiment switch)
 
 TRANSCENDENTAL = ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "asin", "acos", "atan",
                   "atan2", "powr")
