@@ -343,7 +343,9 @@ __device__ inline void copy_rows(const double* stage, int stg_ld, int npt, int e
 // They are separate launches because their resource shapes differ: the ODE bodies need ~250 VGPRs and wide LDS
 // staging rows, the dense phase needs few registers and 23 KiB of LDS, so it runs at a higher occupancy.
 template <class Ode, int CS, bool BLOCKED, int G, int LEVEL, int STAGE>
-__global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET_ODE_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
+__global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
+                                                   ? ASSET_DENSE_WAVES_PER_SIMD : 1)   // LDS-bound to one wave per SIMD anyway: take the registers
+                                             : ASSET_ODE_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
   using D = Dims<Ode, CS, BLOCKED>;
   constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0;
   constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, ORP = D::ORP, NP = D::NP, KS = D::KS;
@@ -839,8 +841,36 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
       }
 
       // ---- D4: H (lower-triangle tiles) and J^T
-      d4 accH[LEVEL >= 2 ? D::NTH : 1];
-      d4 accJ[D::TI * D::TJ];
+      // Small shapes keep every accumulator tile until D6 (the stores then share a handful of lane-condition
+      // branches); wide ones store each tile as it completes -- holding them all would spill.
+#ifndef ASSET_HOLD_TILES
+#define ASSET_HOLD_TILES 6
+#endif
+      constexpr bool HOLD = (D::NTH + D::TI * D::TJ) <= ASSET_HOLD_TILES;
+      constexpr bool CFULL = (IR == IRP);
+      d4 accH[(LEVEL >= 2 && HOLD) ? D::NTH : 1];
+      d4 accJ[HOLD ? D::TI * D::TJ : 1];
+      double* const kkt_dst = a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr;
+      auto store_H_tile = [&](int rt, int ct, const d4& acc) {   // entry v: row r = 16rt + lr, column c = 16ct + lk + 4v
+        const int tix = rt * (rt + 1) / 2 + ct;
+        if (rt > ct) {
+          if (CFULL || 16 * rt + lr < IR) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) kkt_dst[hst[tix][v]] = acc[v];
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+            if (lr >= lk + 4 * v && (CFULL || rt + 1 < D::TI || 16 * rt + lr < IR)) kkt_dst[hst[tix][v]] = acc[v];
+        }
+      };
+      auto store_J_tile = [&](int jt, int ct, const d4& acc) {   // entry v: defect row 16jt + lr, column c
+        if (16 * jt + lr < OR) {
+#pragma unroll
+          for (int v = 0; v < 4; v++)
+            if (CFULL || ct + 1 < D::TI || 16 * ct + lk + 4 * v < IR) kkt_dst[jst[ct * D::TJ + jt][v]] = acc[v];
+        }
+      };
       if constexpr (LEVEL >= 2) {
         // rank-2 time fragments: k=0 -> (A: d, B: HT), k=1 -> (A: HT, B: d), k=2,3 -> 0
         double a2[D::TI], b2[D::TI];
@@ -880,7 +910,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
             for (int i = 0; i < K; i++)
 #pragma unroll
               for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bm[i][kk], acc, 0, 0, 0);
-            accH[rt * (rt + 1) / 2 + ct] = acc;
+            if constexpr (HOLD) accH[rt * (rt + 1) / 2 + ct] = acc;
+            else if (kkt_dst) store_H_tile(rt, ct, acc);
           }
         }
       }
@@ -904,7 +935,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
           for (int i = 0; i < K; i++)
 #pragma unroll
             for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bj[i][kk], acc, 0, 0, 0);
-          accJ[ct * D::TJ + jt] = acc;
+          if constexpr (HOLD) accJ[ct * D::TJ + jt] = acc;
+          else if (kkt_dst) store_J_tile(jt, ct, acc);
         }
       }
       }
@@ -933,11 +965,19 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
       // ---- D6: store.  Entry (v) of a tile held by this lane: block column c = 16*ct + lk + 4v,
       //      row (H) r = 16*rt + lr or (J) jr = 16*jt + lr; 16 consecutive lanes cover 128 contiguous bytes.
       if (a.KKT) {
-        double* dst = a.KKT + seg * size_t(D::NKKT);
+        double* dst = kkt_dst;
+        if constexpr (!HOLD) {
+          if constexpr (LEVEL < 2) {                       // Jacobian-only kinds write the Hessian slots as zero
+            const d4 zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int rt = 0; rt < D::TI; rt++)
+#pragma unroll
+              for (int ct = 0; ct <= rt; ct++) store_H_tile(rt, ct, zero);
+          }
+        } else {
         // Lanes are grouped by the condition that makes their entry a KKT slot, so a handful of branches cover all
         // stores: off-diagonal H tiles are complete, a diagonal tile's entry v is kept when r >= c (lr >= lk + 4v),
         // a J tile's when its defect row exists (lr < OR - 16jt); padded sizes add the c < IR / r < IR tests.
-        constexpr bool CFULL = (IR == IRP);
         auto hval = [&](int tix, int v) { if constexpr (LEVEL >= 2) return accH[tix][v]; else return 0.0; };
         {                                                  // Jacobian-only kinds write the Hessian slots as zero
 #pragma unroll
@@ -961,7 +1001,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? ASSET_DENSE_WAVES_PER_SIMD : ASSET
             }
           }
         }
-        {
 #pragma unroll
         for (int jt = 0; jt < D::TJ; jt++) {
           if (16 * jt + lr < OR) {
