@@ -40,6 +40,7 @@ SYMBOLS = {
     "asset_hip_ode_name": (C.c_char_p, [C.c_int]),
     "asset_hip_ode_sizes": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "asset_hip_has_kernel": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
+    "asset_hip_load_plugin": (C.c_int, [C.c_char_p]),
     "asset_hip_lgl_table": (C.c_int, [C.c_int, C.c_char_p, _dp, C.c_int]),
     "asset_hip_device_count": (C.c_int, []),
     "asset_hip_last_error": (C.c_char_p, []),

@@ -8,6 +8,8 @@
 #include <string>
 
 #include "../../include/asset_hip.h"
+#include <dlfcn.h>
+
 #include "registry.h"
 
 namespace {
@@ -103,6 +105,29 @@ int asset_hip_ode_sizes(const char* ode, int* xv, int* uv, int* pv) {
       return 0;
     }
   return fail(ASSET_HIP_ENOODE, std::string("unknown ODE '") + ode + "'");
+}
+
+int asset_hip_load_plugin(const char* path) {
+  if (!path) return fail(ASSET_HIP_EINVAL, "null plugin path");
+  void* so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!so) return fail(ASSET_HIP_EINVAL, std::string("dlopen failed: ") + dlerror());
+  using entries_fn = asset_hip::KernelEntry* (*)();
+  auto fn = reinterpret_cast<entries_fn>(dlsym(so, "asset_hip_plugin_entries"));
+  if (!fn) {
+    dlclose(so);
+    return fail(ASSET_HIP_EINVAL, std::string(path) + " does not export asset_hip_plugin_entries");
+  }
+  int added = 0;
+  for (asset_hip::KernelEntry* e = fn(); e;) {   // the plugin stays loaded: its entries and device code live in it
+    asset_hip::KernelEntry* nx = e->next;
+    if (!find_entry(e->ode, e->mode, e->blocked)) {
+      e->next = asset_hip::registry_head();
+      asset_hip::registry_head() = e;
+      added++;
+    }
+    e = nx;
+  }
+  return added;
 }
 
 int asset_hip_has_kernel(const char* ode, int mode, int blocked) {

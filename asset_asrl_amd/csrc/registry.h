@@ -24,6 +24,24 @@ struct KernelEntry {
   KernelEntry* next;
 };
 
+#if defined(ASSET_PLUGIN)
+// A plugin (one run-time compiled translation unit, see asset_asrl_amd/jit.py) collects its entries in a list of
+// its own and exports it through asset_hip_plugin_entries(); asset_hip_load_plugin() splices it into the registry
+// of libasset_hip.so.  Nothing here touches the host library's symbols, so the plugin needs no link against it.
+namespace {
+KernelEntry* g_plugin_head = nullptr;
+}
+struct Registrar {
+  explicit Registrar(KernelEntry* e) {
+    e->next = g_plugin_head;
+    g_plugin_head = e;
+  }
+};
+#define ASSET_PLUGIN_EXPORT()                                                                            \
+  extern "C" __attribute__((visibility("default"))) ::asset_hip::KernelEntry* asset_hip_plugin_entries() { \
+    return ::asset_hip::g_plugin_head;                                                                   \
+  }
+#else
 inline KernelEntry*& registry_head() {
   static KernelEntry* head = nullptr;
   return head;
@@ -35,6 +53,7 @@ struct Registrar {
     registry_head() = e;
   }
 };
+#endif
 
 template <class Ode, int CS, bool BLOCKED, int G>
 hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {

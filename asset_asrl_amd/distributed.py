@@ -43,8 +43,8 @@ class ShardedDefectEvaluator:
             self.IR, self.OR, self.NKKT = self.ev.IR, self.ev.OR, self.ev.NKKT
         else:
             from .build import dims
-            from . import synth
-            d = dims(*synth.ODE_SIZES[ode], synth.MODE_CS[mode] if isinstance(mode, str) else max(mode, 2), blocked)
+            from . import _lib, synth
+            d = dims(*_lib.ode_sizes(ode), synth.MODE_CS[mode] if isinstance(mode, str) else max(mode, 2), blocked)
             self.IR, self.OR, self.NKKT = d["IR"], d["OR"], d["NKKT"]
 
     # ---- local evaluation ------------------------------------------------------------------

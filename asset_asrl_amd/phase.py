@@ -16,7 +16,7 @@ from typing import Sequence
 
 import numpy as np
 
-from . import _lib, synth
+from . import _lib, jit, synth
 from .evaluator import (CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, DefectEvaluator, unpack_kkt_block)
 from .indexing import PhaseIndexer
 
@@ -148,13 +148,8 @@ class Phase:
     def transcribe(self):
         if self.ActiveTraj is None:
             raise RuntimeError("No trajectory set: call setTraj first")
-        name = self.ode.ode_name
-        mode_id = _lib.MODES[self.TranscriptionMode]
-        if not _lib.has_kernel(name, mode_id, self._blocked()):
-            raise _lib.AssetHipError(
-                f"no device code for ODE '{name}' with {self.TranscriptionMode}"
-                f"{' BlockConstant' if self._blocked() else ''}: only the ODE functors compiled into libasset_hip.so "
-                f"are available ({_lib.ode_names()}); there is no CPU fallback")
+        # library ODEs are compiled into libasset_hip.so; any other ODEBase gets device code on first use (jit.py)
+        name = jit.ensure_kernel(self.ode, self.TranscriptionMode, self._blocked())
         ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
         ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
         ix.begin_indexing(0, 0)
@@ -176,7 +171,8 @@ class Phase:
         return self._ev
 
     def get_defect(self) -> DefectFunction:
-        return DefectFunction(self.ode.ode_name, self.TranscriptionMode, self._blocked(), self.device)
+        name = jit.ensure_kernel(self.ode, self.TranscriptionMode, self._blocked())
+        return DefectFunction(name, self.TranscriptionMode, self._blocked(), self.device)
 
     # ---- the reference's built-in benchmark of the path ---------------------------------------------
     def test_threads(self, i: int = 1, j: int = 1, n: int = 100, verbose: bool = True):

@@ -33,9 +33,10 @@ ODE_SIZES: Dict[str, Tuple[int, int, int]] = {
 }
 
 
-def _states(name: str, rng: np.random.Generator, nnodes: int):
-    """Returns (X[nnodes,xv], U[nnodes,uv], P[pv]) in well-conditioned ranges."""
-    xv, uv, pv = ODE_SIZES[name]
+def _states(name: str, rng: np.random.Generator, nnodes: int, sizes=None):
+    """Returns (X[nnodes,xv], U[nnodes,uv], P[pv]) in well-conditioned ranges.  ``sizes`` = (xv, uv, pv) describes
+    an ODE outside the config table (user-defined): states/controls ~ U(-1,1), parameters ~ U(0.5,1.5)."""
+    xv, uv, pv = sizes if sizes is not None else ODE_SIZES[name]
     u = rng.uniform
     if name == "brachistochrone":
         X = np.column_stack([u(0, 10, nnodes), u(0, 10, nnodes), u(0.5, 10, nnodes)])
@@ -64,19 +65,21 @@ def _states(name: str, rng: np.random.Generator, nnodes: int):
         X = u(-1, 1, (nnodes, 32))
         U = np.zeros((nnodes, 0))
         P = np.zeros(0)
+    elif sizes is not None:
+        X, U, P = u(-1, 1, (nnodes, xv)), u(-1, 1, (nnodes, uv)), u(0.5, 1.5, pv)
     else:
         raise KeyError(name)
     assert X.shape[1] == xv and U.shape[1] == uv and P.size == pv
     return X, U, P
 
 
-def make_traj(name: str, mode: str, nseg: int, seed: int = SEED, T: float = 10.0) -> np.ndarray:
+def make_traj(name: str, mode: str, nseg: int, seed: int = SEED, T: float = 10.0, sizes=None) -> np.ndarray:
     """Trajectory ``[nnodes, xv+1+uv+pv]`` in the reference's ``setTraj`` row layout [x,t,u,p]."""
     cs = MODE_CS[mode]
     K = cs - 1
     nnodes = K * nseg + 1
     rng = np.random.default_rng(seed)
-    X, U, P = _states(name, rng, nnodes)
+    X, U, P = _states(name, rng, nnodes, sizes)
     h0 = T / nseg
     t = np.empty(nnodes)
     for j in range(K):

@@ -97,6 +97,12 @@ int asset_hip_num_odes(void);
 const char* asset_hip_ode_name(int i);                           /* NULL when i is out of range            */
 int asset_hip_ode_sizes(const char* ode, int* xv, int* uv, int* pv);
 int asset_hip_has_kernel(const char* ode, int mode, int blocked);
+/* Adds the (ode, mode, blocked) kernels of a run-time compiled plugin (a shared object built from the generated
+ * functor of a user ODE, asset_asrl_amd/jit.py) to the table asset_hip_defect_create() searches.  This is where a
+ * user-defined ODE enters: the reference accepts any VectorFunction as ODE right-hand side (ODE.h:128-187,
+ * GenericODESBuildPart1-6.cpp); here its expression graph is differentiated, printed as a device functor and
+ * compiled for gfx950 on first use.  Returns the number of kernels added (>= 0) or a negative ASSET_HIP_E* code. */
+int asset_hip_load_plugin(const char* path);
 /* collocation weight tables: which in {"tc","s","A","B","U","C","D","E"}; out receives cs or (cs-1) or
  * (cs-1)*cs doubles (row = interior point).  Returns the count written or <0. */
 int asset_hip_lgl_table(int cs, const char* which, double* out, int cap);

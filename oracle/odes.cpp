@@ -57,6 +57,7 @@ AD2_ODE(reentry, 5, 2, 0)
 AD2_ODE(twobody_lt, 6, 3, 0)
 AD2_ODE(betts_lowthrust, 7, 3, 1)
 AD2_ODE(synthetic32, 32, 0, 0)
+AD2_ODE(vanderpol, 2, 1, 1)
 
 }  // namespace
 
@@ -79,6 +80,7 @@ GEN_DECL(reentry)
 GEN_DECL(twobody_lt)
 GEN_DECL(betts_lowthrust)
 GEN_DECL(synthetic32)
+GEN_DECL(vanderpol)
 
 extern "C" {
 
@@ -104,6 +106,7 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(twobody_lt, 6, 3, 0, nullptr)
   TRY(betts_lowthrust, 7, 3, 1, nullptr)
   TRY(synthetic32, 32, 0, 0, g_synth32)
+  TRY(vanderpol, 2, 1, 1, nullptr)
   return -1;
 }
 }

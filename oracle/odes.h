@@ -33,6 +33,16 @@ void brachistochrone(const S* y, S* f, const void*) {
   f[2] = g * cos(theta);
 }
 
+// ------------------------------------------------------------------ forced Van der Pol with parameter (2,1,1)
+// Not a BASELINE config: the independent check for ODEs that reach the device through run-time compilation
+// (tests/test_gpu_jit.py defines the same right-hand side in the product's expression DSL).
+template <class S>
+void vanderpol(const S* y, S* f, const void*) {
+  const S &x0 = y[0], &x1 = y[1], &t = y[2], &u = y[3], &mu = y[4];
+  f[0] = x1;
+  f[1] = mu * (1.0 - x0 * x0) * x1 - x0 + u * exp(-0.1 * t);
+}
+
 // ------------------------------------------------------------------ shuttle reentry (5,2,0)
 template <class S>
 void reentry(const S* y, S* f, const void*) {

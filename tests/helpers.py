@@ -11,11 +11,11 @@ class Workload:
     """A synthetic phase: solver vector X, multipliers L and the defect index tables."""
 
     def __init__(self, ode: str, mode: str, nseg: int, blocked: bool = False, seed: int = synth.SEED,
-                 var_offset: int = 0, con_offset: int = 0, extra_vars: int = 0):
-        xv, uv, pv = synth.ODE_SIZES[ode]
+                 var_offset: int = 0, con_offset: int = 0, extra_vars: int = 0, sizes=None):
+        xv, uv, pv = sizes if sizes is not None else synth.ODE_SIZES[ode]
         self.ode, self.mode, self.nseg, self.blocked = ode, mode, nseg, bool(blocked) and uv > 0
         self.cs = synth.MODE_CS[mode]
-        self.traj = synth.make_traj(ode, mode, nseg, seed=seed)
+        self.traj = synth.make_traj(ode, mode, nseg, seed=seed, sizes=sizes)
         ix = PhaseIndexer(xv, uv, pv, 0)
         ix.set_dimensions(self.cs, nseg, self.blocked)
         ix.begin_indexing(var_offset, con_offset)
@@ -38,3 +38,21 @@ class Workload:
 def rel_err(a, b, floor=1.0):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.max(np.abs(a - b)) / max(floor, float(np.max(np.abs(b)))))
+
+
+def make_vanderpol():
+    """A user-defined ODE (not compiled into libasset_hip.so): forced Van der Pol oscillator with one control and one
+    parameter, x0' = x1, x1' = mu (1 - x0^2) x1 - x0 + u exp(-t/10).  The oracle holds the same right-hand side as
+    ``vanderpol`` (oracle/odes.h), differentiated independently by AD2."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+
+    class VanDerPol(ODEBase):
+        def __init__(self):
+            a = ODEArguments(2, 1, 1)
+            x0, x1 = a.XVec().tolist()
+            u, mu, t = a.UVar(0), a.PVar(0), a.TVar()
+            super().__init__(vf.stack([x1, mu * (1.0 - x0 * x0) * x1 - x0 + u * vf.exp(-0.1 * t)]), 2, 1, 1,
+                             name="vanderpol")
+
+    return VanDerPol()

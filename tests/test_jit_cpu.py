@@ -1,0 +1,38 @@
+"""Run-time compilation of a user-defined ODE (asset_asrl_amd/jit.py): code generation, hipcc cross-compile for
+gfx950 and plugin registration all work without a GPU; the numerical check lives in test_gpu_jit.py."""
+import pytest
+
+from asset_asrl_amd import _lib, jit, vf
+from asset_asrl_amd.ode import ODEArguments, ODEBase, ShuttleReentry
+from helpers import make_vanderpol
+
+
+def test_user_ode_gets_device_code_on_first_use():
+    ode = make_vanderpol()
+    name = jit.device_name(ode)
+    assert name.startswith("vanderpol_") and name not in ("vanderpol",)
+    assert jit.ensure_kernel(ode, "LGL5", False) == name          # compiles (or finds the cached plugin) and registers
+    assert _lib.has_kernel(name, _lib.LGL5, False)
+    assert not _lib.has_kernel(name, _lib.LGL7, False)              # only what was asked for
+    assert _lib.ode_sizes(name) == (2, 1, 1)
+    assert name in _lib.ode_names()
+    assert jit.ensure_kernel(ode, "Trapezoidal", True) == name     # BlockConstant control form
+    assert _lib.has_kernel(name, _lib.TRAPEZOIDAL, True)
+    assert jit.ensure_kernel(make_vanderpol(), "LGL5", False) == name   # same maths -> same device name, nothing rebuilt
+
+
+def test_device_name_follows_the_dynamics_not_the_class_name():
+    a = ODEArguments(2, 1, 1)
+    x0, x1 = a.XVec().tolist()
+    other = ODEBase(vf.stack([x1, 2.0 * a.PVar(0) * x1 - x0 + a.UVar(0)]), 2, 1, 1, name="vanderpol")
+    assert jit.device_name(other) != jit.device_name(make_vanderpol())
+
+
+def test_library_odes_keep_their_names_and_are_not_recompiled():
+    assert jit.device_name(ShuttleReentry()) == "reentry"
+    assert jit.ensure_kernel(ShuttleReentry(), "LGL7", False) == "reentry"
+
+
+def test_load_plugin_rejects_a_non_plugin():
+    rc = _lib.lib().asset_hip_load_plugin(_lib.LIB_PATH.encode())
+    assert rc < 0 and b"asset_hip_plugin_entries" in _lib.lib().asset_hip_last_error()
