@@ -6,10 +6,12 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/asset_hip.h"
 #include <dlfcn.h>
 
+#include "assembly_kernels.h"
 #include "registry.h"
 
 namespace {
@@ -58,6 +60,11 @@ struct asset_hip_defect {
   // staging for the host-pointer entry point (allocated lazily)
   double *d_X = nullptr, *d_L = nullptr, *d_fx = nullptr, *d_agx = nullptr, *d_kkt = nullptr;
   double* d_work = nullptr;  // per-workgroup ODE result slots
+  // on-device KKT assembly (asset_hip_defect_set_kkt_map)
+  int32_t* d_map = nullptr;        // [nseg*NKKT] value location of every block slot (encoding: assembly_kernels.h)
+  double* d_values = nullptr;      // [value_hi - value_lo) staging for the host-pointer entry point
+  double* h_values = nullptr;      // pinned mirror of d_values
+  long long value_lo = 0, value_hi = 0, nvalues = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -215,8 +222,9 @@ void asset_hip_defect_destroy(asset_hip_defect_t h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->d_vindex, (void*)h->d_cindex, (void*)h->d_X, (void*)h->d_L, (void*)h->d_fx,
-                  (void*)h->d_agx, (void*)h->d_kkt, (void*)h->d_work})
+                  (void*)h->d_agx, (void*)h->d_kkt, (void*)h->d_work, (void*)h->d_map, (void*)h->d_values})
     if (p) (void)hipFree(p);
+  if (h->h_values) (void)hipHostFree(h->h_values);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -305,6 +313,103 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
   if (kkt && level >= 1 && what >= ASSET_HIP_JAC)
     HIP_TRY(hipMemcpyAsync(kkt, h->d_kkt, sizeof(double) * nkkt, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- on-device assembly
+
+int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locations, long long nvalues) {
+  if (!h || !slot_locations || nvalues <= 0) return fail(ASSET_HIP_EINVAL, "bad kkt map arguments");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nslots = size_t(h->nseg) * h->ke->nkkt;
+  long long lo = nvalues, hi = 0;
+  for (size_t i = 0; i < nslots; i++) {
+    const long long m = slot_locations[i];
+    if (m < 0 || m >= nvalues) return fail(ASSET_HIP_ERANGE, "kkt slot location outside [0, nvalues)");
+    lo = m < lo ? m : lo;
+    hi = m + 1 > hi ? m + 1 : hi;
+  }
+  // slots that share a value location are added atomically: count the uses of every location once, here
+  std::vector<unsigned char> uses(size_t(hi - lo), 0);
+  for (size_t i = 0; i < nslots; i++) {
+    unsigned char& u = uses[size_t(slot_locations[i] - lo)];
+    if (u < 2) u++;
+  }
+  std::vector<int32_t> map(nslots);
+  for (size_t i = 0; i < nslots; i++) {
+    const int32_t m = slot_locations[i];
+    map[i] = uses[size_t(m - lo)] > 1 ? -(m + 2) : m;
+  }
+  if (!h->d_map) HIP_TRY(hipMalloc(&h->d_map, nslots * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(h->d_map, map.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (h->d_values && (hi - lo) != (h->value_hi - h->value_lo)) {
+    (void)hipFree(h->d_values);
+    (void)hipHostFree(h->h_values);
+    h->d_values = nullptr, h->h_values = nullptr;
+  }
+  h->value_lo = lo, h->value_hi = hi, h->nvalues = nvalues;
+  return 0;
+}
+
+static int scatter(asset_hip_defect_t h, const double* d_blocks, double* d_values_base, hipStream_t st) {
+  const size_t nslots = size_t(h->nseg) * h->ke->nkkt;
+  const int block = 256;
+  size_t grid = (nslots + block - 1) / block;
+  const size_t cap = size_t(h->cus) * 16;            // grid-stride: a few resident workgroups per CU
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL(asset_hip::kkt_scatter_kernel, dim3((unsigned)grid), dim3(block), 0, st, d_blocks, h->d_map, nslots,
+                     d_values_base);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hipfail(e, "kkt_scatter_kernel launch");
+  return 0;
+}
+
+int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
+                                           double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_values,
+                                           void* stream) {
+  if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
+  if (what < ASSET_HIP_JAC) return fail(ASSET_HIP_EINVAL, "assembled evaluation needs a kind that produces KKT entries");
+  if (!h->d_map) return fail(ASSET_HIP_EINVAL, "no kkt map: call asset_hip_defect_set_kkt_map first");
+  if (!d_kkt_values) return fail(ASSET_HIP_EINVAL, "kkt value array is null");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  if (!h->d_kkt) HIP_TRY(hipMalloc(&h->d_kkt, sizeof(double) * size_t(h->nseg) * h->ke->nkkt));
+  int rc = launch(h, what, dX, dL, d_fx_blocks, d_agx_blocks, h->d_kkt, st);
+  if (rc) return rc;
+  return scatter(h, h->d_kkt, d_kkt_values, st);
+}
+
+int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double* X, const double* L,
+                                    double* fx_blocks, double* agx_blocks, double* kkt_values) {
+  if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
+  if (!X || !kkt_values) return fail(ASSET_HIP_EINVAL, "X / kkt value array is null");
+  if (what < ASSET_HIP_JAC) return fail(ASSET_HIP_EINVAL, "assembled evaluation needs a kind that produces KKT entries");
+  if (!h->d_map) return fail(ASSET_HIP_EINVAL, "no kkt map: call asset_hip_defect_set_kkt_map first");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t nfx = size_t(h->nseg) * h->ke->orr, nagx = size_t(h->nseg) * h->ke->ir;
+  const size_t nval = size_t(h->value_hi - h->value_lo);
+  if (!h->d_X) HIP_TRY(hipMalloc(&h->d_X, sizeof(double) * h->n_primal));
+  if (!h->d_L) HIP_TRY(hipMalloc(&h->d_L, sizeof(double) * h->n_equal));
+  if (fx_blocks && !h->d_fx) HIP_TRY(hipMalloc(&h->d_fx, sizeof(double) * nfx));
+  if (agx_blocks && !h->d_agx) HIP_TRY(hipMalloc(&h->d_agx, sizeof(double) * nagx));
+  if (!h->d_values) {
+    HIP_TRY(hipMalloc(&h->d_values, sizeof(double) * nval));
+    HIP_TRY(hipHostMalloc(&h->h_values, sizeof(double) * nval, hipHostMallocDefault));
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_X, X, sizeof(double) * h->n_primal, hipMemcpyHostToDevice, h->stream));
+  if (L) HIP_TRY(hipMemcpyAsync(h->d_L, L, sizeof(double) * h->n_equal, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_values, 0, sizeof(double) * nval, h->stream));
+  // the device array covers [value_lo, value_hi) of the caller's: bias the base so that locations index it directly
+  int rc = asset_hip_defect_eval_assembled_device(h, what, h->d_X, L ? h->d_L : nullptr, fx_blocks ? h->d_fx : nullptr,
+                                                  agx_blocks ? h->d_agx : nullptr, h->d_values - h->value_lo, h->stream);
+  if (rc) return rc;
+  if (fx_blocks) HIP_TRY(hipMemcpyAsync(fx_blocks, h->d_fx, sizeof(double) * nfx, hipMemcpyDeviceToHost, h->stream));
+  if (agx_blocks && what != ASSET_HIP_JAC)
+    HIP_TRY(hipMemcpyAsync(agx_blocks, h->d_agx, sizeof(double) * nagx, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->h_values, h->d_values, sizeof(double) * nval, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double* dst = kkt_values + h->value_lo;            // accumulate, as the reference's fill does: O(nnz) contiguous adds
+  for (size_t i = 0; i < nval; i++) dst[i] += h->h_values[i];
   return 0;
 }
 

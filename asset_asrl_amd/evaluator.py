@@ -79,6 +79,39 @@ class DefectEvaluator:
                                                     _dptr(kkt)), "asset_hip_defect_eval")
         return fx, agx, kkt
 
+    # ---- on-device KKT assembly -----------------------------------
+    def set_kkt_map(self, slot_locations, nvalues: int):
+        """slot_locations[V, k] = KKTLocations[InnerKKTStarts[V] + k]: where block slot k of application V lives in the
+        solver's CSR value array of length ``nvalues`` (uploaded once per sparsity analysis)."""
+        m = np.ascontiguousarray(slot_locations, dtype=np.int32)
+        if m.size != self.nseg * self.NKKT:
+            raise ValueError(f"kkt map has {m.size} entries, expected nseg*NKKT = {self.nseg * self.NKKT}")
+        _lib.check(_lib.lib().asset_hip_defect_set_kkt_map(self._h, m.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                           int(nvalues)), "asset_hip_defect_set_kkt_map")
+        self._nvalues = int(nvalues)
+
+    def eval_assembled(self, what: int, X, L, kkt_values):
+        """Like :meth:`eval`, but the KKT entries are ADDED into ``kkt_values`` (the solver's value array) on the
+        device; returns (fx blocks, agx blocks or None)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        L = None if L is None else np.ascontiguousarray(L, dtype=np.float64)
+        if X.size != self.n_primal or (L is not None and L.size != self.n_equal):
+            raise ValueError("X / L size mismatch")
+        if (not isinstance(kkt_values, np.ndarray) or kkt_values.dtype != np.float64 or not kkt_values.flags.c_contiguous
+                or kkt_values.size != getattr(self, "_nvalues", -1)):
+            raise ValueError("kkt_values must be the contiguous float64 value array the map was built for")
+        fx = np.empty((self.nseg, self.OR))
+        agx = np.empty((self.nseg, self.IR)) if what in (JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+        _lib.check(_lib.lib().asset_hip_defect_eval_assembled(self._h, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx),
+                                                              _dptr(kkt_values)), "asset_hip_defect_eval_assembled")
+        return fx, agx
+
+    def eval_assembled_device(self, what: int, X, L, fx, agx, kkt_values, stream=None):
+        st = None if stream is None else C.c_void_p(stream if isinstance(stream, int) else stream.cuda_stream)
+        _lib.check(_lib.lib().asset_hip_defect_eval_assembled_device(self._h, what, self._p(X), self._p(L), self._p(fx),
+                                                                     self._p(agx), self._p(kkt_values), st),
+                   "asset_hip_defect_eval_assembled_device")
+
     # ---- device-pointer evaluation (torch tensors or raw ints) ------------------------------
     @staticmethod
     def _p(t):

@@ -111,14 +111,47 @@ void BatchedDefectConstraint::eval(int what, const double* X, const double* L, d
   if (data.NumAppl() != nappl_) throw std::invalid_argument("index data does not belong to this constraint");
   const bool want_agx = (what == ASSET_HIP_CON_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD_HESS);
   const bool want_kkt = what >= ASSET_HIP_JAC;
-  check(asset_hip_defect_eval(h_, what, X, L, fx_.data(), want_agx ? agx_.data() : nullptr,
-                              want_kkt ? kkt_.data() : nullptr),
-        "asset_hip_defect_eval");
+  const bool assembled = want_kkt && nvalues_ > 0;
+  if (assembled) {
+    ensure_kkt_map(KKTLocations, data);
+    check(asset_hip_defect_eval_assembled(h_, what, X, L, fx_.data(), want_agx ? agx_.data() : nullptr, KKTvals),
+          "asset_hip_defect_eval_assembled");
+  } else {
+    check(asset_hip_defect_eval(h_, what, X, L, fx_.data(), want_agx ? agx_.data() : nullptr,
+                                want_kkt ? kkt_.data() : nullptr),
+          "asset_hip_defect_eval");
+  }
   for (int V = 0; V < nappl_; V++) {  // callee overwrites its FX / AGX slots (fx.setZero(); compute)
     std::memcpy(FX + data.InnerConstraintStarts[V], fx_.data() + size_t(V) * or_, sizeof(double) * or_);
     if (want_agx) std::memcpy(AGX + data.InnerGradientStarts[V], agx_.data() + size_t(V) * ir_, sizeof(double) * ir_);
   }
-  if (want_kkt) scatter_kkt(kkt_.data(), nkkt_, ir_, or_, what == ASSET_HIP_JAC_ADJGRAD_HESS, KKTvals, KKTLocations, data);
+  if (want_kkt && !assembled)
+    scatter_kkt(kkt_.data(), nkkt_, ir_, or_, what == ASSET_HIP_JAC_ADJGRAD_HESS, KKTvals, KKTLocations, data);
+}
+
+void BatchedDefectConstraint::enable_device_assembly(long long nvalues) {
+  if (nvalues <= 0) throw std::invalid_argument("enable_device_assembly: the value array length must be positive");
+  nvalues_ = nvalues;
+  map_source_ = nullptr;
+}
+
+void BatchedDefectConstraint::ensure_kkt_map(const int* lpt, const SolverIndexingData& data) {
+  if (!lpt) throw std::invalid_argument("KKTLocations is null");
+  if (int(data.InnerKKTStarts.size()) != nappl_) throw std::invalid_argument("InnerKKTStarts not filled: call getKKTSpace first");
+  bool fresh = (lpt == map_source_) && map_.size() == size_t(nappl_) * nkkt_;
+  if (fresh) {  // same array: make sure the solver did not re-fill it in place (cheap sample, 64 slots)
+    const size_t n = map_.size(), step = n / 64 + 1;
+    for (size_t s = 0; s < n && fresh; s += step) {
+      const size_t V = s / nkkt_, k = s - V * nkkt_;
+      fresh = (map_[s] == lpt[data.InnerKKTStarts[V] + k]);
+    }
+  }
+  if (fresh) return;
+  map_.resize(size_t(nappl_) * nkkt_);
+  for (int V = 0; V < nappl_; V++)
+    std::memcpy(map_.data() + size_t(V) * nkkt_, lpt + data.InnerKKTStarts[V], sizeof(int) * nkkt_);
+  check(asset_hip_defect_set_kkt_map(h_, map_.data(), nvalues_), "asset_hip_defect_set_kkt_map");
+  map_source_ = lpt;
 }
 
 void BatchedDefectConstraint::constraints(const double* X, double* FX, const SolverIndexingData& data) {

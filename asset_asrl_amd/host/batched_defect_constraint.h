@@ -63,6 +63,15 @@ class BatchedDefectConstraint {
                                                            double* KKTvals, const int* KKTLocations,
                                                            const SolverIndexingData& data);
 
+  // On-device assembly: after this call the three Jacobian kinds add their KKT entries
+  // into KKTvals on the GPU (include/asset_hip.h, asset_hip_defect_eval_assembled) and the host-side scatter below
+  // is not used.  nvalues = KKTmat.nonZeros().  The slot -> value-location map is gathered from KKTLocations and
+  // data.InnerKKTStarts on the first evaluation and again whenever a different KKTLocations array (or a changed one,
+  // detected on a sample) is passed, i.e. after the solver re-analyses the sparsity.
+  void enable_device_assembly(long long nvalues);
+  void disable_device_assembly() { nvalues_ = 0; }
+  bool device_assembly() const { return nvalues_ > 0; }
+
   // block scatter (public so it can be checked on its own): KKTFillAll / KKTFillJac, DenseFunctionBase.h:1413-1523
   static void scatter_kkt(const double* kkt_blocks, int nkkt, int ir, int orr, bool dohess, double* KKTvals,
                           const int* KKTLocations, const SolverIndexingData& data);
@@ -74,6 +83,11 @@ class BatchedDefectConstraint {
   std::string ode_;
   int mode_, ir_ = 0, or_ = 0, nkkt_ = 0, nappl_ = 0;
   std::vector<double> fx_, agx_, kkt_;
+  // device assembly state
+  void ensure_kkt_map(const int* KKTLocations, const SolverIndexingData& data);
+  long long nvalues_ = 0;
+  const int* map_source_ = nullptr;
+  std::vector<int> map_;          // [nappl][nkkt] value location of every block slot
 };
 
 }  // namespace asset_hip_host

@@ -86,6 +86,26 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
 int asset_hip_defect_eval_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
                                  double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_blocks, void* stream);
 
+/* ---- on-device KKT assembly ----
+ * Replaces the function-side scatter of the reference, `mpt[KKTLocations[freeloc]] += value` over every slot of
+ * every application (VectorFunctions/DenseFunctionBase.h:1413-1466 KKTFillAll, :1468-1523 KKTFillJac; locations
+ * from Solvers/NonLinearProgram.cpp:316-330), and its column mutexes (KKTClashes / KKTLocks).
+ *
+ * asset_hip_defect_set_kkt_map: slot_locations[V*NKKT + k] = index in the solver's value array of block slot k of
+ * application V, i.e. KKTLocations[InnerKKTStarts[V] + k] (block slot order as documented above); nvalues = length of
+ * that value array.  Uploaded once per sparsity analysis; locations used by more than one slot are found here and
+ * added atomically on the device.
+ * asset_hip_defect_eval_assembled: host pointers; FX / AGX blocks as in asset_hip_defect_eval; kkt_values[nvalues] is
+ * ACCUMULATED into (the caller zeroes it per evaluation, PSIOPT.cpp:107) -- only the contiguous range of locations
+ * this constraint touches crosses PCIe and is added.  For ASSET_HIP_JAC / JAC_ADJGRAD the Hessian slots add zeros.
+ * asset_hip_defect_eval_assembled_device: everything resident in HBM, d_kkt_values[nvalues] accumulated into on
+ * `stream`, not synchronised. */
+int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locations, long long nvalues);
+int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double* X, const double* L, double* fx_blocks,
+                                    double* agx_blocks, double* kkt_values);
+int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
+                                           double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_values, void* stream);
+
 /* Measures the evaluation kernel itself: `iters` back-to-back device evaluations on the handle's stream
  * bracketed by HIP events (after `warmup` untimed ones); *ms_per_launch = elapsed / iters. */
 int asset_hip_defect_time_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,

@@ -166,9 +166,9 @@ class Nlp:
         self.nkkt = self.num_user_kkt // max(self.nappl, 1)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().oracle_nlp_destroy(self.h)
-            self.h = None
+        h, self.h = getattr(self, "h", None), None
+        if h and lib is not None:          # module globals are gone at interpreter exit
+            lib().oracle_nlp_destroy(h)
 
     def csr(self):
         outer = np.zeros(self.kkt_dim + 1, dtype=np.int32)

@@ -12,7 +12,7 @@ using namespace asset_hip_host;
 extern "C" int shim_run(const char* ode, int mode, int blocked, int ir, int orr, int nappl, const int* vindex,
                         const int* cindex, int primal, int equal, int what, const double* X, const double* L,
                         const int* kkt_locations, int* kkt_rows_out, int* kkt_cols_out, double* kkt_vals,
-                        double* FXE, double* AGX, char* err, int errcap) {
+                        double* FXE, double* AGX, char* err, int errcap, long long assembly_nvalues) {
   try {
     SolverIndexingData data;
     data.input_size = ir, data.output_size = orr, data.num_funcappl = nappl;
@@ -25,6 +25,7 @@ extern "C" int shim_run(const char* ode, int mode, int blocked, int ir, int orr,
     data.getConstraintSpace(fxrows.data(), cfree);
     con.getKKTSpace(kkt_rows_out, kkt_cols_out, kfree, primal, true, true, data);
     if (kfree != con.numKKTEles(true, true) * nappl) throw std::runtime_error("KKT space count mismatch");
+    if (assembly_nvalues > 0) con.enable_device_assembly(assembly_nvalues);   // KKT entries added on the GPU
     std::vector<double> fxc(size_t(orr) * nappl, 0.0), agxc(size_t(ir) * nappl, 0.0);
     switch (what) {
       case ASSET_HIP_CON: con.constraints(X, fxc.data(), data); break;

@@ -1,0 +1,79 @@
+"""On-device KKT assembly: blocks scattered into the solver's CSR value array on the GPU,
+checked against the oracle's restatement of NonLinearProgram::evalKKT / evalSOE (oracle/nlp.cpp), which performs
+the reference's indexed += on the host.  The sparsity analysis (CSR structure, KKTLocations) comes from the oracle,
+standing in for the host solver that owns it."""
+import numpy as np
+import pytest
+import torch
+
+from asset_asrl_amd import _lib
+from asset_asrl_amd.evaluator import JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, DefectEvaluator
+from helpers import Workload, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("reentry", "LGL7", 257, False),            # shared boundary nodes between adjacent segments
+    ("twobody_lt", "LGL5", 75, True),           # BlockConstant: per-segment control parameters
+    ("betts_lowthrust", "LGL5", 40, False),     # a phase parameter shared by every segment (many-way clash)
+    ("brachistochrone", "Trapezoidal", 33, False),
+]
+
+
+def _setup(oracle, ode, mode, nseg, blocked):
+    w = Workload(ode, mode, nseg, blocked, var_offset=3, con_offset=2, extra_vars=4)
+    nlp = w.oracle_nlp(oracle, threads=2)
+    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    locs = nlp.kkt_locations()[:nlp.num_user_kkt].reshape(w.nseg, ev.NKKT)
+    ev.set_kkt_map(locs, nlp.nnz)
+    return w, nlp, ev, locs
+
+
+@pytest.mark.parametrize("ode,mode,nseg,blocked", CASES)
+def test_assembled_values_match_host_scatter(oracle, ode, mode, nseg, blocked):
+    w, nlp, ev, locs = _setup(oracle, ode, mode, nseg, blocked)
+    assert np.unique(locs).size < locs.size                    # the case does exercise shared locations
+    for what in (JAC_ADJGRAD_HESS, JAC_ADJGRAD, JAC):
+        _, _, ref = nlp.eval(what, w.X, w.L)
+        base = np.random.default_rng(what).uniform(-1, 1, nlp.nnz)   # values other functions already added
+        vals = base.copy()
+        fx, agx = ev.eval_assembled(what, w.X, w.L if what != JAC else None, vals)
+        assert rel_err(vals - base, ref) < 1e-8
+        touched = np.zeros(nlp.nnz, bool)
+        touched[locs.ravel()] = True
+        np.testing.assert_array_equal(vals[~touched], base[~touched])     # nothing outside the constraint's slots moves
+        rfx, ragx, _ = nlp.eval_blocks(what, w.X, w.L)
+        assert np.abs(fx - rfx).max() < 1e-10 * max(1.0, np.abs(w.X).max())
+        if agx is not None:
+            assert rel_err(agx, ragx) < 1e-8
+    ev.close()
+
+
+def test_assembled_device_pointers_accumulate(oracle):
+    w, nlp, ev, _ = _setup(oracle, "reentry", "LGL7", 300, False)
+    dev = torch.device("cuda:0")
+    X, L = torch.from_numpy(w.X).to(dev), torch.from_numpy(w.L).to(dev)
+    fx = torch.zeros(w.nseg * ev.OR, dtype=torch.float64, device=dev)
+    agx = torch.zeros(w.nseg * ev.IR, dtype=torch.float64, device=dev)
+    vals = torch.zeros(nlp.nnz, dtype=torch.float64, device=dev)
+    for _ in range(2):                                         # two evaluations into the same array: it accumulates
+        ev.eval_assembled_device(JAC_ADJGRAD_HESS, X, L, fx, agx, vals)
+    torch.cuda.synchronize()
+    _, _, ref = nlp.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    assert rel_err(vals.cpu().numpy(), 2.0 * ref) < 1e-8
+    ev.close()
+
+
+def test_assembly_argument_errors(oracle):
+    w = Workload("brachistochrone", "LGL3", 8)
+    ev = DefectEvaluator("brachistochrone", "LGL3", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    with pytest.raises(ValueError):
+        ev.eval_assembled(JAC_ADJGRAD_HESS, w.X, w.L, np.zeros(10))
+    ev._nvalues = 10
+    with pytest.raises(_lib.AssetHipError, match="no kkt map"):
+        ev.eval_assembled(JAC_ADJGRAD_HESS, w.X, w.L, np.zeros(10))
+    bad = np.zeros((w.nseg, ev.NKKT), dtype=np.int32)
+    bad[3, 5] = 99
+    with pytest.raises(_lib.AssetHipError, match="outside"):
+        ev.set_kkt_map(bad, 50)
+    ev.close()

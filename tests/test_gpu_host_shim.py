@@ -24,7 +24,8 @@ def shim(tmp_path_factory):
 
 @pytest.mark.parametrize("ode,mode,blocked,nseg", [("reentry", "LGL7", False, 37), ("twobody_lt", "LGL5", True, 20),
                                                    ("betts_lowthrust", "LGL3", False, 9), ("reentry", "Trapezoidal", False, 11)])
-def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg):
+@pytest.mark.parametrize("device_assembly", [False, True])
+def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg, device_assembly):
     w = Workload(ode, mode, nseg, blocked, var_offset=2, con_offset=1, extra_vars=3)
     nlp = w.oracle_nlp(oracle, threads=1)
     locs = nlp.kkt_locations()
@@ -39,7 +40,8 @@ def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg):
                            w.vindex.ctypes.data_as(ip), w.cindex.ctypes.data_as(ip), w.n_primal, w.n_equal, what,
                            w.X.ctypes.data_as(dp), w.L.ctypes.data_as(dp), locs.ctypes.data_as(ip),
                            rows.ctypes.data_as(ip), cols.ctypes.data_as(ip), vals.ctypes.data_as(dp),
-                           FXE.ctypes.data_as(dp), AGX.ctypes.data_as(dp), err, 512)
+                           FXE.ctypes.data_as(dp), AGX.ctypes.data_as(dp), err, 512,
+                           C.c_longlong(nlp.nnz if device_assembly else 0))
         assert rc == 0, err.value
         # analyzeSparsity keeps every slot as (row >= col) and files it in CSR row `col` (NonLinearProgram.cpp:282-307)
         lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
