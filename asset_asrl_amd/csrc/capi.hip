@@ -61,7 +61,8 @@ struct asset_hip_defect {
   double *d_X = nullptr, *d_L = nullptr, *d_fx = nullptr, *d_agx = nullptr, *d_kkt = nullptr;
   double* d_work = nullptr;  // per-workgroup ODE result slots
   // on-device KKT assembly (asset_hip_defect_set_kkt_map)
-  int32_t* d_map = nullptr;        // [nseg*NKKT] value location of every block slot (encoding: assembly_kernels.h)
+  int32_t* d_map = nullptr;        // value location of every block slot, slot order or (fused kernels) fragment order
+  size_t map_len = 0;
   double* d_values = nullptr;      // [value_hi - value_lo) staging for the host-pointer entry point
   double* h_values = nullptr;      // pinned mirror of d_values
   long long value_lo = 0, value_hi = 0, nvalues = 0;
@@ -240,7 +241,7 @@ int asset_hip_defect_sizes(asset_hip_defect_t h, int* irows, int* orows, int* nk
 }
 
 static int launch(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx, double* dagx,
-                  double* dkkt, hipStream_t st) {
+                  double* dkkt, hipStream_t st, double* d_values = nullptr) {
   const int level = level_of(what);
   if (level < 0) return fail(ASSET_HIP_EINVAL, "unknown evaluation kind");
   if (!dX) return fail(ASSET_HIP_EINVAL, "X is null");
@@ -256,6 +257,7 @@ static int launch(asset_hip_defect_t h, int what, const double* dX, const double
   a.AGX = (what == ASSET_HIP_CON || what == ASSET_HIP_JAC) ? nullptr : dagx;
   a.KKT = (what >= ASSET_HIP_JAC) ? dkkt : nullptr;
   a.work = h->d_work;
+  if (d_values) a.kmap = h->d_map, a.values = d_values, a.KKT = nullptr;   // fused assembly (ke->fused_assembly)
   hipError_t e = h->ke->launch(level, a, h->cus, st);
   if (e != hipSuccess) return hipfail(e, "kernel launch");
   return 0;
@@ -318,7 +320,7 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
 
 // ---------------------------------------------------------------------------------------------- on-device assembly
 
-int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locations, long long nvalues) {
+int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locations, long long nvalues, int accumulate) {
   if (!h || !slot_locations || nvalues <= 0) return fail(ASSET_HIP_EINVAL, "bad kkt map arguments");
   HIP_TRY(hipSetDevice(h->device));
   const size_t nslots = size_t(h->nseg) * h->ke->nkkt;
@@ -329,19 +331,58 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
     lo = m < lo ? m : lo;
     hi = m + 1 > hi ? m + 1 : hi;
   }
-  // slots that share a value location are added atomically: count the uses of every location once, here
-  std::vector<unsigned char> uses(size_t(hi - lo), 0);
-  for (size_t i = 0; i < nslots; i++) {
-    unsigned char& u = uses[size_t(slot_locations[i] - lo)];
-    if (u < 2) u++;
+  // a location used by exactly one slot is stored to, one that several slots share is added to atomically
+  // (encoding: assembly_kernels.h); in accumulate mode every slot adds
+  std::vector<unsigned char> uses(accumulate ? 0 : size_t(hi - lo), 0);
+  if (!accumulate)
+    for (size_t i = 0; i < nslots; i++) {
+      unsigned char& u = uses[size_t(slot_locations[i] - lo)];
+      if (u < 2) u++;
+    }
+  auto encode = [&](int32_t m) { return (accumulate || uses[size_t(m - lo)] > 1) ? -(m + 2) : m; };
+  std::vector<int32_t> map;
+  if (h->ke->fused_assembly) {
+    // fragment order of the LGL dense stage (defect_kernels.h, ASM): for every segment (4*tiles) rows of 64 lanes;
+    // lane (lr = l & 15, lk = l >> 4), entry v of an accumulator tile is block column c = 16ct + lk + 4v and row
+    // r = 16rt + lr (H, lower-triangle tiles first, tix = rt(rt+1)/2 + ct) or defect row jr = 16jt + lr
+    // (J, tile ct*TJ + jt); -1 where that entry is no KKT slot.
+    const int IR = h->ke->ir, OR = h->ke->orr, NK = h->ke->nkkt;
+    const int TI = (IR + 15) / 16, TJ = (OR + 15) / 16, NTH = TI * (TI + 1) / 2, NF = (NTH + TI * TJ) * 4;
+    std::vector<int32_t> slot_of(size_t(NF) * 64, -1);
+    for (int l = 0; l < 64; l++) {
+      const int lr = l & 15, lk = l >> 4;
+      for (int ct = 0; ct < TI; ct++)
+        for (int v = 0; v < 4; v++) {
+          const int c = 16 * ct + lk + 4 * v;
+          if (c >= IR) continue;
+          const int cst = c * (IR + OR) - c * (c - 1) / 2;   // first slot of block column c
+          for (int rt = ct; rt < TI; rt++) {
+            const int r = 16 * rt + lr;
+            if (r < IR && r >= c) slot_of[size_t((rt * (rt + 1) / 2 + ct) * 4 + v) * 64 + l] = cst + (r - c);
+          }
+          for (int jt = 0; jt < TJ; jt++) {
+            const int jr = 16 * jt + lr;
+            if (jr < OR) slot_of[size_t((NTH + ct * TJ + jt) * 4 + v) * 64 + l] = cst + (IR - c) + jr;
+          }
+        }
+    }
+    map.resize(size_t(h->nseg) * NF * 64);
+    for (int V = 0; V < h->nseg; V++) {
+      const int32_t* loc = slot_locations + size_t(V) * NK;
+      int32_t* dst = map.data() + size_t(V) * NF * 64;
+      for (size_t e = 0; e < size_t(NF) * 64; e++) dst[e] = slot_of[e] < 0 ? -1 : encode(loc[slot_of[e]]);
+    }
+  } else {
+    map.resize(nslots);
+    for (size_t i = 0; i < nslots; i++) map[i] = encode(slot_locations[i]);
   }
-  std::vector<int32_t> map(nslots);
-  for (size_t i = 0; i < nslots; i++) {
-    const int32_t m = slot_locations[i];
-    map[i] = uses[size_t(m - lo)] > 1 ? -(m + 2) : m;
+  if (h->d_map && h->map_len != map.size()) {
+    (void)hipFree(h->d_map);
+    h->d_map = nullptr;
   }
-  if (!h->d_map) HIP_TRY(hipMalloc(&h->d_map, nslots * sizeof(int32_t)));
-  HIP_TRY(hipMemcpy(h->d_map, map.data(), nslots * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!h->d_map) HIP_TRY(hipMalloc(&h->d_map, map.size() * sizeof(int32_t)));
+  h->map_len = map.size();
+  HIP_TRY(hipMemcpy(h->d_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   if (h->d_values && (hi - lo) != (h->value_hi - h->value_lo)) {
     (void)hipFree(h->d_values);
     (void)hipHostFree(h->h_values);
@@ -373,6 +414,8 @@ int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const
   if (!d_kkt_values) return fail(ASSET_HIP_EINVAL, "kkt value array is null");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  if (h->ke->fused_assembly)   // the dense stage adds its accumulators into the value array itself
+    return launch(h, what, dX, dL, d_fx_blocks, d_agx_blocks, nullptr, st, d_kkt_values);
   if (!h->d_kkt) HIP_TRY(hipMalloc(&h->d_kkt, sizeof(double) * size_t(h->nseg) * h->ke->nkkt));
   int rc = launch(h, what, dX, dL, d_fx_blocks, d_agx_blocks, h->d_kkt, st);
   if (rc) return rc;

@@ -54,6 +54,10 @@ struct EvalArgs {
   double* AGX;         // [nseg x IR] blocks or null
   double* KKT;         // [nseg x NKKT] blocks or null
   double* work;        // [grid][G][SLOT] per-workgroup ODE result slots (L2-resident scratch in HBM)
+  // on-device assembly (dense stage, ASM kernels): KKT entries are added into values[kmap[seg*NKKT + slot]]
+  // instead of being stored as blocks (DenseFunctionBase.h:1413-1523 KKTFillAll / KKTFillJac)
+  const int* kmap = nullptr;
+  double* values = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------- sizes
@@ -342,7 +346,7 @@ __device__ inline void copy_rows(const double* stage, int stg_ld, int npt, int e
 // STAGE 1: ODE phases only (P0-P3; results -> workspace slot of every segment).  STAGE 2: dense phase only (P4).
 // They are separate launches because their resource shapes differ: the ODE bodies need ~250 VGPRs and wide LDS
 // staging rows, the dense phase needs few registers and 23 KiB of LDS, so it runs at a higher occupancy.
-template <class Ode, int CS, bool BLOCKED, int G, int LEVEL, int STAGE>
+template <class Ode, int CS, bool BLOCKED, int G, int LEVEL, int STAGE, bool ASM = false>
 __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
                                                    ? ASSET_DENSE_WAVES_PER_SIMD : 1)   // LDS-bound to one wave per SIMD anyway: take the registers
                                              : ASSET_ODE_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
@@ -850,10 +854,39 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
       constexpr bool CFULL = (IR == IRP);
       d4 accH[(LEVEL >= 2 && HOLD) ? D::NTH : 1];
       d4 accJ[HOLD ? D::TI * D::TJ : 1];
-      double* const kkt_dst = a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr;
+      // Where an entry goes: its slot of the segment's KKT block, or (ASM) the solver's value array through the
+      // slot -> location map.  The map entries of a tile are loaded before its product so the stores never wait for
+      // them; locations several slots share (boundary nodes of neighbouring segments, phase parameters) take a
+      // no-return f64 atomic, the others a plain store (10 M atomics per evaluation measured ~65 us on their own).
+      // ASM: the map is stored in fragment order -- entry (f, lane) of a segment, f = 4*tile + v with the H tiles
+      // first -- so a lane reads its own locations with coalesced loads and needs no slot arithmetic; -1 marks an
+      // accumulator entry that is no KKT slot (upper triangle of a diagonal tile, padding).
+      constexpr int NFRAG = (D::NTH + D::TI * D::TJ) * 4;
+      double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr);
+      const int* const kmap_seg = ASM ? a.kmap + seg * size_t(NFRAG) * 64 + lane : nullptr;
+      int hmap[ASM ? D::NTH : 1][4], jmap[ASM ? D::TI * D::TJ : 1][4];
+      auto load_hmap = [&](int tix) {
+        if constexpr (ASM) {
+#pragma unroll
+          for (int v = 0; v < 4; v++) hmap[tix][v] = kmap_seg[(tix * 4 + v) * 64];
+        }
+      };
+      auto load_jmap = [&](int t) {
+        if constexpr (ASM) {
+#pragma unroll
+          for (int v = 0; v < 4; v++) jmap[t][v] = kmap_seg[((D::NTH + t) * 4 + v) * 64];
+        }
+      };
+      auto put_asm = [&](int off, double val) {           // map encoding: assembly_kernels.h
+        if (off >= 0) kkt_dst[off] = val;                  // location owned by this slot alone
+        else if (off != -1) unsafeAtomicAdd(kkt_dst + (-(off + 2)), val);   // shared: global_atomic_add_f64, no return
+      };
       auto store_H_tile = [&](int rt, int ct, const d4& acc) {   // entry v: row r = 16rt + lr, column c = 16ct + lk + 4v
         const int tix = rt * (rt + 1) / 2 + ct;
-        if (rt > ct) {
+        if constexpr (ASM) {
+#pragma unroll
+          for (int v = 0; v < 4; v++) put_asm(hmap[tix][v], acc[v]);
+        } else if (rt > ct) {
           if (CFULL || 16 * rt + lr < IR) {
 #pragma unroll
             for (int v = 0; v < 4; v++) kkt_dst[hst[tix][v]] = acc[v];
@@ -865,12 +898,23 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
         }
       };
       auto store_J_tile = [&](int jt, int ct, const d4& acc) {   // entry v: defect row 16jt + lr, column c
-        if (16 * jt + lr < OR) {
+        if constexpr (ASM) {
+#pragma unroll
+          for (int v = 0; v < 4; v++) put_asm(jmap[ct * D::TJ + jt][v], acc[v]);
+        } else if (16 * jt + lr < OR) {
 #pragma unroll
           for (int v = 0; v < 4; v++)
             if (CFULL || ct + 1 < D::TI || 16 * ct + lk + 4 * v < IR) kkt_dst[jst[ct * D::TJ + jt][v]] = acc[v];
         }
       };
+      if constexpr (ASM) {                                 // all of the segment's map entries, ahead of the products
+        if constexpr (LEVEL >= 2) {
+#pragma unroll
+          for (int tix = 0; tix < D::NTH; tix++) load_hmap(tix);
+        }
+#pragma unroll
+        for (int t = 0; t < D::TI * D::TJ; t++) load_jmap(t);
+      }
       if constexpr (LEVEL >= 2) {
         // rank-2 time fragments: k=0 -> (A: d, B: HT), k=1 -> (A: HT, B: d), k=2,3 -> 0
         double a2[D::TI], b2[D::TI];
@@ -964,10 +1008,9 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
 
       // ---- D6: store.  Entry (v) of a tile held by this lane: block column c = 16*ct + lk + 4v,
       //      row (H) r = 16*rt + lr or (J) jr = 16*jt + lr; 16 consecutive lanes cover 128 contiguous bytes.
-      if (a.KKT) {
-        double* dst = kkt_dst;
+      if (kkt_dst) {
         if constexpr (!HOLD) {
-          if constexpr (LEVEL < 2) {                       // Jacobian-only kinds write the Hessian slots as zero
+          if constexpr (LEVEL < 2 && !ASM) {               // Jacobian-only kinds write the Hessian slots as zero
             const d4 zero = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int rt = 0; rt < D::TI; rt++)
@@ -979,7 +1022,19 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
         // stores: off-diagonal H tiles are complete, a diagonal tile's entry v is kept when r >= c (lr >= lk + 4v),
         // a J tile's when its defect row exists (lr < OR - 16jt); padded sizes add the c < IR / r < IR tests.
         auto hval = [&](int tix, int v) { if constexpr (LEVEL >= 2) return accH[tix][v]; else return 0.0; };
-        {                                                  // Jacobian-only kinds write the Hessian slots as zero
+        if constexpr (ASM) {
+          if constexpr (LEVEL >= 2) {
+#pragma unroll
+            for (int rt = 0; rt < D::TI; rt++)
+#pragma unroll
+              for (int ct = 0; ct <= rt; ct++) store_H_tile(rt, ct, accH[rt * (rt + 1) / 2 + ct]);
+          }
+#pragma unroll
+          for (int jt = 0; jt < D::TJ; jt++)
+#pragma unroll
+            for (int ct = 0; ct < D::TI; ct++) store_J_tile(jt, ct, accJ[ct * D::TJ + jt]);
+        } else {
+        if constexpr (true) {                // Jacobian-only kinds write the Hessian slots as zero (adding zeros: skipped)
 #pragma unroll
           for (int rt = 0; rt < D::TI; rt++)
 #pragma unroll
@@ -987,7 +1042,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
               const int tix = rt * (rt + 1) / 2 + ct;
               if (CFULL || 16 * rt + lr < IR) {            // columns of a tile left of the diagonal are always < IR
 #pragma unroll
-                for (int v = 0; v < 4; v++) dst[hst[tix][v]] = hval(tix, v);
+                for (int v = 0; v < 4; v++) kkt_dst[hst[tix][v]] = hval(tix, v);
               }
             }
 #pragma unroll
@@ -996,7 +1051,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
 #pragma unroll
               for (int t = 0; t < D::TI; t++) {
                 const int tix = t * (t + 1) / 2 + t;
-                if (CFULL || t + 1 < D::TI || 16 * t + lr < IR) dst[hst[tix][v]] = hval(tix, v);
+                if (CFULL || t + 1 < D::TI || 16 * t + lr < IR) kkt_dst[hst[tix][v]] = hval(tix, v);
               }
             }
           }
@@ -1009,8 +1064,9 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
 #pragma unroll
               for (int v = 0; v < 4; v++)
                 if (CFULL || ct + 1 < D::TI || 16 * ct + lk + 4 * v < IR)
-                  dst[jst[ct * D::TJ + jt][v]] = accJ[ct * D::TJ + jt][v];
+                  kkt_dst[jst[ct * D::TJ + jt][v]] = accJ[ct * D::TJ + jt][v];
           }
+        }
         }
         }
       }

@@ -22,6 +22,7 @@ struct KernelEntry {
   // level 0/1/2 ; returns hipError_t
   hipError_t (*launch)(int level, const EvalArgs& a, int cus, hipStream_t st);
   KernelEntry* next;
+  bool fused_assembly = false;   // launch() honours EvalArgs::kmap / values (dense stage adds into the value array itself)
 };
 
 #if defined(ASSET_PLUGIN)
@@ -73,9 +74,11 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   static const int env_b = std::getenv("ASSET_HIP_GRID_B") ? std::atoi(std::getenv("ASSET_HIP_GRID_B")) : 0;  // tuning only
   if (env_b > 0) grid_b = env_b < a.nseg ? env_b : a.nseg;
   static const bool skip_dense = std::getenv("ASSET_HIP_SKIP_DENSE") != nullptr;                               // tuning only
-#define ASSET_LAUNCH(LV, STG, GRID, BYTES)                                                                        \
+#define ASSET_LAUNCH(LV, STG, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, CS, BLOCKED, G, LV, STG, false>), GRID, BYTES)
+#define ASSET_LAUNCH_ASM(LV, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, CS, BLOCKED, G, LV, 2, true>), GRID, BYTES)
+#define ASSET_LAUNCH_K(KERN, GRID, BYTES)                                                                         \
   do {                                                                                                            \
-    auto kern = lgl_defect_kernel<Ode, CS, BLOCKED, G, LV, STG>;                                                  \
+    auto kern = KERN;                                                                                             \
     if (BYTES > 64 * 1024) {                                                                                      \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(BYTES));                 \
@@ -87,10 +90,22 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   } while (0)
   switch (level) {
     case 0: ASSET_LAUNCH(0, 1, grid_a, bytes_ode); return hipSuccess;
-    case 1: ASSET_LAUNCH(1, 1, grid_a, bytes_ode); if (!skip_dense) ASSET_LAUNCH(1, 2, grid_b, bytes_dense); return hipSuccess;
-    case 2: ASSET_LAUNCH(2, 1, grid_a, bytes_ode); if (!skip_dense) ASSET_LAUNCH(2, 2, grid_b, bytes_dense); return hipSuccess;
+    case 1:
+      ASSET_LAUNCH(1, 1, grid_a, bytes_ode);
+      if (skip_dense) return hipSuccess;
+      if (a.kmap) ASSET_LAUNCH_ASM(1, grid_b, bytes_dense);   // KKT entries added straight into the solver's value array
+      else ASSET_LAUNCH(1, 2, grid_b, bytes_dense);
+      return hipSuccess;
+    case 2:
+      ASSET_LAUNCH(2, 1, grid_a, bytes_ode);
+      if (skip_dense) return hipSuccess;
+      if (a.kmap) ASSET_LAUNCH_ASM(2, grid_b, bytes_dense);
+      else ASSET_LAUNCH(2, 2, grid_b, bytes_dense);
+      return hipSuccess;
   }
 #undef ASSET_LAUNCH
+#undef ASSET_LAUNCH_ASM
+#undef ASSET_LAUNCH_K
   return hipErrorInvalidValue;
 }
 
@@ -126,7 +141,7 @@ hipError_t launch_trap(int level, const EvalArgs& a, int cus, hipStream_t st) {
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::NKKT, G,                                                           \
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::lds_bytes(),                                                       \
       size_t(::asset_hip::Dims<ODE, CSV, (BLK != 0)>::WSLOT),                                                      \
-      &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr};                                                \
+      &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr, true};                                          \
   static ::asset_hip::Registrar reg_##ODE##_##CSV##_##BLK(&entry_##ODE##_##CSV##_##BLK);
 
 }  // namespace asset_hip

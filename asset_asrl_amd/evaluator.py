@@ -80,14 +80,17 @@ class DefectEvaluator:
         return fx, agx, kkt
 
     # ---- on-device KKT assembly -----------------------------------
-    def set_kkt_map(self, slot_locations, nvalues: int):
+    def set_kkt_map(self, slot_locations, nvalues: int, accumulate: bool = False):
         """slot_locations[V, k] = KKTLocations[InnerKKTStarts[V] + k]: where block slot k of application V lives in the
-        solver's CSR value array of length ``nvalues`` (uploaded once per sparsity analysis)."""
+        solver's CSR value array of length ``nvalues`` (uploaded once per sparsity analysis).  ``accumulate``: the
+        device-pointer evaluation adds into whatever the value array holds (all atomics) instead of expecting zeros
+        at this constraint's locations."""
         m = np.ascontiguousarray(slot_locations, dtype=np.int32)
         if m.size != self.nseg * self.NKKT:
             raise ValueError(f"kkt map has {m.size} entries, expected nseg*NKKT = {self.nseg * self.NKKT}")
         _lib.check(_lib.lib().asset_hip_defect_set_kkt_map(self._h, m.ctypes.data_as(C.POINTER(C.c_int32)),
-                                                           int(nvalues)), "asset_hip_defect_set_kkt_map")
+                                                           int(nvalues), int(accumulate)),
+                   "asset_hip_defect_set_kkt_map")
         self._nvalues = int(nvalues)
 
     def eval_assembled(self, what: int, X, L, kkt_values):

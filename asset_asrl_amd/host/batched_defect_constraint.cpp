@@ -150,7 +150,7 @@ void BatchedDefectConstraint::ensure_kkt_map(const int* lpt, const SolverIndexin
   map_.resize(size_t(nappl_) * nkkt_);
   for (int V = 0; V < nappl_; V++)
     std::memcpy(map_.data() + size_t(V) * nkkt_, lpt + data.InnerKKTStarts[V], sizeof(int) * nkkt_);
-  check(asset_hip_defect_set_kkt_map(h_, map_.data(), nvalues_), "asset_hip_defect_set_kkt_map");
+  check(asset_hip_defect_set_kkt_map(h_, map_.data(), nvalues_, 0), "asset_hip_defect_set_kkt_map");
   map_source_ = lpt;
 }
 

@@ -93,14 +93,18 @@ int asset_hip_defect_eval_device(asset_hip_defect_t h, int what, const double* d
  *
  * asset_hip_defect_set_kkt_map: slot_locations[V*NKKT + k] = index in the solver's value array of block slot k of
  * application V, i.e. KKTLocations[InnerKKTStarts[V] + k] (block slot order as documented above); nvalues = length of
- * that value array.  Uploaded once per sparsity analysis; locations used by more than one slot are found here and
- * added atomically on the device.
+ * that value array.  Uploaded once per sparsity analysis.  accumulate = 0: locations used by a single slot are found
+ * here and written with plain stores, the shared ones (boundary nodes of adjacent segments, phase parameters) with
+ * f64 atomics -- the device array must hold zeros at this constraint's locations on entry and then holds the
+ * constraint's contributions.  accumulate = 1: every slot is added atomically, a true += into whatever the array
+ * holds (about 2x the evaluation time).
  * asset_hip_defect_eval_assembled: host pointers; FX / AGX blocks as in asset_hip_defect_eval; kkt_values[nvalues] is
- * ACCUMULATED into (the caller zeroes it per evaluation, PSIOPT.cpp:107) -- only the contiguous range of locations
- * this constraint touches crosses PCIe and is added.  For ASSET_HIP_JAC / JAC_ADJGRAD the Hessian slots add zeros.
- * asset_hip_defect_eval_assembled_device: everything resident in HBM, d_kkt_values[nvalues] accumulated into on
- * `stream`, not synchronised. */
-int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locations, long long nvalues);
+ * ACCUMULATED into (the caller zeroes it per evaluation, PSIOPT.cpp:107) -- the contributions are summed in a zeroed
+ * device array first, then the contiguous range of locations this constraint touches crosses PCIe and is added.
+ * For ASSET_HIP_JAC / JAC_ADJGRAD the Hessian slots contribute nothing.
+ * asset_hip_defect_eval_assembled_device: everything resident in HBM; d_kkt_values[nvalues] receives the entries
+ * as the map's mode prescribes, on `stream`, not synchronised. */
+int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locations, long long nvalues, int accumulate);
 int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double* X, const double* L, double* fx_blocks,
                                     double* agx_blocks, double* kkt_values);
 int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,

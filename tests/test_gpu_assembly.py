@@ -20,12 +20,12 @@ CASES = [
 ]
 
 
-def _setup(oracle, ode, mode, nseg, blocked):
+def _setup(oracle, ode, mode, nseg, blocked, accumulate=False):
     w = Workload(ode, mode, nseg, blocked, var_offset=3, con_offset=2, extra_vars=4)
     nlp = w.oracle_nlp(oracle, threads=2)
     ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
     locs = nlp.kkt_locations()[:nlp.num_user_kkt].reshape(w.nseg, ev.NKKT)
-    ev.set_kkt_map(locs, nlp.nnz)
+    ev.set_kkt_map(locs, nlp.nnz, accumulate)
     return w, nlp, ev, locs
 
 
@@ -49,8 +49,24 @@ def test_assembled_values_match_host_scatter(oracle, ode, mode, nseg, blocked):
     ev.close()
 
 
+@pytest.mark.parametrize("mode", ["LGL7", "Trapezoidal"])
+def test_assembled_device_pointers(oracle, mode):
+    """Default map: the device array holds zeros at the constraint's locations and receives its contributions."""
+    w, nlp, ev, _ = _setup(oracle, "reentry", mode, 300, False)
+    dev = torch.device("cuda:0")
+    X, L = torch.from_numpy(w.X).to(dev), torch.from_numpy(w.L).to(dev)
+    fx = torch.zeros(w.nseg * ev.OR, dtype=torch.float64, device=dev)
+    agx = torch.zeros(w.nseg * ev.IR, dtype=torch.float64, device=dev)
+    vals = torch.zeros(nlp.nnz, dtype=torch.float64, device=dev)
+    ev.eval_assembled_device(JAC_ADJGRAD_HESS, X, L, fx, agx, vals)
+    torch.cuda.synchronize()
+    _, _, ref = nlp.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    assert rel_err(vals.cpu().numpy(), ref) < 1e-8
+    ev.close()
+
+
 def test_assembled_device_pointers_accumulate(oracle):
-    w, nlp, ev, _ = _setup(oracle, "reentry", "LGL7", 300, False)
+    w, nlp, ev, _ = _setup(oracle, "reentry", "LGL7", 300, False, accumulate=True)
     dev = torch.device("cuda:0")
     X, L = torch.from_numpy(w.X).to(dev), torch.from_numpy(w.L).to(dev)
     fx = torch.zeros(w.nseg * ev.OR, dtype=torch.float64, device=dev)
