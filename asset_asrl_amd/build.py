@@ -87,7 +87,7 @@ def generate(verbose=True):
     for name, cls in ODE_LIBRARY.items():
         ode = cls()
         sn = _struct_name(name)
-        hdr = "#pragma once\n#include <math.h>\n" + emit_hip_functor(ode.derivatives(), sn)
+        hdr = "#pragma once\n#include <math.h>\n#include \"../asset_math.h\"\n" + emit_hip_functor(ode.derivatives(), sn)
         _write_if_changed(os.path.join(GEN, f"ode_{name}.h"), hdr)
         xv, uv, pv = ode.XVars(), ode.UVars(), ode.PVars()
         # one translation unit per (transcription, control mode): they compile in parallel

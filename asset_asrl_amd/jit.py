@@ -70,7 +70,8 @@ def ensure_kernel(ode, mode: str, blocked: bool) -> str:
         raise _lib.AssetHipError(f"ODE '{ode.ode_name}' ({xv},{uv},{pv}) with {mode}: per-segment working set exceeds "
                                  "one CU's LDS; no kernel can be instantiated")
     sname = "Ode_" + _ident(name)
-    hdr = "#pragma once\n#include <math.h>\n" + emit_hip_functor(d, sname)
+    hdr = ("#pragma once\n#include <math.h>\n#include \"" + os.path.join(build.CSRC, "asset_math.h") + "\"\n"
+           + emit_hip_functor(d, sname))
     tag = f"{mode.lower()}_{int(blocked)}"
     src = (f'#include "ode.h"\n#include "{os.path.join(build.CSRC, "registry.h")}"\n'
            + reg.replace("{S}", sname) + "\nASSET_PLUGIN_EXPORT()\n")

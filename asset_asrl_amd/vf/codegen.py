@@ -159,6 +159,7 @@ class _Printer:
         self.used_y = set()
         self.used_l = set()
         self.yname, self.lname = yname, lname
+        self.device_math = pair_sincos      # device functors: csrc/asset_math.h trig (short argument reduction)
         loaded = loaded or {}
         order = _topo_stop(roots, set(loaded))
         if level_order:
@@ -192,7 +193,7 @@ class _Printer:
                 other = partner[n.id]
                 k = len(self.lines)
                 sn, cn = f"t{k}s", f"t{k}c"
-                self.lines.append(f"double {sn}, {cn}; sincos({self.ref(n.args[0])}, &{sn}, &{cn});")
+                self.lines.append(f"double {sn}, {cn}; asset_sincos({self.ref(n.args[0])}, &{sn}, &{cn});")
                 self.names[n.id] = sn if n.op == "sin" else cn
                 self.names[other.id] = cn if n.op == "sin" else sn
                 continue
@@ -232,6 +233,8 @@ class _Printer:
             return f"fabs({a[0]})"
         if op == "sign":
             return f"(double)(({a[0]} > 0.0) - ({a[0]} < 0.0))"
+        if self.device_math and op in ("sin", "cos", "tan"):
+            return f"asset_{op}({a[0]})"
         return f"{op}({a[0]})"
 
 
