@@ -409,6 +409,12 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
   int jo[D::TJ][K][KS];                                    // (hE J^)^T fragment
   int avb[KS], avs[KS];                                    // DI_i^T fragment: offset in the dense scratch for i = 0, stride in i
   int cjo[n];                                              // dfdy_j[r][cc] of this lane's block column (D1)
+  // JFUSE (small ODEs: all defect rows fit one 16-lane tile next to the N columns of H^ and the g^ column): the B
+  // operand of the M product of interior i carries (hE_i J^_i)^T in the lanes [i*n, i*n+n) -- the lanes that own the
+  // defect rows (i, .) of the J tile -- the g^ column in lane 15 and the H^ columns in the remaining lanes, so the
+  // interior part of J^T falls out of the same 2*TI MFMAs per interior and the separate J product disappears.
+  constexpr bool JFUSE = (LEVEL >= 2) && (D::TJ == 1) && (D::MT == 1) && (K * n <= 15) && (N <= 15 - n);
+  int bo2[JFUSE ? K : 1][KS];                              // B operand offsets of the fused product
   int hst[D::NTH][4], jst[D::TI * D::TJ][4];   // KKT slot of accumulator entry (tile, v) or -1
   double tB[CS], tD[CS], tC[CS], tE = 0.0;                 // weights of the row (i,r) this lane owns in the time-column pass
   if constexpr (STAGE == 2 && LEVEL >= 1) {
@@ -440,6 +446,26 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
         bo[mt][kk] = v;
         bst[mt][kk] = st;
       }
+    if constexpr (JFUSE) {
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        const int jk = lr - i * n;
+        const bool isj = (jk >= 0 && jk < n);
+        const int hr = (isj || lr == 15) ? -1 : ((lr < i * n) ? lr : lr - n);   // rank among the H^ lanes
+        const bool ish = (hr >= 0 && hr < N);
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+          const int b = 4 * kk + lk;
+          int o = ZERO;
+          if (b < N) {
+            if (isj) { const int jp = Ode::JPOS[jk * N + b]; if (jp >= 0) o = D::w_IJ + i * D::NZJ + jp; }
+            else if (ish) { const int hp = Ode::HPOS[(b >= hr) ? b * (b + 1) / 2 + hr : hr * (hr + 1) / 2 + b]; if (hp >= 0) o = D::w_IH + i * D::NZH + hp; }
+            else if (lr == 15) o = D::w_Ig + i * N + b;
+          }
+          bo2[i][kk] = o;
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < n; r++) {
       const int jp = Ode::JPOS[r * N + d1cc];
@@ -779,72 +805,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
           for (int kk = 0; kk < KS; kk++)
             av[ct][i][kk] = scr[avb[kk] + i * avs[kk] + 16 * ct];
 
-      // ---- D3: M_i^T = DI_i^T [hE_i H^_i | E_i g^_i]; column N of the product is sum_b E_i g^_i[b] DI_i[b,c]
-      if constexpr (LEVEL >= 2) {
-        double hi_acc[D::TI][4];
-#pragma unroll
-        for (int ct = 0; ct < D::TI; ct++)
-#pragma unroll
-          for (int v = 0; v < 4; v++) hi_acc[ct][v] = 0.0;
-        double bvall[K][D::MT][KS];                      // all B operands are read before the first M^T write-back
-#pragma unroll
-        for (int i = 0; i < K; i++)
-#pragma unroll
-          for (int mt = 0; mt < D::MT; mt++)
-#pragma unroll
-            for (int kk = 0; kk < KS; kk++) bvall[i][mt][kk] = S[bo[mt][kk] + i * bst[mt][kk]];
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-          const double he = h * tab.E[i];
-#pragma unroll
-          for (int mt = 0; mt < D::MT; mt++) {
-            const int acol = 16 * mt + lr;               // column of [hE H^ | E g^]
-            double bv[KS];
-#pragma unroll
-            for (int kk = 0; kk < KS; kk++) bv[kk] = bvall[i][mt][kk] * ((acol == N) ? tab.E[i] : he);
-#pragma unroll
-            for (int ct = 0; ct < D::TI; ct++) {
-              d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-              for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bv[kk], acc, 0, 0, 0);
-              // acc[v] = (M_i^T)[c = 16ct + lk + 4v][acol].  Every lane accumulates and writes, so there is no branch:
-              // only the lanes owning column N publish hi_acc, and lanes beyond the k-padding write the spare column
-              // K*NP of their row (it exists for bank spreading and is never read).
-              if (mt == N / 16) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) hi_acc[ct][v] += acc[v];
-              }
-              const int mcol = (acol < NP) ? i * NP + acol : K * NP;
-#pragma unroll
-              for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + mcol] = (acol < N) ? acc[v] : 0.0;
-            }
-          }
-        }
-        if ((N & 15) == lr) {                            // the lanes that own column N
-#pragma unroll
-          for (int ct = 0; ct < D::TI; ct++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) HI[16 * ct + lk + 4 * v] = hi_acc[ct][v];
-        }
-        wave_lds_sync();
-        // full time-partial vector HTpar (LGLDefects.h:403-411, 504-505) -> rank-2 rows:
-        //   H += d HT^T + HT d^T  with d = e_TF - e_T   (the four updates of LGLDefects.h:508-511)
-        const double ih = 1.0 / h;
-        for (int c = lane; c < IRP; c += 64) {
-          const int jn = c / q;
-          double v = HI[c] + S[(c < P0) ? D::w_Cg + jn * N + (c - jn * q) : ZERO] * ih;   // HI is zero on padding columns
-          if constexpr (p > 0) {
-            if (c >= P0 && c < IR) {
-#pragma unroll
-              for (int j = 0; j < CS; j++) v += S[D::w_Cg + j * N + q + (c - P0)] * ih;
-            }
-          }
-          R2[IRP + c] = v;          // A-side row 1 / B-side row 0 share this copy
-        }
-        wave_lds_sync();
-      }
-
-      // ---- D4: H (lower-triangle tiles) and J^T
       // Small shapes keep every accumulator tile until D6 (the stores then share a handful of lane-condition
       // branches); wide ones store each tile as it completes -- holding them all would spill.
 #ifndef ASSET_HOLD_TILES
@@ -915,6 +875,127 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
 #pragma unroll
         for (int t = 0; t < D::TI * D::TJ; t++) load_jmap(t);
       }
+      // ---- D3: M_i^T = DI_i^T [hE_i H^_i | E_i g^_i]; column N of the product is sum_b E_i g^_i[b] DI_i[b,c]
+      if constexpr (JFUSE) {
+        double jacc[D::TI][4];                           // interior part of J^T, entry v = (c = 16ct + lk + 4v, jr = lr)
+        double hi_acc[D::TI][4];
+#pragma unroll
+        for (int ct = 0; ct < D::TI; ct++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) hi_acc[ct][v] = 0.0, jacc[ct][v] = 0.0;
+        double bvall[K][KS];                             // all B operands are read before the first M^T write-back
+#pragma unroll
+        for (int i = 0; i < K; i++)
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++) bvall[i][kk] = S[bo2[i][kk]];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+          const double sc = (lr == 15) ? tab.E[i] : h * tab.E[i];   // the g^ column is scaled by E_i, the others by h E_i
+          const bool isj = (lr >= i * n && lr < i * n + n);
+          const int hr = (isj || lr == 15) ? -1 : ((lr < i * n) ? lr : lr - n);   // rank among the H^ lanes
+          const bool ish = (hr >= 0 && hr < N);
+          const int mcol = (hr >= 0 && hr < NP) ? i * NP + hr : K * NP;          // k-padding columns get zeros, others the spare
+          double bv[KS];
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++) bv[kk] = bvall[i][kk] * sc;
+#pragma unroll
+          for (int ct = 0; ct < D::TI; ct++) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bv[kk], acc, 0, 0, 0);
+            // acc[v] = row c = 16ct + lk + 4v of DI_i^T times this lane's column: an M_i^T column, E_i g^_i . DI_i (lane
+            // 15, summed over i into HI) or row (i, lr - i*n) of the interior part of J (LGLDefects.h:452-500)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+              hi_acc[ct][v] += acc[v];
+              jacc[ct][v] = isj ? acc[v] : jacc[ct][v];
+              Mt[(16 * ct + lk + 4 * v) * D::LDM + mcol] = ish ? acc[v] : 0.0;
+            }
+          }
+        }
+        if (lr == 15) {
+#pragma unroll
+          for (int ct = 0; ct < D::TI; ct++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) HI[16 * ct + lk + 4 * v] = hi_acc[ct][v];
+        }
+        // J^T = interior part + cardinal part DC^T; stored right away (its registers are free for the H products)
+        if (kkt_dst) {
+#pragma unroll
+          for (int ct = 0; ct < D::TI; ct++) {
+            d4 acc;
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[v] = jacc[ct][v] + DC[lr * D::LDC + 16 * ct + lk + 4 * v];   // row 15: zero padding
+            store_J_tile(0, ct, acc);
+          }
+        }
+      } else if constexpr (LEVEL >= 2) {
+        double hi_acc[D::TI][4];
+#pragma unroll
+        for (int ct = 0; ct < D::TI; ct++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) hi_acc[ct][v] = 0.0;
+        double bvall[K][D::MT][KS];                      // all B operands are read before the first M^T write-back
+#pragma unroll
+        for (int i = 0; i < K; i++)
+#pragma unroll
+          for (int mt = 0; mt < D::MT; mt++)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) bvall[i][mt][kk] = S[bo[mt][kk] + i * bst[mt][kk]];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+          const double he = h * tab.E[i];
+#pragma unroll
+          for (int mt = 0; mt < D::MT; mt++) {
+            const int acol = 16 * mt + lr;               // column of [hE H^ | E g^]
+            double bv[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) bv[kk] = bvall[i][mt][kk] * ((acol == N) ? tab.E[i] : he);
+#pragma unroll
+            for (int ct = 0; ct < D::TI; ct++) {
+              d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bv[kk], acc, 0, 0, 0);
+              // acc[v] = (M_i^T)[c = 16ct + lk + 4v][acol].  Every lane accumulates and writes, so there is no branch:
+              // only the lanes owning column N publish hi_acc, and lanes beyond the k-padding write the spare column
+              // K*NP of their row (it exists for bank spreading and is never read).
+              if (mt == N / 16) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) hi_acc[ct][v] += acc[v];
+              }
+              const int mcol = (acol < NP) ? i * NP + acol : K * NP;
+#pragma unroll
+              for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + mcol] = (acol < N) ? acc[v] : 0.0;
+            }
+          }
+        }
+        if ((N & 15) == lr) {                            // the lanes that own column N
+#pragma unroll
+          for (int ct = 0; ct < D::TI; ct++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) HI[16 * ct + lk + 4 * v] = hi_acc[ct][v];
+        }
+      }
+      if constexpr (LEVEL >= 2) {
+        wave_lds_sync();
+        // full time-partial vector HTpar (LGLDefects.h:403-411, 504-505) -> rank-2 rows:
+        //   H += d HT^T + HT d^T  with d = e_TF - e_T   (the four updates of LGLDefects.h:508-511)
+        const double ih = 1.0 / h;
+        for (int c = lane; c < IRP; c += 64) {
+          const int jn = c / q;
+          double v = HI[c] + S[(c < P0) ? D::w_Cg + jn * N + (c - jn * q) : ZERO] * ih;   // HI is zero on padding columns
+          if constexpr (p > 0) {
+            if (c >= P0 && c < IR) {
+#pragma unroll
+              for (int j = 0; j < CS; j++) v += S[D::w_Cg + j * N + q + (c - P0)] * ih;
+            }
+          }
+          R2[IRP + c] = v;          // A-side row 1 / B-side row 0 share this copy
+        }
+        wave_lds_sync();
+      }
+
+      // ---- D4: H (lower-triangle tiles) and J^T
       if constexpr (LEVEL >= 2) {
         // rank-2 time fragments: k=0 -> (A: d, B: HT), k=1 -> (A: HT, B: d), k=2,3 -> 0
         double a2[D::TI], b2[D::TI];
@@ -959,7 +1040,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
           }
         }
       }
-      {
+      if constexpr (!JFUSE) {
 #pragma unroll
       for (int jt = 0; jt < D::TJ; jt++) {
         double bj[K][KS];                                // (hE_i J^_i)^T[aa][jr], non-zero only on interior i's rows
@@ -1029,10 +1110,12 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
 #pragma unroll
               for (int ct = 0; ct <= rt; ct++) store_H_tile(rt, ct, accH[rt * (rt + 1) / 2 + ct]);
           }
+          if constexpr (!JFUSE) {
 #pragma unroll
-          for (int jt = 0; jt < D::TJ; jt++)
+            for (int jt = 0; jt < D::TJ; jt++)
 #pragma unroll
-            for (int ct = 0; ct < D::TI; ct++) store_J_tile(jt, ct, accJ[ct * D::TJ + jt]);
+              for (int ct = 0; ct < D::TI; ct++) store_J_tile(jt, ct, accJ[ct * D::TJ + jt]);
+          }
         } else {
         if constexpr (true) {                // Jacobian-only kinds write the Hessian slots as zero (adding zeros: skipped)
 #pragma unroll
@@ -1056,6 +1139,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
             }
           }
         }
+        if constexpr (!JFUSE) {                            // (JFUSE stored the J tile right after the M product)
 #pragma unroll
         for (int jt = 0; jt < D::TJ; jt++) {
           if (16 * jt + lr < OR) {
@@ -1066,6 +1150,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
                 if (CFULL || ct + 1 < D::TI || 16 * ct + lk + 4 * v < IR)
                   kkt_dst[jst[ct * D::TJ + jt][v]] = accJ[ct * D::TJ + jt][v];
           }
+        }
         }
         }
         }
