@@ -114,8 +114,8 @@ struct Dims {
   static constexpr int s_DIc = XM;                     // [K][NCR][IRP]
   static constexpr int s_DC = s_DIc + K * (NP - n) * IRP;  // cardinal part of J, rows = defect rows  [ORP][IRP], padding rows zero
   static constexpr int LDC = IRP + 4;                  // DC row stride: row- and column-wise fragment reads both conflict-free
-  static constexpr int s_R2 = s_DC + ORP * LDC;        // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar
-  static constexpr int s_HI = s_R2 + 2 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
+  static constexpr int s_R2 = s_DC + ORP * LDC;        // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar, [2] = 0
+  static constexpr int s_HI = s_R2 + 3 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
   static constexpr int s_Z0 = s_HI + IRP;              // a cell that always holds 0.0: target of every "no entry" offset
   static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
   static constexpr int SCRATCH = s_Z0 + 2;
@@ -676,7 +676,10 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
       scr[D::s_DIc + e] = v;
     }
     for (int e = lane; e < K * n * IRP; e += 64) scr[D::s_DIx + e] = 0.0;   // padding columns of the state rows
-    for (int e = lane; e < IRP; e += 64) scr[D::s_R2 + e] = (e == TF) ? 1.0 : ((e == T) ? -1.0 : 0.0);
+    for (int e = lane; e < IRP; e += 64) {
+      scr[D::s_R2 + e] = (e == TF) ? 1.0 : ((e == T) ? -1.0 : 0.0);
+      scr[D::s_R2 + 2 * IRP + e] = 0.0;
+    }
     for (int e = lane; e < ORP * D::LDC; e += 64) scr[D::s_DC + e] = 0.0;
     if (lane < 2) scr[D::s_Z0 + lane] = 0.0;
     wave_lds_sync();
@@ -895,6 +898,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
           const int hr = (isj || lr == 15) ? -1 : ((lr < i * n) ? lr : lr - n);   // rank among the H^ lanes
           const bool ish = (hr >= 0 && hr < N);
           const int mcol = (hr >= 0 && hr < NP) ? i * NP + hr : K * NP;          // k-padding columns get zeros, others the spare
+          const double jf = isj ? 1.0 : 0.0;
           double bv[KS];
 #pragma unroll
           for (int kk = 0; kk < KS; kk++) bv[kk] = bvall[i][kk] * sc;
@@ -908,8 +912,9 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
 #pragma unroll
             for (int v = 0; v < 4; v++) {
               hi_acc[ct][v] += acc[v];
-              jacc[ct][v] = isj ? acc[v] : jacc[ct][v];
-              Mt[(16 * ct + lk + 4 * v) * D::LDM + mcol] = ish ? acc[v] : 0.0;
+              jacc[ct][v] = fma(jf, acc[v], jacc[ct][v]);
+              // the spare column takes whatever the J^ / g^ lanes hold; only k-padding columns (N <= hr < NP) need zeros
+              Mt[(16 * ct + lk + 4 * v) * D::LDM + mcol] = (N == NP || ish) ? acc[v] : 0.0;
             }
           }
         }
@@ -1001,9 +1006,9 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
         double a2[D::TI], b2[D::TI];
 #pragma unroll
         for (int t = 0; t < D::TI; t++) {
-          const double dv = R2[16 * t + lr], hv = R2[IRP + 16 * t + lr];
-          a2[t] = (lk == 0) ? dv : ((lk == 1) ? hv : 0.0);
-          b2[t] = (lk == 0) ? hv : ((lk == 1) ? dv : 0.0);
+          // the k index of the lane picks the row: no select (row 2 holds zeros)
+          a2[t] = R2[(lk == 0 ? 0 : (lk == 1 ? IRP : 2 * IRP)) + 16 * t + lr];
+          b2[t] = R2[(lk == 0 ? IRP : (lk == 1 ? 0 : 2 * IRP)) + 16 * t + lr];
         }
 #pragma unroll
         for (int rt = 0; rt < D::TI; rt++) {

@@ -16,7 +16,9 @@ for name in ("kernel_stats", "domain_stats"):
 
 
 def stage_of(kernel_name):
-    return "ode_stage" if kernel_name.rstrip(")").split(">")[0].endswith(", 1") else "dense_stage"
+    """lgl_defect_kernel<Ode, CS, BLOCKED, G, LEVEL, STAGE[, ASM]>: STAGE is the sixth template argument."""
+    args = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
+    return "ode_stage" if len(args) >= 6 and args[5] == "1" else "dense_stage"
 
 
 def counters(sub):
