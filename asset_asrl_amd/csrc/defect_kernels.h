@@ -913,8 +913,12 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
             for (int v = 0; v < 4; v++) {
               hi_acc[ct][v] += acc[v];
               jacc[ct][v] = fma(jf, acc[v], jacc[ct][v]);
-              // the spare column takes whatever the J^ / g^ lanes hold; only k-padding columns (N <= hr < NP) need zeros
-              Mt[(16 * ct + lk + 4 * v) * D::LDM + mcol] = (N == NP || ish) ? acc[v] : 0.0;
+            }
+            // only the lanes on an H^ (or k-padding) column write M^T back: letting the others write a common spare cell
+            // costs an 8-way same-address conflict per store (measured: 224 conflict cycles per segment)
+            if (hr >= 0 && hr < NP) {
+#pragma unroll
+              for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + mcol] = (N == NP || ish) ? acc[v] : 0.0;
             }
           }
         }
@@ -961,16 +965,16 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
               d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
               for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ct][i][kk], bv[kk], acc, 0, 0, 0);
-              // acc[v] = (M_i^T)[c = 16ct + lk + 4v][acol].  Every lane accumulates and writes, so there is no branch:
-              // only the lanes owning column N publish hi_acc, and lanes beyond the k-padding write the spare column
-              // K*NP of their row (it exists for bank spreading and is never read).
+              // acc[v] = (M_i^T)[c = 16ct + lk + 4v][acol].  Every lane accumulates; only the lanes owning column N publish
+              // hi_acc and only the lanes on a column < NP write M^T back.
               if (mt == N / 16) {
 #pragma unroll
                 for (int v = 0; v < 4; v++) hi_acc[ct][v] += acc[v];
               }
-              const int mcol = (acol < NP) ? i * NP + acol : K * NP;
+              if (acol < NP) {                           // (a common spare cell for the other lanes would be an 8-way write conflict)
 #pragma unroll
-              for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + mcol] = (acol < N) ? acc[v] : 0.0;
+                for (int v = 0; v < 4; v++) Mt[(16 * ct + lk + 4 * v) * D::LDM + i * NP + acol] = (acol < N) ? acc[v] : 0.0;
+              }
             }
           }
         }
