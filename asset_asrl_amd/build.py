@@ -25,7 +25,7 @@ LDS_TARGET = 40 * 1024          # keep >= 4 single-wave workgroups per CU when t
 
 
 def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
-    """Mirror of ``Dims<>`` in csrc/defect_kernels.h (sizes + LDS plan).  ``nzj`` / ``nzh`` are the structural
+    """Mirror of ``Dims<>`` in csrc/defect_dims.h (sizes + LDS plan).  ``nzj`` / ``nzh`` are the structural
     non-zero counts of the ODE Jacobian / packed-lower Hessian (dense when omitted)."""
     n = xv
     m, p = (0, uv + pv) if blocked else (uv, pv)

@@ -1,0 +1,209 @@
+// Sizes, memory maps and ODE accessors shared by the LGL defect kernels (defect_kernels.h).
+//
+// Notation: n = XV states, m = UV controls, p = PV parameters (BlockConstant control:
+// m := 0, p := UV + PV, Blocked_ODE_Wrapper.h:7-27), q = n + 1 + m, N = q + p ODE inputs, CS cardinal nodes,
+// K = CS - 1 interior points, IR = CS*q + p segment inputs, OR = K*n defect rows.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "lgl_tables.h"
+
+#ifndef ASSET_ODE_WAVES_PER_SIMD
+#define ASSET_ODE_WAVES_PER_SIMD 1    // register budget of the ODE-stage kernel
+#endif
+#ifndef ASSET_DENSE_WAVES_PER_SIMD
+#define ASSET_DENSE_WAVES_PER_SIMD 2  // register budget of the dense-phase kernel: 512 / 2 = 256 per lane
+#endif
+
+namespace asset_hip {
+
+static __constant__ LglTab d_lgl_tab[3] = ASSET_LGL_TABLE_INIT;
+
+struct EvalArgs {
+  int nseg;
+  const double* X;     // NLP primal vector (device)
+  const double* L;     // equality multipliers (device); unused for value-only
+  const int* vindex;   // [IR x nseg] column-major (device)
+  const int* cindex;   // [OR x nseg] column-major (device)
+  double* FX;          // [nseg x OR] blocks or null
+  double* AGX;         // [nseg x IR] blocks or null
+  double* KKT;         // [nseg x NKKT] blocks or null
+  double* work;        // [grid][G][SLOT] per-workgroup ODE result slots (L2-resident scratch in HBM)
+  // on-device assembly (dense stage, ASM kernels): KKT entries are added into values[kmap[seg*NKKT + slot]]
+  // instead of being stored as blocks (DenseFunctionBase.h:1413-1523 KKTFillAll / KKTFillJac)
+  const int* kmap = nullptr;
+  double* values = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------- sizes
+template <class Ode, int CS_, bool BLOCKED_>
+struct Dims {
+  static constexpr int CS = CS_, K = CS_ - 1;
+  static constexpr int n = Ode::XV;
+  static constexpr int m = BLOCKED_ ? 0 : Ode::UV;                    // Blocked_ODE_Wrapper.h:7-27
+  static constexpr int p = BLOCKED_ ? Ode::UV + Ode::PV : Ode::PV;
+  static constexpr int q = n + 1 + m;
+  static constexpr int N = q + p;
+  static constexpr int T = n;
+  static constexpr int IR = CS * q + p;                               // TranscriptionSizing.h:7-14
+  static constexpr int OR = K * n;
+  static constexpr int TF = q * (CS - 1) + T;
+  static constexpr int P0 = CS * q;
+  static constexpr int NKKT = IR * (IR + 1) / 2 + OR * IR;            // DenseFunctionBase.h:1070-1088
+  static constexpr int NH = N * (N + 1) / 2;                          // packed lower ODE Hessian
+  static constexpr int IRP = (IR + 15) / 16 * 16;
+  static constexpr int ORP = (OR + 15) / 16 * 16;
+  static constexpr int NP = (N + 3) / 4 * 4;                          // rows of one interior's DI tile (MFMA k = 4)
+  static constexpr int KS = NP / 4;                                   // k-steps per interior
+  static constexpr int MT = (N + 1 + 15) / 16;                        // 16-wide column tiles of [hE H^ | E g^]
+  static constexpr int TI = IRP / 16, TJ = ORP / 16;
+  static constexpr int NTH = TI * (TI + 1) / 2;                       // lower-triangle H tiles
+  static constexpr int CW = IRP <= 16 ? 16 : (IRP <= 32 ? 32 : 64);   // lanes per DI row pass (power of two)
+
+  // ---- per-segment slot of ODE results (in doubles): workspace layout in HBM, copied verbatim into LDS by the dense
+  //      stage.  J and H blocks hold only their structural non-zeros, in Ode::JIDX / HIDX order (Ode::JPOS / HPOS
+  //      give the position of a dense entry or -1); readers point "no entry" at a zero cell instead.
+  using ode_t = Ode;
+  static constexpr int NZJ = Ode::NNZ_J, NZH = Ode::NNZ_H;
+  static constexpr int w_z = 0;
+  static constexpr int w_lam = w_z + IR;
+  static constexpr int w_Cf = w_lam + OR;
+  static constexpr int w_CJ = w_Cf + CS * n;
+  static constexpr int w_Cg = w_CJ + CS * NZJ;
+  static constexpr int w_CH = w_Cg + CS * N;
+  static constexpr int w_If = w_CH + CS * NZH;
+  static constexpr int w_IJ = w_If + K * n;
+  static constexpr int w_Ig = w_IJ + K * NZJ;
+  static constexpr int w_IH = w_Ig + K * N;
+  static constexpr int w_SV = w_IH + K * NZH;           // transcendental values of f at the cardinal nodes (P1 -> P3)
+  static constexpr int WSLOT = w_SV + CS * Ode::NSAVE;
+  static constexpr int WSLOTD = w_SV;                   // what the dense stage reads of a slot
+  // ---- dense scratch (one segment at a time)
+  // DI_i is kept as two tiles: state rows (r < n), rewritten for every segment, and the remaining rows (tau / control
+  // / parameter / padding), constant per launch.  M^T is produced after every A fragment has been read into
+  // registers, so it re-uses the state-row tile's memory.
+  static constexpr int NCR = NP - n;                   // constant rows per interior
+  static constexpr int s_DIx = 0;                      // [K][n][IRP]
+  static constexpr int s_M = 0;                        // M^T [IRP][K*NP+1]  (aliases s_DIx)
+  static constexpr int XM = (K * n * IRP > IRP * (K * NP + 1)) ? K * n * IRP : IRP * (K * NP + 1);
+  static constexpr int s_DIc = XM;                     // [K][NCR][IRP]
+  static constexpr int s_DC = s_DIc + K * (NP - n) * IRP;  // cardinal part of J, rows = defect rows  [ORP][IRP], padding rows zero
+  static constexpr int LDC = IRP + 4;                  // DC row stride: row- and column-wise fragment reads both conflict-free
+  static constexpr int s_R2 = s_DC + ORP * LDC;        // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar, [2] = 0
+  static constexpr int s_HI = s_R2 + 3 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
+  static constexpr int s_Z0 = s_HI + IRP;              // a cell that always holds 0.0: target of every "no entry" offset
+  static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
+  static constexpr int SCRATCH = s_Z0 + 2;
+  static constexpr int LDM = K * NP + 1;               // M is stored column-major [IRP][LDM]: conflict-free MFMA write-back
+
+  // ---- ODE-phase staging: every evaluating lane writes its dense J (n x N) and packed H into an LDS row, the wave
+  //      then copies the rows to the workspace with coalesced stores.  Row stride is odd: conflict-free ds_write.
+  static constexpr int NSTG = NZJ + NZH;               // a staging row holds one point's non-zeros [J | H]
+  static constexpr int STG_LD = NSTG | 1;
+  static constexpr int DENSE = WSLOTD + SCRATCH;         // slot buffer + dense scratch (staging aliases both)
+  // lanes per ODE pass: as many as fit in the LDS the dense phase needs anyway (occupancy is LDS-bound)
+#ifndef ASSET_LC_BUDGET
+#define ASSET_LC_BUDGET (64 * 1024)
+#endif
+  // very wide ODEs: no LDS row fits -> the evaluating lanes write J/H straight to the workspace (uncoalesced, correct)
+  static constexpr bool STAGED = (16 * STG_LD * 8 <= ASSET_LC_BUDGET);
+  static constexpr int LC = !STAGED ? 64
+                            : (64 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 64 : ((32 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 32 : 16);
+  // LDS of the two launches: [weight tables | staging rows] and [weight tables | slot buffer | dense scratch]
+  static constexpr size_t lds_bytes_ode() { return size_t(TABSZ + (STAGED ? LC * STG_LD : 0)) * 8; }
+  static constexpr size_t lds_bytes_dense() { return size_t(TABSZ + DENSE) * 8; }
+  static constexpr size_t lds_bytes() { return lds_bytes_ode() > lds_bytes_dense() ? lds_bytes_ode() : lds_bytes_dense(); }
+};
+
+using d4 = __attribute__((ext_vector_type(4))) double;
+
+// ---------------------------------------------------------------------------------------------- ODE accessors
+template <class D>
+struct CardIn {  // y = [z_j (q), P (p)] read from the slot's copy of z; lam = adjoint weights in registers
+  const double* z;
+  const double* w;
+  int j;
+  const double* sv = nullptr;  // saved transcendental values of f at this node (fjgh_load)
+  __device__ double y(int i) const { return i < D::q ? z[j * D::q + i] : z[D::P0 + (i - D::q)]; }
+  __device__ double lam(int k) const { return w[k]; }
+  __device__ double saved(int k) const { return sv[k]; }
+};
+template <class D>
+struct RegIn {
+  const double* yv;
+  const double* lv;
+  __device__ double y(int i) const { return yv[i]; }
+  __device__ double lam(int k) const { return lv[k]; }
+};
+template <class D>
+struct OdeOut {  // routes every derivative entry to its LDS slot (J row-major n x N, H packed lower)
+  double* f_;
+  double* J_;
+  double* g_;
+  double* H_;
+  __device__ void f(int k, double v) { f_[k] = v; }
+  __device__ void J(int k, int i, double v) { J_[k * D::N + i] = v; }
+  __device__ void g(int i, double v) { g_[i] = v; }
+  __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
+};
+
+// LDS-address-space pointer: stores through it are ds_write (tracked by lgkmcnt only), never flat
+typedef __attribute__((address_space(3))) double lds_double;
+
+template <class D, bool ACCG = false>
+struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H non-zeros -> this lane's LDS staging row [J | H]
+  using JP = std::conditional_t<D::STAGED, lds_double*, double*>;
+  double* f_;
+  double* g_;
+  JP J_;
+  JP H_;
+  double* sv_ = nullptr;
+  const double* lamv_ = nullptr;                       // ACCG: multipliers of this point's defect rows ...
+  double gacc_[ACCG ? D::N : 1];                       // ... and g^ = J^^T lam accumulated while J is emitted (fj has no g)
+  __device__ void f(int k, double v) { f_[k] = v; }
+  __device__ void J(int k, int i, double v) {          // (k, i) are literals in the generated bodies: the lookup folds
+    const int c = D::ode_t::JPOS[k * D::N + i];
+    if (c >= 0) {
+      J_[c] = v;
+      if constexpr (ACCG) gacc_[i] += lamv_[k] * v;
+    }
+  }
+  __device__ void g(int i, double v) { g_[i] = v; }
+  __device__ void H(int i, int j, double v) {
+    const int c = D::ode_t::HPOS[i * (i + 1) / 2 + j];
+    if (c >= 0) H_[c] = v;
+  }
+  __device__ void save(int k, double v) { sv_[k] = v; }
+};
+
+template <class D>
+__device__ inline auto stage_or(lds_double* row, double* slot) {
+  if constexpr (D::STAGED) { (void)slot; return row; } else { (void)row; return slot; }
+}
+
+__device__ inline double hsym(const double* Hp, int a, int b) {
+  return a >= b ? Hp[a * (a + 1) / 2 + b] : Hp[b * (b + 1) / 2 + a];
+}
+
+// true when block columns [16ct,16ct+16) and rows [16rt,16rt+16) can hold a cardinal diagonal / parameter entry
+template <class D>
+__device__ constexpr bool tiles_share_node(int ct, int rt) {
+  const int c0 = 16 * ct, c1 = (16 * ct + 15 < D::IR - 1) ? 16 * ct + 15 : D::IR - 1;
+  const int r0 = 16 * rt, r1 = (16 * rt + 15 < D::IR - 1) ? 16 * rt + 15 : D::IR - 1;
+  if (c0 > c1 || r0 > r1) return false;
+  if (D::p > 0 && r1 >= D::P0) return true;                 // parameter rows couple to every column
+  const int jc0 = c0 / D::q, jc1 = c1 / D::q, jr0 = r0 / D::q, jr1 = r1 / D::q;
+  return !(jr1 < jc0 || jc1 < jr0);
+}
+
+// One wave per workgroup.  LDS instructions of a wave execute in issue order, so LDS hand-offs between lanes only
+// need the compiler kept from reordering (and the reads returned); crucially this does NOT wait for outstanding
+// global stores the way __syncthreads() (vmcnt(0)) does -- the block stores of a segment drain behind the next one.
+__device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Hand-offs through the global workspace (same wave writes, then reads): wait for the stores as well.
+__device__ inline void wave_mem_sync() { __syncthreads(); }
+
+}  // namespace asset_hip

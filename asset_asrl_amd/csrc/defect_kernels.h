@@ -1,4 +1,4 @@
-// Batched collocation-defect kernels for gfx950 (CDNA4).  HIP only -- no CUDA path.
+// Batched LGL collocation-defect kernels for gfx950 (CDNA4).  HIP only -- no CUDA path.
 //
 // What is computed, per mesh segment (SURVEY.md section 8 "Mathematical statement"):
 //   value      d_i = sum_j (C_ij x_j + h D_ij f_j) + h E_i f(x^_i, tau_i, u^_i, P)          i = 0..K-1
@@ -8,225 +8,28 @@
 // i.e. the three methods of the reference's LGLDefects (/root/reference/src/OptimalControl/
 // LGLDefects.h:57-122, 123-286, 289-551) evaluated for every segment of a phase and written as the
 // per-application blocks the solver interface scatters into the KKT matrix
-// (/root/reference/src/VectorFunctions/DenseFunctionBase.h:1097-1129, 1276-1391).
+// (/root/reference/src/VectorFunctions/DenseFunctionBase.h:1097-1129, 1276-1391) -- or, in the ASM instantiations,
+// added straight into the solver's value array (DenseFunctionBase.h:1413-1523).
 //
-// Execution shape (one 64-lane wavefront per workgroup, grid-stride over groups of G segments):
-//   P0  gather z = X[Vindex], lam = L[Cindex] for G segments into LDS (index reads coalesced)
-//   P1  lane <-> (segment, cardinal node):   f_j                               (ODE value)
-//   P2  lane <-> (segment, interior point):  x^,tau,u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
-//   P3  lane <-> (segment, cardinal node):   w_j ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f
-//   P4  all 64 lanes on ONE segment at a time.  With DI_i = d(x^_i,tau_i,u^_i,P)/dz (N x IR):
+// One evaluation is two launches of lgl_defect_kernel (one 64-lane wavefront per workgroup, persistent workgroups
+// over contiguous shares of the segments); they hand over through a per-segment workspace slot in HBM (Dims: w_*):
+//   STAGE 1, ODE stage -- lane <-> evaluation point, up to G segments of the workgroup at a time:
+//     P0  gather z = X[Vindex], lam = L[Cindex] into the slots
+//     P1  (segment, cardinal node):   f_j, and every transcendental sub-expression of it        (f_save)
+//     P2  (segment, interior point):  x^,tau,u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f     (fjgh)
+//     P3  (segment, cardinal node):   w_j ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f               (fjgh_load)
+//     J / H non-zeros go through LDS staging rows so that the workspace is written with coalesced stores.
+//   STAGE 2, dense stage -- all 64 lanes on ONE segment at a time.  With DI_i = d(x^_i,tau_i,u^_i,P)/dz (N x IR):
 //         M_i^T   = DI_i^T [hE_i H^_i | E_i g^_i]        16x16x4 f64 MFMA, A = DI_i^T tiles from LDS
 //         H      += DI_i^T M_i   (lower-triangle tiles)  same A fragments, B = M_i from LDS
-//         J^T    += DI_i^T (hE_i J^_i)^T                  same A fragments
-//       The remaining terms are sparse (cardinal diagonal blocks, the two time columns/rows, C/D weights):
-//       each lane adds them to the accumulator entries it owns, then stores its entries straight to the
-//       KKT block in HBM -- no staging tile, no slot map.  For a fixed accumulator register, lanes 0..15 hold 16
-//       consecutive rows of one block column, i.e. 128 contiguous bytes of the reference's slot order.
-// The ODE is an inlined generated functor (asset_asrl_amd/vf/codegen.py), so P1-P3 are straight-line
-// register code; the only HBM traffic is the gather and the block stores.
+//         J^T    += DI_i^T (hE_i J^_i)^T                  same A fragments (or spare columns of the M product)
+//     The sparse remainder (cardinal diagonal blocks, cardinal part of J, the two time rows / columns) enters as
+//     accumulator initial values and one rank-2 product; accumulators are stored straight to the KKT block.
+// The ODE is an inlined generated functor (asset_asrl_amd/vf/codegen.py).  DESIGN.md section 4 has the measurements.
 #pragma once
-#include <hip/hip_runtime.h>
-
-#include <cstdint>
-#include <type_traits>
-
-#include "lgl_tables.h"
-
-#ifndef ASSET_ODE_WAVES_PER_SIMD
-#define ASSET_ODE_WAVES_PER_SIMD 1    // register budget of the ODE-stage kernel
-#endif
-#ifndef ASSET_DENSE_WAVES_PER_SIMD
-#define ASSET_DENSE_WAVES_PER_SIMD 2  // register budget of the dense-phase kernel: 512 / 2 = 256 per lane
-#endif
+#include "defect_dims.h"
 
 namespace asset_hip {
-
-static __constant__ LglTab d_lgl_tab[3] = ASSET_LGL_TABLE_INIT;
-
-struct EvalArgs {
-  int nseg;
-  const double* X;     // NLP primal vector (device)
-  const double* L;     // equality multipliers (device); unused for value-only
-  const int* vindex;   // [IR x nseg] column-major (device)
-  const int* cindex;   // [OR x nseg] column-major (device)
-  double* FX;          // [nseg x OR] blocks or null
-  double* AGX;         // [nseg x IR] blocks or null
-  double* KKT;         // [nseg x NKKT] blocks or null
-  double* work;        // [grid][G][SLOT] per-workgroup ODE result slots (L2-resident scratch in HBM)
-  // on-device assembly (dense stage, ASM kernels): KKT entries are added into values[kmap[seg*NKKT + slot]]
-  // instead of being stored as blocks (DenseFunctionBase.h:1413-1523 KKTFillAll / KKTFillJac)
-  const int* kmap = nullptr;
-  double* values = nullptr;
-};
-
-// ---------------------------------------------------------------------------------------------- sizes
-template <class Ode, int CS_, bool BLOCKED_>
-struct Dims {
-  static constexpr int CS = CS_, K = CS_ - 1;
-  static constexpr int n = Ode::XV;
-  static constexpr int m = BLOCKED_ ? 0 : Ode::UV;                    // Blocked_ODE_Wrapper.h:7-27
-  static constexpr int p = BLOCKED_ ? Ode::UV + Ode::PV : Ode::PV;
-  static constexpr int q = n + 1 + m;
-  static constexpr int N = q + p;
-  static constexpr int T = n;
-  static constexpr int IR = CS * q + p;                               // TranscriptionSizing.h:7-14
-  static constexpr int OR = K * n;
-  static constexpr int TF = q * (CS - 1) + T;
-  static constexpr int P0 = CS * q;
-  static constexpr int NKKT = IR * (IR + 1) / 2 + OR * IR;            // DenseFunctionBase.h:1070-1088
-  static constexpr int NH = N * (N + 1) / 2;                          // packed lower ODE Hessian
-  static constexpr int IRP = (IR + 15) / 16 * 16;
-  static constexpr int ORP = (OR + 15) / 16 * 16;
-  static constexpr int NP = (N + 3) / 4 * 4;                          // rows of one interior's DI tile (MFMA k = 4)
-  static constexpr int KS = NP / 4;                                   // k-steps per interior
-  static constexpr int MT = (N + 1 + 15) / 16;                        // 16-wide column tiles of [hE H^ | E g^]
-  static constexpr int TI = IRP / 16, TJ = ORP / 16;
-  static constexpr int NTH = TI * (TI + 1) / 2;                       // lower-triangle H tiles
-  static constexpr int CW = IRP <= 16 ? 16 : (IRP <= 32 ? 32 : 64);   // lanes per DI row pass (power of two)
-
-  // ---- per-segment slot of ODE results (in doubles): workspace layout in HBM, copied verbatim into LDS by the dense
-  //      stage.  J and H blocks hold only their structural non-zeros, in Ode::JIDX / HIDX order (Ode::JPOS / HPOS
-  //      give the position of a dense entry or -1); readers point "no entry" at a zero cell instead.
-  using ode_t = Ode;
-  static constexpr int NZJ = Ode::NNZ_J, NZH = Ode::NNZ_H;
-  static constexpr int w_z = 0;
-  static constexpr int w_lam = w_z + IR;
-  static constexpr int w_Cf = w_lam + OR;
-  static constexpr int w_CJ = w_Cf + CS * n;
-  static constexpr int w_Cg = w_CJ + CS * NZJ;
-  static constexpr int w_CH = w_Cg + CS * N;
-  static constexpr int w_If = w_CH + CS * NZH;
-  static constexpr int w_IJ = w_If + K * n;
-  static constexpr int w_Ig = w_IJ + K * NZJ;
-  static constexpr int w_IH = w_Ig + K * N;
-  static constexpr int w_SV = w_IH + K * NZH;           // transcendental values of f at the cardinal nodes (P1 -> P3)
-  static constexpr int WSLOT = w_SV + CS * Ode::NSAVE;
-  static constexpr int WSLOTD = w_SV;                   // what the dense stage reads of a slot
-  // ---- dense scratch (one segment at a time)
-  // DI_i is kept as two tiles: state rows (r < n), rewritten for every segment, and the remaining rows (tau / control
-  // / parameter / padding), constant per launch.  M^T is produced after every A fragment has been read into
-  // registers, so it re-uses the state-row tile's memory.
-  static constexpr int NCR = NP - n;                   // constant rows per interior
-  static constexpr int s_DIx = 0;                      // [K][n][IRP]
-  static constexpr int s_M = 0;                        // M^T [IRP][K*NP+1]  (aliases s_DIx)
-  static constexpr int XM = (K * n * IRP > IRP * (K * NP + 1)) ? K * n * IRP : IRP * (K * NP + 1);
-  static constexpr int s_DIc = XM;                     // [K][NCR][IRP]
-  static constexpr int s_DC = s_DIc + K * (NP - n) * IRP;  // cardinal part of J, rows = defect rows  [ORP][IRP], padding rows zero
-  static constexpr int LDC = IRP + 4;                  // DC row stride: row- and column-wise fragment reads both conflict-free
-  static constexpr int s_R2 = s_DC + ORP * LDC;        // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar, [2] = 0
-  static constexpr int s_HI = s_R2 + 3 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
-  static constexpr int s_Z0 = s_HI + IRP;              // a cell that always holds 0.0: target of every "no entry" offset
-  static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
-  static constexpr int SCRATCH = s_Z0 + 2;
-  static constexpr int LDM = K * NP + 1;               // M is stored column-major [IRP][LDM]: conflict-free MFMA write-back
-
-  // ---- ODE-phase staging: every evaluating lane writes its dense J (n x N) and packed H into an LDS row, the wave
-  //      then copies the rows to the workspace with coalesced stores.  Row stride is odd: conflict-free ds_write.
-  static constexpr int NSTG = NZJ + NZH;               // a staging row holds one point's non-zeros [J | H]
-  static constexpr int STG_LD = NSTG | 1;
-  static constexpr int DENSE = WSLOTD + SCRATCH;         // slot buffer + dense scratch (staging aliases both)
-  // lanes per ODE pass: as many as fit in the LDS the dense phase needs anyway (occupancy is LDS-bound)
-#ifndef ASSET_LC_BUDGET
-#define ASSET_LC_BUDGET (64 * 1024)
-#endif
-  // very wide ODEs: no LDS row fits -> the evaluating lanes write J/H straight to the workspace (uncoalesced, correct)
-  static constexpr bool STAGED = (16 * STG_LD * 8 <= ASSET_LC_BUDGET);
-  static constexpr int LC = !STAGED ? 64
-                            : (64 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 64 : ((32 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 32 : 16);
-  // LDS of the two launches: [weight tables | staging rows] and [weight tables | slot buffer | dense scratch]
-  static constexpr size_t lds_bytes_ode() { return size_t(TABSZ + (STAGED ? LC * STG_LD : 0)) * 8; }
-  static constexpr size_t lds_bytes_dense() { return size_t(TABSZ + DENSE) * 8; }
-  static constexpr size_t lds_bytes() { return lds_bytes_ode() > lds_bytes_dense() ? lds_bytes_ode() : lds_bytes_dense(); }
-};
-
-using d4 = __attribute__((ext_vector_type(4))) double;
-
-// ---------------------------------------------------------------------------------------------- ODE accessors
-template <class D>
-struct CardIn {  // y = [z_j (q), P (p)] read from the slot's copy of z; lam = adjoint weights in registers
-  const double* z;
-  const double* w;
-  int j;
-  const double* sv = nullptr;  // saved transcendental values of f at this node (fjgh_load)
-  __device__ double y(int i) const { return i < D::q ? z[j * D::q + i] : z[D::P0 + (i - D::q)]; }
-  __device__ double lam(int k) const { return w[k]; }
-  __device__ double saved(int k) const { return sv[k]; }
-};
-template <class D>
-struct RegIn {
-  const double* yv;
-  const double* lv;
-  __device__ double y(int i) const { return yv[i]; }
-  __device__ double lam(int k) const { return lv[k]; }
-};
-template <class D>
-struct OdeOut {  // routes every derivative entry to its LDS slot (J row-major n x N, H packed lower)
-  double* f_;
-  double* J_;
-  double* g_;
-  double* H_;
-  __device__ void f(int k, double v) { f_[k] = v; }
-  __device__ void J(int k, int i, double v) { J_[k * D::N + i] = v; }
-  __device__ void g(int i, double v) { g_[i] = v; }
-  __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
-};
-
-// LDS-address-space pointer: stores through it are ds_write (tracked by lgkmcnt only), never flat
-typedef __attribute__((address_space(3))) double lds_double;
-
-template <class D, bool ACCG = false>
-struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H non-zeros -> this lane's LDS staging row [J | H]
-  using JP = std::conditional_t<D::STAGED, lds_double*, double*>;
-  double* f_;
-  double* g_;
-  JP J_;
-  JP H_;
-  double* sv_ = nullptr;
-  const double* lamv_ = nullptr;                       // ACCG: multipliers of this point's defect rows ...
-  double gacc_[ACCG ? D::N : 1];                       // ... and g^ = J^^T lam accumulated while J is emitted (fj has no g)
-  __device__ void f(int k, double v) { f_[k] = v; }
-  __device__ void J(int k, int i, double v) {          // (k, i) are literals in the generated bodies: the lookup folds
-    const int c = D::ode_t::JPOS[k * D::N + i];
-    if (c >= 0) {
-      J_[c] = v;
-      if constexpr (ACCG) gacc_[i] += lamv_[k] * v;
-    }
-  }
-  __device__ void g(int i, double v) { g_[i] = v; }
-  __device__ void H(int i, int j, double v) {
-    const int c = D::ode_t::HPOS[i * (i + 1) / 2 + j];
-    if (c >= 0) H_[c] = v;
-  }
-  __device__ void save(int k, double v) { sv_[k] = v; }
-};
-
-template <class D>
-__device__ inline auto stage_or(lds_double* row, double* slot) {
-  if constexpr (D::STAGED) { (void)slot; return row; } else { (void)row; return slot; }
-}
-
-__device__ inline double hsym(const double* Hp, int a, int b) {
-  return a >= b ? Hp[a * (a + 1) / 2 + b] : Hp[b * (b + 1) / 2 + a];
-}
-
-// true when block columns [16ct,16ct+16) and rows [16rt,16rt+16) can hold a cardinal diagonal / parameter entry
-template <class D>
-__device__ constexpr bool tiles_share_node(int ct, int rt) {
-  const int c0 = 16 * ct, c1 = (16 * ct + 15 < D::IR - 1) ? 16 * ct + 15 : D::IR - 1;
-  const int r0 = 16 * rt, r1 = (16 * rt + 15 < D::IR - 1) ? 16 * rt + 15 : D::IR - 1;
-  if (c0 > c1 || r0 > r1) return false;
-  if (D::p > 0 && r1 >= D::P0) return true;                 // parameter rows couple to every column
-  const int jc0 = c0 / D::q, jc1 = c1 / D::q, jr0 = r0 / D::q, jr1 = r1 / D::q;
-  return !(jr1 < jc0 || jc1 < jr0);
-}
-
-// One wave per workgroup.  LDS instructions of a wave execute in issue order, so LDS hand-offs between lanes only
-// need the compiler kept from reordering (and the reads returned); crucially this does NOT wait for outstanding
-// global stores the way __syncthreads() (vmcnt(0)) does -- the block stores of a segment drain behind the next one.
-__device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// Hand-offs through the global workspace (same wave writes, then reads): wait for the stores as well.
-__device__ inline void wave_mem_sync() { __syncthreads(); }
 
 // ---------------------------------------------------------------------------------------------- ODE phases
 // Kept out of line: each is a long straight-line generated body, and separating their register allocation from
@@ -1173,174 +976,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
     for (int t = 0; t + 1 < nts; t++) a.FX[size_t(wg_first) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
 #endif
 #undef TS
-}
-
-}  // namespace asset_hip
-
-// =============================================================================================== Trapezoidal
-// d = -[(x1 - x0) - (h/2)(f0 + f1)], its Jacobian, adjoint gradient and adjoint Hessian
-// (/root/reference/src/OptimalControl/TrapezoidalDefects.h:146-184, 186-260, 263-435).  No interior point and
-// no congruence product: every block entry is a closed form of the two cardinal ODE evaluations, so the kernel
-// is two phases -- lane <-> (segment, node) for the ODE, then lanes stride over the block slots of each segment
-// and store straight to HBM (coalesced, reference slot order).
-namespace asset_hip {
-
-template <class Ode, bool BLOCKED_>
-struct TrapDims {
-  static constexpr int n = Ode::XV;
-  static constexpr int m = BLOCKED_ ? 0 : Ode::UV;
-  static constexpr int p = BLOCKED_ ? Ode::UV + Ode::PV : Ode::PV;
-  static constexpr int q = n + 1 + m;
-  static constexpr int N = q + p;
-  static constexpr int T = n, TF = q + n, P0 = 2 * q;
-  static constexpr int IR = 2 * q + p, OR = n;
-  static constexpr int NKKT = IR * (IR + 1) / 2 + OR * IR;
-  static constexpr int NH = N * (N + 1) / 2;
-  static constexpr int o_z = 0, o_lam = o_z + IR, o_F = o_lam + OR, o_J = o_F + 2 * n, o_G = o_J + 2 * n * N,
-                       o_H = o_G + 2 * N, SLOT = o_H + 2 * NH;
-  static_assert(IR + OR < 256, "slot map packs the row index in 8 bits");
-  template <int G>
-  static constexpr size_t lds_bytes() { return size_t(G) * SLOT * 8 + size_t((NKKT + 3) / 4 * 4) * 2; }
-};
-
-template <class D>
-struct TrapIn {
-  const double* z;
-  const double* l;
-  int j;
-  __device__ double y(int i) const { return i < D::q ? z[j * D::q + i] : z[D::P0 + (i - D::q)]; }
-  __device__ double lam(int k) const { return l[k]; }
-};
-template <class D>
-struct TrapOut {
-  double* f_;
-  double* J_;
-  double* g_;
-  double* H_;
-  __device__ void f(int k, double v) { f_[k] = v; }
-  __device__ void J(int k, int i, double v) { J_[k * D::N + i] = v; }
-  __device__ void g(int i, double v) { g_[i] = v; }
-  __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
-};
-
-// out of line for the same reason as the LGL ODE phases: a long generated body with its own register allocation
-template <class Ode, class D, int LEVEL>
-__device__ __attribute__((noinline)) void trap_node_eval(double* S, int j) {
-  TrapIn<D> in{S + D::o_z, S + D::o_lam, j};
-  TrapOut<D> out{S + D::o_F + j * D::n, S + D::o_J + j * D::n * D::N, S + D::o_G + j * D::N, S + D::o_H + j * D::NH};
-  if constexpr (LEVEL == 0) Ode::f(in, out);
-  else if constexpr (LEVEL == 1) Ode::fj(in, out);
-  else Ode::fjgh(in, out);
-}
-
-template <class Ode, bool BLOCKED, int G, int LEVEL>
-__global__ __launch_bounds__(64) void trap_defect_kernel(EvalArgs a) {
-  using D = TrapDims<Ode, BLOCKED>;
-  constexpr int n = D::n, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0, IR = D::IR, OR = D::OR;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  unsigned short* kmap = reinterpret_cast<unsigned short*>(lds + G * D::SLOT);
-  const int lane = threadIdx.x;
-  if constexpr (LEVEL >= 1) {
-    for (int k = lane; k < D::NKKT; k += 64) {
-      int lo = 0, hi = IR - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (mid * (IR + OR) - mid * (mid - 1) / 2 <= k) lo = mid; else hi = mid - 1;
-      }
-      const int r = k - (lo * (IR + OR) - lo * (lo - 1) / 2);
-      kmap[k] = static_cast<unsigned short>((lo << 8) | (r < IR - lo ? lo + r : IR + (r - (IR - lo))));
-    }
-  }
-  __syncthreads();
-  const int ngroups = (a.nseg + G - 1) / G;
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int seg0 = grp * G, gcount = min(G, a.nseg - seg0);
-    for (int e = lane; e < gcount * IR; e += 64) {
-      const int g = e / IR, r = e - g * IR;
-      lds[g * D::SLOT + D::o_z + r] = a.X[a.vindex[size_t(seg0 + g) * IR + r]];
-    }
-    if constexpr (LEVEL >= 1) {
-      for (int e = lane; e < gcount * OR; e += 64) {
-        const int g = e / OR, r = e - g * OR;
-        lds[g * D::SLOT + D::o_lam + r] = a.L ? a.L[a.cindex[size_t(seg0 + g) * OR + r]] : 0.0;
-      }
-    }
-    __syncthreads();
-    for (int e = lane; e < gcount * 2; e += 64) trap_node_eval<Ode, D, LEVEL>(lds + (e >> 1) * D::SLOT, e & 1);
-    __syncthreads();
-    for (int g = 0; g < gcount; g++) {
-      const double* S = lds + g * D::SLOT;
-      const double* z = S + D::o_z;
-      const double* lam = S + D::o_lam;
-      const double* F0 = S + D::o_F;
-      const double* F1 = F0 + n;
-      const double* J0 = S + D::o_J;
-      const double* J1 = J0 + n * N;
-      const double* G0 = S + D::o_G;
-      const double* G1 = G0 + N;
-      const double* H0 = S + D::o_H;
-      const double* H1 = H0 + D::NH;
-      const double h = z[TF] - z[T];
-      const double mh2 = -h / 2.0;
-      const size_t seg = size_t(seg0 + g);
-      if (a.FX)
-        for (int k = lane; k < OR; k += 64)
-          a.FX[seg * OR + k] = -((z[q + k] - z[k]) - (h / 2.0) * (F0[k] + F1[k]));
-      if constexpr (LEVEL == 0) continue;
-      // final (already negated) Jacobian entry
-      auto jac = [&](int k, int c) -> double {
-        double v;
-        if (c < q) {
-          v = mh2 * J0[k * N + c];
-          if (c == k) v += -1.0;
-          if (c == T) v -= -0.5 * (F0[k] + F1[k]);
-        } else if (c < P0) {
-          const int cc = c - q;
-          v = mh2 * J1[k * N + cc];
-          if (cc == k) v += 1.0;
-          if (cc == T) v += -0.5 * (F0[k] + F1[k]);
-        } else {
-          v = mh2 * (J0[k * N + q + (c - P0)] + J1[k * N + q + (c - P0)]);
-        }
-        return -v;
-      };
-      auto htpar = [&](int c) -> double {
-        if (c < q) return -G0[c] * 0.5;
-        if (c < P0) return -G1[c - q] * 0.5;
-        return -G0[q + (c - P0)] * 0.5 + -G1[q + (c - P0)] * 0.5;
-      };
-      auto hess = [&](int r, int c) -> double {  // r >= c, final sign
-        double v = 0.0;
-        if (r < q) v = mh2 * hsym(H0, r, c);
-        else if (r < P0) { if (c >= q) v = mh2 * hsym(H1, r - q, c - q); }
-        else if (c >= P0) v = mh2 * (hsym(H0, q + r - P0, q + c - P0) + hsym(H1, q + r - P0, q + c - P0));
-        else if (c < q) v = mh2 * hsym(H0, q + r - P0, c);
-        else v = mh2 * hsym(H1, q + r - P0, c - q);
-        if (c == T) v -= htpar(r);
-        if (c == TF) v += htpar(r);
-        if (r == T) v -= htpar(c);
-        if (r == TF) v += htpar(c);
-        return -v;
-      };
-      if (a.AGX)
-        for (int c = lane; c < IR; c += 64) {
-          double acc = 0.0;
-          for (int k = 0; k < OR; k++) acc += lam[k] * jac(k, c);
-          a.AGX[seg * IR + c] = acc;
-        }
-      if (a.KKT) {
-        double* dst = a.KKT + seg * size_t(D::NKKT);
-        for (int k = lane; k < D::NKKT; k += 64) {
-          const int code = kmap[k], c = code >> 8, r = code & 255;
-          double v;
-          if (r < IR) v = (LEVEL >= 2) ? hess(r, c) : 0.0;
-          else v = jac(r - IR, c);
-          dst[k] = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
 }
 
 }  // namespace asset_hip

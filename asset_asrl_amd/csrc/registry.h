@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "defect_kernels.h"
+#include "trap_kernels.h"
 
 namespace asset_hip {
 
