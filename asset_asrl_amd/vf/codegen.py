@@ -89,6 +89,7 @@ def _cnum(v: float) -> str:
     return f"({s})" if v < 0 else s
 
 
+SPLIT_OPS = 1500     # fjgh bodies above this many operations are emitted in two out-of-line parts
 LEVEL_ORDER = os.environ.get("ASSET_LEVEL_ORDER", "1") == "1"   # breadth-first statement schedule (experiment switch)
 
 TRANSCENDENTAL = ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "asin", "acos", "atan",
@@ -294,75 +295,74 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     o.append(arr("HPOS", [hpos.get(e, -1) for e in range(N * (N + 1) // 2)]))
     o.append(arr("JIDX", jnz))
     o.append(arr("HIDX", hnz))
-    sigs = [
-        ("f", "template <class In, class Out> __host__ __device__ static inline void f(const In& in, Out& out)"),
-        ("fj", "template <class In, class Out> __host__ __device__ static inline void fj(const In& in, Out& out)"),
-        ("fjgh", "template <class In, class Out> __host__ __device__ static inline void fjgh(const In& in, Out& out)"),
-    ]
     saved = saved_nodes(d)
     o.insert(-1, f"  static constexpr int NSAVE = {len(saved)};   // transcendental values f_save() hands to fjgh_load()")
-    for level, (_, sig) in enumerate(sigs):
-        low = lower_reciprocals(_level_roots(d, level))
-        p = _Printer(low, pair_sincos=True, level_order=LEVEL_ORDER)
-        it = iter(low)
-        o.append(f"  {sig} {{")
+    # Large bodies (Betts low-thrust: 7 800 operations for value + J + g + H, ~780 values live at the peak) are emitted
+    # as two out-of-line parts -- [f, J, g] and [H] -- so each gets its own register allocation (live sets 221 / 391
+    # instead of 783), in depth-first order (the breadth-first order widens live ranges further).  The parts recompute
+    # what they share.
+    split = st["ops_fjgh"] > SPLIT_OPS
+    level_order = LEVEL_ORDER and not split
+    sig = "template <class In, class Out> __host__ __device__ static {q} void {name}(const In& in, Out& out)"
+
+    def outputs(level):
+        """[(statement format, root)] in the order of _level_roots(d, level)."""
+        outs = [(f"out.f({k}, {{}});", d.f[k]) for k in range(n)]
+        if level >= 1:
+            outs += [(f"out.J({k}, {i}, {{}});", d.J[k][i]) for k in range(n) for i in range(N)]
+        if level >= 2:
+            outs += [(f"out.g({i}, {{}});", d.g[i]) for i in range(N)]
+            outs += [(f"out.H({i}, {j}, {{}});", d.H[i][j]) for i in range(N) for j in range(i + 1)]
+        return outs
+
+    def body(name, outs, extra_roots=(), extra_stmt=None, use_saved=False, q="inline"):
+        roots = [r for _, r in outs] + list(extra_roots)
+        if use_saved:
+            low = lower_reciprocals(roots + saved)       # lowering rebuilds nodes: locate the saved ones afterwards
+            loaded = {low[len(roots) + k].id: f"s{k}" for k in range(len(saved))}
+            low = low[:len(roots)]
+        else:
+            low, loaded = lower_reciprocals(roots), None
+        p = _Printer(low, loaded=loaded, pair_sincos=True, level_order=level_order)
+        o.append("  " + sig.format(q=q, name=name) + " {")
         for i in sorted(p.used_y):
             o.append(f"    const double y{i} = in.y({i});")
         for k in sorted(p.used_l):
             o.append(f"    const double l{k} = in.lam({k});")
-        o += ["    " + ln for ln in p.lines]
-        for k in range(n):
-            o.append(f"    out.f({k}, {p.ref(next(it))});")
-        if level >= 1:
-            for k in range(n):
-                for i in range(N):
-                    o.append(f"    out.J({k}, {i}, {p.ref(next(it))});")
-        if level >= 2:
-            for i in range(N):
-                o.append(f"    out.g({i}, {p.ref(next(it))});")
-            for i in range(N):
-                for j in range(i + 1):
-                    o.append(f"    out.H({i}, {j}, {p.ref(next(it))});")
+        if use_saved:
+            for k in range(len(saved)):
+                o.append(f"    const double s{k} = in.saved({k});")
+        o.extend("    " + ln for ln in p.lines)
+        for (fmt, _), node in zip(outs, low):
+            o.append("    " + fmt.format(p.ref(node)))
+        if extra_stmt:
+            for k, node in enumerate(low[len(outs):]):
+                o.append("    " + extra_stmt.format(k, p.ref(node)))
         o.append("  }")
+
+    def two_parts(name, use_saved):
+        outs = outputs(2)
+        nfjg = n + n * N + N
+        body(name + "_fjg_", outs[:nfjg], use_saved=use_saved, q="__attribute__((noinline))")
+        body(name + "_h_", outs[nfjg:], use_saved=use_saved, q="__attribute__((noinline))")
+        o.append("  " + sig.format(q="inline", name=name) + " {")
+        o.append(f"    {name}_fjg_(in, out);")
+        o.append(f"    {name}_h_(in, out);")
+        o.append("  }")
+
+    body("f", outputs(0))
+    body("fj", outputs(1))
+    if split:
+        two_parts("fjgh", False)
+    else:
+        body("fjgh", outputs(2))
     # ---- f_save / fjgh_load: the value pass stores every transcendental sub-expression of f; the second-derivative
     #      pass at the SAME point (cardinal nodes: LGLDefects.h:336 then :383-384) loads them instead of recomputing
-    sv_ids = {nd.id: k for k, nd in enumerate(saved)}
-    roots0 = _level_roots(d, 0) + saved
-    p = _Printer(lower_reciprocals(roots0), pair_sincos=True, level_order=LEVEL_ORDER)
-    low0 = lower_reciprocals(roots0)
-    o.append("  template <class In, class Out> __host__ __device__ static inline void f_save(const In& in, Out& out) {")
-    for i in sorted(p.used_y):
-        o.append(f"    const double y{i} = in.y({i});")
-    o += ["    " + ln for ln in p.lines]
-    for k in range(n):
-        o.append(f"    out.f({k}, {p.ref(low0[k])});")
-    for k in range(len(saved)):
-        o.append(f"    out.save({k}, {p.ref(low0[n + k])});")
-    o.append("  }")
-    roots2 = _level_roots(d, 2)
-    low2 = lower_reciprocals(roots2 + saved)          # lowering rebuilds nodes: locate the saved ones afterwards
-    loaded = {low2[len(roots2) + k].id: f"s{k}" for k in range(len(saved))}
-    p = _Printer(low2[:len(roots2)], loaded=loaded, pair_sincos=True, level_order=LEVEL_ORDER)
-    o.append("  template <class In, class Out> __host__ __device__ static inline void fjgh_load(const In& in, Out& out) {")
-    for i in sorted(p.used_y):
-        o.append(f"    const double y{i} = in.y({i});")
-    for k in sorted(p.used_l):
-        o.append(f"    const double l{k} = in.lam({k});")
-    for k in range(len(saved)):
-        o.append(f"    const double s{k} = in.saved({k});")
-    o += ["    " + ln for ln in p.lines]
-    it = iter(low2[:len(roots2)])
-    for k in range(n):
-        o.append(f"    out.f({k}, {p.ref(next(it))});")
-    for k in range(n):
-        for i in range(N):
-            o.append(f"    out.J({k}, {i}, {p.ref(next(it))});")
-    for i in range(N):
-        o.append(f"    out.g({i}, {p.ref(next(it))});")
-    for i in range(N):
-        for j in range(i + 1):
-            o.append(f"    out.H({i}, {j}, {p.ref(next(it))});")
-    o.append("  }")
+    body("f_save", outputs(0), extra_roots=saved, extra_stmt="out.save({}, {});")
+    if split:
+        two_parts("fjgh_load", True)
+    else:
+        body("fjgh_load", outputs(2), use_saved=True)
     o.append("};")
     return "\n".join(o) + "\n"
 
