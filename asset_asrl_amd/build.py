@@ -60,18 +60,9 @@ def pick_group(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
     return 64 // cs if d["lds_bytes"]() <= LDS_BUDGET else 0
 
 
-def pick_trap_group(xv, uv, pv, blocked):
-    n = xv
-    m, p = (0, uv + pv) if blocked else (uv, pv)
-    q = n + 1 + m
-    N = q + p
-    IR, OR = 2 * q + p, n
-    slot = IR + OR + 2 * n + 2 * n * N + 2 * N + N * (N + 1)
-    nkkt = IR * (IR + 1) // 2 + OR * IR
-    for G in (32, 16, 8, 4, 2, 1):
-        if G * slot * 8 + (nkkt + 3) // 4 * 4 * 2 <= (32 if G > 1 else 60) * 1024:
-            return G
-    return 0
+def pick_trap_group(xv, uv, pv, blocked, nsave=0, nzj=None, nzh=None):
+    """Trapezoidal runs through the LGL kernels as a two-node scheme (csrc/defect_dims.h, Dims::TRAP)."""
+    return pick_group(xv, uv, pv, 2, blocked, nsave, nzj, nzh)
 
 
 def _struct_name(name: str) -> str:
@@ -101,7 +92,8 @@ def generate(verbose=True):
                     continue  # working set exceeds one CU's LDS -- not instantiated (asset_hip_has_kernel says so)
                 units.append((f"lgl{cs}_{blocked}", f"ASSET_REGISTER_LGL({sn}, {cs}, {blocked}, {G})"))
         for blocked in ((0, 1) if uv > 0 else (0,)):
-            G = pick_trap_group(xv, uv, pv, bool(blocked))
+            st = ode.derivatives().stats()
+            G = pick_trap_group(xv, uv, pv, bool(blocked), len(saved_nodes(ode.derivatives())), st["nnz_J"], st["nnz_H_lower"])
             if G:
                 units.append((f"trap_{blocked}", f"ASSET_REGISTER_TRAP({sn}, {blocked}, {G})"))
         for tag, line in units:

@@ -11,7 +11,6 @@
 #include "../../include/asset_hip.h"
 #include <dlfcn.h>
 
-#include "assembly_kernels.h"
 #include "registry.h"
 
 namespace {
@@ -61,7 +60,7 @@ struct asset_hip_defect {
   double *d_X = nullptr, *d_L = nullptr, *d_fx = nullptr, *d_agx = nullptr, *d_kkt = nullptr;
   double* d_work = nullptr;  // per-workgroup ODE result slots
   // on-device KKT assembly (asset_hip_defect_set_kkt_map)
-  int32_t* d_map = nullptr;        // value location of every block slot, slot order or (fused kernels) fragment order
+  int32_t* d_map = nullptr;        // value location of every accumulator entry, fragment order (defect_kernels.h, ASM)
   size_t map_len = 0;
   double* d_values = nullptr;      // [value_hi - value_lo) staging for the host-pointer entry point
   double* h_values = nullptr;      // pinned mirror of d_values
@@ -210,6 +209,9 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
   if (ke->work_doubles) {
     if ((e = hipMalloc(&h->d_work, size_t(h->nseg) * ke->work_doubles * sizeof(double))) != hipSuccess)
       return bail(e, "hipMalloc(workspace)");
+    // sections no kernel writes must read as zero (the interior-point sections of a Trapezoidal slot, defect_dims.h)
+    if ((e = hipMemset(h->d_work, 0, size_t(h->nseg) * ke->work_doubles * sizeof(double))) != hipSuccess)
+      return bail(e, "hipMemset(workspace)");
   }
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -257,7 +259,7 @@ static int launch(asset_hip_defect_t h, int what, const double* dX, const double
   a.AGX = (what == ASSET_HIP_CON || what == ASSET_HIP_JAC) ? nullptr : dagx;
   a.KKT = (what >= ASSET_HIP_JAC) ? dkkt : nullptr;
   a.work = h->d_work;
-  if (d_values) a.kmap = h->d_map, a.values = d_values, a.KKT = nullptr;   // fused assembly (ke->fused_assembly)
+  if (d_values) a.kmap = h->d_map, a.values = d_values, a.KKT = nullptr;   // on-device assembly
   hipError_t e = h->ke->launch(level, a, h->cus, st);
   if (e != hipSuccess) return hipfail(e, "kernel launch");
   return 0;
@@ -332,7 +334,7 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
     hi = m + 1 > hi ? m + 1 : hi;
   }
   // a location used by exactly one slot is stored to, one that several slots share is added to atomically
-  // (encoding: assembly_kernels.h); in accumulate mode every slot adds
+  // (encoding: defect_dims.h, EvalArgs::kmap); in accumulate mode every slot adds
   std::vector<unsigned char> uses(accumulate ? 0 : size_t(hi - lo), 0);
   if (!accumulate)
     for (size_t i = 0; i < nslots; i++) {
@@ -341,7 +343,7 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
     }
   auto encode = [&](int32_t m) { return (accumulate || uses[size_t(m - lo)] > 1) ? -(m + 2) : m; };
   std::vector<int32_t> map;
-  if (h->ke->fused_assembly) {
+  {
     // fragment order of the LGL dense stage (defect_kernels.h, ASM): for every segment (4*tiles) rows of 64 lanes;
     // lane (lr = l & 15, lk = l >> 4), entry v of an accumulator tile is block column c = 16ct + lk + 4v and row
     // r = 16rt + lr (H, lower-triangle tiles first, tix = rt(rt+1)/2 + ct) or defect row jr = 16jt + lr
@@ -372,9 +374,6 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
       int32_t* dst = map.data() + size_t(V) * NF * 64;
       for (size_t e = 0; e < size_t(NF) * 64; e++) dst[e] = slot_of[e] < 0 ? -1 : encode(loc[slot_of[e]]);
     }
-  } else {
-    map.resize(nslots);
-    for (size_t i = 0; i < nslots; i++) map[i] = encode(slot_locations[i]);
   }
   if (h->d_map && h->map_len != map.size()) {
     (void)hipFree(h->d_map);
@@ -392,19 +391,6 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
   return 0;
 }
 
-static int scatter(asset_hip_defect_t h, const double* d_blocks, double* d_values_base, hipStream_t st) {
-  const size_t nslots = size_t(h->nseg) * h->ke->nkkt;
-  const int block = 256;
-  size_t grid = (nslots + block - 1) / block;
-  const size_t cap = size_t(h->cus) * 16;            // grid-stride: a few resident workgroups per CU
-  if (grid > cap) grid = cap;
-  hipLaunchKernelGGL(asset_hip::kkt_scatter_kernel, dim3((unsigned)grid), dim3(block), 0, st, d_blocks, h->d_map, nslots,
-                     d_values_base);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hipfail(e, "kkt_scatter_kernel launch");
-  return 0;
-}
-
 int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
                                            double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_values,
                                            void* stream) {
@@ -414,12 +400,8 @@ int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const
   if (!d_kkt_values) return fail(ASSET_HIP_EINVAL, "kkt value array is null");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
-  if (h->ke->fused_assembly)   // the dense stage adds its accumulators into the value array itself
-    return launch(h, what, dX, dL, d_fx_blocks, d_agx_blocks, nullptr, st, d_kkt_values);
-  if (!h->d_kkt) HIP_TRY(hipMalloc(&h->d_kkt, sizeof(double) * size_t(h->nseg) * h->ke->nkkt));
-  int rc = launch(h, what, dX, dL, d_fx_blocks, d_agx_blocks, h->d_kkt, st);
-  if (rc) return rc;
-  return scatter(h, h->d_kkt, d_kkt_values, st);
+  // the dense stage places its accumulators in the value array itself (defect_kernels.h, ASM instantiations)
+  return launch(h, what, dX, dL, d_fx_blocks, d_agx_blocks, nullptr, st, d_kkt_values);
 }
 
 int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double* X, const double* L,

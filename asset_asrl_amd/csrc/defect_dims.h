@@ -20,7 +20,7 @@
 
 namespace asset_hip {
 
-static __constant__ LglTab d_lgl_tab[3] = ASSET_LGL_TABLE_INIT;
+static __constant__ LglTab d_lgl_tab[4] = ASSET_LGL_TABLE_INIT;
 
 struct EvalArgs {
   int nseg;
@@ -32,8 +32,14 @@ struct EvalArgs {
   double* AGX;         // [nseg x IR] blocks or null
   double* KKT;         // [nseg x NKKT] blocks or null
   double* work;        // [grid][G][SLOT] per-workgroup ODE result slots (L2-resident scratch in HBM)
-  // on-device assembly (dense stage, ASM kernels): KKT entries are added into values[kmap[seg*NKKT + slot]]
-  // instead of being stored as blocks (DenseFunctionBase.h:1413-1523 KKTFillAll / KKTFillJac)
+  // On-device assembly (dense stage, ASM kernels): KKT entries go into the solver's value array instead of being
+  // stored as blocks (DenseFunctionBase.h:1413-1523 KKTFillAll / KKTFillJac; locations NonLinearProgram.cpp:316-330;
+  // the reference serialises clashing columns with mutexes, KKTClashes / KKTLocks).  kmap holds, per segment and in
+  // accumulator-fragment order, one entry per lane and accumulator entry:  m >= 0 -- value location used by this slot
+  // alone: the entry is STORED (the caller hands over zeros there, as the reference zeroes the KKT values before every
+  // evaluation, PSIOPT.cpp:107);  m <= -2 -- location -(m+2) is shared with other slots of this constraint (boundary
+  // nodes of adjacent segments, phase parameters): no-return f64 atomic add;  -1 -- no KKT slot.  In accumulate mode
+  // every slot is encoded as shared, which makes the evaluation a true += at about 1.4e11 atomics/s.
   const int* kmap = nullptr;
   double* values = nullptr;
 };
@@ -41,7 +47,12 @@ struct EvalArgs {
 // ---------------------------------------------------------------------------------------------- sizes
 template <class Ode, int CS_, bool BLOCKED_>
 struct Dims {
-  static constexpr int CS = CS_, K = CS_ - 1;
+  // CS_ is the transcription id of the C ABI: 2, 3, 4 = LGL3 / LGL5 / LGL7 (the number of cardinal nodes); 1 = Trapezoidal,
+  // which runs through the same kernels as a two-node scheme whose interior point has weight E = 0 and is never
+  // evaluated (lgl_tables.h): its interior sections of the workspace stay at the zeros they are created with.
+  static constexpr bool TRAP = (CS_ == 1);
+  static constexpr int TAB = TRAP ? 3 : CS_ - 2;        // index into d_lgl_tab
+  static constexpr int CS = TRAP ? 2 : CS_, K = CS - 1;
   static constexpr int n = Ode::XV;
   static constexpr int m = BLOCKED_ ? 0 : Ode::UV;                    // Blocked_ODE_Wrapper.h:7-27
   static constexpr int p = BLOCKED_ ? Ode::UV + Ode::PV : Ode::PV;
@@ -138,18 +149,6 @@ struct RegIn {
   __device__ double y(int i) const { return yv[i]; }
   __device__ double lam(int k) const { return lv[k]; }
 };
-template <class D>
-struct OdeOut {  // routes every derivative entry to its LDS slot (J row-major n x N, H packed lower)
-  double* f_;
-  double* J_;
-  double* g_;
-  double* H_;
-  __device__ void f(int k, double v) { f_[k] = v; }
-  __device__ void J(int k, int i, double v) { J_[k * D::N + i] = v; }
-  __device__ void g(int i, double v) { g_[i] = v; }
-  __device__ void H(int i, int j, double v) { H_[i * (i + 1) / 2 + j] = v; }
-};
-
 // LDS-address-space pointer: stores through it are ds_write (tracked by lgkmcnt only), never flat
 typedef __attribute__((address_space(3))) double lds_double;
 
@@ -182,10 +181,6 @@ struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H non-zeros -
 template <class D>
 __device__ inline auto stage_or(lds_double* row, double* slot) {
   if constexpr (D::STAGED) { (void)slot; return row; } else { (void)row; return slot; }
-}
-
-__device__ inline double hsym(const double* Hp, int a, int b) {
-  return a >= b ? Hp[a * (a + 1) / 2 + b] : Hp[b * (b + 1) / 2 + a];
 }
 
 // true when block columns [16ct,16ct+16) and rows [16rt,16rt+16) can hold a cardinal diagonal / parameter entry

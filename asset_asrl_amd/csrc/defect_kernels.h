@@ -149,11 +149,12 @@ __device__ inline void copy_rows(const double* stage, int stg_ld, int npt, int e
 // STAGE 1: ODE phases only (P0-P3; results -> workspace slot of every segment).  STAGE 2: dense phase only (P4).
 // They are separate launches because their resource shapes differ: the ODE bodies need ~250 VGPRs and wide LDS
 // staging rows, the dense phase needs few registers and 23 KiB of LDS, so it runs at a higher occupancy.
-template <class Ode, int CS, bool BLOCKED, int G, int LEVEL, int STAGE, bool ASM = false>
-__global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
+template <class Ode, int SCH, bool BLOCKED, int G, int LEVEL, int STAGE, bool ASM = false>
+__global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
                                                    ? ASSET_DENSE_WAVES_PER_SIMD : 1)   // LDS-bound to one wave per SIMD anyway: take the registers
                                              : ASSET_ODE_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
-  using D = Dims<Ode, CS, BLOCKED>;
+  using D = Dims<Ode, SCH, BLOCKED>;
+  constexpr int CS = D::CS;
   constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0;
   constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, ORP = D::ORP, NP = D::NP, KS = D::KS;
   constexpr int LC = D::LC, NSTG = D::NSTG, STG_LD = D::STG_LD;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
   double tabv[NTAB];
 #pragma unroll
   for (int t = 0; t < NTAB; t++)
-    tabv[t] = (lane + 64 * t < D::TABSZ) ? reinterpret_cast<const double*>(&d_lgl_tab[CS - 2])[lane + 64 * t] : 0.0;
+    tabv[t] = (lane + 64 * t < D::TABSZ) ? reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[lane + 64 * t] : 0.0;
   auto publish_tables = [&]() {
 #pragma unroll
     for (int t = 0; t < NTAB; t++)
@@ -399,6 +400,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
     TS();
     if (g0 == 0) publish_tables();
     // ------------------------------------------------------------------ P2: interior points
+    // (Trapezoidal: the interior point has weight 0; it is not evaluated and its slot sections keep their zeros)
+    if constexpr (!D::TRAP)
     for (int e0 = 0; e0 < gcount * K; e0 += LC) {
       const int e = e0 + lane;
       if (lane < LC && e < gcount * K) {
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, CS, BLOCKED>::lds_bytes
           for (int v = 0; v < 4; v++) jmap[t][v] = kmap_seg[((D::NTH + t) * 4 + v) * 64];
         }
       };
-      auto put_asm = [&](int off, double val) {           // map encoding: assembly_kernels.h
+      auto put_asm = [&](int off, double val) {           // map encoding: defect_dims.h, EvalArgs::kmap
         if (off >= 0) kkt_dst[off] = val;                  // location owned by this slot alone
         else if (off != -1) unsafeAtomicAdd(kkt_dst + (-(off + 2)), val);   // shared: global_atomic_add_f64, no return
       };

@@ -69,10 +69,17 @@ struct LglTab {
        {+4.83872966828888e-3, +1.00138284831491e-1, +1.00138284831491e-1, +4.83872966828888e-3},               \
        {+2.74945307600086e-3, +1.85682012187242e-2, +9.71662045547156e-2, +1.62213410652341e-2}},              \
       {+1.38413023680783e-1, +2.43809523809524e-1, +1.38413023680783e-1}                                       \
+    },                                                                                                         \
+    { /* Trapezoidal as a degenerate two-node scheme: d = (x_0 - x_1) + h (f_0 + f_1) / 2, i.e. C = [1, -1],     \
+         D = [1/2, 1/2] and an "interior point" of weight E = 0 that is never evaluated                         \
+         (/root/reference/src/OptimalControl/TrapezoidalDefects.h:146-184: -[(x_1 - x_0) - (h/2)(f_0 + f_1)]) */ \
+      {0.0, 1.0}, {0.5},                                                                                       \
+      {{0.5, 0.5}}, {{0.0, 0.0}}, {{0.5, 0.5}},                                                                \
+      {{1.0, -1.0}}, {{0.5, 0.5}}, {0.0}                                                                       \
     }                                                                                                          \
   }
 // clang-format on
 
-static const LglTab h_lgl_tab[3] = ASSET_LGL_TABLE_INIT;  // host copy (C-ABI table query, set-up code)
+static const LglTab h_lgl_tab[4] = ASSET_LGL_TABLE_INIT;  // host copy (C-ABI table query, set-up code)
 
 }  // namespace asset_hip

@@ -7,7 +7,6 @@
 #include <cstring>
 
 #include "defect_kernels.h"
-#include "trap_kernels.h"
 
 namespace asset_hip {
 
@@ -23,7 +22,6 @@ struct KernelEntry {
   // level 0/1/2 ; returns hipError_t
   hipError_t (*launch)(int level, const EvalArgs& a, int cus, hipStream_t st);
   KernelEntry* next;
-  bool fused_assembly = false;   // launch() honours EvalArgs::kmap / values (dense stage adds into the value array itself)
 };
 
 #if defined(ASSET_PLUGIN)
@@ -57,9 +55,9 @@ struct Registrar {
 };
 #endif
 
-template <class Ode, int CS, bool BLOCKED, int G>
+template <class Ode, int SCH, bool BLOCKED, int G>
 hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
-  using D = Dims<Ode, CS, BLOCKED>;
+  using D = Dims<Ode, SCH, BLOCKED>;
   constexpr size_t bytes_ode = D::lds_bytes_ode(), bytes_dense = D::lds_bytes_dense();
   static_assert(bytes_ode <= 160 * 1024 && bytes_dense <= 160 * 1024, "per-workgroup LDS exceeds the 160 KiB of a gfx950 CU");
   // ODE launch: the three ODE phases are latency chains, so spread the segments over every resident wave (fewest
@@ -75,8 +73,8 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   static const int env_b = std::getenv("ASSET_HIP_GRID_B") ? std::atoi(std::getenv("ASSET_HIP_GRID_B")) : 0;  // tuning only
   if (env_b > 0) grid_b = env_b < a.nseg ? env_b : a.nseg;
   static const bool skip_dense = std::getenv("ASSET_HIP_SKIP_DENSE") != nullptr;                               // tuning only
-#define ASSET_LAUNCH(LV, STG, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, CS, BLOCKED, G, LV, STG, false>), GRID, BYTES)
-#define ASSET_LAUNCH_ASM(LV, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, CS, BLOCKED, G, LV, 2, true>), GRID, BYTES)
+#define ASSET_LAUNCH(LV, STG, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, LV, STG, false>), GRID, BYTES)
+#define ASSET_LAUNCH_ASM(LV, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, LV, 2, true>), GRID, BYTES)
 #define ASSET_LAUNCH_K(KERN, GRID, BYTES)                                                                         \
   do {                                                                                                            \
     auto kern = KERN;                                                                                             \
@@ -110,30 +108,8 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   return hipErrorInvalidValue;
 }
 
-template <class Ode, bool BLOCKED, int G>
-hipError_t launch_trap(int level, const EvalArgs& a, int cus, hipStream_t st) {
-  const int ngroups = (a.nseg + G - 1) / G;
-  const int grid = ngroups < cus * 8 ? ngroups : cus * 8;
-  using D = TrapDims<Ode, BLOCKED>;
-  constexpr size_t bytes = D::template lds_bytes<G>();
-  static_assert(bytes <= 64 * 1024, "trapezoidal group does not fit the default dynamic LDS window");
-  switch (level) {
-    case 0: hipLaunchKernelGGL((trap_defect_kernel<Ode, BLOCKED, G, 0>), dim3(grid), dim3(64), bytes, st, a); break;
-    case 1: hipLaunchKernelGGL((trap_defect_kernel<Ode, BLOCKED, G, 1>), dim3(grid), dim3(64), bytes, st, a); break;
-    case 2: hipLaunchKernelGGL((trap_defect_kernel<Ode, BLOCKED, G, 2>), dim3(grid), dim3(64), bytes, st, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-#define ASSET_REGISTER_TRAP(ODE, BLK, G)                                                                          \
-  static ::asset_hip::KernelEntry entry_##ODE##_trap_##BLK = {                                                    \
-      ODE::name(), ODE::XV, ODE::UV, ODE::PV, 1, BLK,                                                             \
-      ::asset_hip::TrapDims<ODE, (BLK != 0)>::IR, ::asset_hip::TrapDims<ODE, (BLK != 0)>::OR,                     \
-      ::asset_hip::TrapDims<ODE, (BLK != 0)>::NKKT, G,                                                            \
-      ::asset_hip::TrapDims<ODE, (BLK != 0)>::template lds_bytes<G>(), 0,                                         \
-      &::asset_hip::launch_trap<ODE, (BLK != 0), G>, nullptr};                                                    \
-  static ::asset_hip::Registrar reg_##ODE##_trap_##BLK(&entry_##ODE##_trap_##BLK);
+// Trapezoidal = transcription id 1 of the same kernels (defect_dims.h: Dims::TRAP)
+#define ASSET_REGISTER_TRAP(ODE, BLK, G) ASSET_REGISTER_LGL(ODE, 1, BLK, G)
 
 #define ASSET_REGISTER_LGL(ODE, CSV, BLK, G)                                                                      \
   static ::asset_hip::KernelEntry entry_##ODE##_##CSV##_##BLK = {                                                 \
@@ -142,7 +118,7 @@ hipError_t launch_trap(int level, const EvalArgs& a, int cus, hipStream_t st) {
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::NKKT, G,                                                           \
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::lds_bytes(),                                                       \
       size_t(::asset_hip::Dims<ODE, CSV, (BLK != 0)>::WSLOT),                                                      \
-      &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr, true};                                          \
+      &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr};                                                \
   static ::asset_hip::Registrar reg_##ODE##_##CSV##_##BLK(&entry_##ODE##_##CSV##_##BLK);
 
 }  // namespace asset_hip

@@ -60,7 +60,7 @@ def ensure_kernel(ode, mode: str, blocked: bool) -> str:
     d.name = name
     st = d.stats()
     if mode == "Trapezoidal":
-        G = build.pick_trap_group(xv, uv, pv, blocked)
+        G = build.pick_trap_group(xv, uv, pv, blocked, len(saved_nodes(d)), st["nnz_J"], st["nnz_H_lower"])
         reg = f"ASSET_REGISTER_TRAP({{S}}, {int(blocked)}, {G})"
     else:
         cs = _MODE_CS[mode]

@@ -28,7 +28,7 @@ def counters(sub):
     if not os.path.exists(path):
         return {}
     for r in csv.DictReader(open(path)):
-        if "lgl_defect_kernel" not in r["Kernel_Name"] and "trap_defect_kernel" not in r["Kernel_Name"]:
+        if "lgl_defect_kernel" not in r["Kernel_Name"]:
             continue
         acc[stage_of(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
