@@ -320,6 +320,54 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- mesh error estimate
+
+int asset_hip_mesh_error_deboor(const char* ode, int mode, int blocked, const double* traj, int nnodes, double* tsnd,
+                                double* mesh_errors, double* mesh_dist, double* error_max, double* dist_max,
+                                int device) {
+  if (!ode || !traj || !tsnd || !mesh_errors || !mesh_dist) return fail(ASSET_HIP_EINVAL, "null argument");
+  const asset_hip::KernelEntry* ke = find_entry(ode, mode, blocked);
+  if (!ke) return fail(ASSET_HIP_ENOODE, std::string("no device code compiled for ode='") + ode + "' in this mode");
+  const int cs = asset_hip::mesh_scheme(mode).cs, n = ke->xv, N = ke->xv + 1 + ke->uv + ke->pv;
+  const int nb = (nnodes - 1) / (cs - 1);
+  if (nb < 2 || nb * (cs - 1) + 1 != nnodes)
+    return fail(ASSET_HIP_EINVAL, "the trajectory must hold nb*(cs-1)+1 nodes with nb >= 2 blocks");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(ASSET_HIP_ENODEV, "no HIP device visible: the estimator has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(ASSET_HIP_EINVAL, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  // one allocation: traj | yvec | hs | tsnd | errors | dist | error_max | dist_max
+  const size_t sz_traj = size_t(nnodes) * N, sz_y = size_t(nb) * n, sz_e = size_t(nb + 1) * n;
+  const size_t total = sz_traj + sz_y + nb + (nb + 1) + 2 * sz_e + 2 * size_t(nb + 1);
+  double* buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, total * sizeof(double)));
+  asset_hip::MeshArgs a;
+  a.nb = nb;
+  double* p = buf;
+  a.traj = p, p += sz_traj;
+  a.yvec = p, p += sz_y;
+  a.hs = p, p += nb;
+  a.tsnd = p, p += nb + 1;
+  a.errors = p, p += sz_e;
+  a.dist = p, p += sz_e;
+  a.error_max = p, p += nb + 1;
+  a.dist_max = p;
+  auto done = [&](int rc) { (void)hipFree(buf); return rc; };
+  hipError_t e = hipMemcpy(buf, traj, sz_traj * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return done(hipfail(e, "hipMemcpy(traj)"));
+  if ((e = ke->mesh(a, nullptr)) != hipSuccess) return done(hipfail(e, "mesh kernels"));
+  if ((e = hipMemcpy(tsnd, a.tsnd, (nb + 1) * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess ||
+      (e = hipMemcpy(mesh_errors, a.errors, sz_e * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess ||
+      (e = hipMemcpy(mesh_dist, a.dist, sz_e * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
+    return done(hipfail(e, "hipMemcpy(results)"));
+  if (error_max && (e = hipMemcpy(error_max, a.error_max, (nb + 1) * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
+    return done(hipfail(e, "hipMemcpy(error_max)"));
+  if (dist_max && (e = hipMemcpy(dist_max, a.dist_max, (nb + 1) * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
+    return done(hipfail(e, "hipMemcpy(dist_max)"));
+  return done(0);
+}
+
 // ---------------------------------------------------------------------------------------------- on-device assembly
 
 int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locations, long long nvalues, int accumulate) {

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "defect_kernels.h"
+#include "mesh_kernels.h"
 
 namespace asset_hip {
 
@@ -22,6 +23,7 @@ struct KernelEntry {
   // level 0/1/2 ; returns hipError_t
   hipError_t (*launch)(int level, const EvalArgs& a, int cus, hipStream_t st);
   KernelEntry* next;
+  hipError_t (*mesh)(const MeshArgs& a, hipStream_t st);   // de Boor mesh-error estimate (mesh_kernels.h)
 };
 
 #if defined(ASSET_PLUGIN)
@@ -118,7 +120,8 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::NKKT, G,                                                           \
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::lds_bytes(),                                                       \
       size_t(::asset_hip::Dims<ODE, CSV, (BLK != 0)>::WSLOT),                                                      \
-      &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr};                                                \
+      &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr,        \
+      &::asset_hip::launch_mesh<ODE, CSV, (BLK != 0)>};                                          \
   static ::asset_hip::Registrar reg_##ODE##_##CSV##_##BLK(&entry_##ODE##_##CSV##_##BLK);
 
 }  // namespace asset_hip

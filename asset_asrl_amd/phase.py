@@ -170,6 +170,21 @@ class Phase:
             self.transcribe()
         return self._ev
 
+    # ---- mesh error (device de Boor estimator; the refinement loop itself stays with the host) ----------------
+    def get_meshinfo_deboor(self):
+        """(tsnd, mesh_errors[XV, nb+1], mesh_dist[XV, nb+1]) -- ODEPhase.h:442-585."""
+        from . import mesh
+        name = jit.ensure_kernel(self.ode, self.TranscriptionMode, self._blocked())
+        return mesh.mesh_error_deboor(name, self.TranscriptionMode, self.ActiveTraj, self._blocked(), self.device)[:3]
+
+    def getMeshInfo(self, integ: bool = False, n: int = 100):
+        """(tsnd, bins, error) -- ODEPhaseBase.h:1355-1399; only the de Boor estimator is provided."""
+        if integ:
+            raise NotImplementedError("the integrator-based estimator needs the ODE integrator, which stays on the host")
+        from . import mesh
+        name = jit.ensure_kernel(self.ode, self.TranscriptionMode, self._blocked())
+        return mesh.mesh_info(name, self.TranscriptionMode, self.ActiveTraj, n, self._blocked(), self.device)
+
     def get_defect(self) -> DefectFunction:
         name = jit.ensure_kernel(self.ode, self.TranscriptionMode, self._blocked())
         return DefectFunction(name, self.TranscriptionMode, self._blocked(), self.device)

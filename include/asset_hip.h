@@ -116,6 +116,18 @@ int asset_hip_defect_time_device(asset_hip_defect_t h, int what, const double* d
                                  double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_blocks, int warmup,
                                  int iters, float* ms_per_launch);
 
+/* ---- de Boor mesh-error estimate ----
+ * Replaces ODEPhase<DODE>::get_meshinfo_deboor (OptimalControl/ODEPhase.h:442-585), the estimator behind
+ * ODEPhaseBase::checkMesh / getMeshInfo (ODEPhaseBase.cpp:1443-1462, ODEPhaseBase.h:1355-1399) when
+ * MeshErrorEstimator == "deboor": ODE value at every node, leading-power combination per block, neighbour
+ * differences.  traj: the phase's ActiveTraj as [nnodes][XV+1+UV+PV] row-major node states [x,t,u,p] (host),
+ * nnodes = nb*(cs-1)+1 with nb >= 2 blocks.  Outputs (host): tsnd[nb+1]; mesh_errors, mesh_dist: XV x (nb+1)
+ * column-major (the reference's Eigen matrices); optional error_max[nb+1], dist_max[nb+1] = their column infinity
+ * norms (what checkMesh / getMeshInfo take next).  AutoScaling units (ODEPhase.h:551-559) are not applied.
+ * `blocked` selects the BlockConstant treatment of the last node of a block (ODEPhase.h:529-537). */
+int asset_hip_mesh_error_deboor(const char* ode, int mode, int blocked, const double* traj, int nnodes, double* tsnd,
+                                double* mesh_errors, double* mesh_dist, double* error_max, double* dist_max, int device);
+
 /* ---- introspection ---- */
 int asset_hip_num_odes(void);
 const char* asset_hip_ode_name(int i);                           /* NULL when i is out of range            */

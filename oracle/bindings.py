@@ -131,6 +131,19 @@ def defect_all(ode, mode, x, lam, blocked=False):
     return fx, jx.T.copy(), gx, hx.T.copy()
 
 
+def mesh_error_deboor(ode, mode, traj, blocked=False):
+    """(tsnd[nb+1], mesh_errors[xv, nb+1], mesh_dist[xv, nb+1]) -- ODEPhase.h:442-585."""
+    traj = np.ascontiguousarray(traj, dtype=float)
+    nnodes = traj.shape[0]
+    cs = 2 if mode == TRAPEZOIDAL else mode
+    nb = (nnodes - 1) // (cs - 1)
+    tsnd, err, dist = np.zeros(nb + 1), np.zeros((nb + 1, ode.xv)), np.zeros((nb + 1, ode.xv))
+    rc = lib().oracle_mesh_error_deboor(C.byref(ode), mode, int(blocked), _d(traj), nnodes, _d(tsnd), _d(err), _d(dist))
+    if rc:
+        raise ValueError(f"oracle_mesh_error_deboor rc={rc}")
+    return tsnd, err.T.copy(), dist.T.copy()
+
+
 def phase_num_vars(xv, uv, pv, spv, cs, nd, blocked):
     return lib().oracle_phase_num_vars(xv, uv, pv, spv, cs, nd, int(blocked))
 
