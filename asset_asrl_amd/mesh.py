@@ -33,9 +33,9 @@ def mesh_error_deboor(ode_name: str, mode: str, traj, blocked: bool = False, dev
     return tsnd, err.T.copy(), dist.T.copy(), emax, dmax
 
 
-def mesh_info(ode_name: str, mode: str, traj, n: int, blocked: bool = False, device: int = 0):
-    """(tsnd, bins, error) -- ODEPhaseBase::getMeshInfo(False, n)."""
-    tsnd, _, _, error, dist = mesh_error_deboor(ode_name, mode, traj, blocked, device)
+def bins_from_density(tsnd, error, dist, n: int):
+    """(tsnd, bins, error): cumulative node-density integral and the equidistributed edges of ``n`` new segments
+    (ODEPhaseBase.h:1372-1398)."""
     distint = np.zeros_like(dist)
     distint[1:] = np.cumsum(dist[:-1] * np.diff(tsnd))
     distint /= distint[-1]
@@ -47,3 +47,9 @@ def mesh_info(ode_name: str, mode: str, traj, n: int, blocked: bool = False, dev
         t0, t1, d0, d1 = tsnd[elem], tsnd[elem + 1], distint[elem], distint[elem + 1]
         bins[i] = (di - d0) / ((d1 - d0) / (t1 - t0)) + t0
     return tsnd, bins, error
+
+
+def mesh_info(ode_name: str, mode: str, traj, n: int, blocked: bool = False, device: int = 0):
+    """(tsnd, bins, error) -- ODEPhaseBase::getMeshInfo(False, n)."""
+    tsnd, _, _, error, dist = mesh_error_deboor(ode_name, mode, traj, blocked, device)
+    return bins_from_density(tsnd, error, dist, n)

@@ -92,6 +92,9 @@ class Phase:
         self.numDefects = 0
         self._ev = None
         self._indexer = None
+        self.AutoScaling = False
+        self.XtUPUnits = np.ones(ode.XtUPVars())
+        self._ode_scaled = None
 
     # ---- configuration ---------------------------------------------------------------------
     def switchTranscriptionMode(self, mode: str):
@@ -107,6 +110,29 @@ class Phase:
             raise ValueError(f"Unrecognized control mode: {mode}")
         self.ControlMode = mode
         self._ev = None
+
+    # ---- AutoScaling: the dynamics in scaled units (ODEPhase.h:87-109 setUnits, :293-326 transcribe_dynamics) --
+    def setUnits(self, XtUPUnits):
+        """Units of [x, t, u, p]; the scaled ODE is ``IOScaled(ode, units, units_t / units_x)``."""
+        u = np.asarray(XtUPUnits, dtype=float).ravel()
+        if u.size != self.ode.XtUPVars():
+            raise ValueError("Incorrect size for input units vector")
+        from .ode import ODEBase
+        from .vf import IOScaled
+        xv = self.ode.XVars()
+        self.XtUPUnits = u.copy()
+        func = IOScaled(self.ode.vf(), u, u[xv] / u[:xv])
+        self._ode_scaled = ODEBase(func, xv, self.ode.UVars(), self.ode.PVars(), name=self.ode.ode_name + "_scaled")
+        self._ev = None
+
+    def setAutoScaling(self, flag: bool = True):
+        self.AutoScaling = bool(flag)
+        if self.AutoScaling and self._ode_scaled is None:
+            self.setUnits(self.XtUPUnits)
+        self._ev = None
+
+    def _active_ode(self):
+        return self._ode_scaled if self.AutoScaling else self.ode
 
     def _blocked(self) -> bool:
         return self.ControlMode == "BlockConstant" and self.ode.UVars() > 0
@@ -149,7 +175,7 @@ class Phase:
         if self.ActiveTraj is None:
             raise RuntimeError("No trajectory set: call setTraj first")
         # library ODEs are compiled into libasset_hip.so; any other ODEBase gets device code on first use (jit.py)
-        name = jit.ensure_kernel(self.ode, self.TranscriptionMode, self._blocked())
+        name = jit.ensure_kernel(self._active_ode(), self.TranscriptionMode, self._blocked())
         ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
         ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
         ix.begin_indexing(0, 0)
@@ -162,7 +188,8 @@ class Phase:
     def solver_input(self) -> np.ndarray:
         if self._indexer is None:
             self.transcribe()
-        return self._indexer.makeSolverInput(self.ActiveTraj)
+        traj = self.ActiveTraj / self.XtUPUnits if self.AutoScaling else self.ActiveTraj   # variables in scaled units
+        return self._indexer.makeSolverInput(traj)
 
     @property
     def evaluator(self) -> DefectEvaluator:
@@ -172,21 +199,31 @@ class Phase:
 
     # ---- mesh error (device de Boor estimator; the refinement loop itself stays with the host) ----------------
     def get_meshinfo_deboor(self):
-        """(tsnd, mesh_errors[XV, nb+1], mesh_dist[XV, nb+1]) -- ODEPhase.h:442-585."""
+        """(tsnd, mesh_errors[XV, nb+1], mesh_dist[XV, nb+1]) -- ODEPhase.h:442-585.  The estimate is taken on the
+        unscaled dynamics and trajectory; with AutoScaling the results are converted to scaled units the way
+        ODEPhase.h:551-559 does (y / x-units * t-unit^Order, h / t-unit)."""
         from . import mesh
         name = jit.ensure_kernel(self.ode, self.TranscriptionMode, self._blocked())
-        return mesh.mesh_error_deboor(name, self.TranscriptionMode, self.ActiveTraj, self._blocked(), self.device)[:3]
+        tsnd, err, dist = mesh.mesh_error_deboor(name, self.TranscriptionMode, self.ActiveTraj, self._blocked(),
+                                                 self.device)[:3]
+        if self.AutoScaling:
+            xv = self.ode.XVars()
+            ux, ut = self.XtUPUnits[:xv, None], self.XtUPUnits[xv]
+            order = {"Trapezoidal": 2.0, "LGL3": 3.0, "LGL5": 5.0, "LGL7": 7.0}[self.TranscriptionMode]
+            err = err / ux
+            dist = dist * (ut ** (order + 1) / ux) ** (1.0 / (order + 1))
+        return tsnd, err, dist
 
     def getMeshInfo(self, integ: bool = False, n: int = 100):
         """(tsnd, bins, error) -- ODEPhaseBase.h:1355-1399; only the de Boor estimator is provided."""
         if integ:
             raise NotImplementedError("the integrator-based estimator needs the ODE integrator, which stays on the host")
         from . import mesh
-        name = jit.ensure_kernel(self.ode, self.TranscriptionMode, self._blocked())
-        return mesh.mesh_info(name, self.TranscriptionMode, self.ActiveTraj, n, self._blocked(), self.device)
+        tsnd, err, dist = self.get_meshinfo_deboor()
+        return mesh.bins_from_density(tsnd, np.abs(err).max(axis=0), np.abs(dist).max(axis=0), n)
 
     def get_defect(self) -> DefectFunction:
-        name = jit.ensure_kernel(self.ode, self.TranscriptionMode, self._blocked())
+        name = jit.ensure_kernel(self._active_ode(), self.TranscriptionMode, self._blocked())
         return DefectFunction(name, self.TranscriptionMode, self._blocked(), self.device)
 
     # ---- the reference's built-in benchmark of the path ---------------------------------------------

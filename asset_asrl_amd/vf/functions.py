@@ -372,6 +372,19 @@ def ColMatrix(f: VectorFunction, rows: int, cols: int) -> MatrixFunction:
     return MatrixFunction(f, rows, cols, False)
 
 
+def IOScaled(func: VectorFunction, input_scales, output_scales) -> VectorFunction:
+    """``output_scales * func(input_scales * x)`` (element-wise) -- the reference's IOScaled wrapper
+    (/root/reference/src/VectorFunctions/CommonFunctions/IOScaled.h:8-158).  Here it is a composition in the
+    expression graph, so the scaled ODE is differentiated and compiled like any other and the scale factors fold
+    into the generated device code."""
+    n = func.IRows()
+    si = np.asarray(input_scales, dtype=float).ravel()
+    so = np.asarray(output_scales, dtype=float).ravel()
+    if si.size != n or so.size != func.ORows():
+        raise ValueError("Incorrect size for input / output scales")
+    return func.eval(Arguments(n) * si) * so
+
+
 def ConstantVector(irows: int, v) -> VectorFunction:
     return VectorFunction(irows, [G.const(x) for x in np.asarray(v, dtype=float).ravel()])
 

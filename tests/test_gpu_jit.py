@@ -44,3 +44,27 @@ def test_phase_api_with_user_ode(oracle):
     assert rel_err(jx, rjx) < 1e-8 and rel_err(gx, rgx) < 1e-8 and rel_err(hx, rhx) < 1e-8
     res = ph.test_threads(1, 1, 2, verbose=False)
     assert res["segments"] == 12
+
+
+def test_autoscaling_phase_evaluates_the_scaled_dynamics(oracle):
+    """setUnits / setAutoScaling (ODEPhase.h:87-109, 293-326): the defect of IOScaled(ode, units, t-unit / x-units) at
+    z / units equals the unscaled defect divided by the state units, its Jacobian is diag(1/ux) J diag(uz)."""
+    from asset_asrl_amd.ode import ShuttleReentry
+    w = Workload("reentry", "LGL5", 9)
+    units = np.array([2.0, 0.5, 3.0, 1.5, 0.8, 4.0, 1.25, 2.5])
+    ph = ShuttleReentry().phase("LGL5", w.traj, 9)
+    ph.setUnits(units)
+    ph.setAutoScaling(True)
+    d = ph.get_defect()
+    rng = np.random.default_rng(3)
+    zi = w.X[w.vindex[4]]                                 # one segment's variables, unscaled
+    lam = rng.uniform(-1, 1, d.ORows())
+    uz = np.tile(units, 3)                                # [x,t,u] units at the three cardinal nodes (no parameters)
+    ux = np.tile(units[:5], 2)                            # defect rows: two interior points x five states
+    fx, jx, gx, hx = d.computeall(zi / uz, lam)
+    rfx, rjx, rgx, rhx = oracle.defect_all(oracle.get_ode("reentry", 0), oracle.MODES["LGL5"], zi, lam / ux)
+    assert np.abs(fx - rfx / ux).max() < 1e-10
+    assert rel_err(jx, rjx * uz[None, :] / ux[:, None]) < 1e-8
+    assert rel_err(gx, rgx * uz) < 1e-8
+    assert rel_err(hx, rhx * uz[None, :] * uz[:, None]) < 1e-8
+    assert np.allclose(ph.solver_input()[:8], w.traj[0] / units)       # the NLP variables are in scaled units
