@@ -13,8 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASSET_HIP_LIB") or os.path.join(_HERE, "libasset_hip.so")  # env override: kernel experiments
 
-TRAPEZOIDAL, LGL3, LGL5, LGL7 = 1, 2, 3, 4
-MODES = {"Trapezoidal": TRAPEZOIDAL, "LGL3": LGL3, "LGL5": LGL5, "LGL7": LGL7}
+FUNCTION, TRAPEZOIDAL, LGL3, LGL5, LGL7 = 0, 1, 2, 3, 4
+MODES = {"Function": FUNCTION, "Trapezoidal": TRAPEZOIDAL, "LGL3": LGL3, "LGL5": LGL5, "LGL7": LGL7}
 CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS = range(5)
 
 _dp = C.POINTER(C.c_double)

@@ -328,6 +328,7 @@ int asset_hip_mesh_error_deboor(const char* ode, int mode, int blocked, const do
   if (!ode || !traj || !tsnd || !mesh_errors || !mesh_dist) return fail(ASSET_HIP_EINVAL, "null argument");
   const asset_hip::KernelEntry* ke = find_entry(ode, mode, blocked);
   if (!ke) return fail(ASSET_HIP_ENOODE, std::string("no device code compiled for ode='") + ode + "' in this mode");
+  if (!ke->mesh) return fail(ASSET_HIP_EINVAL, "this entry is not a transcription of an ODE");
   const int cs = asset_hip::mesh_scheme(mode).cs, n = ke->xv, N = ke->xv + 1 + ke->uv + ke->pv;
   const int nb = (nnodes - 1) / (cs - 1);
   if (nb < 2 || nb * (cs - 1) + 1 != nnodes)
@@ -391,7 +392,10 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
     }
   auto encode = [&](int32_t m) { return (accumulate || uses[size_t(m - lo)] > 1) ? -(m + 2) : m; };
   std::vector<int32_t> map;
-  {
+  if (h->ke->mode == ASSET_HIP_FUNCTION) {   // plain functions place their entries slot by slot (func_kernels.h)
+    map.resize(nslots);
+    for (size_t i = 0; i < nslots; i++) map[i] = encode(slot_locations[i]);
+  } else {
     // fragment order of the LGL dense stage (defect_kernels.h, ASM): for every segment (4*tiles) rows of 64 lanes;
     // lane (lr = l & 15, lk = l >> 4), entry v of an accumulator tile is block column c = 16ct + lk + 4v and row
     // r = 16rt + lr (H, lower-triangle tiles first, tix = rt(rt+1)/2 + ct) or defect row jr = 16jt + lr

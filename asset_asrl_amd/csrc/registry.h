@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "defect_kernels.h"
+#include "func_kernels.h"
 #include "mesh_kernels.h"
 
 namespace asset_hip {
@@ -109,6 +110,14 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
 #undef ASSET_LAUNCH_K
   return hipErrorInvalidValue;
 }
+
+// A plain function batched over applications: transcription id 0 (func_kernels.h)
+#define ASSET_REGISTER_FUNC(FN)                                                                                   \
+  static ::asset_hip::KernelEntry entry_##FN##_func = {                                                           \
+      FN::name(), FN::XV, FN::UV, FN::PV, 0, 0,                                                                   \
+      ::asset_hip::FuncDims<FN>::IR, ::asset_hip::FuncDims<FN>::OR, ::asset_hip::FuncDims<FN>::NKKT, 0, 0, 0,    \
+      &::asset_hip::launch_func<FN>, nullptr, nullptr};                                                           \
+  static ::asset_hip::Registrar reg_##FN##_func(&entry_##FN##_func);
 
 // Trapezoidal = transcription id 1 of the same kernels (defect_dims.h: Dims::TRAP)
 #define ASSET_REGISTER_TRAP(ODE, BLK, G) ASSET_REGISTER_LGL(ODE, 1, BLK, G)

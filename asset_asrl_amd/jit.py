@@ -75,6 +75,11 @@ def ensure_kernel(ode, mode: str, blocked: bool) -> str:
     tag = f"{mode.lower()}_{int(blocked)}"
     src = (f'#include "ode.h"\n#include "{os.path.join(build.CSRC, "registry.h")}"\n'
            + reg.replace("{S}", sname) + "\nASSET_PLUGIN_EXPORT()\n")
+    return _build_and_load(name, "ode.h", hdr, tag, src, mode_id, blocked, f"user ODE '{ode.ode_name}'")
+
+
+def _build_and_load(name, hdr_name, hdr, tag, src, mode_id, blocked, what) -> str:
+    """Compile one plugin translation unit (cached by content) and register it; returns ``name``."""
     deps = [os.path.join(build.CSRC, f) for f in sorted(os.listdir(build.CSRC)) if f.endswith(".h")]
     key = hashlib.sha256((hdr + src + " ".join(build.FLAGS)).encode()
                          + b"".join(open(p, "rb").read() for p in deps)).hexdigest()[:16]
@@ -82,16 +87,16 @@ def ensure_kernel(ode, mode: str, blocked: bool) -> str:
     os.makedirs(wd, exist_ok=True)
     so = os.path.join(wd, f"plugin_{tag}_{key}.so")
     if not os.path.exists(so):
-        build._write_if_changed(os.path.join(wd, "ode.h"), hdr)
+        build._write_if_changed(os.path.join(wd, hdr_name), hdr)
         tu = os.path.join(wd, f"tu_{tag}.hip")
         build._write_if_changed(tu, src)
         if not os.path.exists(build.HIPCC):
-            raise _lib.AssetHipError(f"{build.HIPCC} not found: a user-defined ODE needs the HIP compiler at run time")
+            raise _lib.AssetHipError(f"{build.HIPCC} not found: {what} needs the HIP compiler at run time")
         cmd = [build.HIPCC] + build.FLAGS + ["-DASSET_PLUGIN", "-shared", "-I", os.path.join(build.HERE, "..", "include"),
                                              tu, "-o", so + ".tmp"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise _lib.AssetHipError(f"hipcc failed for user ODE '{ode.ode_name}':\n{r.stderr[-3000:]}")
+            raise _lib.AssetHipError(f"hipcc failed for {what}:\n{r.stderr[-3000:]}")
         os.replace(so + ".tmp", so)
     if so not in _loaded:
         rc = _lib.lib().asset_hip_load_plugin(so.encode())
@@ -99,5 +104,25 @@ def ensure_kernel(ode, mode: str, blocked: bool) -> str:
             _lib.check(rc, "asset_hip_load_plugin")
         _loaded.add(so)
     if not _lib.has_kernel(name, mode_id, blocked):
-        raise _lib.AssetHipError(f"plugin {so} did not register ({name}, {mode}, blocked={blocked})")
+        raise _lib.AssetHipError(f"plugin {so} did not register ({name}, mode {mode_id}, blocked={blocked})")
     return name
+
+
+def ensure_function(func, name: str) -> str:
+    """Device code for a plain vector function batched over applications (transcription id 0, csrc/func_kernels.h):
+    ``DefectEvaluator(ensure_function(f, "my_con"), "Function", False, vindex, cindex, ...)`` then evaluates it like a
+    defect -- FX / AGX blocks and the KKT block (Jacobian + lower-triangle adjoint Hessian) of every application."""
+    from .vf.codegen import differentiate_function
+    d = differentiate_function(name, func)
+    body = emit_hip_functor(d, "FnUser")
+    body = "\n".join(ln for ln in body.splitlines() if "name()" not in ln and not ln.startswith("// generated"))
+    dev = f"{_ident(name)}_{hashlib.sha256(body.encode()).hexdigest()[:10]}"
+    if _lib.has_kernel(dev, _lib.FUNCTION, False):
+        return dev
+    d.name = dev
+    sname = "Fn_" + _ident(dev)
+    hdr = ("#pragma once\n#include <math.h>\n#include \"" + os.path.join(build.CSRC, "asset_math.h") + "\"\n"
+           + emit_hip_functor(d, sname))
+    src = (f'#include "fn.h"\n#include "{os.path.join(build.CSRC, "registry.h")}"\n'
+           f"ASSET_REGISTER_FUNC({sname})\nASSET_PLUGIN_EXPORT()\n")
+    return _build_and_load(dev, "fn.h", hdr, "function_0", src, _lib.FUNCTION, False, f"function '{name}'")

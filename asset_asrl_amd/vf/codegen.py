@@ -59,6 +59,13 @@ class OdeDerivatives:
         }
 
 
+def differentiate_function(name: str, func: VectorFunction) -> OdeDerivatives:
+    """Derivatives of a plain vector function (a path constraint, a spacing relation ...).  The record is the ODE
+    one with XV = outputs and the inputs split as XV + 1 + UV (UV = inputs - outputs - 1 may be negative: the
+    function kernels only use XV and the input count)."""
+    return differentiate(name, func, func.ORows(), func.IRows() - func.ORows() - 1, 0)
+
+
 def differentiate(name: str, ode: VectorFunction, xv: int, uv: int, pv: int) -> OdeDerivatives:
     N = xv + 1 + uv + pv
     if ode.IRows() != N:

@@ -39,7 +39,10 @@
 extern "C" {
 #endif
 
-enum { ASSET_HIP_TRAPEZOIDAL = 1, ASSET_HIP_LGL3 = 2, ASSET_HIP_LGL5 = 3, ASSET_HIP_LGL7 = 4 };
+/* ASSET_HIP_FUNCTION: no transcription -- `ode` names a compiled plain vector function (XV outputs of
+ * XV+1+UV+PV inputs: a path constraint, a mesh-spacing or control-spline relation) that is applied as it is, one
+ * evaluation per application (ComputableBase.h:246-335 is generic in the function). */
+enum { ASSET_HIP_FUNCTION = 0, ASSET_HIP_TRAPEZOIDAL = 1, ASSET_HIP_LGL3 = 2, ASSET_HIP_LGL5 = 3, ASSET_HIP_LGL7 = 4 };
 
 enum {
   ASSET_HIP_CON = 0,

@@ -13,8 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-TRAPEZOIDAL, LGL3, LGL5, LGL7 = 1, 2, 3, 4
-MODES = {"Trapezoidal": 1, "LGL3": 2, "LGL5": 3, "LGL7": 4}
+FUNCTION, TRAPEZOIDAL, LGL3, LGL5, LGL7 = 0, 1, 2, 3, 4
+MODES = {"Function": 0, "Trapezoidal": 1, "LGL3": 2, "LGL5": 3, "LGL7": 4}
 CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS = range(5)
 
 _dp = C.POINTER(C.c_double)

@@ -25,6 +25,12 @@ struct Sizes {
 };
 
 bool make_sizes(const oracle_ode* ode, int mode, int blocked, Sizes& s) {
+  if (mode == ORACLE_FUNCTION) {   // the function itself is the constraint: one application = one evaluation
+    s.n = ode->xv, s.m = ode->uv, s.p = ode->pv;
+    s.q = s.n + 1 + s.m, s.N = s.q + s.p, s.T = s.n, s.CS = 1, s.K = 0;
+    s.IR = s.N, s.OR = s.n;
+    return true;
+  }
   if (mode < ORACLE_TRAPEZOIDAL || mode > ORACLE_LGL7) return false;
   s.n = ode->xv;
   if (blocked) {  // Blocked_ODE_Wrapper: UV:=0, PV:=UV+PV, XtUV:=XtV ; the ODE input layout is unchanged
@@ -387,6 +393,7 @@ int oracle_defect_compute(const oracle_ode* ode, int mode, int blocked, const do
   Sizes S;
   if (!make_sizes(ode, mode, blocked, S)) return -1;
   std::fill(fx, fx + S.OR, 0.0);
+  if (mode == ORACLE_FUNCTION) { ode->f(x, fx, ode->ctx); return 0; }
   if (mode == ORACLE_TRAPEZOIDAL) trap_compute(ode, S, x, fx);
   else lgl_compute(ode, S, x, fx);
   return 0;
@@ -397,6 +404,13 @@ int oracle_defect_jacobian(const oracle_ode* ode, int mode, int blocked, const d
   if (!make_sizes(ode, mode, blocked, S)) return -1;
   std::fill(fx, fx + S.OR, 0.0);
   std::fill(jx, jx + (size_t)S.OR * S.IR, 0.0);
+  if (mode == ORACLE_FUNCTION) {   // row-major (OR x IR) from the provider -> column-major
+    std::vector<double> J((size_t)S.OR * S.IR);
+    ode->fj(x, fx, J.data(), ode->ctx);
+    for (int r = 0; r < S.OR; r++)
+      for (int c = 0; c < S.IR; c++) JX(r, c) = J[(size_t)r * S.IR + c];
+    return 0;
+  }
   if (mode == ORACLE_TRAPEZOIDAL) trap_jacobian(ode, S, x, fx, jx);
   else lgl_jacobian(ode, S, x, fx, jx);
   return 0;
@@ -410,6 +424,13 @@ int oracle_defect_all(const oracle_ode* ode, int mode, int blocked, const double
   std::fill(jx, jx + (size_t)S.OR * S.IR, 0.0);
   std::fill(agx, agx + S.IR, 0.0);
   std::fill(hx, hx + (size_t)S.IR * S.IR, 0.0);
+  if (mode == ORACLE_FUNCTION) {   // value, J, adjoint gradient J^T lam, adjoint Hessian sum_k lam_k grad^2 f_k
+    std::vector<double> J((size_t)S.OR * S.IR);
+    ode->fjgh(x, lam, fx, J.data(), agx, hx, ode->ctx);   // H is symmetric: row- and column-major coincide
+    for (int r = 0; r < S.OR; r++)
+      for (int c = 0; c < S.IR; c++) JX(r, c) = J[(size_t)r * S.IR + c];
+    return 0;
+  }
   if (mode == ORACLE_TRAPEZOIDAL) trap_all(ode, S, x, lam, fx, jx, agx, hx);
   else lgl_all(ode, S, x, lam, fx, jx, agx, hx);
   return 0;

@@ -43,6 +43,16 @@ void vanderpol(const S* y, S* f, const void*) {
   f[1] = mu * (1.0 - x0 * x0) * x1 - x0 + u * exp(-0.1 * t);
 }
 
+// ------------------------------------------------------------------ a nonlinear path constraint, 2 outputs of 6 inputs
+// Not an ODE: the independent check for plain functions batched over applications (mode FUNCTION);
+// tests/test_gpu_function.py defines the same function in the product's expression DSL.
+template <class S>
+void pathcon(const S* y, S* f, const void*) {
+  const S &x0 = y[0], &x1 = y[1], &x2 = y[2], &t = y[3], &u0 = y[4], &u1 = y[5];
+  f[0] = x0 * x0 + x1 * u0 - sin(x2);
+  f[1] = u0 * u0 + u1 * u1 - 1.0 + t * x0 * exp(-x1);
+}
+
 // ------------------------------------------------------------------ shuttle reentry (5,2,0)
 template <class S>
 void reentry(const S* y, S* f, const void*) {

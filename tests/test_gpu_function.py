@@ -1,0 +1,98 @@
+"""Plain vector functions batched over applications: a nonlinear path constraint written in
+the DSL, compiled at run time, against the oracle's AD2 derivatives of the same function pushed through the oracle's
+NLP restatement (blocks, scattered CSR values, RHS vectors); and the reference's LGL mesh-spacing relation against
+its closed-form Jacobian (MeshSpacingConstraints.h:128-142)."""
+import numpy as np
+import pytest
+
+from asset_asrl_amd import vf
+from asset_asrl_amd.evaluator import CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, unpack_kkt_block
+from asset_asrl_amd.pathfuncs import FunctionEvaluator, LGLMeshSpacing
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _pathcon():
+    a = vf.Arguments(6)
+    x0, x1, x2, t, u0, u1 = a.tolist()
+    return vf.stack([x0 * x0 + x1 * u0 - vf.sin(x2), u0 * u0 + u1 * u1 - 1.0 + t * x0 * vf.exp(-1.0 * x1)])
+
+
+def _tables(napp, ir, orr, n_primal, n_equal, seed):
+    """Index tables with shared variables: consecutive applications overlap in half of their inputs."""
+    rng = np.random.default_rng(seed)
+    step = ir // 2
+    vindex = (np.arange(napp)[:, None] * step + np.arange(ir)[None, :] + 3).astype(np.int32)
+    cindex = (np.arange(napp)[:, None] * orr + np.arange(orr)[None, :] + 1).astype(np.int32)
+    assert vindex.max() < n_primal and cindex.max() < n_equal
+    return vindex, cindex, rng.uniform(-1, 1, n_primal), 10.0 * rng.uniform(-1, 1, n_equal)
+
+
+def test_path_constraint_matches_oracle_nlp(oracle):
+    napp, ir, orr = 211, 6, 2
+    n_primal, n_equal = 3 * napp + 20, 2 * napp + 5
+    vindex, cindex, X, L = _tables(napp, ir, orr, n_primal, n_equal, 11)
+    ev = FunctionEvaluator(_pathcon(), "pathcon", vindex, cindex, n_primal, n_equal)
+    assert (ev.IR, ev.OR, ev.NKKT) == (6, 2, 21 + 12)
+    nlp = oracle.Nlp(oracle.get_ode("pathcon", 0), oracle.MODES["Function"], False, vindex, cindex, n_primal, n_equal, 2)
+    for what in (JAC_ADJGRAD_HESS, CON, CON_ADJGRAD, JAC, JAC_ADJGRAD):
+        rfx, ragx, rkkt = nlp.eval_blocks(what, X, L)
+        fx, agx, kkt = ev.eval(what, X, L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
+        assert np.abs(fx - rfx).max() < 1e-10
+        if agx is not None:
+            assert rel_err(agx, ragx) < 1e-8
+        if kkt is not None:
+            assert rel_err(kkt, rkkt) < 1e-8
+    # on-device assembly into the solver's value array (shared variables -> shared locations)
+    locs = nlp.kkt_locations()[:nlp.num_user_kkt].reshape(napp, ev.NKKT)
+    assert np.unique(locs).size < locs.size
+    ev.set_kkt_map(locs, nlp.nnz)
+    for what in (JAC_ADJGRAD_HESS, JAC_ADJGRAD):
+        vals = np.zeros(nlp.nnz)
+        ev.eval_assembled(what, X, L, vals)
+        assert rel_err(vals, nlp.eval(what, X, L)[2]) < 1e-8
+    ev.close()
+
+
+def test_lgl_mesh_spacing_closed_form():
+    cs, napp = 4, 100
+    rng = np.random.default_rng(2)
+    t0 = np.sort(rng.uniform(0, 50, napp))
+    h = rng.uniform(0.5, 2.0, napp)
+    frac = np.sort(rng.uniform(0.05, 0.95, (napp, 2)), axis=1)
+    T = np.column_stack([t0, t0 + frac[:, 0] * h, t0 + frac[:, 1] * h, t0 + h])       # node times per application
+    X = T.ravel()
+    vindex = np.arange(napp * cs, dtype=np.int32).reshape(napp, cs)
+    cindex = np.arange(napp * (cs - 2), dtype=np.int32).reshape(napp, cs - 2)
+    L = rng.uniform(-1, 1, napp * (cs - 2))
+    ev = FunctionEvaluator(LGLMeshSpacing(cs), "lglmeshspacing4", vindex, cindex, X.size, L.size)
+    fx, agx, kkt = ev.eval(JAC_ADJGRAD_HESS, X, L)
+    tc = np.array([0.0, 2.65575603264643e-1, 7.34424396735357e-1, 1.0])
+    for V in (0, 17, 99):
+        x = T[V]
+        hh = x[3] - x[0]
+        assert np.allclose(fx[V], tc[1:3] - (x[1:3] - x[0]) / hh, atol=1e-14)
+        J = np.zeros((2, 4))
+        for i in range(2):                                   # MeshSpacingConstraints.h:136-141
+            J[i, i + 1] = -1.0 / hh
+            J[i, 0] = 1.0 / hh - (x[1 + i] - x[0]) / hh ** 2
+            J[i, 3] = (x[1 + i] - x[0]) / hh ** 2
+        H, Jd = unpack_kkt_block(kkt[V], 4, 2)
+        assert rel_err(Jd, J) < 1e-12
+        assert rel_err(agx[V], J.T @ L[2 * V:2 * V + 2]) < 1e-12
+        eps = 1e-6                                           # adjoint Hessian against central differences of J^T lam
+        Hfd = np.zeros((4, 4))
+        for c in range(4):
+            for sgn in (1, -1):
+                xp = x.copy()
+                xp[c] += sgn * eps
+                hp = xp[3] - xp[0]
+                Jp = np.zeros((2, 4))
+                for i in range(2):
+                    Jp[i, i + 1] = -1.0 / hp
+                    Jp[i, 0] = 1.0 / hp - (xp[1 + i] - xp[0]) / hp ** 2
+                    Jp[i, 3] = (xp[1 + i] - xp[0]) / hp ** 2
+                Hfd[:, c] += sgn * (Jp.T @ L[2 * V:2 * V + 2]) / (2 * eps)
+        assert rel_err(H, Hfd) < 1e-6
+    ev.close()

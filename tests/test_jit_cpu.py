@@ -36,3 +36,14 @@ def test_library_odes_keep_their_names_and_are_not_recompiled():
 def test_load_plugin_rejects_a_non_plugin():
     rc = _lib.lib().asset_hip_load_plugin(_lib.LIB_PATH.encode())
     assert rc < 0 and b"asset_hip_plugin_entries" in _lib.lib().asset_hip_last_error()
+
+
+def test_plain_function_gets_device_code():
+    """Transcription id 0: any DSL vector function batched over applications (csrc/func_kernels.h)."""
+    from asset_asrl_amd.pathfuncs import LGLMeshSpacing, SingleMeshSpacing
+    name = jit.ensure_function(LGLMeshSpacing(3), "lglmeshspacing3")
+    assert _lib.has_kernel(name, _lib.FUNCTION, False) and not _lib.has_kernel(name, _lib.LGL3, False)
+    assert jit.ensure_function(LGLMeshSpacing(3), "lglmeshspacing3") == name
+    assert jit.ensure_function(SingleMeshSpacing(0.25), "single_spacing") != name
+    with pytest.raises(ValueError):
+        LGLMeshSpacing(2)
