@@ -101,7 +101,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ASSET_BENCH_FORCE_DIST"):   # (the switch exercises the RCCL path with one rank)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
