@@ -162,10 +162,12 @@ def build(verbose=True, jobs=None) -> str:
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
     # host-side C++ shim (plain g++; links against the C ABI only)
-    host_src = os.path.join(HERE, "host", "batched_defect_constraint.cpp")
+    host_srcs = [os.path.join(HERE, "host", f) for f in ("batched_defect_constraint.cpp", "kkt_assembly.cpp")]
+    host_deps = host_srcs + [os.path.join(HERE, "host", f) for f in ("batched_defect_constraint.h", "kkt_assembly.h")]
     host_lib = os.path.join(HERE, "libasset_host.so")
-    if (not os.path.exists(host_lib) or os.path.getmtime(host_lib) < max(os.path.getmtime(host_src), os.path.getmtime(LIB))):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", host_src, "-o", host_lib, "-L" + HERE, "-lasset_hip",
+    if (not os.path.exists(host_lib)
+            or os.path.getmtime(host_lib) < max([os.path.getmtime(p) for p in host_deps] + [os.path.getmtime(LIB)])):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared"] + host_srcs + ["-o", host_lib, "-L" + HERE, "-lasset_hip",
                "-Wl,-rpath,$ORIGIN"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -48,3 +48,38 @@ extern "C" int shim_run(const char* ode, int mode, int blocked, int ir, int orr,
     return 1;
   }
 }
+
+// ---- KktAssembly (asset_asrl_amd/host/kkt_assembly.h): structure + the four evaluation entry points -------------
+#include "../asset_asrl_amd/host/kkt_assembly.h"
+
+// One constraint (ode, mode): returns nnz; outer[dim+1], inner[cap], locs[num_user + dim]; what: 0 OCC, 1 RHS, 2 SOE, 4 KKT
+extern "C" int assembly_run(const char* ode, int mode, int blocked, int ir, int orr, int nappl, const int* vindex,
+                            const int* cindex, int primal, int equal, int what, const double* X, const double* L,
+                            int* outer, int* inner, int inner_cap, int* locs, double* kkt_vals, double* FXE, double* AGX,
+                            char* err, int errcap) {
+  try {
+    SolverIndexingData data;
+    data.input_size = ir, data.output_size = orr, data.num_funcappl = nappl;
+    data.Vindex.assign(vindex, vindex + size_t(ir) * nappl);
+    data.Cindex.assign(cindex, cindex + size_t(orr) * nappl);
+    BatchedDefectConstraint con(ode, mode, blocked != 0, data, primal, equal, 0);
+    KktAssembly nlp(primal, equal);
+    nlp.add_equality(con, data);
+    nlp.analyze();
+    if (nlp.nnz() > inner_cap) throw std::runtime_error("inner capacity too small");
+    std::memcpy(outer, nlp.outer().data(), sizeof(int) * (nlp.kkt_dim() + 1));
+    std::memcpy(inner, nlp.inner().data(), sizeof(int) * nlp.nnz());
+    std::memcpy(locs, nlp.kkt_locations().data(), sizeof(int) * nlp.kkt_locations().size());
+    switch (what) {
+      case 0: nlp.evalOCC(X, FXE); break;
+      case 1: nlp.evalRHS(X, L, FXE, AGX); break;
+      case 2: nlp.evalSOE(X, FXE, kkt_vals); break;
+      default: nlp.evalKKT(X, L, FXE, AGX, kkt_vals);
+    }
+    return nlp.nnz();
+  } catch (const std::exception& e) {
+    std::strncpy(err, e.what(), errcap - 1);
+    err[errcap - 1] = 0;
+    return -1;
+  }
+}

@@ -53,3 +53,36 @@ def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg, device_
             assert rel_err(AGX, rAGX) < 1e-8
         if what >= oracle.JAC:
             assert rel_err(vals, rvals) < 1e-8
+
+
+@pytest.mark.parametrize("ode,mode,blocked,nseg", [("reentry", "LGL7", False, 41), ("twobody_lt", "LGL5", True, 23),
+                                                   ("betts_lowthrust", "Trapezoidal", False, 12)])
+def test_kkt_assembly_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg):
+    """Product-side sparsity analysis and eval* drivers (host/kkt_assembly.h) against the oracle's restatement of
+    NonLinearProgram: same CSR structure, same KKTLocations, same values for evalOCC / evalRHS / evalSOE / evalKKT."""
+    w = Workload(ode, mode, nseg, blocked, var_offset=2, con_offset=1, extra_vars=3)
+    nlp = w.oracle_nlp(oracle, threads=1)
+    r_outer, r_inner = nlp.csr()
+    r_locs = nlp.kkt_locations()
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    for what, okind in ((4, oracle.JAC_ADJGRAD_HESS), (0, oracle.CON), (1, oracle.CON_ADJGRAD), (2, oracle.JAC)):
+        outer = np.zeros(nlp.kkt_dim + 1, dtype=np.int32)
+        inner = np.zeros(nlp.nnz + 16, dtype=np.int32)
+        locs = np.zeros(r_locs.size, dtype=np.int32)
+        FXE, AGX, vals = np.ones(w.n_equal), np.ones(w.n_primal), np.ones(nlp.nnz)   # stale data: must be overwritten
+        err = C.create_string_buffer(512)
+        nnz = shim.assembly_run(ode.encode(), oracle.MODES[mode], int(w.blocked), w.IR, w.OR, w.nseg,
+                                w.vindex.ctypes.data_as(ip), w.cindex.ctypes.data_as(ip), w.n_primal, w.n_equal, what,
+                                w.X.ctypes.data_as(dp), w.L.ctypes.data_as(dp), outer.ctypes.data_as(ip),
+                                inner.ctypes.data_as(ip), inner.size, locs.ctypes.data_as(ip), vals.ctypes.data_as(dp),
+                                FXE.ctypes.data_as(dp), AGX.ctypes.data_as(dp), err, 512)
+        assert nnz == nlp.nnz, err.value
+        np.testing.assert_array_equal(outer, r_outer)
+        np.testing.assert_array_equal(inner[:nnz], r_inner)
+        np.testing.assert_array_equal(locs, r_locs)
+        rFXE, rAGX, rvals = nlp.eval(okind, w.X, w.L)
+        assert np.abs(FXE - rFXE).max() / max(1.0, np.abs(w.X).max()) < 1e-10
+        if what in (1, 4):
+            assert rel_err(AGX, rAGX) < 1e-8
+        if what in (2, 4):
+            assert rel_err(vals, rvals) < 1e-8
