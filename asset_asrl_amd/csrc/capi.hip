@@ -1,6 +1,7 @@
 // C ABI of libasset_hip.so (see include/asset_hip.h for the contract and the reference interfaces replaced).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -476,9 +477,12 @@ int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double
   HIP_TRY(hipMemcpyAsync(h->d_X, X, sizeof(double) * h->n_primal, hipMemcpyHostToDevice, h->stream));
   if (L) HIP_TRY(hipMemcpyAsync(h->d_L, L, sizeof(double) * h->n_equal, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemsetAsync(h->d_values, 0, sizeof(double) * nval, h->stream));
-  // the device array covers [value_lo, value_hi) of the caller's: bias the base so that locations index it directly
+  // The device array covers [value_lo, value_hi) of the caller's: bias the base address so that locations index it
+  // directly (integer arithmetic: the biased address is only ever used with offsets >= value_lo).
+  double* biased = reinterpret_cast<double*>(reinterpret_cast<uintptr_t>(h->d_values) -
+                                             uintptr_t(h->value_lo) * sizeof(double));
   int rc = asset_hip_defect_eval_assembled_device(h, what, h->d_X, L ? h->d_L : nullptr, fx_blocks ? h->d_fx : nullptr,
-                                                  agx_blocks ? h->d_agx : nullptr, h->d_values - h->value_lo, h->stream);
+                                                  agx_blocks ? h->d_agx : nullptr, biased, h->stream);
   if (rc) return rc;
   if (fx_blocks) HIP_TRY(hipMemcpyAsync(fx_blocks, h->d_fx, sizeof(double) * nfx, hipMemcpyDeviceToHost, h->stream));
   if (agx_blocks && what != ASSET_HIP_JAC)
