@@ -7,7 +7,8 @@ add*Objective`` through ``ConstraintFunction`` / ``ObjectiveFunction``
 (/root/reference/src/VectorFunctions/ComputableBase.h:246-335, DenseFunctionBase.h:1145-1391).
 
 The two mesh relations the reference adds to every LGL phase are provided as DSL functions:
-``LGLMeshSpacing(cs)`` and ``SingleMeshSpacing(s)`` (OptimalControl/MeshSpacingConstraints.h:8-98, 101-193)."""
+``LGLMeshSpacing(cs)`` and ``SingleMeshSpacing(s)`` (OptimalControl/MeshSpacingConstraints.h:8-98, 101-193), and so is
+the segment quadrature behind integral objectives, ``LGLIntegral(integrand, cs, xv, pv)`` (LGLIntegrals.h:9-73)."""
 from __future__ import annotations
 
 from . import _lib, jit, synth, vf
@@ -29,6 +30,37 @@ def SingleMeshSpacing(cardinal_spacing: float, scale: float = 1.0) -> vf.VectorF
     """Inputs (t_0, t_j, t_f); output scale * (s * (t_f - t_0) - (t_j - t_0))  (MeshSpacingConstraints.h:33-41)."""
     t = vf.Arguments(3)
     return ((t.coeff(2) - t.coeff(0)) * cardinal_spacing - (t.coeff(1) - t.coeff(0))) * scale
+
+
+# Reduced_Integral_Weights of the schemes (LGLCoeffs.h:42, 135, 360-364; expressions kept as the reference writes them)
+_REDUCED_INTEGRAL_WEIGHTS = {
+    2: (0.5, 0.5),
+    3: (1.0 / 6.0, 2.0 / 3.0, 1.0 / 6.0),
+    4: (-5.12701665379258 / 4.0 + 10.2540333075852 / 3.0 - 6.12701665379258 / 2.0 + 1.0,
+        10.9353308042859 / 4.0 - 18.9665045333251 / 3.0 + 8.03117372903925 / 2.0,
+        -10.9353308042859 / 4.0 + 13.8394878795326 / 3.0 - 2.90415707524666 / 2.0,
+        5.12701665379258 / 4.0 - 5.12701665379258 / 3.0 + 1.0 / 2.0),
+}
+
+
+def LGLIntegral(integrand: vf.VectorFunction, cs: int, xv: int, pv: int = 0) -> vf.VectorFunction:
+    """Quadrature of ``integrand`` over one segment: inputs ``[x_0(xv), t_0, ..., x_{cs-1}(xv), t_{cs-1}, p(pv)]``,
+    output ``(t_{cs-1} - t_0) * sum_i w_i integrand([x_i, p])`` (LGLIntegrals.h:9-52).  ``integrand`` takes xv + pv
+    inputs."""
+    if cs not in _REDUCED_INTEGRAL_WEIGHTS:
+        raise ValueError("cs must be 2, 3 or 4")
+    if integrand.IRows() != xv + pv:
+        raise ValueError(f"integrand takes {integrand.IRows()} inputs, expected xv + pv = {xv + pv}")
+    xtv = xv + 1
+    a = vf.Arguments(cs * xtv + pv)
+    h = a.coeff((cs - 1) * xtv + xv) - a.coeff(xv)
+    p = a.tail(pv) if pv else None
+    terms = []
+    for i, w in enumerate(_REDUCED_INTEGRAL_WEIGHTS[cs]):
+        xi = a.segment(i * xtv, xv)
+        arg = vf.stack([xi, p]) if pv else xi
+        terms.append(integrand.eval(arg) * w)
+    return vf.sum(*terms) * h
 
 
 class FunctionEvaluator(DefectEvaluator):

@@ -47,3 +47,22 @@ def test_plain_function_gets_device_code():
     assert jit.ensure_function(SingleMeshSpacing(0.25), "single_spacing") != name
     with pytest.raises(ValueError):
         LGLMeshSpacing(2)
+
+
+def test_lgl_integral_quadrature_is_exact_for_cubics():
+    """LGLIntegral (LGLIntegrals.h:9-52): h * sum_i w_i integrand(x_i); the LGL7 reduced weights integrate
+    t^2 + t^3 exactly.  Its device code is generated like any other function's."""
+    import numpy as np
+    from asset_asrl_amd.pathfuncs import LGLIntegral
+    g = vf.Arguments(2)
+    F = LGLIntegral(g.coeff(1) * g.coeff(1) + g.coeff(0), 4, 2)
+    assert (F.IRows(), F.ORows()) == (12, 1)
+    t0, h = 0.3, 1.7
+    z = []
+    for c in (0.0, 2.65575603264643e-1, 7.34424396735357e-1, 1.0):
+        t = t0 + c * h
+        z += [t ** 3, t, t]
+    prim = lambda t: t ** 3 / 3 + t ** 4 / 4
+    assert abs(F.compute(np.array(z))[0] - (prim(t0 + h) - prim(t0))) < 1e-12
+    name = jit.ensure_function(F, "lglintegral_test")
+    assert _lib.has_kernel(name, _lib.FUNCTION, False) and _lib.ode_sizes(name)[0] == 1
