@@ -684,6 +684,10 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
 #pragma unroll
         for (int t = 0; t < D::TI * D::TJ; t++) load_jmap(t);
       }
+      // The product phases run at raised wave priority: the two waves of a SIMD otherwise walk through the same
+      // phases nearly in step and the LDS / VALU / MFMA pipes take turns; any asymmetry in arbitration helps (measured
+      // 0.5 us, the same for every priority assignment tried).
+      __builtin_amdgcn_s_setprio(1);
       // ---- D3: M_i^T = DI_i^T [hE_i H^_i | E_i g^_i]; column N of the product is sum_b E_i g^_i[b] DI_i[b,c]
       if constexpr (JFUSE) {
         double jacc[D::TI][4];                           // interior part of J^T, entry v = (c = 16ct + lk + 4v, jr = lr)
@@ -881,6 +885,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       }
       }
 
+      __builtin_amdgcn_s_setprio(0);
       // ---- D5: adjoint gradient  g = J^T lam  without touching the J tile:
       //      interior part  h * sum_i E_i g^_i^T DI_i  (= h * HI), cardinal part = DC^T lam
       if (a.AGX) {
