@@ -8,7 +8,8 @@ add*Objective`` through ``ConstraintFunction`` / ``ObjectiveFunction``
 
 The two mesh relations the reference adds to every LGL phase are provided as DSL functions:
 ``LGLMeshSpacing(cs)`` and ``SingleMeshSpacing(s)`` (OptimalControl/MeshSpacingConstraints.h:8-98, 101-193), and so is
-the segment quadrature behind integral objectives, ``LGLIntegral(integrand, cs, xv, pv)`` (LGLIntegrals.h:9-73)."""
+the segment quadrature behind integral objectives, ``LGLIntegral(integrand, cs, xv, pv)`` (LGLIntegrals.h:9-73), and
+the control-spline continuity relation ``LGLControlSpline(cs, usize)`` (LGLControlSplines.h:64-315)."""
 from __future__ import annotations
 
 from . import _lib, jit, synth, vf
@@ -61,6 +62,47 @@ def LGLIntegral(integrand: vf.VectorFunction, cs: int, xv: int, pv: int = 0) -> 
         arg = vf.stack([xi, p]) if pv else xi
         terms.append(integrand.eval(arg) * w)
     return vf.sum(*terms) * h
+
+
+# UOneSpline_Weights / UZeroSpline_Weights (LGLCoeffs.h:155-158, 372-388; expressions kept as the reference writes them)
+_UZERO = {
+    3: ((-3.0, 4.0, -1.0),),
+    4: ((-6.12701665379258, 8.03117372903925, -2.90415707524666, 1.0),
+        (10.2540333075852 * 2.0, -18.9665045333251 * 2.0, +13.8394878795326 * 2.0, -5.12701665379258 * 2.0)),
+}
+_UONE = {
+    3: ((1.0, -4.0, 3.0),),
+    4: ((-5.12701665379258 * 3.0 + 10.2540333075852 * 2.0 - 6.12701665379258,
+         10.9353308042859 * 3.0 - 18.9665045333251 * 2.0 + 8.03117372903925,
+         -10.9353308042859 * 3.0 + 13.8394878795326 * 2.0 - 2.90415707524666,
+         5.12701665379258 * 3.0 - 5.12701665379258 * 2.0 + 1.0),
+        (-5.12701665379258 * 6.0 + 10.2540333075852 * 2.0, 10.9353308042859 * 6.0 - 18.9665045333251 * 2.0,
+         -10.9353308042859 * 6.0 + 13.8394878795326 * 2.0, 5.12701665379258 * 6.0 - 5.12701665379258 * 2.0)),
+}
+
+
+def LGLControlSpline(cs: int, usize: int, order: int | None = None) -> vf.VectorFunction:
+    """Continuity of the control polynomial's derivatives across two adjacent segments: inputs are the
+    2*cs-1 blocks ``[t, u(usize)]`` of their nodes, outputs ``j = 0..order-1`` (derivative j+1), ``usize`` rows each:
+    ``sum_i UOne[j][i] u_i / h0^(j+1) - UZero[j][i] u_{i+cs-1} / h1^(j+1)``  (LGLControlSplines.h:64-108)."""
+    if cs not in _UONE:
+        raise ValueError("control splines exist for LGL5 (cs=3) and LGL7 (cs=4)")
+    order = cs - 2 if order is None else order
+    if not 1 <= order <= len(_UONE[cs]):
+        raise ValueError("order out of range for this scheme")
+    tu = usize + 1
+    a = vf.Arguments((2 * cs - 1) * tu)
+    t = lambda i: a.coeff(i * tu)
+    u = lambda i: a.segment(i * tu + 1, usize)
+    h0, h1 = t(cs - 1) - t(0), t(2 * cs - 2) - t(cs - 1)
+    outs = []
+    for j in range(order):
+        acc = None
+        for i in range(cs):
+            term = u(i) * _UONE[cs][j][i] / h0 ** (j + 1) - u(i + cs - 1) * _UZERO[cs][j][i] / h1 ** (j + 1)
+            acc = term if acc is None else acc + term
+        outs.append(acc)
+    return vf.stack(outs)
 
 
 class FunctionEvaluator(DefectEvaluator):

@@ -66,3 +66,24 @@ def test_lgl_integral_quadrature_is_exact_for_cubics():
     assert abs(F.compute(np.array(z))[0] - (prim(t0 + h) - prim(t0))) < 1e-12
     name = jit.ensure_function(F, "lglintegral_test")
     assert _lib.has_kernel(name, _lib.FUNCTION, False) and _lib.ode_sizes(name)[0] == 1
+
+
+def test_control_spline_vanishes_on_a_smooth_control():
+    """LGLControlSpline (LGLControlSplines.h:64-108): derivative continuity of the control polynomial across two
+    segments; a control that is a single cubic (LGL7) / quadratic (LGL5) over both segments satisfies it."""
+    import numpy as np
+    from asset_asrl_amd.pathfuncs import LGLControlSpline
+    tc = np.array([0.0, 2.65575603264643e-1, 7.34424396735357e-1, 1.0])
+    t0, h0, h1 = 0.2, 1.3, 0.7
+    ts = np.concatenate([t0 + tc * h0, (t0 + h0) + tc[1:] * h1])
+    z = np.concatenate([[t, 1 + 2 * t - 0.5 * t ** 2 + 0.3 * t ** 3, t ** 3 - t] for t in ts])
+    F = LGLControlSpline(4, 2)
+    assert (F.IRows(), F.ORows()) == (21, 4)
+    assert np.abs(F.compute(z)).max() < 1e-10                      # 15-digit weight literals
+    zbad = z.copy()
+    zbad[-1] += 0.1                                                # a kink in the last node's control
+    assert np.abs(F.compute(zbad)).max() > 1e-2
+    ts3 = np.array([0.0, 0.5, 1.0, 1.4, 1.8])
+    assert np.abs(LGLControlSpline(3, 1).compute(np.concatenate([[t, 2 - t + 0.7 * t * t] for t in ts3]))).max() < 1e-13
+    with pytest.raises(ValueError):
+        LGLControlSpline(2, 1)
