@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/asset_hip.h"
@@ -321,6 +322,17 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
   return 0;
 }
 
+int asset_hip_host_register(void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(ASSET_HIP_EINVAL, "null range");
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return 0;
+}
+int asset_hip_host_unregister(void* ptr) {
+  if (!ptr) return fail(ASSET_HIP_EINVAL, "null range");
+  HIP_TRY(hipHostUnregister(ptr));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- mesh error estimate
 
 int asset_hip_mesh_error_deboor(const char* ode, int mode, int blocked, const double* traj, int nnodes, double* tsnd,
@@ -489,8 +501,16 @@ int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double
     HIP_TRY(hipMemcpyAsync(agx_blocks, h->d_agx, sizeof(double) * nagx, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(h->h_values, h->d_values, sizeof(double) * nval, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  double* dst = kkt_values + h->value_lo;            // accumulate, as the reference's fill does: O(nnz) contiguous adds
-  for (size_t i = 0; i < nval; i++) dst[i] += h->h_values[i];
+  // accumulate, as the reference's fill does: O(nnz) contiguous adds, split over a few threads (memory-bound)
+  double* dst = kkt_values + h->value_lo;
+  const double* src = h->h_values;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nthr = nval < (size_t(1) << 18) ? 1 : (hw >= 8 ? 8 : (hw ? hw : 1));
+  auto add = [=](size_t b, size_t e) { for (size_t i = b; i < e; i++) dst[i] += src[i]; };
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < nthr; t++) pool.emplace_back(add, nval * t / nthr, nval * (t + 1) / nthr);
+  add(0, nval / nthr);
+  for (auto& th : pool) th.join();
   return 0;
 }
 

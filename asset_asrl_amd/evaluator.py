@@ -37,6 +37,7 @@ class DefectEvaluator:
                                self.cindex.ctypes.data_as(C.POINTER(C.c_int32)),
                                self.n_primal, self.n_equal, int(device))
         self._h = C.c_void_p()
+        self._pinned = None
         _lib.check(L.asset_hip_defect_create(C.byref(desc), C.byref(self._h)), "asset_hip_defect_create")
         ir, orr, nk = C.c_int(), C.c_int(), C.c_int()
         _lib.check(L.asset_hip_defect_sizes(self._h, C.byref(ir), C.byref(orr), C.byref(nk)))
@@ -49,6 +50,9 @@ class DefectEvaluator:
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None and getattr(_lib, "lib", None) is not None:   # module globals vanish at interpreter exit
+            for b in (getattr(self, "_pinned", None) or ()):
+                _lib.lib().asset_hip_host_unregister(b.ctypes.data)
+            self._pinned = None
             _lib.lib().asset_hip_defect_destroy(h)
 
     __del__ = close
@@ -72,12 +76,27 @@ class DefectEvaluator:
             L = np.ascontiguousarray(L, dtype=np.float64)
             if L.size != self.n_equal:
                 raise ValueError(f"L has {L.size} entries, expected {self.n_equal}")
-        fx = np.empty((self.nseg, self.OR))
-        agx = np.empty((self.nseg, self.IR)) if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
-        kkt = np.empty((self.nseg, self.NKKT)) if what >= JAC else None
+        if self._pinned is not None:       # persistent page-locked outputs (pin_outputs): views, overwritten by the next call
+            fx, agx, kkt = self._pinned
+            agx = agx if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+            kkt = kkt if what >= JAC else None
+        else:
+            fx = np.empty((self.nseg, self.OR))
+            agx = np.empty((self.nseg, self.IR)) if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+            kkt = np.empty((self.nseg, self.NKKT)) if what >= JAC else None
         _lib.check(_lib.lib().asset_hip_defect_eval(self._h, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx),
                                                     _dptr(kkt)), "asset_hip_defect_eval")
         return fx, agx, kkt
+
+    def pin_outputs(self):
+        """Allocate the block arrays once and page-lock them (asset_hip_host_register): ``eval`` then returns these
+        arrays, overwritten by every call, and the copies out run at PCIe rate instead of through pageable staging."""
+        if self._pinned is None:
+            bufs = (np.empty((self.nseg, self.OR)), np.empty((self.nseg, self.IR)), np.empty((self.nseg, self.NKKT)))
+            for b in bufs:
+                _lib.check(_lib.lib().asset_hip_host_register(b.ctypes.data, b.nbytes), "asset_hip_host_register")
+            self._pinned = bufs
+        return self
 
     # ---- on-device KKT assembly (SURVEY section 8 row f-1) -----------------------------------
     def set_kkt_map(self, slot_locations, nvalues: int, accumulate: bool = False):

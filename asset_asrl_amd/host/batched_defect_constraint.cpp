@@ -53,9 +53,20 @@ BatchedDefectConstraint::BatchedDefectConstraint(const std::string& ode, int mod
   fx_.resize(size_t(nappl_) * or_);
   agx_.resize(size_t(nappl_) * ir_);
   kkt_.resize(size_t(nappl_) * nkkt_);
+  // the staging arrays live as long as the constraint: page-lock them so the block copies run at PCIe rate
+  pinned_ = asset_hip_host_register(fx_.data(), fx_.size() * sizeof(double)) == 0 &&
+            asset_hip_host_register(agx_.data(), agx_.size() * sizeof(double)) == 0 &&
+            asset_hip_host_register(kkt_.data(), kkt_.size() * sizeof(double)) == 0;
 }
 
-BatchedDefectConstraint::~BatchedDefectConstraint() { asset_hip_defect_destroy(h_); }
+BatchedDefectConstraint::~BatchedDefectConstraint() {
+  if (pinned_) {
+    (void)asset_hip_host_unregister(fx_.data());
+    (void)asset_hip_host_unregister(agx_.data());
+    (void)asset_hip_host_unregister(kkt_.data());
+  }
+  asset_hip_defect_destroy(h_);
+}
 
 std::string BatchedDefectConstraint::name() const {
   const char* m = mode_ == ASSET_HIP_TRAPEZOIDAL ? "Trapezoidal" : (mode_ == 2 ? "LGL3" : (mode_ == 3 ? "LGL5" : "LGL7"));

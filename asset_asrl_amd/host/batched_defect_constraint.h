@@ -83,6 +83,7 @@ class BatchedDefectConstraint {
   std::string ode_;
   int mode_, ir_ = 0, or_ = 0, nkkt_ = 0, nappl_ = 0;
   std::vector<double> fx_, agx_, kkt_;
+  bool pinned_ = false;
   // device assembly state
   void ensure_kkt_map(const int* KKTLocations, const SolverIndexingData& data);
   long long nvalues_ = 0;

@@ -150,3 +150,15 @@ def test_gpu_full_size_properties(oracle):
     X2[np.unique(tidx)] += 0.25
     fx3, _, _ = ev.eval(CON, X2)
     assert np.abs(fx3 - fx).max() < 1e-9
+
+
+def test_pinned_outputs_give_the_same_blocks(oracle):
+    w = Workload("reentry", "LGL5", 300)
+    ev = DefectEvaluator("reentry", "LGL5", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    ref = [None if a is None else a.copy() for a in ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)]
+    ev.pin_outputs()
+    got = ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    assert ev.eval(CON, w.X)[0] is got[0]               # the same page-locked arrays are returned every time
+    ev.close()
