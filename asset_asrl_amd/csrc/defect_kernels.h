@@ -340,6 +340,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
 #else
 #define TS() do {} while (0)
 #endif
+// sub-phase stamps of the dense stage, taken for the second segment of the workgroup (-DASSET_TIMING, tools/dbg_time.py)
+#define TSG() do { if (g == 1) TS(); } while (0)
   for (int g0 = 0; g0 < wg_count; g0 += G) {
     const int seg0 = wg_first + g0;
     TS();
@@ -508,6 +510,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       const double* lam = S + D::w_lam;
       const double h = z[TF] - z[T];
       const size_t seg = size_t(seg0 + g);
+      TSG();   // slot in LDS
 
       if constexpr (LEVEL == 0) continue;
 
@@ -572,6 +575,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         }
       }
       wave_lds_sync();
+      TSG();   // D1: DI / DC tiles
       // time columns: DI rows -+ sum_j B_ij f_j (LGLDefects.h:446-450), DC rows -+ (sum_j D_ij f_j + E_i f^_i) (:484-500)
       auto time_columns = [&](int e, auto own_) {
         constexpr bool own = decltype(own_)::value;      // first pass: the weights are the precomputed per-lane ones
@@ -603,6 +607,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         for (int e = lane + 64; e < ROWS; e += 64) time_columns(e, std::false_type{});
       }
       wave_lds_sync();
+      TSG();   // time columns, FX
 
       // ---- D2: A fragments (DI_i^T tiles) for every tile row, reused by all three products
       double av[D::TI][K][KS];
@@ -797,6 +802,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       }
       if constexpr (LEVEL >= 2) {
         wave_lds_sync();
+        TSG();   // D2 + D3: fragments, M product
         // full time-partial vector HTpar (LGLDefects.h:403-411, 504-505) -> rank-2 rows:
         //   H += d HT^T + HT d^T  with d = e_TF - e_T   (the four updates of LGLDefects.h:508-511)
         const double ih = 1.0 / h;
@@ -812,6 +818,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
           R2[IRP + c] = v;          // A-side row 1 / B-side row 0 share this copy
         }
         wave_lds_sync();
+        TSG();   // rank-2 rows
       }
 
       // ---- D4: H (lower-triangle tiles) and J^T
@@ -886,6 +893,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       }
 
       __builtin_amdgcn_s_setprio(0);
+      TSG();   // D4: H (and J) products
       // ---- D5: adjoint gradient  g = J^T lam  without touching the J tile:
       //      interior part  h * sum_i E_i g^_i^T DI_i  (= h * HI), cardinal part = DC^T lam
       if (a.AGX) {
@@ -976,6 +984,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         }
       }
       wave_lds_sync();  // the next segment rewrites the DI / M / DC tiles
+      TSG();   // D5 + D6: adjoint gradient, stores
     }
     TS();
   }
