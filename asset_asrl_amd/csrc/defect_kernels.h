@@ -483,12 +483,18 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       }
       scr[D::s_DIc + e] = v;
     }
-    for (int e = lane; e < K * n * IRP; e += 64) scr[D::s_DIx + e] = 0.0;   // padding columns of the state rows
+    if constexpr (IR < IRP) {                          // padding columns of the state rows (D1 writes every column < IR)
+      for (int e = lane; e < K * n * IRP; e += 64) scr[D::s_DIx + e] = 0.0;
+    }
     for (int e = lane; e < IRP; e += 64) {
       scr[D::s_R2 + e] = (e == TF) ? 1.0 : ((e == T) ? -1.0 : 0.0);
       scr[D::s_R2 + 2 * IRP + e] = 0.0;
     }
-    for (int e = lane; e < ORP * D::LDC; e += 64) scr[D::s_DC + e] = 0.0;
+    if constexpr (IR < IRP) {                          // DC: padding columns and rows
+      for (int e = lane; e < ORP * D::LDC; e += 64) scr[D::s_DC + e] = 0.0;
+    } else {                                           // only the padding rows (columns >= IRP of a row are never read)
+      for (int e = lane; e < (ORP - OR) * D::LDC; e += 64) scr[D::s_DC + OR * D::LDC + e] = 0.0;
+    }
     if (lane < 2) scr[D::s_Z0 + lane] = 0.0;
     wave_lds_sync();
 
