@@ -61,6 +61,7 @@ struct asset_hip_defect {
   // staging for the host-pointer entry point (allocated lazily)
   double *d_X = nullptr, *d_L = nullptr, *d_fx = nullptr, *d_agx = nullptr, *d_kkt = nullptr;
   double* d_work = nullptr;  // per-workgroup ODE result slots
+  void* d_lane[3] = {nullptr, nullptr, nullptr};   // per-lane constants of the dense stage by derivative level
   // on-device KKT assembly (asset_hip_defect_set_kkt_map)
   int32_t* d_map = nullptr;        // value location of every accumulator entry, fragment order (defect_kernels.h, ASM)
   size_t map_len = 0;
@@ -216,6 +217,14 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
       return bail(e, "hipMemset(workspace)");
   }
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  if (ke->lane_bytes)   // per-lane constants of the dense stage: computed here, once
+    for (int level = 1; level <= 2; level++) {
+      const size_t nb = ke->lane_bytes(level);
+      if (!nb) continue;
+      if ((e = hipMalloc(&h->d_lane[level], nb)) != hipSuccess) return bail(e, "hipMalloc(lane constants)");
+      if ((e = ke->lane_setup(level, h->d_lane[level], h->stream)) != hipSuccess) return bail(e, "lane_setup_kernel");
+    }
+  if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(e, "lane_setup_kernel");
   if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
   if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
   *out = h;
@@ -227,7 +236,8 @@ void asset_hip_defect_destroy(asset_hip_defect_t h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->d_vindex, (void*)h->d_cindex, (void*)h->d_X, (void*)h->d_L, (void*)h->d_fx,
-                  (void*)h->d_agx, (void*)h->d_kkt, (void*)h->d_work, (void*)h->d_map, (void*)h->d_values})
+                  (void*)h->d_agx, (void*)h->d_kkt, (void*)h->d_work, (void*)h->d_map, (void*)h->d_values,
+                  h->d_lane[1], h->d_lane[2]})
     if (p) (void)hipFree(p);
   if (h->h_values) (void)hipHostFree(h->h_values);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -261,6 +271,7 @@ static int launch(asset_hip_defect_t h, int what, const double* dX, const double
   a.AGX = (what == ASSET_HIP_CON || what == ASSET_HIP_JAC) ? nullptr : dagx;
   a.KKT = (what >= ASSET_HIP_JAC) ? dkkt : nullptr;
   a.work = h->d_work;
+  a.lane_consts = h->d_lane[level];
   if (d_values) a.kmap = h->d_map, a.values = d_values, a.KKT = nullptr;   // on-device assembly
   hipError_t e = h->ke->launch(level, a, h->cus, st);
   if (e != hipSuccess) return hipfail(e, "kernel launch");

@@ -42,6 +42,8 @@ struct EvalArgs {
   // every slot is encoded as shared, which makes the evaluation a true += at about 1.4e11 atomics/s.
   const int* kmap = nullptr;
   double* values = nullptr;
+  // per-lane constants of the dense stage, computed once per handle (defect_kernels.h: LaneConsts, lane_setup_kernel)
+  const void* lane_consts = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------- sizes

@@ -144,6 +144,175 @@ __device__ inline void copy_rows(const double* stage, int stg_ld, int npt, int e
   }
 }
 
+// Per-lane constants of the dense stage: every index decode, table weight, fragment offset and store offset that
+// depends only on the lane, never on the segment.  They are the same for every workgroup of every launch of a handle,
+// and deriving them costs ~10 k cycles (dependent look-ups in the sparsity tables), a quarter of the time a workgroup
+// spends on its five segments of the bench workload -- so lane_setup_kernel computes them once per handle and the
+// dense stage loads its lane's record.
+template <class Ode, class D, int LEVEL>
+struct LaneConsts {
+  static constexpr int K = D::K, n = D::n, p = D::p, q = D::q, N = D::N, CS = D::CS, KS = D::KS;
+  static constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, P0 = D::P0;
+  static constexpr int CW = D::CW, RPW = 64 / CW, ROWS = K * n;
+  static constexpr bool BOTH = (RPW == 1);                 // one lane builds the DI and the DC entry of its column
+  static constexpr int CMAIN = (P0 < CW) ? P0 : CW;        // block columns handled by the structured pass
+  // Offsets are relative to the slot base S and always readable: "no entry" points at the zero cell, so the
+  // per-segment loads need no branch (a conditional LDS load costs a full exposed latency each).
+  static constexpr int ZERO = D::WSLOTD + D::s_Z0;
+  // JFUSE (small ODEs: all defect rows fit one 16-lane tile next to the N columns of H^ and the g^ column): the B
+  // operand of the M product of interior i carries (hE_i J^_i)^T in the lanes [i*n, i*n+n) -- the lanes that own the
+  // defect rows (i, .) of the J tile -- the g^ column in lane 15 and the H^ columns in the remaining lanes, so the
+  // interior part of J^T falls out of the same 2*TI MFMAs per interior and the separate J product disappears.
+  static constexpr bool JFUSE = (LEVEL >= 2) && (D::TJ == 1) && (D::MT == 1) && (K * n <= 15) && (N <= 15 - n);
+
+  double wa[K], wb[K], wa2[BOTH ? K : 1], wb2[BOTH ? K : 1];
+  double tB[CS], tD[CS], tC[CS], tE;                       // weights of the row (i,r) this lane owns in the time-column pass
+  int bo[D::MT][KS], bst[D::MT][KS];                       // B fragment of [hE H^ | E g^]: offset for i = 0 and stride in i
+  int cho[LEVEL >= 2 ? D::NTH : 1][4];                     // cardinal Hessian entry feeding accumulator (tile, v)
+  int chp[(LEVEL >= 2 && p > 0) ? D::NTH : 1][4];          // parameter-parameter entry (summed over the cardinal nodes) or -1
+  int jo[D::TJ][K][KS];                                    // (hE J^)^T fragment
+  int avb[KS], avs[KS];                                    // DI_i^T fragment: offset in the dense scratch for i = 0, stride in i
+  int cjo[n];                                              // dfdy_j[r][cc] of this lane's block column (D1)
+  int bo2[JFUSE ? K : 1][KS];                              // B operand offsets of the fused product
+  int hst[D::NTH][4], jst[D::TI * D::TJ][4];               // KKT slot of accumulator entry (tile, v) or -1
+
+  __device__ void compute(const LglTab& tab, int lane) {
+    const int lr = lane & 15, lk = lane >> 4;
+    const int d1c = lane & (CW - 1), d1h = lane / CW;
+    const bool d1ok = (d1c < CMAIN) && (BOTH || d1h < 2);
+    const int d1j = d1ok ? d1c / q : 0, d1cc = d1ok ? d1c - d1j * q : 0;
+    tE = 0.0;
+  #pragma unroll
+      for (int i = 0; i < K; i++) {
+        const bool dcrole = (!BOTH && d1h == 1);
+        wa[i] = dcrole ? tab.C[i][d1j] : tab.A[i][d1j];
+        wb[i] = dcrole ? tab.D[i][d1j] : tab.B[i][d1j];
+        if constexpr (BOTH) { wa2[i] = tab.C[i][d1j]; wb2[i] = tab.D[i][d1j]; }
+      }
+      {
+        const int e = (lane < ROWS) ? lane : 0, i = e / n;
+  #pragma unroll
+        for (int jj = 0; jj < CS; jj++) { tB[jj] = tab.B[i][jj]; tD[jj] = tab.D[i][jj]; tC[jj] = tab.C[i][jj]; }
+        tE = tab.E[i];
+      }
+  #pragma unroll
+      for (int mt = 0; mt < D::MT; mt++)
+  #pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+          const int b = 4 * kk + lk, acol = 16 * mt + lr;
+          int v = ZERO, st = 0;
+          if (b < N) {
+            if (acol < N) {
+              const int hp = Ode::HPOS[(b >= acol) ? b * (b + 1) / 2 + acol : acol * (acol + 1) / 2 + b];
+              if (hp >= 0) { v = D::w_IH + hp; st = D::NZH; }
+            } else if (acol == N) { v = D::w_Ig + b; st = N; }   // the g^ column is scaled by E_i, the others by h E_i
+          }
+          bo[mt][kk] = v;
+          bst[mt][kk] = st;
+        }
+      if constexpr (JFUSE) {
+  #pragma unroll
+        for (int i = 0; i < K; i++) {
+          const int jk = lr - i * n;
+          const bool isj = (jk >= 0 && jk < n);
+          const int hr = (isj || lr == 15) ? -1 : ((lr < i * n) ? lr : lr - n);   // rank among the H^ lanes
+          const bool ish = (hr >= 0 && hr < N);
+  #pragma unroll
+          for (int kk = 0; kk < KS; kk++) {
+            const int b = 4 * kk + lk;
+            int o = ZERO;
+            if (b < N) {
+              if (isj) { const int jp = Ode::JPOS[jk * N + b]; if (jp >= 0) o = D::w_IJ + i * D::NZJ + jp; }
+              else if (ish) { const int hp = Ode::HPOS[(b >= hr) ? b * (b + 1) / 2 + hr : hr * (hr + 1) / 2 + b]; if (hp >= 0) o = D::w_IH + i * D::NZH + hp; }
+              else if (lr == 15) o = D::w_Ig + i * N + b;
+            }
+            bo2[i][kk] = o;
+          }
+        }
+      }
+  #pragma unroll
+      for (int r = 0; r < n; r++) {
+        const int jp = Ode::JPOS[r * N + d1cc];
+        cjo[r] = (d1ok && jp >= 0) ? D::w_CJ + d1j * D::NZJ + jp : ZERO;
+      }
+  #pragma unroll
+      for (int kk = 0; kk < KS; kk++) {
+        const int r = 4 * kk + lk;
+        avb[kk] = ((r < n) ? D::s_DIx + r * IRP : D::s_DIc + (r - n) * IRP) + lr;
+        avs[kk] = ((r < n) ? n : D::NCR) * IRP;
+      }
+  #pragma unroll
+      for (int jt = 0; jt < D::TJ; jt++) {
+        const int jr = 16 * jt + lr;
+        const int ji = (jr < OR) ? jr / n : K, jk = (jr < OR) ? jr - ji * n : 0;
+  #pragma unroll
+        for (int i = 0; i < K; i++)
+  #pragma unroll
+          for (int kk = 0; kk < KS; kk++) {
+            const int aa = 4 * kk + lk;
+            const int jp = (ji == i && aa < N) ? Ode::JPOS[jk * N + aa] : -1;
+            jo[jt][i][kk] = (jp >= 0) ? D::w_IJ + i * D::NZJ + jp : ZERO;
+          }
+      }
+  #pragma unroll
+      for (int ct = 0; ct < D::TI; ct++)
+  #pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int c = 16 * ct + lk + 4 * v;
+          const int cst = c * (IR + OR) - c * (c - 1) / 2;   // first slot of block column c
+  #pragma unroll
+          for (int jt = 0; jt < D::TJ; jt++) {
+            const int jr = 16 * jt + lr;
+            jst[ct * D::TJ + jt][v] = (c < IR && jr < OR) ? cst + (IR - c) + jr : -1;
+          }
+  #pragma unroll
+          for (int rt = ct; rt < D::TI; rt++) {
+            const int r = 16 * rt + lr, tix = rt * (rt + 1) / 2 + ct;
+            const bool ok = (c < IR && r < IR && r >= c);
+            hst[tix][v] = ok ? cst + (r - c) : -1;
+            if constexpr (LEVEL >= 2) {
+              int ch = ZERO, cp = -1;
+              if (ok) {
+                if (c < P0) {
+                  const int jn = c / q, cc = c - jn * q;
+                  if (r < P0) {
+                    if (r / q == jn) { const int rr = r - jn * q, hp = Ode::HPOS[rr * (rr + 1) / 2 + cc]; if (hp >= 0) ch = D::w_CH + jn * D::NZH + hp; }
+                  } else {
+                    const int rr = q + (r - P0), hp = Ode::HPOS[rr * (rr + 1) / 2 + cc];
+                    if (hp >= 0) ch = D::w_CH + jn * D::NZH + hp;
+                  }
+                } else {
+                  const int rr = q + (r - P0), c2 = q + (c - P0);
+                  cp = Ode::HPOS[rr * (rr + 1) / 2 + c2];    // parameter-parameter: summed over the cardinal nodes
+                }
+              }
+              cho[tix][v] = ch;
+              if constexpr (p > 0) chp[tix][v] = cp;
+            }
+          }
+        }
+    }
+};
+
+// The 64 records are stored word-interleaved -- word k of lane l at [k*64 + l] -- so that a wave reads its records with
+// coalesced loads (record-major storage costs 64 cache lines per load instruction).
+template <class LC>
+struct LaneRecord {
+  static_assert(sizeof(LC) % 4 == 0, "record must be a whole number of words");
+  static constexpr int NW = int(sizeof(LC) / 4);
+  union { LC lc; unsigned int w[NW]; };
+  __device__ LaneRecord() {}
+};
+
+template <class Ode, int SCH, bool BLOCKED, int LEVEL>
+__global__ __launch_bounds__(64) void lane_setup_kernel(unsigned int* out) {
+  using LC = LaneConsts<Ode, Dims<Ode, SCH, BLOCKED>, LEVEL>;
+  LaneRecord<LC> r;
+  for (int k = 0; k < LaneRecord<LC>::NW; k++) r.w[k] = 0u;
+  r.lc.compute(d_lgl_tab[Dims<Ode, SCH, BLOCKED>::TAB], threadIdx.x);
+  for (int k = 0; k < LaneRecord<LC>::NW; k++) out[k * 64 + threadIdx.x] = r.w[k];
+}
+
 // ---------------------------------------------------------------------------------------------- kernel
 // LEVEL 0: value only (constraints).  LEVEL 1: value + Jacobian (+ J^T lam).  LEVEL 2: + adjoint Hessian.
 // STAGE 1: ODE phases only (P0-P3; results -> workspace slot of every segment).  STAGE 2: dense phase only (P4).
@@ -194,144 +363,42 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
 
   // ---- per-lane constants of the dense phase, computed once per launch: every index decode, table lookup and
   //      store offset below depends only on the lane, never on the segment
-  constexpr int CW = D::CW, RPW = 64 / CW, ROWS = K * n;
-  constexpr bool BOTH = (RPW == 1);                        // one lane builds the DI and the DC entry of its column
-  constexpr int CMAIN = (P0 < CW) ? P0 : CW;               // block columns handled by the structured pass
+  using LCT = LaneConsts<Ode, D, (LEVEL >= 2 ? 2 : 1)>;
+  constexpr int CW = LCT::CW, RPW = LCT::RPW, ROWS = LCT::ROWS, CMAIN = LCT::CMAIN, ZERO = LCT::ZERO;
+  constexpr bool BOTH = LCT::BOTH, JFUSE = LCT::JFUSE;
+  (void)RPW;
   const int d1c = lane & (CW - 1), d1h = lane / CW;        // column; role 0 -> DI row, 1 -> DC row (when RPW >= 2)
   const bool d1ok = (d1c < CMAIN) && (BOTH || d1h < 2);
-  const int d1j = d1ok ? d1c / q : 0, d1cc = d1ok ? d1c - d1j * q : 0;
-  double wa[K], wb[K], wa2[BOTH ? K : 1], wb2[BOTH ? K : 1];
-  // Offsets below are relative to the slot base S and always readable: "no entry" points at the zero cell, so the
-  // per-segment loads need no branch (a conditional LDS load costs a full exposed latency each).
-  constexpr int ZERO = D::WSLOTD + D::s_Z0;
-  // slot offset of dfdy_j[r][cc] / dfdy^_i[k][b] for run-time indices (the rare paths; table lookups)
+  const int d1cc = d1ok ? d1c - (d1c / q) * q : 0;
+  // slot offset of dfdy_j[r][cc] for run-time indices (the rare paths; table look-ups)
   auto cj_at = [](int j, int r, int cc) { const int jp = Ode::JPOS[r * N + cc]; return jp >= 0 ? D::w_CJ + j * D::NZJ + jp : ZERO; };
   (void)cj_at;
-  int bo[D::MT][KS], bst[D::MT][KS];                       // B fragment of [hE H^ | E g^]: offset for i = 0 and stride in i
-  int cho[LEVEL >= 2 ? D::NTH : 1][4];                     // cardinal Hessian entry feeding accumulator (tile, v)
-  int chp[(LEVEL >= 2 && p > 0) ? D::NTH : 1][4];          // parameter-parameter entry (summed over the cardinal nodes) or -1
-  int jo[D::TJ][K][KS];                                    // (hE J^)^T fragment
-  int avb[KS], avs[KS];                                    // DI_i^T fragment: offset in the dense scratch for i = 0, stride in i
-  int cjo[n];                                              // dfdy_j[r][cc] of this lane's block column (D1)
-  // JFUSE (small ODEs: all defect rows fit one 16-lane tile next to the N columns of H^ and the g^ column): the B
-  // operand of the M product of interior i carries (hE_i J^_i)^T in the lanes [i*n, i*n+n) -- the lanes that own the
-  // defect rows (i, .) of the J tile -- the g^ column in lane 15 and the H^ columns in the remaining lanes, so the
-  // interior part of J^T falls out of the same 2*TI MFMAs per interior and the separate J product disappears.
-  constexpr bool JFUSE = (LEVEL >= 2) && (D::TJ == 1) && (D::MT == 1) && (K * n <= 15) && (N <= 15 - n);
-  int bo2[JFUSE ? K : 1][KS];                              // B operand offsets of the fused product
-  int hst[D::NTH][4], jst[D::TI * D::TJ][4];   // KKT slot of accumulator entry (tile, v) or -1
-  double tB[CS], tD[CS], tC[CS], tE = 0.0;                 // weights of the row (i,r) this lane owns in the time-column pass
-  if constexpr (STAGE == 2 && LEVEL >= 1) {
+  LaneRecord<LCT> lrec;
+  if constexpr (STAGE == 2 && LEVEL >= 1) {              // computed once per handle (lane_setup_kernel)
 #pragma unroll
-    for (int i = 0; i < K; i++) {
-      const bool dcrole = (!BOTH && d1h == 1);
-      wa[i] = dcrole ? tab.C[i][d1j] : tab.A[i][d1j];
-      wb[i] = dcrole ? tab.D[i][d1j] : tab.B[i][d1j];
-      if constexpr (BOTH) { wa2[i] = tab.C[i][d1j]; wb2[i] = tab.D[i][d1j]; }
-    }
-    {
-      const int e = (lane < ROWS) ? lane : 0, i = e / n;
-#pragma unroll
-      for (int jj = 0; jj < CS; jj++) { tB[jj] = tab.B[i][jj]; tD[jj] = tab.D[i][jj]; tC[jj] = tab.C[i][jj]; }
-      tE = tab.E[i];
-    }
-#pragma unroll
-    for (int mt = 0; mt < D::MT; mt++)
-#pragma unroll
-      for (int kk = 0; kk < KS; kk++) {
-        const int b = 4 * kk + lk, acol = 16 * mt + lr;
-        int v = ZERO, st = 0;
-        if (b < N) {
-          if (acol < N) {
-            const int hp = Ode::HPOS[(b >= acol) ? b * (b + 1) / 2 + acol : acol * (acol + 1) / 2 + b];
-            if (hp >= 0) { v = D::w_IH + hp; st = D::NZH; }
-          } else if (acol == N) { v = D::w_Ig + b; st = N; }   // the g^ column is scaled by E_i, the others by h E_i
-        }
-        bo[mt][kk] = v;
-        bst[mt][kk] = st;
-      }
-    if constexpr (JFUSE) {
-#pragma unroll
-      for (int i = 0; i < K; i++) {
-        const int jk = lr - i * n;
-        const bool isj = (jk >= 0 && jk < n);
-        const int hr = (isj || lr == 15) ? -1 : ((lr < i * n) ? lr : lr - n);   // rank among the H^ lanes
-        const bool ish = (hr >= 0 && hr < N);
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) {
-          const int b = 4 * kk + lk;
-          int o = ZERO;
-          if (b < N) {
-            if (isj) { const int jp = Ode::JPOS[jk * N + b]; if (jp >= 0) o = D::w_IJ + i * D::NZJ + jp; }
-            else if (ish) { const int hp = Ode::HPOS[(b >= hr) ? b * (b + 1) / 2 + hr : hr * (hr + 1) / 2 + b]; if (hp >= 0) o = D::w_IH + i * D::NZH + hp; }
-            else if (lr == 15) o = D::w_Ig + i * N + b;
-          }
-          bo2[i][kk] = o;
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < n; r++) {
-      const int jp = Ode::JPOS[r * N + d1cc];
-      cjo[r] = (d1ok && jp >= 0) ? D::w_CJ + d1j * D::NZJ + jp : ZERO;
-    }
-#pragma unroll
-    for (int kk = 0; kk < KS; kk++) {
-      const int r = 4 * kk + lk;
-      avb[kk] = ((r < n) ? D::s_DIx + r * IRP : D::s_DIc + (r - n) * IRP) + lr;
-      avs[kk] = ((r < n) ? n : D::NCR) * IRP;
-    }
-#pragma unroll
-    for (int jt = 0; jt < D::TJ; jt++) {
-      const int jr = 16 * jt + lr;
-      const int ji = (jr < OR) ? jr / n : K, jk = (jr < OR) ? jr - ji * n : 0;
-#pragma unroll
-      for (int i = 0; i < K; i++)
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) {
-          const int aa = 4 * kk + lk;
-          const int jp = (ji == i && aa < N) ? Ode::JPOS[jk * N + aa] : -1;
-          jo[jt][i][kk] = (jp >= 0) ? D::w_IJ + i * D::NZJ + jp : ZERO;
-        }
-    }
-#pragma unroll
-    for (int ct = 0; ct < D::TI; ct++)
-#pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const int c = 16 * ct + lk + 4 * v;
-        const int cst = c * (IR + OR) - c * (c - 1) / 2;   // first slot of block column c
-#pragma unroll
-        for (int jt = 0; jt < D::TJ; jt++) {
-          const int jr = 16 * jt + lr;
-          jst[ct * D::TJ + jt][v] = (c < IR && jr < OR) ? cst + (IR - c) + jr : -1;
-        }
-#pragma unroll
-        for (int rt = ct; rt < D::TI; rt++) {
-          const int r = 16 * rt + lr, tix = rt * (rt + 1) / 2 + ct;
-          const bool ok = (c < IR && r < IR && r >= c);
-          hst[tix][v] = ok ? cst + (r - c) : -1;
-          if constexpr (LEVEL >= 2) {
-            int ch = ZERO, cp = -1;
-            if (ok) {
-              if (c < P0) {
-                const int jn = c / q, cc = c - jn * q;
-                if (r < P0) {
-                  if (r / q == jn) { const int rr = r - jn * q, hp = Ode::HPOS[rr * (rr + 1) / 2 + cc]; if (hp >= 0) ch = D::w_CH + jn * D::NZH + hp; }
-                } else {
-                  const int rr = q + (r - P0), hp = Ode::HPOS[rr * (rr + 1) / 2 + cc];
-                  if (hp >= 0) ch = D::w_CH + jn * D::NZH + hp;
-                }
-              } else {
-                const int rr = q + (r - P0), c2 = q + (c - P0);
-                cp = Ode::HPOS[rr * (rr + 1) / 2 + c2];    // parameter-parameter: summed over the cardinal nodes
-              }
-            }
-            cho[tix][v] = ch;
-            if constexpr (p > 0) chp[tix][v] = cp;
-          }
-        }
-      }
+    for (int k = 0; k < LaneRecord<LCT>::NW; k++) lrec.w[k] = static_cast<const unsigned int*>(a.lane_consts)[k * 64 + lane];
   }
+  const LCT& lc = lrec.lc;
+  const auto& wa = lc.wa;
+  const auto& wb = lc.wb;
+  const auto& wa2 = lc.wa2;
+  const auto& wb2 = lc.wb2;
+  const auto& tB = lc.tB;
+  const auto& tD = lc.tD;
+  const auto& tC = lc.tC;
+  const auto& bo = lc.bo;
+  const auto& bst = lc.bst;
+  const auto& cho = lc.cho;
+  const auto& chp = lc.chp;
+  const auto& jo = lc.jo;
+  const auto& avb = lc.avb;
+  const auto& avs = lc.avs;
+  const auto& cjo = lc.cjo;
+  const auto& bo2 = lc.bo2;
+  const auto& hst = lc.hst;
+  const auto& jst = lc.jst;
+  const double& tE = lc.tE;
+  (void)wa2; (void)wb2; (void)chp; (void)bo2; (void)bo; (void)bst; (void)jo; (void)cho;
 
 #if defined(ASSET_TIMING)
   long long tstamp[24];

@@ -25,6 +25,9 @@ struct KernelEntry {
   hipError_t (*launch)(int level, const EvalArgs& a, int cus, hipStream_t st);
   KernelEntry* next;
   hipError_t (*mesh)(const MeshArgs& a, hipStream_t st);   // de Boor mesh-error estimate (mesh_kernels.h)
+  // per-lane constants of the dense stage for derivative level 1 / 2: table size in bytes (0: none) and the kernel filling it
+  size_t (*lane_bytes)(int level);
+  hipError_t (*lane_setup)(int level, void* out, hipStream_t st);
 };
 
 #if defined(ASSET_PLUGIN)
@@ -116,8 +119,23 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   static ::asset_hip::KernelEntry entry_##FN##_func = {                                                           \
       FN::name(), FN::XV, FN::UV, FN::PV, 0, 0,                                                                   \
       ::asset_hip::FuncDims<FN>::IR, ::asset_hip::FuncDims<FN>::OR, ::asset_hip::FuncDims<FN>::NKKT, 0, 0, 0,    \
-      &::asset_hip::launch_func<FN>, nullptr, nullptr};                                                           \
+      &::asset_hip::launch_func<FN>, nullptr, nullptr, nullptr, nullptr};                                         \
   static ::asset_hip::Registrar reg_##FN##_func(&entry_##FN##_func);
+
+template <class Ode, int SCH, bool BLOCKED>
+size_t lgl_lane_bytes(int level) {
+  using D = Dims<Ode, SCH, BLOCKED>;
+  // bytes of the whole table: 64 word-interleaved records (defect_kernels.h: lane_setup_kernel)
+  return level >= 2 ? sizeof(LaneConsts<Ode, D, 2>) * 64 : (level == 1 ? sizeof(LaneConsts<Ode, D, 1>) * 64 : 0);
+}
+template <class Ode, int SCH, bool BLOCKED>
+hipError_t lgl_lane_setup(int level, void* out, hipStream_t st) {
+  if (level >= 2)
+    hipLaunchKernelGGL((lane_setup_kernel<Ode, SCH, BLOCKED, 2>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));
+  else
+    hipLaunchKernelGGL((lane_setup_kernel<Ode, SCH, BLOCKED, 1>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));
+  return hipGetLastError();
+}
 
 // Trapezoidal = transcription id 1 of the same kernels (defect_dims.h: Dims::TRAP)
 #define ASSET_REGISTER_TRAP(ODE, BLK, G) ASSET_REGISTER_LGL(ODE, 1, BLK, G)
@@ -130,7 +148,8 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
       ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::lds_bytes(),                                                       \
       size_t(::asset_hip::Dims<ODE, CSV, (BLK != 0)>::WSLOT),                                                      \
       &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr,        \
-      &::asset_hip::launch_mesh<ODE, CSV, (BLK != 0)>};                                          \
+      &::asset_hip::launch_mesh<ODE, CSV, (BLK != 0)>, &::asset_hip::lgl_lane_bytes<ODE, CSV, (BLK != 0)>,         \
+      &::asset_hip::lgl_lane_setup<ODE, CSV, (BLK != 0)>};                                                         \
   static ::asset_hip::Registrar reg_##ODE##_##CSV##_##BLK(&entry_##ODE##_##CSV##_##BLK);
 
 }  // namespace asset_hip
