@@ -352,7 +352,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
     wave_lds_sync();
   };
-  if constexpr (STAGE != 1) publish_tables();
   const LglTab& tab = *reinterpret_cast<const LglTab*>(tabL);
 
   // this workgroup's share of the mesh: contiguous, balanced (same rule as IndexingData.h:117-146)
@@ -379,6 +378,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
     for (int k = 0; k < LaneRecord<LCT>::NW; k++) lrec.w[k] = static_cast<const unsigned int*>(a.lane_consts)[k * 64 + lane];
   }
   const LCT& lc = lrec.lc;
+  if constexpr (STAGE != 1) publish_tables();            // after the record loads are in flight: one latency, not two
   const auto& wa = lc.wa;
   const auto& wb = lc.wb;
   const auto& wa2 = lc.wa2;
