@@ -98,6 +98,9 @@ def _build_and_load(name, hdr_name, hdr, tag, src, mode_id, blocked, what) -> st
         if r.returncode != 0:
             raise _lib.AssetHipError(f"hipcc failed for {what}:\n{r.stderr[-3000:]}")
         os.replace(so + ".tmp", so)
+        for f in os.listdir(wd):            # plugins of this unit built against older sources
+            if f.startswith(f"plugin_{tag}_") and f.endswith(".so") and os.path.join(wd, f) != so:
+                os.remove(os.path.join(wd, f))
     if so not in _loaded:
         rc = _lib.lib().asset_hip_load_plugin(so.encode())
         if rc < 0:
