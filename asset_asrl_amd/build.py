@@ -41,7 +41,10 @@ def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
     NP = (N + 3) // 4 * 4
     WSLOTD = IR + OR + cs * n + cs * nzj + cs * N + cs * nzh + K * n + K * nzj + K * N + K * nzh
     WSLOT = WSLOTD + cs * nsave
-    SCRATCH = max(K * n * IRP, IRP * (K * NP + 1)) + K * (NP - n) * IRP + ORP * (IRP + 4) + 4 * IRP + 2
+    LDM = K * NP + 1
+    SCRATCH = max(K * n * IRP, IRP * LDM) + K * (NP - n) * IRP + ORP * (IRP + 4) + 4 * IRP + 2
+    if (70 + WSLOTD + SCRATCH) * 8 > LDS_BUDGET:     # Dims::WIDE: DI resident, M^T one row tile at a time, no DC tile
+        SCRATCH = K * n * IRP + 16 * LDM + K * (NP - n) * IRP + ORP + 4 * IRP + 2
     DENSE = WSLOTD + SCRATCH
     STG_LD = (nzj + nzh) | 1
     budget = 64 * 1024

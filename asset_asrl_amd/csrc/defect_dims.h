@@ -99,18 +99,25 @@ struct Dims {
   // / parameter / padding), constant per launch.  M^T is produced after every A fragment has been read into
   // registers, so it re-uses the state-row tile's memory.
   static constexpr int NCR = NP - n;                   // constant rows per interior
+  static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
+  static constexpr int LDM = K * NP + 1;               // M is stored column-major [IRP][LDM]: conflict-free MFMA write-back
+  static constexpr int LDC = IRP + 4;                  // DC row stride: row- and column-wise fragment reads both conflict-free
+  static constexpr int XM_ALL = (K * n * IRP > IRP * LDM) ? K * n * IRP : IRP * LDM;
+  // WIDE: with all of M^T and the DC tile the working set of one segment exceeds the 160 KiB of a CU (32 states in
+  // LGL7: M^T 124 KB + DC 113 KB + DI 124 KB).  Such shapes keep only DI resident: M^T is produced one 16-row tile at
+  // a time right before the H tiles of that tile row, and the cardinal part of J is formed from the slot where it is
+  // used instead of being kept as a tile (s_DC then holds just the time-column vector, one entry per defect row).
+  static constexpr bool WIDE =
+      size_t(TABSZ + WSLOTD + XM_ALL + K * NCR * IRP + ORP * LDC + 4 * IRP + 2) * 8 > 160 * 1024;
   static constexpr int s_DIx = 0;                      // [K][n][IRP]
-  static constexpr int s_M = 0;                        // M^T [IRP][K*NP+1]  (aliases s_DIx)
-  static constexpr int XM = (K * n * IRP > IRP * (K * NP + 1)) ? K * n * IRP : IRP * (K * NP + 1);
+  static constexpr int s_M = WIDE ? K * n * IRP : 0;   // M^T [IRP][K*NP+1], aliases s_DIx  (WIDE: one row tile [16][LDM] beside it)
+  static constexpr int XM = WIDE ? K * n * IRP + 16 * LDM : XM_ALL;
   static constexpr int s_DIc = XM;                     // [K][NCR][IRP]
   static constexpr int s_DC = s_DIc + K * (NP - n) * IRP;  // cardinal part of J, rows = defect rows  [ORP][IRP], padding rows zero
-  static constexpr int LDC = IRP + 4;                  // DC row stride: row- and column-wise fragment reads both conflict-free
-  static constexpr int s_R2 = s_DC + ORP * LDC;        // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar, [2] = 0
+  static constexpr int s_R2 = s_DC + (WIDE ? ORP : ORP * LDC);   // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar, [2] = 0
   static constexpr int s_HI = s_R2 + 3 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
   static constexpr int s_Z0 = s_HI + IRP;              // a cell that always holds 0.0: target of every "no entry" offset
-  static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
   static constexpr int SCRATCH = s_Z0 + 2;
-  static constexpr int LDM = K * NP + 1;               // M is stored column-major [IRP][LDM]: conflict-free MFMA write-back
 
   // ---- ODE-phase staging: every evaluating lane writes its dense J (n x N) and packed H into an LDS row, the wave
   //      then copies the rows to the workspace with coalesced stores.  Row stride is odd: conflict-free ds_write.

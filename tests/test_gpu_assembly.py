@@ -17,6 +17,7 @@ CASES = [
     ("twobody_lt", "LGL5", 75, True),           # BlockConstant: per-segment control parameters
     ("betts_lowthrust", "LGL5", 40, False),     # a phase parameter shared by every segment (many-way clash)
     ("brachistochrone", "Trapezoidal", 33, False),
+    ("synthetic32", "LGL7", 5, False),          # wide shape: map entries read at the stores
 ]
 
 

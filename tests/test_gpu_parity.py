@@ -47,12 +47,14 @@ CONFIGS = [
     ("twobody_lt", "Trapezoidal", 33, True),
     ("betts_lowthrust", "Trapezoidal", 21, False),
     ("synthetic32", "Trapezoidal", 5, False),
+    ("synthetic32", "LGL5", 7, False),
+    ("synthetic32", "LGL7", 6, False),           # config 4 shape: the wide-shape dense path (Dims::WIDE)
 ]
 
 
 def _all_kernels():
     out = []
-    for ode in ("brachistochrone", "reentry", "twobody_lt", "betts_lowthrust"):
+    for ode in ("brachistochrone", "reentry", "twobody_lt", "betts_lowthrust", "synthetic32"):
         for mode in ("Trapezoidal", "LGL3", "LGL5", "LGL7"):
             for blocked in (False, True):
                 out.append((ode, mode, blocked))
