@@ -43,8 +43,9 @@ def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
     WSLOT = WSLOTD + cs * nsave
     LDM = K * NP + 1
     SCRATCH = max(K * n * IRP, IRP * LDM) + K * (NP - n) * IRP + ORP * (IRP + 4) + 4 * IRP + 2
-    if (70 + WSLOTD + SCRATCH) * 8 > LDS_BUDGET:     # Dims::WIDE: DI resident, M^T one row tile at a time, no DC tile
-        SCRATCH = K * n * IRP + 16 * LDM + K * (NP - n) * IRP + ORP + 4 * IRP + 2
+    if (70 + WSLOTD + SCRATCH) * 8 > LDS_BUDGET:     # Dims::WIDE (csrc/defect_wide.h): DI resident, M in registers, no DC tile
+        SCRATCH = K * n * IRP + K * (N - n) * IRP + (ORP + cs * n + 2) + 4 * IRP + 2 \
+            + (n * N + 3) // 4 + (NH + 3) // 4
     DENSE = WSLOTD + SCRATCH
     STG_LD = (nzj + nzh) | 1
     budget = 64 * 1024

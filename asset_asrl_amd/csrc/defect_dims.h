@@ -98,26 +98,32 @@ struct Dims {
   // DI_i is kept as two tiles: state rows (r < n), rewritten for every segment, and the remaining rows (tau / control
   // / parameter / padding), constant per launch.  M^T is produced after every A fragment has been read into
   // registers, so it re-uses the state-row tile's memory.
-  static constexpr int NCR = NP - n;                   // constant rows per interior
   static constexpr int TABSZ = (sizeof(LglTab) + 7) / 8;   // LDS copy of the scheme's weight tables
   static constexpr int LDM = K * NP + 1;               // M is stored column-major [IRP][LDM]: conflict-free MFMA write-back
   static constexpr int LDC = IRP + 4;                  // DC row stride: row- and column-wise fragment reads both conflict-free
   static constexpr int XM_ALL = (K * n * IRP > IRP * LDM) ? K * n * IRP : IRP * LDM;
   // WIDE: with all of M^T and the DC tile the working set of one segment exceeds the 160 KiB of a CU (32 states in
-  // LGL7: M^T 124 KB + DC 113 KB + DI 124 KB).  Such shapes keep only DI resident: M^T is produced one 16-row tile at
-  // a time right before the H tiles of that tile row, and the cardinal part of J is formed from the slot where it is
-  // used instead of being kept as a tile (s_DC then holds just the time-column vector, one entry per defect row).
+  // LGL7: M^T 124 KB + DC 113 KB beside DI).  Such shapes run the dense stage as one four-wave workgroup per CU
+  // (defect_wide.h) that keeps only DI resident: every wave produces the 16 columns of M_i it is about to use in
+  // registers, and the cardinal part of J is formed from the slot where it is used instead of being kept as a tile
+  // (s_DC then holds the time-column vector, one entry per defect row, and the multiplier weights of J^T lam).
   static constexpr bool WIDE =
-      size_t(TABSZ + WSLOTD + XM_ALL + K * NCR * IRP + ORP * LDC + 4 * IRP + 2) * 8 > 160 * 1024;
+      size_t(TABSZ + WSLOTD + XM_ALL + K * (NP - n) * IRP + ORP * LDC + 4 * IRP + 2) * 8 > 160 * 1024;
+  static constexpr int WNW = 4;                        // waves of the wide dense kernel
+  static constexpr int NCR = WIDE ? N - n : NP - n;    // constant rows per interior (wide: the k-padding rows read a zero row)
   static constexpr int s_DIx = 0;                      // [K][n][IRP]
-  static constexpr int s_M = WIDE ? K * n * IRP : 0;   // M^T [IRP][K*NP+1], aliases s_DIx  (WIDE: one row tile [16][LDM] beside it)
-  static constexpr int XM = WIDE ? K * n * IRP + 16 * LDM : XM_ALL;
+  static constexpr int s_M = 0;                        // M^T [IRP][K*NP+1], aliases s_DIx  (wide: M stays in registers)
+  static constexpr int XM = WIDE ? K * n * IRP : XM_ALL;
   static constexpr int s_DIc = XM;                     // [K][NCR][IRP]
-  static constexpr int s_DC = s_DIc + K * (NP - n) * IRP;  // cardinal part of J, rows = defect rows  [ORP][IRP], padding rows zero
-  static constexpr int s_R2 = s_DC + (WIDE ? ORP : ORP * LDC);   // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar, [2] = 0
+  static constexpr int s_DC = s_DIc + K * NCR * IRP;   // cardinal part of J, rows = defect rows  [ORP][LDC], padding rows zero
+  static constexpr int s_WL = s_DC + ORP;              // wide: sum_i D_ij lam_(i,r)  [CS][n], then the work counter
+  static constexpr int s_CNT = s_WL + CS * n;
+  static constexpr int s_R2 = s_DC + (WIDE ? ORP + CS * n + 2 : ORP * LDC);   // rank-2 time rows: [0] = d = e_TF - e_T (constant), [1] = HTpar, [2] = 0
   static constexpr int s_HI = s_R2 + 3 * IRP;          // sum_i E_i g^_i^T DI_i     [IRP]
   static constexpr int s_Z0 = s_HI + IRP;              // a cell that always holds 0.0: target of every "no entry" offset
-  static constexpr int SCRATCH = s_Z0 + 2;
+  static constexpr int s_JP = s_Z0 + 2;                // wide: Ode::JPOS / HPOS as 16-bit LDS tables (run-time look-ups)
+  static constexpr int s_HP = s_JP + (WIDE ? (n * N + 3) / 4 : 0);
+  static constexpr int SCRATCH = s_HP + (WIDE ? (NH + 3) / 4 : 0);
 
   // ---- ODE-phase staging: every evaluating lane writes its dense J (n x N) and packed H into an LDS row, the wave
   //      then copies the rows to the workspace with coalesced stores.  Row stride is odd: conflict-free ds_write.

@@ -364,8 +364,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   //      store offset below depends only on the lane, never on the segment
   using LCT = LaneConsts<Ode, D, (LEVEL >= 2 ? 2 : 1)>;
   constexpr int CW = LCT::CW, RPW = LCT::RPW, ROWS = LCT::ROWS, CMAIN = LCT::CMAIN, ZERO = LCT::ZERO;
-  constexpr bool BOTH = LCT::BOTH, JFUSE = LCT::JFUSE, WIDE = D::WIDE;
-  static_assert(!WIDE || (BOTH && !JFUSE), "wide shapes build the DI rows with one lane per column");
+  constexpr bool BOTH = LCT::BOTH, JFUSE = LCT::JFUSE;
   (void)RPW;
   const int d1c = lane & (CW - 1), d1h = lane / CW;        // column; role 0 -> DI row, 1 -> DC row (when RPW >= 2)
   const bool d1ok = (d1c < CMAIN) && (BOTH || d1h < 2);
@@ -558,8 +557,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       scr[D::s_R2 + e] = (e == TF) ? 1.0 : ((e == T) ? -1.0 : 0.0);
       scr[D::s_R2 + 2 * IRP + e] = 0.0;
     }
-    if constexpr (WIDE) {                              // no DC tile (the M^T row tile is written in full for every tile row)
-    } else if constexpr (IR < IRP) {                   // DC: padding columns and rows
+    if constexpr (IR < IRP) {                          // DC: padding columns and rows
       for (int e = lane; e < ORP * D::LDC; e += 64) scr[D::s_DC + e] = 0.0;
     } else {                                           // only the padding rows (columns >= IRP of a row are never read)
       for (int e = lane; e < (ORP - OR) * D::LDC; e += 64) scr[D::s_DC + OR * D::LDC + e] = 0.0;
@@ -620,7 +618,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
           double v = wbh[i] * jv;
           if (d1cc == r) v += wa[i];
           dstb[row * dld] = v;
-          if constexpr (BOTH && !WIDE) {
+          if constexpr (BOTH) {
             double v2 = wb2h[i] * jv;
             if (d1cc == r) v2 += wa2[i];
             DC[row * D::LDC + d1c] = v2;
@@ -646,7 +644,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
             }
           }
           DIx[row * IRP + c2] = vi;
-          if constexpr (!WIDE) DC[row * D::LDC + c2] = vc;
+          DC[row * D::LDC + c2] = vc;
         }
       }
       wave_lds_sync();
@@ -659,8 +657,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         const double fi = S[D::w_If + i * n + r];
 #pragma unroll
         for (int jj = 0; jj < CS; jj++) { fv[jj] = S[D::w_Cf + jj * n + r]; zv[jj] = z[jj * q + r]; }
-        const double dit = DIx[e * IRP + T], ditf = DIx[e * IRP + TF];
-        const double dct = WIDE ? 0.0 : DC[e * D::LDC + T], dctf = WIDE ? 0.0 : DC[e * D::LDC + TF];
+        const double dit = DIx[e * IRP + T], ditf = DIx[e * IRP + TF], dct = DC[e * D::LDC + T], dctf = DC[e * D::LDC + TF];
         double sb = 0.0, sd = (own ? tE : tab.E[i]) * fi;
 #pragma unroll
         for (int jj = 0; jj < CS; jj++) {
@@ -669,12 +666,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         }
         DIx[e * IRP + T] = dit - sb;
         DIx[e * IRP + TF] = ditf + sb;
-        if constexpr (WIDE) {
-          DC[e] = sd;                                    // the time-column vector: dc_at() applies it
-        } else {
-          DC[e * D::LDC + T] = dct - sd;
-          DC[e * D::LDC + TF] = dctf + sd;
-        }
+        DC[e * D::LDC + T] = dct - sd;
+        DC[e * D::LDC + TF] = dctf + sd;
         if (a.FX) {                                      // defect value of row (i,r)  (LGLDefects.h:96-103)
           double fxv = h * sd;
 #pragma unroll
@@ -690,8 +683,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       TSG();   // time columns, FX
 
       // ---- D2: A fragments (DI_i^T tiles) for every tile row, reused by all three products
-      double av[WIDE ? 1 : D::TI][K][KS];               // (wide shapes read each fragment where it is used)
-      if constexpr (!WIDE) {
+      double av[D::TI][K][KS];
 #pragma unroll
       for (int ct = 0; ct < D::TI; ct++)
 #pragma unroll
@@ -699,7 +691,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
 #pragma unroll
           for (int kk = 0; kk < KS; kk++)
             av[ct][i][kk] = scr[avb[kk] + i * avs[kk] + 16 * ct];
-      }
 
       // Small shapes keep every accumulator tile until D6 (the stores then share a handful of lane-condition
       // branches); wide ones store each tile as it completes -- holding them all would spill.
@@ -720,7 +711,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       constexpr int NFRAG = (D::NTH + D::TI * D::TJ) * 4;
       double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr);
       const int* const kmap_seg = ASM ? a.kmap + seg * size_t(NFRAG) * 64 + lane : nullptr;
-      int hmap[(ASM && !WIDE) ? D::NTH : 1][4], jmap[(ASM && !WIDE) ? D::TI * D::TJ : 1][4];   // (wide: read at the store)
+      int hmap[ASM ? D::NTH : 1][4], jmap[ASM ? D::TI * D::TJ : 1][4];
       auto load_hmap = [&](int tix) {
         if constexpr (ASM) {
 #pragma unroll
@@ -741,7 +732,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         const int tix = rt * (rt + 1) / 2 + ct;
         if constexpr (ASM) {
 #pragma unroll
-          for (int v = 0; v < 4; v++) put_asm(WIDE ? kmap_seg[(tix * 4 + v) * 64] : hmap[WIDE ? 0 : tix][v], acc[v]);
+          for (int v = 0; v < 4; v++) put_asm(hmap[tix][v], acc[v]);
         } else if (rt > ct) {
           if (CFULL || 16 * rt + lr < IR) {
 #pragma unroll
@@ -756,15 +747,14 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       auto store_J_tile = [&](int jt, int ct, const d4& acc) {   // entry v: defect row 16jt + lr, column c
         if constexpr (ASM) {
 #pragma unroll
-          for (int v = 0; v < 4; v++)
-            put_asm(WIDE ? kmap_seg[((D::NTH + ct * D::TJ + jt) * 4 + v) * 64] : jmap[WIDE ? 0 : ct * D::TJ + jt][v], acc[v]);
+          for (int v = 0; v < 4; v++) put_asm(jmap[ct * D::TJ + jt][v], acc[v]);
         } else if (16 * jt + lr < OR) {
 #pragma unroll
           for (int v = 0; v < 4; v++)
             if (CFULL || ct + 1 < D::TI || 16 * ct + lk + 4 * v < IR) kkt_dst[jst[ct * D::TJ + jt][v]] = acc[v];
         }
       };
-      if constexpr (ASM && !WIDE) {                        // all of the segment's map entries, ahead of the products
+      if constexpr (ASM) {                                 // all of the segment's map entries, ahead of the products
         if constexpr (LEVEL >= 2) {
 #pragma unroll
           for (int tix = 0; tix < D::NTH; tix++) load_hmap(tix);
@@ -772,160 +762,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
 #pragma unroll
         for (int t = 0; t < D::TI * D::TJ; t++) load_jmap(t);
       }
-      if constexpr (WIDE) {
-        // ---- wide shapes: the same products with DI as the only resident tile.
-        const double* SD = DC;                           // sum_j D_ij f_j + E_i f^_i per defect row (time_columns)
-        auto avf = [&](int ct, int i, int kk) { return scr[avb[kk] + i * avs[kk] + 16 * ct]; };
-        // entry (jr, c) of the cardinal part of J -- what the DC tile of the narrow shapes holds (LGLDefects.h:467-500)
-        auto dc_at = [&](int jr, int c) -> double {
-          if (jr >= OR || c >= IR) return 0.0;
-          const int i = jr / n, r = jr - i * n;
-          double v = 0.0;
-          if (c < P0) {
-            const int j = c / q, cc = c - j * q;
-            v = (tab.D[i][j] * h) * S[cj_at(j, r, cc)];
-            if (cc == r) v += tab.C[i][j];
-            if (c == T) v -= SD[jr];
-            if (c == TF) v += SD[jr];
-          } else {
-            for (int jj = 0; jj < CS; jj++) v += (tab.D[i][jj] * h) * S[cj_at(jj, r, q + (c - P0))];
-          }
-          return v;
-        };
-        if constexpr (LEVEL >= 2) {
-          // HI = sum_i E_i g^_i^T DI_i (column N of the M product of the narrow shapes), then the rank-2 rows
-          for (int c = lane; c < IRP; c += 64) {
-            double v = 0.0;
-            for (int i = 0; i < K; i++) {
-              double sacc = 0.0;
-              for (int b = 0; b < N; b++)
-                sacc += S[D::w_Ig + i * N + b] * ((b < n) ? DIx[(i * n + b) * IRP + c] : DIc[(i * D::NCR + (b - n)) * IRP + c]);
-              v += tab.E[i] * sacc;
-            }
-            HI[c] = v;
-          }
-          wave_lds_sync();
-          const double ih = 1.0 / h;
-          for (int c = lane; c < IRP; c += 64) {
-            const int jn = c / q;
-            double v = HI[c] + S[(c < P0) ? D::w_Cg + jn * N + (c - jn * q) : ZERO] * ih;
-            if constexpr (p > 0) {
-              if (c >= P0 && c < IR) {
-                for (int j = 0; j < CS; j++) v += S[D::w_Cg + j * N + q + (c - P0)] * ih;
-              }
-            }
-            R2[IRP + c] = v;
-          }
-          wave_lds_sync();
-          double a2[D::TI], b2[D::TI];
-#pragma unroll
-          for (int t = 0; t < D::TI; t++) {
-            a2[t] = R2[(lk == 0 ? 0 : (lk == 1 ? IRP : 2 * IRP)) + 16 * t + lr];
-            b2[t] = R2[(lk == 0 ? IRP : (lk == 1 ? 0 : 2 * IRP)) + 16 * t + lr];
-          }
-#pragma unroll 1
-          for (int rt = 0; rt < D::TI; rt++) {
-            // rows [16rt, 16rt+16) of M^T = DI^T [hE_i H^_i]: tile-local row lk + 4v, column i*NP + acol
-#pragma unroll 1
-            for (int i = 0; i < K; i++) {
-              const double he = h * tab.E[i];
-              double afr[KS];
-#pragma unroll
-              for (int kk = 0; kk < KS; kk++) afr[kk] = avf(rt, i, kk);
-#pragma unroll
-              for (int mt = 0; mt < D::MT; mt++) {
-                const int acol = 16 * mt + lr;
-                d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < KS; kk++)
-                  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], S[bo[mt][kk] + i * bst[mt][kk]] * he, acc, 0, 0, 0);
-                if (acol < NP) {
-#pragma unroll
-                  for (int v = 0; v < 4; v++) Mt[(lk + 4 * v) * D::LDM + i * NP + acol] = (acol < N) ? acc[v] : 0.0;
-                }
-              }
-            }
-            wave_lds_sync();
-            double bm[K][KS];
-#pragma unroll
-            for (int i = 0; i < K; i++)
-#pragma unroll
-              for (int kk = 0; kk < KS; kk++) bm[i][kk] = Mt[lr * D::LDM + i * NP + 4 * kk + lk];
-            wave_lds_sync();                             // (the next tile row rewrites M^T)
-#pragma unroll 1
-            for (int ct = 0; ct <= rt; ct++) {
-              d4 acc = {0.0, 0.0, 0.0, 0.0};
-              const int tix = rt * (rt + 1) / 2 + ct;
-              if (tiles_share_node<D>(ct, rt)) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                  double val = S[cho[tix][v]];
-                  if constexpr (p > 0) {
-                    const int o = chp[tix][v];
-                    if (o >= 0) {
-                      for (int j = 0; j < CS; j++) val += S[D::w_CH + j * D::NZH + o];
-                    }
-                  }
-                  acc[v] = val;
-                }
-              }
-              double x2 = 0.0, y2 = 0.0;                 // a2[ct], b2[rt] without a dynamic register index
-#pragma unroll
-              for (int t = 0; t < D::TI; t++) { x2 = (t == ct) ? a2[t] : x2; y2 = (t == rt) ? b2[t] : y2; }
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, y2, acc, 0, 0, 0);
-#pragma unroll
-              for (int i = 0; i < K; i++)
-#pragma unroll
-                for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(avf(ct, i, kk), bm[i][kk], acc, 0, 0, 0);
-              if (kkt_dst) store_H_tile(rt, ct, acc);
-            }
-          }
-        } else if constexpr (!ASM) {                     // Jacobian-only kinds write the Hessian slots as zero
-          if (kkt_dst) {
-            const d4 zero = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-            for (int rt = 0; rt < D::TI; rt++)
-#pragma unroll 1
-              for (int ct = 0; ct <= rt; ct++) store_H_tile(rt, ct, zero);
-          }
-        }
-        // J^T tiles: cardinal part as the initial accumulator, interior part (hE_i J^_i DI_i)^T on top
-        if (kkt_dst) {
-#pragma unroll 1
-          for (int jt = 0; jt < D::TJ; jt++) {
-#pragma unroll 1
-            for (int ct = 0; ct < D::TI; ct++) {
-              d4 acc;
-#pragma unroll
-              for (int v = 0; v < 4; v++) acc[v] = dc_at(16 * jt + lr, 16 * ct + lk + 4 * v);
-#pragma unroll 1
-              for (int i = 0; i < K; i++) {
-                if (16 * jt + 15 < i * n || 16 * jt >= (i + 1) * n) continue;   // no defect row of interior i in this tile
-                const double he = h * tab.E[i];
-#pragma unroll
-                for (int kk = 0; kk < KS; kk++)
-                  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(avf(ct, i, kk), he * S[jo[jt][i][kk]], acc, 0, 0, 0);
-              }
-              store_J_tile(jt, ct, acc);
-            }
-          }
-        }
-        if (a.AGX) {                                     // g = J^T lam: interior part h * HI, cardinal part from the slot
-          for (int c = lane; c < IR; c += 64) {
-            double v = 0.0;
-            if constexpr (LEVEL >= 2) {
-              v = h * HI[c];
-            } else {
-              for (int i = 0; i < K; i++)
-                for (int b = 0; b < N; b++)
-                  v += ((h * tab.E[i]) * S[D::w_Ig + i * N + b]) *
-                       ((b < n) ? DIx[(i * n + b) * IRP + c] : DIc[(i * D::NCR + (b - n)) * IRP + c]);
-            }
-            for (int jr = 0; jr < OR; jr++) v += lam[jr] * dc_at(jr, c);
-            a.AGX[seg * IR + c] = v;
-          }
-        }
-      } else {
       // The product phases run at raised wave priority: the two waves of a SIMD otherwise walk through the same
       // phases nearly in step and the LDS / VALU / MFMA pipes take turns; any asymmetry in arbitration helps (measured
       // 0.5 us, the same for every priority assignment tried).
@@ -1219,7 +1055,6 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         }
         }
         }
-      }
       }
       wave_lds_sync();  // the next segment rewrites the DI / M / DC tiles
       TSG();   // D5 + D6: adjoint gradient, stores

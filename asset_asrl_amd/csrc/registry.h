@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "defect_kernels.h"
+#include "defect_wide.h"
 #include "func_kernels.h"
 #include "mesh_kernels.h"
 
@@ -79,9 +80,17 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   static const int env_b = std::getenv("ASSET_HIP_GRID_B") ? std::atoi(std::getenv("ASSET_HIP_GRID_B")) : 0;  // tuning only
   if (env_b > 0) grid_b = env_b < a.nseg ? env_b : a.nseg;
   static const bool skip_dense = std::getenv("ASSET_HIP_SKIP_DENSE") != nullptr;                               // tuning only
-#define ASSET_LAUNCH(LV, STG, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, LV, STG, false>), GRID, BYTES)
-#define ASSET_LAUNCH_ASM(LV, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, LV, 2, true>), GRID, BYTES)
-#define ASSET_LAUNCH_K(KERN, GRID, BYTES)                                                                         \
+#define ASSET_LAUNCH(LV, STG, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, LV, STG, false>), GRID, 64, BYTES)
+  // dense stage: single-wave workgroups, or (wide shapes, defect_wide.h) one four-wave workgroup per CU
+#define ASSET_LAUNCH_DENSE(LV, ASMV)                                                                              \
+  do {                                                                                                            \
+    if constexpr (D::WIDE) {                                                                                      \
+      ASSET_LAUNCH_K((lgl_wide_dense_kernel<Ode, SCH, BLOCKED, LV, ASMV>), (a.nseg < cus ? a.nseg : cus), 256, bytes_dense); \
+    } else {                                                                                                      \
+      ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, LV, 2, ASMV>), grid_b, 64, bytes_dense);            \
+    }                                                                                                             \
+  } while (0)
+#define ASSET_LAUNCH_K(KERN, GRID, BLOCK, BYTES)                                                                       \
   do {                                                                                                            \
     auto kern = KERN;                                                                                             \
     if (BYTES > 64 * 1024) {                                                                                      \
@@ -89,7 +98,7 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(BYTES));                 \
       if (e != hipSuccess) return e;                                                                              \
     }                                                                                                             \
-    hipLaunchKernelGGL(kern, dim3(GRID), dim3(64), BYTES, st, a);                                                 \
+    hipLaunchKernelGGL(kern, dim3(GRID), dim3(BLOCK), BYTES, st, a);                                                \
     hipError_t e2 = hipGetLastError();                                                                            \
     if (e2 != hipSuccess) return e2;                                                                              \
   } while (0)
@@ -98,18 +107,18 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
     case 1:
       ASSET_LAUNCH(1, 1, grid_a, bytes_ode);
       if (skip_dense) return hipSuccess;
-      if (a.kmap) ASSET_LAUNCH_ASM(1, grid_b, bytes_dense);   // KKT entries added straight into the solver's value array
-      else ASSET_LAUNCH(1, 2, grid_b, bytes_dense);
+      if (a.kmap) ASSET_LAUNCH_DENSE(1, true);   // KKT entries added straight into the solver's value array
+      else ASSET_LAUNCH_DENSE(1, false);
       return hipSuccess;
     case 2:
       ASSET_LAUNCH(2, 1, grid_a, bytes_ode);
       if (skip_dense) return hipSuccess;
-      if (a.kmap) ASSET_LAUNCH_ASM(2, grid_b, bytes_dense);
-      else ASSET_LAUNCH(2, 2, grid_b, bytes_dense);
+      if (a.kmap) ASSET_LAUNCH_DENSE(2, true);
+      else ASSET_LAUNCH_DENSE(2, false);
       return hipSuccess;
   }
 #undef ASSET_LAUNCH
-#undef ASSET_LAUNCH_ASM
+#undef ASSET_LAUNCH_DENSE
 #undef ASSET_LAUNCH_K
   return hipErrorInvalidValue;
 }
@@ -126,11 +135,13 @@ template <class Ode, int SCH, bool BLOCKED>
 size_t lgl_lane_bytes(int level) {
   using D = Dims<Ode, SCH, BLOCKED>;
   // bytes of the whole table: 64 word-interleaved records (defect_kernels.h: lane_setup_kernel)
-  return level >= 2 ? sizeof(LaneConsts<Ode, D, 2>) * 64 : (level == 1 ? sizeof(LaneConsts<Ode, D, 1>) * 64 : 0);
+  if constexpr (D::WIDE) return 0;   // the wide dense kernel computes its few lane constants itself
+  else return level >= 2 ? sizeof(LaneConsts<Ode, D, 2>) * 64 : (level == 1 ? sizeof(LaneConsts<Ode, D, 1>) * 64 : 0);
 }
 template <class Ode, int SCH, bool BLOCKED>
 hipError_t lgl_lane_setup(int level, void* out, hipStream_t st) {
-  if (level >= 2)
+  if constexpr (Dims<Ode, SCH, BLOCKED>::WIDE) return hipSuccess;
+  else if (level >= 2)
     hipLaunchKernelGGL((lane_setup_kernel<Ode, SCH, BLOCKED, 2>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));
   else
     hipLaunchKernelGGL((lane_setup_kernel<Ode, SCH, BLOCKED, 1>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));

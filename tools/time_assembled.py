@@ -26,6 +26,7 @@ def timeit(fn,n=100):
     e1.record(st); torch.cuda.synchronize(); return e0.elapsed_time(e1)/n*1e3
 tb=timeit(lambda: ev.eval_device(JAC_ADJGRAD_HESS,X,L,fx,agx,kkt,st))
 ta=timeit(lambda: ev.eval_assembled_device(JAC_ADJGRAD_HESS,X,L,fx,agx,vals,st))
-vals.zero_(); ev.eval_assembled_device(JAC_ADJGRAD_HESS,X,L,fx,agx,vals,st); torch.cuda.synchronize()
+vals.zero_(); torch.cuda.synchronize()   # (the clear runs on torch's stream, the evaluation on st)
+ev.eval_assembled_device(JAC_ADJGRAD_HESS,X,L,fx,agx,vals,st); torch.cuda.synchronize()
 _,_,ref=nlp.eval(JAC_ADJGRAD_HESS,w.X,w.L)
 print(f"{ode} {mode} nseg={nseg}: blocks {tb:.1f} us, assembled {ta:.1f} us; nnz {nlp.nnz} vs slots {nseg*ev.NKKT}; err {rel_err(vals.cpu().numpy(),ref):.1e}")
