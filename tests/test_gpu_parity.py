@@ -154,6 +154,52 @@ def test_gpu_full_size_properties(oracle):
     assert np.abs(fx3 - fx).max() < 1e-9
 
 
+def test_gpu_full_size_wide_shape_properties(oracle):
+    """BASELINE config 4 at full size: 100 000 segments of the 32-state ODE in LGL7 (17.5 GB of blocks, kept on the
+    device).  Oracle on a strided sample, J^T lam == adjoint gradient for every segment, symmetric use of the
+    Hessian slots is implied by the sample; the evaluation is bitwise repeatable."""
+    import torch
+    nseg = 100000
+    w = Workload("synthetic32", "LGL7", nseg)
+    ev = DefectEvaluator("synthetic32", "LGL7", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    dev = torch.device("cuda:0")
+    X, L = torch.from_numpy(w.X).to(dev), torch.from_numpy(w.L).to(dev)
+    fx = torch.zeros(nseg, w.OR, dtype=torch.float64, device=dev)
+    agx = torch.zeros(nseg, w.IR, dtype=torch.float64, device=dev)
+    kkt = torch.zeros(nseg, w.NKKT, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()                              # (torch fills on its stream, the evaluator runs on its own)
+    ev.eval_device(JAC_ADJGRAD_HESS, X, L, fx, agx, kkt)
+    torch.cuda.synchronize()
+    ref = (fx.clone(), agx.clone(), kkt[::1000].clone())
+    torch.cuda.synchronize()
+    ev.eval_device(JAC_ADJGRAD_HESS, X, L, fx, agx, kkt)
+    torch.cuda.synchronize()
+    assert torch.equal(fx, ref[0]) and torch.equal(agx, ref[1]) and torch.equal(kkt[::1000], ref[2])
+    # oracle on a strided sample
+    o = oracle.get_ode("synthetic32", 0)
+    for V in range(0, nseg, 9973):
+        rfx, rjx, rgx, rhx = oracle.defect_all(o, oracle.LGL7, w.X[w.vindex[V]], w.L[w.cindex[V]])
+        H, J = unpack_kkt_block(kkt[V].cpu().numpy(), w.IR, w.OR)
+        assert np.abs(fx[V].cpu().numpy() - rfx).max() / max(1.0, np.abs(w.X).max()) < TOL_RES
+        assert rel_err(J, rjx) < TOL_DER and rel_err(H, rhx) < TOL_DER and rel_err(agx[V].cpu().numpy(), rgx) < TOL_DER
+    # J^T lam identity on every segment, in chunks on the device
+    jslot = np.zeros((w.IR, w.OR), dtype=np.int64)        # slot of J(o, i) in a block: column i's run, after its H entries
+    k = 0
+    for i in range(w.IR):
+        k += w.IR - i
+        jslot[i] = np.arange(k, k + w.OR)
+        k += w.OR
+    jslot_d = torch.from_numpy(jslot.ravel()).to(dev)
+    lam = L[torch.from_numpy(w.cindex.astype(np.int64)).to(dev)]      # [nseg, OR]
+    worst = 0.0
+    for s0 in range(0, nseg, 10000):
+        JT = kkt[s0:s0 + 10000].index_select(1, jslot_d).view(-1, w.IR, w.OR)
+        g2 = torch.einsum("sio,so->si", JT, lam[s0:s0 + 10000])
+        worst = max(worst, float((g2 - agx[s0:s0 + 10000]).abs().max() / agx[s0:s0 + 10000].abs().max()))
+    assert worst < 1e-12
+    ev.close()
+
+
 def test_pinned_outputs_give_the_same_blocks(oracle):
     w = Workload("reentry", "LGL5", 300)
     ev = DefectEvaluator("reentry", "LGL5", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
