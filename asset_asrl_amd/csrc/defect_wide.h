@@ -19,6 +19,33 @@ namespace asset_hip {
 // LDS hand-off between the waves of the workgroup without draining the global stores (__syncthreads waits for them)
 __device__ inline void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Where accumulator entry (tile (jt, ct), v, lane) of J^T finds its cardinal part -- entry (jr, c) of DC,
+// C_ij [cc == r] + h D_ij dfdy_j[r][cc] -+ sd (LGLDefects.h:467-500): everything but the values depends only on the
+// lane, so it is decoded once per handle into one word per entry (the per-entry index arithmetic cost more VALU
+// instructions than the tile's MFMAs take cycles).  Word: bits 0-15 slot offset of dfdy_j[r][cc] (or the zero cell),
+// 16-17 node j, 18-19 interior i, 20 diagonal (cc == r), 21 column T, 22 column TF.  Stored [(jt*TI + ct)*4 + v][lane].
+template <class Ode, int SCH, bool BLOCKED>
+__global__ __launch_bounds__(64) void wide_setup_kernel(unsigned int* out) {
+  using D = Dims<Ode, SCH, BLOCKED>;
+  constexpr int n = D::n, q = D::q, N = D::N, P0 = D::P0, OR = D::OR, TI = D::TI, TJ = D::TJ;
+  constexpr int ZERO = D::WSLOTD + D::s_Z0;
+  static_assert(ZERO < 65536, "slot offsets are packed into 16 bits");
+  const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+  for (int jt = 0; jt < TJ; jt++)
+    for (int ct = 0; ct < TI; ct++)
+      for (int v = 0; v < 4; v++) {
+        const int jr = 16 * jt + lr, c = 16 * ct + lk + 4 * v;
+        unsigned int w = unsigned(ZERO);
+        if (jr < OR && c < P0) {
+          const int i = jr / n, r = jr - i * n, j = c / q, cc = c - j * q;
+          const int jp = Ode::JPOS[r * N + cc];
+          w = unsigned(jp >= 0 ? D::w_CJ + j * D::NZJ + jp : ZERO) | (unsigned(j) << 16) | (unsigned(i) << 18) |
+              (unsigned(cc == r) << 20) | (unsigned(c == D::T) << 21) | (unsigned(c == D::TF) << 22);
+        }
+        out[((jt * TI + ct) * 4 + v) * 64 + lane] = w;
+      }
+}
+
 template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM>
 __global__ __launch_bounds__(256) void lgl_wide_dense_kernel(EvalArgs a) {
   using D = Dims<Ode, SCH, BLOCKED>;
@@ -51,6 +78,7 @@ __global__ __launch_bounds__(256) void lgl_wide_dense_kernel(EvalArgs a) {
   double* DIc = scr + D::s_DIc;
   double* SD = scr + D::s_DC;                            // sum_j D_ij f_j + E_i f^_i per defect row
   double* WL = scr + D::s_WL;                            // sum_i D_ij lam_(i,r)
+  const unsigned int* dcinfo = static_cast<const unsigned int*>(a.lane_consts);   // wide_setup_kernel
   int* counter = reinterpret_cast<int*>(scr + D::s_CNT);
   double* LSD = scr + D::s_CNT + 1;
   double* R2 = scr + D::s_R2;
@@ -418,6 +446,13 @@ __global__ __launch_bounds__(256) void lgl_wide_dense_kernel(EvalArgs a) {
               bj[i][kk] = he * S[(jr < OR && ji == i && aa < N && jp >= 0) ? D::w_IJ + i * D::NZJ + jp : ZERO];
             }
           }
+          unsigned int dcw[CTC][4];                        // (read a chunk ahead of their use)
+#pragma unroll
+          for (int cq = 0; cq < CTC; cq++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+              dcw[cq][v] = (c0 + cq < TI) ? dcinfo[((jt * TI + c0 + cq) * 4 + v) * 64 + lane] : unsigned(ZERO);
+          const double sdv = SD[(jr < OR) ? jr : 0];
 #pragma unroll
           for (int cq = 0; cq < CTC; cq++) {
             const int ct = c0 + cq;
@@ -426,14 +461,12 @@ __global__ __launch_bounds__(256) void lgl_wide_dense_kernel(EvalArgs a) {
 #pragma unroll
             for (int v = 0; v < 4; v++) {
               const int c = 16 * ct + lk + 4 * v;
-              // entry (jr, c) of DC (LGLDefects.h:467-500), branch-free as above
-              const bool okn = (jr < OR && c < P0);
-              const int cn = (c < P0) ? c : P0 - 1, j = cn / q, cc = cn - j * q;
-              const int jp = jposL[jk * N + cc];
-              double val = (tab.D[ji][j] * h) * S[(okn && jp >= 0) ? D::w_CJ + j * D::NZJ + jp : ZERO];
-              const double cw = tab.C[ji][j], sdv = SD[(jr < OR) ? jr : 0];
-              val += (okn && cc == jk) ? cw : 0.0;
-              val += (jr < OR && c == TF) ? sdv : ((jr < OR && c == T) ? -sdv : 0.0);
+              // entry (jr, c) of DC (LGLDefects.h:467-500) from its pre-decoded word; branch-free
+              const unsigned int wd = dcw[cq][v];
+              const int j = (wd >> 16) & 3, i2 = (wd >> 18) & 3;
+              double val = (tab.D[i2][j] * h) * S[wd & 0xffffu];
+              val += (wd & (1u << 20)) ? tab.C[i2][j] : 0.0;
+              val += (wd & (1u << 22)) ? sdv : ((wd & (1u << 21)) ? -sdv : 0.0);
               if constexpr (p > 0) {
                 const bool okp = (jr < OR && c >= P0 && c < IR);
                 const int jq = jposL[jk * N + (okp ? q + (c - P0) : 0)];

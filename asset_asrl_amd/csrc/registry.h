@@ -135,13 +135,15 @@ template <class Ode, int SCH, bool BLOCKED>
 size_t lgl_lane_bytes(int level) {
   using D = Dims<Ode, SCH, BLOCKED>;
   // bytes of the whole table: 64 word-interleaved records (defect_kernels.h: lane_setup_kernel)
-  if constexpr (D::WIDE) return 0;   // the wide dense kernel computes its few lane constants itself
+  if constexpr (D::WIDE) return level >= 1 ? size_t(D::TJ) * D::TI * 4 * 64 * sizeof(unsigned int) : 0;   // defect_wide.h: wide_setup_kernel
   else return level >= 2 ? sizeof(LaneConsts<Ode, D, 2>) * 64 : (level == 1 ? sizeof(LaneConsts<Ode, D, 1>) * 64 : 0);
 }
 template <class Ode, int SCH, bool BLOCKED>
 hipError_t lgl_lane_setup(int level, void* out, hipStream_t st) {
-  if constexpr (Dims<Ode, SCH, BLOCKED>::WIDE) return hipSuccess;
-  else if (level >= 2)
+  if constexpr (Dims<Ode, SCH, BLOCKED>::WIDE) {
+    hipLaunchKernelGGL((wide_setup_kernel<Ode, SCH, BLOCKED>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));
+    return hipGetLastError();
+  } else if (level >= 2)
     hipLaunchKernelGGL((lane_setup_kernel<Ode, SCH, BLOCKED, 2>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));
   else
     hipLaunchKernelGGL((lane_setup_kernel<Ode, SCH, BLOCKED, 1>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));

@@ -1,13 +1,14 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh <tag>'): rocprofv3 kernel stats + PMC passes of bench.py.
+# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh <tag> [workload]'): rocprofv3 kernel stats + PMC passes of bench.py.
 # Outputs land in gpurun_out/<tag>/ ; tools/summarize_profiles.py turns them into profiles/<round>_*.{csv,json}.
 # --pmc passes are separate runs and never combined with any trace domain other than the counter collection itself.
 tag=${1:-prof}
+wl=${2:-reentry_lgl7_10k}     # bench workload name
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline"
+B="python3 $R/bench.py --no-cpu-baseline --workload $wl"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B --steps 200 --warmup 20 > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- $B --steps 20 --warmup 2 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- $B --steps 20 --warmup 2 > $O/pmc_write.log 2>&1

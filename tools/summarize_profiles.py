@@ -17,6 +17,8 @@ for name in ("kernel_stats", "domain_stats"):
 
 def stage_of(kernel_name):
     """lgl_defect_kernel<Ode, CS, BLOCKED, G, LEVEL, STAGE[, ASM]>: STAGE is the sixth template argument."""
+    if "lgl_wide_dense_kernel" in kernel_name:            # four-wave dense stage of the wide shapes (defect_wide.h)
+        return "dense_stage"
     args = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
     return "ode_stage" if len(args) >= 6 and args[5] == "1" else "dense_stage"
 
@@ -28,7 +30,7 @@ def counters(sub):
     if not os.path.exists(path):
         return {}
     for r in csv.DictReader(open(path)):
-        if "lgl_defect_kernel" not in r["Kernel_Name"]:
+        if "lgl_defect_kernel" not in r["Kernel_Name"] and "lgl_wide_dense_kernel" not in r["Kernel_Name"]:
             continue
         acc[stage_of(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
@@ -52,7 +54,7 @@ out = {
     "source": f"tools/collect_profiles.sh {tag} (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes "
               "of `python3 bench.py --no-cpu-baseline`)",
     "kernel_stats": [{"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])} for r in kernels
-                     if "defect_kernel" in r["Name"]],
+                     if "defect_kernel" in r["Name"] or "wide_dense_kernel" in r["Name"]],
     "per_kernel": per_kernel,
     "hbm": {"fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section)", "bytes_per_launch": total,
             "note": "one evaluation = ODE-stage launch + dense-stage launch; traffic above the algorithmic bytes is the "
