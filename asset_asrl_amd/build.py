@@ -24,7 +24,7 @@ LDS_BUDGET = 160 * 1024
 LDS_TARGET = 40 * 1024          # keep >= 4 single-wave workgroups per CU when the sizes allow it
 
 
-def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
+def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None, trap=False):
     """Mirror of ``Dims<>`` in csrc/defect_dims.h (sizes + LDS plan).  ``nzj`` / ``nzh`` are the structural
     non-zero counts of the ODE Jacobian / packed-lower Hessian (dense when omitted)."""
     n = xv
@@ -43,7 +43,7 @@ def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
     WSLOT = WSLOTD + cs * nsave
     LDM = K * NP + 1
     SCRATCH = max(K * n * IRP, IRP * LDM) + K * (NP - n) * IRP + ORP * (IRP + 4) + 4 * IRP + 2
-    if (70 + WSLOTD + SCRATCH) * 8 > LDS_BUDGET:     # Dims::WIDE (csrc/defect_wide.h): DI resident, M in registers, no DC tile
+    if (70 + WSLOTD + SCRATCH) * 8 > LDS_BUDGET or (IR >= 64 and not trap):     # Dims::WIDE (csrc/defect_wide.h): DI resident, M in registers, no DC tile
         SCRATCH = K * n * IRP + K * (N - n) * IRP + (ORP + cs * n + 2) + 4 * IRP + 2 \
             + (n * N + 3) // 4 + (NH + 3) // 4
     DENSE = WSLOTD + SCRATCH
@@ -59,14 +59,14 @@ def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
                 lds_bytes_ode=(70 + (LC * STG_LD if staged else 0)) * 8, lds_bytes_dense=(70 + DENSE) * 8)
 
 
-def pick_group(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None):
-    d = dims(xv, uv, pv, cs, blocked, nsave, nzj, nzh)
+def pick_group(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None, trap=False):
+    d = dims(xv, uv, pv, cs, blocked, nsave, nzj, nzh, trap)
     return 64 // cs if d["lds_bytes"]() <= LDS_BUDGET else 0
 
 
 def pick_trap_group(xv, uv, pv, blocked, nsave=0, nzj=None, nzh=None):
     """Trapezoidal runs through the LGL kernels as a two-node scheme (csrc/defect_dims.h, Dims::TRAP)."""
-    return pick_group(xv, uv, pv, 2, blocked, nsave, nzj, nzh)
+    return pick_group(xv, uv, pv, 2, blocked, nsave, nzj, nzh, trap=True)
 
 
 def _struct_name(name: str) -> str:

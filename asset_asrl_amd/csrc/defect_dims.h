@@ -107,8 +107,15 @@ struct Dims {
   // (defect_wide.h) that keeps only DI resident: every wave produces the 16 columns of M_i it is about to use in
   // registers, and the cardinal part of J is formed from the slot where it is used instead of being kept as a tile
   // (s_DC then holds the time-column vector, one entry per defect row, and the multiplier weights of J^T lam).
+  // Shapes from IR = 64 on take the same kernel even though they fit: holding their accumulators, fragments and lane
+  // constants in one wave spills (32 states in LGL5, 10 000 segments: 6.7 ms single-wave, 1.2 ms four-wave; LGL3:
+  // 0.64 -> 0.38 ms), while at IR = 40 (TwoBody-LGL7) the single-wave layout is still twice as fast.
+#ifndef ASSET_WIDE_MIN_IR
+#define ASSET_WIDE_MIN_IR 64
+#endif
   static constexpr bool WIDE =
-      size_t(TABSZ + WSLOTD + XM_ALL + K * (NP - n) * IRP + ORP * LDC + 4 * IRP + 2) * 8 > 160 * 1024;
+      size_t(TABSZ + WSLOTD + XM_ALL + K * (NP - n) * IRP + ORP * LDC + 4 * IRP + 2) * 8 > 160 * 1024 ||
+      (!TRAP && IR >= ASSET_WIDE_MIN_IR);
   static constexpr int WNW = 4;                        // waves of the wide dense kernel
   static constexpr int NCR = WIDE ? N - n : NP - n;    // constant rows per interior (wide: the k-padding rows read a zero row)
   static constexpr int s_DIx = 0;                      // [K][n][IRP]

@@ -46,8 +46,12 @@ __global__ __launch_bounds__(64) void wide_setup_kernel(unsigned int* out) {
       }
 }
 
+#ifndef ASSET_WIDE_WGS
+#define ASSET_WIDE_WGS 2              // workgroups per CU when two working sets fit its LDS (halves the register budget)
+#endif
 template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM>
-__global__ __launch_bounds__(256) void lgl_wide_dense_kernel(EvalArgs a) {
+__global__ __launch_bounds__(256, (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * ASSET_WIDE_WGS <= 160 * 1024 ? ASSET_WIDE_WGS : 1))
+void lgl_wide_dense_kernel(EvalArgs a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   static_assert(D::WIDE && LEVEL >= 1, "wide shapes, derivative kinds only (the value comes from the ODE stage)");
   constexpr int CS = D::CS, K = D::K, n = D::n, p = D::p, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0;

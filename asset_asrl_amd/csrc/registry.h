@@ -77,6 +77,8 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   int per_cu_b = int((160 * 1024) / bytes_dense);
   per_cu_b = per_cu_b < 1 ? 1 : (per_cu_b >= 8 ? 8 : (per_cu_b >= 6 ? 6 : (per_cu_b >= 4 ? 4 : per_cu_b)));
   int grid_b = a.nseg < cus * per_cu_b ? a.nseg : cus * per_cu_b;
+  const int wide_wgs = (bytes_dense * ASSET_WIDE_WGS <= 160 * 1024) ? ASSET_WIDE_WGS : 1;   // four-wave workgroups per CU (defect_wide.h)
+  (void)wide_wgs;
   static const int env_b = std::getenv("ASSET_HIP_GRID_B") ? std::atoi(std::getenv("ASSET_HIP_GRID_B")) : 0;  // tuning only
   if (env_b > 0) grid_b = env_b < a.nseg ? env_b : a.nseg;
   static const bool skip_dense = std::getenv("ASSET_HIP_SKIP_DENSE") != nullptr;                               // tuning only
@@ -85,7 +87,7 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
 #define ASSET_LAUNCH_DENSE(LV, ASMV)                                                                              \
   do {                                                                                                            \
     if constexpr (D::WIDE) {                                                                                      \
-      ASSET_LAUNCH_K((lgl_wide_dense_kernel<Ode, SCH, BLOCKED, LV, ASMV>), (a.nseg < cus ? a.nseg : cus), 256, bytes_dense); \
+      ASSET_LAUNCH_K((lgl_wide_dense_kernel<Ode, SCH, BLOCKED, LV, ASMV>), (a.nseg < cus * wide_wgs ? a.nseg : cus * wide_wgs), 256, bytes_dense); \
     } else {                                                                                                      \
       ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, LV, 2, ASMV>), grid_b, 64, bytes_dense);            \
     }                                                                                                             \
