@@ -58,7 +58,7 @@ void lgl_wide_dense_kernel(EvalArgs a) {
   constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, NP = D::NP, KS = D::KS, MT = (NP + 15) / 16;
   constexpr int TI = D::TI, TJ = D::TJ, NTH = D::NTH, NCR = D::NCR, ROWS = K * n;
   constexpr int ZERO = D::WSLOTD + D::s_Z0;              // slot-relative offset of a cell that holds 0.0
-  constexpr int CTC = 3;                                 // column tiles of one J work unit
+  constexpr int CTC = TI > 5 ? (TI + 1) / 2 : TI;        // column tiles of one J work unit
   constexpr int NJC = (TI + CTC - 1) / CTC;
   constexpr int NHU = (LEVEL >= 2 || !ASM) ? TI : 0;     // H work units (Jacobian-only block kinds store zeros there)
   constexpr int NUNITS = NHU + TJ * NJC;
@@ -433,35 +433,53 @@ void lgl_wide_dense_kernel(EvalArgs a) {
             }
           }
         } else {
-          // ------------------------------------------------ J^T tiles (jt, ct in one chunk): cardinal part from the slot
-          //                                                  as the initial accumulator, (hE_i J^_i DI_i)^T on top
+          // ------------------------------------------------ J^T tiles (jt, a chunk of column tiles):
+          //   (hE_i J^_i DI_i)^T by MFMA, then the cardinal part, formed from the slot, added to the accumulators.
+          //   Everything a tile needs is requested before the MFMAs of the tile ahead of it issue: one wave per SIMD
+          //   has no other wave to hide a latency behind.
           const int uj = u - NHU, jt = uj / NJC, c0 = (uj - jt * NJC) * CTC;
           const int jr = 16 * jt + lr;
           const int ji = (jr < OR) ? jr / n : 0, jk = (jr < OR) ? jr - ji * n : 0;
-          double bj[K][KS];
-#pragma unroll
-          for (int i = 0; i < K; i++) {
-            if (16 * jt + 15 < i * n || 16 * jt >= (i + 1) * n) continue;   // no defect row of interior i in this tile
-            const double he = h * tab.E[i];
-#pragma unroll
-            for (int kk = 0; kk < KS; kk++) {
-              const int aa = 4 * kk + lk;
-              const int jp = jposL[jk * N + ((aa < N) ? aa : N - 1)];
-              bj[i][kk] = he * S[(jr < OR && ji == i && aa < N && jp >= 0) ? D::w_IJ + i * D::NZJ + jp : ZERO];
-            }
-          }
-          unsigned int dcw[CTC][4];                        // (read a chunk ahead of their use)
+          unsigned int dcw[CTC][4];
 #pragma unroll
           for (int cq = 0; cq < CTC; cq++)
 #pragma unroll
             for (int v = 0; v < 4; v++)
               dcw[cq][v] = (c0 + cq < TI) ? dcinfo[((jt * TI + c0 + cq) * 4 + v) * 64 + lane] : unsigned(ZERO);
           const double sdv = SD[(jr < OR) ? jr : 0];
+          d4 acc[CTC];
+#pragma unroll
+          for (int cq = 0; cq < CTC; cq++) acc[cq] = d4{0.0, 0.0, 0.0, 0.0};
+          const int i_lo = (16 * jt) / n, i_hi = min(K - 1, (16 * jt + 15) / n);   // interiors with defect rows in this tile
+#pragma unroll 1
+          for (int i = i_lo; i <= i_hi; i++) {
+            const double he = h * tab.E[i];
+            double bj[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) {
+              const int aa = 4 * kk + lk;
+              const int jp = jposL[jk * N + ((aa < N) ? aa : N - 1)];
+              bj[kk] = he * S[(jr < OR && ji == i && aa < N && jp >= 0) ? D::w_IJ + i * D::NZJ + jp : ZERO];
+            }
+            double af[2][KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) af[0][kk] = avf(c0, i, kk);
+#pragma unroll
+            for (int cq = 0; cq < CTC; cq++) {
+              if (c0 + cq >= TI) break;
+              if (cq + 1 < CTC && c0 + cq + 1 < TI) {
+#pragma unroll
+                for (int kk = 0; kk < KS; kk++) af[(cq + 1) & 1][kk] = avf(c0 + cq + 1, i, kk);
+              }
+#pragma unroll
+              for (int kk = 0; kk < KS; kk++)
+                acc[cq] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cq & 1][kk], bj[kk], acc[cq], 0, 0, 0);
+            }
+          }
 #pragma unroll
           for (int cq = 0; cq < CTC; cq++) {
             const int ct = c0 + cq;
             if (ct >= TI) break;
-            d4 acc;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
               const int c = 16 * ct + lk + 4 * v;
@@ -477,21 +495,7 @@ void lgl_wide_dense_kernel(EvalArgs a) {
 #pragma unroll
                 for (int jj = 0; jj < CS; jj++) val += (tab.D[ji][jj] * h) * S[(okp && jq >= 0) ? D::w_CJ + jj * D::NZJ + jq : ZERO];
               }
-              acc[v] = val;
-            }
-#pragma unroll
-            for (int i = 0; i < K; i++) {
-              if (16 * jt + 15 < i * n || 16 * jt >= (i + 1) * n) continue;
-              double af[KS];
-#pragma unroll
-              for (int kk = 0; kk < KS; kk++) af[kk] = avf(ct, i, kk);
-#pragma unroll
-              for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bj[i][kk], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-              const int c = 16 * ct + lk + 4 * v;
-              put((NTH + ct * TJ + jt) * 4 + v, (c < IR && jr < OR) ? col_start(c) + (IR - c) + jr : -1, acc[v]);
+              put((NTH + ct * TJ + jt) * 4 + v, (c < IR && jr < OR) ? col_start(c) + (IR - c) + jr : -1, acc[cq][v] + val);
             }
           }
         }
