@@ -102,6 +102,64 @@ class PhaseIndexer:
         assert V.shape == (D, ir)
         return np.ascontiguousarray(V, dtype=np.int32), np.ascontiguousarray(Cx, dtype=np.int32)
 
+    # ---- region tables for plain functions -------------------------------------------------
+    REGIONS = ("Front", "Back", "FrontandBack", "BackandFront", "Path", "InnerPath", "NodalPath", "PairWisePath",
+               "FrontNodalBackPath", "Params", "ODEParams", "StaticParams")
+
+    def make_Vindex_Cindex(self, region: str, xtuv=(), odepv=(), statpv=(), orows: int = 0, next_cloc: int | None = None):
+        """Index tables of a function applied over a phase region (PhaseIndexer.cpp:132-360, PhaseRegionFlags of
+        OptimalControlFlags.h:7-25): one application per column of the reference's tables = one row here.  Input of
+        an application: the chosen state/time/control variables ``xtuv`` at the region's state(s), then the chosen
+        ODE parameters and static parameters.  Returns ``(Vindex[napp, IR], Cindex[napp, orows], next_cloc)``; constraint
+        rows are numbered consecutively from ``next_cloc`` (default: after the phase's own rows so far).  A function
+        of controls only in a BlockConstant phase is applied once per defect (PhaseIndexer.cpp:153-157, 231-243)."""
+        xtuv = [int(v) for v in xtuv]
+        odepv = [int(v) for v in odepv]
+        statpv = [int(v) for v in statpv]
+        if any(v < 0 or v >= self.XtUVars() for v in xtuv) or any(v < 0 or v >= self.pv for v in odepv) or \
+                any(v < 0 or v >= self.spv for v in statpv):
+            raise ValueError("variable index outside the phase's dimensions")
+        cs, D, S = self.DefectCardinalStates, self.numDefects, self.numStates
+        only_u = bool(xtuv) and all(v >= self.XtVars() for v in xtuv) and self.BlockedControls
+        o = self.var_offset
+        par = [o + self.ODEParamLoc0 + v for v in odepv] + [o + self.StaticParamLoc0 + v for v in statpv]
+
+        def at(state):
+            return [self.getXTUVarLoc(v, state) for v in xtuv]
+        first, last = at(0), at(S - 1)
+        nodal = [i * (cs - 1) for i in range(D + 1)]
+        if region in ("Params", "ODEParams", "StaticParams"):
+            rows = [par]
+        elif region == "Front":
+            rows = [first + par]
+        elif region == "Back":
+            rows = [last + par]
+        elif region == "FrontandBack":
+            rows = [first + last + par]
+        elif region == "BackandFront":
+            rows = [last + first + par]
+        elif region == "Path":
+            states = nodal[:D] if only_u else range(S)
+            rows = [at(k) + par for k in states]
+        elif region == "InnerPath":
+            states = nodal[1:D - 1] if only_u else range(1, S - 1)
+            rows = [at(k) + par for k in states]
+        elif region == "NodalPath":
+            states = nodal[:D] if only_u else nodal
+            rows = [at(k) + par for k in states]
+        elif region == "PairWisePath":
+            pairs = list(zip(nodal[:D - 1], nodal[1:D])) if only_u else [(k, k + 1) for k in range(S - 1)]
+            rows = [at(a) + at(b) + par for a, b in pairs]
+        elif region == "FrontNodalBackPath":
+            states = nodal[1:D - 1] if only_u else nodal[1:D]
+            rows = [first + at(k) + last + par for k in states]
+        else:
+            raise ValueError(f"unknown phase region {region!r}; one of {self.REGIONS} (DefectPath: make_defect_Vindex_Cindex)")
+        V = np.asarray(rows, dtype=np.int32).reshape(len(rows), -1)
+        c0 = self.con_offset + self.numPhaseEqCons if next_cloc is None else int(next_cloc)
+        Cx = (c0 + np.arange(len(rows) * orows, dtype=np.int64)).reshape(len(rows), orows).astype(np.int32)
+        return np.ascontiguousarray(V), np.ascontiguousarray(Cx), c0 + len(rows) * orows
+
     # ---- trajectory <-> solver vector ------------------------------------------------------
     def makeSolverInput(self, ActiveTraj: Sequence[np.ndarray], ActiveStaticParams=None) -> np.ndarray:
         T = np.asarray(ActiveTraj, dtype=float)

@@ -95,6 +95,10 @@ class Phase:
         self.AutoScaling = False
         self.XtUPUnits = np.ones(ode.XtUPVars())
         self._ode_scaled = None
+        self._eq_funcs = []       # (region, func, xtuv, opv, spv) -- addEqualCon
+        self._iq_funcs = []       # addInequalCon
+        self._eq_evs = []
+        self._iq_evs = []
 
     # ---- configuration ---------------------------------------------------------------------
     def switchTranscriptionMode(self, mode: str):
@@ -170,6 +174,86 @@ class Phase:
     def returnTraj(self):
         return [row.copy() for row in self.ActiveTraj]
 
+    # ---- user constraints over phase regions (ODEPhaseBase.h addEqualCon / addInequalCon) -----------------
+    def _add_func(self, store, region, func, xtuv, opv, spv):
+        if region not in PhaseIndexer.REGIONS:
+            raise ValueError(f"unknown phase region {region!r}")
+        xtuv, opv, spv = [int(v) for v in xtuv], [int(v) for v in opv], [int(v) for v in spv]
+        states = {"FrontandBack": 2, "BackandFront": 2, "PairWisePath": 2, "FrontNodalBackPath": 3,
+                  "Params": 0, "ODEParams": 0, "StaticParams": 0}.get(region, 1)
+        need = states * len(xtuv) + len(opv) + len(spv)
+        if func.IRows() != need:
+            raise ValueError(f"function takes {func.IRows()} inputs, the region and variable lists supply {need}")
+        store.append((region, func, xtuv, opv, spv))
+        self._ev = None
+        return len(store) - 1
+
+    def addEqualCon(self, region: str, func, XtUVars=(), OPVars=(), SPVars=()) -> int:
+        """``func(X[region variables]) = 0`` at every application of the region (``"Path"``: every state of the
+        mesh, ``"Front"``, ``"Back"``, ``"PairWisePath"`` ...; PhaseIndexer.make_Vindex_Cindex).  The function is a
+        vf expression; it is differentiated symbolically, compiled for the device on first use and evaluated for all
+        applications at once through the same handle API as the defects (transcription id 0).  Returns its index."""
+        return self._add_func(self._eq_funcs, region, func, XtUVars, OPVars, SPVars)
+
+    def addInequalCon(self, region: str, func, XtUVars=(), OPVars=(), SPVars=()) -> int:
+        """``func(...) <= 0`` over a region; evaluated like an equality, its rows are numbered in the phase's
+        inequality space (PhaseIndexer.cpp:78-92)."""
+        return self._add_func(self._iq_funcs, region, func, XtUVars, OPVars, SPVars)
+
+    def removeEqualCon(self, index: int):
+        del self._eq_funcs[index]
+        self._ev = None
+
+    def removeInequalCon(self, index: int):
+        del self._iq_funcs[index]
+        self._ev = None
+
+    def _scaled_func(self, region, func, xtuv, opv):
+        """With AutoScaling the solver's variables are in scaled units: compose the function with the input units
+        (the reference wraps user functions in IOScaled the same way; outputs keep their scale)."""
+        if not self.AutoScaling:
+            return func
+        from .vf import IOScaled
+        xtu = self.ode.XtUVars()
+        ux = [self.XtUPUnits[v] for v in xtuv]
+        states = (func.IRows() - len(opv)) // max(1, len(xtuv)) if xtuv else 0
+        units = ux * states + [self.XtUPUnits[xtu + v] for v in opv]
+        units += [1.0] * (func.IRows() - len(units))
+        return IOScaled(func, units, np.ones(func.ORows()))
+
+    def _make_function_evaluators(self, ix):
+        from .pathfuncs import FunctionEvaluator
+        self._eq_evs, self._iq_evs = [], []
+        next_eq, next_iq = ix.con_offset + ix.numPhaseEqCons, 0
+        todo = []
+        for store, is_eq in ((self._eq_funcs, True), (self._iq_funcs, False)):
+            for k, (region, func, xtuv, opv, spv) in enumerate(store):
+                f = self._scaled_func(region, func, xtuv, opv)
+                V, Cx, nxt = ix.make_Vindex_Cindex(region, xtuv, opv, spv, f.ORows(), next_eq if is_eq else next_iq)
+                if is_eq:
+                    next_eq = nxt
+                else:
+                    next_iq = nxt
+                todo.append((is_eq, f, f"{'eq' if is_eq else 'iq'}{k}_{region.lower()}", V, Cx))
+        # every equality evaluator (the defects included) takes the phase's whole equality multiplier vector
+        self.numPhaseEqCons, self.numPhaseIqCons = next_eq - ix.con_offset, next_iq
+        for is_eq, f, name, V, Cx in todo:
+            ev = FunctionEvaluator(f, name, V, Cx, ix.numPhaseVars, next_eq if is_eq else next_iq, self.device)
+            (self._eq_evs if is_eq else self._iq_evs).append(ev)
+
+    @property
+    def equality_evaluators(self):
+        """Device evaluators of the functions added with addEqualCon, in order (after ``evaluator``, the defects)."""
+        if self._ev is None:
+            self.transcribe()
+        return list(self._eq_evs)
+
+    @property
+    def inequality_evaluators(self):
+        if self._ev is None:
+            self.transcribe()
+        return list(self._iq_evs)
+
     # ---- transcription ------------------------------------------------------------------------
     def transcribe(self):
         if self.ActiveTraj is None:
@@ -181,8 +265,9 @@ class Phase:
         ix.begin_indexing(0, 0)
         V, Cx = ix.make_defect_Vindex_Cindex()
         self._indexer = ix
+        self._make_function_evaluators(ix)
         self._ev = DefectEvaluator(name, self.TranscriptionMode, self._blocked(), V, Cx, ix.numPhaseVars,
-                                   ix.numPhaseEqCons, self.device)
+                                   self.numPhaseEqCons, self.device)
         return self
 
     def solver_input(self) -> np.ndarray:

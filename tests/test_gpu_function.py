@@ -96,3 +96,46 @@ def test_lgl_mesh_spacing_closed_form():
                 Hfd[:, c] += sgn * (Jp.T @ L[2 * V:2 * V + 2]) / (2 * eps)
         assert rel_err(H, Hfd) < 1e-6
     ev.close()
+
+
+def test_phase_add_constraints_evaluate_over_their_regions(oracle):
+    """Phase.addEqualCon / addInequalCon (ODEPhaseBase.h; region tables of PhaseIndexer.cpp:132-360): a path equality
+    at every state and a pair-wise inequality, evaluated on the device through the phase, against the oracle's NLP
+    restatement running the same index tables."""
+    from asset_asrl_amd.ode import ShuttleReentry
+    from helpers import Workload
+    w = Workload("reentry", "LGL5", 23)
+    ph = ShuttleReentry().phase("LGL5", w.traj, 23)
+    k_eq = ph.addEqualCon("Path", _pathcon(), [0, 1, 2, 5, 6, 7])            # x0, x1, x2, t, u0, u1 of every state
+    a = vf.Arguments(4)
+    k_iq = ph.addInequalCon("PairWisePath", vf.stack([a[0] * a[2] - a[1] * a[3] - 0.5]), [3, 4])
+    assert (k_eq, k_iq) == (0, 0)
+    ph.transcribe()
+    ix = ph._indexer
+    S = ix.numStates
+    (eq,), (iq,) = ph.equality_evaluators, ph.inequality_evaluators
+    assert eq.nseg == S and iq.nseg == S - 1
+    assert ph.numPhaseEqCons == ix.numPhaseEqCons + 2 * S and ph.numPhaseIqCons == S - 1
+    assert ph.evaluator.n_equal == ph.numPhaseEqCons                      # one multiplier vector for all equalities
+    X = ph.solver_input()
+    rng = np.random.default_rng(5)
+    L = 10.0 * rng.uniform(-1, 1, ph.numPhaseEqCons)
+    V, Cx, _ = ix.make_Vindex_Cindex("Path", [0, 1, 2, 5, 6, 7], orows=2)
+    nlp = oracle.Nlp(oracle.get_ode("pathcon", 0), oracle.MODES["Function"], False, V, Cx, X.size, L.size, 2)
+    for what in (JAC_ADJGRAD_HESS, CON):
+        rfx, ragx, rkkt = nlp.eval_blocks(what, X, L)
+        fx, agx, kkt = eq.eval(what, X, L if what == JAC_ADJGRAD_HESS else None)
+        assert np.abs(fx - rfx).max() < 1e-10
+        if kkt is not None:
+            assert rel_err(agx, ragx) < 1e-8 and rel_err(kkt, rkkt) < 1e-8
+    # the inequality: closed form
+    Li = rng.uniform(-1, 1, ph.numPhaseIqCons)
+    fx, agx, kkt = iq.eval(JAC_ADJGRAD_HESS, X, Li)
+    xs = X[: S * 8].reshape(S, 8)
+    np.testing.assert_allclose(fx[:, 0], xs[:-1, 3] * xs[1:, 3] - xs[:-1, 4] * xs[1:, 4] - 0.5, atol=1e-13)
+    H, J = unpack_kkt_block(kkt[4], 4, 1)
+    np.testing.assert_allclose(J[0], [xs[5, 3], -xs[5, 4], xs[4, 3], -xs[4, 4]], atol=1e-13)
+    np.testing.assert_allclose(H, Li[4] * np.array([[0, 0, 1, 0], [0, 0, 0, -1], [1, 0, 0, 0], [0, -1, 0, 0.0]]), atol=1e-13)
+    # the defects still evaluate with the longer multiplier vector
+    fxd, _, _ = ph.evaluator.eval(CON, X)
+    assert fxd.shape == (23, ph.evaluator.OR)
