@@ -145,8 +145,17 @@ struct Dims {
   static constexpr bool STAGED = (16 * STG_LD * 8 <= ASSET_LC_BUDGET);
   static constexpr int LC = !STAGED ? 64
                             : (64 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 64 : ((32 * STG_LD * 8 <= ASSET_LC_BUDGET) ? 32 : 16);
-  // LDS of the two launches: [weight tables | staging rows] and [weight tables | slot buffer | dense scratch]
-  static constexpr size_t lds_bytes_ode() { return size_t(TABSZ + (STAGED ? LC * STG_LD : 0)) * 8; }
+  // ODE-stage hand-offs: what a later phase of the stage reads of an earlier one (z, lam, f_j, g^_i, the saved
+  // transcendentals) is mirrored in LDS, one short slot per segment of the group, so that the phases are separated by
+  // an LDS wait instead of a drain of the wave's global stores plus a round trip to L2 (the workspace copy is still
+  // written: the dense stage reads it).  Only when it fits beside the staging rows at four workgroups per CU.
+  static constexpr int GM = 64 / CS;                   // segments per group of the ODE stage (build.py: pick_group)
+  static constexpr int m_z = 0, m_lam = IR, m_Cf = m_lam + OR, m_Ig = m_Cf + CS * n, m_SV = m_Ig + K * N;
+  static constexpr int MSLOT = (m_SV + CS * Ode::NSAVE) | 1;
+  // (not for Trapezoidal: its interior sections are never written and must read as the zeros the workspace is created with)
+  static constexpr bool MIRROR = !TRAP && STAGED && size_t(TABSZ + LC * STG_LD + GM * MSLOT) * 8 <= 40 * 1024;
+  // LDS of the two launches: [weight tables | staging rows | mirror] and [weight tables | slot buffer | dense scratch]
+  static constexpr size_t lds_bytes_ode() { return size_t(TABSZ + (STAGED ? LC * STG_LD : 0) + (MIRROR ? GM * MSLOT : 0)) * 8; }
   static constexpr size_t lds_bytes_dense() { return size_t(TABSZ + DENSE) * 8; }
   static constexpr size_t lds_bytes() { return lds_bytes_ode() > lds_bytes_dense() ? lds_bytes_ode() : lds_bytes_dense(); }
 };
@@ -154,12 +163,12 @@ struct Dims {
 using d4 = __attribute__((ext_vector_type(4))) double;
 
 // ---------------------------------------------------------------------------------------------- ODE accessors
-template <class D>
+template <class D, class ZP = const double*>
 struct CardIn {  // y = [z_j (q), P (p)] read from the slot's copy of z; lam = adjoint weights in registers
-  const double* z;
+  ZP z;
   const double* w;
   int j;
-  const double* sv = nullptr;  // saved transcendental values of f at this node (fjgh_load)
+  ZP sv = nullptr;             // saved transcendental values of f at this node (fjgh_load)
   __device__ double y(int i) const { return i < D::q ? z[j * D::q + i] : z[D::P0 + (i - D::q)]; }
   __device__ double lam(int k) const { return w[k]; }
   __device__ double saved(int k) const { return sv[k]; }
@@ -174,17 +183,23 @@ struct RegIn {
 // LDS-address-space pointer: stores through it are ds_write (tracked by lgkmcnt only), never flat
 typedef __attribute__((address_space(3))) double lds_double;
 
-template <class D, bool ACCG = false>
+template <class D, bool ACCG = false, bool MIR = false, bool MF = false, bool MG = false>
 struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H non-zeros -> this lane's LDS staging row [J | H]
   using JP = std::conditional_t<D::STAGED, lds_double*, double*>;
+  using SP = std::conditional_t<MIR, lds_double*, double*>;     // MIR: what a later phase reads goes to the LDS mirror
   double* f_;
   double* g_;
   JP J_;
   JP H_;
-  double* sv_ = nullptr;
+  SP sv_ = nullptr;
+  lds_double* f2_ = nullptr;                           // mirror copy of f (MF) / of g (MG)
+  lds_double* g2_ = nullptr;
   const double* lamv_ = nullptr;                       // ACCG: multipliers of this point's defect rows ...
   double gacc_[ACCG ? D::N : 1];                       // ... and g^ = J^^T lam accumulated while J is emitted (fj has no g)
-  __device__ void f(int k, double v) { f_[k] = v; }
+  __device__ void f(int k, double v) {
+    f_[k] = v;
+    if constexpr (MF) f2_[k] = v;
+  }
   __device__ void J(int k, int i, double v) {          // (k, i) are literals in the generated bodies: the lookup folds
     const int c = D::ode_t::JPOS[k * D::N + i];
     if (c >= 0) {
@@ -192,7 +207,10 @@ struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H non-zeros -
       if constexpr (ACCG) gacc_[i] += lamv_[k] * v;
     }
   }
-  __device__ void g(int i, double v) { g_[i] = v; }
+  __device__ void g(int i, double v) {
+    g_[i] = v;
+    if constexpr (MG) g2_[i] = v;
+  }
   __device__ void H(int i, int j, double v) {
     const int c = D::ode_t::HPOS[i * (i + 1) / 2 + j];
     if (c >= 0) H_[c] = v;

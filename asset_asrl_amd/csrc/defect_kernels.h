@@ -34,11 +34,26 @@ namespace asset_hip {
 // ---------------------------------------------------------------------------------------------- ODE phases
 // Kept out of line: each is a long straight-line generated body, and separating their register allocation from
 // the dense phase keeps the latter's accumulators and fragments in registers.
-template <class Ode, class D, int LEVEL>
-__device__ __attribute__((noinline)) void interior_eval(double* S, int i, const LglTab* tabp, lds_double* row) {
+// Where a phase of the ODE stage reads what an earlier phase left: the segment's workspace slot, or (MIR) its short
+// LDS mirror (defect_dims.h: Dims::MIRROR).
+template <class D, bool MIR>
+struct PhaseIn {
+  using P = std::conditional_t<MIR, const lds_double*, const double*>;
+  P z, lam, Cf, Ig, SV;
+  __device__ PhaseIn(const double* S, const lds_double* M)
+      : z(pick(S + D::w_z, M + D::m_z)), lam(pick(S + D::w_lam, M + D::m_lam)), Cf(pick(S + D::w_Cf, M + D::m_Cf)),
+        Ig(pick(S + D::w_Ig, M + D::m_Ig)), SV(pick(S + D::w_SV, M + D::m_SV)) {}
+  __device__ static P pick(const double* s, const lds_double* m) {
+    if constexpr (MIR) { (void)s; return m; } else { (void)m; return s; }
+  }
+};
+
+template <class Ode, class D, int LEVEL, bool MIR>
+__device__ __attribute__((noinline)) void interior_eval(double* S, lds_double* M, int i, const LglTab* tabp, lds_double* row) {
   constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
-  const double* z = S + D::w_z;
+  const PhaseIn<D, MIR> pin(S, M);
+  const auto z = pin.z;
   const double h = z[D::TF] - z[T];
   double y[N];
   double li[n > 0 ? n : 1];
@@ -46,7 +61,7 @@ __device__ __attribute__((noinline)) void interior_eval(double* S, int i, const 
   for (int k = 0; k < n; k++) {
     double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * S[D::w_Cf + j * n + k]);
+    for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * pin.Cf[j * n + k]);
     y[k] = acc;
   }
   y[T] = z[T] + h * tab.s[i];
@@ -60,10 +75,13 @@ __device__ __attribute__((noinline)) void interior_eval(double* S, int i, const 
 #pragma unroll
   for (int k = 0; k < p; k++) y[q + k] = z[D::P0 + k];
 #pragma unroll
-  for (int k = 0; k < n; k++) li[k] = (LEVEL >= 1) ? S[D::w_lam + i * n + k] : 0.0;
+  for (int k = 0; k < n; k++) li[k] = (LEVEL >= 1) ? pin.lam[i * n + k] : 0.0;
   RegIn<D> in{y, li};
-  OdeOutStaged<D, LEVEL == 1> out{S + D::w_If + i * n, S + D::w_Ig + i * N, stage_or<D>(row, S + D::w_IJ + i * D::NZJ),
-                                  stage_or<D>(row + D::NZJ, S + D::w_IH + i * D::NZH)};
+  // g^_i feeds the adjoint weights of P3 (mirror copy); f^_i is only read by the dense stage
+  OdeOutStaged<D, LEVEL == 1, false, false, MIR && LEVEL >= 2> out{S + D::w_If + i * n, S + D::w_Ig + i * N,
+                                                                   stage_or<D>(row, S + D::w_IJ + i * D::NZJ),
+                                                                   stage_or<D>(row + D::NZJ, S + D::w_IH + i * D::NZH)};
+  if constexpr (MIR && LEVEL >= 2) out.g2_ = M + D::m_Ig + i * N;
   (void)K;
   if constexpr (LEVEL == 0) Ode::f(in, out);
   else if constexpr (LEVEL == 1) {
@@ -74,11 +92,12 @@ __device__ __attribute__((noinline)) void interior_eval(double* S, int i, const 
   } else Ode::fjgh(in, out);
 }
 
-template <class Ode, class D>
-__device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const LglTab* tabp, lds_double* row) {
+template <class Ode, class D, bool MIR>
+__device__ __attribute__((noinline)) void cardinal_eval2(double* S, lds_double* M, int j, const LglTab* tabp, lds_double* row) {
   constexpr int K = D::K, n = D::n, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
-  const double* z = S + D::w_z;
+  const PhaseIn<D, MIR> pin(S, M);
+  const auto z = pin.z;
   const double h = z[D::TF] - z[T];
   double w[n > 0 ? n : 1];
 #pragma unroll
@@ -86,12 +105,12 @@ __device__ __attribute__((noinline)) void cardinal_eval2(double* S, int j, const
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < K; i++) {
-      acc += S[D::w_Ig + i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
-      acc += S[D::w_lam + i * n + k] * (tab.D[i][j] * h);
+      acc += pin.Ig[i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
+      acc += pin.lam[i * n + k] * (tab.D[i][j] * h);
     }
     w[k] = acc;
   }
-  CardIn<D> in{z, w, j, S + D::w_SV + j * Ode::NSAVE};
+  CardIn<D, typename PhaseIn<D, MIR>::P> in{z, w, j, pin.SV + j * Ode::NSAVE};
   OdeOutStaged<D> out{S + D::w_Cf + j * n, S + D::w_Cg + j * N, stage_or<D>(row, S + D::w_CJ + j * D::NZJ),
                       stage_or<D>(row + D::NZJ, S + D::w_CH + j * D::NZH)};
   Ode::fjgh_load(in, out);   // the transcendental sub-expressions of f at this node were stored by P1
@@ -107,14 +126,24 @@ struct GatherIn {  // y = X[Vindex(node j, component i)]: the first ODE phase re
   __device__ double saved(int) const { return 0.0; }
 };
 
-template <class Ode, class D, int LEVEL>
-__device__ __attribute__((noinline)) void cardinal_eval1(double* S, int j, lds_double* row, const double* X, const int* vi) {
-  GatherIn<D> in{X, vi, j};
-  OdeOutStaged<D> out{S + D::w_Cf + j * D::n, nullptr, stage_or<D>(row, S + D::w_CJ + j * D::NZJ), nullptr,
-                      S + D::w_SV + j * Ode::NSAVE};
+template <class Ode, class D, int LEVEL, bool MIR, class In>
+__device__ inline void cardinal_eval1_body(const In& in, double* S, lds_double* M, int j, lds_double* row) {
+  OdeOutStaged<D, false, MIR, MIR> out{S + D::w_Cf + j * D::n, nullptr, stage_or<D>(row, S + D::w_CJ + j * D::NZJ), nullptr};
+  if constexpr (MIR) {                                   // f_j: workspace (dense stage) and mirror (P2); saved values: mirror only
+    out.f2_ = M + D::m_Cf + j * D::n;
+    out.sv_ = M + D::m_SV + j * Ode::NSAVE;
+  } else {
+    out.sv_ = S + D::w_SV + j * Ode::NSAVE;
+  }
   if constexpr (LEVEL == 1) Ode::fj(in, out);
   else if constexpr (LEVEL == 2) Ode::f_save(in, out);
   else Ode::f(in, out);
+}
+
+template <class Ode, class D, int LEVEL, bool MIR>
+__device__ __attribute__((noinline)) void cardinal_eval1(double* S, lds_double* M, int j, lds_double* row, const double* X, const int* vi) {
+  // (reads the solver vector itself rather than P0's copy in the mirror: its loads then overlap P0's -- measured 0.25 us)
+  cardinal_eval1_body<Ode, D, LEVEL, MIR>(GatherIn<D>{X, vi, j}, S, M, j, row);
 }
 
 // Coalesced copy of `npt` LDS staging rows (NC doubles each) to the workspace: element idx = row*NC + k goes to
@@ -337,6 +366,9 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   double* slotb = body;
   double* scr = body + D::WSLOTD;
   double* stage = body;
+  constexpr bool MIR = D::MIRROR && LEVEL >= 1 && STAGE == 1;
+  lds_double* const mirror = (lds_double*)(body + LC * STG_LD);   // [G][MSLOT] (ODE stage, MIR)
+  static_assert(!MIR || G <= D::GM, "the LDS mirror holds one slot per segment of a group");
   const int lane = threadIdx.x;
   const int lr = lane & 15, lk = lane >> 4;
   // the scheme's weight tables are read with lane-dependent indices all over the kernel: keep them in LDS
@@ -436,12 +468,18 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
 #pragma unroll
       for (int t = 0; t < NZ; t++) {
         const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
-        if (e < gcount * IR) Wg[g * D::WSLOT + D::w_z + r] = zv[t];
+        if (e < gcount * IR) {
+          Wg[g * D::WSLOT + D::w_z + r] = zv[t];
+          if constexpr (MIR) mirror[g * D::MSLOT + D::m_z + r] = zv[t];
+        }
       }
 #pragma unroll
       for (int t = 0; t < NL; t++) {
         const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
-        if (e < gcount * OR) Wg[g * D::WSLOT + D::w_lam + r] = lv[t];
+        if (e < gcount * OR) {
+          Wg[g * D::WSLOT + D::w_lam + r] = lv[t];
+          if constexpr (MIR) mirror[g * D::MSLOT + D::m_lam + r] = lv[t];
+        }
       }
     }
     // (no wait here: P1 reads X itself; the barrier after P1 also covers these stores before P2 reads the slots)
@@ -452,7 +490,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       const int e = e0 + lane;
       if (lane < LC && e < gcount * CS) {
         const int g = e / CS, j = e - g * CS;
-        cardinal_eval1<Ode, D, LEVEL>(Wg + g * D::WSLOT, j, (lds_double*)(stage + lane * STG_LD), a.X, a.vindex + size_t(seg0 + g) * IR);
+        cardinal_eval1<Ode, D, LEVEL, MIR>(Wg + g * D::WSLOT, mirror + g * D::MSLOT, j, (lds_double*)(stage + lane * STG_LD), a.X,
+                                           a.vindex + size_t(seg0 + g) * IR);
       }
       if constexpr (LEVEL == 1 && D::STAGED) {
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
@@ -464,7 +503,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
       }
     }
-    wave_mem_sync();
+    if constexpr (MIR) wave_lds_sync();   // P2 reads the mirror: no wait for the global stores
+    else wave_mem_sync();
 
     TS();
     if (g0 == 0) publish_tables();
@@ -475,7 +515,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       const int e = e0 + lane;
       if (lane < LC && e < gcount * K) {
         const int g = e / K, i = e - g * K;
-        interior_eval<Ode, D, LEVEL>(Wg + g * D::WSLOT, i, &tab, (lds_double*)(stage + lane * STG_LD));
+        interior_eval<Ode, D, LEVEL, MIR>(Wg + g * D::WSLOT, mirror + g * D::MSLOT, i, &tab, (lds_double*)(stage + lane * STG_LD));
       }
       if constexpr (LEVEL >= 1 && D::STAGED) {
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
@@ -488,7 +528,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
       }
     }
-    wave_mem_sync();
+    if constexpr (MIR) wave_lds_sync();
+    else wave_mem_sync();
 
     TS();
     // ------------------------------------------------------------------ P3: cardinal second derivatives
@@ -497,7 +538,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         const int e = e0 + lane;
         if (lane < LC && e < gcount * CS) {
           const int g = e / CS, j = e - g * CS;
-          cardinal_eval2<Ode, D>(Wg + g * D::WSLOT, j, &tab, (lds_double*)(stage + lane * STG_LD));
+          cardinal_eval2<Ode, D, MIR>(Wg + g * D::WSLOT, mirror + g * D::MSLOT, j, &tab, (lds_double*)(stage + lane * STG_LD));
         }
         wave_lds_sync();   // staging rows are LDS-only hand-offs: do not wait for the global stores
         const int npt = D::STAGED ? min(LC, gcount * CS - e0) : 0;
