@@ -200,6 +200,28 @@ def test_gpu_full_size_wide_shape_properties(oracle):
     ev.close()
 
 
+@pytest.mark.parametrize("ode,mode,blocked", [("reentry", "LGL7", False), ("twobody_lt", "LGL5", True), ("betts_lowthrust", "Trapezoidal", False)])
+def test_renumbered_variables_give_the_same_blocks(ode, mode, blocked):
+    """The kernels read the solver vectors only through Vindex / Cindex (ComputableBase.h:351-378): renumbering the
+    variables and multipliers by a random permutation -- tables that are no longer those of a phase -- must not change
+    a single bit of the blocks."""
+    w = Workload(ode, mode, 77, blocked, var_offset=3, con_offset=2, extra_vars=4)
+    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    ref = [a.copy() for a in ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)]
+    ref0 = ev.eval(CON, w.X)[0].copy()
+    ev.close()
+    rng = np.random.default_rng(3)
+    pv, pc = rng.permutation(w.n_primal), rng.permutation(w.n_equal)     # new position of old variable i: pv[i]
+    X2, L2 = np.empty_like(w.X), np.empty_like(w.L)
+    X2[pv], L2[pc] = w.X, w.L
+    ev2 = DefectEvaluator(ode, mode, w.blocked, pv[w.vindex].astype(np.int32), pc[w.cindex].astype(np.int32), w.n_primal, w.n_equal)
+    got = ev2.eval(JAC_ADJGRAD_HESS, X2, L2)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ev2.eval(CON, X2)[0], ref0)
+    ev2.close()
+
+
 def test_pinned_outputs_give_the_same_blocks(oracle):
     w = Workload("reentry", "LGL5", 300)
     ev = DefectEvaluator("reentry", "LGL5", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
