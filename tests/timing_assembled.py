@@ -1,7 +1,7 @@
 """Times the on-device assembled evaluation (ODE stage + dense stage + KKT scatter) against the block evaluation.
-usage: python tools/time_assembled.py [ode mode nseg blocked]"""
+usage: python tests/timing_assembled.py [ode mode nseg blocked]"""
 import sys, os, numpy as np, torch
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives under tests/: it checks against the oracle)
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 from helpers import Workload, rel_err
 from asset_asrl_amd.evaluator import DefectEvaluator, JAC_ADJGRAD_HESS

@@ -1,7 +1,7 @@
 """Times one workload's evaluation on the GPU and checks it against the oracle.
-usage: [ASSET_HIP_LIB=..] [ASSET_HIP_SKIP_DENSE=1] python tools/time_k.py [ode mode nseg blocked what]"""
+usage: [ASSET_HIP_LIB=..] [ASSET_HIP_SKIP_DENSE=1] python tests/timing_blocks.py [ode mode nseg blocked what]"""
 import sys, os, numpy as np, torch
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives under tests/: it checks against the oracle)
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 from helpers import Workload, rel_err
 from asset_asrl_amd.evaluator import DefectEvaluator
