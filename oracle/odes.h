@@ -43,6 +43,19 @@ void vanderpol(const S* y, S* f, const void*) {
   f[1] = mu * (1.0 - x0 * x0) * x1 - x0 + u * exp(-0.1 * t);
 }
 
+// ------------------------------------------------------------------ coupled oscillators (12,3,2): wide shapes with u and p
+// Not a BASELINE config: in LGL7 its segment has IR = 66 inputs, which puts a run-time compiled ODE with controls and
+// parameters through the four-wave dense kernel (tests/test_gpu_jit.py defines the same right-hand side in the DSL).
+template <class S>
+void coupled12(const S* y, S* f, const void*) {
+  const int n = 12;
+  const S& t = y[12];
+  const S* u = y + 13;
+  const S &p0 = y[16], &p1 = y[17];
+  for (int k = 0; k < n; k++)
+    f[k] = -0.5 * y[k] + sin(y[(k + 1) % n]) * y[(k + 5) % n] * u[k % 3] + p0 * cos(t) + p1 * y[k] * y[(k + 7) % n];
+}
+
 // ------------------------------------------------------------------ a nonlinear path constraint, 2 outputs of 6 inputs
 // Not an ODE: the independent check for plain functions batched over applications (mode FUNCTION);
 // tests/test_gpu_function.py defines the same function in the product's expression DSL.

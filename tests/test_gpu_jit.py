@@ -6,7 +6,7 @@ import pytest
 
 from asset_asrl_amd import jit
 from asset_asrl_amd.evaluator import CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, DefectEvaluator
-from helpers import Workload, make_vanderpol, rel_err
+from helpers import Workload, make_coupled12, make_vanderpol, rel_err
 from test_gpu_parity import _check_blocks
 
 pytestmark = pytest.mark.gpu
@@ -25,6 +25,30 @@ def test_jit_ode_matches_oracle(oracle, mode, blocked):
         ref = nlp.eval_blocks(what, w.X, w.L)
         got = ev.eval(what, w.X, w.L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
         _check_blocks(got, ref, w, what)
+    ev.close()
+
+
+@pytest.mark.parametrize("mode,blocked", [("LGL7", False), ("LGL7", True), ("LGL5", False)])
+def test_wide_user_ode_with_controls_and_parameters(oracle, mode, blocked):
+    """(12, 3, 2) in LGL7: IR = 66 -> the four-wave dense kernel with control-interpolation rows and parameter columns
+    (csrc/defect_wide.h); BlockConstant and LGL5 forms of the same ODE take the single-wave kernel."""
+    from asset_asrl_amd.evaluator import JAC_ADJGRAD_HESS as KIND
+    name = jit.ensure_kernel(make_coupled12(), mode, blocked)
+    w = Workload("coupled12", mode, 29, blocked, sizes=(12, 3, 2), var_offset=2, con_offset=1, extra_vars=3)
+    nlp = oracle.Nlp(oracle.get_ode("coupled12", 0), oracle.MODES[mode], w.blocked, w.vindex, w.cindex, w.n_primal,
+                     w.n_equal, 2)
+    ev = DefectEvaluator(name, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    assert ev.IR == (4 if mode == "LGL7" else 3) * (13 if blocked else 16) + (5 if blocked else 2)
+    for what in (KIND, CON, CON_ADJGRAD, JAC, JAC_ADJGRAD):
+        ref = nlp.eval_blocks(what, w.X, w.L)
+        got = ev.eval(what, w.X, w.L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
+        _check_blocks(got, ref, w, what)
+    # on-device assembly through the same kernels (shared boundary nodes and the two phase parameters)
+    locs = nlp.kkt_locations()[:nlp.num_user_kkt].reshape(w.nseg, ev.NKKT)
+    ev.set_kkt_map(locs, nlp.nnz)
+    vals = np.zeros(nlp.nnz)
+    ev.eval_assembled(KIND, w.X, w.L, vals)
+    assert rel_err(vals, nlp.eval(KIND, w.X, w.L)[2]) < 1e-8
     ev.close()
 
 
