@@ -389,7 +389,7 @@ void lgl_wide_dense_kernel(EvalArgs a) {
 #pragma unroll
               for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int kk = 0; kk < KS; kk++) bv[mt][kk] = S[bo[mt][kk] + ((bo[mt][kk] != ZERO) ? i * D::NZH : 0)] * he;
+                for (int kk = 0; kk < KS; kk++) bv[mt][kk] = S[bo[mt][kk] + ((bo[mt][kk] != ZERO) ? i * D::NZH : 0)];
               // M_i[:, 16rt..16rt+16) = (hE_i H^_i) DI_i[:, tile]: with H^ as the A operand the accumulator entry v of
               // row tile mt -- row 16mt + lk + 4v of M_i, column lr -- is exactly the B operand of k-step 4mt + v of the
               // H product below, so M never leaves the registers
@@ -401,7 +401,7 @@ void lgl_wide_dense_kernel(EvalArgs a) {
                 for (int kk = 0; kk < KS; kk++) am = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[mt][kk], afr[kk], am, 0, 0, 0);
 #pragma unroll
                 for (int v = 0; v < 4; v++)
-                  if (4 * mt + v < KS) bm[4 * mt + v] = am[v];   // (rows >= N of [hE H^] are zero: the k-padding)
+                  if (4 * mt + v < KS) bm[4 * mt + v] = am[v] * he;   // hE_i scales the product (rows >= N of H^ are zero: the k-padding)
               }
               double af[2][KS];                            // fragments of tile ct + 1 fly while tile ct's MFMAs issue
 #pragma unroll
