@@ -94,7 +94,7 @@ __device__ __attribute__((noinline)) void interior_eval(double* S, lds_double* M
 
 template <class Ode, class D, bool MIR>
 __device__ __attribute__((noinline)) void cardinal_eval2(double* S, lds_double* M, int j, const LglTab* tabp, lds_double* row) {
-  constexpr int K = D::K, n = D::n, N = D::N, T = D::T, CS = D::CS;
+  constexpr int K = D::K, n = D::n, N = D::N, T = D::T;
   const LglTab& tab = *tabp;
   const PhaseIn<D, MIR> pin(S, M);
   const auto z = pin.z;

@@ -69,7 +69,7 @@ void lgl_wide_dense_kernel(EvalArgs a) {
   double* slotb = lds + D::TABSZ;
   double* scr = slotb + D::WSLOTD;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  [[maybe_unused]] const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (timing rows, -DASSET_TIMING)
   const int lr = lane & 15, lk = lane >> 4;
   for (int e = tid; e < D::TABSZ; e += 256) tabL[e] = reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[e];
   const LglTab& tab = *reinterpret_cast<const LglTab*>(tabL);
