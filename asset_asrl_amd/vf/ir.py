@@ -15,6 +15,7 @@ Nothing here is copied from the reference; only the calculus is the same.
 """
 from __future__ import annotations
 
+import hashlib
 import math
 from typing import Dict, Iterable, List, Sequence, Tuple
 
@@ -28,13 +29,16 @@ _BINARY = ("add", "sub", "mul", "div", "atan2")
 class Node:
     """One DAG vertex.  Immutable, unique per (op, args, value) inside its Graph."""
 
-    __slots__ = ("op", "args", "value", "id")
+    __slots__ = ("op", "args", "value", "id", "skey")
 
     def __init__(self, op: str, args: Tuple["Node", ...], value, nid: int):
         self.op = op
         self.args = args
         self.value = value  # float for const, int index for var/lam, exponent for pow/powi
         self.id = nid
+        # structural key: depends only on the expression, not on what else the process built before (ids do); the
+        # operands of commutative nodes are ordered by it, so the same function always prints as the same code
+        self.skey = hashlib.blake2b(f"{op}|{value!r}|{','.join(a.skey for a in args)}".encode(), digest_size=10).hexdigest()
 
     def is_const(self) -> bool:
         return self.op == "const"
@@ -90,7 +94,7 @@ class Graph:
             return self.sub(a, b.args[0])
         if a.op == "neg":
             return self.sub(b, a.args[0])
-        if a.id > b.id:
+        if a.skey > b.skey:
             a, b = b, a
         return self._mk("add", (a, b))
 
@@ -133,7 +137,7 @@ class Graph:
             return self.neg(self.mul(a.args[0], b))
         if b.op == "neg":
             return self.neg(self.mul(a, b.args[0]))
-        if a.id > b.id:
+        if a.skey > b.skey:
             a, b = b, a
         return self._mk("mul", (a, b))
 
