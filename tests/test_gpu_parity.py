@@ -154,6 +154,47 @@ def test_gpu_full_size_properties(oracle):
     assert np.abs(fx3 - fx).max() < 1e-9
 
 
+@pytest.mark.parametrize("ode,mode,nseg,blocked", [
+    ("betts_lowthrust", "LGL5", 1000, False),        # BASELINE configs[1]
+    ("reentry", "LGL7", 5000, False),                # BASELINE configs[2] (initial mesh)
+])
+def test_baseline_configs_at_full_size_match_the_oracle_everywhere(oracle, ode, mode, nseg, blocked):
+    """Every block of every segment against the oracle's NLP restatement at the BASELINE sizes."""
+    w = Workload(ode, mode, nseg, blocked)
+    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    nlp = w.oracle_nlp(oracle, threads=8)
+    for what in (JAC_ADJGRAD_HESS, CON):
+        _check_blocks(ev.eval(what, w.X, w.L if what == JAC_ADJGRAD_HESS else None), nlp.eval_blocks(what, w.X, w.L), w, what)
+    ev.close()
+
+
+def test_baseline_multi_phase_config_eight_linked_phases(oracle):
+    """BASELINE configs[3]: eight TwoBody LGL5 phases with BlockConstant control in one solver vector (their variables
+    and constraint rows one after the other, as OptimalControlProblem lays linked phases out): one evaluator per phase,
+    each against the oracle on its own slice."""
+    nseg, phases = 400, 8
+    ws, voff, coff = [], 0, 0
+    for k in range(phases):
+        w = Workload("twobody_lt", "LGL5", nseg, True, seed=100 + k, var_offset=voff, con_offset=coff)
+        ws.append(w)
+        voff, coff = w.n_primal, w.n_equal                # the next phase starts where this one's vectors end
+    n_primal, n_equal = ws[-1].n_primal, ws[-1].n_equal
+    X, L = np.zeros(n_primal), np.zeros(n_equal)
+    for w in ws:                                           # every phase contributes its own slice of the two vectors
+        v0, c0 = w.indexer.var_offset, w.indexer.con_offset
+        X[v0:v0 + w.indexer.numPhaseVars] = w.X[v0:v0 + w.indexer.numPhaseVars]
+        L[c0:c0 + w.indexer.numPhaseEqCons] = w.L[c0:c0 + w.indexer.numPhaseEqCons]
+    for w in ws:
+        ev = DefectEvaluator("twobody_lt", "LGL5", True, w.vindex, w.cindex, n_primal, n_equal)
+        nlp = oracle.Nlp(oracle.get_ode("twobody_lt", 0), oracle.MODES["LGL5"], True, w.vindex, w.cindex, n_primal, n_equal, 4)
+        got = ev.eval(JAC_ADJGRAD_HESS, X, L)
+        ref = nlp.eval_blocks(JAC_ADJGRAD_HESS, X, L)
+        fx, agx, kkt = got
+        assert np.abs(fx - ref[0]).max() / max(1.0, np.abs(X).max()) < TOL_RES
+        assert rel_err(agx, ref[1]) < TOL_DER and rel_err(kkt, ref[2]) < TOL_DER
+        ev.close()
+
+
 def test_gpu_full_size_wide_shape_properties(oracle):
     """BASELINE config 4 at full size: 100 000 segments of the 32-state ODE in LGL7 (17.5 GB of blocks, kept on the
     device).  Oracle on a strided sample, J^T lam == adjoint gradient for every segment, symmetric use of the
