@@ -114,5 +114,9 @@ void KktAssembly::evalRHS(const double* X, const double* L, double* FXE, double*
   eval(ASSET_HIP_CON_ADJGRAD, X, L, FXE, AGX, nullptr);
 }
 void KktAssembly::evalOCC(const double* X, double* FXE) { eval(ASSET_HIP_CON, X, nullptr, FXE, nullptr, nullptr); }
+// the solver's initialisation pass (NonLinearProgram.cpp:627-683): value, J^T L and J -- no adjoint Hessian
+void KktAssembly::evalAUG(const double* X, const double* L, double* FXE, double* AGX, double* vals) {
+  eval(ASSET_HIP_JAC_ADJGRAD, X, L, FXE, AGX, vals);
+}
 
 }  // namespace asset_hip_host

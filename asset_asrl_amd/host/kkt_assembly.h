@@ -5,7 +5,7 @@
 // Mirrored, relative to /root/reference/src/Solvers:
 //   countElems / getMATSpace / getRHSSpace / setMATDimensions / finalizeData   NonLinearProgram.cpp:41-254
 //   analyzeSparsity  (upper-triangular row-major CSR, KKTLocations)              NonLinearProgram.cpp:267-344
-//   evalKKT / evalSOE / evalOCC / evalRHS                                         NonLinearProgram.cpp:347-449,473-537,590-626
+//   evalKKT / evalSOE / evalOCC / evalRHS / evalAUG                               NonLinearProgram.cpp:347-449,473-537,590-683
 //   RHSFillOP, fillSolverCoeffs                                                   NonLinearProgram.h:264-290,379-407
 // The KKT system has dimension PrimalVars + EqualCons here (no slacks / inequalities: they stay with the host solver's
 // own NLP); besides the user entries it carries one diagonal slot per primal variable and per equality constraint
@@ -43,6 +43,7 @@ class KktAssembly {
   void evalSOE(const double* X, double* FXE, double* kkt_values);                                  // value + J
   void evalRHS(const double* X, const double* L, double* FXE, double* AGX);                        // value + J^T L
   void evalOCC(const double* X, double* FXE);                                                      // value
+  void evalAUG(const double* X, const double* L, double* FXE, double* AGX, double* kkt_values);   // value + J^T L + J (init pass)
 
  private:
   struct Entry {

@@ -74,6 +74,7 @@ extern "C" int assembly_run(const char* ode, int mode, int blocked, int ir, int 
       case 0: nlp.evalOCC(X, FXE); break;
       case 1: nlp.evalRHS(X, L, FXE, AGX); break;
       case 2: nlp.evalSOE(X, FXE, kkt_vals); break;
+      case 3: nlp.evalAUG(X, L, FXE, AGX, kkt_vals); break;
       default: nlp.evalKKT(X, L, FXE, AGX, kkt_vals);
     }
     return nlp.nnz();

@@ -59,13 +59,14 @@ def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg, device_
                                                    ("betts_lowthrust", "Trapezoidal", False, 12)])
 def test_kkt_assembly_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg):
     """Product-side sparsity analysis and eval* drivers (host/kkt_assembly.h) against the oracle's restatement of
-    NonLinearProgram: same CSR structure, same KKTLocations, same values for evalOCC / evalRHS / evalSOE / evalKKT."""
+    NonLinearProgram: same CSR structure, same KKTLocations, same values for evalOCC / evalRHS / evalSOE / evalAUG / evalKKT."""
     w = Workload(ode, mode, nseg, blocked, var_offset=2, con_offset=1, extra_vars=3)
     nlp = w.oracle_nlp(oracle, threads=1)
     r_outer, r_inner = nlp.csr()
     r_locs = nlp.kkt_locations()
     ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
-    for what, okind in ((4, oracle.JAC_ADJGRAD_HESS), (0, oracle.CON), (1, oracle.CON_ADJGRAD), (2, oracle.JAC)):
+    for what, okind in ((4, oracle.JAC_ADJGRAD_HESS), (0, oracle.CON), (1, oracle.CON_ADJGRAD), (2, oracle.JAC),
+                        (3, oracle.JAC_ADJGRAD)):
         outer = np.zeros(nlp.kkt_dim + 1, dtype=np.int32)
         inner = np.zeros(nlp.nnz + 16, dtype=np.int32)
         locs = np.zeros(r_locs.size, dtype=np.int32)
@@ -82,7 +83,7 @@ def test_kkt_assembly_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg)
         np.testing.assert_array_equal(locs, r_locs)
         rFXE, rAGX, rvals = nlp.eval(okind, w.X, w.L)
         assert np.abs(FXE - rFXE).max() / max(1.0, np.abs(w.X).max()) < 1e-10
-        if what in (1, 4):
+        if what in (1, 3, 4):
             assert rel_err(AGX, rAGX) < 1e-8
-        if what in (2, 4):
+        if what in (2, 3, 4):
             assert rel_err(vals, rvals) < 1e-8
