@@ -139,3 +139,56 @@ def test_phase_add_constraints_evaluate_over_their_regions(oracle):
     # the defects still evaluate with the longer multiplier vector
     fxd, _, _ = ph.evaluator.eval(CON, X)
     assert fxd.shape == (23, ph.evaluator.OR)
+
+
+def test_segment_quadrature_and_control_spline_on_the_device():
+    """LGLIntegral / LGLControlSpline (LGLIntegrals.h:9-52, LGLControlSplines.h:64-108) batched over segments on the
+    device: known answers -- the LGL7 quadrature is exact for the cubic integrand of a polynomial trajectory, and the
+    spline relation vanishes on a control that is one cubic across both segments -- and the device's adjoint gradient
+    against central differences of the device's own values."""
+    from asset_asrl_amd.pathfuncs import LGLControlSpline, LGLIntegral
+    tc = np.array([0.0, 2.65575603264643e-1, 7.34424396735357e-1, 1.0])
+    nseg = 150
+    rng = np.random.default_rng(9)
+    t0 = np.sort(rng.uniform(0, 20, nseg))
+    h = rng.uniform(0.3, 2.0, nseg)
+    # --- quadrature: states (t^3, t), integrand x1^2 + x0 = t^2 + t^3
+    g = vf.Arguments(2)
+    F = LGLIntegral(g.coeff(1) * g.coeff(1) + g.coeff(0), 4, 2)
+    T = t0[:, None] + tc[None, :] * h[:, None]
+    Z = np.stack([T ** 3, T, T], axis=2).reshape(nseg, 12)                   # [x0, x1, t] at the four nodes
+    X = Z.ravel()
+    vindex = np.arange(nseg * 12, dtype=np.int32).reshape(nseg, 12)
+    cindex = np.arange(nseg, dtype=np.int32).reshape(nseg, 1)
+    L = rng.uniform(0.5, 1.5, nseg)
+    ev = FunctionEvaluator(F, "lglintegral_test", vindex, cindex, X.size, L.size)
+    fx, agx, kkt = ev.eval(JAC_ADJGRAD_HESS, X, L)
+    prim = lambda t: t ** 3 / 3 + t ** 4 / 4
+    np.testing.assert_allclose(fx[:, 0], prim(t0 + h) - prim(t0), rtol=1e-12, atol=1e-12)
+    eps = 1e-6
+    for col in (0, 4, 11):                                                   # a state, an interior state, the end time
+        Xp, Xm = X.copy(), X.copy()
+        Xp[col::12] += eps
+        Xm[col::12] -= eps
+        fd = (ev.eval(CON, Xp)[0][:, 0] - ev.eval(CON, Xm)[0][:, 0]) / (2 * eps)
+        np.testing.assert_allclose(agx[:, col], L * fd, rtol=1e-6, atol=1e-6)
+    H, J = unpack_kkt_block(kkt[3], 12, 1)
+    np.testing.assert_allclose(J[0] * L[3], agx[3], rtol=1e-12, atol=1e-12)   # one output: J^T lam = lam * J
+    assert np.abs(H - H.T).max() == 0.0
+    ev.close()
+    # --- control spline over pairs of segments: [t, u0, u1] at the 7 nodes of two adjacent segments
+    S = LGLControlSpline(4, 2)
+    npair = 60
+    ta = np.sort(rng.uniform(0, 10, npair))
+    h0, h1 = rng.uniform(0.5, 1.5, npair), rng.uniform(0.5, 1.5, npair)
+    ts = np.concatenate([ta[:, None] + tc[None, :] * h0[:, None], (ta + h0)[:, None] + tc[None, 1:] * h1[:, None]], axis=1)
+    Zs = np.stack([ts, 1 + 2 * ts - 0.5 * ts ** 2 + 0.3 * ts ** 3, ts ** 3 - ts], axis=2).reshape(npair, 21)
+    vind = np.arange(npair * 21, dtype=np.int32).reshape(npair, 21)
+    cind = np.arange(npair * 4, dtype=np.int32).reshape(npair, 4)
+    ev = FunctionEvaluator(S, "lglcontrolspline4", vind, cind, Zs.size, npair * 4)
+    fx = ev.eval(CON, Zs.ravel())[0]
+    assert np.abs(fx).max() < 1e-9 * max(1.0, np.abs(Zs).max() ** 3)         # 15-digit weight literals
+    Zbad = Zs.copy()
+    Zbad[:, -1] += 0.1                                                        # a kink in the last node's control
+    assert np.abs(ev.eval(CON, Zbad.ravel())[0]).max(axis=1).min() > 1e-2
+    ev.close()
