@@ -92,7 +92,6 @@ struct Dims {
   static constexpr int w_Ig = w_IJ + K * NZJ;
   static constexpr int w_IH = w_Ig + K * N;
   static constexpr int w_SV = w_IH + K * NZH;           // transcendental values of f at the cardinal nodes (P1 -> P3)
-  static constexpr int WSLOT = w_SV + CS * Ode::NSAVE;
   static constexpr int WSLOTD = w_SV;                   // what the dense stage reads of a slot
   // ---- dense scratch (one segment at a time)
   // DI_i is kept as two tiles: state rows (r < n), rewritten for every segment, and the remaining rows (tau / control
@@ -154,6 +153,7 @@ struct Dims {
   static constexpr int MSLOT = (m_SV + CS * Ode::NSAVE) | 1;
   // (not for Trapezoidal: its interior sections are never written and must read as the zeros the workspace is created with)
   static constexpr bool MIRROR = !TRAP && STAGED && size_t(TABSZ + LC * STG_LD + GM * MSLOT) * 8 <= 40 * 1024;
+  static constexpr int WSLOT = MIRROR ? w_SV : w_SV + CS * Ode::NSAVE;   // (the saved values live in the mirror when there is one)
   // LDS of the two launches: [weight tables | staging rows | mirror] and [weight tables | slot buffer | dense scratch]
   static constexpr size_t lds_bytes_ode() { return size_t(TABSZ + (STAGED ? LC * STG_LD : 0) + (MIRROR ? GM * MSLOT : 0)) * 8; }
   static constexpr size_t lds_bytes_dense() { return size_t(TABSZ + DENSE) * 8; }
