@@ -66,8 +66,9 @@ def test_assembled_device_pointers(oracle, mode):
     ev.close()
 
 
-def test_assembled_device_pointers_accumulate(oracle):
-    w, nlp, ev, _ = _setup(oracle, "reentry", "LGL7", 300, False, accumulate=True)
+@pytest.mark.parametrize("ode,nseg", [("reentry", 300), ("synthetic32", 7)])
+def test_assembled_device_pointers_accumulate(oracle, ode, nseg):
+    w, nlp, ev, _ = _setup(oracle, ode, "LGL7", nseg, False, accumulate=True)
     dev = torch.device("cuda:0")
     X, L = torch.from_numpy(w.X).to(dev), torch.from_numpy(w.L).to(dev)
     fx = torch.zeros(w.nseg * ev.OR, dtype=torch.float64, device=dev)

@@ -97,6 +97,17 @@ def test_ragged_segment_counts(oracle, nseg):
                   w, JAC_ADJGRAD_HESS)
 
 
+@pytest.mark.parametrize("mode,nseg", [("LGL7", 1), ("LGL7", 2), ("LGL7", 3), ("LGL7", 257), ("LGL5", 1), ("LGL5", 511), ("LGL3", 513)])
+def test_ragged_segment_counts_wide_shapes(oracle, mode, nseg):
+    """The four-wave dense kernel (csrc/defect_wide.h): fewer segments than workgroups, one segment, counts that leave
+    the workgroups with unequal shares."""
+    w = Workload("synthetic32", mode, nseg)
+    ev = DefectEvaluator("synthetic32", mode, False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    _check_blocks(ev.eval(JAC_ADJGRAD_HESS, w.X, w.L), w.oracle_nlp(oracle, threads=8).eval_blocks(oracle.JAC_ADJGRAD_HESS, w.X, w.L),
+                  w, JAC_ADJGRAD_HESS)
+    ev.close()
+
+
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
 
