@@ -39,3 +39,15 @@ print(f"de Boor mesh error: max {err.max():.3e} at t/T = {tsnd[err.argmax()]:.3f
 defect = phase.get_defect()                                       # one segment as a VectorFunction: z[IR] -> d[OR]
 fx1, jx1, gx1, hx1 = defect.computeall(X[ev.vindex[0]], L[:ev.OR])
 print(f"get_defect().computeall: fx {fx1.shape} jx {jx1.shape} gx {gx1.shape} hx {hx1.shape}")
+
+# a user path constraint over every state of the mesh (reference: phase.addInequalCon("Path", ...), Reentry.py heating
+# constraint): written in the expression DSL, compiled for the device on first use, evaluated for all states at once
+from asset_asrl_amd import vf                                     # noqa: E402
+a = vf.Arguments(3)                                               # altitude, velocity, angle of attack (scaled units)
+qdot = 0.2 * vf.exp(-2.0 * a[0]) * a[1] * a[1] * a[1] * (1.0 + a[2] * a[2]) - 70.0
+phase.addInequalCon("Path", vf.stack([qdot]), [0, 3, 6])
+(iq,) = phase.inequality_evaluators                               # re-transcribes: one device evaluator per function
+X = phase.solver_input()
+fq, gq, kq = iq.eval(JAC_ADJGRAD_HESS, X, np.ones(phase.numPhaseIqCons))
+print(f"path inequality at {iq.nseg} states: values {fq.shape}, gradient blocks {gq.shape}, KKT blocks {kq.shape}, "
+      f"max value {fq.max():.3f}")
