@@ -14,11 +14,11 @@ IR,OR,NK=ev.IR,ev.OR,ev.NKKT
 dev=torch.device("cuda:0")
 X=torch.from_numpy(w.X).to(dev); L=torch.from_numpy(w.L).to(dev)
 fx=torch.zeros(nseg*OR,dtype=torch.float64,device=dev); agx=torch.zeros(nseg*IR,dtype=torch.float64,device=dev)
-kkt=torch.zeros(nseg*NK,dtype=torch.float64,device=dev)
+kkt=torch.zeros(nseg*int(os.environ.get('ASSET_FAKE_KKT',NK)),dtype=torch.float64,device=dev)
 if os.environ.get('NOKKT'): kkt=None
 ms=min(ev.time_device(what,X,L,fx,agx,kkt,10,200) for _ in range(3))
 msg=f"{ode} {mode} nseg={nseg} what={what}: {ms*1e3:.2f} us"
-if not os.environ.get("ASSET_HIP_SKIP_DENSE"):
+if not os.environ.get("ASSET_HIP_SKIP_DENSE") and not os.environ.get("NOCHECK"):
     sys.path.insert(0,os.path.join(ROOT))
     from oracle import bindings as ob
     ws=Workload(ode,mode,min(nseg,300),blocked)
