@@ -46,6 +46,71 @@ __global__ __launch_bounds__(64) void wide_setup_kernel(unsigned int* out) {
       }
 }
 
+// Structurally zero operand fragments are known at compile time (Ode::HPOS / JPOS): k-step kk of the M product for row
+// tile mt reads the 16 x 4 block H^[16mt.., 4kk..], k-step kk of a J^T tile reads J^[rows of the tile, 4kk..]; a block
+// with no structural entry contributes nothing and its MFMA is skipped (32-state BASELINE ODE: 13 of 27 and 7 of 9).
+template <class Ode, class D>
+struct WideSparsity {
+  static constexpr int N = D::N, n = D::n, KS = D::KS, MT = (D::NP + 15) / 16, TJ = D::TJ, K = D::K, OR = D::OR;
+  static constexpr unsigned hmask(int mt) {              // bit kk: block (mt, kk) of H^ has a structural entry
+    unsigned m = 0;
+    for (int kk = 0; kk < KS; kk++)
+      for (int r = 16 * mt; r < 16 * mt + 16 && r < N; r++)
+        for (int c = 4 * kk; c < 4 * kk + 4 && c < N; c++)
+          if (Ode::HPOS[r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r] >= 0) m |= 1u << kk;
+    return m;
+  }
+  static constexpr unsigned jmask(int jt) {              // bit kk: some defect row of J tile jt has an entry in inputs 4kk..4kk+3
+    unsigned m = 0;
+    for (int kk = 0; kk < KS; kk++)
+      for (int jr = 16 * jt; jr < 16 * jt + 16 && jr < OR; jr++)
+        for (int c = 4 * kk; c < 4 * kk + 4 && c < N; c++)
+          if (Ode::JPOS[(jr % n) * N + c] >= 0) m |= 1u << kk;
+    return m;
+  }
+  static constexpr bool di_entry(int b, int c) {         // can DI_i[b][c] be non-zero (LGLDefects.h:417-458)?
+    constexpr int q = D::q, P0 = D::P0, IR = D::IR, T = D::T, TF = D::TF;
+    if (c >= IR || b >= N) return false;
+    if (b < n) {
+      if (c == T || c == TF) return true;                // time columns: -+ sum_j B_ij f_j
+      if (c < P0) { const int cc = c % q; return cc == b || Ode::JPOS[b * N + cc] >= 0; }
+      return Ode::JPOS[b * N + q + (c - P0)] >= 0;       // parameter columns
+    }
+    if (b == T) return c == T || c == TF;
+    if (b < q) return c < P0 && (c % q) == b;            // control-interpolation rows
+    return c == P0 + (b - q);                            // parameter identity rows
+  }
+  static constexpr unsigned dmask(int ct) {              // bit kk: rows 4kk..4kk+3 of DI have an entry in column tile ct
+    unsigned m = 0;
+    for (int kk = 0; kk < KS; kk++)
+      for (int b = 4 * kk; b < 4 * kk + 4; b++)
+        for (int c = 16 * ct; c < 16 * ct + 16; c++)
+          if (di_entry(b, c)) m |= 1u << kk;
+    return m;
+  }
+  struct DTable {
+    unsigned m[D::TI];
+    constexpr DTable() : m{} {
+      for (int ct = 0; ct < D::TI; ct++) m[ct] = dmask(ct);
+    }
+  };
+  static constexpr DTable DT{};
+  struct JTable {
+    unsigned m[TJ];
+    constexpr JTable() : m{} {
+      for (int jt = 0; jt < TJ; jt++) m[jt] = jmask(jt);
+    }
+  };
+  static constexpr JTable JT{};
+  struct HTable {                                        // (tables, so that nothing of this is evaluated on the device)
+    unsigned m[MT];
+    constexpr HTable() : m{} {
+      for (int mt = 0; mt < MT; mt++) m[mt] = hmask(mt);
+    }
+  };
+  static constexpr HTable HT{};
+};
+
 #ifndef ASSET_WIDE_WGS
 #define ASSET_WIDE_WGS 2              // workgroups per CU when two working sets fit its LDS (halves the register budget)
 #endif
@@ -62,6 +127,8 @@ void lgl_wide_dense_kernel(EvalArgs a) {
   constexpr int NJC = (TI + CTC - 1) / CTC;
   constexpr int NHU = (LEVEL >= 2 || !ASM) ? TI : 0;     // H work units (Jacobian-only block kinds store zeros there)
   constexpr int NUNITS = NHU + TJ * NJC;
+  using WS = WideSparsity<Ode, D>;
+  static_assert(KS <= 32 && TJ <= 32, "fragment masks are 32-bit");
   (void)p;
 
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -384,12 +451,15 @@ void lgl_wide_dense_kernel(EvalArgs a) {
               // (an MFMA fed by an LDS read issued right before it runs at half rate -- measured 135 vs 74 cycles -- so
               //  every operand is read a batch ahead of the MFMAs that use it)
               double afr[KS], bv[MT][KS];
+              const unsigned dmr = WS::DT.m[rt];           // k-steps in which DI has entries in tile rt
 #pragma unroll
-              for (int kk = 0; kk < KS; kk++) afr[kk] = avf(rt, i, kk);
+              for (int kk = 0; kk < KS; kk++)
+                if (dmr >> kk & 1) afr[kk] = avf(rt, i, kk);
 #pragma unroll
               for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int kk = 0; kk < KS; kk++) bv[mt][kk] = S[bo[mt][kk] + ((bo[mt][kk] != ZERO) ? i * D::NZH : 0)];
+                for (int kk = 0; kk < KS; kk++)
+                  if (WS::HT.m[mt] >> kk & 1) bv[mt][kk] = S[bo[mt][kk] + ((bo[mt][kk] != ZERO) ? i * D::NZH : 0)];
               // M_i[:, 16rt..16rt+16) = (hE_i H^_i) DI_i[:, tile]: with H^ as the A operand the accumulator entry v of
               // row tile mt -- row 16mt + lk + 4v of M_i, column lr -- is exactly the B operand of k-step 4mt + v of the
               // H product below, so M never leaves the registers
@@ -398,24 +468,29 @@ void lgl_wide_dense_kernel(EvalArgs a) {
               for (int mt = 0; mt < MT; mt++) {
                 d4 am = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < KS; kk++) am = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[mt][kk], afr[kk], am, 0, 0, 0);
+                for (int kk = 0; kk < KS; kk++)
+                  if ((WS::HT.m[mt] >> kk & 1) && (dmr >> kk & 1))
+                    am = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[mt][kk], afr[kk], am, 0, 0, 0);
 #pragma unroll
                 for (int v = 0; v < 4; v++)
                   if (4 * mt + v < KS) bm[4 * mt + v] = am[v] * he;   // hE_i scales the product (rows >= N of H^ are zero: the k-padding)
               }
               double af[2][KS];                            // fragments of tile ct + 1 fly while tile ct's MFMAs issue
 #pragma unroll
-              for (int kk = 0; kk < KS; kk++) af[0][kk] = avf(0, i, kk);
+              for (int kk = 0; kk < KS; kk++)
+                if (WS::DT.m[0] >> kk & 1) af[0][kk] = avf(0, i, kk);
 #pragma unroll
               for (int ct = 0; ct < TI; ct++) {
                 if (ct > rt) continue;
                 if (ct + 1 < TI && ct + 1 <= rt) {
 #pragma unroll
-                  for (int kk = 0; kk < KS; kk++) af[(ct + 1) & 1][kk] = avf(ct + 1, i, kk);
+                  for (int kk = 0; kk < KS; kk++)
+                    if (WS::DT.m[ct + 1 < TI ? ct + 1 : 0] >> kk & 1) af[(ct + 1) & 1][kk] = avf(ct + 1, i, kk);
                 }
 #pragma unroll
                 for (int kk = 0; kk < KS; kk++)
-                  acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ct & 1][kk], bm[kk], acc[ct], 0, 0, 0);
+                  if (WS::DT.m[ct] >> kk & 1)
+                    acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ct & 1][kk], bm[kk], acc[ct], 0, 0, 0);
               }
             }
           } else {
@@ -451,6 +526,7 @@ void lgl_wide_dense_kernel(EvalArgs a) {
 #pragma unroll
           for (int cq = 0; cq < CTC; cq++) acc[cq] = d4{0.0, 0.0, 0.0, 0.0};
           const int i_lo = (16 * jt) / n, i_hi = min(K - 1, (16 * jt + 15) / n);   // interiors with defect rows in this tile
+          const unsigned jm = WS::JT.m[jt];                // k-steps whose J^ fragment has a structural entry
 #pragma unroll 1
           for (int i = i_lo; i <= i_hi; i++) {
             const double he = h * tab.E[i];
@@ -463,17 +539,20 @@ void lgl_wide_dense_kernel(EvalArgs a) {
             }
             double af[2][KS];
 #pragma unroll
-            for (int kk = 0; kk < KS; kk++) af[0][kk] = avf(c0, i, kk);
+            for (int kk = 0; kk < KS; kk++)
+              if ((jm & WS::DT.m[c0]) >> kk & 1) af[0][kk] = avf(c0, i, kk);
 #pragma unroll
             for (int cq = 0; cq < CTC; cq++) {
               if (c0 + cq >= TI) break;
               if (cq + 1 < CTC && c0 + cq + 1 < TI) {
 #pragma unroll
-                for (int kk = 0; kk < KS; kk++) af[(cq + 1) & 1][kk] = avf(c0 + cq + 1, i, kk);
+                for (int kk = 0; kk < KS; kk++)
+                  if ((jm & WS::DT.m[c0 + cq + 1]) >> kk & 1) af[(cq + 1) & 1][kk] = avf(c0 + cq + 1, i, kk);
               }
 #pragma unroll
               for (int kk = 0; kk < KS; kk++)
-                acc[cq] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cq & 1][kk], bj[kk], acc[cq], 0, 0, 0);
+                if ((jm & WS::DT.m[c0 + cq]) >> kk & 1)
+                  acc[cq] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cq & 1][kk], bj[kk], acc[cq], 0, 0, 0);
             }
           }
 #pragma unroll
