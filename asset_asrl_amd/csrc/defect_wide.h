@@ -451,10 +451,8 @@ void lgl_wide_dense_kernel(EvalArgs a) {
               // (an MFMA fed by an LDS read issued right before it runs at half rate -- measured 135 vs 74 cycles -- so
               //  every operand is read a batch ahead of the MFMAs that use it)
               double afr[KS], bv[MT][KS];
-              const unsigned dmr = WS::DT.m[rt];           // k-steps in which DI has entries in tile rt
 #pragma unroll
-              for (int kk = 0; kk < KS; kk++)
-                if (dmr >> kk & 1) afr[kk] = avf(rt, i, kk);
+              for (int kk = 0; kk < KS; kk++) afr[kk] = avf(rt, i, kk);   // (a run-time DI mask for tile rt did not pay here)
 #pragma unroll
               for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -469,8 +467,7 @@ void lgl_wide_dense_kernel(EvalArgs a) {
                 d4 am = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int kk = 0; kk < KS; kk++)
-                  if ((WS::HT.m[mt] >> kk & 1) && (dmr >> kk & 1))
-                    am = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[mt][kk], afr[kk], am, 0, 0, 0);
+                  if (WS::HT.m[mt] >> kk & 1) am = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[mt][kk], afr[kk], am, 0, 0, 0);
 #pragma unroll
                 for (int v = 0; v < 4; v++)
                   if (4 * mt + v < KS) bm[4 * mt + v] = am[v] * he;   // hE_i scales the product (rows >= N of H^ are zero: the k-padding)
