@@ -128,6 +128,8 @@ void lgl_wide_dense_kernel(EvalArgs a) {
   constexpr int NHU = (LEVEL >= 2 || !ASM) ? TI : 0;     // H work units (Jacobian-only block kinds store zeros there)
   constexpr int NUNITS = NHU + TJ * NJC;
   using WS = WideSparsity<Ode, D>;
+  // the interior loop of an H unit is unrolled when the workgroup has a CU's registers to itself (two per CU: it spills)
+  constexpr int IUNROLL = (D::lds_bytes_dense() * ASSET_WIDE_WGS <= 160 * 1024) ? 1 : K;
   static_assert(KS <= 32 && TJ <= 32, "fragment masks are 32-bit");
   (void)p;
 
@@ -445,8 +447,8 @@ void lgl_wide_dense_kernel(EvalArgs a) {
               const double x2 = R2[(lk == 0 ? 0 : (lk == 1 ? IRP : 2 * IRP)) + 16 * ct + lr];
               acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, y2, acc[ct], 0, 0, 0);   // rank-2 time update
             }
-#pragma unroll 1
-            for (int i = 0; i < K; i++) {
+#pragma unroll(IUNROLL)
+            for (int i = 0; i < K; i++) {                  // (a rolled loop copies all accumulators at its back edge)
               const double he = h * tab.E[i];
               // (an MFMA fed by an LDS read issued right before it runs at half rate -- measured 135 vs 74 cycles -- so
               //  every operand is read a batch ahead of the MFMAs that use it)
