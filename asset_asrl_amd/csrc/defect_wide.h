@@ -420,8 +420,8 @@ void lgl_wide_dense_kernel(EvalArgs a) {
             const double y2 = R2[(lk == 0 ? IRP : (lk == 1 ? 0 : 2 * IRP)) + 16 * rt + lr];
 #pragma unroll
             for (int ct = 0; ct < TI; ct++) {
+              if (ct > rt) continue;                       // (tiles above the diagonal: their accumulators are never touched)
               acc[ct] = d4{0.0, 0.0, 0.0, 0.0};
-              if (ct > rt) continue;
               if (tiles_share_node<D>(ct, rt)) {           // cardinal diagonal / parameter blocks (LGLDefects.h:386-402)
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
