@@ -123,13 +123,16 @@ void lgl_wide_dense_kernel(EvalArgs a) {
   constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, NP = D::NP, KS = D::KS, MT = (NP + 15) / 16;
   constexpr int TI = D::TI, TJ = D::TJ, NTH = D::NTH, NCR = D::NCR, ROWS = K * n;
   constexpr int ZERO = D::WSLOTD + D::s_Z0;              // slot-relative offset of a cell that holds 0.0
-  constexpr int CTC = TI > 5 ? (TI + 1) / 2 : TI;        // column tiles of one J work unit
+  // column tiles of one J work unit: a whole tile row when the workgroup has the CU's registers to itself (3 / 5 / 9
+  // tiles per unit measured 19.4 / 16.0 / 15.1 ms on the 32-state LGL7 shape), half a row with two workgroups per CU
+  constexpr bool FULLREG = !(D::lds_bytes_dense() * ASSET_WIDE_WGS <= 160 * 1024);
+  constexpr int CTC = (FULLREG || TI <= 5) ? TI : (TI + 1) / 2;
   constexpr int NJC = (TI + CTC - 1) / CTC;
   constexpr int NHU = (LEVEL >= 2 || !ASM) ? TI : 0;     // H work units (Jacobian-only block kinds store zeros there)
   constexpr int NUNITS = NHU + TJ * NJC;
   using WS = WideSparsity<Ode, D>;
   // the interior loop of an H unit is unrolled when the workgroup has a CU's registers to itself (two per CU: it spills)
-  constexpr int IUNROLL = (D::lds_bytes_dense() * ASSET_WIDE_WGS <= 160 * 1024) ? 1 : K;
+  constexpr int IUNROLL = FULLREG ? K : 1;
   static_assert(KS <= 32 && TJ <= 32, "fragment masks are 32-bit");
   (void)p;
 
@@ -420,8 +423,8 @@ void lgl_wide_dense_kernel(EvalArgs a) {
             const double y2 = R2[(lk == 0 ? IRP : (lk == 1 ? 0 : 2 * IRP)) + 16 * rt + lr];
 #pragma unroll
             for (int ct = 0; ct < TI; ct++) {
-              if (ct > rt) continue;                       // (tiles above the diagonal: their accumulators are never touched)
-              acc[ct] = d4{0.0, 0.0, 0.0, 0.0};
+              acc[ct] = d4{0.0, 0.0, 0.0, 0.0};            // (all of them: initialising only ct <= rt measured 15 % slower on
+              if (ct > rt) continue;                       //  the shapes that run two workgroups per CU)
               if (tiles_share_node<D>(ct, rt)) {           // cardinal diagonal / parameter blocks (LGLDefects.h:386-402)
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
