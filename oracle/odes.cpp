@@ -59,6 +59,7 @@ AD2_ODE(betts_lowthrust, 7, 3, 1)
 AD2_ODE(synthetic32, 32, 0, 0)
 AD2_ODE(vanderpol, 2, 1, 1)
 AD2_ODE(coupled12, 12, 3, 2)
+AD2_ODE(coupled16, 16, 3, 2)
 AD2_ODE(pathcon, 2, 3, 0)
 
 }  // namespace
@@ -84,6 +85,7 @@ GEN_DECL(betts_lowthrust)
 GEN_DECL(synthetic32)
 GEN_DECL(vanderpol)
 GEN_DECL(coupled12)
+GEN_DECL(coupled16)
 GEN_DECL(pathcon)
 
 extern "C" {
@@ -112,6 +114,7 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(synthetic32, 32, 0, 0, g_synth32)
   TRY(vanderpol, 2, 1, 1, nullptr)
   TRY(coupled12, 12, 3, 2, nullptr)
+  TRY(coupled16, 16, 3, 2, nullptr)
   TRY(pathcon, 2, 3, 0, nullptr)
   return -1;
 }

@@ -46,15 +46,19 @@ void vanderpol(const S* y, S* f, const void*) {
 // ------------------------------------------------------------------ coupled oscillators (12,3,2): wide shapes with u and p
 // Not a BASELINE config: in LGL7 its segment has IR = 66 inputs, which puts a run-time compiled ODE with controls and
 // parameters through the four-wave dense kernel (tests/test_gpu_jit.py defines the same right-hand side in the DSL).
-template <class S>
-void coupled12(const S* y, S* f, const void*) {
-  const int n = 12;
-  const S& t = y[12];
-  const S* u = y + 13;
-  const S &p0 = y[16], &p1 = y[17];
+template <int n, class S>
+void coupled_n(const S* y, S* f) {
+  const S& t = y[n];
+  const S* u = y + n + 1;
+  const S &p0 = y[n + 4], &p1 = y[n + 5];
   for (int k = 0; k < n; k++)
     f[k] = -0.5 * y[k] + sin(y[(k + 1) % n]) * y[(k + 5) % n] * u[k % 3] + p0 * cos(t) + p1 * y[k] * y[(k + 7) % n];
 }
+template <class S>
+void coupled12(const S* y, S* f, const void*) { coupled_n<12>(y, f); }
+// (16,3,2): with BlockConstant control its LGL7 segment has IR = 73 -- the four-wave kernel with five parameter columns
+template <class S>
+void coupled16(const S* y, S* f, const void*) { coupled_n<16>(y, f); }
 
 // ------------------------------------------------------------------ a nonlinear path constraint, 2 outputs of 6 inputs
 // Not an ODE: the independent check for plain functions batched over applications (mode FUNCTION);

@@ -58,22 +58,27 @@ def make_vanderpol():
     return VanDerPol()
 
 
-def make_coupled12():
-    """A wider user-defined ODE, (12, 3, 2): x_k' = -x_k/2 + sin(x_{k+1}) x_{k+5} u_{k mod 3} + p0 cos t + p1 x_k x_{k+7}
-    (indices mod 12).  In LGL7 a segment has IR = 66 inputs, so its dense stage is the four-wave kernel -- with control
-    rows and parameter columns, which the 32-state BASELINE ODE does not have.  The oracle holds the same right-hand
-    side as ``coupled12`` (oracle/odes.h)."""
+def make_coupled(n: int = 12):
+    """A wider user-defined ODE, (n, 3, 2): x_k' = -x_k/2 + sin(x_{k+1}) x_{k+5} u_{k mod 3} + p0 cos t + p1 x_k x_{k+7}
+    (indices mod n).  n = 12: in LGL7 a segment has IR = 66 inputs, so its dense stage is the four-wave kernel -- with
+    control rows and parameter columns, which the 32-state BASELINE ODE does not have; n = 16: the BlockConstant form
+    (IR = 73) is wide too, with five parameter columns.  The oracle holds the same right-hand sides as ``coupled12`` /
+    ``coupled16`` (oracle/odes.h)."""
     from asset_asrl_amd import vf
     from asset_asrl_amd.ode import ODEArguments, ODEBase
 
-    class Coupled12(ODEBase):
+    class Coupled(ODEBase):
         def __init__(self):
-            a = ODEArguments(12, 3, 2)
+            a = ODEArguments(n, 3, 2)
             x = a.XVec().tolist()
             t, p0, p1 = a.TVar(), a.PVar(0), a.PVar(1)
             u = [a.UVar(k) for k in range(3)]
-            rhs = [-0.5 * x[k] + vf.sin(x[(k + 1) % 12]) * x[(k + 5) % 12] * u[k % 3] + p0 * vf.cos(t) + p1 * x[k] * x[(k + 7) % 12]
-                   for k in range(12)]
-            super().__init__(vf.stack(rhs), 12, 3, 2, name="coupled12")
+            rhs = [-0.5 * x[k] + vf.sin(x[(k + 1) % n]) * x[(k + 5) % n] * u[k % 3] + p0 * vf.cos(t) + p1 * x[k] * x[(k + 7) % n]
+                   for k in range(n)]
+            super().__init__(vf.stack(rhs), n, 3, 2, name=f"coupled{n}")
 
-    return Coupled12()
+    return Coupled()
+
+
+def make_coupled12():
+    return make_coupled(12)

@@ -6,7 +6,7 @@ import pytest
 
 from asset_asrl_amd import jit
 from asset_asrl_amd.evaluator import CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, DefectEvaluator
-from helpers import Workload, make_coupled12, make_vanderpol, rel_err
+from helpers import Workload, make_coupled, make_coupled12, make_vanderpol, rel_err
 from test_gpu_parity import _check_blocks
 
 pytestmark = pytest.mark.gpu
@@ -28,17 +28,19 @@ def test_jit_ode_matches_oracle(oracle, mode, blocked):
     ev.close()
 
 
-@pytest.mark.parametrize("mode,blocked", [("LGL7", False), ("LGL7", True), ("LGL5", False)])
-def test_wide_user_ode_with_controls_and_parameters(oracle, mode, blocked):
+@pytest.mark.parametrize("n,mode,blocked", [(12, "LGL7", False), (12, "LGL7", True), (12, "LGL5", False),
+                                            (16, "LGL7", True), (16, "LGL5", False)])
+def test_wide_user_ode_with_controls_and_parameters(oracle, n, mode, blocked):
     """(12, 3, 2) in LGL7: IR = 66 -> the four-wave dense kernel with control-interpolation rows and parameter columns
-    (csrc/defect_wide.h); BlockConstant and LGL5 forms of the same ODE take the single-wave kernel."""
+    (csrc/defect_wide.h); its BlockConstant and LGL5 forms take the single-wave kernel.  (16, 3, 2): the BlockConstant
+    LGL7 form (IR = 73, five parameter columns) and the LGL5 form (IR = 62, narrow) of a second size."""
     from asset_asrl_amd.evaluator import JAC_ADJGRAD_HESS as KIND
-    name = jit.ensure_kernel(make_coupled12(), mode, blocked)
-    w = Workload("coupled12", mode, 29, blocked, sizes=(12, 3, 2), var_offset=2, con_offset=1, extra_vars=3)
-    nlp = oracle.Nlp(oracle.get_ode("coupled12", 0), oracle.MODES[mode], w.blocked, w.vindex, w.cindex, w.n_primal,
+    name = jit.ensure_kernel(make_coupled(n), mode, blocked)
+    w = Workload(f"coupled{n}", mode, 29, blocked, sizes=(n, 3, 2), var_offset=2, con_offset=1, extra_vars=3)
+    nlp = oracle.Nlp(oracle.get_ode(f"coupled{n}", 0), oracle.MODES[mode], w.blocked, w.vindex, w.cindex, w.n_primal,
                      w.n_equal, 2)
     ev = DefectEvaluator(name, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
-    assert ev.IR == (4 if mode == "LGL7" else 3) * (13 if blocked else 16) + (5 if blocked else 2)
+    assert ev.IR == (4 if mode == "LGL7" else 3) * (n + 1 if blocked else n + 4) + (5 if blocked else 2)
     for what in (KIND, CON, CON_ADJGRAD, JAC, JAC_ADJGRAD):
         ref = nlp.eval_blocks(what, w.X, w.L)
         got = ev.eval(what, w.X, w.L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
