@@ -347,11 +347,25 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
                 o.append("    " + extra_stmt.format(k, p.ref(node)))
         o.append("  }")
 
+    def share_order(outs):
+        """Greedy order of a part's outputs: next comes the one that shares the most with what is already computed
+        (ties: the one that adds the least).  The statements are emitted depth-first per output, so this keeps the
+        values several outputs need close to all of their uses: Betts' Hessian part peaks at 294 live values instead
+        of 394 in row-major order (column-major 328, random 410-460)."""
+        sub = [set(x.id for x in topo_order([r]) if x.args) for _, r in outs]
+        done, rem, order = set(), list(range(len(outs))), []
+        while rem:
+            k = max(rem, key=lambda k: (len(sub[k] & done), -len(sub[k] - done), -k))
+            rem.remove(k)
+            order.append(outs[k])
+            done |= sub[k]
+        return order
+
     def two_parts(name, use_saved):
         outs = outputs(2)
         nfjg = n + n * N + N
-        body(name + "_fjg_", outs[:nfjg], use_saved=use_saved, q="__attribute__((noinline))")
-        body(name + "_h_", outs[nfjg:], use_saved=use_saved, q="__attribute__((noinline))")
+        body(name + "_fjg_", outs[:nfjg], use_saved=use_saved, q="__attribute__((noinline))")   # (ordering it too: no change)
+        body(name + "_h_", share_order(outs[nfjg:]), use_saved=use_saved, q="__attribute__((noinline))")
         o.append("  " + sig.format(q="inline", name=name) + " {")
         o.append(f"    {name}_fjg_(in, out);")
         o.append(f"    {name}_h_(in, out);")
