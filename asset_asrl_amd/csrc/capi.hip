@@ -221,8 +221,15 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
     for (int level = 1; level <= 2; level++) {
       const size_t nb = ke->lane_bytes(level);
       if (!nb) continue;
-      if ((e = hipMalloc(&h->d_lane[level], nb)) != hipSuccess) return bail(e, "hipMalloc(lane constants)");
+      // ASSET_LANE_REPLICAS copies: every workgroup of the dense stage loads the whole table when it starts, all at the
+      // same moment -- with one copy that is thousands of requests for the same few hundred cache lines, which the L2
+      // channels holding them serve one after the other; workgroup b reads copy b % ASSET_LANE_REPLICAS.
+      if ((e = hipMalloc(&h->d_lane[level], nb * ASSET_LANE_REPLICAS)) != hipSuccess) return bail(e, "hipMalloc(lane constants)");
       if ((e = ke->lane_setup(level, h->d_lane[level], h->stream)) != hipSuccess) return bail(e, "lane_setup_kernel");
+      for (int r = 1; r < ASSET_LANE_REPLICAS; r++)
+        if ((e = hipMemcpyAsync(static_cast<char*>(h->d_lane[level]) + size_t(r) * nb, h->d_lane[level], nb,
+                                hipMemcpyDeviceToDevice, h->stream)) != hipSuccess)
+          return bail(e, "hipMemcpy(lane constants)");
     }
   if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail(e, "lane_setup_kernel");
   if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");

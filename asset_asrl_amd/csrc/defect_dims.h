@@ -18,6 +18,10 @@
 #define ASSET_DENSE_WAVES_PER_SIMD 2  // register budget of the dense-phase kernel: 512 / 2 = 256 per lane
 #endif
 
+#ifndef ASSET_LANE_REPLICAS
+#define ASSET_LANE_REPLICAS 64        // copies of the dense stage's per-lane constant table (capi.hip)
+#endif
+
 namespace asset_hip {
 
 static __constant__ LglTab d_lgl_tab[4] = ASSET_LGL_TABLE_INIT;
@@ -154,6 +158,11 @@ struct Dims {
   // (not for Trapezoidal: its interior sections are never written and must read as the zeros the workspace is created with)
   static constexpr bool MIRROR = !TRAP && STAGED && size_t(TABSZ + LC * STG_LD + GM * MSLOT) * 8 <= 40 * 1024;
   static constexpr int WSLOT = MIRROR ? w_SV : w_SV + CS * Ode::NSAVE;   // (the saved values live in the mirror when there is one)
+  // Fused single launch (defect_kernels.h, STAGE 3): the ODE stage of a wave's own GF segments runs in the LDS the
+  // dense phase needs anyway (rows of GF*CS points and GF mirror slots alias the slot buffer and the dense scratch).
+  static constexpr int GF_FIT = int((size_t(DENSE) * 8) / (size_t(CS * STG_LD + MSLOT) * 8));
+  static constexpr int GF = GF_FIT < 64 / CS ? GF_FIT : 64 / CS;
+  static constexpr bool FUSED = MIRROR && STAGED && LC == 64 && !WIDE && GF >= 2;
   // LDS of the two launches: [weight tables | staging rows | mirror] and [weight tables | slot buffer | dense scratch]
   static constexpr size_t lds_bytes_ode() { return size_t(TABSZ + (STAGED ? LC * STG_LD : 0) + (MIRROR ? GM * MSLOT : 0)) * 8; }
   static constexpr size_t lds_bytes_dense() { return size_t(TABSZ + DENSE) * 8; }
@@ -182,6 +191,9 @@ struct RegIn {
 };
 // LDS-address-space pointer: stores through it are ds_write (tracked by lgkmcnt only), never flat
 typedef __attribute__((address_space(3))) double lds_double;
+// global-address-space pointer: stores through it are global_store even inside an out-of-line device function (a
+// generic pointer there means flat_store, which also occupies the LDS counter)
+typedef __attribute__((address_space(1))) double glb_double;
 
 template <class D, bool ACCG = false, bool MIR = false, bool MF = false, bool MG = false>
 struct OdeOutStaged {  // f, g -> workspace slot (few scalars); J, H non-zeros -> this lane's LDS staging row [J | H]
@@ -238,6 +250,14 @@ __device__ constexpr bool tiles_share_node(int ct, int rt) {
 // need the compiler kept from reordering (and the reads returned); crucially this does NOT wait for outstanding
 // global stores the way __syncthreads() (vmcnt(0)) does -- the block stores of a segment drain behind the next one.
 __device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Waits until every outstanding vector-memory operation of the wave has completed (s_waitcnt vmcnt(0) as a compiler
+// builtin, so the waitcnt insertion pass knows that no load is pending afterwards).  gfx9 counts loads and stores in
+// the one in-order vmcnt: a wait for a load that was issued before some stores whose number the compiler cannot count
+// (stores under lane conditions) becomes vmcnt(0) and drains those stores too.  Loops that prefetch while they store
+// therefore call this once per iteration, after the last load has been issued and before the first store: the loads
+// are then known to have landed and nothing later in the iteration waits on vmcnt, so the stores drain behind the
+// next iteration's compute.   encoding: vmcnt = 0 (bits 3:0 and 15:14), expcnt = 7 (6:4), lgkmcnt = 15 (11:8)
+__device__ inline void wave_loads_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // Hand-offs through the global workspace (same wave writes, then reads): wait for the stores as well.
 __device__ inline void wave_mem_sync() { __syncthreads(); }
 

@@ -173,6 +173,245 @@ __device__ inline void copy_rows(const double* stage, int stg_ld, int npt, int e
   }
 }
 
+// ---------------------------------------------------------------------------------------------- pipelined ODE stage
+// (PIPE shapes: derivative level 2, LDS mirror, staged rows, one pass per phase.)  gfx9 tracks loads and stores in one
+// in-order vmcnt, a non-inlined device function drains it on entry AND before it returns, and a wait for any load that
+// follows stores under lane conditions becomes vmcnt(0).  In the plain layout of the stage that serialised: the gather's
+// stores (one full round trip each), every phase's own result stores (drained at its return) and -- the large one --
+// the coalesced copy-out of a phase's J / H rows, which the next phase's entry waited for at the HBM write rate with
+// every workgroup of the device doing the same at the same moment.  Here
+//   * the ODE bodies write LDS only (staging row, mirror; f^ in the rows the interior phase leaves unused), except g_j;
+//   * the copy-out of the interior rows is issued INSIDE the out-of-line function of the next phase, behind its entry
+//     wait, so it drains under that phase's arithmetic (its exit wait then finds the stores done);
+//   * what the dense stage needs of the mirror (z, lam, f_j, g^_i) is copied once, coalesced, at the end of the group.
+template <class D, bool HASROW, bool FL, bool FG, bool GL, bool GG, bool SV>
+struct OdeOutPipe {
+  lds_double* row_;     // [J | H] staging row of this lane
+  lds_double* fl_;      // LDS destination of f (FL)
+  glb_double* fg_;      // global destination of f (FG)
+  lds_double* gl_;      // LDS destination of g (GL)
+  glb_double* gg_;      // global destination of g (GG)
+  lds_double* sv_;      // saved transcendentals (SV)
+  __device__ void f(int k, double v) {
+    if constexpr (FL) fl_[k] = v;
+    if constexpr (FG) fg_[k] = v;
+  }
+  __device__ void J(int k, int i, double v) {
+    if constexpr (HASROW) { const int c = D::ode_t::JPOS[k * D::N + i]; if (c >= 0) row_[c] = v; }
+  }
+  __device__ void g(int i, double v) {
+    if constexpr (GL) gl_[i] = v;
+    if constexpr (GG) gg_[i] = v;
+  }
+  __device__ void H(int i, int j, double v) {
+    if constexpr (HASROW) { const int c = D::ode_t::HPOS[i * (i + 1) / 2 + j]; if (c >= 0) row_[D::NZJ + c] = v; }
+  }
+  __device__ void save(int k, double v) { if constexpr (SV) sv_[k] = v; }
+};
+
+template <class D, int GP>
+struct PipeDims {   // GP = segments per group: 64 / CS in the ODE-stage launch, Dims::GF in the fused kernel
+  static constexpr int K = D::K, CS = D::CS, n = D::n;
+  // f^_i of the interior phase: staged in the rows that phase leaves unused (GP*K of the GP*CS), else stored directly
+  static constexpr bool IFROW = (GP * CS - GP * K) * D::STG_LD >= GP * K * n;
+  static constexpr int if_off = GP * K * D::STG_LD;     // (doubles from the start of the staging rows)
+};
+
+// P1: f_j and its transcendental sub-expressions -> mirror.  No global store.
+template <class Ode, class D>
+__device__ __attribute__((noinline)) void pipe_cardinal_value(lds_double* M, int j, const double* X, const int* vi) {
+  OdeOutPipe<D, false, true, false, false, false, true> out{nullptr, M + D::m_Cf + j * D::n, nullptr, nullptr, nullptr,
+                                                           M + D::m_SV + j * Ode::NSAVE};
+  GatherIn<D> in{X, vi, j};
+  Ode::f_save(in, out);
+}
+
+// P2: interior point i of one segment: J^, H^ -> row; g^ -> mirror; f^ -> spare rows (or the slot).
+template <class Ode, class D, bool IFROW>
+__device__ __attribute__((noinline)) void pipe_interior(glb_double* S, lds_double* M, int i, const LglTab* tabp, lds_double* row,
+                                                        lds_double* ifrow) {
+  constexpr int n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, CS = D::CS;
+  const LglTab& tab = *tabp;
+  const lds_double* z = M + D::m_z;
+  const lds_double* Cf = M + D::m_Cf;
+  const lds_double* lam = M + D::m_lam;
+  const double h = z[D::TF] - z[T];
+  double y[N];
+  double li[n > 0 ? n : 1];
+#pragma unroll
+  for (int k = 0; k < n; k++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * Cf[j * n + k]);
+    y[k] = acc;
+  }
+  y[T] = z[T] + h * tab.s[i];
+#pragma unroll
+  for (int k = 0; k < m; k++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < CS; j++) acc += tab.U[i][j] * z[j * q + n + 1 + k];
+    y[n + 1 + k] = acc;
+  }
+#pragma unroll
+  for (int k = 0; k < p; k++) y[q + k] = z[D::P0 + k];
+#pragma unroll
+  for (int k = 0; k < n; k++) li[k] = lam[i * n + k];
+  RegIn<D> in{y, li};
+  OdeOutPipe<D, true, IFROW, !IFROW, true, false, false> out{
+      row, ifrow, S + D::w_If + i * n, M + D::m_Ig + i * N, nullptr, nullptr};
+  Ode::fjgh(in, out);
+}
+
+// Coalesced copy of `npt` staging rows ([J | H], NSTG doubles each) to the workspace sections (wJ, wH) of the points
+// they belong to: point e = g * PER + k of segment g.  Four elements per lane in flight.
+template <class D, int PER>
+__device__ inline void pipe_copy_rows(const lds_double* stage, int npt, int lane, glb_double* Wg, int wJ, int wH) {
+  constexpr int NC = D::NSTG, RSTEP = 64 / NC, KSTEP = 64 % NC;
+  int row = lane / NC, k = lane - row * NC;
+  const int total = npt * NC;
+  for (int base = 0; base < total; base += 256) {
+    double v[4];
+    glb_double* d[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      ok[u] = base + 64 * u + lane < total;
+      v[u] = stage[ok[u] ? row * D::STG_LD + k : 0];
+      const int g = row / PER, i = row - g * PER;
+      d[u] = Wg + g * D::WSLOT + ((k < D::NZJ) ? (wJ + i * D::NZJ + k) : (wH + i * D::NZH + (k - D::NZJ)));
+      row += RSTEP;
+      k += KSTEP;
+      if (k >= NC) { k -= NC; row++; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (ok[u]) *d[u] = v[u];
+  }
+}
+
+// P3 of a whole group: first the copy-out of the interior phase (rows + staged f^), then -- while those stores drain --
+// the cardinal second derivatives of this lane's point into the same rows.  g_j goes straight to the slot.
+template <class Ode, class D, int GP>
+__device__ __attribute__((noinline)) void pipe_cardinal_second(glb_double* Wg, lds_double* mirror, lds_double* stage,
+                                                               const LglTab* tabp, int gcount, int lane) {
+  constexpr int K = D::K, n = D::n, N = D::N, T = D::T, CS = D::CS;
+  if constexpr (!D::TRAP) {
+    if constexpr (D::NSTG > 0) pipe_copy_rows<D, K>(stage, gcount * K, lane, Wg, D::w_IJ, D::w_IH);
+    if constexpr (PipeDims<D, GP>::IFROW) {
+      for (int e = lane; e < gcount * K * n; e += 64) {
+        const int g = e / (K * n);
+        Wg[g * D::WSLOT + D::w_If + (e - g * K * n)] = stage[PipeDims<D, GP>::if_off + e];
+      }
+    }
+    wave_lds_sync();   // the rows are free once their reads have returned (the stores carry the data in registers)
+  }
+  if (lane < gcount * CS) {
+    const int g = lane / CS, j = lane - g * CS;
+    const LglTab& tab = *tabp;
+    const lds_double* M = mirror + g * D::MSLOT;
+    const lds_double* z = M + D::m_z;
+    const double h = z[D::TF] - z[T];
+    double w[n > 0 ? n : 1];
+#pragma unroll
+    for (int k = 0; k < n; k++) {  // C_AVS[j]  (LGLDefects.h:369-374)
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        acc += M[D::m_Ig + i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
+        acc += M[D::m_lam + i * n + k] * (tab.D[i][j] * h);
+      }
+      w[k] = acc;
+    }
+    CardIn<D, const lds_double*> in{z, w, j, M + D::m_SV + j * Ode::NSAVE};
+    OdeOutPipe<D, true, false, false, false, true, false> out{stage + lane * D::STG_LD, nullptr, nullptr, nullptr,
+                                                              Wg + g * D::WSLOT + D::w_Cg + j * N, nullptr};
+    Ode::fjgh_load(in, out);   // the transcendental sub-expressions of f at this node were stored by P1
+  }
+}
+
+// Coalesced copy of NW consecutive doubles of every segment's mirror slot (from m0) to its workspace slot (from w0).
+template <class D, int NW>
+__device__ inline void pipe_copy_mirror(const lds_double* mirror, int gcount, int lane, glb_double* Wg, int m0, int w0) {
+  const int total = gcount * NW;
+  for (int base = 0; base < total; base += 256) {
+    double v[4];
+    glb_double* d[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = base + 64 * u + lane;
+      ok[u] = e < total;
+      const int g = ok[u] ? e / NW : 0, r = ok[u] ? e - g * NW : 0;
+      v[u] = mirror[g * D::MSLOT + m0 + r];
+      d[u] = Wg + g * D::WSLOT + w0 + r;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (ok[u]) *d[u] = v[u];
+  }
+}
+
+// The ODE stage of one group of at most GP segments (lane <-> evaluation point, one pass per phase).
+template <class Ode, class D, int GP, class Pub>
+__device__ inline void pipe_ode_group(const EvalArgs& a, int lane, int seg0, int gcount, double* Wg, double* stage,
+                                      lds_double* mirror, const LglTab* tabp, Pub&& publish_tables) {
+  constexpr int CS = D::CS, K = D::K, n = D::n, N = D::N, IR = D::IR, OR = D::OR, STG_LD = D::STG_LD;
+  static_assert(GP * CS <= 64, "one pass per phase");
+  {   // P0: gather into the mirror only -- index loads, value loads, LDS writes; no store to wait behind
+    constexpr int NZ = (GP * IR + 63) / 64, NL = (GP * OR + 63) / 64;
+    const int* vseg = a.vindex + size_t(seg0) * IR;      // this group's Vindex / Cindex columns are contiguous
+    const int* cseg = a.cindex + size_t(seg0) * OR;
+    int vi[NZ], ci[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) vi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : -1;
+#pragma unroll
+    for (int t = 0; t < NL; t++) ci[t] = (lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : -1;
+    double zv[NZ], lv[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) zv[t] = (vi[t] >= 0) ? a.X[vi[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NL; t++) lv[t] = (ci[t] >= 0) ? a.L[ci[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NZ; t++) {
+      const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
+      if (e < gcount * IR) mirror[g * D::MSLOT + D::m_z + r] = zv[t];
+    }
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
+      if (e < gcount * OR) mirror[g * D::MSLOT + D::m_lam + r] = lv[t];
+    }
+  }
+  if (lane < gcount * CS) {          // P1 (reads the solver vector itself: its loads overlap the gather's)
+    const int g = lane / CS, j = lane - g * CS;
+    pipe_cardinal_value<Ode, D>(mirror + g * D::MSLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
+  }
+  wave_lds_sync();
+  publish_tables();
+  if constexpr (!D::TRAP) {          // P2
+    if (lane < gcount * K) {
+      const int g = lane / K, i = lane - g * K;
+      pipe_interior<Ode, D, PipeDims<D, GP>::IFROW>((glb_double*)Wg + g * D::WSLOT, mirror + g * D::MSLOT, i, tabp,
+                                                    (lds_double*)(stage + lane * STG_LD),
+                                                    (lds_double*)(stage + PipeDims<D, GP>::if_off + lane * n));
+    }
+    wave_lds_sync();
+  }
+  // P3, preceded (inside the function) by the copy-out of P2
+  pipe_cardinal_second<Ode, D, GP>((glb_double*)Wg, mirror, (lds_double*)stage, tabp, gcount, lane);
+  wave_lds_sync();
+  pipe_copy_rows<D, CS>((const lds_double*)stage, D::NSTG > 0 ? gcount * CS : 0, lane, (glb_double*)Wg, D::w_CJ, D::w_CH);
+  {   // what the dense stage reads of the mirror: [z | lam | f_j] (contiguous in both layouts) and g^_i
+    constexpr int NA = IR + OR + CS * n, NB = K * N;
+    static_assert(D::w_z == 0 && D::w_lam == IR && D::w_Cf == IR + OR && D::m_z == 0 && D::m_lam == IR && D::m_Cf == IR + OR,
+                  "slot and mirror share the layout of their first three sections");
+    pipe_copy_mirror<D, NA>(mirror, gcount, lane, (glb_double*)Wg, 0, 0);
+    pipe_copy_mirror<D, NB>(mirror, gcount, lane, (glb_double*)Wg, D::m_Ig, D::w_Ig);
+  }
+  wave_lds_sync();   // (whatever follows rewrites the mirror and the rows)
+}
+
 // Per-lane constants of the dense stage: every index decode, table weight, fragment offset and store offset that
 // depends only on the lane, never on the segment.  They are the same for every workgroup of every launch of a handle,
 // and deriving them costs ~10 k cycles (dependent look-ups in the sparsity tables), a quarter of the time a workgroup
@@ -347,8 +586,12 @@ __global__ __launch_bounds__(64) void lane_setup_kernel(unsigned int* out) {
 // STAGE 1: ODE phases only (P0-P3; results -> workspace slot of every segment).  STAGE 2: dense phase only (P4).
 // They are separate launches because their resource shapes differ: the ODE bodies need ~250 VGPRs and wide LDS
 // staging rows, the dense phase needs few registers and 23 KiB of LDS, so it runs at a higher occupancy.
+// STAGE 3: both in one launch (FUSED shapes, derivative level 2, meshes of at most GF segments per workgroup): every
+//          wave runs the ODE stage for its own few segments, waits for its own slot stores and goes on with the dense
+//          phase -- one ramp-up (dispatch, first loads, cold instruction cache) per evaluation instead of two, no
+//          device-wide drain of the slot stores between the stages, and the slots are read back from L2.
 template <class Ode, int SCH, bool BLOCKED, int G, int LEVEL, int STAGE, bool ASM = false>
-__global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
+__global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
                                                    ? ASSET_DENSE_WAVES_PER_SIMD : 1)   // LDS-bound to one wave per SIMD anyway: take the registers
                                              : ASSET_ODE_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
   using D = Dims<Ode, SCH, BLOCKED>;
@@ -366,8 +609,13 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   double* slotb = body;
   double* scr = body + D::WSLOTD;
   double* stage = body;
+  static_assert(STAGE != 3 || (D::FUSED && LEVEL == 2), "no fused kernel for this shape / level");
   constexpr bool MIR = D::MIRROR && LEVEL >= 1 && STAGE == 1;
-  lds_double* const mirror = (lds_double*)(body + LC * STG_LD);   // [G][MSLOT] (ODE stage, MIR)
+#ifndef ASSET_ODE_PIPE
+#define ASSET_ODE_PIPE 1
+#endif
+  constexpr bool PIPE = ASSET_ODE_PIPE && MIR && LEVEL == 2 && D::STAGED && LC == 64 && G * CS <= 64;
+  lds_double* const mirror = (lds_double*)(body + (STAGE == 3 ? D::GF * CS : LC) * STG_LD);   // [G][MSLOT] (ODE stage, MIR)
   static_assert(!MIR || G <= D::GM, "the LDS mirror holds one slot per segment of a group");
   const int lane = threadIdx.x;
   const int lr = lane & 15, lk = lane >> 4;
@@ -404,13 +652,22 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   // slot offset of dfdy_j[r][cc] for run-time indices (the rare paths; table look-ups)
   auto cj_at = [](int j, int r, int cc) { const int jp = Ode::JPOS[r * N + cc]; return jp >= 0 ? D::w_CJ + j * D::NZJ + jp : ZERO; };
   (void)cj_at;
+  if constexpr (STAGE == 3) {
+    // the workgroup's segments are one group (the host sizes the grid so): ODE stage first, while the kernel holds
+    // nothing else in registers; its results go to the slots and are read back below once the stores have landed
+    pipe_ode_group<Ode, D, D::GF>(a, lane, wg_first, min(wg_count, D::GF), a.work + size_t(wg_first) * D::WSLOT, stage, mirror,
+                                  &tab, publish_tables);
+  }
   LaneRecord<LCT> lrec;
-  if constexpr (STAGE == 2 && LEVEL >= 1) {              // computed once per handle (lane_setup_kernel)
+  if constexpr (STAGE >= 2 && LEVEL >= 1) {              // computed once per handle (lane_setup_kernel)
+    const unsigned int* rec = static_cast<const unsigned int*>(a.lane_consts) +
+                              size_t(blockIdx.x % ASSET_LANE_REPLICAS) * (LaneRecord<LCT>::NW * 64);   // this workgroup's copy
 #pragma unroll
-    for (int k = 0; k < LaneRecord<LCT>::NW; k++) lrec.w[k] = static_cast<const unsigned int*>(a.lane_consts)[k * 64 + lane];
+    for (int k = 0; k < LaneRecord<LCT>::NW; k++) lrec.w[k] = rec[k * 64 + lane];
   }
   const LCT& lc = lrec.lc;
-  if constexpr (STAGE != 1) publish_tables();            // after the record loads are in flight: one latency, not two
+  if constexpr (STAGE == 2) publish_tables();            // after the record loads are in flight: one latency, not two
+  if constexpr (STAGE == 3) wave_loads_landed();         // the slot stores of the ODE stage (and the record loads)
   const auto& wa = lc.wa;
   const auto& wb = lc.wb;
   const auto& wa2 = lc.wa2;
@@ -440,14 +697,24 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
 #define TS() do {} while (0)
 #endif
 // sub-phase stamps of the dense stage, taken for the second segment of the workgroup (-DASSET_TIMING, tools/dbg_time.py)
-#define TSG() do { if (g == 1) TS(); } while (0)
+#ifndef ASSET_TSG_SEG
+#define ASSET_TSG_SEG 1
+#endif
+#define TSG() do { if (g == ASSET_TSG_SEG) TS(); } while (0)
   for (int g0 = 0; g0 < wg_count; g0 += G) {
     const int seg0 = wg_first + g0;
     TS();
     const int gcount = min(G, wg_count - g0);
     double* Wg = a.work + size_t(seg0) * D::WSLOT;  // ODE result slots of this group's segments (HBM / L2)
 
-    if constexpr (STAGE == 1) {
+    if constexpr (STAGE == 1 && PIPE) {
+      // ---------------------------------------------------------------- pipelined ODE stage (see OdeOutPipe above)
+      bool first = (g0 == 0);
+      pipe_ode_group<Ode, D, G>(a, lane, seg0, gcount, Wg, stage, mirror, &tab, [&]() { if (first) publish_tables(); });
+      TS();
+      continue;
+    }
+    if constexpr (STAGE == 1 && !PIPE) {
     // ------------------------------------------------------------------ P0: gather z = X[Vindex], lam = L[Cindex]
     // Two dependent HBM round trips (index, then value): every index load is issued before the first value load,
     // so the whole gather costs two latencies instead of two per 64 elements.
@@ -605,6 +872,9 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
     }
     if (lane < 2) scr[D::s_Z0 + lane] = 0.0;
     wave_lds_sync();
+    // No load may be outstanding when the segment loop is entered (see wave_loads_landed): the first slot's loads have
+    // had the constant-tile build to arrive.
+    wave_loads_landed();
 
     TS();
     // ------------------------------------------------------------------ P4: per-segment dense phase
@@ -691,6 +961,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       wave_lds_sync();
       TSG();   // D1: DI / DC tiles
       // time columns: DI rows -+ sum_j B_ij f_j (LGLDefects.h:446-450), DC rows -+ (sum_j D_ij f_j + E_i f^_i) (:484-500)
+      double fx_hold = 0.0;
       auto time_columns = [&](int e, auto own_) {
         constexpr bool own = decltype(own_)::value;      // first pass: the weights are the precomputed per-lane ones
         const int i = e / n, r = e - i * n;
@@ -709,15 +980,15 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
         DIx[e * IRP + TF] = ditf + sb;
         DC[e * D::LDC + T] = dct - sd;
         DC[e * D::LDC + TF] = dctf + sd;
-        if (a.FX) {                                      // defect value of row (i,r)  (LGLDefects.h:96-103)
-          double fxv = h * sd;
+        double fxv = h * sd;                             // defect value of row (i,r)  (LGLDefects.h:96-103)
 #pragma unroll
-          for (int jj = 0; jj < CS; jj++) fxv += (own ? tC[jj] : tab.C[i][jj]) * zv[jj];
-          a.FX[seg * OR + e] = fxv;
-        }
+        for (int jj = 0; jj < CS; jj++) fxv += (own ? tC[jj] : tab.C[i][jj]) * zv[jj];
+        if constexpr (own) fx_hold = fxv;                // stored with the segment's other results (after the load fence)
+        else if (a.FX) a.FX[seg * OR + e] = fxv;
       };
       if (lane < ROWS) time_columns(lane, std::true_type{});
       if constexpr (ROWS > 64) {
+        wave_loads_landed();                             // (stores follow: see below)
         for (int e = lane + 64; e < ROWS; e += 64) time_columns(e, std::false_type{});
       }
       wave_lds_sync();
@@ -803,6 +1074,15 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
 #pragma unroll
         for (int t = 0; t < D::TI * D::TJ; t++) load_jmap(t);
       }
+      // Every load of this iteration (the next slot, the map entries) has been issued; from here on the segment only
+      // stores.  store_fence() is called once, right before the first store: it waits for those loads -- and, vmcnt
+      // being one in-order counter on gfx9, for the previous segment's stores, which have had this segment's tile build
+      // and first product to drain.  Without it the compiler cannot count the (conditional) stores that follow the
+      // loads and waits with vmcnt(0) where the prefetched slot is consumed at the top of the next iteration, i.e. for
+      // every store of this segment: the block stores then never overlap any compute of the wave that issued them.
+      // (One unconditional call site per instantiation: the waitcnt pass is path-insensitive, a fence under a lane- or
+      // pointer-condition does not count.)
+      constexpr int FENCE_AT = JFUSE ? 0 : (HOLD ? 2 : 1);
       // The product phases run at raised wave priority: the two waves of a SIMD otherwise walk through the same
       // phases nearly in step and the LDS / VALU / MFMA pipes take turns; any asymmetry in arbitration helps (measured
       // 0.5 us, the same for every priority assignment tried).
@@ -858,6 +1138,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
             for (int v = 0; v < 4; v++) HI[16 * ct + lk + 4 * v] = hi_acc[ct][v];
         }
         // J^T = interior part + cardinal part DC^T; stored right away (its registers are free for the H products)
+        if constexpr (FENCE_AT == 0) wave_loads_landed();
         if (kkt_dst) {
 #pragma unroll
           for (int ct = 0; ct < D::TI; ct++) {
@@ -936,6 +1217,7 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       }
 
       // ---- D4: H (lower-triangle tiles) and J^T
+      if constexpr (FENCE_AT == 1) wave_loads_landed();    // tiles are stored as they complete
       if constexpr (LEVEL >= 2) {
         // rank-2 time fragments: k=0 -> (A: d, B: HT), k=1 -> (A: HT, B: d), k=2,3 -> 0
         double a2[D::TI], b2[D::TI];
@@ -1010,6 +1292,8 @@ __global__ __launch_bounds__(64, STAGE == 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       TSG();   // D4: H (and J) products
       // ---- D5: adjoint gradient  g = J^T lam  without touching the J tile:
       //      interior part  h * sum_i E_i g^_i^T DI_i  (= h * HI), cardinal part = DC^T lam
+      if constexpr (FENCE_AT == 2) wave_loads_landed();
+      if (a.FX && lane < ROWS) a.FX[seg * OR + lane] = fx_hold;
       if (a.AGX) {
         for (int c = lane; c < IR; c += 64) {
           double v = 0.0;

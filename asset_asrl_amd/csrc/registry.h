@@ -113,6 +113,14 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
       else ASSET_LAUNCH_DENSE(1, false);
       return hipSuccess;
     case 2:
+      if constexpr (D::FUSED) {
+        // single launch when every workgroup's share fits one group of the fused kernel (defect_kernels.h, STAGE 3)
+        static const bool no_fuse = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                               // tuning only
+        if (!a.kmap && !no_fuse && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= D::GF) {
+          ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 3, false>), grid_b, 64, bytes_dense);
+          return hipSuccess;
+        }
+      }
       ASSET_LAUNCH(2, 1, grid_a, bytes_ode);
       if (skip_dense) return hipSuccess;
       if (a.kmap) ASSET_LAUNCH_DENSE(2, true);

@@ -3,18 +3,38 @@
 Segments are independent given X and L (every application reads only its own Vindex/Cindex column,
 /root/reference/src/VectorFunctions/DenseFunctionBase.h:1296-1312), so the evaluation itself needs no
 collective: rank r evaluates the contiguous range the reference's ByApplication rule would give thread r
-(/root/reference/src/VectorFunctions/IndexingData.h:117-146).  The only exchange step is the optional gather of
-the per-shard FX / AGX / KKT blocks to the rank that owns the host KKT system (`gather_blocks`): disjoint
-blocks, no reduction -- boundary-node Hessian entries are emitted by both neighbours and summed by the
-scatter, exactly as on one device.
+(/root/reference/src/VectorFunctions/IndexingData.h:117-146; the worker launch it replaces:
+/root/reference/src/Solvers/NonLinearProgram.cpp:519-526).  The one exchange step of a solver iteration is the
+gather of the per-shard FX / AGX / KKT blocks to the rank that owns the host KKT system: disjoint blocks, no
+reduction -- boundary-node Hessian entries are emitted by both neighbours and summed by the scatter, exactly as on
+one device.
+
+Device-resident path (``alloc_device`` / ``eval_device`` / ``gather_device``): every rank owns ONE flat buffer in
+HBM, ``[fx | agx | kkt]`` sized for the largest shard, that the evaluation kernels write in place; the exchange is a
+single ``dist.gather`` of that buffer into the root's ``[world, slot]`` receive buffer (RCCL: grouped send/recv over
+xGMI, every peer on its own link).  Nothing touches the host.  Shards differ by at most one segment, so the padding is
+at most one segment per rank; ``blocks_on_root`` returns views when the shards are equal and compacts otherwise.
+
+``PhaseShardedEvaluator`` is the multi-phase form (BASELINE.json configs[3]: eight linked phases): whole phases are
+dealt to the ranks round-robin -- phases are independent given X and L too
+(/root/reference/src/OptimalControl/OptimalControlProblem.cpp:115-155) -- and gathered the same way.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Callable, List, Optional, Sequence
 
 import numpy as np
 
 from .indexing import thread_split
+
+_ADJ = (1, 3, 4)     # evaluation kinds that produce an adjoint gradient (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS)
+
+
+def _sizes(ode, mode, blocked):
+    from . import _lib, synth
+    from .build import dims
+    d = dims(*_lib.ode_sizes(ode), synth.MODE_CS[mode] if isinstance(mode, str) else max(mode, 2), blocked)
+    return d["IR"], d["OR"], d["NKKT"]
 
 
 class ShardedDefectEvaluator:
@@ -42,19 +62,80 @@ class ShardedDefectEvaluator:
                                         cindex[self.start:self.start + self.count], n_primal, n_equal, device)
             self.IR, self.OR, self.NKKT = self.ev.IR, self.ev.OR, self.ev.NKKT
         else:
-            from .build import dims
-            from . import _lib, synth
-            d = dims(*_lib.ode_sizes(ode), synth.MODE_CS[mode] if isinstance(mode, str) else max(mode, 2), blocked)
-            self.IR, self.OR, self.NKKT = d["IR"], d["OR"], d["NKKT"]
+            self.IR, self.OR, self.NKKT = _sizes(ode, mode, blocked)
+        self._local = self._recv = None
 
-    # ---- local evaluation ------------------------------------------------------------------
+    # ---- local evaluation (host arrays) -----------------------------------------------------
     def eval_local(self, what: int, X, L=None):
         """Host-pointer evaluation of this rank's shard -> (fx, agx, kkt) numpy blocks (or empty arrays)."""
         if self.ev is None:
             return (np.zeros((0, self.OR)), np.zeros((0, self.IR)), np.zeros((0, self.NKKT)))
         return self.ev.eval(what, X, L)
 
-    # ---- exchange --------------------------------------------------------------------------
+    # ---- device-resident evaluation + exchange ---------------------------------------------
+    @property
+    def slot_doubles(self) -> int:
+        """Length of a rank's flat output buffer: [fx | agx | kkt] for max_count segments."""
+        return self.max_count * (self.OR + self.IR + self.NKKT)
+
+    def _views(self, flat, count=None):
+        m = self.max_count
+        o1, o2 = m * self.OR, m * (self.OR + self.IR)
+        fx, agx, kkt = flat[:o1].view(m, self.OR), flat[o1:o2].view(m, self.IR), flat[o2:].view(m, self.NKKT)
+        if count is not None:
+            fx, agx, kkt = fx[:count], agx[:count], kkt[:count]
+        return fx, agx, kkt
+
+    def alloc_device(self, device, dst: int = 0):
+        """Allocate the flat output buffer on `device` (and the receive buffer on rank `dst`).  The padding segment of
+        a shorter shard is zero and stays zero."""
+        import torch
+        self._dst = dst
+        self._local = torch.zeros(self.slot_doubles, dtype=torch.float64, device=device)
+        self.fx, self.agx, self.kkt = self._views(self._local)
+        if self.rank == dst and self.world > 1:
+            self._recv = torch.empty((self.world, self.slot_doubles), dtype=torch.float64, device=device)
+        return self
+
+    def eval_device(self, what: int, X, L=None, stream=None):
+        """Evaluate this rank's shard into its flat buffer (enqueued on `stream`, not synchronised).  X / L: device
+        tensors (the whole solver vectors).  Returns the (fx, agx, kkt) views of the local shard."""
+        if self._local is None:
+            raise RuntimeError("call alloc_device() first")
+        if self.ev is not None:
+            self.ev.eval_device(what, X, L, self.fx, self.agx if what in _ADJ else None,
+                                self.kkt if what >= 2 else None, stream)
+        return self.fx[:self.count], self.agx[:self.count], self.kkt[:self.count]
+
+    def gather_device(self, async_op: bool = False):
+        """The exchange step: one gather of every rank's flat buffer to the root, device to device.  Ordered after the
+        work already enqueued on the current stream (c10d semantics); returns the work handle when `async_op`."""
+        if self.world == 1:
+            return None
+        out = list(self._recv.unbind(0)) if self.rank == self._dst else None
+        return self.dist.gather(self._local, out, dst=self._dst, group=self.group, async_op=async_op)
+
+    def shard_blocks_on_root(self):
+        """Per rank, the (fx, agx, kkt) views of its shard in the root's receive buffer after `gather_device` -- no
+        copy; shard r covers segments shards[r][0] ... of the phase.  None on the other ranks."""
+        if self.world == 1:
+            return [self._views(self._local, self.count)]
+        if self.rank != self._dst:
+            return None
+        return [self._views(self._recv[r], c) for r, (_, c) in enumerate(self.shards)]
+
+    def blocks_on_root(self):
+        """(fx[nseg_total, OR], agx[nseg_total, IR], kkt[nseg_total, NKKT]) on the root (None elsewhere): the shards
+        of `shard_blocks_on_root` concatenated per kind (one device copy; the scatter can as well walk the shards)."""
+        import torch
+        per = self.shard_blocks_on_root()
+        if per is None:
+            return None
+        if len(per) == 1:
+            return per[0]
+        return tuple(torch.cat([p[k] for p in per], dim=0) for k in range(3))
+
+    # ---- exchange of host blocks (kept for callers that evaluate through host pointers) -----
     def gather_blocks(self, blocks, dst: int = 0, device=None):
         """Gather one kind of block ([count, width] array/tensor) from every rank to `dst`.
 
@@ -72,3 +153,67 @@ class ShardedDefectEvaluator:
         if self.rank != dst:
             return None
         return torch.cat([o[:c] for o, (_, c) in zip(out, self.shards)], dim=0)
+
+
+class PhaseShardedEvaluator:
+    """Several phases of one problem (same ODE / transcription / size), whole phases per rank: phase k belongs to rank
+    k % world.  `phases` = list of (vindex, cindex) tables into the problem's X and L."""
+
+    def __init__(self, ode: str, mode, blocked: bool, phases: Sequence, n_primal: int, n_equal: int,
+                 rank: Optional[int] = None, world: Optional[int] = None, device: int = 0, group=None,
+                 evaluator_factory: Optional[Callable] = None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.nphases = len(phases)
+        self.nseg = int(np.asarray(phases[0][0]).shape[0])
+        if any(np.asarray(v).shape[0] != self.nseg for v, _ in phases):
+            raise ValueError("PhaseShardedEvaluator: phases must have the same number of segments")
+        self.owner = [k % self.world for k in range(self.nphases)]
+        self.mine = [k for k in range(self.nphases) if self.owner[k] == self.rank]
+        self.per_rank = -(-self.nphases // self.world)       # slots per rank (the last ranks may leave one unused)
+        if evaluator_factory is None:
+            from .evaluator import DefectEvaluator
+            evaluator_factory = DefectEvaluator
+        self.evs: List = [evaluator_factory(ode, mode, blocked, phases[k][0], phases[k][1], n_primal, n_equal, device)
+                          for k in self.mine]
+        if self.evs:
+            self.IR, self.OR, self.NKKT = self.evs[0].IR, self.evs[0].OR, self.evs[0].NKKT
+        else:
+            self.IR, self.OR, self.NKKT = _sizes(ode, mode, blocked)
+        self.width = self.OR + self.IR + self.NKKT
+        self._local = self._recv = None
+
+    def _views(self, flat):
+        m = self.nseg
+        o1, o2 = m * self.OR, m * (self.OR + self.IR)
+        return flat[:o1].view(m, self.OR), flat[o1:o2].view(m, self.IR), flat[o2:].view(m, self.NKKT)
+
+    def alloc_device(self, device, dst: int = 0):
+        import torch
+        self._dst = dst
+        self._local = torch.zeros((self.per_rank, self.nseg * self.width), dtype=torch.float64, device=device)
+        if self.rank == dst and self.world > 1:
+            self._recv = torch.empty((self.world, self.per_rank, self.nseg * self.width), dtype=torch.float64,
+                                     device=device)
+        return self
+
+    def eval_device(self, what: int, X, L=None, stream=None):
+        for s, ev in enumerate(self.evs):
+            fx, agx, kkt = self._views(self._local[s])
+            ev.eval_device(what, X, L, fx, agx if what in _ADJ else None, kkt if what >= 2 else None, stream)
+
+    def gather_device(self, async_op: bool = False):
+        if self.world == 1:
+            return None
+        out = list(self._recv.unbind(0)) if self.rank == self._dst else None
+        return self.dist.gather(self._local, out, dst=self._dst, group=self.group, async_op=async_op)
+
+    def blocks_on_root(self):
+        """List over phases of (fx, agx, kkt) views on the root (None elsewhere)."""
+        if self.world == 1:
+            return [self._views(self._local[s]) for s in range(self.nphases)]
+        if self.rank != self._dst:
+            return None
+        return [self._views(self._recv[self.owner[k], k // self.world]) for k in range(self.nphases)]
