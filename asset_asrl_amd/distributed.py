@@ -13,7 +13,8 @@ Device-resident path (``alloc_device`` / ``eval_device`` / ``gather_device``): e
 HBM, ``[fx | agx | kkt]`` sized for the largest shard, that the evaluation kernels write in place; the exchange is a
 single ``dist.gather`` of that buffer into the root's ``[world, slot]`` receive buffer (RCCL: grouped send/recv over
 xGMI, every peer on its own link).  Nothing touches the host.  Shards differ by at most one segment, so the padding is
-at most one segment per rank; ``blocks_on_root`` returns views when the shards are equal and compacts otherwise.
+at most one segment per rank; ``shard_blocks_on_root`` returns per-shard views of the receive buffer (no copy),
+``blocks_on_root`` the phase-order concatenation.
 
 ``PhaseShardedEvaluator`` is the multi-phase form (BASELINE.json configs[3]: eight linked phases): whole phases are
 dealt to the ranks round-robin -- phases are independent given X and L too
@@ -86,14 +87,14 @@ class ShardedDefectEvaluator:
             fx, agx, kkt = fx[:count], agx[:count], kkt[:count]
         return fx, agx, kkt
 
-    def alloc_device(self, device, dst: int = 0):
+    def alloc_device(self, device, dst: int = 0, always_exchange: bool = False):
         """Allocate the flat output buffer on `device` (and the receive buffer on rank `dst`).  The padding segment of
-        a shorter shard is zero and stays zero."""
+        a shorter shard is zero and stays zero.  `always_exchange`: run the gather even in a world of one rank (tests)."""
         import torch
         self._dst = dst
         self._local = torch.zeros(self.slot_doubles, dtype=torch.float64, device=device)
         self.fx, self.agx, self.kkt = self._views(self._local)
-        if self.rank == dst and self.world > 1:
+        if self.rank == dst and (self.world > 1 or always_exchange):
             self._recv = torch.empty((self.world, self.slot_doubles), dtype=torch.float64, device=device)
         return self
 
@@ -110,7 +111,7 @@ class ShardedDefectEvaluator:
     def gather_device(self, async_op: bool = False):
         """The exchange step: one gather of every rank's flat buffer to the root, device to device.  Ordered after the
         work already enqueued on the current stream (c10d semantics); returns the work handle when `async_op`."""
-        if self.world == 1:
+        if self.world == 1 and self._recv is None:
             return None
         out = list(self._recv.unbind(0)) if self.rank == self._dst else None
         return self.dist.gather(self._local, out, dst=self._dst, group=self.group, async_op=async_op)
@@ -118,10 +119,8 @@ class ShardedDefectEvaluator:
     def shard_blocks_on_root(self):
         """Per rank, the (fx, agx, kkt) views of its shard in the root's receive buffer after `gather_device` -- no
         copy; shard r covers segments shards[r][0] ... of the phase.  None on the other ranks."""
-        if self.world == 1:
-            return [self._views(self._local, self.count)]
-        if self.rank != self._dst:
-            return None
+        if self._recv is None:
+            return [self._views(self._local, self.count)] if self.world == 1 else None
         return [self._views(self._recv[r], c) for r, (_, c) in enumerate(self.shards)]
 
     def blocks_on_root(self):
@@ -190,11 +189,11 @@ class PhaseShardedEvaluator:
         o1, o2 = m * self.OR, m * (self.OR + self.IR)
         return flat[:o1].view(m, self.OR), flat[o1:o2].view(m, self.IR), flat[o2:].view(m, self.NKKT)
 
-    def alloc_device(self, device, dst: int = 0):
+    def alloc_device(self, device, dst: int = 0, always_exchange: bool = False):
         import torch
         self._dst = dst
         self._local = torch.zeros((self.per_rank, self.nseg * self.width), dtype=torch.float64, device=device)
-        if self.rank == dst and self.world > 1:
+        if self.rank == dst and (self.world > 1 or always_exchange):
             self._recv = torch.empty((self.world, self.per_rank, self.nseg * self.width), dtype=torch.float64,
                                      device=device)
         return self
@@ -205,15 +204,13 @@ class PhaseShardedEvaluator:
             ev.eval_device(what, X, L, fx, agx if what in _ADJ else None, kkt if what >= 2 else None, stream)
 
     def gather_device(self, async_op: bool = False):
-        if self.world == 1:
+        if self.world == 1 and self._recv is None:
             return None
         out = list(self._recv.unbind(0)) if self.rank == self._dst else None
         return self.dist.gather(self._local, out, dst=self._dst, group=self.group, async_op=async_op)
 
     def blocks_on_root(self):
         """List over phases of (fx, agx, kkt) views on the root (None elsewhere)."""
-        if self.world == 1:
-            return [self._views(self._local[s]) for s in range(self.nphases)]
-        if self.rank != self._dst:
-            return None
+        if self._recv is None:
+            return [self._views(self._local[s]) for s in range(self.nphases)] if self.world == 1 else None
         return [self._views(self._recv[self.owner[k], k // self.world]) for k in range(self.nphases)]

@@ -33,10 +33,60 @@ def build(force: bool = False) -> str:
     return so
 
 
-def lib():
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def build_native() -> str:
+    """The same sources built the way the reference builds its own (-O2 -march=native -ffast-math,
+    /root/reference/CMakeLists.txt:55,160) -- for bench.py's cpu_baseline leg only; the parity tests keep the strict-IEEE
+    library.  -march=native code must be compiled on the machine that runs it: the file name carries a hash of this
+    host's CPU model and flags, so a library built elsewhere is never loaded."""
+    import hashlib
+    ident = cpu_model()
+    try:
+        ident += next(ln for ln in open("/proc/cpuinfo") if ln.startswith("flags"))
+    except (OSError, StopIteration):
+        pass
+    so = os.path.join(_HERE, f"liboracle_native_{hashlib.sha256(ident.encode()).hexdigest()[:10]}.so")
+    srcs = [os.path.join(_HERE, f) for f in ("defect.cpp", "nlp.cpp", "mesh.cpp", "odes.cpp")]
+    gen = os.path.join(_HERE, "gen", "odes_gen.c")
+    deps = srcs + [gen] + [os.path.join(_HERE, f) for f in ("odes.h", "ad2.h", "lgl_coeffs.h", "oracle.h")]
+    if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+        return so
+    flags = ["-O2", "-march=native", "-ffast-math", "-fPIC"]
+    objs = []
+    tmp = so + ".build"
+    os.makedirs(tmp, exist_ok=True)
+    for src in srcs:
+        o = os.path.join(tmp, os.path.basename(src) + ".o")
+        subprocess.check_call(["g++", "-std=c++17", "-pthread", "-Wno-unused-function"] + flags + ["-c", src, "-o", o])
+        objs.append(o)
+    if os.path.exists(gen):
+        o = os.path.join(tmp, "odes_gen.o")
+        subprocess.check_call(["gcc"] + flags + ["-c", gen, "-o", o])
+        objs.append(o)
+    subprocess.check_call(["g++", "-shared", "-pthread", "-o", so] + objs)
+    return so
+
+
+def use_native():
+    """Switch this process to the natively optimised library (bench.py's cpu_baseline leg)."""
+    global _LIB
+    _LIB = None
+    lib(build_native())
+
+
+def lib(path=None):
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        L = C.CDLL(path or build())
         L.oracle_get_ode.argtypes = [C.c_char_p, C.c_int, C.POINTER(OdeStruct)]
         L.oracle_set_synthetic32.argtypes = [_dp]
         L.oracle_defect_sizes.argtypes = [C.c_int] * 5 + [_ip, _ip]

@@ -1,0 +1,60 @@
+"""The device-resident sharded path on a real GPU: one rank, RCCL backend, exchange forced (a gather in a world of one
+rank still goes through c10d's NCCL path), against the oracle.  Runs in a child process so that the process group
+does not outlive the test."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r"""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from helpers import Workload, rel_err
+from asset_asrl_amd.distributed import ShardedDefectEvaluator
+from oracle import bindings as ob
+w = Workload("reentry", "LGL7", 333)
+sh = ShardedDefectEvaluator("reentry", "LGL7", False, w.vindex, w.cindex, w.n_primal, w.n_equal, device=0)
+sh.alloc_device(torch.device("cuda", 0), always_exchange=True)
+X, L = torch.from_numpy(w.X).cuda(), torch.from_numpy(w.L).cuda()
+st = torch.cuda.Stream()
+with torch.cuda.stream(st):
+    for _ in range(2):
+        sh.eval_device(4, X, L, st)
+        sh.gather_device()
+torch.cuda.synchronize()
+fx, agx, kkt = [t.cpu().numpy() for t in sh.blocks_on_root()]
+rfx, ragx, rkkt = w.oracle_nlp(ob, threads=4).eval_blocks(4, w.X, w.L)
+print(json.dumps({{"fx": float(np.abs(fx - rfx).max() / max(1.0, np.abs(w.X).max())), "agx": rel_err(agx, ragx),
+                  "kkt": rel_err(kkt, rkkt), "shape": list(kkt.shape)}}))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_sharded_device_path_with_rccl_gather_matches_the_oracle(oracle):
+    r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["shape"] == [333, 1008]
+    assert out["fx"] < 1e-10 and out["agx"] < 1e-8 and out["kkt"] < 1e-8, out
+
+
+@pytest.mark.gpu
+def test_bench_runs_the_exchange_path_with_one_rank():
+    env = dict(os.environ, ASSET_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("{"), r.stdout[-500:]      # the JSON line is the last line
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 0
+    assert "exchange_ms" in out and out["exchange_bytes_into_root"] > 8e7
