@@ -258,6 +258,15 @@ __device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" :::
 // are then known to have landed and nothing later in the iteration waits on vmcnt, so the stores drain behind the
 // next iteration's compute.   encoding: vmcnt = 0 (bits 3:0 and 15:14), expcnt = 7 (6:4), lgkmcnt = 15 (11:8)
 __device__ inline void wave_loads_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// The per-segment fence of the dense stage's store phase (defect_kernels.h), OFF by default.  Measured (round 2): with
+// the fence the prefetched slot is consumed without a wait at the top of the next iteration, yet a 10 000-segment phase
+// runs no faster (two launches 53.3 vs 53.4 us, fused 43.1 vs 42.9 us) and large meshes run 6-7 % slower (100 000
+// segments 537 vs 506 us, 1 000 000 segments 5.01 vs 4.66 ms): a wave's time in the store phase is the issue of its
+// own stores (about 2.4 bytes per cycle and wave, tools/ubench_store.hip), not the wait the compiler places.
+#ifndef ASSET_STORE_FENCE
+#define ASSET_STORE_FENCE 0
+#endif
+__device__ inline void wave_store_fence() { if constexpr (ASSET_STORE_FENCE != 0) wave_loads_landed(); }
 // Hand-offs through the global workspace (same wave writes, then reads): wait for the stores as well.
 __device__ inline void wave_mem_sync() { __syncthreads(); }
 

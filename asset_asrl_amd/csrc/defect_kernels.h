@@ -874,7 +874,7 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
     wave_lds_sync();
     // No load may be outstanding when the segment loop is entered (see wave_loads_landed): the first slot's loads have
     // had the constant-tile build to arrive.
-    wave_loads_landed();
+    wave_store_fence();
 
     TS();
     // ------------------------------------------------------------------ P4: per-segment dense phase
@@ -1074,14 +1074,9 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
 #pragma unroll
         for (int t = 0; t < D::TI * D::TJ; t++) load_jmap(t);
       }
-      // Every load of this iteration (the next slot, the map entries) has been issued; from here on the segment only
-      // stores.  store_fence() is called once, right before the first store: it waits for those loads -- and, vmcnt
-      // being one in-order counter on gfx9, for the previous segment's stores, which have had this segment's tile build
-      // and first product to drain.  Without it the compiler cannot count the (conditional) stores that follow the
-      // loads and waits with vmcnt(0) where the prefetched slot is consumed at the top of the next iteration, i.e. for
-      // every store of this segment: the block stores then never overlap any compute of the wave that issued them.
-      // (One unconditional call site per instantiation: the waitcnt pass is path-insensitive, a fence under a lane- or
-      // pointer-condition does not count.)
+      // Optional load fence (defect_dims.h: wave_store_fence, off by default): called once per segment, after the last
+      // load of the iteration has been issued and before its first store, at one unconditional call site per
+      // instantiation (the waitcnt pass is path-insensitive: a fence under a lane- or pointer-condition does not count).
       constexpr int FENCE_AT = JFUSE ? 0 : (HOLD ? 2 : 1);
       // The product phases run at raised wave priority: the two waves of a SIMD otherwise walk through the same
       // phases nearly in step and the LDS / VALU / MFMA pipes take turns; any asymmetry in arbitration helps (measured
@@ -1138,7 +1133,7 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
             for (int v = 0; v < 4; v++) HI[16 * ct + lk + 4 * v] = hi_acc[ct][v];
         }
         // J^T = interior part + cardinal part DC^T; stored right away (its registers are free for the H products)
-        if constexpr (FENCE_AT == 0) wave_loads_landed();
+        if constexpr (FENCE_AT == 0) wave_store_fence();
         if (kkt_dst) {
 #pragma unroll
           for (int ct = 0; ct < D::TI; ct++) {
@@ -1217,7 +1212,7 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       }
 
       // ---- D4: H (lower-triangle tiles) and J^T
-      if constexpr (FENCE_AT == 1) wave_loads_landed();    // tiles are stored as they complete
+      if constexpr (FENCE_AT == 1) wave_store_fence();    // tiles are stored as they complete
       if constexpr (LEVEL >= 2) {
         // rank-2 time fragments: k=0 -> (A: d, B: HT), k=1 -> (A: HT, B: d), k=2,3 -> 0
         double a2[D::TI], b2[D::TI];
@@ -1292,7 +1287,7 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
       TSG();   // D4: H (and J) products
       // ---- D5: adjoint gradient  g = J^T lam  without touching the J tile:
       //      interior part  h * sum_i E_i g^_i^T DI_i  (= h * HI), cardinal part = DC^T lam
-      if constexpr (FENCE_AT == 2) wave_loads_landed();
+      if constexpr (FENCE_AT == 2) wave_store_fence();
       if (a.FX && lane < ROWS) a.FX[seg * OR + lane] = fx_hold;
       if (a.AGX) {
         for (int c = lane; c < IR; c += 64) {

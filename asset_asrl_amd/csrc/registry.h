@@ -8,6 +8,7 @@
 
 #include "defect_kernels.h"
 #include "defect_wide.h"
+#include "defect_units.h"
 #include "func_kernels.h"
 #include "mesh_kernels.h"
 
@@ -121,7 +122,24 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
           return hipSuccess;
         }
       }
-      ASSET_LAUNCH(2, 1, grid_a, bytes_ode);
+      if constexpr (Ode::NUNITS > 1) {
+        // heavy right-hand side: the ODE stage runs one wave per output unit (defect_units.h)
+        static const bool no_units = std::getenv("ASSET_HIP_NO_UNITS") != nullptr;                             // tuning only
+        if (!no_units) {
+          constexpr int GPMAX = 64 / D::CS;
+          int gp = (a.nseg + cus - 1) / cus;                 // one workgroup of NUNITS waves per CU when the mesh allows
+          gp = gp < 1 ? 1 : (gp > GPMAX ? GPMAX : gp);
+          const size_t bytes_units = UnitsDims<D>::lds_bytes(gp);
+          auto kern = lgl_ode_units_kernel<Ode, SCH, BLOCKED>;
+          hipLaunchKernelGGL(kern, dim3((a.nseg + gp - 1) / gp), dim3(64 * Ode::NUNITS), bytes_units, st, a, gp);
+          hipError_t e2 = hipGetLastError();
+          if (e2 != hipSuccess) return e2;
+        } else {
+          ASSET_LAUNCH(2, 1, grid_a, bytes_ode);
+        }
+      } else {
+        ASSET_LAUNCH(2, 1, grid_a, bytes_ode);
+      }
       if (skip_dense) return hipSuccess;
       if (a.kmap) ASSET_LAUNCH_DENSE(2, true);
       else ASSET_LAUNCH_DENSE(2, false);

@@ -371,8 +371,23 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
         o.append(f"    {name}_h_(in, out);")
         o.append("  }")
 
+    # ---- units: a heavy fjgh body is also emitted as NUNITS bodies that partition its outputs by input direction --
+    #      unit "column k" = {J[:,k], H[i>=k,k]}, the cheap columns together with f and g -- so that the ODE stage can
+    #      give every unit its own WAVE (csrc/defect_units.h): each evaluates all of a group's points for its share of the
+    #      outputs, recomputing the forward values it needs.  Betts: 7 792 operations as one body (hundreds of spilled
+    #      values) against at most ~2 300 per unit.
+    units = plan_units(d, outputs(2)) if split else None
+    o.insert(-1, f"  static constexpr int NUNITS = {len(units) if units else 1};   // bodies fjgh_unit<U> (1: none, use fjgh)")
+
     body("f", outputs(0))
     body("fj", outputs(1))
+    if units:
+        for u, outs in enumerate(units):
+            body(f"fjgh_u{u}_", outs, q="__attribute__((noinline))")
+        o.append("  template <int U, class In, class Out> __host__ __device__ static inline void fjgh_unit(const In& in, Out& out) {")
+        for u in range(len(units)):
+            o.append(f"    {'if' if u == 0 else 'else if'} constexpr (U == {u}) fjgh_u{u}_(in, out);")
+        o.append("  }")
     if split:
         two_parts("fjgh", False)
     else:
@@ -386,6 +401,41 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
         body("fjgh_load", outputs(2), use_saved=True)
     o.append("};")
     return "\n".join(o) + "\n"
+
+
+MAX_UNITS = 8
+
+
+def plan_units(d: OdeDerivatives, outs) -> List[list]:
+    """Partition the level-2 outputs ([(statement format, root)] in outputs(2) order) into units by input direction."""
+    N, n = d.nin, d.xv
+    f_outs = outs[:n]
+    j_outs = outs[n:n + n * N]
+    g_outs = outs[n + n * N:n + n * N + N]
+    h_outs = outs[n + n * N + N:]
+    hpos = {}
+    e = 0
+    for i in range(N):
+        for j in range(i + 1):
+            hpos[(i, j)] = e
+            e += 1
+
+    def cost(group):
+        return sum(1 for x in topo_order(lower_reciprocals([r for _, r in group])) if x.args)
+
+    cols = []
+    for k in range(N):
+        grp = [j_outs[r * N + k] for r in range(n)] + [h_outs[hpos[(i, k)]] for i in range(k, N)]
+        cols.append((cost(grp), k, grp))
+    top = max(c for c, _, _ in cols)
+    units, light = [], list(f_outs) + list(g_outs)
+    for c, k, grp in sorted(cols, key=lambda t: -t[0]):
+        if c >= 0.5 * top and len(units) < MAX_UNITS - 1:
+            units.append(grp)
+        else:
+            light += grp
+    units.append(light)
+    return units
 
 
 def saved_nodes(d: OdeDerivatives) -> List[Node]:

@@ -20,6 +20,8 @@ def stage_of(kernel_name):
     if "lgl_wide_dense_kernel" in kernel_name:            # four-wave dense stage of the wide shapes (defect_wide.h)
         return "dense_stage"
     args = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
+    if len(args) >= 6 and args[5] == "3":                 # fused single launch (defect_kernels.h, STAGE 3)
+        return "fused"
     return "ode_stage" if len(args) >= 6 and args[5] == "1" else "dense_stage"
 
 
@@ -38,7 +40,9 @@ def counters(sub):
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 per_kernel, total = {}, 0.0
-for st in ("ode_stage", "dense_stage"):
+for st in ("fused", "ode_stage", "dense_stage"):
+    if st not in fetch and st not in write:
+        continue
     f_kb = fetch.get(st, {}).get("FETCH_SIZE", 0.0)
     w_kb = write.get(st, {}).get("WRITE_SIZE", 0.0)
     hbm = (2.0 * f_kb + w_kb) * 1024.0   # gfx950: FETCH_SIZE under-reports a wide coalesced stream by 2x (MI355X_MICROARCH.md, HBM section)
@@ -57,8 +61,8 @@ out = {
                      if "defect_kernel" in r["Name"] or "wide_dense_kernel" in r["Name"]],
     "per_kernel": per_kernel,
     "hbm": {"fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section)", "bytes_per_launch": total,
-            "note": "one evaluation = ODE-stage launch + dense-stage launch; traffic above the algorithmic bytes is the "
-                    "ODE-result workspace written by the first launch and read by the second"},
+            "note": "one evaluation = the fused launch, or ODE-stage launch + dense-stage launch; traffic above the "
+                    "algorithmic bytes is the ODE-result workspace (written, and in the two-launch form read back from HBM)"},
     "sq_counters_per_dispatch": sq,
 }
 json.dump(out, open(os.path.join(dst, f"{rnd}_{workload}_pmc.json"), "w"), indent=1)
