@@ -55,7 +55,7 @@ def build_native() -> str:
     except (OSError, StopIteration):
         pass
     so = os.path.join(_HERE, f"liboracle_native_{hashlib.sha256(ident.encode()).hexdigest()[:10]}.so")
-    srcs = [os.path.join(_HERE, f) for f in ("defect.cpp", "nlp.cpp", "mesh.cpp", "odes.cpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("defect.cpp", "nlp.cpp", "mesh.cpp", "pathfuncs.cpp", "odes.cpp")]
     gen = os.path.join(_HERE, "gen", "odes_gen.c")
     deps = srcs + [gen] + [os.path.join(_HERE, f) for f in ("odes.h", "ad2.h", "lgl_coeffs.h", "oracle.h")]
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
@@ -108,6 +108,12 @@ def lib(path=None):
         L.oracle_nlp_kkt_coords.argtypes = [C.c_void_p, _ip, _ip]
         L.oracle_nlp_eval.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
         L.oracle_nlp_eval_blocks.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.oracle_single_mesh_spacing_all.argtypes = [C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.oracle_lgl_mesh_spacing_all.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.oracle_control_spline_all.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.oracle_lgl_integral_all.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.oracle_aux_table.argtypes = [C.c_int, C.c_char_p]
+        L.oracle_aux_table.restype = _dp
         _LIB = L
     return _LIB
 
@@ -271,3 +277,38 @@ class Nlp:
         if rc:
             raise RuntimeError(f"oracle_nlp_eval_blocks rc={rc}")
         return fx, agx, kkt
+
+
+# ---- the other per-segment functions of a phase (oracle/pathfuncs.cpp) ------------------------------------------------
+def _all(call, irr, orr, x, lam):
+    """-> (fx[orr], jx[orr, irr], gx[irr], hx[irr, irr])"""
+    x = np.ascontiguousarray(x, dtype=float)
+    lam = np.ascontiguousarray(lam, dtype=float)
+    assert x.size == irr and lam.size == orr, (x.size, irr, lam.size, orr)
+    fx, jx, gx, hx = np.zeros(orr), np.zeros((irr, orr)), np.zeros(irr), np.zeros((irr, irr))
+    rc = call(_d(x), _d(lam), _d(fx), _d(jx), _d(gx), _d(hx))
+    if rc:
+        raise ValueError(f"oracle path function rc={rc}")
+    return fx, jx.T.copy(), gx, hx.T.copy()
+
+
+def single_mesh_spacing_all(cardinal_spacing, x, lam, scale=1.0):
+    return _all(lambda *a: lib().oracle_single_mesh_spacing_all(float(cardinal_spacing), float(scale), *a), 3, 1, x, lam)
+
+
+def lgl_mesh_spacing_all(cs, x, lam):
+    return _all(lambda *a: lib().oracle_lgl_mesh_spacing_all(cs, *a), cs, cs - 2, x, lam)
+
+
+def control_spline_all(cs, usize, x, lam, order=0):
+    o = order or cs - 2
+    return _all(lambda *a: lib().oracle_control_spline_all(cs, usize, o, *a), (2 * cs - 1) * (usize + 1), usize * o, x, lam)
+
+
+def lgl_integral_all(integrand: OdeStruct, cs, xv, pv, x, lam):
+    return _all(lambda *a: lib().oracle_lgl_integral_all(C.byref(integrand), cs, xv, pv, *a), cs * (xv + 1) + pv, 1, x, lam)
+
+
+def aux_table(cs, which):
+    p = lib().oracle_aux_table(cs, which.encode())
+    return np.array([p[i] for i in range(cs)]) if p else None

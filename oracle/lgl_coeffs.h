@@ -83,4 +83,37 @@ static inline const lgl_tables* lgl_get(int cs) {
   return (cs >= 2 && cs <= 4) ? &LGL_TABLES[cs - 2] : (const lgl_tables*)0;
 }
 
+
+/* Quadrature and control-spline weights used by the other per-segment functions of a phase (oracle/pathfuncs.cpp),
+ * restated from LGLCoeffs.h: Reduced_Integral_Weights :42, :135, :360-364; UZeroSpline_Weights / UOneSpline_Weights
+ * :155-158 (CS=3), :372-388 (CS=4).  The literals and the expressions are the reference's. */
+static const double lgl_reduced_integral_weights_[3][4] = {
+    {0.5, 0.5, 0.0, 0.0},
+    {1.0 / 6.0, 2.0 / 3.0, 1.0 / 6.0, 0.0},
+    {-5.12701665379258 / 4.0 + 10.2540333075852 / 3.0 - 6.12701665379258 / 2.0 + 1.0,
+     10.9353308042859 / 4.0 - 18.9665045333251 / 3.0 + 8.03117372903925 / 2.0,
+     -10.9353308042859 / 4.0 + 13.8394878795326 / 3.0 - 2.90415707524666 / 2.0,
+     5.12701665379258 / 4.0 - 5.12701665379258 / 3.0 + 1.0 / 2.0}};
+static const double lgl_uzero_spline_weights_[2][2][4] = {
+    {{-3.0, 4.0, -1.0, 0.0}, {0.0, 0.0, 0.0, 0.0}},
+    {{-6.12701665379258, 8.03117372903925, -2.90415707524666, 1.0},
+     {10.2540333075852 * 2.0, -18.9665045333251 * 2.0, +13.8394878795326 * 2.0, -5.12701665379258 * 2.0}}};
+static const double lgl_uone_spline_weights_[2][2][4] = {
+    {{1.0, -4.0, 3.0, 0.0}, {0.0, 0.0, 0.0, 0.0}},
+    {{-5.12701665379258 * 3.0 + 10.2540333075852 * 2.0 - 6.12701665379258,
+      10.9353308042859 * 3.0 - 18.9665045333251 * 2.0 + 8.03117372903925,
+      -10.9353308042859 * 3.0 + 13.8394878795326 * 2.0 - 2.90415707524666,
+      5.12701665379258 * 3.0 - 5.12701665379258 * 2.0 + 1.0},
+     {-5.12701665379258 * 6.0 + 10.2540333075852 * 2.0, 10.9353308042859 * 6.0 - 18.9665045333251 * 2.0,
+      -10.9353308042859 * 6.0 + 13.8394878795326 * 2.0, 5.12701665379258 * 6.0 - 5.12701665379258 * 2.0}}};
+static inline const double* oracle_reduced_integral_weights(int cs) {
+  return (cs >= 2 && cs <= 4) ? lgl_reduced_integral_weights_[cs - 2] : 0;
+}
+static inline const double (*oracle_uzero_spline_weights(int cs))[4] {
+  return (cs == 3 || cs == 4) ? lgl_uzero_spline_weights_[cs - 3] : 0;
+}
+static inline const double (*oracle_uone_spline_weights(int cs))[4] {
+  return (cs == 3 || cs == 4) ? lgl_uone_spline_weights_[cs - 3] : 0;
+}
+
 #endif

@@ -61,6 +61,8 @@ AD2_ODE(vanderpol, 2, 1, 1)
 AD2_ODE(coupled12, 12, 3, 2)
 AD2_ODE(coupled16, 16, 3, 2)
 AD2_ODE(pathcon, 2, 3, 0)
+AD2_ODE(integrand_quad2, 1, 0, 0)
+AD2_ODE(integrand_powp, 1, 2, 0)
 
 }  // namespace
 
@@ -87,6 +89,8 @@ GEN_DECL(vanderpol)
 GEN_DECL(coupled12)
 GEN_DECL(coupled16)
 GEN_DECL(pathcon)
+GEN_DECL(integrand_quad2)
+GEN_DECL(integrand_powp)
 
 extern "C" {
 
@@ -116,6 +120,8 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(coupled12, 12, 3, 2, nullptr)
   TRY(coupled16, 16, 3, 2, nullptr)
   TRY(pathcon, 2, 3, 0, nullptr)
+  TRY(integrand_quad2, 1, 0, 0, nullptr)
+  TRY(integrand_powp, 1, 2, 0, nullptr)
   return -1;
 }
 }

@@ -70,6 +70,17 @@ void pathcon(const S* y, S* f, const void*) {
   f[1] = u0 * u0 + u1 * u1 - 1.0 + t * x0 * exp(-x1);
 }
 
+// ------------------------------------------------------------------ integrands (one output) for the segment quadrature
+// quad2: I(x0, x1) = x1^2 + x0 (the integrand of tests/test_gpu_function.py);  record (xv, uv, pv) = (1, 0, 0): 2 inputs.
+// powp: I(x0, x1, x2, p) = p x0^2 + sin(x1) x2 + exp(-x0 x2) / (1 + p^2): three node values and a phase parameter;
+// record (1, 2, 0): 4 inputs.
+template <class S>
+void integrand_quad2(const S* y, S* f, const void*) { f[0] = y[1] * y[1] + y[0]; }
+template <class S>
+void integrand_powp(const S* y, S* f, const void*) {
+  f[0] = y[3] * y[0] * y[0] + sin(y[1]) * y[2] + exp(-(y[0] * y[2])) / (1.0 + y[3] * y[3]);
+}
+
 // ------------------------------------------------------------------ shuttle reentry (5,2,0)
 template <class S>
 void reentry(const S* y, S* f, const void*) {

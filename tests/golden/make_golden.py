@@ -29,7 +29,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from asset_asrl_amd import synth  # noqa: E402
-from oracle import bindings as ob  # noqa: E402  (tables only: data, not algorithms)
+import json  # noqa: E402
+
+# The collocation weights come from the reference's own header, parsed by tests/golden/parse_lglcoeffs.py into
+# tests/golden/lgl_tables.json -- NOT from the oracle (or the product): the vectors must not share their only copy of
+# the coefficients with the code they check.
+_REF_NAMES = {"s": "InteriorSpacings", "A": "Cardinal_XInterp_Weights", "B": "Cardinal_DXInterp_Weights",
+              "U": "Cardinal_UPoly_Weights", "C": "Cardinal_XDef_Weights", "D": "Cardinal_DXDef_Weights",
+              "E": "Interior_DXDef_Weights"}
+_REF_TABLES = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lgl_tables.json")))["tables"]
+
+
+def ref_table(cs, which):
+    return np.array(_REF_TABLES[str(cs)][_REF_NAMES[which]], dtype=float)
+
+
+def synthetic32_coeffs(n: int = 32, seed: int = 32) -> np.ndarray:
+    """a, b, c ~ U(0.5, 1.5), seed 32 -- the definition of the synthetic ODE, restated here."""
+    rng = np.random.default_rng(seed)
+    return np.concatenate([rng.uniform(0.5, 1.5, n) for _ in range(3)])
 
 mp.mp.dps = 50
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -280,7 +298,7 @@ def ode_betts(y, M):
 
 def ode_synthetic32(y, M):
     n = 32
-    abc = ob.synthetic32_coeffs()
+    abc = synthetic32_coeffs()
     a, b, c = abc[:n], abc[n:2 * n], abc[2 * n:]
     ct = M.cos(y[n])
     return [(-float(a[k])) * y[k] + float(b[k]) * M.sin(y[(k + 1) % n]) * y[(k + 5) % n] + float(c[k]) * ct
@@ -306,7 +324,7 @@ def defect_value(name, mode, blocked, z, M):
     h = card[-1][n] - card[0][n]
     if mode == "Trapezoidal":
         return [-((card[1][k] - card[0][k]) - (h / 2.0) * (fj[0][k] + fj[1][k])) for k in range(n)]
-    tab = {k: ob.lgl_table(cs, k) for k in "sABUCDE"}
+    tab = {k: ref_table(cs, k) for k in "sABUCDE"}
     out = []
     for i in range(cs - 1):
         xi = []

@@ -144,8 +144,9 @@ def test_phase_add_constraints_evaluate_over_their_regions(oracle):
 def test_segment_quadrature_and_control_spline_on_the_device():
     """LGLIntegral / LGLControlSpline (LGLIntegrals.h:9-52, LGLControlSplines.h:64-108) batched over segments on the
     device: known answers -- the LGL7 quadrature is exact for the cubic integrand of a polynomial trajectory, and the
-    spline relation vanishes on a control that is one cubic across both segments -- and the device's adjoint gradient
-    against central differences of the device's own values."""
+    spline relation vanishes on a control that is one cubic across both segments -- and value, Jacobian, adjoint gradient
+    and adjoint Hessian of every application against the oracle's restatement (oracle/pathfuncs.cpp, itself pinned by
+    the 50-digit vectors of tests/golden/pathfuncs.npz)."""
     from asset_asrl_amd.pathfuncs import LGLControlSpline, LGLIntegral
     tc = np.array([0.0, 2.65575603264643e-1, 7.34424396735357e-1, 1.0])
     nseg = 150
@@ -165,13 +166,13 @@ def test_segment_quadrature_and_control_spline_on_the_device():
     fx, agx, kkt = ev.eval(JAC_ADJGRAD_HESS, X, L)
     prim = lambda t: t ** 3 / 3 + t ** 4 / 4
     np.testing.assert_allclose(fx[:, 0], prim(t0 + h) - prim(t0), rtol=1e-12, atol=1e-12)
-    eps = 1e-6
-    for col in (0, 4, 11):                                                   # a state, an interior state, the end time
-        Xp, Xm = X.copy(), X.copy()
-        Xp[col::12] += eps
-        Xm[col::12] -= eps
-        fd = (ev.eval(CON, Xp)[0][:, 0] - ev.eval(CON, Xm)[0][:, 0]) / (2 * eps)
-        np.testing.assert_allclose(agx[:, col], L * fd, rtol=1e-6, atol=1e-6)
+    from oracle import bindings as ob                                         # every application against the oracle's
+    quad2 = ob.get_ode("integrand_quad2", 0)                                  # restatement of LGLIntegrals.h:18-52
+    for V in range(nseg):
+        rfx, rjx, rgx, rhx = ob.lgl_integral_all(quad2, 4, 2, 0, Z[V], L[V:V + 1])
+        Hd, Jd = unpack_kkt_block(kkt[V], 12, 1)
+        assert abs(fx[V, 0] - rfx[0]) < 1e-10 * max(1.0, np.abs(Z).max())
+        assert rel_err(Jd, rjx) < 1e-8 and rel_err(agx[V], rgx) < 1e-8 and rel_err(Hd, rhx) < 1e-8
     H, J = unpack_kkt_block(kkt[3], 12, 1)
     np.testing.assert_allclose(J[0] * L[3], agx[3], rtol=1e-12, atol=1e-12)   # one output: J^T lam = lam * J
     assert np.abs(H - H.T).max() == 0.0
@@ -188,7 +189,63 @@ def test_segment_quadrature_and_control_spline_on_the_device():
     ev = FunctionEvaluator(S, "lglcontrolspline4", vind, cind, Zs.size, npair * 4)
     fx = ev.eval(CON, Zs.ravel())[0]
     assert np.abs(fx).max() < 1e-9 * max(1.0, np.abs(Zs).max() ** 3)         # 15-digit weight literals
+    Zr = Zs + rng.uniform(-0.05, 0.05, Zs.shape) * (np.arange(21) % 3 != 0)   # perturbed controls, same node times
+    Ls = rng.uniform(-2, 2, npair * 4)
+    fx, agx, kkt = ev.eval(JAC_ADJGRAD_HESS, Zr.ravel(), Ls)                  # against LGLControlSplines.h:92-309 restated
+    for V in range(npair):
+        rfx, rjx, rgx, rhx = ob.control_spline_all(4, 2, Zr[V], Ls[4 * V:4 * V + 4])
+        Hd, Jd = unpack_kkt_block(kkt[V], 21, 4)
+        assert np.abs(fx[V] - rfx).max() < 1e-10 * max(1.0, np.abs(rfx).max())
+        assert rel_err(Jd, rjx) < 1e-8 and rel_err(agx[V], rgx) < 1e-8 and rel_err(Hd, rhx) < 1e-8
     Zbad = Zs.copy()
     Zbad[:, -1] += 0.1                                                        # a kink in the last node's control
     assert np.abs(ev.eval(CON, Zbad.ravel())[0]).max(axis=1).min() > 1e-2
     ev.close()
+
+
+def test_mesh_spacing_and_parametrised_integral_match_the_oracle():
+    """LGLMeshSpacing<3,4>, SingleMeshSpacing (MeshSpacingConstraints.h:8-193) and an LGL5 / LGL3 quadrature whose integrand
+    takes a phase parameter, batched on the device, against the oracle's closed forms application by application."""
+    from oracle import bindings as ob
+    from asset_asrl_amd.pathfuncs import LGLIntegral, LGLMeshSpacing, SingleMeshSpacing
+    rng = np.random.default_rng(31)
+    napp = 90
+
+    def run(F, name, Z, orr, ref):
+        irr = Z.shape[1]
+        vindex = np.arange(napp * irr, dtype=np.int32).reshape(napp, irr)
+        cindex = np.arange(napp * orr, dtype=np.int32).reshape(napp, orr)
+        L = rng.uniform(-2, 2, napp * orr)
+        ev = FunctionEvaluator(F, name, vindex, cindex, Z.size, L.size)
+        fx, agx, kkt = ev.eval(JAC_ADJGRAD_HESS, Z.ravel(), L)
+        for V in range(napp):
+            rfx, rjx, rgx, rhx = ref(Z[V], L[orr * V:orr * V + orr])
+            Hd, Jd = unpack_kkt_block(kkt[V], irr, orr)
+            assert np.abs(fx[V] - rfx).max() < 1e-10 * max(1.0, np.abs(Z).max())
+            assert rel_err(Jd, rjx) < 1e-8 and rel_err(agx[V], rgx) < 1e-8 and rel_err(Hd, rhx, floor=1e-12) < 1e-8
+        ev.close()
+
+    def times(cs):
+        tc = synth_tc(cs)
+        t = rng.uniform(0, 5, (napp, 1)) + tc[None, :] * rng.uniform(0.4, 2.0, (napp, 1))
+        return t + rng.uniform(-0.02, 0.02, t.shape) * (np.arange(cs) > 0)
+
+    for cs in (3, 4):
+        run(LGLMeshSpacing(cs), f"lglmeshspacing{cs}", times(cs), cs - 2, lambda x, l, cs=cs: ob.lgl_mesh_spacing_all(cs, x, l))
+    s = float(synth_tc(4)[1])
+    run(SingleMeshSpacing(s, 2.5), "singlemeshspacing_t", np.sort(rng.uniform(0, 3, (napp, 3)), axis=1), 1,
+        lambda x, l: ob.single_mesh_spacing_all(s, x, l, scale=2.5))
+    g = vf.Arguments(4)
+    integ = g.coeff(3) * g.coeff(0) * g.coeff(0) + vf.sin(g.coeff(1)) * g.coeff(2) \
+        + vf.exp(-1.0 * (g.coeff(0) * g.coeff(2))) / (1.0 + g.coeff(3) * g.coeff(3))
+    powp = ob.get_ode("integrand_powp", 0)
+    for cs in (3, 2):
+        Z = np.concatenate([np.concatenate([rng.uniform(-1, 1, (napp, cs, 3)), times(cs)[:, :, None]], axis=2).reshape(napp, -1),
+                            rng.uniform(0.5, 1.5, (napp, 1))], axis=1)
+        run(LGLIntegral(integ, cs, 3, 1), f"lglintegral{cs}_powp", Z, 1,
+            lambda x, l, cs=cs: ob.lgl_integral_all(powp, cs, 3, 1, x, l))
+
+
+def synth_tc(cs):
+    from asset_asrl_amd import synth
+    return synth._TC[cs]
