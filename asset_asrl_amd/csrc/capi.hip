@@ -409,19 +409,22 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
   long long lo = nvalues, hi = 0;
   for (size_t i = 0; i < nslots; i++) {
     const long long m = slot_locations[i];
-    if (m < 0 || m >= nvalues) return fail(ASSET_HIP_ERANGE, "kkt slot location outside [0, nvalues)");
+    if (m == -1) continue;   // a slot the caller does not want (the Jacobian slots of an objective: Hessian only)
+    if (m < 0 || m >= nvalues) return fail(ASSET_HIP_ERANGE, "kkt slot location outside [0, nvalues) and not -1");
     lo = m < lo ? m : lo;
     hi = m + 1 > hi ? m + 1 : hi;
   }
+  if (hi <= lo) return fail(ASSET_HIP_EINVAL, "kkt map keeps no slot");
   // a location used by exactly one slot is stored to, one that several slots share is added to atomically
   // (encoding: defect_dims.h, EvalArgs::kmap); in accumulate mode every slot adds
   std::vector<unsigned char> uses(accumulate ? 0 : size_t(hi - lo), 0);
   if (!accumulate)
     for (size_t i = 0; i < nslots; i++) {
+      if (slot_locations[i] < 0) continue;
       unsigned char& u = uses[size_t(slot_locations[i] - lo)];
       if (u < 2) u++;
     }
-  auto encode = [&](int32_t m) { return (accumulate || uses[size_t(m - lo)] > 1) ? -(m + 2) : m; };
+  auto encode = [&](int32_t m) { return m < 0 ? -1 : ((accumulate || uses[size_t(m - lo)] > 1) ? -(m + 2) : m); };
   std::vector<int32_t> map;
   if (h->ke->mode == ASSET_HIP_FUNCTION) {   // plain functions place their entries slot by slot (func_kernels.h)
     map.resize(nslots);

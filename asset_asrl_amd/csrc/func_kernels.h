@@ -47,7 +47,7 @@ struct FuncOut {
     if constexpr (ASM) {
       const int m = kmap[slot];
       if (m >= 0) kkt[m] = v;
-      else unsafeAtomicAdd(kkt + (-(m + 2)), v);
+      else if (m != -1) unsafeAtomicAdd(kkt + (-(m + 2)), v);   // (-1: a dropped slot, e.g. the Jacobian of an objective)
     } else kkt[slot] = v;
   }
   __device__ void f(int k, double v) { if (fx) fx[k] = v; }

@@ -27,7 +27,7 @@ static void check(int rc, const char* what) {
 BatchedDefectConstraint::BatchedDefectConstraint(const std::string& ode, int mode, bool blocked,
                                                  const SolverIndexingData& data, int primal_vars, int equal_cons,
                                                  int device)
-    : ode_(ode), mode_(mode), nappl_(data.NumAppl()) {
+    : ode_(ode), mode_(mode), nappl_(data.NumAppl()), n_equal_(equal_cons) {
   if (data.NumAppl() <= 0) throw std::invalid_argument("BatchedDefectConstraint: no function applications");
   asset_hip_defect_desc d;
   std::memset(&d, 0, sizeof d);
@@ -100,7 +100,7 @@ void BatchedDefectConstraint::getKKTSpace(int* KKTrows, int* KKTcols, int& freel
 }
 
 void BatchedDefectConstraint::scatter_kkt(const double* blocks, int nkkt, int ir, int orr, bool dohess,
-                                          double* KKTvals, const int* lpt, const SolverIndexingData& data) {
+                                          double* KKTvals, const int* lpt, const SolverIndexingData& data, bool dojac) {
   for (int V = 0; V < data.NumAppl(); V++) {
     const double* blk = blocks + size_t(V) * nkkt;
     int freeloc = data.InnerKKTStarts[V];
@@ -112,19 +112,24 @@ void BatchedDefectConstraint::scatter_kkt(const double* blocks, int nkkt, int ir
         freeloc += ir - i;
         k += ir - i;
       }
-      for (int j = 0; j < orr; j++) KKTvals[lpt[freeloc++]] += blk[k++];
+      if (dojac) {
+        for (int j = 0; j < orr; j++) KKTvals[lpt[freeloc++]] += blk[k++];
+      } else {  // KKTFillHess: the block carries the Jacobian entries, the objective's KKT space has no slot for them
+        k += orr;
+      }
     }
   }
 }
 
 void BatchedDefectConstraint::eval(int what, const double* X, const double* L, double* FX, double* AGX,
-                                   double* KKTvals, const int* KKTLocations, const SolverIndexingData& data) {
+                                   double* KKTvals, const int* KKTLocations, const SolverIndexingData& data,
+                                   bool hess_only) {
   if (data.NumAppl() != nappl_) throw std::invalid_argument("index data does not belong to this constraint");
   const bool want_agx = (what == ASSET_HIP_CON_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD_HESS);
   const bool want_kkt = what >= ASSET_HIP_JAC;
   const bool assembled = want_kkt && nvalues_ > 0;
   if (assembled) {
-    ensure_kkt_map(KKTLocations, data);
+    ensure_kkt_map(KKTLocations, data, hess_only);
     check(asset_hip_defect_eval_assembled(h_, what, X, L, fx_.data(), want_agx ? agx_.data() : nullptr, KKTvals),
           "asset_hip_defect_eval_assembled");
   } else {
@@ -137,7 +142,42 @@ void BatchedDefectConstraint::eval(int what, const double* X, const double* L, d
     if (want_agx) std::memcpy(AGX + data.InnerGradientStarts[V], agx_.data() + size_t(V) * ir_, sizeof(double) * ir_);
   }
   if (want_kkt && !assembled)
-    scatter_kkt(kkt_.data(), nkkt_, ir_, or_, what == ASSET_HIP_JAC_ADJGRAD_HESS, KKTvals, KKTLocations, data);
+    scatter_kkt(kkt_.data(), nkkt_, ir_, or_, what == ASSET_HIP_JAC_ADJGRAD_HESS, KKTvals, KKTLocations, data, !hess_only);
+}
+
+// ---- objective: the function's single output weighted by ObjScale (DenseScalarFunctionBase.h:14-80)
+void BatchedDefectConstraint::objective(double ObjScale, const double* X, double& Val, const SolverIndexingData& data) {
+  if (or_ != 1 || n_equal_ != 1)
+    throw std::invalid_argument("objective: the function must have one output and be constructed with equal_cons = 1");
+  std::vector<double> fx(size_t(nappl_), 0.0);
+  SolverIndexingData d = data;                       // value slots: one per application, in order
+  d.InnerConstraintStarts.resize(nappl_);
+  for (int V = 0; V < nappl_; V++) d.InnerConstraintStarts[V] = V;
+  eval(ASSET_HIP_CON, X, nullptr, fx.data(), nullptr, nullptr, nullptr, d);
+  for (int V = 0; V < nappl_; V++) Val += fx[V] * ObjScale;
+}
+void BatchedDefectConstraint::objective_gradient(double ObjScale, const double* X, double& Val, double* GX,
+                                                 const SolverIndexingData& data) {
+  if (or_ != 1 || n_equal_ != 1)
+    throw std::invalid_argument("objective: the function must have one output and be constructed with equal_cons = 1");
+  std::vector<double> fx(size_t(nappl_), 0.0);
+  SolverIndexingData d = data;
+  d.InnerConstraintStarts.resize(nappl_);
+  for (int V = 0; V < nappl_; V++) d.InnerConstraintStarts[V] = V;
+  eval(ASSET_HIP_CON_ADJGRAD, X, &ObjScale, fx.data(), GX, nullptr, nullptr, d);    // J^T lam with lam = ObjScale
+  for (int V = 0; V < nappl_; V++) Val += fx[V] * ObjScale;
+}
+void BatchedDefectConstraint::objective_gradient_hessian(double ObjScale, const double* X, double& Val, double* GX,
+                                                         double* KKTvals, const int* KKTLocations,
+                                                         const SolverIndexingData& data) {
+  if (or_ != 1 || n_equal_ != 1)
+    throw std::invalid_argument("objective: the function must have one output and be constructed with equal_cons = 1");
+  std::vector<double> fx(size_t(nappl_), 0.0);
+  SolverIndexingData d = data;
+  d.InnerConstraintStarts.resize(nappl_);
+  for (int V = 0; V < nappl_; V++) d.InnerConstraintStarts[V] = V;
+  eval(ASSET_HIP_JAC_ADJGRAD_HESS, X, &ObjScale, fx.data(), GX, KKTvals, KKTLocations, d, /*hess_only=*/true);
+  for (int V = 0; V < nappl_; V++) Val += fx[V] * ObjScale;
 }
 
 void BatchedDefectConstraint::enable_device_assembly(long long nvalues) {
@@ -146,23 +186,40 @@ void BatchedDefectConstraint::enable_device_assembly(long long nvalues) {
   map_source_ = nullptr;
 }
 
-void BatchedDefectConstraint::ensure_kkt_map(const int* lpt, const SolverIndexingData& data) {
+void BatchedDefectConstraint::ensure_kkt_map(const int* lpt, const SolverIndexingData& data, bool hess_only) {
   if (!lpt) throw std::invalid_argument("KKTLocations is null");
   if (int(data.InnerKKTStarts.size()) != nappl_) throw std::invalid_argument("InnerKKTStarts not filled: call getKKTSpace first");
-  bool fresh = (lpt == map_source_) && map_.size() == size_t(nappl_) * nkkt_;
-  if (fresh) {  // same array: make sure the solver did not re-fill it in place (cheap sample, 64 slots)
-    const size_t n = map_.size(), step = n / 64 + 1;
-    for (size_t s = 0; s < n && fresh; s += step) {
-      const size_t V = s / nkkt_, k = s - V * nkkt_;
-      fresh = (map_[s] == lpt[data.InnerKKTStarts[V] + k]);
+  // where block slot k of application V lives in the caller's KKT space: slot order `for i: {H(j>=i,i); J(:,i)}`; with
+  // hess_only the space holds the Hessian slots alone (an objective) and the block's Jacobian slots are dropped (-1)
+  auto space_slot = [&](int V, int i, int j_h, int j_j) -> int {   // exactly one of j_h / j_j is >= 0
+    int off = data.InnerKKTStarts[V];
+    if (!hess_only) {
+      off += i * (ir_ + or_) - i * (i - 1) / 2;                   // first slot of block column i
+      return lpt[off + (j_h >= 0 ? j_h - i : (ir_ - i) + j_j)];
     }
+    if (j_h < 0) return -1;
+    off += i * ir_ - i * (i - 1) / 2;
+    return lpt[off + (j_h - i)];
+  };
+  bool fresh = (lpt == map_source_) && map_.size() == size_t(nappl_) * nkkt_ && map_hess_only_ == hess_only;
+  if (fresh) {  // same array: make sure the solver did not re-fill it in place (cheap sample)
+    for (int V = 0; V < nappl_ && fresh; V += nappl_ / 16 + 1)
+      fresh = (map_[size_t(V) * nkkt_] == space_slot(V, 0, 0, -1)) &&
+              (map_[size_t(V) * nkkt_ + nkkt_ - or_ - 1] == space_slot(V, ir_ - 1, ir_ - 1, -1));
   }
   if (fresh) return;
   map_.resize(size_t(nappl_) * nkkt_);
-  for (int V = 0; V < nappl_; V++)
-    std::memcpy(map_.data() + size_t(V) * nkkt_, lpt + data.InnerKKTStarts[V], sizeof(int) * nkkt_);
+  for (int V = 0; V < nappl_; V++) {
+    int* m = map_.data() + size_t(V) * nkkt_;
+    int k = 0;
+    for (int i = 0; i < ir_; i++) {
+      for (int j = i; j < ir_; j++) m[k++] = space_slot(V, i, j, -1);
+      for (int j = 0; j < or_; j++) m[k++] = space_slot(V, i, -1, j);
+    }
+  }
   check(asset_hip_defect_set_kkt_map(h_, map_.data(), nvalues_, 0), "asset_hip_defect_set_kkt_map");
   map_source_ = lpt;
+  map_hess_only_ = hess_only;
 }
 
 void BatchedDefectConstraint::constraints(const double* X, double* FX, const SolverIndexingData& data) {

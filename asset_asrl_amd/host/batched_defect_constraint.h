@@ -72,20 +72,34 @@ class BatchedDefectConstraint {
   void disable_device_assembly() { nvalues_ = 0; }
   bool device_assembly() const { return nvalues_ > 0; }
 
-  // block scatter (public so it can be checked on its own): KKTFillAll / KKTFillJac, DenseFunctionBase.h:1413-1523
+  // block scatter (public so it can be checked on its own): KKTFillAll / KKTFillJac, DenseFunctionBase.h:1413-1523;
+  // dojac = false: KKTFillHess of a scalar objective (DenseScalarFunctionBase.h:82-126), whose space holds no
+  // Jacobian slots
   static void scatter_kkt(const double* kkt_blocks, int nkkt, int ir, int orr, bool dohess, double* KKTvals,
-                          const int* KKTLocations, const SolverIndexingData& data);
+                          const int* KKTLocations, const SolverIndexingData& data, bool dojac = true);
+
+  // ---- the same function used as an OBJECTIVE (one output): SolverObjectiveSpec::Concept, SolverInterfaceSpecs.h:252-281;
+  //      bodies DenseScalarFunctionBase.h:14-80.  Val is accumulated (+= ObjScale * f over the applications), the GX
+  //      slots are overwritten with ObjScale * grad f, the Hessian entries ObjScale * hess f are accumulated into KKTvals.
+  //      The index data of an objective has one Cindex row that points at multiplier 0 (the device reads ObjScale there);
+  //      its KKT space must have been claimed with getKKTSpace(..., dojac = false, dohess = true, ...), and the object
+  //      must have been constructed with equal_cons = 1 (its multiplier vector is the single number ObjScale).
+  void objective(double ObjScale, const double* X, double& Val, const SolverIndexingData& data);
+  void objective_gradient(double ObjScale, const double* X, double& Val, double* GX, const SolverIndexingData& data);
+  void objective_gradient_hessian(double ObjScale, const double* X, double& Val, double* GX, double* KKTvals,
+                                  const int* KKTLocations, const SolverIndexingData& data);
 
  private:
   void eval(int what, const double* X, const double* L, double* FX, double* AGX, double* KKTvals,
-            const int* KKTLocations, const SolverIndexingData& data);
+            const int* KKTLocations, const SolverIndexingData& data, bool hess_only = false);
   asset_hip_defect_t h_ = nullptr;
   std::string ode_;
-  int mode_, ir_ = 0, or_ = 0, nkkt_ = 0, nappl_ = 0;
+  int mode_, ir_ = 0, or_ = 0, nkkt_ = 0, nappl_ = 0, n_equal_ = 0;
   std::vector<double> fx_, agx_, kkt_;
   bool pinned_ = false;
   // device assembly state
-  void ensure_kkt_map(const int* KKTLocations, const SolverIndexingData& data);
+  void ensure_kkt_map(const int* KKTLocations, const SolverIndexingData& data, bool hess_only);
+  bool map_hess_only_ = false;
   long long nvalues_ = 0;
   const int* map_source_ = nullptr;
   std::vector<int> map_;          // [nappl][nkkt] value location of every block slot

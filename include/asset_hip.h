@@ -104,7 +104,8 @@ int asset_hip_host_unregister(void* ptr);
  *
  * asset_hip_defect_set_kkt_map: slot_locations[V*NKKT + k] = index in the solver's value array of block slot k of
  * application V, i.e. KKTLocations[InnerKKTStarts[V] + k] (block slot order as documented above); nvalues = length of
- * that value array.  Uploaded once per sparsity analysis.  accumulate = 0: locations used by a single slot are found
+ * that value array, or -1 for a slot whose entry is to be dropped (an objective keeps only the Hessian slots of its
+ * blocks: DenseScalarFunctionBase.h:48-80, getKKTSpace with dojac = false).  Uploaded once per sparsity analysis.  accumulate = 0: locations used by a single slot are found
  * here and written with plain stores, the shared ones (boundary nodes of adjacent segments, phase parameters) with
  * f64 atomics -- the device array must hold zeros at this constraint's locations on entry and then holds the
  * constraint's contributions.  accumulate = 1: every slot is added atomically, a true += into whatever the array

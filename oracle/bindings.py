@@ -55,7 +55,7 @@ def build_native() -> str:
     except (OSError, StopIteration):
         pass
     so = os.path.join(_HERE, f"liboracle_native_{hashlib.sha256(ident.encode()).hexdigest()[:10]}.so")
-    srcs = [os.path.join(_HERE, f) for f in ("defect.cpp", "nlp.cpp", "mesh.cpp", "pathfuncs.cpp", "odes.cpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("defect.cpp", "nlp.cpp", "mesh.cpp", "pathfuncs.cpp", "fullnlp.cpp", "odes.cpp")]
     gen = os.path.join(_HERE, "gen", "odes_gen.c")
     deps = srcs + [gen] + [os.path.join(_HERE, f) for f in ("odes.h", "ad2.h", "lgl_coeffs.h", "oracle.h")]
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
@@ -113,6 +113,21 @@ def lib(path=None):
         L.oracle_control_spline_all.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
         L.oracle_lgl_integral_all.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
         L.oracle_aux_table.argtypes = [C.c_int, C.c_char_p]
+        vp = C.c_void_p
+        L.oracle_fullnlp_create.argtypes = [C.c_int] * 3
+        L.oracle_fullnlp_create.restype = vp
+        L.oracle_fullnlp_destroy.argtypes = [vp]
+        L.oracle_fullnlp_add.argtypes = [vp, C.c_int, C.POINTER(OdeStruct), C.c_int, C.c_int, C.c_int, _ip, _ip]
+        L.oracle_fullnlp_add_integral.argtypes = [vp, C.c_int, C.POINTER(OdeStruct), C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip]
+        L.oracle_fullnlp_add_mesh_spacing.argtypes = [vp, C.c_int, C.c_int, C.c_int, _ip, _ip]
+        L.oracle_fullnlp_add_control_spline.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip]
+        for fn in ("analyze", "kkt_dim", "nnz", "num_user_kkt", "num_solver_kkt"):
+            getattr(L, "oracle_fullnlp_" + fn).argtypes = [vp]
+        L.oracle_fullnlp_csr.argtypes = [vp, _ip, _ip]
+        L.oracle_fullnlp_kkt_locations.argtypes = [vp, _ip]
+        L.oracle_fullnlp_solver_coeffs.argtypes = [vp]
+        L.oracle_fullnlp_solver_coeffs.restype = _dp
+        L.oracle_fullnlp_eval.argtypes = [vp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.oracle_aux_table.restype = _dp
         _LIB = L
     return _LIB
@@ -312,3 +327,74 @@ def lgl_integral_all(integrand: OdeStruct, cs, xv, pv, x, lam):
 def aux_table(cs, which):
     p = lib().oracle_aux_table(cs, which.encode())
     return np.array([p[i] for i in range(cs)]) if p else None
+
+
+class FullNlp:
+    """Objectives + equalities + inequalities with slacks: the whole KKT layout (oracle/fullnlp.cpp)."""
+    OBJ, EQ, IQ = 0, 1, 2
+
+    def __init__(self, primal, equal, inequal):
+        self.primal, self.equal, self.inequal = primal, equal, inequal
+        self.h = lib().oracle_fullnlp_create(primal, equal, inequal)
+        self._keep = []
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and lib is not None:
+            lib().oracle_fullnlp_destroy(h)
+
+    def _tables(self, vindex, cindex):
+        v = np.ascontiguousarray(vindex, dtype=np.int32)
+        c = np.ascontiguousarray(cindex if cindex is not None else np.zeros((v.shape[0], 1)), dtype=np.int32)
+        self._keep += [v, c]
+        return v, c
+
+    def add(self, kind, ode, mode, blocked, vindex, cindex=None):
+        v, c = self._tables(vindex, cindex)
+        self._keep.append(ode)
+        assert lib().oracle_fullnlp_add(self.h, kind, C.byref(ode), mode, int(blocked), v.shape[0], _i(v), _i(c)) >= 0
+
+    def add_integral(self, kind, integrand, cs, xv, pv, vindex, cindex=None):
+        v, c = self._tables(vindex, cindex)
+        self._keep.append(integrand)
+        assert lib().oracle_fullnlp_add_integral(self.h, kind, C.byref(integrand), cs, xv, pv, v.shape[0], _i(v), _i(c)) >= 0
+
+    def add_mesh_spacing(self, kind, cs, vindex, cindex):
+        v, c = self._tables(vindex, cindex)
+        assert lib().oracle_fullnlp_add_mesh_spacing(self.h, kind, cs, v.shape[0], _i(v), _i(c)) >= 0
+
+    def add_control_spline(self, kind, cs, usize, vindex, cindex):
+        v, c = self._tables(vindex, cindex)
+        assert lib().oracle_fullnlp_add_control_spline(self.h, kind, cs, usize, v.shape[0], _i(v), _i(c)) >= 0
+
+    def analyze(self):
+        L = lib()
+        L.oracle_fullnlp_analyze(self.h)
+        self.kkt_dim, self.nnz = L.oracle_fullnlp_kkt_dim(self.h), L.oracle_fullnlp_nnz(self.h)
+        self.num_user_kkt, self.num_solver_kkt = L.oracle_fullnlp_num_user_kkt(self.h), L.oracle_fullnlp_num_solver_kkt(self.h)
+
+    def csr(self):
+        outer, inner = np.zeros(self.kkt_dim + 1, dtype=np.int32), np.zeros(self.nnz, dtype=np.int32)
+        lib().oracle_fullnlp_csr(self.h, _i(outer), _i(inner))
+        return outer, inner
+
+    def kkt_locations(self):
+        locs = np.zeros(self.num_user_kkt + self.num_solver_kkt, dtype=np.int32)
+        lib().oracle_fullnlp_kkt_locations(self.h, _i(locs))
+        return locs
+
+    def set_solver_coeffs(self, coeffs):
+        p = lib().oracle_fullnlp_solver_coeffs(self.h)
+        for i, v in enumerate(np.asarray(coeffs, dtype=float)):
+            p[i] = v
+
+    def eval(self, level, obj_scale, X, LE, LI):
+        """-> (val, PGX, AGX, FXE, FXI, vals)"""
+        X, LE, LI = (np.ascontiguousarray(a, dtype=float) for a in (X, LE, LI))
+        val = C.c_double(0.0)
+        PGX, AGX = np.zeros(self.primal), np.zeros(self.primal)
+        FXE, FXI, vals = np.zeros(self.equal), np.zeros(max(self.inequal, 1)), np.zeros(self.nnz)
+        rc = lib().oracle_fullnlp_eval(self.h, level, float(obj_scale), _d(X), _d(LE), _d(LI),
+                                       C.cast(C.byref(val), _dp), _d(PGX), _d(AGX), _d(FXE), _d(FXI), _d(vals))
+        assert rc == 0
+        return val.value, PGX, AGX, FXE, FXI[: self.inequal], vals

@@ -62,6 +62,7 @@ AD2_ODE(coupled12, 12, 3, 2)
 AD2_ODE(coupled16, 16, 3, 2)
 AD2_ODE(pathcon, 2, 3, 0)
 AD2_ODE(integrand_quad2, 1, 0, 0)
+AD2_ODE(pairprod, 1, 2, 0)
 AD2_ODE(integrand_powp, 1, 2, 0)
 
 }  // namespace
@@ -90,6 +91,7 @@ GEN_DECL(coupled12)
 GEN_DECL(coupled16)
 GEN_DECL(pathcon)
 GEN_DECL(integrand_quad2)
+GEN_DECL(pairprod)
 GEN_DECL(integrand_powp)
 
 extern "C" {
@@ -121,6 +123,7 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(coupled16, 16, 3, 2, nullptr)
   TRY(pathcon, 2, 3, 0, nullptr)
   TRY(integrand_quad2, 1, 0, 0, nullptr)
+  TRY(pairprod, 1, 2, 0, nullptr)
   TRY(integrand_powp, 1, 2, 0, nullptr)
   return -1;
 }

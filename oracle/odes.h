@@ -74,6 +74,9 @@ void pathcon(const S* y, S* f, const void*) {
 // quad2: I(x0, x1) = x1^2 + x0 (the integrand of tests/test_gpu_function.py);  record (xv, uv, pv) = (1, 0, 0): 2 inputs.
 // powp: I(x0, x1, x2, p) = p x0^2 + sin(x1) x2 + exp(-x0 x2) / (1 + p^2): three node values and a phase parameter;
 // record (1, 2, 0): 4 inputs.
+// pairprod: c(a0, a1, b0, b1) = a0 b0 - a1 b1 - 0.5 -- the pair-wise path inequality of the function tests; record (1, 2, 0)
+template <class S>
+void pairprod(const S* y, S* f, const void*) { f[0] = y[0] * y[2] - y[1] * y[3] - 0.5; }
 template <class S>
 void integrand_quad2(const S* y, S* f, const void*) { f[0] = y[1] * y[1] + y[0]; }
 template <class S>

@@ -82,3 +82,73 @@ def make_coupled(n: int = 12):
 
 def make_coupled12():
     return make_coupled(12)
+
+
+class FullProblem:
+    """One Reentry LGL5 phase with everything a phase can hand the solver: the defect equality, a path equality at every
+    state, the mesh-spacing equality of every segment, a pair-wise path inequality between neighbouring states and an
+    integral objective over every segment.  Index tables only (numpy); the product and the oracle both build their
+    programs from `functions`: (kind, tag, vindex, cindex) with kind 0 objective / 1 equality / 2 inequality."""
+
+    def __init__(self, nseg: int = 13, seed: int = 77):
+        self.w = w = Workload("reentry", "LGL5", nseg, seed=seed)
+        ix = w.indexer
+        xtu, xv, S, cs = ix.XtUVars(), ix.xv, ix.numStates, w.cs
+        self.n_primal = w.n_primal
+        rows = w.n_equal
+        state = lambda k, v: k * xtu + v                                   # location of variable v of state k
+
+        def take(n):
+            nonlocal rows
+            r = np.arange(rows, rows + n, dtype=np.int32)
+            rows += n
+            return r
+        fns = [(1, "defect", w.vindex, w.cindex)]
+        pv = np.array([[state(k, v) for v in (0, 1, 2, 5, 6, 7)] for k in range(S)], dtype=np.int32)
+        fns.append((1, "pathcon", pv, take(2 * S).reshape(S, 2)))
+        tv = np.array([[state(s * (cs - 1) + j, xv) for j in range(cs)] for s in range(nseg)], dtype=np.int32)
+        fns.append((1, "meshspacing", tv, take(nseg * (cs - 2)).reshape(nseg, cs - 2)))
+        self.n_equal = rows
+        qv = np.array([[state(k + d, v) for d in (0, 1) for v in (3, 4)] for k in range(S - 1)], dtype=np.int32)
+        fns.append((2, "pairprod", qv, np.arange(S - 1, dtype=np.int32).reshape(S - 1, 1)))
+        self.n_inequal = S - 1
+        ov = np.array([[state(s * (cs - 1) + j, v) for j in range(cs) for v in (2, 0, xv)] for s in range(nseg)], dtype=np.int32)
+        fns.append((0, "integral", ov, None))
+        self.functions = fns
+        rng = np.random.default_rng(seed + 1)
+        self.X = w.X
+        self.LE = 10.0 * rng.uniform(-1, 1, self.n_equal)
+        self.LI = rng.uniform(0.1, 2.0, self.n_inequal)
+        self.obj_scale = 0.37
+        nsolver = self.n_inequal + self.n_primal + self.n_inequal + self.n_equal + self.n_inequal
+        self.solver_coeffs = np.concatenate([np.ones(self.n_inequal), rng.uniform(0.5, 1.5, nsolver - self.n_inequal)])
+
+    def oracle_nlp(self, ob):
+        n = ob.FullNlp(self.n_primal, self.n_equal, self.n_inequal)
+        for kind, tag, v, c in self.functions:
+            if tag == "defect":
+                n.add(kind, ob.get_ode("reentry", 0), ob.MODES["LGL5"], False, v, c)
+            elif tag == "pathcon":
+                n.add(kind, ob.get_ode("pathcon", 0), ob.MODES["Function"], False, v, c)
+            elif tag == "meshspacing":
+                n.add_mesh_spacing(kind, 3, v, c)
+            elif tag == "pairprod":
+                n.add(kind, ob.get_ode("pairprod", 0), ob.MODES["Function"], False, v, c)
+            else:
+                n.add_integral(kind, ob.get_ode("integrand_quad2", 0), 3, 2, 0, v, c)
+        n.analyze()
+        n.set_solver_coeffs(self.solver_coeffs)
+        return n
+
+    def product_functions(self):
+        """DSL definitions of the plain functions (the defect is the library ODE): tag -> (vf function, jit name)."""
+        from asset_asrl_amd import vf
+        from asset_asrl_amd.pathfuncs import LGLIntegral, LGLMeshSpacing
+        a = vf.Arguments(6)
+        x0, x1, x2, t, u0, u1 = a.tolist()
+        b = vf.Arguments(4)
+        g = vf.Arguments(2)
+        return {"pathcon": (vf.stack([x0 * x0 + x1 * u0 - vf.sin(x2), u0 * u0 + u1 * u1 - 1.0 + t * x0 * vf.exp(-1.0 * x1)]), "pathcon"),
+                "meshspacing": (LGLMeshSpacing(3), "lglmeshspacing3"),
+                "pairprod": (vf.stack([b[0] * b[2] - b[1] * b[3] - 0.5]), "iq0_pairwisepath"),
+                "integral": (LGLIntegral(g.coeff(1) * g.coeff(1) + g.coeff(0), 3, 2), "lglintegral3_quad2")}

@@ -2,6 +2,7 @@
 // NonLinearProgram::getMATSpace/getRHSSpace do for a single-thread NLP, runs one evaluation kind through the shim's
 // Concept-style methods and returns the scattered results.  Compiled by tests/test_gpu_host_shim.py.
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <vector>
 
@@ -76,6 +77,60 @@ extern "C" int assembly_run(const char* ode, int mode, int blocked, int ir, int 
       case 2: nlp.evalSOE(X, FXE, kkt_vals); break;
       case 3: nlp.evalAUG(X, L, FXE, AGX, kkt_vals); break;
       default: nlp.evalKKT(X, L, FXE, AGX, kkt_vals);
+    }
+    return nlp.nnz();
+  } catch (const std::exception& e) {
+    std::strncpy(err, e.what(), errcap - 1);
+    err[errcap - 1] = 0;
+    return -1;
+  }
+}
+
+// ---- KktAssembly with objectives, equalities and inequalities (slacks): the whole KKT layout ------------------------
+struct FnDesc {
+  int kind;            // 0 objective, 1 equality, 2 inequality
+  const char* name;    // device-side name (library ODE or run-time compiled function)
+  int mode, blocked, ir, orr, nappl;
+  const int* vindex;   // [ir x nappl] column-major
+  const int* cindex;   // [orr x nappl]; objectives: ignored (all applications read multiplier 0 = ObjScale)
+};
+
+// level: 0 evalOCC, 1 evalRHS, 2 evalSOE, 3 evalAUG, 4 evalKKT.  Returns nnz (or -1); *val = objective value.
+extern "C" int fullnlp_run(const FnDesc* fns, int nfn, int primal, int equal, int inequal, int level, double ObjScale,
+                           const double* X, const double* LE, const double* LI, const double* solver_coeffs,
+                           int* outer, int* inner, int inner_cap, int* locs, int locs_cap, double* val, double* PGX,
+                           double* AGX, double* FXE, double* FXI, double* kkt_vals, char* err, int errcap) {
+  try {
+    std::vector<SolverIndexingData> datas(nfn);
+    std::vector<std::unique_ptr<BatchedDefectConstraint>> cons;
+    for (int k = 0; k < nfn; k++) {
+      const FnDesc& f = fns[k];
+      SolverIndexingData& d = datas[k];
+      d.input_size = f.ir, d.output_size = f.orr, d.num_funcappl = f.nappl;
+      d.Vindex.assign(f.vindex, f.vindex + size_t(f.ir) * f.nappl);
+      if (f.kind == 0) d.Cindex.assign(size_t(f.orr) * f.nappl, 0);
+      else d.Cindex.assign(f.cindex, f.cindex + size_t(f.orr) * f.nappl);
+      const int ncon = f.kind == 0 ? 1 : (f.kind == 1 ? equal : inequal);
+      cons.emplace_back(new BatchedDefectConstraint(f.name, f.mode, f.blocked != 0, d, primal, ncon, 0));
+    }
+    KktAssembly nlp(primal, equal, inequal);
+    for (int k = 0; k < nfn; k++) {
+      if (fns[k].kind == 0) nlp.add_objective(*cons[k], datas[k]);
+      else if (fns[k].kind == 1) nlp.add_equality(*cons[k], datas[k]);
+      else nlp.add_inequality(*cons[k], datas[k]);
+    }
+    nlp.analyze();
+    if (nlp.nnz() > inner_cap || int(nlp.kkt_locations().size()) > locs_cap) throw std::runtime_error("capacity too small");
+    std::memcpy(outer, nlp.outer().data(), sizeof(int) * (nlp.kkt_dim() + 1));
+    std::memcpy(inner, nlp.inner().data(), sizeof(int) * nlp.nnz());
+    std::memcpy(locs, nlp.kkt_locations().data(), sizeof(int) * nlp.kkt_locations().size());
+    if (solver_coeffs) std::memcpy(nlp.solver_coeffs().data(), solver_coeffs, sizeof(double) * nlp.num_solver_kkt());
+    switch (level) {
+      case 0: *val = nlp.evalOCC(ObjScale, X, FXE, FXI); break;
+      case 1: *val = nlp.evalRHS(ObjScale, X, LE, LI, PGX, AGX, FXE, FXI); break;
+      case 2: nlp.evalSOE(X, FXE, FXI, kkt_vals); *val = 0.0; break;
+      case 3: *val = nlp.evalAUG(ObjScale, X, LE, LI, PGX, AGX, FXE, FXI, kkt_vals); break;
+      default: *val = nlp.evalKKT(ObjScale, X, LE, LI, PGX, AGX, FXE, FXI, kkt_vals);
     }
     return nlp.nnz();
   } catch (const std::exception& e) {
