@@ -36,6 +36,7 @@ SYMBOLS = {
     "asset_hip_defect_eval_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "asset_hip_defect_time_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int,
                                                                                          C.POINTER(C.c_float)]),
+    "asset_hip_defect_set_appl_consts": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "asset_hip_defect_set_kkt_map": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_longlong, C.c_int]),
     "asset_hip_defect_eval_assembled": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "asset_hip_defect_eval_assembled_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),

@@ -62,6 +62,7 @@ struct asset_hip_defect {
   double *d_X = nullptr, *d_L = nullptr, *d_fx = nullptr, *d_agx = nullptr, *d_kkt = nullptr;
   double* d_work = nullptr;  // per-workgroup ODE result slots
   void* d_lane[3] = {nullptr, nullptr, nullptr};   // per-lane constants of the dense stage by derivative level
+  double* d_aconst = nullptr;      // constants of every application of a plain function (asset_hip_defect_set_appl_consts)
   // on-device KKT assembly (asset_hip_defect_set_kkt_map)
   int32_t* d_map = nullptr;        // value location of every accumulator entry, fragment order (defect_kernels.h, ASM)
   size_t map_len = 0;
@@ -243,7 +244,7 @@ void asset_hip_defect_destroy(asset_hip_defect_t h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->d_vindex, (void*)h->d_cindex, (void*)h->d_X, (void*)h->d_L, (void*)h->d_fx,
-                  (void*)h->d_agx, (void*)h->d_kkt, (void*)h->d_work, (void*)h->d_map, (void*)h->d_values,
+                  (void*)h->d_agx, (void*)h->d_kkt, (void*)h->d_work, (void*)h->d_map, (void*)h->d_values, (void*)h->d_aconst,
                   h->d_lane[1], h->d_lane[2]})
     if (p) (void)hipFree(p);
   if (h->h_values) (void)hipHostFree(h->h_values);
@@ -279,6 +280,9 @@ static int launch(asset_hip_defect_t h, int what, const double* dX, const double
   a.KKT = (what >= ASSET_HIP_JAC) ? dkkt : nullptr;
   a.work = h->d_work;
   a.lane_consts = h->d_lane[level];
+  a.appl_consts = h->d_aconst;
+  if (h->ke->naconst > 0 && !h->d_aconst)
+    return fail(ASSET_HIP_EINVAL, "this function reads constants of its applications: call asset_hip_defect_set_appl_consts first");
   if (d_values) a.kmap = h->d_map, a.values = d_values, a.KKT = nullptr;   // on-device assembly
   hipError_t e = h->ke->launch(level, a, h->cus, st);
   if (e != hipSuccess) return hipfail(e, "kernel launch");
@@ -337,6 +341,17 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
   if (kkt && level >= 1 && what >= ASSET_HIP_JAC)
     HIP_TRY(hipMemcpyAsync(kkt, h->d_kkt, sizeof(double) * nkkt, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int asset_hip_defect_set_appl_consts(asset_hip_defect_t h, const double* consts, int per_application) {
+  if (!h || !consts) return fail(ASSET_HIP_EINVAL, "null handle / constants");
+  if (per_application != h->ke->naconst || per_application <= 0)
+    return fail(ASSET_HIP_EINVAL, "the number of constants per application does not match the function");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = size_t(h->nseg) * per_application;
+  if (!h->d_aconst) HIP_TRY(hipMalloc(&h->d_aconst, n * sizeof(double)));
+  HIP_TRY(hipMemcpy(h->d_aconst, consts, n * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 

@@ -48,6 +48,8 @@ struct EvalArgs {
   double* values = nullptr;
   // per-lane constants of the dense stage, computed once per handle (defect_kernels.h: LaneConsts, lane_setup_kernel)
   const void* lane_consts = nullptr;
+  // plain functions (func_kernels.h): constants of every application, [nseg][F::NACONST] (vf.ApplConst) or null
+  const double* appl_consts = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------- sizes

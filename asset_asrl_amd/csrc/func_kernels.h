@@ -29,8 +29,10 @@ struct FuncIn {
   const double* L;
   const int* vi;
   const int* ci;
+  const double* ac;    // this application's constants (vf.ApplConst; asset_hip_defect_set_appl_consts) or null
   __device__ double y(int i) const { return X[vi[i]]; }
   __device__ double lam(int k) const { return L ? L[ci[k]] : 0.0; }
+  __device__ double aconst(int k) const { return ac[k]; }
 };
 
 // out.J / out.g / out.H place an entry in FX, AGX or the block slot; ASM: into the solver's value array through the
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(64) void func_kernel(EvalArgs a) {
   using D = FuncDims<F>;
   const int V = blockIdx.x * blockDim.x + threadIdx.x;
   if (V >= a.nseg) return;
-  FuncIn<F> in{a.X, a.L, a.vindex + size_t(V) * D::IR, a.cindex + size_t(V) * D::OR};
+  FuncIn<F> in{a.X, a.L, a.vindex + size_t(V) * D::IR, a.cindex + size_t(V) * D::OR,
+               F::NACONST > 0 ? a.appl_consts + size_t(V) * F::NACONST : nullptr};
   FuncOut<F, ASM> out{a.FX ? a.FX + size_t(V) * D::OR : nullptr, a.AGX ? a.AGX + size_t(V) * D::IR : nullptr,
                       ASM ? a.values : (a.KKT ? a.KKT + size_t(V) * D::NKKT : nullptr),
                       ASM ? a.kmap + size_t(V) * D::NKKT : nullptr, LEVEL >= 2};

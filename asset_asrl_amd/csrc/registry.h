@@ -30,6 +30,7 @@ struct KernelEntry {
   // per-lane constants of the dense stage for derivative level 1 / 2: table size in bytes (0: none) and the kernel filling it
   size_t (*lane_bytes)(int level);
   hipError_t (*lane_setup)(int level, void* out, hipStream_t st);
+  int naconst = 0;        // plain functions: constants per application the function reads (vf.ApplConst)
 };
 
 #if defined(ASSET_PLUGIN)
@@ -156,7 +157,7 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   static ::asset_hip::KernelEntry entry_##FN##_func = {                                                           \
       FN::name(), FN::XV, FN::UV, FN::PV, 0, 0,                                                                   \
       ::asset_hip::FuncDims<FN>::IR, ::asset_hip::FuncDims<FN>::OR, ::asset_hip::FuncDims<FN>::NKKT, 0, 0, 0,    \
-      &::asset_hip::launch_func<FN>, nullptr, nullptr, nullptr, nullptr};                                         \
+      &::asset_hip::launch_func<FN>, nullptr, nullptr, nullptr, nullptr, FN::NACONST};                            \
   static ::asset_hip::Registrar reg_##FN##_func(&entry_##FN##_func);
 
 template <class Ode, int SCH, bool BLOCKED>

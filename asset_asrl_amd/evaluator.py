@@ -88,6 +88,11 @@ class DefectEvaluator:
                                                     _dptr(kkt)), "asset_hip_defect_eval")
         return fx, agx, kkt
 
+    def set_appl_consts(self, consts):
+        """Constants of every application of a plain function that reads some (vf.ApplConst): array [nseg, nconst]."""
+        c = np.ascontiguousarray(consts, dtype=np.float64).reshape(self.nseg, -1)
+        _lib.check(_lib.lib().asset_hip_defect_set_appl_consts(self._h, _dptr(c), c.shape[1]), "asset_hip_defect_set_appl_consts")
+
     def pin_outputs(self):
         """Allocate the block arrays once and page-lock them (asset_hip_host_register): ``eval`` then returns these
         arrays, overwritten by every call, and the copies out run at PCIe rate instead of through pageable staging."""

@@ -68,6 +68,10 @@ BatchedDefectConstraint::~BatchedDefectConstraint() {
   asset_hip_defect_destroy(h_);
 }
 
+void BatchedDefectConstraint::set_appl_consts(const double* consts, int per_application) {
+  check(asset_hip_defect_set_appl_consts(h_, consts, per_application), "asset_hip_defect_set_appl_consts");
+}
+
 std::string BatchedDefectConstraint::name() const {
   const char* m = mode_ == ASSET_HIP_TRAPEZOIDAL ? "Trapezoidal" : (mode_ == 2 ? "LGL3" : (mode_ == 3 ? "LGL5" : "LGL7"));
   return std::string("HIP_") + m + "Defects<" + ode_ + ">";

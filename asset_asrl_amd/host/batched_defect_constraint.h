@@ -41,6 +41,9 @@ class BatchedDefectConstraint {
   BatchedDefectConstraint(const BatchedDefectConstraint&) = delete;
   BatchedDefectConstraint& operator=(const BatchedDefectConstraint&) = delete;
 
+  // constants of the function's applications (a plain function built with vf.ApplConst): [NumAppl][per_application]
+  void set_appl_consts(const double* consts, int per_application);
+
   std::string name() const;
   int IRows() const { return ir_; }
   int ORows() const { return or_; }

@@ -104,7 +104,7 @@ class PhaseIndexer:
 
     # ---- region tables for plain functions -------------------------------------------------
     REGIONS = ("Front", "Back", "FrontandBack", "BackandFront", "Path", "InnerPath", "NodalPath", "PairWisePath",
-               "FrontNodalBackPath", "Params", "ODEParams", "StaticParams")
+               "FrontNodalBackPath", "DefectPath", "DefectPairWisePath", "Params", "ODEParams", "StaticParams")
 
     def make_Vindex_Cindex(self, region: str, xtuv=(), odepv=(), statpv=(), orows: int = 0, next_cloc: int | None = None):
         """Index tables of a function applied over a phase region (PhaseIndexer.cpp:132-360, PhaseRegionFlags of
@@ -153,8 +153,13 @@ class PhaseIndexer:
         elif region == "FrontNodalBackPath":
             states = nodal[1:D - 1] if only_u else nodal[1:D]
             rows = [first + at(k) + last + par for k in states]
+        elif region == "DefectPath":            # the cs states of every defect (PhaseIndexer.cpp:361-372)
+            rows = [[self.getXTUVarLoc(v, i * (cs - 1) + j, i) for j in range(cs) for v in xtuv] + par for i in range(D)]
+        elif region == "DefectPairWisePath":    # the 2cs-1 states of every pair of adjacent defects (:392-403)
+            rows = [[self.getXTUVarLoc(v, i * (cs - 1) + j, i) for j in range(2 * cs - 1) for v in xtuv] + par
+                    for i in range(D - 1)]
         else:
-            raise ValueError(f"unknown phase region {region!r}; one of {self.REGIONS} (DefectPath: make_defect_Vindex_Cindex)")
+            raise ValueError(f"unknown phase region {region!r}; one of {self.REGIONS}")
         V = np.asarray(rows, dtype=np.int32).reshape(len(rows), -1)
         c0 = self.con_offset + self.numPhaseEqCons if next_cloc is None else int(next_cloc)
         Cx = (c0 + np.arange(len(rows) * orows, dtype=np.int64)).reshape(len(rows), orows).astype(np.int32)

@@ -27,10 +27,13 @@ def LGLMeshSpacing(cs: int) -> vf.VectorFunction:
     return vf.stack([tc[i + 1] - (t.coeff(1 + i) - t.coeff(0)) / h for i in range(cs - 2)])
 
 
-def SingleMeshSpacing(cardinal_spacing: float, scale: float = 1.0) -> vf.VectorFunction:
-    """Inputs (t_0, t_j, t_f); output scale * (s * (t_f - t_0) - (t_j - t_0))  (MeshSpacingConstraints.h:33-41)."""
+def SingleMeshSpacing(cardinal_spacing=None, scale: float = 1.0) -> vf.VectorFunction:
+    """Inputs (t_0, t_j, t_f); output scale * (s * (t_f - t_0) - (t_j - t_0))  (MeshSpacingConstraints.h:33-41).
+    ``cardinal_spacing=None``: s is constant 0 of the function application (vf.ApplConst) -- one device function for
+    all the SingleMeshSpacing objects of a phase, which differ in nothing but s."""
     t = vf.Arguments(3)
-    return ((t.coeff(2) - t.coeff(0)) * cardinal_spacing - (t.coeff(1) - t.coeff(0))) * scale
+    s = vf.ApplConst(3, 0) if cardinal_spacing is None else cardinal_spacing
+    return ((t.coeff(2) - t.coeff(0)) * s - (t.coeff(1) - t.coeff(0))) * scale
 
 
 # Reduced_Integral_Weights of the schemes (LGLCoeffs.h:42, 135, 360-364; expressions kept as the reference writes them)
@@ -109,7 +112,10 @@ class FunctionEvaluator(DefectEvaluator):
     """``func`` applied to ``X[vindex[V]]`` for every application V, multipliers ``L[cindex[V]]``; device code is
     generated and compiled on first use (jit.ensure_function)."""
 
-    def __init__(self, func: vf.VectorFunction, name: str, vindex, cindex, n_primal: int, n_equal: int, device: int = 0):
+    def __init__(self, func: vf.VectorFunction, name: str, vindex, cindex, n_primal: int, n_equal: int, device: int = 0,
+                 appl_consts=None):
         self.func = func
         dev_name = jit.ensure_function(func, name)
         super().__init__(dev_name, _lib.FUNCTION, False, vindex, cindex, n_primal, n_equal, device)
+        if appl_consts is not None:
+            self.set_appl_consts(appl_consts)

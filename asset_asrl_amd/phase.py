@@ -6,8 +6,13 @@ Kept names / argument meaning (host orchestration only; nothing here is timed):
   ``test_threads(i, j, n)`` and ``returnTraj``
 (/root/reference/src/OptimalControl/ODEPhaseBase.cpp:536-670,1364-1441; ODEPhase.h:165-341,687-717;
  /root/reference/src/VectorFunctions/DenseFunctionBase.h:1546-1631).
-Constraints, objectives, PSIOPT and mesh refinement stay with the host solver and are out of scope here
-(SURVEY.md section 8): a Phase in this package carries only the dynamics (defect) constraint.
+Beside the defects a phase hands the solver the other per-segment functions the reference registers itself when it
+transcribes (ODEPhaseBase.cpp:962-1061): the mesh-spacing equalities (``LGLMeshSpacing`` over every defect,
+``SingleMeshSpacing`` at every inner nodal state) and, in the spline control modes, the control-spline continuity
+equalities (``LGLControlSpline`` over every pair of adjacent defects); user equalities / inequalities over phase regions
+(``addEqualCon`` / ``addInequalCon``) and integral objectives (``addIntegralObjective``, ODEPhaseBase.cpp:743-889:
+``LGLIntegral`` over every defect).  Each is one device evaluator batched over its applications.  PSIOPT, bounds, links
+and the mesh refinement loop stay with the host solver.
 """
 from __future__ import annotations
 
@@ -97,8 +102,12 @@ class Phase:
         self._ode_scaled = None
         self._eq_funcs = []       # (region, func, xtuv, opv, spv) -- addEqualCon
         self._iq_funcs = []       # addInequalCon
+        self._integral_objs = []  # (integrand, xtuv, opv, spv) -- addIntegralObjective
         self._eq_evs = []
         self._iq_evs = []
+        self._obj_evs = []
+        self._auto_evs = {}       # "mesh_spacing", "nodal_spacing", "control_spline": evaluators the phase adds itself
+        self.EnableMeshSpacing = True      # (the reference always adds them; the switch is for callers that only want the defects)
 
     # ---- configuration ---------------------------------------------------------------------
     def switchTranscriptionMode(self, mode: str):
@@ -200,6 +209,20 @@ class Phase:
         inequality space (PhaseIndexer.cpp:78-92)."""
         return self._add_func(self._iq_funcs, region, func, XtUVars, OPVars, SPVars)
 
+    def addIntegralObjective(self, integrand, XtUVars=(), OPVars=(), SPVars=()) -> int:
+        """Minimise ``int integrand(x, t, u, p) dt`` over the phase (ODEPhaseBase.cpp:743-889): the segment quadrature
+        ``LGLIntegral`` (LGLIntegrals.h:9-52; Trapezoidal phases use the two-node rule) of ``integrand`` over every defect,
+        summed.  ``integrand`` takes the chosen variables of one state and the chosen parameters; it is evaluated, with
+        its gradient and Hessian, on the device like any other function (``objective_evaluators``)."""
+        xtuv, opv, spv = [int(v) for v in XtUVars], [int(v) for v in OPVars], [int(v) for v in SPVars]
+        if integrand.ORows() != 1 or integrand.IRows() != len(xtuv) + len(opv) + len(spv):
+            raise ValueError("an integrand has one output and takes the listed state variables and parameters")
+        if self.ode.TVar() in xtuv:
+            raise ValueError("list the time variable among the integrand's inputs only through a state variable copy")
+        self._integral_objs.append((integrand, xtuv, opv, spv))
+        self._ev = None
+        return len(self._integral_objs) - 1
+
     def removeEqualCon(self, index: int):
         del self._eq_funcs[index]
         self._ev = None
@@ -221,10 +244,36 @@ class Phase:
         units += [1.0] * (func.IRows() - len(units))
         return IOScaled(func, units, np.ones(func.ORows()))
 
-    def _make_function_evaluators(self, ix):
-        from .pathfuncs import FunctionEvaluator
+    def _make_function_evaluators(self, ix, build_only: bool = False):
+        from .pathfuncs import FunctionEvaluator as _FE
+
+        def FunctionEvaluator(F, name, *args, **kw):      # build_only: device code only (no handle: works without a GPU)
+            return jit.ensure_function(F, name) if build_only else _FE(F, name, *args, **kw)
         self._eq_evs, self._iq_evs = [], []
         next_eq, next_iq = ix.con_offset + ix.numPhaseEqCons, 0
+        # ---- what the phase registers itself, right after the defects (transcribe_phase, ODEPhaseBase.cpp:1371-1375:
+        #      dynamics, axis functions, control functions, integrals, user functions): mesh spacing, then control splines
+        from .pathfuncs import LGLControlSpline, LGLIntegral, LGLMeshSpacing, SingleMeshSpacing
+        cs, D, tv = ix.DefectCardinalStates, ix.numDefects, [self.ode.TVar()]
+        auto = []
+        if self.EnableMeshSpacing:
+            if self.TranscriptionMode in ("LGL5", "LGL7"):     # transcribe_axis_funcs: LGLMeshSpacing<CS> over DefectPath
+                V, Cx, next_eq = ix.make_Vindex_Cindex("DefectPath", tv, (), (), cs - 2, next_eq)
+                auto.append(("mesh_spacing", LGLMeshSpacing(cs), f"lglmeshspacing{cs}", V, Cx))
+            if D >= 2:
+                # SingleMeshSpacing(i / D) at the inner nodal states i = 1..D-1 (FrontNodalBackPath; the reference adds one
+                # function object per state, addPartitionedEquality): ONE device function whose spacing is a constant of the
+                # application (vf.ApplConst), so the D - 1 relations are one batched evaluator
+                V, Cx, next_eq = ix.make_Vindex_Cindex("FrontNodalBackPath", tv, (), (), 1, next_eq)
+                auto.append(("nodal_spacing", SingleMeshSpacing(None), "nodalmeshspacing", V, Cx))
+        if self.ode.UVars() > 0 and not self._blocked() and D >= 2:   # transcribe_control_funcs
+            order = {("LGL7", "HighestOrderSpline"): 2, ("LGL7", "FirstOrderSpline"): 1, ("LGL5", "HighestOrderSpline"): 1,
+                     ("LGL5", "FirstOrderSpline"): 1}.get((self.TranscriptionMode, self.ControlMode))
+            if order:
+                tu = tv + list(range(self.ode.TVar() + 1, self.ode.TVar() + 1 + self.ode.UVars()))
+                F = LGLControlSpline(cs, self.ode.UVars(), order)
+                V, Cx, next_eq = ix.make_Vindex_Cindex("DefectPairWisePath", tu, (), (), F.ORows(), next_eq)
+                auto.append(("control_spline", F, f"lglcontrolspline{cs}_{self.ode.UVars()}_{order}", V, Cx))
         todo = []
         for store, is_eq in ((self._eq_funcs, True), (self._iq_funcs, False)):
             for k, (region, func, xtuv, opv, spv) in enumerate(store):
@@ -240,6 +289,18 @@ class Phase:
         for is_eq, f, name, V, Cx in todo:
             ev = FunctionEvaluator(f, name, V, Cx, ix.numPhaseVars, next_eq if is_eq else next_iq, self.device)
             (self._eq_evs if is_eq else self._iq_evs).append(ev)
+        self._auto_evs = {}
+        for tag, F, name, V, Cx in auto:
+            consts = (np.arange(1, D) / D)[:, None] if tag == "nodal_spacing" else None    # cspace of one bin (:963-970)
+            self._auto_evs[tag] = FunctionEvaluator(F, name, V, Cx, ix.numPhaseVars, next_eq, self.device, appl_consts=consts)
+        # ---- integral objectives: LGLIntegral over every defect (ODEPhaseBase.cpp:743-889)
+        self._obj_evs = []
+        for k, (integrand, xtuv, opv, spv) in enumerate(self._integral_objs):
+            f = LGLIntegral(integrand, cs, len(xtuv), len(opv) + len(spv))
+            V, _, _ = ix.make_Vindex_Cindex("DefectPath", xtuv + tv, opv, spv, 0, 0)
+            Cx = np.zeros((V.shape[0], 1), dtype=np.int32)           # every application reads multiplier 0 = ObjScale
+            self._obj_evs.append(FunctionEvaluator(f, f"obj{k}_integral{cs}", V, Cx, ix.numPhaseVars, 1,
+                                                   self.device))
 
     @property
     def equality_evaluators(self):
@@ -247,6 +308,20 @@ class Phase:
         if self._ev is None:
             self.transcribe()
         return list(self._eq_evs)
+
+    @property
+    def objective_evaluators(self):
+        """Device evaluators of the integral objectives (one output per defect; multiplier vector = [ObjScale])."""
+        if self._ev is None:
+            self.transcribe()
+        return list(self._obj_evs)
+
+    @property
+    def phase_function_evaluators(self):
+        """The equalities the phase adds itself: {"mesh_spacing", "nodal_spacing", "control_spline"} -> evaluator."""
+        if self._ev is None:
+            self.transcribe()
+        return dict(self._auto_evs)
 
     @property
     def inequality_evaluators(self):
@@ -268,6 +343,20 @@ class Phase:
         self._make_function_evaluators(ix)
         self._ev = DefectEvaluator(name, self.TranscriptionMode, self._blocked(), V, Cx, ix.numPhaseVars,
                                    self.numPhaseEqCons, self.device)
+        return self
+
+    def prebuild_device_code(self):
+        """Generate and compile (or find in the in-tree cache) the device code of everything this phase would hand the
+        solver -- defects, the functions it registers itself, user functions, objectives -- without creating a device
+        handle: runs where there is a compiler but no GPU (the build step), so that a GPU box only loads plugins."""
+        if self.ActiveTraj is None:
+            raise RuntimeError("No trajectory set: call setTraj first")
+        jit.ensure_kernel(self._active_ode(), self.TranscriptionMode, self._blocked())
+        ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
+        ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
+        ix.begin_indexing(0, 0)
+        self._make_function_evaluators(ix, build_only=True)
+        self._eq_evs, self._iq_evs, self._obj_evs, self._auto_evs = [], [], [], {}
         return self
 
     def solver_input(self) -> np.ndarray:

@@ -166,6 +166,7 @@ class _Printer:
         self.lines: List[str] = []
         self.used_y = set()
         self.used_l = set()
+        self.used_c = set()
         self.yname, self.lname = yname, lname
         self.device_math = pair_sincos      # device functors: csrc/asset_math.h trig (short argument reduction)
         loaded = loaded or {}
@@ -192,6 +193,8 @@ class _Printer:
                 self.used_y.add(n.value)
             elif n.op == "lam":
                 self.used_l.add(n.value)
+            elif n.op == "aconst":
+                self.used_c.add(n.value)
             if n.id in loaded:
                 self.names[n.id] = loaded[n.id]
                 continue
@@ -216,6 +219,8 @@ class _Printer:
             return self.yname.format(n.value)
         if n.op == "lam":
             return self.lname.format(n.value)
+        if n.op == "aconst":
+            return f"c{n.value}"
         return self.names[n.id]
 
     def _expr(self, n: Node) -> str:
@@ -287,6 +292,8 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     o.append(f"struct {struct_name} {{")
     o.append(f"  static constexpr int XV = {d.xv}, UV = {d.uv}, PV = {d.pv}, NIN = {N};")
     o.append(f"  static constexpr int NNZ_J = {st['nnz_J']}, NNZ_H = {st['nnz_H_lower']};")
+    nac = 1 + max([nd.value for nd in topo_order(_level_roots(d, 2)) if nd.op == "aconst"], default=-1)
+    o.append(f"  static constexpr int NACONST = {nac};   // constants of the application the function reads (vf.ApplConst)")
     o.append(f"  static constexpr const char* name() {{ return \"{d.name}\"; }}")
     # structural sparsity: compact position of every J (row-major) / H (packed lower) entry or -1, and its inverse.
     # The LGL workspace stores only the non-zeros; the dense accessors ignore these tables.
@@ -336,6 +343,8 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
             o.append(f"    const double y{i} = in.y({i});")
         for k in sorted(p.used_l):
             o.append(f"    const double l{k} = in.lam({k});")
+        for k in sorted(p.used_c):
+            o.append(f"    const double c{k} = in.aconst({k});")   # constants of the application (vf.ApplConst)
         if use_saved:
             for k in range(len(saved)):
                 o.append(f"    const double s{k} = in.saved({k});")

@@ -128,11 +128,11 @@ class VectorFunction:
         return self.compute(arg)
 
     # ---- host-side numeric evaluation (set-up / tests only) ------------------------
-    def compute(self, x) -> np.ndarray:
+    def compute(self, x, appl_consts=()) -> np.ndarray:
         x = np.asarray(x, dtype=float).ravel()
         if x.size != self._irows:
             raise ValueError("Input vector has incorrect size")
-        return np.array(evaluate(self.outs, x))
+        return np.array(evaluate(self.outs, x, (), appl_consts))
 
     # ---- arithmetic ----------------------------------------------------------------
     def _bin(self, other, fn, swap=False):
@@ -284,6 +284,13 @@ class MatrixFunction:
 
 def Arguments(n: int) -> VectorFunction:
     return VectorFunction(n, [G.var(i) for i in range(n)])
+
+
+def ApplConst(irows: int, k: int = 0) -> VectorFunction:
+    """Scalar function (of `irows` inputs) whose value is the k-th constant of the function application: data the caller
+    supplies per application beside the solver vector (``FunctionEvaluator(..., appl_consts=array[napp, nconst])``).  It
+    has no derivative, so it adds no column to the function's Jacobian / Hessian blocks."""
+    return VectorFunction(irows, [G.aconst(k)])
 
 
 def Segment(irows: int, size: int, start: int) -> VectorFunction:

@@ -46,7 +46,7 @@ class Node:
     def __repr__(self):
         if self.op == "const":
             return f"c({self.value!r})"
-        if self.op in ("var", "lam"):
+        if self.op in ("var", "lam", "aconst"):
             return f"{self.op}{self.value}"
         return f"{self.op}#{self.id}"
 
@@ -81,6 +81,12 @@ class Graph:
     def lam(self, k: int) -> Node:
         """Adjoint (multiplier) input; a second family of leaves."""
         return self._mk("lam", (), int(k))
+
+    def aconst(self, k: int) -> Node:
+        """Constant of the function APPLICATION (a third family of leaves): a number the caller supplies per application
+        beside the solver variables -- e.g. the nodal spacing of the reference's SingleMeshSpacing objects, one object per
+        state there.  Never differentiated against; its derivative with respect to every input is zero."""
+        return self._mk("aconst", (), int(k))
 
     # ---- arithmetic with folding --------------------------------------------------
     def add(self, a: Node, b: Node) -> Node:
@@ -219,6 +225,8 @@ class Graph:
             return self.zero
         if op in ("var", "lam"):
             return self.one if n is w else self.zero
+        if op == "aconst":
+            return self.zero
         a = n.args[0]
         da = self.d(a, w)
         if op in _UNARY or op in ("powi", "powr"):
@@ -395,7 +403,7 @@ def topo_order(roots: Sequence[Node]) -> List[Node]:
     return out
 
 
-def evaluate(roots: Sequence[Node], y: Sequence[float], lam: Sequence[float] = ()) -> List[float]:
+def evaluate(roots: Sequence[Node], y: Sequence[float], lam: Sequence[float] = (), aconst: Sequence[float] = ()) -> List[float]:
     """Host-side numeric walk of the DAG (set-up time checks only, never the hot path)."""
     val: Dict[int, float] = {}
     for n in topo_order(roots):
@@ -406,6 +414,8 @@ def evaluate(roots: Sequence[Node], y: Sequence[float], lam: Sequence[float] = (
             v = float(y[n.value])
         elif op == "lam":
             v = float(lam[n.value])
+        elif op == "aconst":
+            v = float(aconst[n.value])
         elif op == "add":
             v = val[n.args[0].id] + val[n.args[1].id]
         elif op == "sub":

@@ -90,6 +90,13 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
 int asset_hip_defect_eval_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
                                  double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_blocks, void* stream);
 
+/* Plain functions (ASSET_HIP_FUNCTION) may read constants of their applications beside the solver vector -- data with no
+ * derivative, e.g. the nodal spacing of every SingleMeshSpacing object the reference creates, one object per state
+ * (OptimalControl/ODEPhaseBase.cpp:962-985, MeshSpacingConstraints.h:8-41): consts[V * per_application + k] is constant k
+ * of application V.  Uploaded once; evaluation fails with ASSET_HIP_EINVAL while a function that reads constants has
+ * none. */
+int asset_hip_defect_set_appl_consts(asset_hip_defect_t h, const double* consts, int per_application);
+
 /* Page-locks / releases a caller-owned host range so that the host-pointer entry points move it by DMA at PCIe rate
  * instead of through the driver's pageable staging (about 4x faster for the block arrays).  For buffers that live
  * across evaluations -- the reference's RHS coefficient arrays and KKT value array do (NonLinearProgram.h:330-341,

@@ -121,6 +121,7 @@ def lib(path=None):
         L.oracle_fullnlp_add_integral.argtypes = [vp, C.c_int, C.POINTER(OdeStruct), C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip]
         L.oracle_fullnlp_add_mesh_spacing.argtypes = [vp, C.c_int, C.c_int, C.c_int, _ip, _ip]
         L.oracle_fullnlp_add_control_spline.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip]
+        L.oracle_fullnlp_add_single_mesh_spacing.argtypes = [vp, C.c_int, _dp, C.c_double, C.c_int, _ip, _ip]
         for fn in ("analyze", "kkt_dim", "nnz", "num_user_kkt", "num_solver_kkt"):
             getattr(L, "oracle_fullnlp_" + fn).argtypes = [vp]
         L.oracle_fullnlp_csr.argtypes = [vp, _ip, _ip]
@@ -366,6 +367,11 @@ class FullNlp:
     def add_control_spline(self, kind, cs, usize, vindex, cindex):
         v, c = self._tables(vindex, cindex)
         assert lib().oracle_fullnlp_add_control_spline(self.h, kind, cs, usize, v.shape[0], _i(v), _i(c)) >= 0
+
+    def add_single_mesh_spacing(self, kind, spacings, vindex, cindex, scale=1.0):
+        v, c = self._tables(vindex, cindex)
+        sp = np.ascontiguousarray(spacings, dtype=float)
+        assert lib().oracle_fullnlp_add_single_mesh_spacing(self.h, kind, _d(sp), float(scale), v.shape[0], _i(v), _i(c)) >= 0
 
     def analyze(self):
         L = lib()

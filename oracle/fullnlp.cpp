@@ -23,7 +23,7 @@ struct Fn {
   std::vector<int> vindex, cindex;   // col-major [ir x nappl], [orr x nappl]
   std::vector<int> con_starts, grad_starts, kkt_starts;
   // x[ir], lam[orr] -> fx[orr], jx[orr x ir col-major], agx[ir], hx[ir x ir col-major]
-  std::function<void(const double*, const double*, double*, double*, double*, double*)> all;
+  std::function<void(int, const double*, const double*, double*, double*, double*, double*)> all;   // (application, ...)
   int VLoc(int i, int V) const { return vindex[(size_t)V * ir + i]; }
   int CLoc(int j, int V) const { return cindex[(size_t)V * orr + j]; }
 };
@@ -40,7 +40,7 @@ struct oracle_fullnlp {
 
 namespace {
 int add_fn(oracle_fullnlp* n, int kind, int ir, int orr, int nappl, const int* vindex, const int* cindex,
-           std::function<void(const double*, const double*, double*, double*, double*, double*)> all) {
+           std::function<void(int, const double*, const double*, double*, double*, double*, double*)> all) {
   Fn f;
   f.kind = kind, f.ir = ir, f.orr = orr, f.nappl = nappl;
   f.vindex.assign(vindex, vindex + (size_t)ir * nappl);
@@ -68,7 +68,7 @@ int oracle_fullnlp_add(oracle_fullnlp* n, int kind, const oracle_ode* fn, int mo
   if (kind == 0 && orr != 1) return -2;
   const oracle_ode o = *fn;
   return add_fn(n, kind, ir, orr, nappl, vindex, cindex,
-                [o, mode, blocked](const double* x, const double* l, double* fx, double* jx, double* ag, double* hx) {
+                [o, mode, blocked](int, const double* x, const double* l, double* fx, double* jx, double* ag, double* hx) {
                   oracle_defect_all(&o, mode, blocked, x, l, fx, jx, ag, hx);
                 });
 }
@@ -76,21 +76,31 @@ int oracle_fullnlp_add_integral(oracle_fullnlp* n, int kind, const oracle_ode* i
                                 int nappl, const int* vindex, const int* cindex) {
   const oracle_ode o = *integrand;
   return add_fn(n, kind, cs * (xv + 1) + pv, 1, nappl, vindex, cindex,
-                [o, cs, xv, pv](const double* x, const double* l, double* fx, double* jx, double* ag, double* hx) {
+                [o, cs, xv, pv](int, const double* x, const double* l, double* fx, double* jx, double* ag, double* hx) {
                   oracle_lgl_integral_all(&o, cs, xv, pv, x, l, fx, jx, ag, hx);
                 });
 }
 int oracle_fullnlp_add_mesh_spacing(oracle_fullnlp* n, int kind, int cs, int nappl, const int* vindex, const int* cindex) {
   return add_fn(n, kind, cs, cs - 2, nappl, vindex, cindex,
-                [cs](const double* x, const double* l, double* fx, double* jx, double* ag, double* hx) {
+                [cs](int, const double* x, const double* l, double* fx, double* jx, double* ag, double* hx) {
                   oracle_lgl_mesh_spacing_all(cs, x, l, fx, jx, ag, hx);
                 });
 }
 int oracle_fullnlp_add_control_spline(oracle_fullnlp* n, int kind, int cs, int usize, int nappl, const int* vindex,
                                       const int* cindex) {
   return add_fn(n, kind, (2 * cs - 1) * (usize + 1), usize * (cs - 2), nappl, vindex, cindex,
-                [cs, usize](const double* x, const double* l, double* fx, double* jx, double* ag, double* hx) {
+                [cs, usize](int, const double* x, const double* l, double* fx, double* jx, double* ag, double* hx) {
                   oracle_control_spline_all(cs, usize, 0, x, l, fx, jx, ag, hx);
+                });
+}
+
+// SingleMeshSpacing objects, one per application, each with its own spacing (ODEPhaseBase.cpp:962-985 addPartitionedEquality)
+int oracle_fullnlp_add_single_mesh_spacing(oracle_fullnlp* n, int kind, const double* spacings, double scale, int nappl,
+                                           const int* vindex, const int* cindex) {
+  std::vector<double> sp(spacings, spacings + nappl);
+  return add_fn(n, kind, 3, 1, nappl, vindex, cindex,
+                [sp, scale](int V, const double* x, const double* l, double* fx, double* jx, double* ag, double* hx) {
+                  oracle_single_mesh_spacing_all(sp[V], scale, x, l, fx, jx, ag, hx);
                 });
 }
 
@@ -210,7 +220,7 @@ int oracle_fullnlp_eval(oracle_fullnlp* n, int level, double ObjScale, const dou
         for (int j = 0; j < f.orr; j++) l[j] = (L && grads) ? L[f.CLoc(j, V)] : 0.0;
       std::fill(fx.begin(), fx.end(), 0.0), std::fill(jx.begin(), jx.end(), 0.0);
       std::fill(ag.begin(), ag.end(), 0.0), std::fill(hx.begin(), hx.end(), 0.0);
-      f.all(x.data(), l.data(), fx.data(), jx.data(), ag.data(), hx.data());
+      f.all(V, x.data(), l.data(), fx.data(), jx.data(), ag.data(), hx.data());
       if (f.kind == 0) {
         *val += fx[0] * ObjScale;
         if (grads)

@@ -106,6 +106,8 @@ def test_phase_add_constraints_evaluate_over_their_regions(oracle):
     from helpers import Workload
     w = Workload("reentry", "LGL5", 23)
     ph = ShuttleReentry().phase("LGL5", w.traj, 23)
+    ph.setControlMode("NoSpline")                                             # (only the user functions beside the defects:
+    ph.EnableMeshSpacing = False                                              #  the phase's own ones: test_gpu_phase_functions.py)
     k_eq = ph.addEqualCon("Path", _pathcon(), [0, 1, 2, 5, 6, 7])            # x0, x1, x2, t, u0, u1 of every state
     a = vf.Arguments(4)
     k_iq = ph.addInequalCon("PairWisePath", vf.stack([a[0] * a[2] - a[1] * a[3] - 0.5]), [3, 4])

@@ -1,0 +1,99 @@
+"""What ``Phase.transcribe()`` registers beside the defects, as the reference's own transcribe does
+(ODEPhaseBase.cpp:962-1061, 743-889, 1371-1375): the mesh-spacing equalities (LGLMeshSpacing over every defect,
+SingleMeshSpacing at every inner nodal state), the control-spline equalities of the spline control modes, integral
+objectives -- each one device evaluator, checked application by application against the oracle's restatements, and the
+row numbering / index tables against the registration order of the reference."""
+import numpy as np
+import pytest
+
+from asset_asrl_amd import vf
+from asset_asrl_amd.evaluator import JAC_ADJGRAD_HESS, unpack_kkt_block
+from asset_asrl_amd.ode import ShuttleReentry
+from helpers import Workload, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ev, X, L, ref, scale=1.0):
+    fx, agx, kkt = ev.eval(JAC_ADJGRAD_HESS, X, L)
+    for V in range(ev.nseg):
+        rfx, rjx, rgx, rhx = ref(V, X[ev.vindex[V]], L[ev.cindex[V]])
+        Hd, Jd = unpack_kkt_block(kkt[V], ev.IR, ev.OR)
+        assert np.abs(fx[V] - rfx).max() < 1e-10 * max(1.0, scale)
+        assert rel_err(Jd, rjx) < 1e-8 and rel_err(agx[V], rgx) < 1e-8 and rel_err(Hd, rhx, floor=1e-9) < 1e-8
+
+
+@pytest.mark.parametrize("mode,control,order", [("LGL7", "HighestOrderSpline", 2), ("LGL7", "FirstOrderSpline", 1),
+                                                ("LGL5", "HighestOrderSpline", 1)])
+def test_transcribe_registers_spacing_and_spline_equalities(oracle, mode, control, order):
+    nseg = 17
+    w = Workload("reentry", mode, nseg)
+    ph = ShuttleReentry().phase(mode, w.traj, nseg)
+    ph.setControlMode(control)
+    ph.transcribe()
+    ix, cs, D = ph._indexer, w.cs, nseg
+    S, xtu, tcol = ix.numStates, ix.XtUVars(), ph.ode.TVar()
+    evs = ph.phase_function_evaluators
+    assert set(evs) == {"mesh_spacing", "nodal_spacing", "control_spline"}
+    ms, ns, sp = evs["mesh_spacing"], evs["nodal_spacing"], evs["control_spline"]
+    # rows: defects, then LGLMeshSpacing, SingleMeshSpacing, LGLControlSpline (transcribe_phase order)
+    r0 = ix.numPhaseEqCons
+    np.testing.assert_array_equal(ms.cindex.ravel(), r0 + np.arange(D * (cs - 2)))
+    r1 = r0 + D * (cs - 2)
+    np.testing.assert_array_equal(ns.cindex.ravel(), r1 + np.arange(D - 1))
+    r2 = r1 + D - 1
+    np.testing.assert_array_equal(sp.cindex.ravel(), r2 + np.arange((D - 1) * 2 * order))
+    assert ph.numPhaseEqCons == r2 + (D - 1) * 2 * order == ph.evaluator.n_equal
+    # tables: the node times of a defect / first, nodal, last time / [t, u0, u1] of the 2cs-1 states of a defect pair
+    t_of = lambda k: k * xtu + tcol
+    np.testing.assert_array_equal(ms.vindex, [[t_of(i * (cs - 1) + j) for j in range(cs)] for i in range(D)])
+    np.testing.assert_array_equal(ns.vindex, [[t_of(0), t_of(i * (cs - 1)), t_of(S - 1)] for i in range(1, D)])
+    np.testing.assert_array_equal(sp.vindex, [[(i * (cs - 1) + j) * xtu + v for j in range(2 * cs - 1) for v in (tcol, tcol + 1, tcol + 2)]
+                                              for i in range(D - 1)])
+    X = ph.solver_input()
+    rng = np.random.default_rng(3)
+    X = X + rng.uniform(-1e-3, 1e-3, X.size)                                   # off the exact spacing: non-zero residuals
+    L = rng.uniform(-2, 2, ph.numPhaseEqCons)
+    _check(ms, X, L, lambda V, x, l: oracle.lgl_mesh_spacing_all(cs, x, l))
+    _check(ns, X, L, lambda V, x, l: oracle.single_mesh_spacing_all((V + 1) / D, x, l), scale=np.abs(X).max())
+    _check(sp, X, L, lambda V, x, l: oracle.control_spline_all(cs, 2, x, l, order=order), scale=np.abs(X).max() ** 2)
+    # the defects still evaluate with the longer multiplier vector
+    assert ph.evaluator.eval(JAC_ADJGRAD_HESS, X, L)[0].shape == (nseg, ph.evaluator.OR)
+
+
+def test_no_spline_equalities_without_spline_control(oracle):
+    w = Workload("reentry", "LGL7", 5)
+    for control in ("NoSpline", "BlockConstant"):
+        ph = ShuttleReentry().phase("LGL7", w.traj, 5)
+        ph.setControlMode(control)
+        ph.transcribe()
+        assert set(ph.phase_function_evaluators) == {"mesh_spacing", "nodal_spacing"}
+    ph = ShuttleReentry().phase("LGL3", Workload("reentry", "LGL3", 5).traj, 5)
+    ph.transcribe()
+    assert set(ph.phase_function_evaluators) == {"nodal_spacing"}              # LGL3: no inner cardinal node, no spline
+
+
+def test_integral_objective_evaluates_the_segment_quadrature(oracle):
+    """addIntegralObjective (ODEPhaseBase.cpp:743-889): LGLIntegral of the integrand over every defect; the evaluator's
+    multiplier vector is [ObjScale], its adjoint gradient the scaled gradient, its Hessian block the scaled Hessian."""
+    nseg = 19
+    w = Workload("reentry", "LGL7", nseg)
+    ph = ShuttleReentry().phase("LGL7", w.traj, nseg)
+    g = vf.Arguments(2)
+    assert ph.addIntegralObjective(g.coeff(1) * g.coeff(1) + g.coeff(0), [2, 0]) == 0      # inputs (v, h): h^2 + v
+    ph.transcribe()
+    (ob_ev,) = ph.objective_evaluators
+    ix, cs, xtu, tcol = ph._indexer, 4, ph._indexer.XtUVars(), ph.ode.TVar()
+    np.testing.assert_array_equal(ob_ev.vindex, [[(i * 3 + j) * xtu + v for j in range(cs) for v in (2, 0, tcol)] for i in range(nseg)])
+    X = ph.solver_input()
+    scale = np.array([0.37])
+    quad2 = oracle.get_ode("integrand_quad2", 0)
+    _check(ob_ev, X, scale, lambda V, x, l: oracle.lgl_integral_all(quad2, 4, 2, 0, x, l), scale=np.abs(X).max() ** 2)
+    # the objective value: sum over the defects of h * sum_j w_j (h_j^2 + v_j)  [inputs (v, h): y1^2 + y0], w = Reduced_Integral_Weights of the header
+    import json
+    import os
+    wts = np.array(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lgl_tables.json")))["tables"]["4"]["Reduced_Integral_Weights"])
+    fx = ob_ev.eval(0, X)[0]
+    T = ph.ActiveTraj
+    expect = sum((T[3 * i + 3, tcol] - T[3 * i, tcol]) * np.dot(wts, T[3 * i:3 * i + 4, 0] ** 2 + T[3 * i:3 * i + 4, 2]) for i in range(nseg))
+    assert abs(fx.sum() - expect) < 1e-11 * abs(expect), (fx.sum(), expect)
