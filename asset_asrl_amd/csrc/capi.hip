@@ -7,13 +7,60 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/asset_hip.h"
 #include <dlfcn.h>
 
 #include "registry.h"
+
+namespace asset_hip {
+// values[loc[l]] = sum of stage[ptr[l] .. ptr[l+1]) in a FIXED order: thread t of the block adds cells t, t+256, ... in
+// sequence, then the 256 partial sums are folded by a tree of fixed shape.  One block per location.
+__global__ __launch_bounds__(256) void asm_reduce_kernel(double* values, const double* stage, const int* ptr, const int* loc) {
+  __shared__ double part[256];
+  const int l = blockIdx.x, t = threadIdx.x;
+  double s = 0.0;
+  for (int k = ptr[l] + t; k < ptr[l + 1]; k += 256) s += stage[k];
+  part[t] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) part[t] += part[t + w];
+    __syncthreads();
+  }
+  if (t == 0) values[loc[l]] = part[0];
+}
+
+// RHS fill on the device (NonLinearProgram.h:401-407 RHSFillOP: target[rows[k]] += coeffs[k]) as a GATHER: one thread per
+// target row adds that row's contributions (ptr / src: CSR by row over the block entries, source order) in a fixed
+// order -- no atomics, bitwise repeatable.  Rows with many contributors (phase parameters) take gather_long_kernel.
+__global__ __launch_bounds__(256) void rhs_gather_kernel(double* target, const double* blocks, const int* rows, const int* ptr,
+                                                         const int* src, int nrows, int long_from) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows || r >= long_from) return;
+  double s = 0.0;
+  for (int k = ptr[r]; k < ptr[r + 1]; k++) s += blocks[src[k]];
+  target[rows[r]] += s;
+}
+__global__ __launch_bounds__(256) void rhs_gather_long_kernel(double* target, const double* blocks, const int* rows,
+                                                              const int* ptr, const int* src, int long_from) {
+  __shared__ double part[256];
+  const int r = long_from + blockIdx.x, t = threadIdx.x;
+  double s = 0.0;
+  for (int k = ptr[r] + t; k < ptr[r + 1]; k += 256) s += blocks[src[k]];
+  part[t] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) part[t] += part[t + w];
+    __syncthreads();
+  }
+  if (t == 0) target[rows[r]] += part[0];
+}
+
+}  // namespace asset_hip
 
 namespace {
 
@@ -69,6 +116,16 @@ struct asset_hip_defect {
   double* d_values = nullptr;      // [value_hi - value_lo) staging for the host-pointer entry point
   double* h_values = nullptr;      // pinned mirror of d_values
   long long value_lo = 0, value_hi = 0, nvalues = 0;
+  // locations with three or more contributing slots: staged cells + fixed-order reduction (defect_dims.h, asm_reduce_kernel)
+  double* d_stage = nullptr;
+  int *d_multi_ptr = nullptr, *d_multi_loc = nullptr;
+  int nmulti = 0;
+  size_t nstage = 0;
+  // device RHS fill (asset_hip_defect_eval_kkt_device): CSR by target row over the FX / AGX block entries
+  int *d_fx_rows = nullptr, *d_fx_ptr = nullptr, *d_fx_src = nullptr, *d_gx_rows = nullptr, *d_gx_ptr = nullptr, *d_gx_src = nullptr;
+  int n_fx_rows = 0, fx_long_from = 0, n_gx_rows = 0, gx_long_from = 0;
+  double *d_fxb = nullptr, *d_agxb = nullptr;    // block buffers of that entry point
+  std::vector<int32_t> h_vindex, h_cindex;       // kept for the RHS tables (built on first use)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -210,6 +267,8 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
     return bail(e, "hipMemcpy(vindex)");
   if ((e = hipMemcpy(h->d_cindex, d->cindex, nc * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess)
     return bail(e, "hipMemcpy(cindex)");
+  h->h_vindex.assign(d->vindex, d->vindex + nv);
+  h->h_cindex.assign(d->cindex, d->cindex + nc);
   if (ke->work_doubles) {
     if ((e = hipMalloc(&h->d_work, size_t(h->nseg) * ke->work_doubles * sizeof(double))) != hipSuccess)
       return bail(e, "hipMalloc(workspace)");
@@ -245,6 +304,8 @@ void asset_hip_defect_destroy(asset_hip_defect_t h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->d_vindex, (void*)h->d_cindex, (void*)h->d_X, (void*)h->d_L, (void*)h->d_fx,
                   (void*)h->d_agx, (void*)h->d_kkt, (void*)h->d_work, (void*)h->d_map, (void*)h->d_values, (void*)h->d_aconst,
+                  (void*)h->d_stage, (void*)h->d_multi_ptr, (void*)h->d_multi_loc, (void*)h->d_fx_rows, (void*)h->d_fx_ptr,
+                  (void*)h->d_fx_src, (void*)h->d_gx_rows, (void*)h->d_gx_ptr, (void*)h->d_gx_src, (void*)h->d_fxb, (void*)h->d_agxb,
                   h->d_lane[1], h->d_lane[2]})
     if (p) (void)hipFree(p);
   if (h->h_values) (void)hipHostFree(h->h_values);
@@ -283,9 +344,17 @@ static int launch(asset_hip_defect_t h, int what, const double* dX, const double
   a.appl_consts = h->d_aconst;
   if (h->ke->naconst > 0 && !h->d_aconst)
     return fail(ASSET_HIP_EINVAL, "this function reads constants of its applications: call asset_hip_defect_set_appl_consts first");
-  if (d_values) a.kmap = h->d_map, a.values = d_values, a.KKT = nullptr;   // on-device assembly
+  if (d_values) {                                                          // on-device assembly
+    a.kmap = h->d_map, a.values = d_values, a.KKT = nullptr;
+    a.stage = h->d_stage, a.nvalues = int(h->nvalues);
+  }
   hipError_t e = h->ke->launch(level, a, h->cus, st);
   if (e != hipSuccess) return hipfail(e, "kernel launch");
+  if (d_values && h->nmulti > 0 && level >= 2) {   // the staged locations (Hessian entries only): fixed-order sums
+    hipLaunchKernelGGL(asset_hip::asm_reduce_kernel, dim3(h->nmulti), dim3(256), 0, st, d_values, h->d_stage, h->d_multi_ptr,
+                       h->d_multi_loc);
+    if ((e = hipGetLastError()) != hipSuccess) return hipfail(e, "asm_reduce_kernel");
+  }
   return 0;
 }
 
@@ -430,20 +499,65 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
     hi = m + 1 > hi ? m + 1 : hi;
   }
   if (hi <= lo) return fail(ASSET_HIP_EINVAL, "kkt map keeps no slot");
-  // a location used by exactly one slot is stored to, one that several slots share is added to atomically
-  // (encoding: defect_dims.h, EvalArgs::kmap); in accumulate mode every slot adds
+  // a location used by exactly one slot is stored to; one that two slots share is added to atomically (two terms: the
+  // order cannot matter); one that three or more share is STAGED -- every such slot gets a cell of its own and the cells
+  // of a location are summed in slot order afterwards (encoding: defect_dims.h, EvalArgs::kmap / stage).  In accumulate
+  // mode every slot adds atomically into whatever the array holds.
   std::vector<unsigned char> uses(accumulate ? 0 : size_t(hi - lo), 0);
   if (!accumulate)
     for (size_t i = 0; i < nslots; i++) {
       if (slot_locations[i] < 0) continue;
       unsigned char& u = uses[size_t(slot_locations[i] - lo)];
-      if (u < 2) u++;
+      if (u < 3) u++;
     }
-  auto encode = [&](int32_t m) { return m < 0 ? -1 : ((accumulate || uses[size_t(m - lo)] > 1) ? -(m + 2) : m); };
+  // only Hessian slots are staged (a Jacobian slot's location belongs to one constraint row of one application; and the
+  // Jacobian-only evaluation kinds write no Hessian entry, so they must not leave cells half-filled)
+  const int IRk = h->ke->ir, ORk = h->ke->orr, NKk = h->ke->nkkt;
+  std::vector<unsigned char> is_h(NKk, 0);
+  for (int c = 0, k = 0; c < IRk; c++) {
+    for (int j = c; j < IRk; j++) is_h[k++] = 1;
+    k += ORk;
+  }
+  auto staged = [&](size_t i) {
+    const int32_t m = slot_locations[i];
+    return m >= 0 && is_h[i % size_t(NKk)] && uses[size_t(m - lo)] >= 3;
+  };
+  std::vector<int32_t> multi_loc, multi_ptr(1, 0);
+  std::unordered_map<int32_t, int> multi_of;           // location -> index in multi_loc
+  if (!accumulate) {
+    for (size_t i = 0; i < nslots; i++) {
+      const int32_t m = slot_locations[i];
+      if (staged(i) && multi_of.emplace(m, 0).second) multi_loc.push_back(m);
+    }
+    std::sort(multi_loc.begin(), multi_loc.end());
+    for (size_t l = 0; l < multi_loc.size(); l++) multi_of[multi_loc[l]] = int(l);
+    std::vector<int> cnt(multi_loc.size(), 0);
+    for (size_t i = 0; i < nslots; i++) {
+      if (staged(i)) cnt[multi_of[slot_locations[i]]]++;
+    }
+    multi_ptr.resize(multi_loc.size() + 1);
+    for (size_t l = 0; l < multi_loc.size(); l++) multi_ptr[l + 1] = multi_ptr[l] + cnt[l];
+    if (nvalues + (long long)multi_ptr.back() + 2 > 2147483647LL)
+      return fail(ASSET_HIP_ERANGE, "value array + staging cells exceed the 32-bit map range");
+  }
+  std::vector<int32_t> enc(nslots);                     // map word of every slot, slot order (cells are handed out in it)
+  {
+    std::vector<int> fill(multi_ptr.begin(), multi_ptr.end() - (multi_ptr.size() > 1 ? 1 : 0));
+    for (size_t i = 0; i < nslots; i++) {
+      const int32_t m = slot_locations[i];
+      if (m < 0) enc[i] = -1;
+      else if (accumulate) enc[i] = -(m + 2);
+      else {
+        const unsigned char u = uses[size_t(m - lo)];
+        if (u == 1) enc[i] = m;
+        else if (!staged(i) || !multi_of.count(m)) enc[i] = -(m + 2);   // (a location staged for its Hessian slots takes no other)
+        else enc[i] = -(int32_t(nvalues) + fill[multi_of[m]]++ + 2);
+      }
+    }
+  }
   std::vector<int32_t> map;
   if (h->ke->mode == ASSET_HIP_FUNCTION) {   // plain functions place their entries slot by slot (func_kernels.h)
-    map.resize(nslots);
-    for (size_t i = 0; i < nslots; i++) map[i] = encode(slot_locations[i]);
+    map = enc;
   } else {
     // fragment order of the LGL dense stage (defect_kernels.h, ASM): for every segment (4*tiles) rows of 64 lanes;
     // lane (lr = l & 15, lk = l >> 4), entry v of an accumulator tile is block column c = 16ct + lk + 4v and row
@@ -473,7 +587,9 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
     for (int V = 0; V < h->nseg; V++) {
       const int32_t* loc = slot_locations + size_t(V) * NK;
       int32_t* dst = map.data() + size_t(V) * NF * 64;
-      for (size_t e = 0; e < size_t(NF) * 64; e++) dst[e] = slot_of[e] < 0 ? -1 : encode(loc[slot_of[e]]);
+      const int32_t* encV = enc.data() + size_t(V) * NK;
+      (void)loc;
+      for (size_t e = 0; e < size_t(NF) * 64; e++) dst[e] = slot_of[e] < 0 ? -1 : encV[slot_of[e]];
     }
   }
   if (h->d_map && h->map_len != map.size()) {
@@ -489,6 +605,19 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
     h->d_values = nullptr, h->h_values = nullptr;
   }
   h->value_lo = lo, h->value_hi = hi, h->nvalues = nvalues;
+  // staging cells and the reduction lists
+  for (void* p : {(void*)h->d_stage, (void*)h->d_multi_ptr, (void*)h->d_multi_loc})
+    if (p) (void)hipFree(p);
+  h->d_stage = nullptr, h->d_multi_ptr = h->d_multi_loc = nullptr;
+  h->nmulti = int(multi_loc.size()), h->nstage = size_t(multi_ptr.back());
+  if (h->nmulti > 0) {
+    HIP_TRY(hipMalloc(&h->d_stage, h->nstage * sizeof(double)));
+    HIP_TRY(hipMemset(h->d_stage, 0, h->nstage * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->d_multi_ptr, multi_ptr.size() * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_multi_loc, multi_loc.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(h->d_multi_ptr, multi_ptr.data(), multi_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_multi_loc, multi_loc.data(), multi_loc.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -503,6 +632,82 @@ int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
   // the dense stage places its accumulators in the value array itself (defect_kernels.h, ASM instantiations)
   return launch(h, what, dX, dL, d_fx_blocks, d_agx_blocks, nullptr, st, d_kkt_values);
+}
+
+// CSR by target row over the entries of a block array ([nseg][width], entry e = V * width + i goes to row index[e]):
+// rows sorted ascending, short rows (<= 64 contributors) first.  Returns the split point.
+static int build_rhs_csr(const std::vector<int32_t>& index, std::vector<int>& rows, std::vector<int>& ptr,
+                         std::vector<int>& src) {
+  const size_t n = index.size();
+  std::vector<int> order(n);
+  for (size_t e = 0; e < n; e++) order[e] = int(e);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return index[a] < index[b]; });   // source order within a row
+  struct Row { int row, begin, end; };
+  std::vector<Row> rr;
+  for (size_t k = 0; k < n;) {
+    size_t e = k;
+    while (e < n && index[order[e]] == index[order[k]]) e++;
+    rr.push_back(Row{index[order[k]], int(k), int(e)});
+    k = e;
+  }
+  std::stable_partition(rr.begin(), rr.end(), [](const Row& r) { return r.end - r.begin <= 64; });
+  rows.clear(), ptr.assign(1, 0), src.clear();
+  src.reserve(n);
+  int long_from = int(rr.size());
+  for (size_t i = 0; i < rr.size(); i++) {
+    if (rr[i].end - rr[i].begin > 64 && long_from == int(rr.size())) long_from = int(i);
+    rows.push_back(rr[i].row);
+    for (int k = rr[i].begin; k < rr[i].end; k++) src.push_back(order[k]);
+    ptr.push_back(int(src.size()));
+  }
+  return long_from;
+}
+
+int asset_hip_defect_eval_kkt_device(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* d_FXE,
+                                     double* d_AGX, double* d_kkt_values, void* stream) {
+  if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
+  if (!d_FXE) return fail(ASSET_HIP_EINVAL, "FXE is null");
+  const bool want_kkt = what >= ASSET_HIP_JAC;
+  const bool want_agx = (what == ASSET_HIP_CON_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD_HESS);
+  if (want_kkt && (!h->d_map || !d_kkt_values)) return fail(ASSET_HIP_EINVAL, "no kkt map / value array for a kind that fills the matrix");
+  if (want_agx && !d_AGX) return fail(ASSET_HIP_EINVAL, "AGX is null for a kind that produces the adjoint gradient");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  const int IR = h->ke->ir, OR = h->ke->orr;
+  if (!h->d_fx_rows) {   // the gather tables, once per handle
+    std::vector<int> rows, ptr, src;
+    auto up = [&](int*& d, const std::vector<int>& v) -> hipError_t {
+      hipError_t e = hipMalloc(&d, (v.size() + 1) * sizeof(int));
+      return e != hipSuccess ? e : hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+    };
+    h->fx_long_from = build_rhs_csr(h->h_cindex, rows, ptr, src);
+    h->n_fx_rows = int(rows.size());
+    HIP_TRY(up(h->d_fx_rows, rows));
+    HIP_TRY(up(h->d_fx_ptr, ptr));
+    HIP_TRY(up(h->d_fx_src, src));
+    h->gx_long_from = build_rhs_csr(h->h_vindex, rows, ptr, src);
+    h->n_gx_rows = int(rows.size());
+    HIP_TRY(up(h->d_gx_rows, rows));
+    HIP_TRY(up(h->d_gx_ptr, ptr));
+    HIP_TRY(up(h->d_gx_src, src));
+    HIP_TRY(hipMalloc(&h->d_fxb, sizeof(double) * size_t(h->nseg) * OR));
+    HIP_TRY(hipMalloc(&h->d_agxb, sizeof(double) * size_t(h->nseg) * IR));
+  }
+  int rc = launch(h, what, dX, dL, h->d_fxb, want_agx ? h->d_agxb : nullptr, nullptr, st, want_kkt ? d_kkt_values : nullptr);
+  if (rc) return rc;
+  auto gather = [&](double* target, const double* blocks, const int* rows, const int* ptr, const int* src, int nrows,
+                    int long_from) -> hipError_t {
+    if (long_from > 0)
+      hipLaunchKernelGGL(asset_hip::rhs_gather_kernel, dim3((long_from + 255) / 256), dim3(256), 0, st, target, blocks, rows, ptr,
+                         src, nrows, long_from);
+    if (nrows > long_from)
+      hipLaunchKernelGGL(asset_hip::rhs_gather_long_kernel, dim3(nrows - long_from), dim3(256), 0, st, target, blocks, rows,
+                         ptr, src, long_from);
+    return hipGetLastError();
+  };
+  HIP_TRY(gather(d_FXE, h->d_fxb, h->d_fx_rows, h->d_fx_ptr, h->d_fx_src, h->n_fx_rows, h->fx_long_from));
+  if (want_agx) HIP_TRY(gather(d_AGX, h->d_agxb, h->d_gx_rows, h->d_gx_ptr, h->d_gx_src, h->n_gx_rows, h->gx_long_from));
+  return 0;
 }
 
 int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double* X, const double* L,

@@ -46,6 +46,13 @@ struct EvalArgs {
   // every slot is encoded as shared, which makes the evaluation a true += at about 1.4e11 atomics/s.
   const int* kmap = nullptr;
   double* values = nullptr;
+  // Locations that three or more slots share (entries between phase parameters: one contribution per segment) are not
+  // added to atomically -- the order of the additions, hence the last bits of the sum, would change from run to run --
+  // but STAGED: the map names such a location as nvalues + k, slot k of `stage`, every staged slot owns one cell, and
+  // asm_reduce_kernel sums the cells of each location in slot order afterwards (capi.hip).  Locations with exactly two
+  // contributors (boundary nodes of adjacent segments) keep the atomic: a + b = b + a, bit for bit.
+  double* stage = nullptr;
+  int nvalues = 0;
   // per-lane constants of the dense stage, computed once per handle (defect_kernels.h: LaneConsts, lane_setup_kernel)
   const void* lane_consts = nullptr;
   // plain functions (func_kernels.h): constants of every application, [nseg][F::NACONST] (vf.ApplConst) or null
@@ -246,6 +253,17 @@ __device__ constexpr bool tiles_share_node(int ct, int rt) {
   if (D::p > 0 && r1 >= D::P0) return true;                 // parameter rows couple to every column
   const int jc0 = c0 / D::q, jc1 = c1 / D::q, jr0 = r0 / D::q, jr1 = r1 / D::q;
   return !(jr1 < jc0 || jc1 < jr0);
+}
+
+// Assembled store of one KKT entry through its map word (EvalArgs::kmap): m >= 0 plain store, -1 dropped, m <= -2 shared
+// location -(m + 2): atomic add, or (>= nvalues) its own staging cell.
+__device__ inline void asm_put(const EvalArgs& a, double* values, int m, double v) {
+  if (m >= 0) values[m] = v;
+  else if (m != -1) {
+    const int loc = -(m + 2);
+    if (loc < a.nvalues) unsafeAtomicAdd(values + loc, v);       // global_atomic_add_f64, no return
+    else a.stage[loc - a.nvalues] = v;
+  }
 }
 
 // One wave per workgroup.  LDS instructions of a wave execute in issue order, so LDS hand-offs between lanes only

@@ -1036,10 +1036,7 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
           for (int v = 0; v < 4; v++) jmap[t][v] = kmap_seg[((D::NTH + t) * 4 + v) * 64];
         }
       };
-      auto put_asm = [&](int off, double val) {           // map encoding: defect_dims.h, EvalArgs::kmap
-        if (off >= 0) kkt_dst[off] = val;                  // location owned by this slot alone
-        else if (off != -1) unsafeAtomicAdd(kkt_dst + (-(off + 2)), val);   // shared: global_atomic_add_f64, no return
-      };
+      auto put_asm = [&](int off, double val) { asm_put(a, kkt_dst, off, val); };   // map encoding: defect_dims.h
       auto store_H_tile = [&](int rt, int ct, const d4& acc) {   // entry v: row r = 16rt + lr, column c = 16ct + lk + 4v
         const int tix = rt * (rt + 1) / 2 + ct;
         if constexpr (ASM) {

@@ -391,9 +391,7 @@ void lgl_wide_dense_kernel(EvalArgs a) {
     const int* const kmap_seg = ASM ? a.kmap + seg * size_t((NTH + TI * TJ) * 4) * 64 + lane : nullptr;
     auto put = [&](int frag, int slot, double val) {
       if constexpr (ASM) {
-        const int off = kmap_seg[frag * 64];
-        if (off >= 0) kkt_dst[off] = val;
-        else if (off != -1) unsafeAtomicAdd(kkt_dst + (-(off + 2)), val);
+        asm_put(a, kkt_dst, kmap_seg[frag * 64], val);
       } else {
         if (slot >= 0) kkt_dst[slot] = val;
       }

@@ -45,12 +45,10 @@ struct FuncOut {
   double* kkt;        // block base, or the value array (ASM)
   const int* kmap;    // this application's slot -> location entries (ASM)
   bool hess;
+  const EvalArgs* args;
   __device__ void put(int slot, double v) {
-    if constexpr (ASM) {
-      const int m = kmap[slot];
-      if (m >= 0) kkt[m] = v;
-      else if (m != -1) unsafeAtomicAdd(kkt + (-(m + 2)), v);   // (-1: a dropped slot, e.g. the Jacobian of an objective)
-    } else kkt[slot] = v;
+    if constexpr (ASM) asm_put(*args, kkt, kmap[slot], v);   // (-1: a dropped slot, e.g. the Jacobian of an objective)
+    else kkt[slot] = v;
   }
   __device__ void f(int k, double v) { if (fx) fx[k] = v; }
   __device__ void J(int k, int i, double v) { if (kkt) put(D::col_start(i) + (D::IR - i) + k, v); }
@@ -68,7 +66,7 @@ __global__ __launch_bounds__(64) void func_kernel(EvalArgs a) {
                F::NACONST > 0 ? a.appl_consts + size_t(V) * F::NACONST : nullptr};
   FuncOut<F, ASM> out{a.FX ? a.FX + size_t(V) * D::OR : nullptr, a.AGX ? a.AGX + size_t(V) * D::IR : nullptr,
                       ASM ? a.values : (a.KKT ? a.KKT + size_t(V) * D::NKKT : nullptr),
-                      ASM ? a.kmap + size_t(V) * D::NKKT : nullptr, LEVEL >= 2};
+                      ASM ? a.kmap + size_t(V) * D::NKKT : nullptr, LEVEL >= 2, &a};
   if constexpr (LEVEL == 0) F::f(in, out);
   else if constexpr (LEVEL == 2) F::fjgh(in, out);
   else {

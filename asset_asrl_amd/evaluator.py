@@ -139,6 +139,14 @@ class DefectEvaluator:
                                                                      self._p(agx), self._p(kkt_values), st),
                    "asset_hip_defect_eval_assembled_device")
 
+    def eval_kkt_device(self, what: int, X, L, FXE, AGX, kkt_values, stream=None):
+        """Constraint values ADDED into FXE[n_equal], adjoint gradient into AGX[n_primal], KKT entries into kkt_values
+        (as eval_assembled_device): the constraint's whole share of an evalKKT on the device, bitwise repeatable."""
+        st = None if stream is None else C.c_void_p(stream if isinstance(stream, int) else stream.cuda_stream)
+        _lib.check(_lib.lib().asset_hip_defect_eval_kkt_device(self._h, what, self._p(X), self._p(L), self._p(FXE),
+                                                               self._p(AGX), self._p(kkt_values), st),
+                   "asset_hip_defect_eval_kkt_device")
+
     # ---- device-pointer evaluation (torch tensors or raw ints) ------------------------------
     @staticmethod
     def _p(t):

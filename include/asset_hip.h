@@ -114,8 +114,10 @@ int asset_hip_host_unregister(void* ptr);
  * that value array, or -1 for a slot whose entry is to be dropped (an objective keeps only the Hessian slots of its
  * blocks: DenseScalarFunctionBase.h:48-80, getKKTSpace with dojac = false).  Uploaded once per sparsity analysis.  accumulate = 0: locations used by a single slot are found
  * here and written with plain stores, the shared ones (boundary nodes of adjacent segments, phase parameters) with
- * f64 atomics -- the device array must hold zeros at this constraint's locations on entry and then holds the
- * constraint's contributions.  accumulate = 1: every slot is added atomically, a true += into whatever the array
+ * f64 atomics when exactly two slots share them (the sum of two terms does not depend on their order) and, when three or
+ * more do (entries between phase parameters: one contribution per segment), through staging cells that are summed in
+ * slot order after the kernel, so the assembled values are bitwise repeatable -- the device array must hold zeros at
+ * this constraint's locations on entry and then holds the constraint's contributions.  accumulate = 1: every slot is added atomically, a true += into whatever the array
  * holds (about 2x the evaluation time).
  * asset_hip_defect_eval_assembled: host pointers; FX / AGX blocks as in asset_hip_defect_eval; kkt_values[nvalues] is
  * ACCUMULATED into (the caller zeroes it per evaluation, PSIOPT.cpp:107) -- the contributions are summed in a zeroed
@@ -128,6 +130,18 @@ int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double
                                     double* agx_blocks, double* kkt_values);
 int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
                                            double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_values, void* stream);
+
+/* The whole of the reference's evalKKT / evalSOE / evalRHS / evalOCC share of ONE constraint on the device
+ * (Solvers/NonLinearProgram.cpp:347-537 worker bodies + the RHS fill NonLinearProgram.h:379-407): the constraint values
+ * are ADDED into d_FXE[n_equal] at their Cindex rows, the adjoint gradient into d_AGX[n_primal] at their Vindex rows
+ * (kinds that contract with L; may be NULL otherwise), the KKT entries into d_kkt_values as
+ * asset_hip_defect_eval_assembled_device does (kinds >= ASSET_HIP_JAC; needs the map).  No block array leaves the
+ * device.  The RHS fill is a gather -- one thread per target row adds that row's contributions in source order, rows
+ * with many contributors (phase parameters) by a fixed tree -- and the value locations with three or more contributors
+ * are summed in slot order from staging cells: every output is bitwise repeatable from run to run.  The target vectors
+ * are accumulated into: zero them per evaluation (setRHSCoeffsZero, NonLinearProgram.cpp:487). */
+int asset_hip_defect_eval_kkt_device(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* d_FXE,
+                                     double* d_AGX, double* d_kkt_values, void* stream);
 
 /* Measures the evaluation kernel itself: `iters` back-to-back device evaluations on the handle's stream
  * bracketed by HIP events (after `warmup` untimed ones); *ms_per_launch = elapsed / iters. */

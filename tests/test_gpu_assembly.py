@@ -95,3 +95,40 @@ def test_assembly_argument_errors(oracle):
     with pytest.raises(_lib.AssetHipError, match="outside"):
         ev.set_kkt_map(bad, 50)
     ev.close()
+
+
+@pytest.mark.parametrize("ode,mode,nseg,blocked", [
+    ("betts_lowthrust", "LGL5", 1000, False),        # BASELINE configs[1]: the phase parameter couples all 1 000 segments
+    ("twobody_lt", "LGL5", 10000, True),             # BASELINE configs[3] dynamics, BlockConstant control, one phase's size
+])
+def test_full_size_assembly_and_rhs_on_the_device_are_exact_and_repeatable(oracle, ode, mode, nseg, blocked):
+    """asset_hip_defect_eval_kkt_device at BASELINE sizes: KKT values, FXE and AGX assembled on the device against the
+    oracle's evalKKT restatement, and bit-for-bit the same in two runs -- the many-way sums (parameter-parameter Hessian
+    entries, the parameter's adjoint gradient) are staged / gathered in a fixed order, not added atomically."""
+    w, nlp, ev, locs = _setup(oracle, ode, mode, nseg, blocked)
+    counts = np.bincount(locs.ravel())
+    if ode == "betts_lowthrust":
+        assert counts.max() == nseg                          # the many-way location exists (H of the parameter with itself)
+    dev = torch.device("cuda:0")
+    X, L = torch.from_numpy(w.X).to(dev), torch.from_numpy(w.L).to(dev)
+    runs = []
+    for _ in range(2):
+        FXE = torch.zeros(w.n_equal, dtype=torch.float64, device=dev)
+        AGX = torch.zeros(w.n_primal, dtype=torch.float64, device=dev)
+        vals = torch.zeros(nlp.nnz, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        ev.eval_kkt_device(JAC_ADJGRAD_HESS, X, L, FXE, AGX, vals)
+        torch.cuda.synchronize()
+        runs.append((FXE.cpu().numpy(), AGX.cpu().numpy(), vals.cpu().numpy()))
+    for a, b in zip(*runs):
+        np.testing.assert_array_equal(a, b)                  # bitwise repeatable
+    rFXE, rAGX, rvals = nlp.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    FXE, AGX, vals = runs[0]
+    assert np.abs(FXE - rFXE).max() < 1e-10 * max(1.0, np.abs(w.X).max())
+    assert rel_err(AGX, rAGX) < 1e-8 and rel_err(vals, rvals) < 1e-8
+    # value-only and gradient kinds through the same entry point
+    FXE = torch.zeros(w.n_equal, dtype=torch.float64, device=dev)
+    ev.eval_kkt_device(0, X, None, FXE, None, None)
+    torch.cuda.synchronize()
+    assert np.abs(FXE.cpu().numpy() - rFXE).max() < 1e-10 * max(1.0, np.abs(w.X).max())
+    ev.close()
