@@ -39,6 +39,7 @@ SYMBOLS = {
     "asset_hip_defect_set_appl_consts": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "asset_hip_defect_set_kkt_map": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_longlong, C.c_int]),
     "asset_hip_defect_eval_assembled": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "asset_hip_defect_eval_assembled_zeroed": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "asset_hip_defect_eval_assembled_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "asset_hip_defect_eval_kkt_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "asset_hip_mesh_error_deboor": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]),

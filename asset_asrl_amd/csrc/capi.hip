@@ -710,8 +710,20 @@ int asset_hip_defect_eval_kkt_device(asset_hip_defect_t h, int what, const doubl
   return 0;
 }
 
+static int eval_assembled_host(asset_hip_defect_t h, int what, const double* X, const double* L, double* fx_blocks,
+                               double* agx_blocks, double* kkt_values, bool target_zeroed);
+
 int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double* X, const double* L,
                                     double* fx_blocks, double* agx_blocks, double* kkt_values) {
+  return eval_assembled_host(h, what, X, L, fx_blocks, agx_blocks, kkt_values, false);
+}
+int asset_hip_defect_eval_assembled_zeroed(asset_hip_defect_t h, int what, const double* X, const double* L,
+                                           double* fx_blocks, double* agx_blocks, double* kkt_values) {
+  return eval_assembled_host(h, what, X, L, fx_blocks, agx_blocks, kkt_values, true);
+}
+
+static int eval_assembled_host(asset_hip_defect_t h, int what, const double* X, const double* L, double* fx_blocks,
+                               double* agx_blocks, double* kkt_values, bool target_zeroed) {
   if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
   if (!X || !kkt_values) return fail(ASSET_HIP_EINVAL, "X / kkt value array is null");
   if (what < ASSET_HIP_JAC) return fail(ASSET_HIP_EINVAL, "assembled evaluation needs a kind that produces KKT entries");
@@ -740,6 +752,14 @@ int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double
   if (fx_blocks) HIP_TRY(hipMemcpyAsync(fx_blocks, h->d_fx, sizeof(double) * nfx, hipMemcpyDeviceToHost, h->stream));
   if (agx_blocks && what != ASSET_HIP_JAC)
     HIP_TRY(hipMemcpyAsync(agx_blocks, h->d_agx, sizeof(double) * nagx, hipMemcpyDeviceToHost, h->stream));
+  if (target_zeroed) {
+    // the caller's range holds zeros (it was just cleared and this constraint is the first to fill it): the values go
+    // straight into it -- by DMA when the array is page-locked (asset_hip_host_register), through the driver's staging
+    // otherwise -- and no host pass over the values is needed at all
+    HIP_TRY(hipMemcpyAsync(kkt_values + h->value_lo, h->d_values, sizeof(double) * nval, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   HIP_TRY(hipMemcpyAsync(h->h_values, h->d_values, sizeof(double) * nval, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   // accumulate, as the reference's fill does: O(nnz) contiguous adds, split over a few threads (memory-bound)

@@ -117,9 +117,10 @@ class DefectEvaluator:
                    "asset_hip_defect_set_kkt_map")
         self._nvalues = int(nvalues)
 
-    def eval_assembled(self, what: int, X, L, kkt_values):
+    def eval_assembled(self, what: int, X, L, kkt_values, target_zeroed: bool = False):
         """Like :meth:`eval`, but the KKT entries are ADDED into ``kkt_values`` (the solver's value array) on the
-        device; returns (fx blocks, agx blocks or None)."""
+        device; returns (fx blocks, agx blocks or None).  ``target_zeroed``: the array was just cleared and this is the
+        first function to fill its range -- the range is overwritten by one device-to-host copy, no host add."""
         X = np.ascontiguousarray(X, dtype=np.float64)
         L = None if L is None else np.ascontiguousarray(L, dtype=np.float64)
         if X.size != self.n_primal or (L is not None and L.size != self.n_equal):
@@ -129,8 +130,9 @@ class DefectEvaluator:
             raise ValueError("kkt_values must be the contiguous float64 value array the map was built for")
         fx = np.empty((self.nseg, self.OR))
         agx = np.empty((self.nseg, self.IR)) if what in (JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
-        _lib.check(_lib.lib().asset_hip_defect_eval_assembled(self._h, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx),
-                                                              _dptr(kkt_values)), "asset_hip_defect_eval_assembled")
+        fn = _lib.lib().asset_hip_defect_eval_assembled_zeroed if target_zeroed else _lib.lib().asset_hip_defect_eval_assembled
+        _lib.check(fn(self._h, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx), _dptr(kkt_values)),
+                   "asset_hip_defect_eval_assembled")
         return fx, agx
 
     def eval_assembled_device(self, what: int, X, L, fx, agx, kkt_values, stream=None):

@@ -130,6 +130,13 @@ int asset_hip_defect_eval_assembled(asset_hip_defect_t h, int what, const double
                                     double* agx_blocks, double* kkt_values);
 int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
                                            double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_values, void* stream);
+/* As asset_hip_defect_eval_assembled, for the FIRST function that fills its range of a value array the caller has just
+ * zeroed (the reference zeroes the KKT values before every evalKKT, PSIOPT.cpp:107): the contiguous range of locations
+ * this constraint touches is OVERWRITTEN with its contributions by one device-to-host copy (DMA at PCIe rate when the
+ * array is page-locked, asset_hip_host_register) -- no host pass over the values.  Functions that share locations with
+ * it must be evaluated afterwards through the accumulating entry point. */
+int asset_hip_defect_eval_assembled_zeroed(asset_hip_defect_t h, int what, const double* X, const double* L,
+                                           double* fx_blocks, double* agx_blocks, double* kkt_values);
 
 /* The whole of the reference's evalKKT / evalSOE / evalRHS / evalOCC share of ONE constraint on the device
  * (Solvers/NonLinearProgram.cpp:347-537 worker bodies + the RHS fill NonLinearProgram.h:379-407): the constraint values

@@ -47,6 +47,12 @@ def test_assembled_values_match_host_scatter(oracle, ode, mode, nseg, blocked):
         assert np.abs(fx - rfx).max() < 1e-10 * max(1.0, np.abs(w.X).max())
         if agx is not None:
             assert rel_err(agx, ragx) < 1e-8
+    # first function into a freshly zeroed array: its range is overwritten by one copy, nothing else is touched
+    _, _, ref = nlp.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    vals = np.zeros(nlp.nnz)
+    vals[:locs.min()] = 7.0                                       # (outside the constraint's range)
+    ev.eval_assembled(JAC_ADJGRAD_HESS, w.X, w.L, vals, target_zeroed=True)
+    assert rel_err(vals[locs.min():], ref[locs.min():]) < 1e-8 and np.all(vals[:locs.min()] == 7.0)
     ev.close()
 
 
