@@ -172,6 +172,12 @@ struct Dims {
   static constexpr int GF_FIT = int((size_t(DENSE) * 8) / (size_t(CS * STG_LD + MSLOT) * 8));
   static constexpr int GF = GF_FIT < 64 / CS ? GF_FIT : 64 / CS;
   static constexpr bool FUSED = MIRROR && STAGED && LC == 64 && !WIDE && GF >= 2;
+  // two-wave form (STAGE 4): the pair's ODE stage -- rows of GF2*(K+CS) points (interior and cardinal regions side by
+  // side) and GF2 mirror slots -- in the two waves' bodies
+  static constexpr int GF2_FIT = int((size_t(2 * DENSE) * 8) / (size_t((K + CS) * STG_LD + MSLOT) * 8));
+  static constexpr int GF2 = (GF2_FIT < 64 / CS ? GF2_FIT : 64 / CS) & ~1;   // even: both waves get GF2/2
+  static constexpr bool FUSED2 = FUSED && GF2 >= 4;
+  static constexpr size_t lds_bytes_fused2() { return size_t(2 * (TABSZ + DENSE)) * 8; }
   // LDS of the two launches: [weight tables | staging rows | mirror] and [weight tables | slot buffer | dense scratch]
   static constexpr size_t lds_bytes_ode() { return size_t(TABSZ + (STAGED ? LC * STG_LD : 0) + (MIRROR ? GM * MSLOT : 0)) * 8; }
   static constexpr size_t lds_bytes_dense() { return size_t(TABSZ + DENSE) * 8; }

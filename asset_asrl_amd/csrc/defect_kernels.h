@@ -266,9 +266,10 @@ __device__ __attribute__((noinline)) void pipe_interior(glb_double* S, lds_doubl
 // Coalesced copy of `npt` staging rows ([J | H], NSTG doubles each) to the workspace sections (wJ, wH) of the points
 // they belong to: point e = g * PER + k of segment g.  Four elements per lane in flight.
 template <class D, int PER>
-__device__ inline void pipe_copy_rows(const lds_double* stage, int npt, int lane, glb_double* Wg, int wJ, int wH) {
+__device__ inline void pipe_copy_rows(const lds_double* stage, int npt, int lane, glb_double* Wg, int wJ, int wH,
+                                      int row0 = 0) {   // rows [row0, row0 + npt) of the staging area (point = row)
   constexpr int NC = D::NSTG, RSTEP = 64 / NC, KSTEP = 64 % NC;
-  int row = lane / NC, k = lane - row * NC;
+  int row = row0 + lane / NC, k = lane - (lane / NC) * NC;
   const int total = npt * NC;
   for (int base = 0; base < total; base += 256) {
     double v[4];
@@ -292,11 +293,11 @@ __device__ inline void pipe_copy_rows(const lds_double* stage, int npt, int lane
 
 // P3 of a whole group: first the copy-out of the interior phase (rows + staged f^), then -- while those stores drain --
 // the cardinal second derivatives of this lane's point into the same rows.  g_j goes straight to the slot.
-template <class Ode, class D, int GP>
+template <class Ode, class D, int GP, bool COPY = true>
 __device__ __attribute__((noinline)) void pipe_cardinal_second(glb_double* Wg, lds_double* mirror, lds_double* stage,
                                                                const LglTab* tabp, int gcount, int lane) {
   constexpr int K = D::K, n = D::n, N = D::N, T = D::T, CS = D::CS;
-  if constexpr (!D::TRAP) {
+  if constexpr (!D::TRAP && COPY) {
     if constexpr (D::NSTG > 0) pipe_copy_rows<D, K>(stage, gcount * K, lane, Wg, D::w_IJ, D::w_IH);
     if constexpr (PipeDims<D, GP>::IFROW) {
       for (int e = lane; e < gcount * K * n; e += 64) {
@@ -332,7 +333,8 @@ __device__ __attribute__((noinline)) void pipe_cardinal_second(glb_double* Wg, l
 
 // Coalesced copy of NW consecutive doubles of every segment's mirror slot (from m0) to its workspace slot (from w0).
 template <class D, int NW>
-__device__ inline void pipe_copy_mirror(const lds_double* mirror, int gcount, int lane, glb_double* Wg, int m0, int w0) {
+__device__ inline void pipe_copy_mirror(const lds_double* mirror, int gcount, int lane, glb_double* Wg, int m0, int w0,
+                                        int g0 = 0) {   // segments [g0, g0 + gcount) of the group
   const int total = gcount * NW;
   for (int base = 0; base < total; base += 256) {
     double v[4];
@@ -342,7 +344,7 @@ __device__ inline void pipe_copy_mirror(const lds_double* mirror, int gcount, in
     for (int u = 0; u < 4; u++) {
       const int e = base + 64 * u + lane;
       ok[u] = e < total;
-      const int g = ok[u] ? e / NW : 0, r = ok[u] ? e - g * NW : 0;
+      const int g = g0 + (ok[u] ? e / NW : 0), r = ok[u] ? e - (e / NW) * NW : 0;
       v[u] = mirror[g * D::MSLOT + m0 + r];
       d[u] = Wg + g * D::WSLOT + w0 + r;
     }
@@ -410,6 +412,83 @@ __device__ inline void pipe_ode_group(const EvalArgs& a, int lane, int seg0, int
     pipe_copy_mirror<D, NB>(mirror, gcount, lane, (glb_double*)Wg, D::m_Ig, D::w_Ig);
   }
   wave_lds_sync();   // (whatever follows rewrites the mirror and the rows)
+}
+
+// The ODE stage of a TWO-WAVE workgroup (fused kernel, STAGE 4): the group is both waves' segments, wave 0 evaluates the
+// cardinal phases (P1, P3), wave 1 the interior phase (P2) and the copy-out of its rows.  The generated bodies are bound
+// by instruction issue, whatever the number of active lanes: one wave with 40 points costs the SIMD it runs on as much as
+// one with 20, so letting each wave of a pair evaluate its own half (STAGE 3) issues every body twice per pair.  Here a
+// body is issued once per pair, and while a wave waits at a barrier the other workgroup's wave on its SIMD has the issue
+// slots.  Rows: region A = GP2*K rows (P2), region B = GP2*CS rows (P3) -- P3 runs while wave 1 still copies region A out.
+template <class Ode, class D, int GP2, class Pub>
+__device__ inline void pipe_ode_group2(const EvalArgs& a, int tid, int seg0, int gcount, double* Wg, double* stage,
+                                       lds_double* mirror, const LglTab* tabp, Pub&& publish_tables) {
+  constexpr int CS = D::CS, K = D::K, n = D::n, N = D::N, IR = D::IR, OR = D::OR, STG_LD = D::STG_LD;
+  static_assert(GP2 * CS <= 64, "one pass per phase");
+#ifndef ASSET_ROLE_SHIFT
+#define ASSET_ROLE_SHIFT 8
+#endif
+  // which wave of the pair takes the cardinal phases alternates from one workgroup of a CU to the next (workgroups are
+  // dealt to the 8 XCDs x 32 CUs breadth first: workgroup b is the (b >> 8)-th of its CU), so that the cardinal waves of
+  // the workgroups sharing a CU do not pile up on the same SIMDs
+  const int lane = tid & 63, wave = (tid >> 6) ^ ((ASSET_ROLE_SHIFT >= 0) ? ((int(blockIdx.x) >> ASSET_ROLE_SHIFT) & 1) : 0);
+  {   // P0: gather into the mirror, both waves
+    constexpr int NZ = (GP2 * IR + 127) / 128, NL = (GP2 * OR + 127) / 128;
+    const int* vseg = a.vindex + size_t(seg0) * IR;
+    const int* cseg = a.cindex + size_t(seg0) * OR;
+    int vi[NZ], ci[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) vi[t] = (tid + 128 * t < gcount * IR) ? vseg[tid + 128 * t] : -1;
+#pragma unroll
+    for (int t = 0; t < NL; t++) ci[t] = (tid + 128 * t < gcount * OR) ? cseg[tid + 128 * t] : -1;
+    double zv[NZ], lv[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) zv[t] = (vi[t] >= 0) ? a.X[vi[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NL; t++) lv[t] = (ci[t] >= 0) ? a.L[ci[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NZ; t++) {
+      const int e = tid + 128 * t, g = e / IR, r = e - g * IR;
+      if (e < gcount * IR) mirror[g * D::MSLOT + D::m_z + r] = zv[t];
+    }
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      const int e = tid + 128 * t, g = e / OR, r = e - g * OR;
+      if (e < gcount * OR) mirror[g * D::MSLOT + D::m_lam + r] = lv[t];
+    }
+  }
+  if (wave == 0 && lane < gcount * CS) {   // P1 (reads the solver vector itself: no barrier before it)
+    const int g = lane / CS, j = lane - g * CS;
+    pipe_cardinal_value<Ode, D>(mirror + g * D::MSLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
+  }
+  publish_tables();                         // (each wave its own copy of the weight tables)
+  __syncthreads();
+  lds_double* const rowsA = (lds_double*)stage;
+  lds_double* const rowsB = (lds_double*)stage + GP2 * K * STG_LD;
+  if (wave == 1 && lane < gcount * K) {     // P2
+    const int g = lane / K, i = lane - g * K;
+    pipe_interior<Ode, D, false>((glb_double*)Wg + g * D::WSLOT, mirror + g * D::MSLOT, i, tabp, rowsA + lane * STG_LD, nullptr);
+  }
+  __syncthreads();
+  if (wave == 1) {                          // copy-out of P2, while wave 0 evaluates P3 into its own rows
+    if constexpr (D::NSTG > 0) pipe_copy_rows<D, K>(rowsA, gcount * K, lane, (glb_double*)Wg, D::w_IJ, D::w_IH);
+  } else {
+    pipe_cardinal_second<Ode, D, GP2, false>((glb_double*)Wg, mirror, rowsB, tabp, gcount, lane);
+  }
+  __syncthreads();
+  {   // copy-out of P3 and of the mirror sections the dense phase reads: each wave takes half of the rows / segments
+    const int half_r = (gcount * CS + 1) / 2, r0 = wave * half_r, nr = min(half_r, gcount * CS - r0);
+    if constexpr (D::NSTG > 0)
+      if (nr > 0) pipe_copy_rows<D, CS>(rowsB, nr, lane, (glb_double*)Wg, D::w_CJ, D::w_CH, r0);
+    constexpr int NA = IR + OR + CS * n, NB = K * N;
+    const int half_g = (gcount + 1) / 2, g0 = wave * half_g, ng = min(half_g, gcount - g0);
+    if (ng > 0) {
+      pipe_copy_mirror<D, NA>(mirror, ng, lane, (glb_double*)Wg, 0, 0, g0);
+      pipe_copy_mirror<D, NB>(mirror, ng, lane, (glb_double*)Wg, D::m_Ig, D::w_Ig, g0);
+    }
+  }
+  wave_loads_landed();                      // this wave's slot stores have completed ...
+  __syncthreads();                          // ... and so have the other wave's: either may read any slot of the group now
 }
 
 // Per-lane constants of the dense stage: every index decode, table weight, fragment offset and store offset that
@@ -590,8 +669,10 @@ __global__ __launch_bounds__(64) void lane_setup_kernel(unsigned int* out) {
 //          wave runs the ODE stage for its own few segments, waits for its own slot stores and goes on with the dense
 //          phase -- one ramp-up (dispatch, first loads, cold instruction cache) per evaluation instead of two, no
 //          device-wide drain of the slot stores between the stages, and the slots are read back from L2.
+// STAGE 4: as STAGE 3 with TWO-wave workgroups (FUSED2 shapes): the ODE stage of both waves' segments is evaluated once
+//          per pair (pipe_ode_group2), then each wave runs the dense phase of its own segments in its own half of the LDS.
 template <class Ode, int SCH, bool BLOCKED, int G, int LEVEL, int STAGE, bool ASM = false>
-__global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
+__global__ __launch_bounds__(STAGE == 4 ? 128 : 64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
                                                    ? ASSET_DENSE_WAVES_PER_SIMD : 1)   // LDS-bound to one wave per SIMD anyway: take the registers
                                              : ASSET_ODE_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
   using D = Dims<Ode, SCH, BLOCKED>;
@@ -604,12 +685,15 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   (void)m; (void)p; (void)ORP;
 
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* tabL = lds;                       // weight tables (persistent)
-  double* body = lds + D::TABSZ;            // [slot buffer | dense scratch], aliased by the ODE staging rows
+  // STAGE 4: [tables wave 0 | tables wave 1 | body wave 0 | body wave 1]; the ODE stage of the pair uses both bodies
+  const int wave = (STAGE == 4) ? int(threadIdx.x >> 6) : 0;
+  double* tabL = lds + (STAGE == 4 ? wave * D::TABSZ : 0);                       // weight tables (persistent)
+  double* body = lds + (STAGE == 4 ? 2 * D::TABSZ + wave * D::DENSE : D::TABSZ);   // [slot buffer | dense scratch], aliased by the ODE staging rows
   double* slotb = body;
   double* scr = body + D::WSLOTD;
   double* stage = body;
   static_assert(STAGE != 3 || (D::FUSED && LEVEL == 2), "no fused kernel for this shape / level");
+  static_assert(STAGE != 4 || (D::FUSED2 && LEVEL == 2), "no two-wave fused kernel for this shape / level");
   constexpr bool MIR = D::MIRROR && LEVEL >= 1 && STAGE == 1;
 #ifndef ASSET_ODE_PIPE
 #define ASSET_ODE_PIPE 1
@@ -617,7 +701,7 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   constexpr bool PIPE = ASSET_ODE_PIPE && MIR && LEVEL == 2 && D::STAGED && LC == 64 && G * CS <= 64;
   lds_double* const mirror = (lds_double*)(body + (STAGE == 3 ? D::GF * CS : LC) * STG_LD);   // [G][MSLOT] (ODE stage, MIR)
   static_assert(!MIR || G <= D::GM, "the LDS mirror holds one slot per segment of a group");
-  const int lane = threadIdx.x;
+  const int lane = (STAGE == 4) ? int(threadIdx.x & 63) : int(threadIdx.x);
   const int lr = lane & 15, lk = lane >> 4;
   // the scheme's weight tables are read with lane-dependent indices all over the kernel: keep them in LDS
   // (ODE stage: the copy is finished just before its first use in P2, so its latency hides behind P0 / P1)
@@ -635,9 +719,11 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   const LglTab& tab = *reinterpret_cast<const LglTab*>(tabL);
 
   // this workgroup's share of the mesh: contiguous, balanced (same rule as IndexingData.h:117-146)
-  const int per = a.nseg / int(gridDim.x), rem = a.nseg % int(gridDim.x);
-  const int wg_first = int(blockIdx.x) * per + min(int(blockIdx.x), rem);
-  const int wg_count = per + (int(blockIdx.x) < rem ? 1 : 0);
+  // (STAGE 4: every WAVE has a share; the pair's shares are adjacent)
+  const int nshare = int(gridDim.x) * (STAGE == 4 ? 2 : 1), share = int(blockIdx.x) * (STAGE == 4 ? 2 : 1) + wave;
+  const int per = a.nseg / nshare, rem = a.nseg % nshare;
+  const int wg_first = share * per + min(share, rem);
+  const int wg_count = per + (share < rem ? 1 : 0);
   (void)G;
 
   // ---- per-lane constants of the dense phase, computed once per launch: every index decode, table lookup and
@@ -652,11 +738,31 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   // slot offset of dfdy_j[r][cc] for run-time indices (the rare paths; table look-ups)
   auto cj_at = [](int j, int r, int cc) { const int jp = Ode::JPOS[r * N + cc]; return jp >= 0 ? D::w_CJ + j * D::NZJ + jp : ZERO; };
   (void)cj_at;
+#if defined(ASSET_TIMING)
+  long long tstamp[24];
+  int nts = 0;
+#define TS() do { if (nts < 24) tstamp[nts++] = clock64(); } while (0)
+#else
+#define TS() do {} while (0)
+#endif
+// sub-phase stamps of the dense stage, taken for the second segment of the workgroup (-DASSET_TIMING, tools/dbg_time.py)
+#ifndef ASSET_TSG_SEG
+#define ASSET_TSG_SEG 1
+#endif
+#define TSG() do { if (g == ASSET_TSG_SEG) TS(); } while (0)
+  if constexpr (STAGE >= 3) TS();   // (timing builds: kernel start)
   if constexpr (STAGE == 3) {
     // the workgroup's segments are one group (the host sizes the grid so): ODE stage first, while the kernel holds
     // nothing else in registers; its results go to the slots and are read back below once the stores have landed
     pipe_ode_group<Ode, D, D::GF>(a, lane, wg_first, min(wg_count, D::GF), a.work + size_t(wg_first) * D::WSLOT, stage, mirror,
                                   &tab, publish_tables);
+  }
+  if constexpr (STAGE == 4) {
+    const int s0 = share - wave, first0 = s0 * per + min(s0, rem);            // the pair's first segment and count
+    const int cnt = (per + (s0 < rem ? 1 : 0)) + (per + (s0 + 1 < rem ? 1 : 0));
+    double* const area = lds + 2 * D::TABSZ;                                   // both bodies
+    pipe_ode_group2<Ode, D, D::GF2>(a, int(threadIdx.x), first0, min(cnt, D::GF2), a.work + size_t(first0) * D::WSLOT, area,
+                                    (lds_double*)(area + D::GF2 * (K + CS) * STG_LD), &tab, publish_tables);
   }
   LaneRecord<LCT> lrec;
   if constexpr (STAGE >= 2 && LEVEL >= 1) {              // computed once per handle (lane_setup_kernel)
@@ -668,6 +774,7 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   const LCT& lc = lrec.lc;
   if constexpr (STAGE == 2) publish_tables();            // after the record loads are in flight: one latency, not two
   if constexpr (STAGE == 3) wave_loads_landed();         // the slot stores of the ODE stage (and the record loads)
+  // (STAGE 4: pipe_ode_group2 ends with the wait and a barrier)
   const auto& wa = lc.wa;
   const auto& wb = lc.wb;
   const auto& wa2 = lc.wa2;
@@ -689,18 +796,6 @@ __global__ __launch_bounds__(64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_byte
   const double& tE = lc.tE;
   (void)wa2; (void)wb2; (void)chp; (void)bo2; (void)bo; (void)bst; (void)jo; (void)cho;
 
-#if defined(ASSET_TIMING)
-  long long tstamp[24];
-  int nts = 0;
-#define TS() do { if (nts < 24) tstamp[nts++] = clock64(); } while (0)
-#else
-#define TS() do {} while (0)
-#endif
-// sub-phase stamps of the dense stage, taken for the second segment of the workgroup (-DASSET_TIMING, tools/dbg_time.py)
-#ifndef ASSET_TSG_SEG
-#define ASSET_TSG_SEG 1
-#endif
-#define TSG() do { if (g == ASSET_TSG_SEG) TS(); } while (0)
   for (int g0 = 0; g0 < wg_count; g0 += G) {
     const int seg0 = wg_first + g0;
     TS();

@@ -118,6 +118,19 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
       if constexpr (D::FUSED) {
         // single launch when every workgroup's share fits one group of the fused kernel (defect_kernels.h, STAGE 3)
         static const bool no_fuse = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                               // tuning only
+        if constexpr (D::FUSED2) {
+          // two-wave workgroups: the ODE bodies are issued once per pair of waves (defect_kernels.h, STAGE 4)
+          static const bool no_fuse2 = std::getenv("ASSET_HIP_NO_FUSE2") != nullptr;                           // tuning only
+          const int pairs = grid_b / 2;
+          // (measured, 10 000 segments: TwoBody-LGL5-BlockConstant 42.2 -> 39.6 us, Reentry-LGL7 43.2 -> 43.0 us; with 2-3
+          //  segments per wave -- Reentry-LGL7 x 5 000 -- the pair's barriers cost more than the shared bodies save:
+          //  29.6 -> 32.9 us, so short shares keep the one-wave form)
+          const int share = (a.nseg + 2 * pairs - 1) / (pairs > 0 ? 2 * pairs : 1);
+          if (!a.kmap && !no_fuse && !no_fuse2 && !skip_dense && pairs > 0 && share >= 4 && share <= D::GF2 / 2) {
+            ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 4, false>), pairs, 128, D::lds_bytes_fused2());
+            return hipSuccess;
+          }
+        }
         if (!a.kmap && !no_fuse && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= D::GF) {
           ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 3, false>), grid_b, 64, bytes_dense);
           return hipSuccess;

@@ -17,3 +17,19 @@ def oracle():
     from oracle import bindings
     bindings.build()
     return bindings
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first_on_the_gpu(request):
+    """On a GPU box: let PyTorch create its HIP context before libasset_hip.so touches the device.  The other order
+    works only while nothing large has been allocated yet (observed: torch's lazy initialisation after a 100 000-segment
+    evaluator reports "No HIP GPUs are available"); the order must not depend on which test file happens to run first."""
+    if os.path.exists("/dev/kfd") and "not gpu" not in (request.config.getoption("-m") or ""):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+                torch.zeros(1, device="cuda:0")
+        except Exception:
+            pass
+    yield
