@@ -94,3 +94,33 @@ def test_autoscaling_phase_evaluates_the_scaled_dynamics(oracle):
     assert rel_err(gx, rgx * uz) < 1e-8
     assert rel_err(hx, rhx * uz[None, :] * uz[:, None]) < 1e-8
     assert np.allclose(ph.solver_input()[:8], w.traj[0] / units)       # the NLP variables are in scaled units
+
+
+def test_cold_run_time_compilation_of_a_never_seen_ode(oracle):
+    """The run-time compiler itself, cold, on the GPU box: an ODE whose generated code no cache can hold -- the forced
+    Van der Pol oscillator with exp(-t/10) written as exp(-(1/10 + c) t) * exp(c t), c drawn from os.urandom for this test
+    run (the same real function to rounding, a different expression graph, hence a different content hash) -- goes through
+    code generation, hipcc, plugin load and registration here, and its blocks match the oracle's Van der Pol."""
+    import os
+    import shutil
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+    c = 1e-3 * (1 + int.from_bytes(os.urandom(4), "little") / 2 ** 32)
+    a = ODEArguments(2, 1, 1)
+    x0, x1 = a.XVec().tolist()
+    u, mu, t = a.UVar(0), a.PVar(0), a.TVar()
+    ode = ODEBase(vf.stack([x1, mu * (1.0 - x0 * x0) * x1 - x0 + u * (vf.exp(-(0.1 + c) * t) * vf.exp(c * t))]), 2, 1, 1,
+                  name="vanderpol_salted")
+    name = jit.device_name(ode)
+    wd = os.path.join(jit.JIT_DIR, name)
+    assert not os.path.exists(wd), "the salted ODE must not be in the plugin cache"
+    try:
+        assert jit.ensure_kernel(ode, "LGL5", False) == name             # compiles here, now
+        assert any(f.startswith("plugin_lgl5_0_") and f.endswith(".so") for f in os.listdir(wd))
+        w = Workload("vanderpol", "LGL5", 21, False, sizes=SIZES)
+        nlp = oracle.Nlp(oracle.get_ode("vanderpol", 0), oracle.MODES["LGL5"], False, w.vindex, w.cindex, w.n_primal, w.n_equal, 2)
+        ev = DefectEvaluator(name, "LGL5", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+        _check_blocks(ev.eval(JAC_ADJGRAD_HESS, w.X, w.L), nlp.eval_blocks(JAC_ADJGRAD_HESS, w.X, w.L), w, JAC_ADJGRAD_HESS)
+        ev.close()
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)                             # (the plugin stays loaded; its files need not stay)

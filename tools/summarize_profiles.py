@@ -19,9 +19,13 @@ def stage_of(kernel_name):
     """lgl_defect_kernel<Ode, CS, BLOCKED, G, LEVEL, STAGE[, ASM]>: STAGE is the sixth template argument."""
     if "lgl_wide_dense_kernel" in kernel_name:            # four-wave dense stage of the wide shapes (defect_wide.h)
         return "dense_stage"
+    if "lgl_ode_units_kernel" in kernel_name:             # ODE stage of heavy right-hand sides, one wave per output unit
+        return "ode_units"
     args = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
     if len(args) >= 6 and args[5] == "3":                 # fused single launch (defect_kernels.h, STAGE 3)
         return "fused"
+    if len(args) >= 6 and args[5] == "4":                 # fused, two-wave workgroups (STAGE 4)
+        return "fused2"
     return "ode_stage" if len(args) >= 6 and args[5] == "1" else "dense_stage"
 
 
@@ -32,7 +36,7 @@ def counters(sub):
     if not os.path.exists(path):
         return {}
     for r in csv.DictReader(open(path)):
-        if "lgl_defect_kernel" not in r["Kernel_Name"] and "lgl_wide_dense_kernel" not in r["Kernel_Name"]:
+        if not any(k in r["Kernel_Name"] for k in ("lgl_defect_kernel", "lgl_wide_dense_kernel", "lgl_ode_units_kernel")):
             continue
         acc[stage_of(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
@@ -40,7 +44,7 @@ def counters(sub):
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 per_kernel, total = {}, 0.0
-for st in ("fused", "ode_stage", "dense_stage"):
+for st in ("fused", "fused2", "ode_units", "ode_stage", "dense_stage"):
     if st not in fetch and st not in write:
         continue
     f_kb = fetch.get(st, {}).get("FETCH_SIZE", 0.0)
@@ -58,7 +62,7 @@ out = {
     "source": f"tools/collect_profiles.sh {tag} (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes "
               "of `python3 bench.py --no-cpu-baseline`)",
     "kernel_stats": [{"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])} for r in kernels
-                     if "defect_kernel" in r["Name"] or "wide_dense_kernel" in r["Name"]],
+                     if "defect_kernel" in r["Name"] or "wide_dense_kernel" in r["Name"] or "ode_units_kernel" in r["Name"]],
     "per_kernel": per_kernel,
     "hbm": {"fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section)", "bytes_per_launch": total,
             "note": "one evaluation = the fused launch, or ODE-stage launch + dense-stage launch; traffic above the "
