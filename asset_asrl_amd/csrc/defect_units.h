@@ -1,4 +1,4 @@
-// ODE stage for heavy right-hand sides: one WAVE per output unit.
+// ODE stage for heavy right-hand sides: one WORKGROUP (a single wave) per output unit and group of segments.
 //
 // The ODE stage of defect_kernels.h maps a lane to an evaluation point and runs the whole generated body
 // f + J + g + H of that point in the lane.  For a heavy ODE (Betts' modified-equinoctial low-thrust dynamics with J2-J4
@@ -8,9 +8,9 @@
 //
 // Here the body is cut by OUTPUT: the generator (vf/codegen.py, plan_units) emits Ode::NUNITS bodies fjgh_unit<U>,
 // unit "column k" = {J[:,k], H[i>=k,k]} (the second derivatives in input direction k) and one unit for f, g and the cheap
-// columns; each recomputes the forward values it needs (6 x ~1 700 + 1 200 operations instead of 7 792, no spills).  A
-// workgroup is NUNITS waves; wave u evaluates unit u for every point of the group (lane <-> point), so the chain a point
-// waits for is one unit long and the idle SIMDs of a small mesh do the rest in parallel.  Phases as in the reference's
+// columns; each recomputes the forward values it needs (6 x ~1 700 + 1 200 operations instead of 7 792, no spills).  The
+// grid is (groups of segments) x (units); a workgroup evaluates its unit for every point of its group (lane <-> point), so
+// the chain a point waits for is one unit long and the idle SIMDs of a small mesh do the rest in parallel.  Phases as in the reference's
 // adjoint-Hessian method (LGLDefects.h:325-412): cardinal values -> interior points (all units) -> cardinal second
 // derivatives with the adjoint weights w_j (all units), hand-offs through an LDS mirror of the group's small vectors.
 // Results go to the same per-segment workspace slots the dense stage (defect_kernels.h, STAGE 2) reads.
@@ -52,11 +52,14 @@ struct OdeOutUnit {
   }
 };
 
-template <class D>
-struct OdeOutValue {   // cardinal values: mirror (the interior points read them) and slot (the dense stage does)
+template <class D, bool SLOT>
+struct OdeOutValue {   // cardinal values: mirror (the interior points read them) and, from one unit, the slot (the dense stage does)
   lds_double* fm_;
   glb_double* f_;
-  __device__ void f(int k, double v) { fm_[k] = v; f_[k] = v; }
+  __device__ void f(int k, double v) {
+    fm_[k] = v;
+    if constexpr (SLOT) f_[k] = v;
+  }
 };
 
 template <class Ode, class In, class Out, int U = 0>
@@ -67,112 +70,127 @@ __device__ inline void run_unit(int unit, const In& in, Out& out) {
   }
 }
 
-template <class Ode, int SCH, bool BLOCKED>
-__global__ __launch_bounds__(64 * Ode::NUNITS) void lgl_ode_units_kernel(EvalArgs a, int gp) {
+// PHASE 0: gather, cardinal values (every unit's workgroup computes them for itself: the value body is light), interior
+//          points -- unit u = blockIdx.y.   PHASE 1 (second launch: it needs g^ of every unit's interior pass): cardinal
+//          second derivatives.  Single-wave workgroups at one wave per SIMD: each unit body has the whole register file
+//          (512 with the accumulation registers as spill space), where seven waves in one workgroup had 256 each and
+//          spilled ~1 KB per lane to scratch (110 MB of scratch traffic per evaluation of 1 000 Betts segments).
+template <class Ode, int SCH, bool BLOCKED, int PHASE>
+__global__ __launch_bounds__(64, 1) void lgl_ode_units_kernel(EvalArgs a, int gp) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using UD = UnitsDims<D>;
   constexpr int CS = D::CS, K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, IR = D::IR, OR = D::OR;
-  constexpr int NU = Ode::NUNITS, NT = 64 * NU;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   lds_double* const tabL = (lds_double*)lds;
   lds_double* const mirror = (lds_double*)(lds + D::TABSZ);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int unit = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform
+  const int lane = threadIdx.x;
+  const int unit = blockIdx.y;
   const int seg0 = int(blockIdx.x) * gp;
   const int gcount = min(gp, a.nseg - seg0);
   if (gcount <= 0) return;
   glb_double* const Wg = (glb_double*)(a.work + size_t(seg0) * D::WSLOT);
 
-  // ---- P0: weight tables and the group's z, lam -> LDS (and the slots: the dense stage reads them there)
-  for (int e = tid; e < D::TABSZ; e += NT) tabL[e] = reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[e];
+  // ---- P0: weight tables and the group's z, lam -> LDS (unit 0 of the first launch also fills the slots' copies)
+  for (int e = lane; e < D::TABSZ; e += 64) tabL[e] = reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[e];
   {
     const int* vseg = a.vindex + size_t(seg0) * IR;
     const int* cseg = a.cindex + size_t(seg0) * OR;
-    for (int e = tid; e < gcount * IR; e += NT) {
+    for (int e = lane; e < gcount * IR; e += 64) {
       const int g = e / IR, r = e - g * IR;
       const double v = a.X[vseg[e]];
       mirror[g * UD::MS + UD::m_z + r] = v;
-      Wg[g * D::WSLOT + D::w_z + r] = v;
+      if (PHASE == 0 && unit == 0) Wg[g * D::WSLOT + D::w_z + r] = v;
     }
-    for (int e = tid; e < gcount * OR; e += NT) {
+    for (int e = lane; e < gcount * OR; e += 64) {
       const int g = e / OR, r = e - g * OR;
       const double v = a.L[cseg[e]];
       mirror[g * UD::MS + UD::m_lam + r] = v;
-      Wg[g * D::WSLOT + D::w_lam + r] = v;
+      if (PHASE == 0 && unit == 0) Wg[g * D::WSLOT + D::w_lam + r] = v;
+    }
+    if constexpr (PHASE == 1 && !D::TRAP) {   // g^_i of the first launch (every unit contributed its share)
+      for (int e = lane; e < gcount * K * N; e += 64) {
+        const int g = e / (K * N), r = e - g * K * N;
+        mirror[g * UD::MS + UD::m_Ig + r] = Wg[g * D::WSLOT + D::w_Ig + r];
+      }
     }
   }
-  __syncthreads();
+  wave_lds_sync();
   const LglTab& tab = *reinterpret_cast<const LglTab*>(lds);
 
-  // ---- P1: cardinal values f_j (the light value body; wave 0)
-  if (unit == 0 && lane < gcount * CS) {
-    const int g = lane / CS, j = lane - g * CS;
-    const lds_double* M = mirror + g * UD::MS;
-    CardIn<D, const lds_double*> in{M + UD::m_z, nullptr, j, nullptr};
-    OdeOutValue<D> out{mirror + g * UD::MS + UD::m_Cf + j * n, Wg + g * D::WSLOT + D::w_Cf + j * n};
-    Ode::f(in, out);
-  }
-  __syncthreads();
-
-  // ---- P2: interior points, every unit its share of [f^, J^, g^, H^]  (Trapezoidal: none)
-  if constexpr (!D::TRAP) {
-    if (lane < gcount * K) {
-      const int g = lane / K, i = lane - g * K;
+  if constexpr (PHASE == 0) {
+    // ---- P1: cardinal values f_j -> mirror (this unit's own copy); unit 0 writes the slots
+    if (lane < gcount * CS) {
+      const int g = lane / CS, j = lane - g * CS;
+      const lds_double* M = mirror + g * UD::MS;
+      CardIn<D, const lds_double*> in{M + UD::m_z, nullptr, j, nullptr};
+      if (unit == 0) {
+        OdeOutValue<D, true> out{mirror + g * UD::MS + UD::m_Cf + j * n, Wg + g * D::WSLOT + D::w_Cf + j * n};
+        Ode::f(in, out);
+      } else {
+        OdeOutValue<D, false> out{mirror + g * UD::MS + UD::m_Cf + j * n, nullptr};
+        Ode::f(in, out);
+      }
+    }
+    wave_lds_sync();
+    // ---- P2: interior points, this unit's share of [f^, J^, g^, H^]  (Trapezoidal: none)
+    if constexpr (!D::TRAP) {
+      if (lane < gcount * K) {
+        const int g = lane / K, i = lane - g * K;
+        const lds_double* M = mirror + g * UD::MS;
+        const lds_double* z = M + UD::m_z;
+        const double h = z[D::TF] - z[T];
+        double y[N];
+        double li[n > 0 ? n : 1];
+#pragma unroll
+        for (int k = 0; k < n; k++) {
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * M[UD::m_Cf + j * n + k]);
+          y[k] = acc;
+        }
+        y[T] = z[T] + h * tab.s[i];
+#pragma unroll
+        for (int k = 0; k < m; k++) {
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < CS; j++) acc += tab.U[i][j] * z[j * q + n + 1 + k];
+          y[n + 1 + k] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < p; k++) y[q + k] = z[D::P0 + k];
+#pragma unroll
+        for (int k = 0; k < n; k++) li[k] = M[UD::m_lam + i * n + k];
+        RegIn<D> in{y, li};
+        glb_double* S = Wg + g * D::WSLOT;
+        OdeOutUnit<D, false, true> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH,
+                                       nullptr};
+        run_unit<Ode>(unit, in, out);
+      }
+    }
+  } else {
+    // ---- P3: cardinal nodes with the adjoint weights w_j (LGLDefects.h:369-374), this unit's share of [J, g, H]
+    if (lane < gcount * CS) {
+      const int g = lane / CS, j = lane - g * CS;
       const lds_double* M = mirror + g * UD::MS;
       const lds_double* z = M + UD::m_z;
       const double h = z[D::TF] - z[T];
-      double y[N];
-      double li[n > 0 ? n : 1];
+      double w[n > 0 ? n : 1];
 #pragma unroll
       for (int k = 0; k < n; k++) {
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * M[UD::m_Cf + j * n + k]);
-        y[k] = acc;
+        for (int i = 0; i < K; i++) {
+          if constexpr (!D::TRAP) acc += M[UD::m_Ig + i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
+          acc += M[UD::m_lam + i * n + k] * (tab.D[i][j] * h);
+        }
+        w[k] = acc;
       }
-      y[T] = z[T] + h * tab.s[i];
-#pragma unroll
-      for (int k = 0; k < m; k++) {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < CS; j++) acc += tab.U[i][j] * z[j * q + n + 1 + k];
-        y[n + 1 + k] = acc;
-      }
-#pragma unroll
-      for (int k = 0; k < p; k++) y[q + k] = z[D::P0 + k];
-#pragma unroll
-      for (int k = 0; k < n; k++) li[k] = M[UD::m_lam + i * n + k];
-      RegIn<D> in{y, li};
+      CardIn<D, const lds_double*> in{z, w, j, nullptr};
       glb_double* S = Wg + g * D::WSLOT;
-      OdeOutUnit<D, true, true> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH,
-                              mirror + g * UD::MS + UD::m_Ig + i * N};
+      // (the unit that owns f emits f_j again: dropped, P1's value is the one every reader uses)
+      OdeOutUnit<D, false, false> out{S + D::w_Cf + j * n, S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
       run_unit<Ode>(unit, in, out);
     }
-    __syncthreads();
-  }
-
-  // ---- P3: cardinal nodes with the adjoint weights w_j (LGLDefects.h:369-374), every unit its share of [J, g, H]
-  if (lane < gcount * CS) {
-    const int g = lane / CS, j = lane - g * CS;
-    const lds_double* M = mirror + g * UD::MS;
-    const lds_double* z = M + UD::m_z;
-    const double h = z[D::TF] - z[T];
-    double w[n > 0 ? n : 1];
-#pragma unroll
-    for (int k = 0; k < n; k++) {
-      double acc = 0.0;
-#pragma unroll
-      for (int i = 0; i < K; i++) {
-        if constexpr (!D::TRAP) acc += M[UD::m_Ig + i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
-        acc += M[UD::m_lam + i * n + k] * (tab.D[i][j] * h);
-      }
-      w[k] = acc;
-    }
-    CardIn<D, const lds_double*> in{z, w, j, nullptr};
-    glb_double* S = Wg + g * D::WSLOT;
-    // (the unit that owns f emits f_j again: dropped, P1's value is the one every reader uses)
-    OdeOutUnit<D, false, false> out{S + D::w_Cf + j * n, S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
-    run_unit<Ode>(unit, in, out);
   }
 }
 

@@ -141,11 +141,13 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
         static const bool no_units = std::getenv("ASSET_HIP_NO_UNITS") != nullptr;                             // tuning only
         if (!no_units) {
           constexpr int GPMAX = 64 / D::CS;
-          int gp = (a.nseg + cus - 1) / cus;                 // one workgroup of NUNITS waves per CU when the mesh allows
+          // about one workgroup per SIMD: groups x units ~ 4 per CU
+          int gp = (a.nseg * Ode::NUNITS + 4 * cus - 1) / (4 * cus);
           gp = gp < 1 ? 1 : (gp > GPMAX ? GPMAX : gp);
           const size_t bytes_units = UnitsDims<D>::lds_bytes(gp);
-          auto kern = lgl_ode_units_kernel<Ode, SCH, BLOCKED>;
-          hipLaunchKernelGGL(kern, dim3((a.nseg + gp - 1) / gp), dim3(64 * Ode::NUNITS), bytes_units, st, a, gp);
+          const dim3 grid((a.nseg + gp - 1) / gp, Ode::NUNITS);
+          hipLaunchKernelGGL((lgl_ode_units_kernel<Ode, SCH, BLOCKED, 0>), grid, dim3(64), bytes_units, st, a, gp);
+          hipLaunchKernelGGL((lgl_ode_units_kernel<Ode, SCH, BLOCKED, 1>), grid, dim3(64), bytes_units, st, a, gp);
           hipError_t e2 = hipGetLastError();
           if (e2 != hipSuccess) return e2;
         } else {

@@ -98,6 +98,7 @@ def _cnum(v: float) -> str:
 
 SPLIT_OPS = 1500     # fjgh bodies above this many operations are emitted in two out-of-line parts
 LEVEL_ORDER = os.environ.get("ASSET_LEVEL_ORDER", "1") == "1"   # breadth-first statement schedule (experiment switch)
+UNIT_LEVEL_ORDER = os.environ.get("ASSET_UNIT_LEVEL_ORDER", "0") == "1"   # the same for the unit bodies of heavy ODEs
 
 TRANSCENDENTAL = ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "asin", "acos", "atan",
                   "atan2", "powr")
@@ -329,7 +330,7 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
             outs += [(f"out.H({i}, {j}, {{}});", d.H[i][j]) for i in range(N) for j in range(i + 1)]
         return outs
 
-    def body(name, outs, extra_roots=(), extra_stmt=None, use_saved=False, q="inline"):
+    def body(name, outs, extra_roots=(), extra_stmt=None, use_saved=False, q="inline", level_order=level_order):
         roots = [r for _, r in outs] + list(extra_roots)
         if use_saved:
             low = lower_reciprocals(roots + saved)       # lowering rebuilds nodes: locate the saved ones afterwards
@@ -392,7 +393,7 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     body("fj", outputs(1))
     if units:
         for u, outs in enumerate(units):
-            body(f"fjgh_u{u}_", outs, q="__attribute__((noinline))")
+            body(f"fjgh_u{u}_", outs, q="__attribute__((noinline))", level_order=UNIT_LEVEL_ORDER)
         o.append("  template <int U, class In, class Out> __host__ __device__ static inline void fjgh_unit(const In& in, Out& out) {")
         for u in range(len(units)):
             o.append(f"    {'if' if u == 0 else 'else if'} constexpr (U == {u}) fjgh_u{u}_(in, out);")
