@@ -1,7 +1,10 @@
 """Host-visible evaluation rates of the bench workload: what a solver on the HOST pays per
 evaluation through each host-pointer entry point (PCIe included), next to the device-resident time.
 
-  python tools/host_visible.py            # on the GPU box
+  python tests/measure_host_visible.py            # on the GPU box
+
+Lives under tests/ because it borrows the oracle's sparsity analysis in place of the host solver that would own it
+(only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/); nothing of the oracle is timed.
 """
 import json
 import os
