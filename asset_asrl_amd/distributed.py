@@ -156,7 +156,14 @@ class ShardedDefectEvaluator:
 
 class PhaseShardedEvaluator:
     """Several phases of one problem (same ODE / transcription / size), whole phases per rank: phase k belongs to rank
-    k % world.  `phases` = list of (vindex, cindex) tables into the problem's X and L."""
+    k % world.  `phases` = list of (vindex, cindex) tables into the problem's X and L.
+
+    A rank's phases are evaluated as ONE function: the defect evaluator takes a variable / constraint index table per
+    application and nothing in it knows about phases, so the tables of the local phases are concatenated and the whole
+    rank is one launch (measured on one MI355X, 8 phases x 1 250 Reentry-LGL7 segments: 141.9 us as eight launches on one
+    stream, 138.9 us on eight streams joined by events, 168.5 us forked and joined inside one C call -- a 1 250-segment
+    launch is latency-bound at ~17 us and cross-stream events cost more than they hide -- against one merged launch,
+    DESIGN.md section 6)."""
 
     def __init__(self, ode: str, mode, blocked: bool, phases: Sequence, n_primal: int, n_equal: int,
                  rank: Optional[int] = None, world: Optional[int] = None, device: int = 0, group=None,
@@ -175,33 +182,44 @@ class PhaseShardedEvaluator:
         if evaluator_factory is None:
             from .evaluator import DefectEvaluator
             evaluator_factory = DefectEvaluator
-        self.evs: List = [evaluator_factory(ode, mode, blocked, phases[k][0], phases[k][1], n_primal, n_equal, device)
-                          for k in self.mine]
-        if self.evs:
-            self.IR, self.OR, self.NKKT = self.evs[0].IR, self.evs[0].OR, self.evs[0].NKKT
+        self.ev = None
+        if self.mine:
+            vix = np.concatenate([np.asarray(phases[k][0]) for k in self.mine], axis=0)
+            cix = np.concatenate([np.asarray(phases[k][1]) for k in self.mine], axis=0)
+            self.ev = evaluator_factory(ode, mode, blocked, vix, cix, n_primal, n_equal, device)
+            self.IR, self.OR, self.NKKT = self.ev.IR, self.ev.OR, self.ev.NKKT
         else:
             self.IR, self.OR, self.NKKT = _sizes(ode, mode, blocked)
         self.width = self.OR + self.IR + self.NKKT
         self._local = self._recv = None
 
-    def _views(self, flat):
-        m = self.nseg
-        o1, o2 = m * self.OR, m * (self.OR + self.IR)
-        return flat[:o1].view(m, self.OR), flat[o1:o2].view(m, self.IR), flat[o2:].view(m, self.NKKT)
+    def _nlocal(self, rank: int) -> int:
+        return len(range(rank, self.nphases, self.world))
+
+    def _views(self, flat, nlocal: int):
+        """(fx, agx, kkt) of a rank's flat buffer: [fx | agx | kkt], each over that rank's nlocal * nseg applications."""
+        m = nlocal * self.nseg
+        o1, o2, o3 = m * self.OR, m * (self.OR + self.IR), m * self.width
+        return flat[:o1].view(m, self.OR), flat[o1:o2].view(m, self.IR), flat[o2:o3].view(m, self.NKKT)
+
+    def _phase_views(self, flat, nlocal: int, slot: int):
+        lo, hi = slot * self.nseg, (slot + 1) * self.nseg
+        return tuple(v[lo:hi] for v in self._views(flat, nlocal))
 
     def alloc_device(self, device, dst: int = 0, always_exchange: bool = False):
         import torch
         self._dst = dst
-        self._local = torch.zeros((self.per_rank, self.nseg * self.width), dtype=torch.float64, device=device)
+        self._local = torch.zeros(self.per_rank * self.nseg * self.width, dtype=torch.float64, device=device)
         if self.rank == dst and (self.world > 1 or always_exchange):
-            self._recv = torch.empty((self.world, self.per_rank, self.nseg * self.width), dtype=torch.float64,
+            self._recv = torch.empty((self.world, self.per_rank * self.nseg * self.width), dtype=torch.float64,
                                      device=device)
         return self
 
     def eval_device(self, what: int, X, L=None, stream=None):
-        for s, ev in enumerate(self.evs):
-            fx, agx, kkt = self._views(self._local[s])
-            ev.eval_device(what, X, L, fx, agx if what in _ADJ else None, kkt if what >= 2 else None, stream)
+        if self.ev is None:
+            return
+        fx, agx, kkt = self._views(self._local, len(self.mine))
+        self.ev.eval_device(what, X, L, fx, agx if what in _ADJ else None, kkt if what >= 2 else None, stream)
 
     def gather_device(self, async_op: bool = False):
         if self.world == 1 and self._recv is None:
@@ -212,5 +230,8 @@ class PhaseShardedEvaluator:
     def blocks_on_root(self):
         """List over phases of (fx, agx, kkt) views on the root (None elsewhere)."""
         if self._recv is None:
-            return [self._views(self._local[s]) for s in range(self.nphases)] if self.world == 1 else None
-        return [self._views(self._recv[self.owner[k], k // self.world]) for k in range(self.nphases)]
+            if self.world != 1:
+                return None
+            return [self._phase_views(self._local, self.nphases, k) for k in range(self.nphases)]
+        return [self._phase_views(self._recv[self.owner[k]], self._nlocal(self.owner[k]), k // self.world)
+                for k in range(self.nphases)]

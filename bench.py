@@ -178,7 +178,7 @@ def main():
             sh = PhaseShardedEvaluator(ode, mode, blocked, [(wk.vindex, wk.cindex) for wk in ws], n_primal, n_equal,
                                        rank=rank, world=world, device=local_rank)
             local_segments = len(sh.mine) * nseg
-            evs = sh.evs
+            evs = [sh.ev] if sh.ev is not None else []
         sh.alloc_device(dev, always_exchange=use_dist)
         IR, OR, NKKT = sh.IR, sh.OR, sh.NKKT
 
@@ -241,7 +241,6 @@ def main():
         kkkt = torch.empty(n0 * NKKT, dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
         ms_kernel = e0.time_device(JAC_ADJGRAD_HESS, X, L, kfx, kagx, kkkt, warmup=5, iters=max(20, min(a.steps, 200)))
-        ms_kernel *= len(evs)                                   # (phases of a multi-phase rank run one after the other)
         del kfx, kagx, kkkt
     bseg = algorithmic_bytes_per_segment(IR, OR)
     achieved = local_segments * bseg / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
