@@ -355,9 +355,16 @@ __device__ inline void pipe_copy_mirror(const lds_double* mirror, int gcount, in
 }
 
 // The ODE stage of one group of at most GP segments (lane <-> evaluation point, one pass per phase).
+#if defined(ASSET_TIMING)
+#define ASSET_PTS_PARAMS , long long* pts_, int* npts_
+#define PTS() do { if (pts_ && *npts_ < 24) pts_[(*npts_)++] = clock64(); } while (0)
+#else
+#define ASSET_PTS_PARAMS
+#define PTS() do {} while (0)
+#endif
 template <class Ode, class D, int GP, class Pub>
 __device__ inline void pipe_ode_group(const EvalArgs& a, int lane, int seg0, int gcount, double* Wg, double* stage,
-                                      lds_double* mirror, const LglTab* tabp, Pub&& publish_tables) {
+                                      lds_double* mirror, const LglTab* tabp, Pub&& publish_tables ASSET_PTS_PARAMS) {
   constexpr int CS = D::CS, K = D::K, n = D::n, N = D::N, IR = D::IR, OR = D::OR, STG_LD = D::STG_LD;
   static_assert(GP * CS <= 64, "one pass per phase");
   {   // P0: gather into the mirror only -- index loads, value loads, LDS writes; no store to wait behind
@@ -385,12 +392,14 @@ __device__ inline void pipe_ode_group(const EvalArgs& a, int lane, int seg0, int
       if (e < gcount * OR) mirror[g * D::MSLOT + D::m_lam + r] = lv[t];
     }
   }
+  PTS();                             // (timing builds) gather issued and written to the mirror
   if (lane < gcount * CS) {          // P1 (reads the solver vector itself: its loads overlap the gather's)
     const int g = lane / CS, j = lane - g * CS;
     pipe_cardinal_value<Ode, D>(mirror + g * D::MSLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
   }
   wave_lds_sync();
   publish_tables();
+  PTS();                             // P1
   if constexpr (!D::TRAP) {          // P2
     if (lane < gcount * K) {
       const int g = lane / K, i = lane - g * K;
@@ -400,9 +409,11 @@ __device__ inline void pipe_ode_group(const EvalArgs& a, int lane, int seg0, int
     }
     wave_lds_sync();
   }
+  PTS();                             // P2
   // P3, preceded (inside the function) by the copy-out of P2
   pipe_cardinal_second<Ode, D, GP>((glb_double*)Wg, mirror, (lds_double*)stage, tabp, gcount, lane);
   wave_lds_sync();
+  PTS();                             // copy-out of P2 + P3
   pipe_copy_rows<D, CS>((const lds_double*)stage, D::NSTG > 0 ? gcount * CS : 0, lane, (glb_double*)Wg, D::w_CJ, D::w_CH);
   {   // what the dense stage reads of the mirror: [z | lam | f_j] (contiguous in both layouts) and g^_i
     constexpr int NA = IR + OR + CS * n, NB = K * N;
@@ -412,6 +423,7 @@ __device__ inline void pipe_ode_group(const EvalArgs& a, int lane, int seg0, int
     pipe_copy_mirror<D, NB>(mirror, gcount, lane, (glb_double*)Wg, D::m_Ig, D::w_Ig);
   }
   wave_lds_sync();   // (whatever follows rewrites the mirror and the rows)
+  PTS();             // copy-out of P3 and of the mirror issued
 }
 
 // The ODE stage of a TWO-WAVE workgroup (fused kernel, STAGE 4): the group is both waves' segments, wave 0 evaluates the
@@ -742,8 +754,12 @@ __global__ __launch_bounds__(STAGE == 4 ? 128 : 64, STAGE >= 2 ? (Dims<Ode, SCH,
   long long tstamp[24];
   int nts = 0;
 #define TS() do { if (nts < 24) tstamp[nts++] = clock64(); } while (0)
+#define ASSET_PTS_ARGS , tstamp, &nts
+#define ASSET_PTS_NONE , nullptr, nullptr
 #else
 #define TS() do {} while (0)
+#define ASSET_PTS_ARGS
+#define ASSET_PTS_NONE
 #endif
 // sub-phase stamps of the dense stage, taken for the second segment of the workgroup (-DASSET_TIMING, tools/dbg_time.py)
 #ifndef ASSET_TSG_SEG
@@ -751,11 +767,14 @@ __global__ __launch_bounds__(STAGE == 4 ? 128 : 64, STAGE >= 2 ? (Dims<Ode, SCH,
 #endif
 #define TSG() do { if (g == ASSET_TSG_SEG) TS(); } while (0)
   if constexpr (STAGE >= 3) TS();   // (timing builds: kernel start)
+#if defined(ASSET_WALLCLOCK)
+  const long long wall_t0 = wall_clock64();
+#endif
   if constexpr (STAGE == 3) {
     // the workgroup's segments are one group (the host sizes the grid so): ODE stage first, while the kernel holds
     // nothing else in registers; its results go to the slots and are read back below once the stores have landed
     pipe_ode_group<Ode, D, D::GF>(a, lane, wg_first, min(wg_count, D::GF), a.work + size_t(wg_first) * D::WSLOT, stage, mirror,
-                                  &tab, publish_tables);
+                                  &tab, publish_tables ASSET_PTS_ARGS);
   }
   if constexpr (STAGE == 4) {
     const int s0 = share - wave, first0 = s0 * per + min(s0, rem);            // the pair's first segment and count
@@ -773,7 +792,11 @@ __global__ __launch_bounds__(STAGE == 4 ? 128 : 64, STAGE >= 2 ? (Dims<Ode, SCH,
   }
   const LCT& lc = lrec.lc;
   if constexpr (STAGE == 2) publish_tables();            // after the record loads are in flight: one latency, not two
-  if constexpr (STAGE == 3) wave_loads_landed();         // the slot stores of the ODE stage (and the record loads)
+  if constexpr (STAGE == 3) {
+    TS();                                                // (timing builds) record loads issued
+    wave_loads_landed();                                 // the slot stores of the ODE stage (and the record loads)
+    TS();                                                // ... landed
+  }
   // (STAGE 4: pipe_ode_group2 ends with the wait and a barrier)
   const auto& wa = lc.wa;
   const auto& wb = lc.wb;
@@ -805,7 +828,7 @@ __global__ __launch_bounds__(STAGE == 4 ? 128 : 64, STAGE >= 2 ? (Dims<Ode, SCH,
     if constexpr (STAGE == 1 && PIPE) {
       // ---------------------------------------------------------------- pipelined ODE stage (see OdeOutPipe above)
       bool first = (g0 == 0);
-      pipe_ode_group<Ode, D, G>(a, lane, seg0, gcount, Wg, stage, mirror, &tab, [&]() { if (first) publish_tables(); });
+      pipe_ode_group<Ode, D, G>(a, lane, seg0, gcount, Wg, stage, mirror, &tab, [&]() { if (first) publish_tables(); } ASSET_PTS_NONE);
       TS();
       continue;
     }
@@ -1473,6 +1496,14 @@ __global__ __launch_bounds__(STAGE == 4 ? 128 : 64, STAGE >= 2 ? (Dims<Ode, SCH,
     }
     TS();
   }
+#if defined(ASSET_WALLCLOCK)   // (tuning builds) 100 MHz wall-clock at the start and the end of every workgroup, left in FX
+  if (lane == 0 && a.FX && wg_count > 0) {
+    a.FX[size_t(wg_first) * OR + 0] = double(wall_t0);
+    a.FX[size_t(wg_first) * OR + 1] = double(wall_clock64());
+    a.FX[size_t(wg_first) * OR + 2] = double(__builtin_amdgcn_s_getreg(63492));   // HW_ID
+    a.FX[size_t(wg_first) * OR + 3] = double(__builtin_amdgcn_s_getreg(63508));   // XCC_ID
+  }
+#endif
 #if defined(ASSET_TIMING)
   if (blockIdx.x == 7 && lane == 0 && a.FX)
     for (int t = 0; t + 1 < nts; t++) a.FX[size_t(wg_first) * OR + t] = double(tstamp[t + 1] - tstamp[t]);

@@ -16,7 +16,12 @@ for rep in range(3):
 G=int(sys.argv[1]) if len(sys.argv)>1 else 2048; per=10000//G; rem=10000%G
 first=7*per+min(7,rem)
 d=fx.ravel()[first*15:first*15+23].astype(int)
-if os.environ.get("ASSET_HIP_SKIP_DENSE"):
+if os.environ.get("ASSET_DBG_FUSED"):      # fused single launch (the default for this workload): ODE stage stamps first
+    names=["P0 gather -> mirror","P1 cardinal f_save (+ tables)","P2 interior fjgh","copy-out of P2 + P3 cardinal fjgh",
+           "copy-out of P3 and mirror issued","lane record loads issued","slot stores landed (vmcnt 0)","to the segment loop",
+           "constant tiles","segment 0 (+ slot of segment 1)","D1 DI/DC tiles","time columns, FX","D2+D3 fragments, M product",
+           "rank-2 rows","D4 H/J products","D5+D6 adjoint gradient, stores","remaining segments"]
+elif os.environ.get("ASSET_HIP_SKIP_DENSE"):
     names=["P0 gather","P1 cardinal f_save","P2 interior fjgh + copy-out","P3 ..."]
 else:
     names=["group start","constant tiles","segment 0 (+ slot of segment 1)","D1 DI/DC tiles","time columns, FX","D2+D3 fragments, M product",
