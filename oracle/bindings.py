@@ -57,7 +57,8 @@ def build_native() -> str:
     so = os.path.join(_HERE, f"liboracle_native_{hashlib.sha256(ident.encode()).hexdigest()[:10]}.so")
     srcs = [os.path.join(_HERE, f) for f in ("defect.cpp", "nlp.cpp", "mesh.cpp", "pathfuncs.cpp", "fullnlp.cpp", "odes.cpp")]
     gen = os.path.join(_HERE, "gen", "odes_gen.c")
-    deps = srcs + [gen] + [os.path.join(_HERE, f) for f in ("odes.h", "ad2.h", "lgl_coeffs.h", "oracle.h")]
+    gen4 = os.path.join(_HERE, "gen", "odes_gen4.c")          # the same bodies over four segments at once (batch4.h)
+    deps = srcs + [gen, gen4] + [os.path.join(_HERE, f) for f in ("odes.h", "ad2.h", "lgl_coeffs.h", "oracle.h", "batch4.h")]
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
         return so
     flags = ["-O2", "-march=native", "-ffast-math", "-fPIC"]
@@ -68,10 +69,11 @@ def build_native() -> str:
         o = os.path.join(tmp, os.path.basename(src) + ".o")
         subprocess.check_call(["g++", "-std=c++17", "-pthread", "-Wno-unused-function"] + flags + ["-c", src, "-o", o])
         objs.append(o)
-    if os.path.exists(gen):
-        o = os.path.join(tmp, "odes_gen.o")
-        subprocess.check_call(["gcc"] + flags + ["-c", gen, "-o", o])
-        objs.append(o)
+    for g in (gen, gen4):
+        if os.path.exists(g):
+            o = os.path.join(tmp, os.path.basename(g) + ".o")
+            subprocess.check_call(["gcc"] + flags + ["-c", g, "-o", o])
+            objs.append(o)
     subprocess.check_call(["g++", "-shared", "-pthread", "-o", so] + objs)
     return so
 
@@ -101,6 +103,8 @@ def lib(path=None):
                                         C.c_int]
         L.oracle_nlp_create.restype = C.c_void_p
         L.oracle_nlp_destroy.argtypes = [C.c_void_p]
+        L.oracle_nlp_set_batch4.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_nlp_set_batch4.restype = C.c_int
         for fn in ("oracle_nlp_kkt_dim", "oracle_nlp_nnz", "oracle_nlp_num_user_kkt"):
             getattr(L, fn).argtypes = [C.c_void_p]
         L.oracle_nlp_csr.argtypes = [C.c_void_p, _ip, _ip]
@@ -254,6 +258,11 @@ class Nlp:
         h, self.h = getattr(self, "h", None), None
         if h and lib is not None:          # module globals are gone at interpreter exit
             lib().oracle_nlp_destroy(h)
+
+    def set_batch4(self, on=True) -> bool:
+        """LGL evalKKT four applications at a time (oracle/batch4.h; the reference's SuperScalar loop).  False when the
+        loaded library / ODE provider has no four-wide body."""
+        return lib().oracle_nlp_set_batch4(self.h, int(bool(on))) == 0
 
     def csr(self):
         outer = np.zeros(self.kkt_dim + 1, dtype=np.int32)

@@ -13,6 +13,7 @@
 
 #include "lgl_coeffs.h"
 #include "oracle.h"
+#include "batch4.h"
 
 namespace {
 
@@ -50,6 +51,28 @@ bool make_sizes(const oracle_ode* ode, int mode, int blocked, Sizes& s) {
   return true;
 }
 
+// The LGL bodies below are templates over the arithmetic type R: double (the parity oracle) or four segments side by
+// side in one AVX register (v4d; the reference's SuperScalar batching, DenseFunctionBase.h:1318-1380 with
+// DefaultSuperScalar = Array<double,4,1>, TypeDefs/EigenTypes.h:72-75).  With R = double the operations and their order
+// are exactly those of the untemplated text this replaced.
+template <class R> inline R bc(double c);
+template <> inline double bc<double>(double c) { return c; }
+template <> inline v4d bc<v4d>(double c) { return v4d{c, c, c, c}; }
+
+struct OdeScalar {   // the registry's function pointers (odes.cpp)
+  const oracle_ode* o;
+  void f(const double* y, double* fx) const { o->f(y, fx, o->ctx); }
+  void fj(const double* y, double* fx, double* J) const { o->fj(y, fx, J, o->ctx); }
+  void fjgh(const double* y, const double* lam, double* fx, double* J, double* g, double* H) const {
+    o->fjgh(y, lam, fx, J, g, H, o->ctx);
+  }
+};
+struct OdeV4 {       // generated analytic derivatives compiled for four segments at once (gen/odes_gen4.c)
+  const oracle_ode4* o;
+  void f(const v4d* y, v4d* fx) const { o->f(y, fx); }
+  void fjgh(const v4d* y, const v4d* lam, v4d* fx, v4d* J, v4d* g, v4d* H) const { o->fjgh(y, lam, fx, J, g, H); }
+};
+
 // column-major element accessors
 #define DI(a, c) di[(a) + (size_t)(c) * S.N]
 #define JX(r, c) jx[(r) + (size_t)(c) * S.OR]
@@ -58,10 +81,11 @@ bool make_sizes(const oracle_ode* ode, int mode, int blocked, Sizes& s) {
 #define OJ(J, k, a) (J)[(size_t)(k) * S.N + (a)]
 #define OH(H, a, b) (H)[(size_t)(a) * S.N + (b)]
 
-void load_cardinals(const Sizes& S, const double* x, std::vector<double>& C_XS) {
-  C_XS.assign((size_t)S.CS * S.N, 0.0);
+template <class R>
+void load_cardinals(const Sizes& S, const R* x, std::vector<R>& C_XS) {
+  C_XS.assign((size_t)S.CS * S.N, bc<R>(0.0));
   for (int i = 0; i < S.CS; i++) {
-    double* c = &C_XS[(size_t)i * S.N];
+    R* c = &C_XS[(size_t)i * S.N];
     for (int k = 0; k < S.q; k++) c[k] = x[i * S.q + k];
     for (int k = 0; k < S.p; k++) c[S.q + k] = x[S.CS * S.q + k];
   }
@@ -91,39 +115,41 @@ void lgl_compute(const oracle_ode* ode, const Sizes& S, const double* x, double*
 }
 
 // Builds DI_DCS = d(x^_i, tau_i, u^_i, P)/dz for interior i (LGLDefects.h:162-216 / :415-458)
-void build_DI(const Sizes& S, const lgl_tables* L, int i, double h, const std::vector<double>& C_DXS,
-              const std::vector<double>& C_JDXS, std::vector<double>& di) {
-  std::fill(di.begin(), di.end(), 0.0);
+template <class R>
+void build_DI(const Sizes& S, const lgl_tables* L, int i, R h, const std::vector<R>& C_DXS,
+              const std::vector<R>& C_JDXS, std::vector<R>& di) {
+  std::fill(di.begin(), di.end(), bc<R>(0.0));
   const int tf = S.q * (S.CS - 1) + S.T;
-  DI(S.T, S.T) = 1.0 - L->s[i];
-  DI(S.T, tf) = L->s[i];
-  for (int k = 0; k < S.p; k++) DI(S.q + k, S.CS * S.q + k) = 1.0;
+  DI(S.T, S.T) = bc<R>(1.0 - L->s[i]);
+  DI(S.T, tf) = bc<R>(L->s[i]);
+  for (int k = 0; k < S.p; k++) DI(S.q + k, S.CS * S.q + k) = bc<R>(1.0);
   for (int j = 0; j < S.CS; j++) {
-    const double* Jj = &C_JDXS[(size_t)j * S.n * S.N];
-    const double* fj = &C_DXS[(size_t)j * S.n];
-    for (int k = 0; k < S.n; k++) DI(k, j * S.q + k) = L->A[i][j];  // diagonal .setConstant (assignment)
-    const double bh = L->B[i][j] * h;
+    const R* Jj = &C_JDXS[(size_t)j * S.n * S.N];
+    const R* fj = &C_DXS[(size_t)j * S.n];
+    for (int k = 0; k < S.n; k++) DI(k, j * S.q + k) = bc<R>(L->A[i][j]);  // diagonal .setConstant (assignment)
+    const R bh = L->B[i][j] * h;
     for (int k = 0; k < S.n; k++)
       for (int c = 0; c < S.q; c++) DI(k, j * S.q + c) += bh * OJ(Jj, k, c);
     for (int k = 0; k < S.n; k++)
       for (int c = 0; c < S.p; c++) DI(k, S.CS * S.q + c) += bh * OJ(Jj, k, S.q + c);
     for (int k = 0; k < S.n; k++) DI(k, S.T) -= L->B[i][j] * fj[k];
     for (int k = 0; k < S.n; k++) DI(k, tf) += L->B[i][j] * fj[k];
-    for (int k = 0; k < S.m; k++) DI(S.n + 1 + k, j * S.q + S.n + 1 + k) = L->U[i][j];
+    for (int k = 0; k < S.m; k++) DI(S.n + 1 + k, j * S.q + S.n + 1 + k) = bc<R>(L->U[i][j]);
   }
 }
 
 // Cardinal contributions to fx rows / jx rows of interior i  (LGLDefects.h:218-246 / :460-488)
-void cardinal_fx_jx(const Sizes& S, const lgl_tables* L, int i, double h, const std::vector<double>& C_XS,
-                    const std::vector<double>& C_DXS, const std::vector<double>& C_JDXS, double* fx, double* jx) {
+template <class R>
+void cardinal_fx_jx(const Sizes& S, const lgl_tables* L, int i, R h, const std::vector<R>& C_XS,
+                    const std::vector<R>& C_DXS, const std::vector<R>& C_JDXS, R* fx, R* jx) {
   const int tf = S.q * (S.CS - 1) + S.T;
   for (int j = 0; j < S.CS; j++) {
-    const double* cx = &C_XS[(size_t)j * S.N];
-    const double* cd = &C_DXS[(size_t)j * S.n];
-    const double* Jj = &C_JDXS[(size_t)j * S.n * S.N];
+    const R* cx = &C_XS[(size_t)j * S.N];
+    const R* cd = &C_DXS[(size_t)j * S.n];
+    const R* Jj = &C_JDXS[(size_t)j * S.n * S.N];
     for (int k = 0; k < S.n; k++) fx[i * S.n + k] += (L->C[i][j] * cx[k] + (L->D[i][j] * h) * cd[k]);
-    for (int k = 0; k < S.n; k++) JX(i * S.n + k, j * S.q + k) = L->C[i][j];
-    const double dh = L->D[i][j] * h;
+    for (int k = 0; k < S.n; k++) JX(i * S.n + k, j * S.q + k) = bc<R>(L->C[i][j]);
+    const R dh = L->D[i][j] * h;
     for (int k = 0; k < S.n; k++)
       for (int c = 0; c < S.q; c++) JX(i * S.n + k, j * S.q + c) += dh * OJ(Jj, k, c);
     for (int k = 0; k < S.n; k++)
@@ -134,14 +160,15 @@ void cardinal_fx_jx(const Sizes& S, const lgl_tables* L, int i, double h, const 
 }
 
 // Interior contribution to fx / jx rows of interior i  (LGLDefects.h:251-260 / :491-500)
-void interior_fx_jx(const Sizes& S, const lgl_tables* L, int i, double h, const double* I_DXS, const double* I_JDXS,
-                    const std::vector<double>& di, double* fx, double* jx) {
+template <class R>
+void interior_fx_jx(const Sizes& S, const lgl_tables* L, int i, R h, const R* I_DXS, const R* I_JDXS,
+                    const std::vector<R>& di, R* fx, R* jx) {
   const int tf = S.q * (S.CS - 1) + S.T;
-  const double he = h * L->E[i];
+  const R he = h * L->E[i];
   for (int k = 0; k < S.n; k++) fx[i * S.n + k] += he * I_DXS[k];
   for (int k = 0; k < S.n; k++)
     for (int c = 0; c < S.IR; c++) {
-      double acc = 0.0;
+      R acc = bc<R>(0.0);
       for (int a = 0; a < S.N; a++) acc += (he * OJ(I_JDXS, k, a)) * DI(a, c);
       JX(i * S.n + k, c) += acc;
     }
@@ -175,41 +202,41 @@ void lgl_jacobian(const oracle_ode* ode, const Sizes& S, const double* x, double
   }
 }
 
-void lgl_all(const oracle_ode* ode, const Sizes& S, const double* x, const double* lam, double* fx, double* jx,
-             double* agx, double* hx) {
+template <class R, class ODE>
+void lgl_all_t(const ODE& ode, const Sizes& S, const R* x, const R* lam, R* fx, R* jx, R* agx, R* hx) {
   const lgl_tables* L = lgl_get(S.CS);
   const int tf = S.q * (S.CS - 1) + S.T;
-  std::vector<double> C_XS, C_DXS((size_t)S.CS * S.n, 0.0), C_JDXS((size_t)S.CS * S.n * S.N, 0.0);
-  std::vector<double> C_AGXS(S.N, 0.0), C_AVS((size_t)S.CS * S.n, 0.0), C_HDXS((size_t)S.N * S.N, 0.0);
-  std::vector<double> I_XS((size_t)S.K * S.N, 0.0), I_DXS((size_t)S.K * S.n, 0.0);
-  std::vector<double> I_JDXS((size_t)S.K * S.n * S.N, 0.0), I_AGXS((size_t)S.K * S.N, 0.0);
-  std::vector<double> I_AVS((size_t)S.K * S.n, 0.0), I_HDXS((size_t)S.K * S.N * S.N, 0.0);
-  std::vector<double> di((size_t)S.N * S.IR, 0.0), HTpar(S.IR, 0.0), tmp((size_t)S.N * S.IR, 0.0);
+  std::vector<R> C_XS, C_DXS((size_t)S.CS * S.n, bc<R>(0.0)), C_JDXS((size_t)S.CS * S.n * S.N, bc<R>(0.0));
+  std::vector<R> C_AGXS(S.N, bc<R>(0.0)), C_AVS((size_t)S.CS * S.n, bc<R>(0.0)), C_HDXS((size_t)S.N * S.N, bc<R>(0.0));
+  std::vector<R> I_XS((size_t)S.K * S.N, bc<R>(0.0)), I_DXS((size_t)S.K * S.n, bc<R>(0.0));
+  std::vector<R> I_JDXS((size_t)S.K * S.n * S.N, bc<R>(0.0)), I_AGXS((size_t)S.K * S.N, bc<R>(0.0));
+  std::vector<R> I_AVS((size_t)S.K * S.n, bc<R>(0.0)), I_HDXS((size_t)S.K * S.N * S.N, bc<R>(0.0));
+  std::vector<R> di((size_t)S.N * S.IR, bc<R>(0.0)), HTpar(S.IR, bc<R>(0.0)), tmp((size_t)S.N * S.IR, bc<R>(0.0));
 
   load_cardinals(S, x, C_XS);
   // (1) cardinal values only (:325-337).  The reference evaluates the cardinal ODE value a second time in
   // step (3); ODE nodes assign their outputs, so one evaluation is equivalent.
-  for (int i = 0; i < S.CS; i++) ode->f(&C_XS[(size_t)i * S.N], &C_DXS[(size_t)i * S.n], ode->ctx);
-  const double h = C_XS[(size_t)(S.CS - 1) * S.N + S.T] - C_XS[S.T];                                   // :339
+  for (int i = 0; i < S.CS; i++) ode.f(&C_XS[(size_t)i * S.N], &C_DXS[(size_t)i * S.n]);
+  const R h = C_XS[(size_t)(S.CS - 1) * S.N + S.T] - C_XS[S.T];                                   // :339
 
   // (2) interiors: interpolate, full ODE evaluation with lambda_i, accumulate cardinal adjoint weights (:341-375)
   for (int i = 0; i < S.K; i++) {
-    double* ix = &I_XS[(size_t)i * S.N];
+    R* ix = &I_XS[(size_t)i * S.N];
     ix[S.T] = C_XS[S.T] + h * L->s[i];
     for (int k = 0; k < S.p; k++) ix[S.q + k] = x[S.CS * S.q + k];
-    double* iav = &I_AVS[(size_t)i * S.n];
+    R* iav = &I_AVS[(size_t)i * S.n];
     for (int k = 0; k < S.n; k++) iav[k] = lam[i * S.n + k];
     for (int j = 0; j < S.CS; j++) {
-      const double* cx = &C_XS[(size_t)j * S.N];
-      const double* cd = &C_DXS[(size_t)j * S.n];
+      const R* cx = &C_XS[(size_t)j * S.N];
+      const R* cd = &C_DXS[(size_t)j * S.n];
       for (int k = 0; k < S.n; k++) ix[k] += (L->A[i][j] * cx[k] + (L->B[i][j] * h) * cd[k]);
       for (int k = 0; k < S.m; k++) ix[S.n + 1 + k] += L->U[i][j] * cx[S.n + 1 + k];
     }
-    ode->fjgh(ix, iav, &I_DXS[(size_t)i * S.n], &I_JDXS[(size_t)i * S.n * S.N], &I_AGXS[(size_t)i * S.N],
-              &I_HDXS[(size_t)i * S.N * S.N], ode->ctx);
+    ode.fjgh(ix, iav, &I_DXS[(size_t)i * S.n], &I_JDXS[(size_t)i * S.n * S.N], &I_AGXS[(size_t)i * S.N],
+             &I_HDXS[(size_t)i * S.N * S.N]);
     for (int j = 0; j < S.CS; j++) {
       const double scale = L->E[i] * L->B[i][j];
-      double* cav = &C_AVS[(size_t)j * S.n];
+      R* cav = &C_AVS[(size_t)j * S.n];
       for (int k = 0; k < S.n; k++) cav[k] += I_AGXS[(size_t)i * S.N + k] * (scale * h * h);
       for (int k = 0; k < S.n; k++) cav[k] += iav[k] * (L->D[i][j] * h);
     }
@@ -217,10 +244,10 @@ void lgl_all(const oracle_ode* ode, const Sizes& S, const double* x, const doubl
 
   // (3) cardinals: Jacobian + Hessian weighted by the accumulated adjoint (:377-412)
   for (int j = 0; j < S.CS; j++) {
-    std::fill(C_AGXS.begin(), C_AGXS.end(), 0.0);
-    std::fill(C_HDXS.begin(), C_HDXS.end(), 0.0);
-    ode->fjgh(&C_XS[(size_t)j * S.N], &C_AVS[(size_t)j * S.n], &C_DXS[(size_t)j * S.n],
-              &C_JDXS[(size_t)j * S.n * S.N], C_AGXS.data(), C_HDXS.data(), ode->ctx);
+    std::fill(C_AGXS.begin(), C_AGXS.end(), bc<R>(0.0));
+    std::fill(C_HDXS.begin(), C_HDXS.end(), bc<R>(0.0));
+    ode.fjgh(&C_XS[(size_t)j * S.N], &C_AVS[(size_t)j * S.n], &C_DXS[(size_t)j * S.n],
+             &C_JDXS[(size_t)j * S.n * S.N], C_AGXS.data(), C_HDXS.data());
     const int o = j * S.q, P0 = S.CS * S.q;
     for (int a = 0; a < S.q; a++)
       for (int b = 0; b < S.q; b++) HX(o + a, o + b) += OH(C_HDXS, a, b);
@@ -239,23 +266,23 @@ void lgl_all(const oracle_ode* ode, const Sizes& S, const double* x, const doubl
     build_DI(S, L, i, h, C_DXS, C_JDXS, di);
     cardinal_fx_jx(S, L, i, h, C_XS, C_DXS, C_JDXS, fx, jx);
     interior_fx_jx(S, L, i, h, &I_DXS[(size_t)i * S.n], &I_JDXS[(size_t)i * S.n * S.N], di, fx, jx);
-    const double he = h * L->E[i];
-    const double* Hi = &I_HDXS[(size_t)i * S.N * S.N];
+    const R he = h * L->E[i];
+    const R* Hi = &I_HDXS[(size_t)i * S.N * S.N];
     // tmp = (H_i * he) * DI   (N x IR)
     for (int a = 0; a < S.N; a++)
       for (int c = 0; c < S.IR; c++) {
-        double acc = 0.0;
+        R acc = bc<R>(0.0);
         for (int b = 0; b < S.N; b++) acc += (OH(Hi, a, b) * he) * DI(b, c);
         tmp[a + (size_t)c * S.N] = acc;
       }
     for (int r = 0; r < S.IR; r++)
       for (int c = 0; c < S.IR; c++) {
-        double acc = 0.0;
+        R acc = bc<R>(0.0);
         for (int a = 0; a < S.N; a++) acc += DI(a, r) * tmp[a + (size_t)c * S.N];
         HX(r, c) += acc;
       }
     for (int c = 0; c < S.IR; c++) {
-      double acc = 0.0;
+      R acc = bc<R>(0.0);
       for (int a = 0; a < S.N; a++) acc += (I_AGXS[(size_t)i * S.N + a] * L->E[i]) * DI(a, c);
       HTpar[c] += acc;
     }
@@ -267,10 +294,15 @@ void lgl_all(const oracle_ode* ode, const Sizes& S, const double* x, const doubl
   for (int c = 0; c < S.IR; c++) HX(S.T, c) -= HTpar[c];
   for (int c = 0; c < S.IR; c++) HX(tf, c) += HTpar[c];
   for (int c = 0; c < S.IR; c++) {
-    double acc = 0.0;
+    R acc = bc<R>(0.0);
     for (int r = 0; r < S.OR; r++) acc += lam[r] * JX(r, c);
     agx[c] = acc;
   }
+}
+
+void lgl_all(const oracle_ode* ode, const Sizes& S, const double* x, const double* lam, double* fx, double* jx,
+             double* agx, double* hx) {
+  lgl_all_t<double>(OdeScalar{ode}, S, x, lam, fx, jx, agx, hx);
 }
 
 // ----------------------------------------------------------------------------------- Trapezoidal
@@ -373,6 +405,19 @@ void trap_all(const oracle_ode* ode, const Sizes& S, const double* x, const doub
 }
 
 }  // namespace
+
+// Four segments at once (nlp.cpp, bench.py's cpu_baseline leg): x, lam, and every output are arrays of v4d, lane = segment.
+int oracle_defect_all_v4(const oracle_ode* ode, const oracle_ode4* ode4, int mode, int blocked, const v4d* x, const v4d* lam,
+                         v4d* fx, v4d* jx, v4d* agx, v4d* hx) {
+  Sizes S;
+  if (!make_sizes(ode, mode, blocked, S) || mode < ORACLE_LGL3 || !ode4 || !ode4->fjgh) return -1;
+  std::fill(fx, fx + S.OR, bc<v4d>(0.0));
+  std::fill(jx, jx + (size_t)S.OR * S.IR, bc<v4d>(0.0));
+  std::fill(agx, agx + S.IR, bc<v4d>(0.0));
+  std::fill(hx, hx + (size_t)S.IR * S.IR, bc<v4d>(0.0));
+  lgl_all_t<v4d>(OdeV4{ode4}, S, x, lam, fx, jx, agx, hx);
+  return 0;
+}
 
 extern "C" {
 

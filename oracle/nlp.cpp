@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 
+#include "batch4.h"
 #include "oracle.h"
 
 namespace {
@@ -34,6 +35,8 @@ struct IndexData {  // SolverIndexingData
 
 struct oracle_nlp {
   oracle_ode ode;
+  oracle_ode4 ode4 = {nullptr, nullptr};   // four-wide twin of `ode` (batch4.h), when the registry has one
+  bool batch4 = false;                      // oracle_nlp_set_batch4: LGL evalKKT processes four applications at a time
   int mode, blocked;
   int ir, orr, nkkt_per_appl;
   int primal, equal, threads;
@@ -143,7 +146,67 @@ void eval_slice(oracle_nlp* n, const IndexData& d, int what, const double* X, co
                 double* agx_out, double* kktvals, double* kkt_blocks, bool blocks, size_t appl_base) {
   const int IR = d.ir, OR = d.orr;
   std::vector<double> x(IR), l(OR), fx(OR), jx((size_t)OR * IR), agx(IR), hx((size_t)IR * IR);
-  for (int V = 0; V < d.nappl; V++) {
+  // what happens to one application's results: value / adjoint-gradient slots, then the block or the KKT scatter
+  auto emit = [&](int V) {
+    // value / adjoint-gradient slots: callee overwrites (fx.setZero(); compute)
+    const size_t a = appl_base + V;
+    double* fdst = fx_out ? fx_out + (blocks ? a * OR : (size_t)d.con_starts[V]) : nullptr;
+    if (fdst) std::memcpy(fdst, fx.data(), sizeof(double) * OR);
+    if (agx_out && what != ORACLE_CON && what != ORACLE_JAC) {
+      double* gdst = agx_out + (blocks ? a * IR : (size_t)d.grad_starts[V]);
+      std::memcpy(gdst, agx.data(), sizeof(double) * IR);
+    }
+    if (what < ORACLE_JAC) return;
+    const bool dohess = (what == ORACLE_JAC_ADJGRAD_HESS);
+    if (blocks) {
+      if (!kkt_blocks) return;
+      double* blk = kkt_blocks + a * n->nkkt_per_appl;
+      int k = 0;
+      for (int i = 0; i < IR; i++) {
+        for (int j = i; j < IR; j++) blk[k++] = dohess ? hx[j + (size_t)i * IR] : 0.0;
+        for (int j = 0; j < OR; j++) blk[k++] = jx[j + (size_t)i * OR];
+      }
+      return;
+    }
+    // KKTFillAll / KKTFillJac (DenseFunctionBase.h:1413-1523), unique_constraints = true
+    int freeloc = d.kkt_starts[V];
+    const int* lpt = n->kkt_locs.data();
+    for (int i = 0; i < IR; i++) {
+      const int var = d.VLoc(i, V);
+      if (dohess) {
+        const int lk = n->clashes[var];
+        if (lk >= 0) n->locks[lk].lock();
+        for (int j = i; j < IR; j++) kktvals[lpt[freeloc++]] += hx[j + (size_t)i * IR];
+        if (lk >= 0) n->locks[lk].unlock();
+      } else {
+        freeloc += IR - i;
+      }
+      for (int j = 0; j < OR; j++) kktvals[lpt[freeloc++]] += jx[j + (size_t)i * OR];
+    }
+  };
+  int V0 = 0;
+  // SuperScalar batching (DenseFunctionBase.h:1318-1380): whole packs of four applications through the four-wide body,
+  // results emitted pack lane by pack lane (ScalarCallBack), then the remainder one application at a time
+  if (n->batch4 && n->ode4.fjgh && what == ORACLE_JAC_ADJGRAD_HESS && n->mode >= ORACLE_LGL3) {
+    std::vector<v4d> x4(IR), l4(OR), fx4(OR), jx4((size_t)OR * IR), agx4(IR), hx4((size_t)IR * IR);
+    for (; V0 + 4 <= d.nappl; V0 += 4) {
+      for (int k = 0; k < 4; k++) {
+        gather(d, V0 + k, X, L, x.data(), l.data());
+        for (int i = 0; i < IR; i++) x4[i][k] = x[i];
+        for (int j = 0; j < OR; j++) l4[j][k] = l[j];
+      }
+      oracle_defect_all_v4(&n->ode, &n->ode4, n->mode, n->blocked, x4.data(), l4.data(), fx4.data(), jx4.data(),
+                           agx4.data(), hx4.data());
+      for (int k = 0; k < 4; k++) {
+        for (int j = 0; j < OR; j++) fx[j] = fx4[j][k];
+        for (int i = 0; i < IR; i++) agx[i] = agx4[i][k];
+        for (size_t e = 0; e < jx.size(); e++) jx[e] = jx4[e][k];
+        for (size_t e = 0; e < hx.size(); e++) hx[e] = hx4[e][k];
+        emit(V0 + k);
+      }
+    }
+  }
+  for (int V = V0; V < d.nappl; V++) {
     gather(d, V, X, (what == ORACLE_CON || what == ORACLE_JAC) ? nullptr : L, x.data(), l.data());
     switch (what) {
       case ORACLE_CON:
@@ -164,41 +227,7 @@ void eval_slice(oracle_nlp* n, const IndexData& d, int what, const double* X, co
         oracle_defect_all(&n->ode, n->mode, n->blocked, x.data(), l.data(), fx.data(), jx.data(), agx.data(),
                           hx.data());
     }
-    // value / adjoint-gradient slots: callee overwrites (fx.setZero(); compute)
-    const size_t a = appl_base + V;
-    double* fdst = fx_out ? fx_out + (blocks ? a * OR : (size_t)d.con_starts[V]) : nullptr;
-    if (fdst) std::memcpy(fdst, fx.data(), sizeof(double) * OR);
-    if (agx_out && what != ORACLE_CON && what != ORACLE_JAC) {
-      double* gdst = agx_out + (blocks ? a * IR : (size_t)d.grad_starts[V]);
-      std::memcpy(gdst, agx.data(), sizeof(double) * IR);
-    }
-    if (what < ORACLE_JAC) continue;
-    const bool dohess = (what == ORACLE_JAC_ADJGRAD_HESS);
-    if (blocks) {
-      if (!kkt_blocks) continue;
-      double* blk = kkt_blocks + a * n->nkkt_per_appl;
-      int k = 0;
-      for (int i = 0; i < IR; i++) {
-        for (int j = i; j < IR; j++) blk[k++] = dohess ? hx[j + (size_t)i * IR] : 0.0;
-        for (int j = 0; j < OR; j++) blk[k++] = jx[j + (size_t)i * OR];
-      }
-      continue;
-    }
-    // KKTFillAll / KKTFillJac (DenseFunctionBase.h:1413-1523), unique_constraints = true
-    int freeloc = d.kkt_starts[V];
-    const int* lpt = n->kkt_locs.data();
-    for (int i = 0; i < IR; i++) {
-      const int var = d.VLoc(i, V);
-      if (dohess) {
-        const int lk = n->clashes[var];
-        if (lk >= 0) n->locks[lk].lock();
-        for (int j = i; j < IR; j++) kktvals[lpt[freeloc++]] += hx[j + (size_t)i * IR];
-        if (lk >= 0) n->locks[lk].unlock();
-      } else {
-        freeloc += IR - i;
-      }
-      for (int j = 0; j < OR; j++) kktvals[lpt[freeloc++]] += jx[j + (size_t)i * OR];
-    }
+    emit(V);
   }
 }
 
@@ -318,6 +347,15 @@ oracle_nlp* oracle_nlp_create(const oracle_ode* ode, int mode, int blocked, int 
   }
   analyze_sparsity(n);
   return n;
+}
+
+/* bench.py's cpu_baseline leg: evaluate LGL evalKKT four applications at a time (batch4.h).  Returns 0, or -1 when this
+ * library / ODE has no four-wide body (the scalar loop stays). */
+int oracle_nlp_set_batch4(oracle_nlp* n, int on) {
+  if (!on) { n->batch4 = false; return 0; }
+  if (oracle_get_ode4(&n->ode, &n->ode4) != 0 || n->mode < ORACLE_LGL3) return -1;
+  n->batch4 = true;
+  return 0;
 }
 
 void oracle_nlp_destroy(oracle_nlp* n) { delete n; }

@@ -8,6 +8,7 @@
 // checked against provider 0 in tests/test_oracle.py.
 #include <cstring>
 
+#include "batch4.h"
 #include "odes.h"
 #include "oracle.h"
 
@@ -73,6 +74,8 @@ AD2_ODE(integrand_powp, 1, 2, 0)
   extern "C" void ode_##NAME##_fj(const double*, double*, double*) __attribute__((weak));               \
   extern "C" void ode_##NAME##_fjgh(const double*, const double*, double*, double*, double*, double*)   \
       __attribute__((weak));                                                                            \
+  extern "C" void ode_##NAME##_f4(const v4d*, v4d*) __attribute__((weak));                              \
+  extern "C" void ode_##NAME##_fjgh4(const v4d*, const v4d*, v4d*, v4d*, v4d*, v4d*) __attribute__((weak)); \
   namespace {                                                                                           \
   void gen_##NAME##_f(const double* y, double* f, const void*) { ode_##NAME##_f(y, f); }                \
   void gen_##NAME##_fj(const double* y, double* f, double* J, const void*) { ode_##NAME##_fj(y, f, J); } \
@@ -111,6 +114,32 @@ void oracle_set_synthetic32(const double* abc) { std::memcpy(g_synth32, abc, siz
     }                                                                               \
     return -2;                                                                      \
   }
+
+}  // extern "C"
+
+// four-wide twin of a generated registry entry (batch4.h)
+#define TRY4(NAME)                                                                  \
+  if (ode->fjgh == &gen_##NAME##_fjgh && ode_##NAME##_fjgh4 && ode_##NAME##_f4) {   \
+    out->f = &ode_##NAME##_f4, out->fjgh = &ode_##NAME##_fjgh4;                     \
+    return 0;                                                                       \
+  }
+int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
+  TRY4(brachistochrone)
+  TRY4(reentry)
+  TRY4(twobody_lt)
+  TRY4(betts_lowthrust)
+  TRY4(synthetic32)
+  TRY4(vanderpol)
+  TRY4(coupled12)
+  TRY4(coupled16)
+  TRY4(pathcon)
+  TRY4(integrand_quad2)
+  TRY4(pairprod)
+  TRY4(integrand_powp)
+  return -1;
+}
+
+extern "C" {
 
 int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(brachistochrone, 3, 1, 0, nullptr)

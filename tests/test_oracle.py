@@ -102,3 +102,26 @@ def test_generated_provider_matches_ad2(oracle):
         b = oracle.defect_all(o1, oracle.MODES[mode], x, lam)
         for u, v in zip(a, b):
             assert rel_err(u, v) < 1e-12
+
+
+@pytest.mark.parametrize("name,mode,nseg,blocked", [("reentry", "LGL7", 203, False), ("twobody_lt", "LGL5", 101, True),
+                                                   ("betts_lowthrust", "LGL5", 50, False),
+                                                   ("brachistochrone", "LGL3", 42, False)])
+def test_four_segment_batches_match_the_scalar_loop(oracle, name, mode, nseg, blocked):
+    """bench.py's cpu_baseline leg runs the oracle four segments at a time (oracle/batch4.h, the reference's SuperScalar
+    loop, DenseFunctionBase.h:1318-1380): same blocks, same scattered KKT values as one segment at a time -- including a
+    remainder that is not a multiple of four, split over three threads."""
+    from helpers import Workload
+    w = Workload(name, mode, nseg, blocked)
+    ode = oracle.get_ode(name, 1)                      # generated analytic derivatives: the provider that has four-wide bodies
+    out = []
+    for b4 in (False, True):
+        nlp = oracle.Nlp(ode, oracle.MODES[mode], blocked, w.vindex, w.cindex, w.n_primal, w.n_equal, 3)
+        if b4:
+            assert nlp.set_batch4(True)
+        out.append(list(nlp.eval(oracle.JAC_ADJGRAD_HESS, w.X, w.L)) + list(nlp.eval_blocks(oracle.JAC_ADJGRAD_HESS, w.X, w.L)))
+    for a, b in zip(*out):
+        np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(a).max()))
+    # the AD2 provider has no four-wide twin: the switch reports it and the scalar loop stays
+    nlp = oracle.Nlp(oracle.get_ode(name, 0), oracle.MODES[mode], blocked, w.vindex, w.cindex, w.n_primal, w.n_equal, 1)
+    assert not nlp.set_batch4(True)
