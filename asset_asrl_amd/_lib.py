@@ -34,6 +34,10 @@ SYMBOLS = {
     "asset_hip_defect_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "asset_hip_defect_eval": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "asset_hip_defect_eval_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),
+    "asset_hip_jit_compile": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
+                                       C.c_int, C.c_char_p]),
+    "asset_hip_jit_plugin": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_char_p), C.c_int, C.c_char_p]),
     "asset_hip_defect_time_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int,
                                                                                          C.POINTER(C.c_float)]),
     "asset_hip_defect_set_appl_consts": (C.c_int, [C.c_void_p, _dp, C.c_int]),

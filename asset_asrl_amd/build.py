@@ -161,7 +161,7 @@ def build(verbose=True, jobs=None) -> str:
         res = list(ex.map(_compile, srcs))
     objs = [o for o, _ in res]
     if any(ch for _, ch in res) or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lhiprtc"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])

@@ -1,5 +1,6 @@
 // C ABI of libasset_hip.so (see include/asset_hip.h for the contract and the reference interfaces replaced).
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -14,6 +15,7 @@
 
 #include "../../include/asset_hip.h"
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include "registry.h"
 
@@ -175,6 +177,156 @@ int asset_hip_ode_sizes(const char* ode, int* xv, int* uv, int* pv) {
   return fail(ASSET_HIP_ENOODE, std::string("unknown ODE '") + ode + "'");
 }
 
+
+// ---- in-process run-time compilation (hiprtc) ---------------------------------------------------------------------------
+namespace {
+// what one compilation leaves behind: the code object and, per kernel slot of the table (registry.h), the lowered name
+struct RtcBlob {
+  std::vector<std::pair<int, std::string>> names;
+  std::vector<char> code;
+};
+const char kRtcMagic[] = "ASSET-HIP-RTC-1";
+
+bool rtc_write(const std::string& path, const RtcBlob& b) {
+  const std::string tmp = path + ".tmp" + std::to_string(long(getpid()));
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  std::fprintf(f, "%s\n%zu\n", kRtcMagic, b.names.size());
+  for (auto& n : b.names) std::fprintf(f, "%d %s\n", n.first, n.second.c_str());
+  std::fprintf(f, "%zu\n", b.code.size());
+  const bool ok = std::fwrite(b.code.data(), 1, b.code.size(), f) == b.code.size();
+  std::fclose(f);
+  if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) {   // (rename: a reader never sees half a file)
+    std::remove(tmp.c_str());
+    return false;
+  }
+  return true;
+}
+bool rtc_read(const std::string& path, RtcBlob& b) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  char line[1024];
+  size_t n = 0, bytes = 0;
+  bool ok = std::fgets(line, sizeof line, f) && !std::strncmp(line, kRtcMagic, sizeof kRtcMagic - 1) &&
+            std::fgets(line, sizeof line, f) && std::sscanf(line, "%zu", &n) == 1;
+  for (size_t i = 0; ok && i < n; i++) {
+    int slot = -1;
+    char name[960];
+    ok = std::fgets(line, sizeof line, f) && std::sscanf(line, "%d %959s", &slot, name) == 2 && slot >= 0 && slot < asset_hip::K_COUNT;
+    if (ok) b.names.emplace_back(slot, name);
+  }
+  ok = ok && std::fgets(line, sizeof line, f) && std::sscanf(line, "%zu", &bytes) == 1 && bytes > 0;
+  if (ok) {
+    b.code.resize(bytes);
+    ok = std::fread(b.code.data(), 1, bytes, f) == bytes;
+  }
+  std::fclose(f);
+  return ok;
+}
+
+int rtc_compile(const char* source, const char* functor, int kind, int mode, int blocked, int seg_per_group,
+                const char* const* options, int noptions, RtcBlob& out) {
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, source, "asset_hip_plugin.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    return fail(ASSET_HIP_ECOMPILE, "hiprtcCreateProgram failed");
+  std::vector<std::pair<int, std::string>> exprs;
+  for (int slot = 0; slot < asset_hip::K_COUNT; slot++) {
+    const std::string ex = asset_hip::rtc_kernel_expr(slot, kind, functor, mode, blocked != 0, seg_per_group);
+    if (ex.empty()) continue;
+    exprs.emplace_back(slot, ex);
+    if (hiprtcAddNameExpression(prog, ex.c_str()) != HIPRTC_SUCCESS) {
+      hiprtcDestroyProgram(&prog);
+      return fail(ASSET_HIP_ECOMPILE, "hiprtcAddNameExpression(" + ex + ") failed");
+    }
+  }
+  const hiprtcResult rc = hiprtcCompileProgram(prog, noptions, const_cast<const char**>(options));
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    std::string log;
+    if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) {
+      log.resize(n);
+      hiprtcGetProgramLog(prog, &log[0]);
+    }
+    hiprtcDestroyProgram(&prog);
+    if (log.size() > 6000) log = log.substr(0, 3000) + "\n...\n" + log.substr(log.size() - 3000);
+    return fail(ASSET_HIP_ECOMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + log);
+  }
+  size_t bytes = 0;
+  if (hiprtcGetCodeSize(prog, &bytes) != HIPRTC_SUCCESS || !bytes) {
+    hiprtcDestroyProgram(&prog);
+    return fail(ASSET_HIP_ECOMPILE, "hiprtcGetCodeSize failed");
+  }
+  out.code.resize(bytes);
+  hiprtcGetCode(prog, out.code.data());
+  for (auto& ex : exprs) {
+    const char* low = nullptr;
+    if (hiprtcGetLoweredName(prog, ex.second.c_str(), &low) != HIPRTC_SUCCESS || !low) {
+      hiprtcDestroyProgram(&prog);
+      return fail(ASSET_HIP_ECOMPILE, "hiprtcGetLoweredName(" + ex.second + ") failed");
+    }
+    out.names.emplace_back(ex.first, low);
+  }
+  hiprtcDestroyProgram(&prog);
+  return 0;
+}
+}  // namespace
+
+int asset_hip_jit_compile(const char* source, const char* functor, int kind, int mode, int blocked, int seg_per_group,
+                          const char* const* options, int noptions, const char* cache_path) {
+  if (!source || !functor || !cache_path || (kind != 1 && kind != 2)) return fail(ASSET_HIP_EINVAL, "bad jit arguments");
+  RtcBlob blob;
+  const int rc = rtc_compile(source, functor, kind, mode, blocked, seg_per_group, options, noptions, blob);
+  if (rc) return rc;
+  if (!rtc_write(cache_path, blob)) return fail(ASSET_HIP_EINVAL, std::string("cannot write ") + cache_path);
+  return 0;
+}
+
+int asset_hip_jit_plugin(const char* name, const char* source, const char* functor, int kind, int mode, int blocked,
+                         int seg_per_group, const char* const* options, int noptions, const char* cache_path) {
+  if (!name || !functor || (kind != 1 && kind != 2)) return fail(ASSET_HIP_EINVAL, "bad jit arguments");
+  if (find_entry(name, kind == 2 ? ASSET_HIP_FUNCTION : mode, blocked)) return 0;
+  RtcBlob blob;
+  if (!(cache_path && rtc_read(cache_path, blob))) {
+    blob = RtcBlob();
+    if (!source) return fail(ASSET_HIP_EINVAL, std::string("no compiled module at ") + (cache_path ? cache_path : "(null)") + " and no source");
+    const int rc = rtc_compile(source, functor, kind, mode, blocked, seg_per_group, options, noptions, blob);
+    if (rc) return rc;
+    if (cache_path && !rtc_write(cache_path, blob)) return fail(ASSET_HIP_EINVAL, std::string("cannot write ") + cache_path);
+  }
+  hipModule_t mod = nullptr;   // stays loaded for the life of the process: its entry and device code live in it
+  HIP_TRY(hipModuleLoadData(&mod, blob.code.data()));
+  auto* table = new asset_hip::KernelTable();
+  hipDeviceptr_t dmeta = nullptr;
+  size_t mbytes = 0;
+  hipError_t e = hipModuleGetGlobal(&dmeta, &mbytes, mod, "asset_rtc_meta");
+  if (e != hipSuccess || mbytes != sizeof table->meta) {
+    delete table;
+    hipModuleUnload(mod);
+    return fail(ASSET_HIP_ECOMPILE, "the module has no asset_rtc_meta table of the expected size (rtc_device.h)");
+  }
+  HIP_TRY(hipMemcpy(table->meta, reinterpret_cast<void*>(dmeta), sizeof table->meta, hipMemcpyDeviceToHost));
+  if (table->meta[asset_hip::MF_KIND] != kind || (kind == 1 && (table->meta[asset_hip::MF_MODE] != mode ||
+                                                               table->meta[asset_hip::MF_BLOCKED] != (blocked ? 1 : 0)))) {
+    delete table;
+    hipModuleUnload(mod);
+    return fail(ASSET_HIP_EINVAL, "the module was compiled for another transcription / kind than requested");
+  }
+  for (auto& n : blob.names) {
+    hipFunction_t fn = nullptr;
+    if ((e = hipModuleGetFunction(&fn, mod, n.second.c_str())) != hipSuccess) {
+      delete table;
+      hipModuleUnload(mod);
+      return hipfail(e, ("hipModuleGetFunction(" + n.second + ")").c_str());
+    }
+    table->k[n.first].mod = fn;
+  }
+  auto* ke = new asset_hip::KernelEntry();
+  asset_hip::entry_from_table(*ke, strdup(name), table);
+  ke->next = asset_hip::registry_head();
+  asset_hip::registry_head() = ke;
+  return 0;
+}
+
 int asset_hip_load_plugin(const char* path) {
   if (!path) return fail(ASSET_HIP_EINVAL, "null plugin path");
   void* so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -277,15 +429,15 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
       return bail(e, "hipMemset(workspace)");
   }
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-  if (ke->lane_bytes)   // per-lane constants of the dense stage: computed here, once
+  // per-lane constants of the dense stage: computed here, once
     for (int level = 1; level <= 2; level++) {
-      const size_t nb = ke->lane_bytes(level);
+      const size_t nb = asset_hip::entry_lane_bytes(ke, level);
       if (!nb) continue;
       // ASSET_LANE_REPLICAS copies: every workgroup of the dense stage loads the whole table when it starts, all at the
       // same moment -- with one copy that is thousands of requests for the same few hundred cache lines, which the L2
       // channels holding them serve one after the other; workgroup b reads copy b % ASSET_LANE_REPLICAS.
       if ((e = hipMalloc(&h->d_lane[level], nb * ASSET_LANE_REPLICAS)) != hipSuccess) return bail(e, "hipMalloc(lane constants)");
-      if ((e = ke->lane_setup(level, h->d_lane[level], h->stream)) != hipSuccess) return bail(e, "lane_setup_kernel");
+      if ((e = asset_hip::entry_lane_setup(ke, level, h->d_lane[level], h->stream)) != hipSuccess) return bail(e, "lane_setup_kernel");
       for (int r = 1; r < ASSET_LANE_REPLICAS; r++)
         if ((e = hipMemcpyAsync(static_cast<char*>(h->d_lane[level]) + size_t(r) * nb, h->d_lane[level], nb,
                                 hipMemcpyDeviceToDevice, h->stream)) != hipSuccess)
@@ -348,7 +500,7 @@ static int launch(asset_hip_defect_t h, int what, const double* dX, const double
     a.kmap = h->d_map, a.values = d_values, a.KKT = nullptr;
     a.stage = h->d_stage, a.nvalues = int(h->nvalues);
   }
-  hipError_t e = h->ke->launch(level, a, h->cus, st);
+  hipError_t e = asset_hip::entry_launch(h->ke, level, a, h->cus, st);
   if (e != hipSuccess) return hipfail(e, "kernel launch");
   if (d_values && h->nmulti > 0 && level >= 2) {   // the staged locations (Hessian entries only): fixed-order sums
     hipLaunchKernelGGL(asset_hip::asm_reduce_kernel, dim3(h->nmulti), dim3(256), 0, st, d_values, h->d_stage, h->d_multi_ptr,
@@ -443,7 +595,7 @@ int asset_hip_mesh_error_deboor(const char* ode, int mode, int blocked, const do
   if (!ode || !traj || !tsnd || !mesh_errors || !mesh_dist) return fail(ASSET_HIP_EINVAL, "null argument");
   const asset_hip::KernelEntry* ke = find_entry(ode, mode, blocked);
   if (!ke) return fail(ASSET_HIP_ENOODE, std::string("no device code compiled for ode='") + ode + "' in this mode");
-  if (!ke->mesh) return fail(ASSET_HIP_EINVAL, "this entry is not a transcription of an ODE");
+  if (!asset_hip::entry_has_mesh(ke)) return fail(ASSET_HIP_EINVAL, "this entry is not a transcription of an ODE");
   const int cs = asset_hip::mesh_scheme(mode).cs, n = ke->xv, N = ke->xv + 1 + ke->uv + ke->pv;
   const int nb = (nnodes - 1) / (cs - 1);
   if (nb < 2 || nb * (cs - 1) + 1 != nnodes)
@@ -472,7 +624,7 @@ int asset_hip_mesh_error_deboor(const char* ode, int mode, int blocked, const do
   auto done = [&](int rc) { (void)hipFree(buf); return rc; };
   hipError_t e = hipMemcpy(buf, traj, sz_traj * sizeof(double), hipMemcpyHostToDevice);
   if (e != hipSuccess) return done(hipfail(e, "hipMemcpy(traj)"));
-  if ((e = ke->mesh(a, nullptr)) != hipSuccess) return done(hipfail(e, "mesh kernels"));
+  if ((e = asset_hip::entry_mesh(ke, a, nullptr)) != hipSuccess) return done(hipfail(e, "mesh kernels"));
   if ((e = hipMemcpy(tsnd, a.tsnd, (nb + 1) * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess ||
       (e = hipMemcpy(mesh_errors, a.errors, sz_e * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess ||
       (e = hipMemcpy(mesh_dist, a.dist, sz_e * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)

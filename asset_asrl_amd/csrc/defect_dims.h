@@ -184,6 +184,18 @@ struct Dims {
   static constexpr size_t lds_bytes() { return lds_bytes_ode() > lds_bytes_dense() ? lds_bytes_ode() : lds_bytes_dense(); }
 };
 
+// Which (derivative level, stage) variants of lgl_defect_kernel a shape has.  The launcher (registry.h) uses no other; a
+// run-time compiled module (rtc_device.h) names every variant and gets the others as empty kernels.
+template <class D, int LEVEL, int STAGE>
+constexpr bool lgl_variant_valid() {
+  if (STAGE == 1) return true;                 // ODE stage (and the whole value-only kind): every shape
+  if (D::WIDE) return false;                   // wide shapes: dense stage in defect_wide.h
+  if (STAGE == 2) return LEVEL >= 1;
+  if (STAGE == 3) return D::FUSED && LEVEL == 2;
+  if (STAGE == 4) return D::FUSED2 && LEVEL == 2;
+  return false;
+}
+
 using d4 = __attribute__((ext_vector_type(4))) double;
 
 // ---------------------------------------------------------------------------------------------- ODE accessors

@@ -665,11 +665,13 @@ struct LaneRecord {
 
 template <class Ode, int SCH, bool BLOCKED, int LEVEL>
 __global__ __launch_bounds__(64) void lane_setup_kernel(unsigned int* out) {
-  using LC = LaneConsts<Ode, Dims<Ode, SCH, BLOCKED>, LEVEL>;
-  LaneRecord<LC> r;
-  for (int k = 0; k < LaneRecord<LC>::NW; k++) r.w[k] = 0u;
-  r.lc.compute(d_lgl_tab[Dims<Ode, SCH, BLOCKED>::TAB], threadIdx.x);
-  for (int k = 0; k < LaneRecord<LC>::NW; k++) out[k * 64 + threadIdx.x] = r.w[k];
+  if constexpr (!Dims<Ode, SCH, BLOCKED>::WIDE) {   // (wide shapes: wide_setup_kernel)
+    using LC = LaneConsts<Ode, Dims<Ode, SCH, BLOCKED>, LEVEL>;
+    LaneRecord<LC> r;
+    for (int k = 0; k < LaneRecord<LC>::NW; k++) r.w[k] = 0u;
+    r.lc.compute(d_lgl_tab[Dims<Ode, SCH, BLOCKED>::TAB], threadIdx.x);
+    for (int k = 0; k < LaneRecord<LC>::NW; k++) out[k * 64 + threadIdx.x] = r.w[k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- kernel
@@ -683,10 +685,8 @@ __global__ __launch_bounds__(64) void lane_setup_kernel(unsigned int* out) {
 //          device-wide drain of the slot stores between the stages, and the slots are read back from L2.
 // STAGE 4: as STAGE 3 with TWO-wave workgroups (FUSED2 shapes): the ODE stage of both waves' segments is evaluated once
 //          per pair (pipe_ode_group2), then each wave runs the dense phase of its own segments in its own half of the LDS.
-template <class Ode, int SCH, bool BLOCKED, int G, int LEVEL, int STAGE, bool ASM = false>
-__global__ __launch_bounds__(STAGE == 4 ? 128 : 64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
-                                                   ? ASSET_DENSE_WAVES_PER_SIMD : 1)   // LDS-bound to one wave per SIMD anyway: take the registers
-                                             : ASSET_ODE_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
+template <class Ode, int SCH, bool BLOCKED, int G, int LEVEL, int STAGE, bool ASM>
+__device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   constexpr int CS = D::CS;
   constexpr int K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0;
@@ -1509,6 +1509,14 @@ __global__ __launch_bounds__(STAGE == 4 ? 128 : 64, STAGE >= 2 ? (Dims<Ode, SCH,
     for (int t = 0; t + 1 < nts; t++) a.FX[size_t(wg_first) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
 #endif
 #undef TS
+}
+
+// The kernel proper: the body above for the variants the shape has (lgl_variant_valid), nothing otherwise.
+template <class Ode, int SCH, bool BLOCKED, int G, int LEVEL, int STAGE, bool ASM = false>
+__global__ __launch_bounds__(STAGE == 4 ? 128 : 64, STAGE >= 2 ? (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * 4 * ASSET_DENSE_WAVES_PER_SIMD <= 160 * 1024
+                                                   ? ASSET_DENSE_WAVES_PER_SIMD : 1)   // LDS-bound to one wave per SIMD anyway: take the registers
+                                             : ASSET_ODE_WAVES_PER_SIMD) void lgl_defect_kernel(EvalArgs a) {
+  if constexpr (lgl_variant_valid<Dims<Ode, SCH, BLOCKED>, LEVEL, STAGE>()) lgl_defect_body<Ode, SCH, BLOCKED, G, LEVEL, STAGE, ASM>(a);
 }
 
 }  // namespace asset_hip

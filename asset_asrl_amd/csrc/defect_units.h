@@ -76,7 +76,7 @@ __device__ inline void run_unit(int unit, const In& in, Out& out) {
 //          (512 with the accumulation registers as spill space), where seven waves in one workgroup had 256 each and
 //          spilled ~1 KB per lane to scratch (110 MB of scratch traffic per evaluation of 1 000 Betts segments).
 template <class Ode, int SCH, bool BLOCKED, int PHASE>
-__global__ __launch_bounds__(64, 1) void lgl_ode_units_kernel(EvalArgs a, int gp) {
+__device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using UD = UnitsDims<D>;
   constexpr int CS = D::CS, K = D::K, n = D::n, m = D::m, p = D::p, q = D::q, N = D::N, T = D::T, IR = D::IR, OR = D::OR;
@@ -192,6 +192,13 @@ __global__ __launch_bounds__(64, 1) void lgl_ode_units_kernel(EvalArgs a, int gp
       run_unit<Ode>(unit, in, out);
     }
   }
+}
+
+// The kernel proper (ODEs whose generated functor is cut into units; an empty kernel for the others, which a run-time
+// compiled module still names).
+template <class Ode, int SCH, bool BLOCKED, int PHASE>
+__global__ __launch_bounds__(64, 1) void lgl_ode_units_kernel(EvalArgs a, int gp) {
+  if constexpr (Ode::NUNITS > 1) lgl_ode_units_body<Ode, SCH, BLOCKED, PHASE>(a, gp);
 }
 
 }  // namespace asset_hip

@@ -115,8 +115,7 @@ struct WideSparsity {
 #define ASSET_WIDE_WGS 2              // workgroups per CU when two working sets fit its LDS (halves the register budget)
 #endif
 template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM>
-__global__ __launch_bounds__(256, (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * ASSET_WIDE_WGS <= 160 * 1024 ? ASSET_WIDE_WGS : 1))
-void lgl_wide_dense_kernel(EvalArgs a) {
+__device__ __forceinline__ void lgl_wide_dense_body(const EvalArgs& a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   static_assert(D::WIDE && LEVEL >= 1, "wide shapes, derivative kinds only (the value comes from the ODE stage)");
   constexpr int CS = D::CS, K = D::K, n = D::n, p = D::p, q = D::q, N = D::N, T = D::T, TF = D::TF, P0 = D::P0;
@@ -596,6 +595,13 @@ void lgl_wide_dense_kernel(EvalArgs a) {
   }
 #endif
 #undef TSW
+}
+
+// The kernel proper (wide shapes only; an empty kernel for the others, which a run-time compiled module still names).
+template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM>
+__global__ __launch_bounds__(256, (Dims<Ode, SCH, BLOCKED>::lds_bytes_dense() * ASSET_WIDE_WGS <= 160 * 1024 ? ASSET_WIDE_WGS : 1))
+void lgl_wide_dense_kernel(EvalArgs a) {
+  if constexpr (Dims<Ode, SCH, BLOCKED>::WIDE && LEVEL >= 1) lgl_wide_dense_body<Ode, SCH, BLOCKED, LEVEL, ASM>(a);
 }
 
 }  // namespace asset_hip

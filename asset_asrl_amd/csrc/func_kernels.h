@@ -80,23 +80,4 @@ __global__ __launch_bounds__(64) void func_kernel(EvalArgs a) {
   }
 }
 
-template <class F>
-hipError_t launch_func(int level, const EvalArgs& a, int, hipStream_t st) {
-  const int grid = (a.nseg + 63) / 64;
-  const bool asmb = a.kmap != nullptr;
-#define ASSET_FUNC_LAUNCH(LV)                                                                   \
-  do {                                                                                          \
-    if (asmb) hipLaunchKernelGGL((func_kernel<F, LV, true>), dim3(grid), dim3(64), 0, st, a);   \
-    else hipLaunchKernelGGL((func_kernel<F, LV, false>), dim3(grid), dim3(64), 0, st, a);       \
-  } while (0)
-  switch (level) {
-    case 0: hipLaunchKernelGGL((func_kernel<F, 0, false>), dim3(grid), dim3(64), 0, st, a); break;
-    case 1: ASSET_FUNC_LAUNCH(1); break;
-    case 2: ASSET_FUNC_LAUNCH(2); break;
-    default: return hipErrorInvalidValue;
-  }
-#undef ASSET_FUNC_LAUNCH
-  return hipGetLastError();
-}
-
 }  // namespace asset_hip

@@ -1,0 +1,59 @@
+// What the host has to know about one compiled (ODE, transcription, control mode) -- or one plain function -- to create
+// handles for it and to launch its kernels: a flat table of integers, all of them compile-time constants of Dims<...>.
+// Translation units compiled into libasset_hip.so read the table directly (registry.h); a module compiled at run time
+// (hiprtc, rtc_device.h) carries it as the device constant `asset_rtc_meta`, which the loader copies back
+// (capi.hip: asset_hip_jit_plugin).  One launcher serves both.
+#pragma once
+#include "defect_kernels.h"
+#include "defect_units.h"
+#include "defect_wide.h"
+#include "func_kernels.h"
+
+namespace asset_hip {
+
+enum MetaField {
+  MF_KIND = 0,       // 1: transcription of an ODE, 2: plain function
+  MF_XV, MF_UV, MF_PV,
+  MF_MODE,           // ASSET_HIP_* transcription id (0 for plain functions)
+  MF_BLOCKED,
+  MF_IR, MF_OR, MF_NKKT,
+  MF_G,              // segments per group of the ODE stage
+  MF_LDS_BYTES,
+  MF_WORK_DOUBLES,   // workspace doubles per segment (ODE result slot)
+  MF_NACONST,        // plain functions: constants per application (vf.ApplConst)
+  MF_BYTES_ODE, MF_BYTES_DENSE,
+  MF_WIDE, MF_WIDE_WGS,
+  MF_FUSED, MF_GF, MF_FUSED2, MF_GF2, MF_BYTES_FUSED2,
+  MF_NUNITS, MF_UNITS_BASE_BYTES, MF_UNITS_SLOT_BYTES, MF_CS,
+  MF_LANE_BYTES1, MF_LANE_BYTES2,
+  MF_COUNT
+};
+
+template <class Ode, int SCH, bool BLOCKED>
+constexpr long long lgl_lane_table_bytes(int level) {
+  using D = Dims<Ode, SCH, BLOCKED>;
+  // bytes of the whole table: 64 word-interleaved records (defect_kernels.h: lane_setup_kernel; defect_wide.h: wide_setup_kernel)
+  if constexpr (D::WIDE) return level >= 1 ? (long long)(D::TJ) * D::TI * 4 * 64 * sizeof(unsigned int) : 0;
+  else return level >= 2 ? (long long)sizeof(LaneConsts<Ode, D, 2>) * 64 : (level == 1 ? (long long)sizeof(LaneConsts<Ode, D, 1>) * 64 : 0);
+}
+
+template <class Ode, int SCH, bool BLOCKED, int G>
+struct LglMeta {
+  using D = Dims<Ode, SCH, BLOCKED>;
+  using UD = UnitsDims<D>;
+  static constexpr long long v[MF_COUNT] = {
+      1, Ode::XV, Ode::UV, Ode::PV, SCH, BLOCKED ? 1 : 0, D::IR, D::OR, D::NKKT, G, (long long)D::lds_bytes(), D::WSLOT, 0,
+      (long long)D::lds_bytes_ode(), (long long)D::lds_bytes_dense(), D::WIDE ? 1 : 0,
+      (D::lds_bytes_dense() * ASSET_WIDE_WGS <= 160 * 1024) ? ASSET_WIDE_WGS : 1,
+      D::FUSED ? 1 : 0, D::GF, D::FUSED2 ? 1 : 0, D::GF2, (long long)D::lds_bytes_fused2(),
+      Ode::NUNITS, (long long)D::TABSZ * 8, (long long)UD::MS * 8, D::CS,
+      lgl_lane_table_bytes<Ode, SCH, BLOCKED>(1), lgl_lane_table_bytes<Ode, SCH, BLOCKED>(2)};
+};
+
+template <class F>
+struct FuncMeta {
+  using D = FuncDims<F>;
+  static constexpr long long v[MF_COUNT] = {2, F::XV, F::UV, F::PV, 0, 0, D::IR, D::OR, D::NKKT, 0, 0, 0, F::NACONST};
+};
+
+}  // namespace asset_hip

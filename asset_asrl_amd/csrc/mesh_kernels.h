@@ -126,15 +126,4 @@ __global__ __launch_bounds__(64) void mesh_error_kernel(MeshArgs a, int n, doubl
   if (i == a.nb - 1) a.error_max[a.nb] = emax, a.dist_max[a.nb] = dmax;
 }
 
-template <class Ode, int SCH, bool BLOCKED>
-hipError_t launch_mesh(const MeshArgs& a, hipStream_t st) {
-  constexpr MeshScheme sc = mesh_scheme(SCH);
-  const int grid = (a.nb + 63) / 64;
-  hipLaunchKernelGGL((mesh_yvec_kernel<Ode, SCH, BLOCKED>), dim3(grid), dim3(64), 0, st, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((mesh_error_kernel<0>), dim3(grid), dim3(64), 0, st, a, int(Ode::XV), sc.order, sc.error_weight);
-  return hipGetLastError();
-}
-
 }  // namespace asset_hip

@@ -1,18 +1,49 @@
-// Kernel registry: every (ODE functor, transcription mode, blocked) instantiation compiled into
-// libasset_hip.so registers one entry; the C ABI (capi.hip) looks entries up by name at create time.
+// Kernel registry: every (ODE functor, transcription mode, blocked) instantiation compiled into libasset_hip.so registers
+// one entry; so does every module compiled at run time (capi.hip: asset_hip_jit_plugin).  The C ABI (capi.hip) looks
+// entries up by name at create time.  An entry is data -- the integers of kernel_meta.h and one reference per kernel
+// variant -- and ONE launcher (launch_lgl_table below) serves the kernels linked into the library (host stubs) and the
+// kernels of a run-time module (hipFunction_t) alike.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
-#include "defect_kernels.h"
-#include "defect_wide.h"
-#include "defect_units.h"
-#include "func_kernels.h"
+#include "kernel_meta.h"
 #include "mesh_kernels.h"
 
 namespace asset_hip {
+
+// ---- kernel references ---------------------------------------------------------------------------------------------
+struct KRef {
+  const void* host = nullptr;   // host stub of a kernel linked into this process (hipLaunchKernel)
+  hipFunction_t mod = nullptr;  // kernel of a run-time module (hipModuleLaunchKernel)
+  explicit operator bool() const { return host || mod; }
+};
+inline hipError_t klaunch(const KRef& k, dim3 grid, dim3 block, size_t shmem, hipStream_t st, void** args) {
+  if (k.mod)
+    return hipModuleLaunchKernel(k.mod, grid.x, grid.y, grid.z, block.x, block.y, block.z, unsigned(shmem), st, args, nullptr);
+  if (!k.host) return hipErrorInvalidDeviceFunction;
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(k.host, hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));
+    if (e != hipSuccess) return e;
+  }
+  return hipLaunchKernel(k.host, grid, block, args, shmem, st);
+}
+
+// kernel slots of a table (the same numbering for the static fill and for the name expressions of a run-time module)
+constexpr int K_LGL(int level, int stage, bool asmb) { return level * 8 + (stage - 1) * 2 + (asmb ? 1 : 0); }   // 0..23
+constexpr int K_WIDE(int level, bool asmb) { return 24 + (level - 1) * 2 + (asmb ? 1 : 0); }                     // 24..27
+constexpr int K_WIDE_SETUP = 28, K_LANE_SETUP1 = 29, K_LANE_SETUP2 = 30, K_UNITS0 = 31, K_UNITS1 = 32;
+constexpr int K_MESH_YVEC = 33, K_MESH_ERROR = 34;
+constexpr int K_FUNC(int level, bool asmb) { return 35 + level * 2 + (asmb ? 1 : 0); }                           // 35..40
+constexpr int K_COUNT = 41;
+
+struct KernelTable {
+  long long meta[MF_COUNT] = {};
+  KRef k[K_COUNT];
+};
 
 struct KernelEntry {
   const char* ode;
@@ -23,20 +54,23 @@ struct KernelEntry {
   int seg_per_group;      // segments whose ODE results one workgroup keeps in its workspace at a time
   size_t lds_bytes;
   size_t work_doubles;    // workspace doubles per segment (ODE result slot)
-  // level 0/1/2 ; returns hipError_t
-  hipError_t (*launch)(int level, const EvalArgs& a, int cus, hipStream_t st);
+  int naconst;            // plain functions: constants per application the function reads (vf.ApplConst)
+  const KernelTable* table;
   KernelEntry* next;
-  hipError_t (*mesh)(const MeshArgs& a, hipStream_t st);   // de Boor mesh-error estimate (mesh_kernels.h)
-  // per-lane constants of the dense stage for derivative level 1 / 2: table size in bytes (0: none) and the kernel filling it
-  size_t (*lane_bytes)(int level);
-  hipError_t (*lane_setup)(int level, void* out, hipStream_t st);
-  int naconst = 0;        // plain functions: constants per application the function reads (vf.ApplConst)
 };
+inline void entry_from_table(KernelEntry& e, const char* name, const KernelTable* t) {
+  const long long* m = t->meta;
+  e.ode = name, e.xv = int(m[MF_XV]), e.uv = int(m[MF_UV]), e.pv = int(m[MF_PV]), e.mode = int(m[MF_MODE]);
+  e.blocked = int(m[MF_BLOCKED]), e.ir = int(m[MF_IR]), e.orr = int(m[MF_OR]), e.nkkt = int(m[MF_NKKT]);
+  e.seg_per_group = int(m[MF_G]), e.lds_bytes = size_t(m[MF_LDS_BYTES]), e.work_doubles = size_t(m[MF_WORK_DOUBLES]);
+  e.naconst = int(m[MF_NACONST]), e.table = t, e.next = nullptr;
+}
 
 #if defined(ASSET_PLUGIN)
-// A plugin (one run-time compiled translation unit, see asset_asrl_amd/jit.py) collects its entries in a list of
-// its own and exports it through asset_hip_plugin_entries(); asset_hip_load_plugin() splices it into the registry
-// of libasset_hip.so.  Nothing here touches the host library's symbols, so the plugin needs no link against it.
+// A plugin (one translation unit compiled by hipcc at run time: asset_asrl_amd/jit.py with ASSET_HIP_JIT=hipcc) collects
+// its entries in a list of its own and exports it through asset_hip_plugin_entries(); asset_hip_load_plugin() splices it
+// into the registry of libasset_hip.so.  Nothing here touches the host library's symbols, so the plugin needs no link
+// against it.
 namespace {
 KernelEntry* g_plugin_head = nullptr;
 }
@@ -55,7 +89,6 @@ inline KernelEntry*& registry_head() {
   static KernelEntry* head = nullptr;
   return head;
 }
-
 struct Registrar {
   explicit Registrar(KernelEntry* e) {
     e->next = registry_head();
@@ -64,11 +97,13 @@ struct Registrar {
 };
 #endif
 
-template <class Ode, int SCH, bool BLOCKED, int G>
-hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
-  using D = Dims<Ode, SCH, BLOCKED>;
-  constexpr size_t bytes_ode = D::lds_bytes_ode(), bytes_dense = D::lds_bytes_dense();
-  static_assert(bytes_ode <= 160 * 1024 && bytes_dense <= 160 * 1024, "per-workgroup LDS exceeds the 160 KiB of a gfx950 CU");
+// ---- the launcher ---------------------------------------------------------------------------------------------------
+inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalArgs& a, int cus, hipStream_t st) {
+  const long long* m = t.meta;
+  const size_t bytes_ode = size_t(m[MF_BYTES_ODE]), bytes_dense = size_t(m[MF_BYTES_DENSE]);
+  const bool wide = m[MF_WIDE] != 0;
+  EvalArgs args = a;
+  void* kargs[] = {&args};
   // ODE launch: the three ODE phases are latency chains, so spread the segments over every resident wave (fewest
   // passes per wave); a workgroup walks its share in groups of at most G segments (= 64 points of the widest phase)
   int per_cu_a = int((160 * 1024) / bytes_ode);
@@ -79,46 +114,29 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
   int per_cu_b = int((160 * 1024) / bytes_dense);
   per_cu_b = per_cu_b < 1 ? 1 : (per_cu_b >= 8 ? 8 : (per_cu_b >= 6 ? 6 : (per_cu_b >= 4 ? 4 : per_cu_b)));
   int grid_b = a.nseg < cus * per_cu_b ? a.nseg : cus * per_cu_b;
-  const int wide_wgs = (bytes_dense * ASSET_WIDE_WGS <= 160 * 1024) ? ASSET_WIDE_WGS : 1;   // four-wave workgroups per CU (defect_wide.h)
-  (void)wide_wgs;
+  const int wide_wgs = int(m[MF_WIDE_WGS]);   // four-wave workgroups per CU (defect_wide.h)
   static const int env_b = std::getenv("ASSET_HIP_GRID_B") ? std::atoi(std::getenv("ASSET_HIP_GRID_B")) : 0;  // tuning only
   if (env_b > 0) grid_b = env_b < a.nseg ? env_b : a.nseg;
   static const bool skip_dense = std::getenv("ASSET_HIP_SKIP_DENSE") != nullptr;                               // tuning only
-#define ASSET_LAUNCH(LV, STG, GRID, BYTES) ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, LV, STG, false>), GRID, 64, BYTES)
+  auto ode_stage = [&](int lv) { return klaunch(t.k[K_LGL(lv, 1, false)], dim3(grid_a), dim3(64), bytes_ode, st, kargs); };
   // dense stage: single-wave workgroups, or (wide shapes, defect_wide.h) one four-wave workgroup per CU
-#define ASSET_LAUNCH_DENSE(LV, ASMV)                                                                              \
-  do {                                                                                                            \
-    if constexpr (D::WIDE) {                                                                                      \
-      ASSET_LAUNCH_K((lgl_wide_dense_kernel<Ode, SCH, BLOCKED, LV, ASMV>), (a.nseg < cus * wide_wgs ? a.nseg : cus * wide_wgs), 256, bytes_dense); \
-    } else {                                                                                                      \
-      ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, LV, 2, ASMV>), grid_b, 64, bytes_dense);            \
-    }                                                                                                             \
-  } while (0)
-#define ASSET_LAUNCH_K(KERN, GRID, BLOCK, BYTES)                                                                       \
-  do {                                                                                                            \
-    auto kern = KERN;                                                                                             \
-    if (BYTES > 64 * 1024) {                                                                                      \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(BYTES));                 \
-      if (e != hipSuccess) return e;                                                                              \
-    }                                                                                                             \
-    hipLaunchKernelGGL(kern, dim3(GRID), dim3(BLOCK), BYTES, st, a);                                                \
-    hipError_t e2 = hipGetLastError();                                                                            \
-    if (e2 != hipSuccess) return e2;                                                                              \
-  } while (0)
+  auto dense_stage = [&](int lv) {
+    const bool asmb = a.kmap != nullptr;   // KKT entries added straight into the solver's value array
+    if (wide)
+      return klaunch(t.k[K_WIDE(lv, asmb)], dim3(a.nseg < cus * wide_wgs ? a.nseg : cus * wide_wgs), dim3(256), bytes_dense, st, kargs);
+    return klaunch(t.k[K_LGL(lv, 2, asmb)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);
+  };
+  hipError_t e;
   switch (level) {
-    case 0: ASSET_LAUNCH(0, 1, grid_a, bytes_ode); return hipSuccess;
+    case 0: return ode_stage(0);
     case 1:
-      ASSET_LAUNCH(1, 1, grid_a, bytes_ode);
-      if (skip_dense) return hipSuccess;
-      if (a.kmap) ASSET_LAUNCH_DENSE(1, true);   // KKT entries added straight into the solver's value array
-      else ASSET_LAUNCH_DENSE(1, false);
-      return hipSuccess;
-    case 2:
-      if constexpr (D::FUSED) {
+      if ((e = ode_stage(1)) != hipSuccess || skip_dense) return e;
+      return dense_stage(1);
+    case 2: {
+      if (m[MF_FUSED]) {
         // single launch when every workgroup's share fits one group of the fused kernel (defect_kernels.h, STAGE 3)
         static const bool no_fuse = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                               // tuning only
-        if constexpr (D::FUSED2) {
+        if (m[MF_FUSED2]) {
           // two-wave workgroups: the ODE bodies are issued once per pair of waves (defect_kernels.h, STAGE 4)
           static const bool no_fuse2 = std::getenv("ASSET_HIP_NO_FUSE2") != nullptr;                           // tuning only
           const int pairs = grid_b / 2;
@@ -126,87 +144,175 @@ hipError_t launch_lgl(int level, const EvalArgs& a, int cus, hipStream_t st) {
           //  segments per wave -- Reentry-LGL7 x 5 000 -- the pair's barriers cost more than the shared bodies save:
           //  29.6 -> 32.9 us, so short shares keep the one-wave form)
           const int share = (a.nseg + 2 * pairs - 1) / (pairs > 0 ? 2 * pairs : 1);
-          if (!a.kmap && !no_fuse && !no_fuse2 && !skip_dense && pairs > 0 && share >= 4 && share <= D::GF2 / 2) {
-            ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 4, false>), pairs, 128, D::lds_bytes_fused2());
-            return hipSuccess;
-          }
+          if (!a.kmap && !no_fuse && !no_fuse2 && !skip_dense && pairs > 0 && share >= 4 && share <= int(m[MF_GF2]) / 2)
+            return klaunch(t.k[K_LGL(2, 4, false)], dim3(pairs), dim3(128), size_t(m[MF_BYTES_FUSED2]), st, kargs);
         }
-        if (!a.kmap && !no_fuse && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= D::GF) {
-          ASSET_LAUNCH_K((lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 3, false>), grid_b, 64, bytes_dense);
-          return hipSuccess;
-        }
+        if (!a.kmap && !no_fuse && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]))
+          return klaunch(t.k[K_LGL(2, 3, false)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);
       }
-      if constexpr (Ode::NUNITS > 1) {
+      static const bool no_units = std::getenv("ASSET_HIP_NO_UNITS") != nullptr;                               // tuning only
+      if (m[MF_NUNITS] > 1 && !no_units) {
         // heavy right-hand side: the ODE stage runs one wave per output unit (defect_units.h)
-        static const bool no_units = std::getenv("ASSET_HIP_NO_UNITS") != nullptr;                             // tuning only
-        if (!no_units) {
-          constexpr int GPMAX = 64 / D::CS;
-          // about one workgroup per SIMD: groups x units ~ 4 per CU
-          int gp = (a.nseg * Ode::NUNITS + 4 * cus - 1) / (4 * cus);
-          gp = gp < 1 ? 1 : (gp > GPMAX ? GPMAX : gp);
-          const size_t bytes_units = UnitsDims<D>::lds_bytes(gp);
-          const dim3 grid((a.nseg + gp - 1) / gp, Ode::NUNITS);
-          hipLaunchKernelGGL((lgl_ode_units_kernel<Ode, SCH, BLOCKED, 0>), grid, dim3(64), bytes_units, st, a, gp);
-          hipLaunchKernelGGL((lgl_ode_units_kernel<Ode, SCH, BLOCKED, 1>), grid, dim3(64), bytes_units, st, a, gp);
-          hipError_t e2 = hipGetLastError();
-          if (e2 != hipSuccess) return e2;
-        } else {
-          ASSET_LAUNCH(2, 1, grid_a, bytes_ode);
-        }
-      } else {
-        ASSET_LAUNCH(2, 1, grid_a, bytes_ode);
+        const int nunits = int(m[MF_NUNITS]), gpmax = 64 / int(m[MF_CS]);
+        // about one workgroup per SIMD: groups x units ~ 4 per CU
+        int gp = (a.nseg * nunits + 4 * cus - 1) / (4 * cus);
+        gp = gp < 1 ? 1 : (gp > gpmax ? gpmax : gp);
+        const size_t bytes_units = size_t(m[MF_UNITS_BASE_BYTES]) + size_t(gp) * size_t(m[MF_UNITS_SLOT_BYTES]);
+        const dim3 grid((a.nseg + gp - 1) / gp, nunits);
+        void* uargs[] = {&args, &gp};
+        if ((e = klaunch(t.k[K_UNITS0], grid, dim3(64), bytes_units, st, uargs)) != hipSuccess) return e;
+        if ((e = klaunch(t.k[K_UNITS1], grid, dim3(64), bytes_units, st, uargs)) != hipSuccess) return e;
+      } else if ((e = ode_stage(2)) != hipSuccess) {
+        return e;
       }
       if (skip_dense) return hipSuccess;
-      if (a.kmap) ASSET_LAUNCH_DENSE(2, true);
-      else ASSET_LAUNCH_DENSE(2, false);
-      return hipSuccess;
+      return dense_stage(2);
+    }
   }
-#undef ASSET_LAUNCH
-#undef ASSET_LAUNCH_DENSE
-#undef ASSET_LAUNCH_K
   return hipErrorInvalidValue;
 }
 
 // A plain function batched over applications: transcription id 0 (func_kernels.h)
-#define ASSET_REGISTER_FUNC(FN)                                                                                   \
-  static ::asset_hip::KernelEntry entry_##FN##_func = {                                                           \
-      FN::name(), FN::XV, FN::UV, FN::PV, 0, 0,                                                                   \
-      ::asset_hip::FuncDims<FN>::IR, ::asset_hip::FuncDims<FN>::OR, ::asset_hip::FuncDims<FN>::NKKT, 0, 0, 0,    \
-      &::asset_hip::launch_func<FN>, nullptr, nullptr, nullptr, nullptr, FN::NACONST};                            \
-  static ::asset_hip::Registrar reg_##FN##_func(&entry_##FN##_func);
+inline hipError_t launch_func_table(const KernelTable& t, int level, const EvalArgs& a, hipStream_t st) {
+  if (level < 0 || level > 2) return hipErrorInvalidValue;
+  EvalArgs args = a;
+  void* kargs[] = {&args};
+  const bool asmb = level >= 1 && a.kmap != nullptr;
+  return klaunch(t.k[K_FUNC(level, asmb)], dim3((a.nseg + 63) / 64), dim3(64), 0, st, kargs);
+}
 
-template <class Ode, int SCH, bool BLOCKED>
-size_t lgl_lane_bytes(int level) {
+inline hipError_t entry_launch(const KernelEntry* ke, int level, const EvalArgs& a, int cus, hipStream_t st) {
+  return ke->table->meta[MF_KIND] == 2 ? launch_func_table(*ke->table, level, a, st) : launch_lgl_table(*ke->table, level, a, cus, st);
+}
+
+// de Boor mesh-error estimate (mesh_kernels.h); only transcriptions of an ODE have it
+inline bool entry_has_mesh(const KernelEntry* ke) { return bool(ke->table->k[K_MESH_YVEC]); }
+inline hipError_t entry_mesh(const KernelEntry* ke, const MeshArgs& a, hipStream_t st) {
+  const MeshScheme sc = mesh_scheme(ke->mode);
+  MeshArgs args = a;
+  const int grid = (a.nb + 63) / 64;
+  void* yargs[] = {&args};
+  hipError_t e = klaunch(ke->table->k[K_MESH_YVEC], dim3(grid), dim3(64), 0, st, yargs);
+  if (e != hipSuccess) return e;
+  int xv = ke->xv;
+  double order = sc.order, weight = sc.error_weight;
+  void* eargs[] = {&args, &xv, &order, &weight};
+  return klaunch(ke->table->k[K_MESH_ERROR], dim3(grid), dim3(64), 0, st, eargs);
+}
+
+// per-lane constants of the dense stage for derivative level 1 / 2: table size in bytes (0: none) and the kernel filling it
+inline size_t entry_lane_bytes(const KernelEntry* ke, int level) {
+  return level >= 2 ? size_t(ke->table->meta[MF_LANE_BYTES2]) : (level == 1 ? size_t(ke->table->meta[MF_LANE_BYTES1]) : 0);
+}
+inline hipError_t entry_lane_setup(const KernelEntry* ke, int level, void* out, hipStream_t st) {
+  void* kargs[] = {&out};
+  const KernelTable& t = *ke->table;
+  return klaunch(t.meta[MF_WIDE] ? t.k[K_WIDE_SETUP] : (level >= 2 ? t.k[K_LANE_SETUP2] : t.k[K_LANE_SETUP1]), dim3(1), dim3(64), 0, st, kargs);
+}
+
+// ---- tables of the kernels linked into this translation unit ---------------------------------------------------------
+#define ASSET_KPTR(...) reinterpret_cast<const void*>(&__VA_ARGS__)
+template <class Ode, int SCH, bool BLOCKED, int G>
+const KernelTable* lgl_static_table() {
   using D = Dims<Ode, SCH, BLOCKED>;
-  // bytes of the whole table: 64 word-interleaved records (defect_kernels.h: lane_setup_kernel)
-  if constexpr (D::WIDE) return level >= 1 ? size_t(D::TJ) * D::TI * 4 * 64 * sizeof(unsigned int) : 0;   // defect_wide.h: wide_setup_kernel
-  else return level >= 2 ? sizeof(LaneConsts<Ode, D, 2>) * 64 : (level == 1 ? sizeof(LaneConsts<Ode, D, 1>) * 64 : 0);
+  static KernelTable t = [] {
+    KernelTable r;
+    for (int i = 0; i < MF_COUNT; i++) r.meta[i] = LglMeta<Ode, SCH, BLOCKED, G>::v[i];
+    r.k[K_LGL(0, 1, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 0, 1, false>);
+    r.k[K_LGL(1, 1, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 1, 1, false>);
+    r.k[K_LGL(2, 1, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 1, false>);
+    if constexpr (D::WIDE) {
+      r.k[K_WIDE(1, false)].host = ASSET_KPTR(lgl_wide_dense_kernel<Ode, SCH, BLOCKED, 1, false>);
+      r.k[K_WIDE(1, true)].host = ASSET_KPTR(lgl_wide_dense_kernel<Ode, SCH, BLOCKED, 1, true>);
+      r.k[K_WIDE(2, false)].host = ASSET_KPTR(lgl_wide_dense_kernel<Ode, SCH, BLOCKED, 2, false>);
+      r.k[K_WIDE(2, true)].host = ASSET_KPTR(lgl_wide_dense_kernel<Ode, SCH, BLOCKED, 2, true>);
+      r.k[K_WIDE_SETUP].host = ASSET_KPTR(wide_setup_kernel<Ode, SCH, BLOCKED>);
+    } else {
+      r.k[K_LGL(1, 2, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 1, 2, false>);
+      r.k[K_LGL(1, 2, true)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 1, 2, true>);
+      r.k[K_LGL(2, 2, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 2, false>);
+      r.k[K_LGL(2, 2, true)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 2, true>);
+      r.k[K_LANE_SETUP1].host = ASSET_KPTR(lane_setup_kernel<Ode, SCH, BLOCKED, 1>);
+      r.k[K_LANE_SETUP2].host = ASSET_KPTR(lane_setup_kernel<Ode, SCH, BLOCKED, 2>);
+      if constexpr (D::FUSED) r.k[K_LGL(2, 3, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 3, false>);
+      if constexpr (D::FUSED2) r.k[K_LGL(2, 4, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 4, false>);
+    }
+    if constexpr (Ode::NUNITS > 1) {
+      r.k[K_UNITS0].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 0>);
+      r.k[K_UNITS1].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 1>);
+    }
+    r.k[K_MESH_YVEC].host = ASSET_KPTR(mesh_yvec_kernel<Ode, SCH, BLOCKED>);
+    r.k[K_MESH_ERROR].host = ASSET_KPTR(mesh_error_kernel<0>);
+    return r;
+  }();
+  return &t;
 }
-template <class Ode, int SCH, bool BLOCKED>
-hipError_t lgl_lane_setup(int level, void* out, hipStream_t st) {
-  if constexpr (Dims<Ode, SCH, BLOCKED>::WIDE) {
-    hipLaunchKernelGGL((wide_setup_kernel<Ode, SCH, BLOCKED>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));
-    return hipGetLastError();
-  } else if (level >= 2)
-    hipLaunchKernelGGL((lane_setup_kernel<Ode, SCH, BLOCKED, 2>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));
-  else
-    hipLaunchKernelGGL((lane_setup_kernel<Ode, SCH, BLOCKED, 1>), dim3(1), dim3(64), 0, st, static_cast<unsigned int*>(out));
-  return hipGetLastError();
+template <class F>
+const KernelTable* func_static_table() {
+  static KernelTable t = [] {
+    KernelTable r;
+    for (int i = 0; i < MF_COUNT; i++) r.meta[i] = FuncMeta<F>::v[i];
+    r.k[K_FUNC(0, false)].host = ASSET_KPTR(func_kernel<F, 0, false>);
+    r.k[K_FUNC(1, false)].host = ASSET_KPTR(func_kernel<F, 1, false>);
+    r.k[K_FUNC(1, true)].host = ASSET_KPTR(func_kernel<F, 1, true>);
+    r.k[K_FUNC(2, false)].host = ASSET_KPTR(func_kernel<F, 2, false>);
+    r.k[K_FUNC(2, true)].host = ASSET_KPTR(func_kernel<F, 2, true>);
+    return r;
+  }();
+  return &t;
 }
+#undef ASSET_KPTR
+
+struct StaticEntry {   // (static initialisation: the table is filled and the entry registered before main)
+  KernelEntry e;
+  Registrar* reg;
+  StaticEntry(const char* name, const KernelTable* t) {
+    entry_from_table(e, name, t);
+    reg = new Registrar(&e);
+  }
+};
+
+#define ASSET_REGISTER_FUNC(FN) \
+  static ::asset_hip::StaticEntry entry_##FN##_func(FN::name(), ::asset_hip::func_static_table<FN>());
 
 // Trapezoidal = transcription id 1 of the same kernels (defect_dims.h: Dims::TRAP)
 #define ASSET_REGISTER_TRAP(ODE, BLK, G) ASSET_REGISTER_LGL(ODE, 1, BLK, G)
 
-#define ASSET_REGISTER_LGL(ODE, CSV, BLK, G)                                                                      \
-  static ::asset_hip::KernelEntry entry_##ODE##_##CSV##_##BLK = {                                                 \
-      ODE::name(), ODE::XV, ODE::UV, ODE::PV, CSV, BLK,                                                           \
-      ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::IR, ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::OR,                   \
-      ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::NKKT, G,                                                           \
-      ::asset_hip::Dims<ODE, CSV, (BLK != 0)>::lds_bytes(),                                                       \
-      size_t(::asset_hip::Dims<ODE, CSV, (BLK != 0)>::WSLOT),                                                      \
-      &::asset_hip::launch_lgl<ODE, CSV, (BLK != 0), G>, nullptr,        \
-      &::asset_hip::launch_mesh<ODE, CSV, (BLK != 0)>, &::asset_hip::lgl_lane_bytes<ODE, CSV, (BLK != 0)>,         \
-      &::asset_hip::lgl_lane_setup<ODE, CSV, (BLK != 0)>};                                                         \
-  static ::asset_hip::Registrar reg_##ODE##_##CSV##_##BLK(&entry_##ODE##_##CSV##_##BLK);
+#define ASSET_REGISTER_LGL(ODE, CSV, BLK, G) \
+  static ::asset_hip::StaticEntry entry_##ODE##_##CSV##_##BLK(ODE::name(), ::asset_hip::lgl_static_table<ODE, CSV, (BLK != 0), G>());
+
+// ---- name expressions of the kernels of a run-time module (capi.hip: asset_hip_jit_plugin) -----------------------------
+// kind 1: `type` is the ODE functor, kind 2: the function functor.  Slots without a kernel for that kind: empty string.
+inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, int csv, bool blocked, int g) {
+  const std::string b = blocked ? "true" : "false";
+  const std::string lgl = type + ", " + std::to_string(csv) + ", " + b;
+  auto tf = [](bool v) { return std::string(v ? "true" : "false"); };
+  if (kind == 2) {
+    for (int lv = 0; lv <= 2; lv++)
+      for (int as = 0; as <= (lv >= 1 ? 1 : 0); as++)
+        if (slot == K_FUNC(lv, as != 0)) return "asset_hip::func_kernel<" + type + ", " + std::to_string(lv) + ", " + tf(as != 0) + ">";
+    return "";
+  }
+  for (int lv = 0; lv <= 2; lv++)
+    for (int stg = 1; stg <= 4; stg++)
+      for (int as = 0; as <= 1; as++) {
+        if (slot != K_LGL(lv, stg, as != 0)) continue;
+        const bool used = (stg == 1 && !as) || (stg == 2 && lv >= 1) || (stg >= 3 && lv == 2 && !as);
+        if (!used) return "";
+        return "asset_hip::lgl_defect_kernel<" + lgl + ", " + std::to_string(g) + ", " + std::to_string(lv) + ", " +
+               std::to_string(stg) + ", " + tf(as != 0) + ">";
+      }
+  for (int lv = 1; lv <= 2; lv++)
+    for (int as = 0; as <= 1; as++)
+      if (slot == K_WIDE(lv, as != 0)) return "asset_hip::lgl_wide_dense_kernel<" + lgl + ", " + std::to_string(lv) + ", " + tf(as != 0) + ">";
+  if (slot == K_WIDE_SETUP) return "asset_hip::wide_setup_kernel<" + lgl + ">";
+  if (slot == K_LANE_SETUP1) return "asset_hip::lane_setup_kernel<" + lgl + ", 1>";
+  if (slot == K_LANE_SETUP2) return "asset_hip::lane_setup_kernel<" + lgl + ", 2>";
+  if (slot == K_UNITS0) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 0>";
+  if (slot == K_UNITS1) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 1>";
+  if (slot == K_MESH_YVEC) return "asset_hip::mesh_yvec_kernel<" + lgl + ">";
+  if (slot == K_MESH_ERROR) return "asset_hip::mesh_error_kernel<0>";
+  return "";
+}
 
 }  // namespace asset_hip

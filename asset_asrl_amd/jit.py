@@ -1,13 +1,15 @@
-"""Run-time device code for user-defined ODEs.
+"""Run-time device code for user-defined ODEs and functions.
 
 The reference takes any VectorFunction as ODE right-hand side (``oc.ode_x_u_p.ode(vf, Xv, Uv, Pv)``,
 /root/reference/src/OptimalControl/ODE.h:128-187, pybind/OptimalControl/GenericODESBuildPart1-6.cpp) and walks its
 expression tree at every evaluation.  Here the expression graph of an :class:`~asset_asrl_amd.ode.ODEBase` is
 differentiated symbolically, printed as a HIP functor (``vf/codegen.py``) and compiled for gfx950 together with the
-defect kernels of the requested transcription -- one small shared object per (ODE, mode, control mode), built with
-``hipcc`` on first use, cached in-tree next to the other generated sources, and handed to the library through
-``asset_hip_load_plugin`` (include/asset_hip.h).  There is no interpreter and no CPU fallback: without ``hipcc`` the
-call fails.
+defect kernels of the requested transcription -- one module per (ODE, mode, control mode), compiled IN PROCESS with
+hiprtc on first use (``asset_hip_jit_plugin``, include/asset_hip.h: the library calls the compiler library itself, no
+compiler driver is started), cached in-tree next to the other generated sources as the code object plus the lowered
+kernel names.  ``ASSET_HIP_JIT=hipcc`` selects the older route instead (a shared object built by the ``hipcc`` driver,
+``asset_hip_load_plugin``); it is a switch for debugging, not a fallback: whichever route is selected, a failure raises.
+There is no interpreter and no CPU fallback.
 """
 from __future__ import annotations
 
@@ -23,6 +25,14 @@ from .vf.codegen import emit_hip_functor, saved_nodes
 JIT_DIR = os.path.join(build.GEN, "jit")
 _MODE_CS = {"LGL3": 2, "LGL5": 3, "LGL7": 4}
 _loaded: set = set()
+# The build step (__graft_entry__.build) runs where there is no device: it compiles and caches the modules the test suite
+# will ask for and registers nothing.  Set through compile_only_mode().
+_COMPILE_ONLY = False
+
+
+def compile_only_mode(on: bool = True):
+    global _COMPILE_ONLY
+    _COMPILE_ONLY = bool(on)
 
 
 def _ident(s: str) -> str:
@@ -44,8 +54,9 @@ def device_name(ode) -> str:
     return ode._device_name
 
 
-def ensure_kernel(ode, mode: str, blocked: bool) -> str:
-    """Make sure device code for (ode, mode, blocked) is registered; returns the device-side ODE name."""
+def ensure_kernel(ode, mode: str, blocked: bool, compile_only=None) -> str:
+    """Make sure device code for (ode, mode, blocked) is registered; returns the device-side ODE name.
+    compile_only: compile and cache without registering (the build step on a machine without a device)."""
     name = device_name(ode)
     blocked = bool(blocked) and ode.UVars() > 0
     mode_id = _lib.MODES[mode]
@@ -73,45 +84,96 @@ def ensure_kernel(ode, mode: str, blocked: bool) -> str:
     hdr = ("#pragma once\n#include <math.h>\n#include \"" + os.path.join(build.CSRC, "asset_math.h") + "\"\n"
            + emit_hip_functor(d, sname))
     tag = f"{mode.lower()}_{int(blocked)}"
-    src = (f'#include "ode.h"\n#include "{os.path.join(build.CSRC, "registry.h")}"\n'
-           + reg.replace("{S}", sname) + "\nASSET_PLUGIN_EXPORT()\n")
-    return _build_and_load(name, "ode.h", hdr, tag, src, mode_id, blocked, f"user ODE '{ode.ode_name}'")
+    cs_id = 1 if mode == "Trapezoidal" else _MODE_CS[mode]
+    return _build_and_load(name, "ode.h", hdr, tag, reg.replace("{S}", sname), mode_id, blocked,
+                           f"user ODE '{ode.ode_name}'", rtc=(sname, 1, cs_id, G, f"ASSET_RTC_LGL({sname}, {cs_id}, {int(blocked)}, {G})"),
+                           compile_only=compile_only)
 
 
-def _build_and_load(name, hdr_name, hdr, tag, src, mode_id, blocked, what) -> str:
-    """Compile one plugin translation unit (cached by content) and register it; returns ``name``."""
+def jit_route() -> str:
+    r = os.environ.get("ASSET_HIP_JIT", "hiprtc")
+    if r not in ("hiprtc", "hipcc"):
+        raise _lib.AssetHipError(f"ASSET_HIP_JIT={r!r}: expected 'hiprtc' or 'hipcc'")
+    return r
+
+
+def rtc_options():
+    """hiprtc options: the flags of the static build plus where the compiler library finds its own headers (it has the HIP
+    device headers built in, but neither the resource directory of its clang nor <hip/hip_runtime.h> as a file)."""
+    import glob
+    rocm = os.path.dirname(os.path.dirname(os.path.realpath(build.HIPCC)))
+    res = sorted(glob.glob(os.path.join(rocm, "lib", "llvm", "lib", "clang", "*", "include")))
+    opts = [f for f in build.FLAGS if f != "-fPIC"] + ["-Wno-cuda-compat", "-Wno-pragma-once-outside-header"]
+    opts += ["-I" + res[-1]] if res else []
+    opts += ["-I" + os.path.join(rocm, "include")]
+    return opts
+
+
+def _build_and_load(name, hdr_name, hdr, tag, reg_line, mode_id, blocked, what, rtc, compile_only=None) -> str:
+    """Compile one generated translation unit (cached by content) and register it; returns ``name``.
+    rtc = (functor, kind, mode id, segments per group, the ASSET_RTC_* line)."""
+    if compile_only is None:
+        compile_only = _COMPILE_ONLY
     deps = [os.path.join(build.CSRC, f) for f in sorted(os.listdir(build.CSRC)) if f.endswith(".h")]
-    key = hashlib.sha256((hdr + src + " ".join(build.FLAGS)).encode()
-                         + b"".join(open(p, "rb").read() for p in deps)).hexdigest()[:16]
+    route = jit_route()
     wd = os.path.join(JIT_DIR, name)
     os.makedirs(wd, exist_ok=True)
-    so = os.path.join(wd, f"plugin_{tag}_{key}.so")
-    if not os.path.exists(so):
-        build._write_if_changed(os.path.join(wd, hdr_name), hdr)
-        tu = os.path.join(wd, f"tu_{tag}.hip")
-        build._write_if_changed(tu, src)
-        if not os.path.exists(build.HIPCC):
-            raise _lib.AssetHipError(f"{build.HIPCC} not found: {what} needs the HIP compiler at run time")
-        cmd = [build.HIPCC] + build.FLAGS + ["-DASSET_PLUGIN", "-shared", "-I", os.path.join(build.HERE, "..", "include"),
-                                             tu, "-o", so + ".tmp"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise _lib.AssetHipError(f"hipcc failed for {what}:\n{r.stderr[-3000:]}")
-        os.replace(so + ".tmp", so)
-        for f in os.listdir(wd):            # plugins of this unit built against older sources
-            if f.startswith(f"plugin_{tag}_") and f.endswith(".so") and os.path.join(wd, f) != so:
+
+    def key_of(src, flags):
+        return hashlib.sha256((hdr + src + " ".join(flags)).encode()
+                              + b"".join(open(p, "rb").read() for p in deps)).hexdigest()[:16]
+
+    def drop_older(prefix, suffix, keep):
+        for f in os.listdir(wd):            # builds of this unit against older sources
+            if f.startswith(prefix) and f.endswith(suffix) and os.path.join(wd, f) != keep:
                 os.remove(os.path.join(wd, f))
-    if so not in _loaded:
-        rc = _lib.lib().asset_hip_load_plugin(so.encode())
-        if rc < 0:
-            _lib.check(rc, "asset_hip_load_plugin")
-        _loaded.add(so)
+
+    if route == "hiprtc":
+        functor, kind, cs_id, G, rtc_line = rtc
+        opts = rtc_options()
+        src = hdr + f'\n#include "{os.path.join(build.CSRC, "rtc_device.h")}"\n{rtc_line}\n'
+        mod = os.path.join(wd, f"module_{tag}_{key_of(src, opts)}.rtc")
+        copts = (C.c_char_p * len(opts))(*[o.encode() for o in opts])
+        args = (src.encode(), functor.encode(), kind, cs_id, int(blocked), G, copts, len(opts), mod.encode())
+        if compile_only:                    # (the build step, which has no device: compile and cache)
+            if not os.path.exists(mod):
+                _lib.check(_lib.lib().asset_hip_jit_compile(*args), f"asset_hip_jit_compile ({what})")
+                drop_older(f"module_{tag}_", ".rtc", mod)
+            return name
+        fresh = not os.path.exists(mod)
+        _lib.check(_lib.lib().asset_hip_jit_plugin(name.encode(), *args), f"asset_hip_jit_plugin ({what})")
+        if fresh:
+            drop_older(f"module_{tag}_", ".rtc", mod)
+    else:
+        src = (f'#include "{hdr_name}"\n#include "{os.path.join(build.CSRC, "registry.h")}"\n' + reg_line
+               + "\nASSET_PLUGIN_EXPORT()\n")
+        so = os.path.join(wd, f"plugin_{tag}_{key_of(src, build.FLAGS)}.so")
+        if not os.path.exists(so):
+            build._write_if_changed(os.path.join(wd, hdr_name), hdr)
+            tu = os.path.join(wd, f"tu_{tag}.hip")
+            build._write_if_changed(tu, src)
+            if not os.path.exists(build.HIPCC):
+                raise _lib.AssetHipError(f"{build.HIPCC} not found: {what} needs the HIP compiler driver (ASSET_HIP_JIT=hipcc)")
+            cmd = [build.HIPCC] + build.FLAGS + ["-DASSET_PLUGIN", "-shared", "-I", os.path.join(build.HERE, "..", "include"),
+                                                 tu, "-o", so + ".tmp"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise _lib.AssetHipError(f"hipcc failed for {what}:\n{r.stderr[-3000:]}")
+            os.replace(so + ".tmp", so)
+            drop_older(f"plugin_{tag}_", ".so", so)
+        if compile_only:
+            return name
+        if so not in _loaded:
+            rc = _lib.lib().asset_hip_load_plugin(so.encode())
+            if rc < 0:
+                _lib.check(rc, "asset_hip_load_plugin")
+            _loaded.add(so)
     if not _lib.has_kernel(name, mode_id, blocked):
-        raise _lib.AssetHipError(f"plugin {so} did not register ({name}, mode {mode_id}, blocked={blocked})")
+        raise _lib.AssetHipError(f"{what}: the compiled module did not register ({name}, mode {mode_id}, blocked={blocked})")
     return name
 
 
-def ensure_function(func, name: str) -> str:
+def ensure_function(func, name: str, compile_only=None) -> str:
     """Device code for a plain vector function batched over applications (transcription id 0, csrc/func_kernels.h):
     ``DefectEvaluator(ensure_function(f, "my_con"), "Function", False, vindex, cindex, ...)`` then evaluates it like a
     defect -- FX / AGX blocks and the KKT block (Jacobian + lower-triangle adjoint Hessian) of every application."""
@@ -126,6 +188,5 @@ def ensure_function(func, name: str) -> str:
     sname = "Fn_" + _ident(dev)
     hdr = ("#pragma once\n#include <math.h>\n#include \"" + os.path.join(build.CSRC, "asset_math.h") + "\"\n"
            + emit_hip_functor(d, sname))
-    src = (f'#include "fn.h"\n#include "{os.path.join(build.CSRC, "registry.h")}"\n'
-           f"ASSET_REGISTER_FUNC({sname})\nASSET_PLUGIN_EXPORT()\n")
-    return _build_and_load(dev, "fn.h", hdr, "function_0", src, _lib.FUNCTION, False, f"function '{name}'")
+    return _build_and_load(dev, "fn.h", hdr, "function_0", f"ASSET_REGISTER_FUNC({sname})", _lib.FUNCTION, False,
+                           f"function '{name}'", rtc=(sname, 2, 0, 0, f"ASSET_RTC_FUNC({sname})"), compile_only=compile_only)

@@ -57,7 +57,8 @@ enum {
   ASSET_HIP_EINVAL = -1,      /* bad argument / null pointer / size mismatch          */
   ASSET_HIP_ENOODE = -2,      /* no device code for this (ode, mode, blocked) triple  */
   ASSET_HIP_ENODEV = -3,      /* no usable HIP device                                  */
-  ASSET_HIP_ERANGE = -4       /* an index in vindex/cindex is outside [0,n)            */
+  ASSET_HIP_ERANGE = -4,      /* an index in vindex/cindex is outside [0,n)            */
+  ASSET_HIP_ECOMPILE = -5     /* run-time compilation failed (asset_hip_last_error holds the compiler's log) */
 };
 
 typedef struct asset_hip_defect* asset_hip_defect_t;
@@ -179,6 +180,20 @@ int asset_hip_has_kernel(const char* ode, int mode, int blocked);
  * GenericODESBuildPart1-6.cpp); here its expression graph is differentiated, printed as a device functor and
  * compiled for gfx950 on first use.  Returns the number of kernels added (>= 0) or a negative ASSET_HIP_E* code. */
 int asset_hip_load_plugin(const char* path);
+/* The same, compiled in process (hiprtc) instead of by the compiler driver.  `source` is the generated translation unit:
+ * the functor, `#include "<csrc>/rtc_device.h"` and one ASSET_RTC_LGL(functor, mode, blocked, seg_per_group) or
+ * ASSET_RTC_FUNC(functor) line; kind 1 = transcription of an ODE, 2 = plain function (mode, blocked, seg_per_group
+ * ignored); options = hiprtc options ("--offload-arch=gfx950", "-I...", ...).
+ *   asset_hip_jit_compile  compiles and writes the code object and the lowered kernel names to cache_path; needs no device.
+ *   asset_hip_jit_plugin   registers the module under `name` on the current device: from cache_path when that file
+ *                          exists, else by compiling `source` (and writing cache_path when it is not NULL).  0 when
+ *                          (name, mode, blocked) is registered afterwards (also when it was already), otherwise an error
+ *                          code -- ASSET_HIP_ECOMPILE with the compiler's log in asset_hip_last_error(), a hipError_t
+ *                          when the module cannot be loaded (no device); there is no fallback. */
+int asset_hip_jit_compile(const char* source, const char* functor, int kind, int mode, int blocked, int seg_per_group,
+                          const char* const* options, int noptions, const char* cache_path);
+int asset_hip_jit_plugin(const char* name, const char* source, const char* functor, int kind, int mode, int blocked,
+                         int seg_per_group, const char* const* options, int noptions, const char* cache_path);
 /* collocation weight tables: which in {"tc","s","A","B","U","C","D","E"}; out receives cs or (cs-1) or
  * (cs-1)*cs doubles (row = interior point).  Returns the count written or <0. */
 int asset_hip_lgl_table(int cs, const char* which, double* out, int cap);

@@ -100,7 +100,7 @@ def test_cold_run_time_compilation_of_a_never_seen_ode(oracle):
     """The run-time compiler itself, cold, on the GPU box: an ODE whose generated code no cache can hold -- the forced
     Van der Pol oscillator with exp(-t/10) written as exp(-(1/10 + c) t) * exp(c t), c drawn from os.urandom for this test
     run (the same real function to rounding, a different expression graph, hence a different content hash) -- goes through
-    code generation, hipcc, plugin load and registration here, and its blocks match the oracle's Van der Pol."""
+    code generation, in-process compilation (hiprtc), module load and registration here, and its blocks match the oracle's Van der Pol."""
     import os
     import shutil
     from asset_asrl_amd import vf
@@ -115,12 +115,15 @@ def test_cold_run_time_compilation_of_a_never_seen_ode(oracle):
     wd = os.path.join(jit.JIT_DIR, name)
     assert not os.path.exists(wd), "the salted ODE must not be in the plugin cache"
     try:
+        os.environ.pop("ASSET_HIP_JIT", None)                            # the default route: hiprtc, inside this process
         assert jit.ensure_kernel(ode, "LGL5", False) == name             # compiles here, now
-        assert any(f.startswith("plugin_lgl5_0_") and f.endswith(".so") for f in os.listdir(wd))
+        made = os.listdir(wd)
+        assert any(f.startswith("module_lgl5_0_") and f.endswith(".rtc") for f in made)
+        assert not any(f.endswith(".so") or f.endswith(".hip") for f in made)   # no compiler driver, no host code
         w = Workload("vanderpol", "LGL5", 21, False, sizes=SIZES)
         nlp = oracle.Nlp(oracle.get_ode("vanderpol", 0), oracle.MODES["LGL5"], False, w.vindex, w.cindex, w.n_primal, w.n_equal, 2)
         ev = DefectEvaluator(name, "LGL5", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
         _check_blocks(ev.eval(JAC_ADJGRAD_HESS, w.X, w.L), nlp.eval_blocks(JAC_ADJGRAD_HESS, w.X, w.L), w, JAC_ADJGRAD_HESS)
         ev.close()
     finally:
-        shutil.rmtree(wd, ignore_errors=True)                             # (the plugin stays loaded; its files need not stay)
+        shutil.rmtree(wd, ignore_errors=True)                             # (the module stays loaded; its files need not stay)

@@ -1,5 +1,10 @@
-"""Run-time compilation of a user-defined ODE (asset_asrl_amd/jit.py): code generation, hipcc cross-compile for
-gfx950 and plugin registration all work without a GPU; the numerical check lives in test_gpu_jit.py."""
+"""Run-time compilation of a user-defined ODE (asset_asrl_amd/jit.py): code generation and compilation for gfx950 work
+without a GPU -- in process through hiprtc (the default route: compile and cache; loading the module needs a device, so
+registration is checked in test_gpu_jit.py), and through the hipcc driver (ASSET_HIP_JIT=hipcc: a shared object, which
+registers on a CPU box too).  The numerical checks live in test_gpu_jit.py."""
+import glob
+import os
+
 import pytest
 
 from asset_asrl_amd import _lib, jit, vf
@@ -7,10 +12,39 @@ from asset_asrl_amd.ode import ODEArguments, ODEBase, ShuttleReentry
 from helpers import make_vanderpol
 
 
-def test_user_ode_gets_device_code_on_first_use():
+def test_user_ode_is_compiled_in_process_and_cached(monkeypatch):
+    monkeypatch.delenv("ASSET_HIP_JIT", raising=False)
     ode = make_vanderpol()
     name = jit.device_name(ode)
     assert name.startswith("vanderpol_") and name not in ("vanderpol",)
+    assert jit.ensure_kernel(ode, "LGL5", False, compile_only=True) == name
+    mods = glob.glob(os.path.join(jit.JIT_DIR, name, "module_lgl5_0_*.rtc"))
+    assert len(mods) == 1                                            # one cache file per (ODE, mode, control mode), keyed by content
+    head = open(mods[0], "rb").read(4096).split(b"\n")
+    assert head[0] == b"ASSET-HIP-RTC-1" and int(head[1]) >= 10      # code object + the lowered names of the kernel slots
+    assert any(b"lgl_defect_kernel" in ln and name.encode() in ln for ln in head[2:2 + int(head[1])])
+    stamp = os.path.getmtime(mods[0])
+    assert jit.ensure_kernel(make_vanderpol(), "LGL5", False, compile_only=True) == name   # same maths -> same name,
+    assert os.path.getmtime(mods[0]) == stamp                                                # nothing rebuilt
+    if not os.path.exists("/dev/kfd"):                               # no device: loading the module must fail loudly
+        with pytest.raises(_lib.AssetHipError):
+            jit.ensure_kernel(ode, "LGL5", False)
+
+
+def test_compile_errors_come_back_with_the_compilers_log(monkeypatch, tmp_path):
+    import ctypes as C
+    opts = jit.rtc_options()
+    copts = (C.c_char_p * len(opts))(*[o.encode() for o in opts])
+    rc = _lib.lib().asset_hip_jit_compile(b"struct Broken { int x }\n", b"Broken", 2, 0, 0, 0, copts, len(opts),
+                                          str(tmp_path / "broken.rtc").encode())
+    assert rc == -5 and b"error" in _lib.lib().asset_hip_last_error()
+    assert not (tmp_path / "broken.rtc").exists()
+
+
+def test_user_ode_through_the_compiler_driver_registers(monkeypatch):
+    monkeypatch.setenv("ASSET_HIP_JIT", "hipcc")
+    ode = make_vanderpol()
+    name = jit.device_name(ode)
     assert jit.ensure_kernel(ode, "LGL5", False) == name          # compiles (or finds the cached plugin) and registers
     assert _lib.has_kernel(name, _lib.LGL5, False)
     assert not _lib.has_kernel(name, _lib.LGL7, False)              # only what was asked for
@@ -38,10 +72,15 @@ def test_load_plugin_rejects_a_non_plugin():
     assert rc < 0 and b"asset_hip_plugin_entries" in _lib.lib().asset_hip_last_error()
 
 
-def test_plain_function_gets_device_code():
+def test_plain_function_gets_device_code(monkeypatch):
     """Transcription id 0: any DSL vector function batched over applications (csrc/func_kernels.h)."""
     from asset_asrl_amd.pathfuncs import LGLMeshSpacing, SingleMeshSpacing
+    monkeypatch.delenv("ASSET_HIP_JIT", raising=False)
+    dev = jit.ensure_function(LGLMeshSpacing(3), "lglmeshspacing3", compile_only=True)      # in process, cached
+    assert glob.glob(os.path.join(jit.JIT_DIR, dev, "module_function_0_*.rtc"))
+    monkeypatch.setenv("ASSET_HIP_JIT", "hipcc")                                             # driver route: registers here
     name = jit.ensure_function(LGLMeshSpacing(3), "lglmeshspacing3")
+    assert name == dev
     assert _lib.has_kernel(name, _lib.FUNCTION, False) and not _lib.has_kernel(name, _lib.LGL3, False)
     assert jit.ensure_function(LGLMeshSpacing(3), "lglmeshspacing3") == name
     assert jit.ensure_function(SingleMeshSpacing(0.25), "single_spacing") != name
@@ -49,7 +88,8 @@ def test_plain_function_gets_device_code():
         LGLMeshSpacing(2)
 
 
-def test_lgl_integral_quadrature_is_exact_for_cubics():
+def test_lgl_integral_quadrature_is_exact_for_cubics(monkeypatch):
+    monkeypatch.delenv("ASSET_HIP_JIT", raising=False)
     """LGLIntegral (LGLIntegrals.h:9-52): h * sum_i w_i integrand(x_i); the LGL7 reduced weights integrate
     t^2 + t^3 exactly.  Its device code is generated like any other function's."""
     import numpy as np
@@ -64,8 +104,8 @@ def test_lgl_integral_quadrature_is_exact_for_cubics():
         z += [t ** 3, t, t]
     prim = lambda t: t ** 3 / 3 + t ** 4 / 4
     assert abs(F.compute(np.array(z))[0] - (prim(t0 + h) - prim(t0))) < 1e-12
-    name = jit.ensure_function(F, "lglintegral_test")
-    assert _lib.has_kernel(name, _lib.FUNCTION, False) and _lib.ode_sizes(name)[0] == 1
+    name = jit.ensure_function(F, "lglintegral_test", compile_only=True)     # (registration: test_gpu_function.py)
+    assert glob.glob(os.path.join(jit.JIT_DIR, name, "module_function_0_*.rtc"))
 
 
 def test_control_spline_vanishes_on_a_smooth_control():
