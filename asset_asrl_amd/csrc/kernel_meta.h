@@ -53,7 +53,9 @@ struct LglMeta {
 template <class F>
 struct FuncMeta {
   using D = FuncDims<F>;
-  static constexpr long long v[MF_COUNT] = {2, F::XV, F::UV, F::PV, 0, 0, D::IR, D::OR, D::NKKT, 0, 0, 0, F::NACONST};
+  // MF_G: applications per workgroup of the block kinds (func_kernels.h: FuncStage; 0: 64, stored directly), MF_LDS_BYTES: their LDS
+  static constexpr long long v[MF_COUNT] = {2, F::XV, F::UV, F::PV, 0, 0, D::IR, D::OR, D::NKKT, FuncStage<F>::APW,
+                                            (long long)FuncStage<F>::lds_bytes(), 0, F::NACONST};
 };
 
 }  // namespace asset_hip

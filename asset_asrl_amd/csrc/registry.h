@@ -178,7 +178,11 @@ inline hipError_t launch_func_table(const KernelTable& t, int level, const EvalA
   EvalArgs args = a;
   void* kargs[] = {&args};
   const bool asmb = level >= 1 && a.kmap != nullptr;
-  return klaunch(t.k[K_FUNC(level, asmb)], dim3((a.nseg + 63) / 64), dim3(64), 0, st, kargs);
+  // block kinds: APW applications per workgroup, their blocks staged in LDS (func_kernels.h: FuncStage)
+  const bool staged = level >= 1 && !asmb && t.meta[MF_G] > 0;
+  const int apw = staged ? int(t.meta[MF_G]) : 64;
+  const size_t shmem = staged ? size_t(t.meta[MF_LDS_BYTES]) : 0;
+  return klaunch(t.k[K_FUNC(level, asmb)], dim3((a.nseg + apw - 1) / apw), dim3(64), shmem, st, kargs);
 }
 
 inline hipError_t entry_launch(const KernelEntry* ke, int level, const EvalArgs& a, int cus, hipStream_t st) {
