@@ -62,18 +62,20 @@ def build_native() -> str:
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
         return so
     flags = ["-O2", "-march=native", "-ffast-math", "-fPIC"]
-    objs = []
     tmp = so + ".build"
     os.makedirs(tmp, exist_ok=True)
+    jobs = []
     for src in srcs:
         o = os.path.join(tmp, os.path.basename(src) + ".o")
-        subprocess.check_call(["g++", "-std=c++17", "-pthread", "-Wno-unused-function"] + flags + ["-c", src, "-o", o])
-        objs.append(o)
+        jobs.append((["g++", "-std=c++17", "-pthread", "-Wno-unused-function", "-Wno-psabi"] + flags + ["-c", src, "-o", o], o))
     for g in (gen, gen4):
         if os.path.exists(g):
             o = os.path.join(tmp, os.path.basename(g) + ".o")
-            subprocess.check_call(["gcc"] + flags + ["-c", g, "-o", o])
-            objs.append(o)
+            jobs.append((["gcc", "-Wno-psabi"] + flags + ["-c", g, "-o", o], o))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:     # (the two generated files take ~10 s each)
+        list(pool.map(lambda j: subprocess.check_call(j[0]), jobs))
+    objs = [o for _, o in jobs]
     subprocess.check_call(["g++", "-shared", "-pthread", "-o", so] + objs)
     return so
 
