@@ -97,6 +97,27 @@ def test_ragged_segment_counts(oracle, nseg):
                   w, JAC_ADJGRAD_HESS)
 
 
+@pytest.mark.parametrize("ode,mode,blocked,nseg", [
+    # Reentry-LGL7 on 256 CUs x 8 workgroups: fused up to 7 segments per workgroup (14 336), two launches beyond; the
+    # two-wave form takes shares of exactly 4 (GF2 = 8)
+    ("reentry", "LGL7", False, 2047), ("reentry", "LGL7", False, 2049), ("reentry", "LGL7", False, 6145),
+    ("reentry", "LGL7", False, 8192), ("reentry", "LGL7", False, 8193), ("reentry", "LGL7", False, 14336),
+    ("reentry", "LGL7", False, 14337),
+    # TwoBody-LGL5-BlockConstant: two-wave shares of 4..10 (GF2 = 20), one-wave up to GF = 15, then two launches
+    ("twobody_lt", "LGL5", True, 6143), ("twobody_lt", "LGL5", True, 8193), ("twobody_lt", "LGL5", True, 20481),
+    ("twobody_lt", "LGL5", True, 30719), ("twobody_lt", "LGL5", True, 30721),
+    # Betts (ODE stage in units): fewer segments than one group, a ragged last group
+    ("betts_lowthrust", "LGL5", False, 3), ("betts_lowthrust", "LGL5", False, 1031)])
+def test_launch_form_boundaries(oracle, ode, mode, blocked, nseg):
+    """Mesh sizes on either side of every switch of the launcher (csrc/registry.h: launch_lgl_table): one-wave fused,
+    two-wave fused, ODE stage + dense stage, units -- every block against the oracle."""
+    w = Workload(ode, mode, nseg, blocked)
+    ev = DefectEvaluator(ode, mode, blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    ref = w.oracle_nlp(oracle, threads=8).eval_blocks(oracle.JAC_ADJGRAD_HESS, w.X, w.L)
+    _check_blocks(ev.eval(JAC_ADJGRAD_HESS, w.X, w.L), ref, w, JAC_ADJGRAD_HESS)
+    ev.close()
+
+
 @pytest.mark.parametrize("mode,nseg", [("LGL7", 1), ("LGL7", 2), ("LGL7", 3), ("LGL7", 257), ("LGL5", 1), ("LGL5", 511), ("LGL3", 513)])
 def test_ragged_segment_counts_wide_shapes(oracle, mode, nseg):
     """The four-wave dense kernel (csrc/defect_wide.h): fewer segments than workgroups, one segment, counts that leave
