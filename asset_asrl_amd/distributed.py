@@ -16,6 +16,13 @@ xGMI, every peer on its own link).  Nothing touches the host.  Shards differ by 
 at most one segment per rank; ``shard_blocks_on_root`` returns per-shard views of the receive buffer (no copy),
 ``blocks_on_root`` the phase-order concatenation.
 
+Host-visible path (``HostSharedBlocks``): the reference's solver keeps the KKT system on the host, and on one GPU the
+blocks reach it over ONE PCIe link (84 MB for a 10 000-segment LGL7 phase: 1.7 ms, 40x the evaluation).  With one
+process per GPU every rank has a link of its own: each rank copies its flat buffer straight into its range of one
+page-locked host buffer that all ranks map (a file in /dev/shm), and the only synchronisation is a barrier -- the shards
+never cross xGMI and never funnel through the root's link.  This is where more GPUs buy the host solver time even when
+the evaluation itself is tens of microseconds.
+
 ``PhaseShardedEvaluator`` is the multi-phase form (BASELINE.json configs[3]: eight linked phases): whole phases are
 dealt to the ranks round-robin -- phases are independent given X and L too
 (/root/reference/src/OptimalControl/OptimalControlProblem.cpp:115-155) -- and gathered the same way.
@@ -36,6 +43,66 @@ def _sizes(ode, mode, blocked):
     from .build import dims
     d = dims(*_lib.ode_sizes(ode), synth.MODE_CS[mode] if isinstance(mode, str) else max(mode, 2), blocked)
     return d["IR"], d["OR"], d["NKKT"]
+
+
+class HostSharedBlocks:
+    """One host buffer of ``world * slot_doubles`` doubles that every rank of the job maps (POSIX shared memory) and
+    page-locks; rank r owns the range [r * slot_doubles, (r + 1) * slot_doubles).  ``push`` enqueues the D2H copy of a
+    rank's flat device buffer into its range; ``wait`` completes it and meets the other ranks at a barrier, after which
+    the root (any rank) reads every shard from ``.buf`` -- host memory, no collective in the data path."""
+
+    def __init__(self, slot_doubles: int, rank: int, world: int, group=None, barrier_group=None, tag: Optional[str] = None):
+        import os
+        import torch
+        import torch.distributed as dist
+        self.rank, self.world, self.slot = rank, world, int(slot_doubles)
+        self.group, self.barrier_group = group, barrier_group
+        self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        if tag is None:                       # one name for the whole job, chosen by rank 0
+            box = [f"asset_hip_blocks_{os.getpid()}_{int.from_bytes(os.urandom(4), 'little'):08x}"]
+            if self._dist is not None and world > 1:
+                self._dist.broadcast_object_list(box, src=0, group=group)
+            tag = box[0]
+        self.path = os.path.join("/dev/shm", tag)
+        n = self.slot * world
+        if rank == 0:
+            with open(self.path, "wb") as f:
+                f.truncate(n * 8)
+        self._barrier()
+        self.buf = torch.from_file(self.path, shared=True, size=n, dtype=torch.float64)
+        self._registered = False
+        if torch.cuda.is_available():         # page-lock the mapping: the D2H copies then run at the link's rate
+            rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), n * 8, 0)
+            if int(rc) != 0:
+                raise RuntimeError(f"cudaHostRegister of the shared block buffer failed (rc={int(rc)})")
+            self._registered = True
+        self.mine = self.buf[rank * self.slot:(rank + 1) * self.slot]
+        self._barrier()
+        if rank == 0:
+            os.unlink(self.path)              # every rank holds its mapping; the name is no longer needed
+
+    def _barrier(self):
+        if self._dist is not None and self.world > 1:
+            self._dist.barrier(group=self.barrier_group if self.barrier_group is not None else self.group)
+
+    def push(self, local_flat):
+        """Enqueue (on the current stream of `local_flat`'s device) the copy of this rank's flat buffer into its range."""
+        self.mine.copy_(local_flat, non_blocking=True)
+
+    def wait(self, stream=None):
+        import torch
+        if torch.cuda.is_available():
+            (stream if stream is not None else torch.cuda.current_stream()).synchronize()
+        self._barrier()
+
+    def shard(self, r: int):
+        return self.buf[r * self.slot:(r + 1) * self.slot]
+
+    def close(self):
+        import torch
+        if self._registered:
+            torch.cuda.cudart().cudaHostUnregister(self.buf.data_ptr())
+            self._registered = False
 
 
 class ShardedDefectEvaluator:
@@ -115,6 +182,22 @@ class ShardedDefectEvaluator:
             return None
         out = list(self._recv.unbind(0)) if self.rank == self._dst else None
         return self.dist.gather(self._local, out, dst=self._dst, group=self.group, async_op=async_op)
+
+    def alloc_host_shared(self, barrier_group=None, tag: Optional[str] = None):
+        """The host-visible exchange: a page-locked host buffer shared by the ranks (HostSharedBlocks).  After
+        ``eval_device(...); push_host(); wait_host()`` every rank's (fx, agx, kkt) blocks are in host memory;
+        ``host_shard_blocks()`` returns them per shard as numpy views."""
+        self._host = HostSharedBlocks(self.slot_doubles, self.rank, self.world, self.group, barrier_group, tag)
+        return self
+
+    def push_host(self):
+        self._host.push(self._local)
+
+    def wait_host(self, stream=None):
+        self._host.wait(stream)
+
+    def host_shard_blocks(self):
+        return [tuple(v.numpy() for v in self._views(self._host.shard(r), c)) for r, (_, c) in enumerate(self.shards)]
 
     def shard_blocks_on_root(self):
         """Per rank, the (fx, agx, kkt) views of its shard in the root's receive buffer after `gather_device` -- no

@@ -139,6 +139,8 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+    # CPU-side barriers of the host-visible exchange (no device work to wait for: a gloo group next to the RCCL one)
+    gloo_group = dist.new_group(backend="gloo") if dist is not None else None
 
     from helpers import Workload
 
@@ -236,6 +238,37 @@ def main():
         extra["exchange_ms"] = timed(exchange, k2, 5) / k2 * 1e3
         extra["exchange_bytes_into_root"] = 8 * max(world - 1, 1) * (sh.slot_doubles if nphases == 1 else sh.per_rank * nseg * sh.width)
 
+    # host-visible rate (NOT `value`): the blocks in host memory, where the reference's solver keeps its KKT system.  Every
+    # rank copies its shard over its own PCIe link into its range of one page-locked host buffer all ranks map
+    # (asset_asrl_amd/distributed.py: HostSharedBlocks); the step ends at a barrier.  One GPU: one link.
+    host_visible = None
+    if nphases == 1 and nseg * (OR + IR + NKKT) * 8 <= 4 << 30:
+        k3 = max(5, min(a.steps, 50))
+        if use_dist:
+            sh.alloc_host_shared(barrier_group=gloo_group)
+
+            def host_step():
+                evaluate()
+                sh.push_host()
+                sh.wait_host(stream)
+            bytes_rank = sh.slot_doubles * 8
+        else:
+            hfx, hagx, hkkt = (torch.empty(t.numel(), dtype=torch.float64, pin_memory=True) for t in (fx, agx, kkt))
+
+            def host_step():
+                evaluate()
+                hfx.copy_(fx, non_blocking=True)
+                hagx.copy_(agx, non_blocking=True)
+                hkkt.copy_(kkt, non_blocking=True)
+                stream.synchronize()
+            bytes_rank = (fx.numel() + agx.numel() + kkt.numel()) * 8
+        th = timed(host_step, k3, 2) / k3
+        host_visible = {"ms_per_step": th * 1e3, "segments_per_s": total_segments / th, "bytes_per_rank": bytes_rank,
+                        "path": "evaluation, then every rank's FX/AGX/KKT blocks device-to-host over its own PCIe link into "
+                                "one page-locked host buffer shared by the ranks; barrier"}
+        if use_dist:
+            sh._host.close()
+
     # kernel-only duration of this rank's share on the handle's own stream, HIP events around the launches
     ms_kernel = 0.0
     if evs:
@@ -303,6 +336,8 @@ def main():
             "per_rank_kernel_ms": per_rank_ms,
         }
         out.update(extra)
+        if host_visible is not None:
+            out["host_visible"] = host_visible
         if world == 1 and not a.no_cpu_baseline:
             # bounded sample: the oracle's CSR scatter needs 12 B per KKT slot on the host -- cap it at 2e8 slots
             cap = max(1, int(2e8) // NKKT)

@@ -72,6 +72,19 @@ def _worker(rank, world, port, nseg, q):
     assert sh._local.numel() == sh.max_count * (sh.OR + sh.IR + sh.NKKT)
     shards = sh.shard_blocks_on_root()
     full = sh.blocks_on_root()
+    # host-visible exchange: every rank copies its flat buffer into its range of one shared host buffer, then a barrier
+    sh.alloc_host_shared()
+    sh.eval_device(4, X, L)
+    sh.push_host()
+    sh.wait_host()
+    hs = sh.host_shard_blocks()
+    assert len(hs) == world and not os.path.exists(sh._host.path)     # (the name is unlinked once every rank has mapped it)
+    host_full = [np.concatenate([h[k] for h in hs], axis=0) for k in range(3)]   # read on EVERY rank: it is host memory
+    for got_h, loc in zip(hs[rank], (lfx, lagx, lkkt)):
+        np.testing.assert_array_equal(got_h, loc.numpy())
+    if rank == 0:
+        q.put(("host", host_full))
+    sh._host.close()
     if rank == 0:
         assert len(shards) == world and all(s[2].shape[0] == c for s, (_, c) in zip(shards, sh.shards))
         assert shards[0][0].data_ptr() == sh._recv[0].data_ptr()          # views of the receive buffer, no copy
@@ -91,6 +104,9 @@ def test_two_rank_shard_and_gather(oracle, nseg):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, nseg, q)) for r in range(2)]
     for p in procs:
         p.start()
+    tagged = q.get(timeout=120)
+    assert tagged[0] == "host"
+    hfx, hagx, hkkt = tagged[1]
     fx, agx, kkt, shards, dfx, dagx, dkkt = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
@@ -98,7 +114,8 @@ def test_two_rank_shard_and_gather(oracle, nseg):
     w = Workload("reentry", "LGL5", nseg)
     rfx, ragx, rkkt = w.oracle_nlp(oracle).eval_blocks(oracle.JAC_ADJGRAD_HESS, w.X, w.L)
     assert [c for _, c in shards] == ([5, 4] if nseg == 9 else [1, 0])
-    for got, ref in ((fx, rfx), (agx, ragx), (kkt, rkkt), (dfx, rfx), (dagx, ragx), (dkkt, rkkt)):
+    for got, ref in ((fx, rfx), (agx, ragx), (kkt, rkkt), (dfx, rfx), (dagx, ragx), (dkkt, rkkt), (hfx, rfx), (hagx, ragx),
+                     (hkkt, rkkt)):
         np.testing.assert_array_equal(got, ref)
 
 

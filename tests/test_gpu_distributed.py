@@ -33,8 +33,17 @@ with torch.cuda.stream(st):
 torch.cuda.synchronize()
 fx, agx, kkt = [t.cpu().numpy() for t in sh.blocks_on_root()]
 rfx, ragx, rkkt = w.oracle_nlp(ob, threads=4).eval_blocks(4, w.X, w.L)
+# host-visible exchange: the flat buffer copied into this rank's range of the shared page-locked host buffer
+sh.alloc_host_shared()
+with torch.cuda.stream(st):
+    sh.eval_device(4, X, L, st)
+    sh.push_host()
+    sh.wait_host(st)
+hfx, hagx, hkkt = sh.host_shard_blocks()[0]
+host_same = bool(np.array_equal(hfx, fx) and np.array_equal(hagx, agx) and np.array_equal(hkkt, kkt))
+sh._host.close()
 print(json.dumps({{"fx": float(np.abs(fx - rfx).max() / max(1.0, np.abs(w.X).max())), "agx": rel_err(agx, ragx),
-                  "kkt": rel_err(kkt, rkkt), "shape": list(kkt.shape)}}))
+                  "kkt": rel_err(kkt, rkkt), "shape": list(kkt.shape), "host_same": host_same}}))
 dist.destroy_process_group()
 """
 
@@ -46,6 +55,7 @@ def test_sharded_device_path_with_rccl_gather_matches_the_oracle(oracle):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["shape"] == [333, 1008]
     assert out["fx"] < 1e-10 and out["agx"] < 1e-8 and out["kkt"] < 1e-8, out
+    assert out["host_same"]                  # the host-shared exchange delivers the same bits
 
 
 @pytest.mark.gpu
@@ -58,3 +68,4 @@ def test_bench_runs_the_exchange_path_with_one_rank():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 0
     assert "exchange_ms" in out and out["exchange_bytes_into_root"] > 8e7
+    assert out["host_visible"]["ms_per_step"] > out["ms_per_step"] and out["host_visible"]["bytes_per_rank"] > 8e7
