@@ -140,7 +140,12 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     # CPU-side barriers of the host-visible exchange (no device work to wait for: a gloo group next to the RCCL one)
-    gloo_group = dist.new_group(backend="gloo") if dist is not None else None
+    gloo_group = None
+    if dist is not None:
+        try:
+            gloo_group = dist.new_group(backend="gloo")
+        except Exception as exc:                           # (no usable interface for gloo: barrier on the RCCL group instead)
+            print(f"[bench] gloo group unavailable ({exc}); host-visible barriers use the RCCL group", file=sys.stderr)
 
     from helpers import Workload
 
