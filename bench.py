@@ -234,6 +234,26 @@ def main():
             dt = float(t.item())
         return dt
 
+    # Kernel-only duration of this rank's share on the handle's own stream, HIP events around the launches -- measured
+    # FIRST and until it settles: the part clocks up under load (the same kernel: 49.8 us over the first 100 launches after
+    # an idle second, 45.2 after 300, 42.6 after 900), so the rounds below are repeated until two agree within 1 %.  The
+    # timed region of the contract follows immediately, on a device that is already at its working clocks.
+    ms_kernel, kernel_rounds = 0.0, []
+    if evs:
+        e0 = evs[0]
+        n0 = e0.nseg
+        kfx = torch.empty(n0 * OR, dtype=torch.float64, device=dev)
+        kagx = torch.empty(n0 * IR, dtype=torch.float64, device=dev)
+        kkkt = torch.empty(n0 * NKKT, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        iters = 200 if n0 * (OR + IR + NKKT) * 8 < (1 << 30) else 20
+        for _ in range(8):
+            kernel_rounds.append(e0.time_device(JAC_ADJGRAD_HESS, X, L, kfx, kagx, kkkt, warmup=5, iters=iters))
+            if len(kernel_rounds) >= 2 and abs(kernel_rounds[-1] - kernel_rounds[-2]) <= 0.01 * kernel_rounds[-1]:
+                break
+        ms_kernel = kernel_rounds[-1]
+        del kfx, kagx, kkkt
+
     dt = timed(step, a.steps, a.warmup)                       # THE measurement: K steps, exchange included when N > 1
     extra = {}
     if exchange is not None and use_dist:
@@ -274,17 +294,6 @@ def main():
         if use_dist:
             sh._host.close()
 
-    # kernel-only duration of this rank's share on the handle's own stream, HIP events around the launches
-    ms_kernel = 0.0
-    if evs:
-        e0 = evs[0]
-        n0 = e0.nseg
-        kfx = torch.empty(n0 * OR, dtype=torch.float64, device=dev)
-        kagx = torch.empty(n0 * IR, dtype=torch.float64, device=dev)
-        kkkt = torch.empty(n0 * NKKT, dtype=torch.float64, device=dev)
-        torch.cuda.synchronize()
-        ms_kernel = e0.time_device(JAC_ADJGRAD_HESS, X, L, kfx, kagx, kkkt, warmup=5, iters=max(20, min(a.steps, 200)))
-        del kfx, kagx, kkkt
     bseg = algorithmic_bytes_per_segment(IR, OR)
     achieved = local_segments * bseg / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
     per_rank_ms = [ms_kernel]
@@ -336,7 +345,7 @@ def main():
                          "kernel": ("lgl_defect_kernel (ODE stage) + lgl_wide_dense_kernel" if IR >= 64 else
                                     "lgl_defect_kernel (fused single launch up to 7 segments per workgroup, else ODE-stage + dense-stage launches)")
                                    + "; rank 0's share, all launches of one evaluation timed",
-                         "kernel_ms": ms_kernel, "segments_in_kernel": local_segments,
+                         "kernel_ms": ms_kernel, "kernel_ms_rounds": kernel_rounds, "segments_in_kernel": local_segments,
                          "algorithmic_bytes_per_segment": bseg},
             "per_rank_kernel_ms": per_rank_ms,
         }
