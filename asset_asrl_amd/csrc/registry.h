@@ -147,8 +147,9 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
           if (!a.kmap && !no_fuse && !no_fuse2 && !skip_dense && pairs > 0 && share >= 4 && share <= int(m[MF_GF2]) / 2)
             return klaunch(t.k[K_LGL(2, 4, false)], dim3(pairs), dim3(128), size_t(m[MF_BYTES_FUSED2]), st, kargs);
         }
-        if (!a.kmap && !no_fuse && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]))
-          return klaunch(t.k[K_LGL(2, 3, false)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);
+        // (also with on-device assembly: the dense part places its entries through the map either way)
+        if (!no_fuse && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]))
+          return klaunch(t.k[K_LGL(2, 3, a.kmap != nullptr)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);
       }
       static const bool no_units = std::getenv("ASSET_HIP_NO_UNITS") != nullptr;                               // tuning only
       if (m[MF_NUNITS] > 1 && !no_units) {
@@ -238,7 +239,10 @@ const KernelTable* lgl_static_table() {
       r.k[K_LGL(2, 2, true)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 2, true>);
       r.k[K_LANE_SETUP1].host = ASSET_KPTR(lane_setup_kernel<Ode, SCH, BLOCKED, 1>);
       r.k[K_LANE_SETUP2].host = ASSET_KPTR(lane_setup_kernel<Ode, SCH, BLOCKED, 2>);
-      if constexpr (D::FUSED) r.k[K_LGL(2, 3, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 3, false>);
+      if constexpr (D::FUSED) {
+        r.k[K_LGL(2, 3, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 3, false>);
+        r.k[K_LGL(2, 3, true)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 3, true>);
+      }
       if constexpr (D::FUSED2) r.k[K_LGL(2, 4, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 4, false>);
     }
     if constexpr (Ode::NUNITS > 1) {
@@ -301,7 +305,7 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
     for (int stg = 1; stg <= 4; stg++)
       for (int as = 0; as <= 1; as++) {
         if (slot != K_LGL(lv, stg, as != 0)) continue;
-        const bool used = (stg == 1 && !as) || (stg == 2 && lv >= 1) || (stg >= 3 && lv == 2 && !as);
+        const bool used = (stg == 1 && !as) || (stg == 2 && lv >= 1) || (stg == 3 && lv == 2) || (stg == 4 && lv == 2 && !as);
         if (!used) return "";
         return "asset_hip::lgl_defect_kernel<" + lgl + ", " + std::to_string(g) + ", " + std::to_string(lv) + ", " +
                std::to_string(stg) + ", " + tf(as != 0) + ">";
