@@ -69,3 +69,22 @@ def test_bench_runs_the_exchange_path_with_one_rank():
     assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 0
     assert "exchange_ms" in out and out["exchange_bytes_into_root"] > 8e7
     assert out["host_visible"]["ms_per_step"] > out["ms_per_step"] and out["host_visible"]["bytes_per_rank"] > 8e7
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharing_one_gpu_match_the_oracle(oracle):
+    """World size 2 with real kernels: two processes on GPU 0 (gloo; the shard rule gives 167 + 166 segments), the device
+    gather and the host-shared exchange both deliver the oracle's blocks."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "two_rank_one_gpu.py")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["shards"] == [[0, 167], [167, 166]]
+    assert out["host_fx"] < 1e-10 and out["host_agx"] < 1e-8 and out["host_kkt"] < 1e-8, out
+    assert out.get("gather_kkt", 1.0) < 1e-8, out
