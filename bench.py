@@ -127,6 +127,9 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed launch with WORLD_SIZE={a.gpus} (got {world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    backend = os.environ.get("ASSET_BENCH_BACKEND", "nccl")     # "gloo": functional runs of N ranks that share devices
+    if backend != "nccl":                                        # (RCCL refuses two ranks on one GPU); never for a reported number
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -138,12 +141,15 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     # CPU-side barriers of the host-visible exchange (no device work to wait for: a gloo group next to the RCCL one)
     gloo_group = None
     if dist is not None:
         try:
-            gloo_group = dist.new_group(backend="gloo")
+            gloo_group = dist.new_group(backend="gloo") if backend == "nccl" else None
         except Exception as exc:                           # (no usable interface for gloo: barrier on the RCCL group instead)
             print(f"[bench] gloo group unavailable ({exc}); host-visible barriers use the RCCL group", file=sys.stderr)
 
