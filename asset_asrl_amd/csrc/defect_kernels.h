@@ -11,8 +11,10 @@
 // (/root/reference/src/VectorFunctions/DenseFunctionBase.h:1097-1129, 1276-1391) -- or, in the ASM instantiations,
 // added straight into the solver's value array (DenseFunctionBase.h:1413-1523).
 //
-// One evaluation is two launches of lgl_defect_kernel (one 64-lane wavefront per workgroup, persistent workgroups
-// over contiguous shares of the segments); they hand over through a per-segment workspace slot in HBM (Dims: w_*):
+// One evaluation is one launch of lgl_defect_kernel -- both stages in one kernel (STAGE 3 / 4, meshes whose shares fit one
+// group per workgroup: up to 14 336 Reentry-LGL7 segments on 256 CUs) -- or two (STAGE 1, then STAGE 2): one 64-lane
+// wavefront per workgroup (two in STAGE 4), persistent workgroups over contiguous shares of the segments; the stages
+// hand over through a per-segment workspace slot (Dims: w_*) that the fused forms read back from L2 / the Infinity Cache:
 //   STAGE 1, ODE stage -- lane <-> evaluation point, up to G segments of the workgroup at a time:
 //     P0  gather z = X[Vindex], lam = L[Cindex] into the slots
 //     P1  (segment, cardinal node):   f_j, and every transcendental sub-expression of it        (f_save)
