@@ -38,6 +38,10 @@ SYMBOLS = {
                                        C.c_int, C.c_char_p]),
     "asset_hip_jit_plugin": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_char_p), C.c_int, C.c_char_p]),
+    "asset_hip_bundle_create": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "asset_hip_bundle_eval_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
+    "asset_hip_bundle_destroy": (None, [C.c_void_p]),
     "asset_hip_defect_time_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int,
                                                                                          C.POINTER(C.c_float)]),
     "asset_hip_defect_set_appl_consts": (C.c_int, [C.c_void_p, _dp, C.c_int]),

@@ -273,7 +273,7 @@ int rtc_compile(const char* source, const char* functor, int kind, int mode, int
 
 int asset_hip_jit_compile(const char* source, const char* functor, int kind, int mode, int blocked, int seg_per_group,
                           const char* const* options, int noptions, const char* cache_path) {
-  if (!source || !functor || !cache_path || (kind != 1 && kind != 2)) return fail(ASSET_HIP_EINVAL, "bad jit arguments");
+  if (!source || !functor || !cache_path || kind < 1 || kind > 3) return fail(ASSET_HIP_EINVAL, "bad jit arguments");
   RtcBlob blob;
   const int rc = rtc_compile(source, functor, kind, mode, blocked, seg_per_group, options, noptions, blob);
   if (rc) return rc;
@@ -283,8 +283,8 @@ int asset_hip_jit_compile(const char* source, const char* functor, int kind, int
 
 int asset_hip_jit_plugin(const char* name, const char* source, const char* functor, int kind, int mode, int blocked,
                          int seg_per_group, const char* const* options, int noptions, const char* cache_path) {
-  if (!name || !functor || (kind != 1 && kind != 2)) return fail(ASSET_HIP_EINVAL, "bad jit arguments");
-  if (find_entry(name, kind == 2 ? ASSET_HIP_FUNCTION : mode, blocked)) return 0;
+  if (!name || !functor || kind < 1 || kind > 3) return fail(ASSET_HIP_EINVAL, "bad jit arguments");
+  if (find_entry(name, kind >= 2 ? ASSET_HIP_FUNCTION : mode, kind >= 2 ? 0 : blocked)) return 0;
   RtcBlob blob;
   if (!(cache_path && rtc_read(cache_path, blob))) {
     blob = RtcBlob();
@@ -390,6 +390,7 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
                   d->blocked);
     return fail(ASSET_HIP_ENOODE, buf);
   }
+  if (ke->table->meta[asset_hip::MF_KIND] == 3) return fail(ASSET_HIP_EINVAL, "a bundle is launched through asset_hip_bundle_*, it is not a function");
   // bounds-check the index tables once, on the host (the kernels trust them)
   const size_t nv = size_t(ke->ir) * d->nseg, nc = size_t(ke->orr) * d->nseg;
   for (size_t i = 0; i < nv; i++)
@@ -475,14 +476,14 @@ int asset_hip_defect_sizes(asset_hip_defect_t h, int* irows, int* orows, int* nk
   return 0;
 }
 
-static int launch(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx, double* dagx,
-                  double* dkkt, hipStream_t st, double* d_values = nullptr) {
+// the kernel arguments of one evaluation of a handle (block kinds)
+static int fill_args(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx, double* dagx,
+                     double* dkkt, asset_hip::EvalArgs& a) {
   const int level = level_of(what);
   if (level < 0) return fail(ASSET_HIP_EINVAL, "unknown evaluation kind");
   if (!dX) return fail(ASSET_HIP_EINVAL, "X is null");
   const bool needs_l = (what == ASSET_HIP_CON_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD_HESS);
   if (needs_l && !dL) return fail(ASSET_HIP_EINVAL, "L is null for an evaluation kind that contracts with multipliers");
-  asset_hip::EvalArgs a;
   a.nseg = h->nseg;
   a.X = dX;
   a.L = needs_l ? dL : nullptr;
@@ -496,6 +497,15 @@ static int launch(asset_hip_defect_t h, int what, const double* dX, const double
   a.appl_consts = h->d_aconst;
   if (h->ke->naconst > 0 && !h->d_aconst)
     return fail(ASSET_HIP_EINVAL, "this function reads constants of its applications: call asset_hip_defect_set_appl_consts first");
+  return 0;
+}
+
+static int launch(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx, double* dagx,
+                  double* dkkt, hipStream_t st, double* d_values = nullptr) {
+  asset_hip::EvalArgs a;
+  const int rc = fill_args(h, what, dX, dL, dfx, dagx, dkkt, a);
+  if (rc) return rc;
+  const int level = level_of(what);
   if (d_values) {                                                          // on-device assembly
     a.kmap = h->d_map, a.values = d_values, a.KKT = nullptr;
     a.stage = h->d_stage, a.nvalues = int(h->nvalues);
@@ -515,6 +525,66 @@ int asset_hip_defect_eval_device(asset_hip_defect_t h, int what, const double* d
   if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
   HIP_TRY(hipSetDevice(h->device));
   return launch(h, what, dX, dL, dfx, dagx, dkkt, stream ? static_cast<hipStream_t>(stream) : h->stream);
+}
+
+// ---- bundles: several plain functions in one launch (func_kernels.h: func_bundle_kernel) ---------------------------------
+struct asset_hip_bundle {
+  const asset_hip::KernelEntry* ke = nullptr;
+  std::vector<asset_hip_defect_t> members;
+  int device = 0;
+};
+
+int asset_hip_bundle_create(const char* name, const asset_hip_defect_t* members, int n, asset_hip_bundle_t* out) {
+  if (!name || !members || !out || n < 1 || n > asset_hip::BUNDLE_MAX) return fail(ASSET_HIP_EINVAL, "bad bundle arguments");
+  const asset_hip::KernelEntry* ke = find_entry(name, ASSET_HIP_FUNCTION, 0);
+  if (!ke || ke->table->meta[asset_hip::MF_KIND] != 3) return fail(ASSET_HIP_ENOODE, std::string("no compiled bundle '") + name + "'");
+  if (ke->table->meta[asset_hip::MF_XV] != n) return fail(ASSET_HIP_EINVAL, "the bundle was compiled for another number of functions");
+  for (int k = 0; k < n; k++) {
+    const asset_hip_defect_t h = members[k];
+    if (!h || h->ke->mode != ASSET_HIP_FUNCTION || h->ke->table->meta[asset_hip::MF_KIND] != 2)
+      return fail(ASSET_HIP_EINVAL, "bundle members are handles of plain functions");
+    if (h->device != members[0]->device) return fail(ASSET_HIP_EINVAL, "bundle members live on different devices");
+    if (ke->table->meta[asset_hip::MF_BYTES_ODE + k] != (long long)(h->ke->ir) * 65536 + h->ke->orr)
+      return fail(ASSET_HIP_EINVAL, "member " + std::to_string(k) + " does not have the sizes of the bundle's function " + std::to_string(k));
+  }
+  auto* b = new (std::nothrow) asset_hip_bundle();
+  if (!b) return fail(ASSET_HIP_EINVAL, "out of memory");
+  b->ke = ke, b->members.assign(members, members + n), b->device = members[0]->device;
+  *out = b;
+  return 0;
+}
+
+void asset_hip_bundle_destroy(asset_hip_bundle_t b) { delete b; }
+
+int asset_hip_bundle_eval_device(asset_hip_bundle_t b, int what, const double* dX, const double* const* dL,
+                                 double* const* d_fx, double* const* d_agx, double* const* d_kkt, void* stream) {
+  if (!b || !d_fx) return fail(ASSET_HIP_EINVAL, "bad bundle arguments");
+  const int level = level_of(what);
+  if (level < 0) return fail(ASSET_HIP_EINVAL, "unknown evaluation kind");
+  HIP_TRY(hipSetDevice(b->device));
+  asset_hip::BundleArgs args;
+  const int n = int(b->members.size());
+  args.n = n;
+  size_t shmem = 0;
+  int blocks = 0;
+  for (int k = 0; k < n; k++) {
+    asset_hip_defect_t h = b->members[k];
+    const int rc = fill_args(h, what, dX, dL ? dL[k] : nullptr, d_fx[k], d_agx ? d_agx[k] : nullptr, d_kkt ? d_kkt[k] : nullptr,
+                             args.a[k]);
+    if (rc) return rc;
+    const long long* m = h->ke->table->meta;
+    const bool staged = level >= 1 && m[asset_hip::MF_G] > 0;     // (as launch_func_table: the block kinds stage in LDS)
+    const int apw = staged ? int(m[asset_hip::MF_G]) : 64;
+    if (staged && size_t(m[asset_hip::MF_LDS_BYTES]) > shmem) shmem = size_t(m[asset_hip::MF_LDS_BYTES]);
+    args.start[k] = blocks;
+    blocks += (h->nseg + apw - 1) / apw;
+  }
+  for (int k = n; k <= asset_hip::BUNDLE_MAX; k++) args.start[k] = blocks;
+  void* kargs[] = {&args};
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : b->members[0]->stream;
+  hipError_t e = asset_hip::klaunch(b->ke->table->k[asset_hip::K_BUNDLE(level)], dim3(blocks), dim3(64), shmem, st, kargs);
+  if (e != hipSuccess) return hipfail(e, "bundle launch");
+  return 0;
 }
 
 int asset_hip_defect_time_device(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx,

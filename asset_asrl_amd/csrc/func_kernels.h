@@ -108,13 +108,13 @@ struct FuncOut {
 // Launch (registry.h: launch_func_table): 64 lanes per workgroup; the block kinds (LEVEL >= 1, not ASM) of a function with
 // FuncStage::APW > 0 take APW applications per workgroup and FuncStage::lds_bytes() of dynamic LDS, everything else 64.
 template <class F, int LEVEL, bool ASM>
-__global__ __launch_bounds__(64, ASSET_FUNC_WAVES) void func_kernel(EvalArgs a) {
+__device__ __forceinline__ void func_body(const EvalArgs& a, int block) {   // block: index of this workgroup within the function's grid
   using D = FuncDims<F>;
   using ST = FuncStage<F>;
   constexpr bool STG = !ASM && LEVEL >= 1 && ST::APW > 0;
   constexpr int APW = STG ? ST::APW : 64;
   const int lane = threadIdx.x;
-  const int V0 = blockIdx.x * APW, V = V0 + lane;
+  const int V0 = block * APW, V = V0 + lane;
   const bool active = lane < APW && V < a.nseg;
   if constexpr (STG) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64, ASSET_FUNC_WAVES) void func_kernel(EvalArgs a) 
       }
 #if defined(ASSET_FUNC_TIMING)   // (tuning builds) gather / body / copy-out cycles of workgroup 7, left in its first application's FX
       ts3 = clock64();
-      if (blockIdx.x == 7 && lane == 0 && a.FX && D::OR >= 3) {
+      if (block == 7 && lane == 0 && a.FX && D::OR >= 3) {
         a.FX[size_t(V0) * D::OR + 0] = double(ts1 - ts0);
         a.FX[size_t(V0) * D::OR + 1] = double(ts2 - ts1);
         a.FX[size_t(V0) * D::OR + 2] = double(ts3 - ts2);
@@ -190,6 +190,38 @@ __global__ __launch_bounds__(64, ASSET_FUNC_WAVES) void func_kernel(EvalArgs a) 
       }
     }
   }
+}
+
+template <class F, int LEVEL, bool ASM>
+__global__ __launch_bounds__(64, ASSET_FUNC_WAVES) void func_kernel(EvalArgs a) {
+  func_body<F, LEVEL, ASM>(a, int(blockIdx.x));
+}
+
+// ---- several functions in ONE launch ----------------------------------------------------------------------------------
+// What a phase hands the solver beside its defects -- mesh spacing, nodal spacing, control splines, path constraints,
+// integrands -- are five or six functions of a few hundred to a few thousand workgroups each: launched one after the
+// other every one of them costs its own ramp (3.5-6 us apiece for 10 000 segments, none fills the device).  A bundle is a
+// kernel over a list of functors: workgroups [start[k], start[k+1]) evaluate function k with its own arguments (index
+// tables, outputs, multipliers).  Compiled at run time for the list at hand (rtc_device.h: ASSET_RTC_BUNDLE).
+constexpr int BUNDLE_MAX = 8;
+struct BundleArgs {
+  EvalArgs a[BUNDLE_MAX];
+  int start[BUNDLE_MAX + 1];   // first workgroup of every function; start[n] = the grid
+  int n;
+};
+template <int LEVEL, int I, class F, class... Rest>
+__device__ __forceinline__ void bundle_run(const BundleArgs& b, int k, int block) {
+  if (k == I) func_body<F, LEVEL, false>(b.a[I], block);
+  else if constexpr (sizeof...(Rest) > 0) bundle_run<LEVEL, I + 1, Rest...>(b, k, block);
+}
+template <int LEVEL, class... Fs>
+__global__ __launch_bounds__(64, ASSET_FUNC_WAVES) void func_bundle_kernel(BundleArgs b) {
+  static_assert(sizeof...(Fs) >= 1 && sizeof...(Fs) <= BUNDLE_MAX, "a bundle holds 1..BUNDLE_MAX functions");
+  int k = 0, first = 0;
+#pragma unroll
+  for (int i = 1; i < int(sizeof...(Fs)); i++)
+    if (int(blockIdx.x) >= b.start[i]) k = i, first = b.start[i];
+  bundle_run<LEVEL, 0, Fs...>(b, k, int(blockIdx.x) - first);
 }
 
 }  // namespace asset_hip

@@ -58,4 +58,13 @@ struct FuncMeta {
                                             (long long)FuncStage<F>::lds_bytes(), 0, F::NACONST};
 };
 
+// A bundle of plain functions (func_kernels.h: func_bundle_kernel): MF_KIND 3, MF_XV = number of functions, and from
+// MF_BYTES_ODE on one word per function, IR * 65536 + OR, so that the loader can check the members it is given.
+template <class... Fs>
+struct BundleMeta {
+  static_assert(MF_BYTES_ODE + BUNDLE_MAX <= MF_COUNT, "signature words fit the table");
+  static constexpr long long v[MF_COUNT] = {3, sizeof...(Fs), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                            (long long)(FuncDims<Fs>::IR) * 65536 + FuncDims<Fs>::OR...};
+};
+
 }  // namespace asset_hip

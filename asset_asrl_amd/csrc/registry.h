@@ -38,7 +38,8 @@ constexpr int K_WIDE(int level, bool asmb) { return 24 + (level - 1) * 2 + (asmb
 constexpr int K_WIDE_SETUP = 28, K_LANE_SETUP1 = 29, K_LANE_SETUP2 = 30, K_UNITS0 = 31, K_UNITS1 = 32;
 constexpr int K_MESH_YVEC = 33, K_MESH_ERROR = 34;
 constexpr int K_FUNC(int level, bool asmb) { return 35 + level * 2 + (asmb ? 1 : 0); }                           // 35..40
-constexpr int K_COUNT = 41;
+constexpr int K_BUNDLE(int level) { return 41 + level; }                                                         // 41..43
+constexpr int K_COUNT = 44;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -290,11 +291,16 @@ struct StaticEntry {   // (static initialisation: the table is filled and the en
   static ::asset_hip::StaticEntry entry_##ODE##_##CSV##_##BLK(ODE::name(), ::asset_hip::lgl_static_table<ODE, CSV, (BLK != 0), G>());
 
 // ---- name expressions of the kernels of a run-time module (capi.hip: asset_hip_jit_plugin) -----------------------------
-// kind 1: `type` is the ODE functor, kind 2: the function functor.  Slots without a kernel for that kind: empty string.
+// kind 1: `type` is the ODE functor, kind 2: the function functor, kind 3: the functor list of a bundle.  Slots without a kernel for that kind: empty string.
 inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, int csv, bool blocked, int g) {
   const std::string b = blocked ? "true" : "false";
   const std::string lgl = type + ", " + std::to_string(csv) + ", " + b;
   auto tf = [](bool v) { return std::string(v ? "true" : "false"); };
+  if (kind == 3) {   // a bundle: `type` is the comma-separated functor list
+    for (int lv = 0; lv <= 2; lv++)
+      if (slot == K_BUNDLE(lv)) return "asset_hip::func_bundle_kernel<" + std::to_string(lv) + ", " + type + ">";
+    return "";
+  }
   if (kind == 2) {
     for (int lv = 0; lv <= 2; lv++)
       for (int as = 0; as <= (lv >= 1 ? 1 : 0); as++)

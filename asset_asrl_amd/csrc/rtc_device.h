@@ -2,7 +2,7 @@
 // The generated source is
 //     #include "ode.h"                      the generated functor
 //     #include "<csrc>/rtc_device.h"
-//     ASSET_RTC_LGL(OdeName, CSV, BLK, G)   or   ASSET_RTC_FUNC(FnName)
+//     ASSET_RTC_LGL(OdeName, CSV, BLK, G)   or   ASSET_RTC_FUNC(FnName)   or   ASSET_RTC_BUNDLE(Fn0, Fn1, ...)
 // and the loader names the kernels it wants (hiprtcAddNameExpression): every variant the launcher of registry.h may use.
 // Variants a shape does not have compile to empty kernels (lgl_variant_valid, the guards of the wide / units / setup
 // kernels), so the list does not depend on the shape.
@@ -16,6 +16,9 @@
 #define ASSET_RTC_FUNC(FN)                                                                                         \
   extern "C" __device__ const long long asset_rtc_meta[::asset_hip::MF_COUNT] = {                                  \
       ASSET_RTC_META_LIST((::asset_hip::FuncMeta<FN>::v))};
+#define ASSET_RTC_BUNDLE(...)                                                                                      \
+  extern "C" __device__ const long long asset_rtc_meta[::asset_hip::MF_COUNT] = {                                  \
+      ASSET_RTC_META_LIST((::asset_hip::BundleMeta<__VA_ARGS__>::v))};
 // (an array cannot be initialised from another array: spell the elements out)
 #define ASSET_RTC_META_LIST(V)                                                                                     \
   V[0], V[1], V[2], V[3], V[4], V[5], V[6], V[7], V[8], V[9], V[10], V[11], V[12], V[13], V[14], V[15], V[16], V[17],  \

@@ -25,6 +25,7 @@ from .vf.codegen import emit_hip_functor, saved_nodes
 JIT_DIR = os.path.join(build.GEN, "jit")
 _MODE_CS = {"LGL3": 2, "LGL5": 3, "LGL7": 4}
 _loaded: set = set()
+_FUNCTORS: dict = {}        # device name of a plain function -> (functor struct name, its derivatives)
 # The build step (__graft_entry__.build) runs where there is no device: it compiles and caches the modules the test suite
 # will ask for and registers nothing.  Set through compile_only_mode().
 _COMPILE_ONLY = False
@@ -182,11 +183,38 @@ def ensure_function(func, name: str, compile_only=None) -> str:
     body = emit_hip_functor(d, "FnUser")
     body = "\n".join(ln for ln in body.splitlines() if "name()" not in ln and not ln.startswith("// generated"))
     dev = f"{_ident(name)}_{hashlib.sha256(body.encode()).hexdigest()[:10]}"
-    if _lib.has_kernel(dev, _lib.FUNCTION, False):
-        return dev
     d.name = dev
     sname = "Fn_" + _ident(dev)
+    _FUNCTORS[dev] = (sname, d)                 # (a bundle is assembled from the functors of its members: ensure_bundle)
+    if _lib.has_kernel(dev, _lib.FUNCTION, False):
+        return dev
     hdr = ("#pragma once\n#include <math.h>\n#include \"" + os.path.join(build.CSRC, "asset_math.h") + "\"\n"
            + emit_hip_functor(d, sname))
     return _build_and_load(dev, "fn.h", hdr, "function_0", f"ASSET_REGISTER_FUNC({sname})", _lib.FUNCTION, False,
                            f"function '{name}'", rtc=(sname, 2, 0, 0, f"ASSET_RTC_FUNC({sname})"), compile_only=compile_only)
+
+
+def ensure_bundle(dev_names, compile_only=None) -> str:
+    """One module that evaluates the plain functions `dev_names` (device names returned by ensure_function, in this order)
+    in a single launch (csrc/func_kernels.h: func_bundle_kernel; include/asset_hip.h: asset_hip_bundle_*).  hiprtc only."""
+    if not 1 <= len(dev_names) <= 8:
+        raise ValueError("a bundle holds 1..8 functions")
+    if jit_route() != "hiprtc":
+        raise _lib.AssetHipError("function bundles are compiled in process (unset ASSET_HIP_JIT=hipcc)")
+    missing = [n for n in dev_names if n not in _FUNCTORS]
+    if missing:
+        raise _lib.AssetHipError(f"ensure_bundle: {missing} were not produced by ensure_function in this process")
+    snames = [_FUNCTORS[n][0] for n in dev_names]
+    name = "bundle_" + hashlib.sha256(",".join(dev_names).encode()).hexdigest()[:12]
+    if _lib.has_kernel(name, _lib.FUNCTION, False):
+        return name
+    body, seen = [], set()
+    for n in dev_names:
+        sname, d = _FUNCTORS[n]
+        if sname not in seen:
+            seen.add(sname)
+            body.append(emit_hip_functor(d, sname))
+    hdr = ("#include <math.h>\n#include \"" + os.path.join(build.CSRC, "asset_math.h") + "\"\n" + "\n".join(body))
+    flist = ", ".join(snames)
+    return _build_and_load(name, "bundle.h", hdr, "bundle_0", "", _lib.FUNCTION, False, f"bundle of {len(dev_names)} functions",
+                           rtc=(flist, 3, 0, 0, f"ASSET_RTC_BUNDLE({flist})"), compile_only=compile_only)

@@ -108,6 +108,53 @@ def LGLControlSpline(cs: int, usize: int, order: int | None = None) -> vf.Vector
     return vf.stack(outs)
 
 
+class FunctionBundle:
+    """Several FunctionEvaluators of one problem evaluated in ONE launch (include/asset_hip.h: asset_hip_bundle_*).  The
+    members keep their own index tables, multiplier vectors and outputs; `eval_device` takes one tensor per member."""
+
+    def __init__(self, evaluators):
+        import ctypes as C
+        self.members = list(evaluators)
+        self.name = jit.ensure_bundle([e.device_name for e in self.members])
+        hs = (C.c_void_p * len(self.members))(*[e._h for e in self.members])
+        self._b = C.c_void_p()
+        _lib.check(_lib.lib().asset_hip_bundle_create(self.name.encode(), hs, len(self.members), C.byref(self._b)),
+                   "asset_hip_bundle_create")
+
+    def bind_device(self, what: int, X, Ls, fxs, agxs, kkts, stream=None):
+        """A zero-argument callable that enqueues the evaluation of every member (arguments converted once)."""
+        import ctypes as C
+        n = len(self.members)
+        VP = C.c_void_p * n
+
+        def arr(ts):
+            return VP(*[None if t is None else (t if isinstance(t, int) else t.data_ptr()) for t in ts])
+        args = (self._b, what, DefectEvaluator._p(X), arr(Ls), arr(fxs), arr(agxs), arr(kkts),
+                None if stream is None else C.c_void_p(stream if isinstance(stream, int) else stream.cuda_stream))
+        fn = _lib.lib().asset_hip_bundle_eval_device
+        keep = (X, Ls, fxs, agxs, kkts)
+
+        def call(_fn=fn, _args=args, _keep=keep):
+            rc = _fn(*_args)
+            if rc:
+                _lib.check(rc, "asset_hip_bundle_eval_device")
+        return call
+
+    def eval_device(self, what: int, X, Ls, fxs, agxs, kkts, stream=None):
+        self.bind_device(what, X, Ls, fxs, agxs, kkts, stream)()
+
+    def close(self):
+        if getattr(self, "_b", None):
+            _lib.lib().asset_hip_bundle_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FunctionEvaluator(DefectEvaluator):
     """``func`` applied to ``X[vindex[V]]`` for every application V, multipliers ``L[cindex[V]]``; device code is
     generated and compiled on first use (jit.ensure_function)."""
@@ -116,6 +163,7 @@ class FunctionEvaluator(DefectEvaluator):
                  appl_consts=None):
         self.func = func
         dev_name = jit.ensure_function(func, name)
+        self.device_name = dev_name
         super().__init__(dev_name, _lib.FUNCTION, False, vindex, cindex, n_primal, n_equal, device)
         if appl_consts is not None:
             self.set_appl_consts(appl_consts)

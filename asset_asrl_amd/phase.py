@@ -329,6 +329,20 @@ class Phase:
             self.transcribe()
         return list(self._iq_evs)
 
+    def function_bundle(self):
+        """Everything the phase hands the solver beside its defects -- the equalities it adds itself, the user's path
+        equalities and inequalities, the integral objectives -- as ONE launch (pathfuncs.FunctionBundle).  Returns
+        (bundle, members) with members = [(kind, evaluator)], kind in {"equality", "inequality", "objective"}: the
+        multiplier vector of an equality is LE, of an inequality LI, of an objective [ObjScale]."""
+        from .pathfuncs import FunctionBundle
+        if self._ev is None:
+            self.transcribe()
+        members = [("equality", e) for e in self._auto_evs.values()] + [("equality", e) for e in self._eq_evs] + \
+                  [("inequality", e) for e in self._iq_evs] + [("objective", e) for e in self._obj_evs]
+        if not members:
+            raise RuntimeError("the phase has no function beside its defects")
+        return FunctionBundle([e for _, e in members]), members
+
     # ---- transcription ------------------------------------------------------------------------
     def transcribe(self):
         if self.ActiveTraj is None:
@@ -355,7 +369,10 @@ class Phase:
         ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
         ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
         ix.begin_indexing(0, 0)
-        self._make_function_evaluators(ix, build_only=True)
+        self._make_function_evaluators(ix, build_only=True)      # (build_only: the lists hold device names, not evaluators)
+        names = list(self._auto_evs.values()) + list(self._eq_evs) + list(self._iq_evs) + list(self._obj_evs)
+        if 1 <= len(names) <= 8:
+            jit.ensure_bundle(names)                              # function_bundle(): the same list in one launch
         self._eq_evs, self._iq_evs, self._obj_evs, self._auto_evs = [], [], [], {}
         return self
 

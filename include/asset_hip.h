@@ -98,6 +98,19 @@ int asset_hip_defect_eval_device(asset_hip_defect_t h, int what, const double* d
  * none. */
 int asset_hip_defect_set_appl_consts(asset_hip_defect_t h, const double* consts, int per_application);
 
+/* Several plain functions in ONE launch.  What a phase hands the solver beside its defects (mesh spacing, control splines,
+ * path constraints, integrands: ODEPhaseBase.cpp:1371-1375 registers them one by one, NonLinearProgram::eval* calls them
+ * one by one) are launch-bound on a GPU when evaluated one after the other.  A bundle is a module compiled for a list of
+ * functors (asset_hip_jit_plugin with kind 3, functor = the comma-separated list, source ending in
+ * ASSET_RTC_BUNDLE(list)); its members are ordinary function handles, given in the order of the list, each with its own
+ * index tables; one call evaluates all of them with the same evaluation kind.  dL / d_fx / d_agx / d_kkt: one device
+ * pointer per member (dL, d_agx, d_kkt or single entries may be NULL as for asset_hip_defect_eval_device). */
+typedef struct asset_hip_bundle* asset_hip_bundle_t;
+int asset_hip_bundle_create(const char* name, const asset_hip_defect_t* members, int n, asset_hip_bundle_t* out);
+int asset_hip_bundle_eval_device(asset_hip_bundle_t b, int what, const double* dX, const double* const* dL,
+                                 double* const* d_fx, double* const* d_agx, double* const* d_kkt, void* stream);
+void asset_hip_bundle_destroy(asset_hip_bundle_t b);
+
 /* Page-locks / releases a caller-owned host range so that the host-pointer entry points move it by DMA at PCIe rate
  * instead of through the driver's pageable staging (about 4x faster for the block arrays).  For buffers that live
  * across evaluations -- the reference's RHS coefficient arrays and KKT value array do (NonLinearProgram.h:330-341,
@@ -182,8 +195,8 @@ int asset_hip_has_kernel(const char* ode, int mode, int blocked);
 int asset_hip_load_plugin(const char* path);
 /* The same, compiled in process (hiprtc) instead of by the compiler driver.  `source` is the generated translation unit:
  * the functor, `#include "<csrc>/rtc_device.h"` and one ASSET_RTC_LGL(functor, mode, blocked, seg_per_group) or
- * ASSET_RTC_FUNC(functor) line; kind 1 = transcription of an ODE, 2 = plain function (mode, blocked, seg_per_group
- * ignored); options = hiprtc options ("--offload-arch=gfx950", "-I...", ...).
+ * ASSET_RTC_FUNC(functor) line; kind 1 = transcription of an ODE, 2 = plain function, 3 = bundle of plain functions (mode,
+ * blocked, seg_per_group ignored); options = hiprtc options ("--offload-arch=gfx950", "-I...", ...).
  *   asset_hip_jit_compile  compiles and writes the code object and the lowered kernel names to cache_path; needs no device.
  *   asset_hip_jit_plugin   registers the module under `name` on the current device: from cache_path when that file
  *                          exists, else by compiling `source` (and writing cache_path when it is not NULL).  0 when

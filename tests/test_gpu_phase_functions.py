@@ -97,3 +97,47 @@ def test_integral_objective_evaluates_the_segment_quadrature(oracle):
     T = ph.ActiveTraj
     expect = sum((T[3 * i + 3, tcol] - T[3 * i, tcol]) * np.dot(wts, T[3 * i:3 * i + 4, 0] ** 2 + T[3 * i:3 * i + 4, 2]) for i in range(nseg))
     assert abs(fx.sum() - expect) < 1e-11 * abs(expect), (fx.sum(), expect)
+
+
+def test_function_bundle_gives_the_blocks_of_the_separate_launches():
+    """Phase.function_bundle(): the mesh-spacing, nodal-spacing and control-spline equalities, a user path equality, a
+    pair-wise inequality and an integral objective in ONE launch -- bit for bit what one launch per function returns, for
+    the three block kinds and the value-only kind."""
+    import torch
+    from asset_asrl_amd.evaluator import CON, JAC_ADJGRAD, JAC_ADJGRAD_HESS
+    nseg = 37
+    w = Workload("reentry", "LGL7", nseg)
+    ph = ShuttleReentry().phase("LGL7", w.traj, nseg)
+    a = vf.Arguments(6)
+    x0, x1, x2, t, u0, u1 = a.tolist()
+    ph.addEqualCon("Path", vf.stack([x0 * x0 + x1 * u0 - vf.sin(x2), u0 * u0 + u1 * u1 - 1.0 + t * x0 * vf.exp(-1.0 * x1)]),
+                   [0, 1, 2, 5, 6, 7])
+    b = vf.Arguments(4)
+    ph.addInequalCon("PairWisePath", vf.stack([b[0] * b[2] - b[1] * b[3] - 0.5]), [0, 1])
+    g = vf.Arguments(2)
+    ph.addIntegralObjective(g.coeff(1) * g.coeff(1) + g.coeff(0), [2, 0])
+    ph.transcribe()
+    bundle, members = ph.function_bundle()
+    assert [k for k, _ in members] == ["equality"] * 4 + ["inequality", "objective"]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    X = torch.from_numpy(ph.solver_input()).to(dev)
+    LE = torch.from_numpy(rng.uniform(-1, 1, ph.numPhaseEqCons)).to(dev)
+    LI = torch.from_numpy(rng.uniform(-1, 1, max(1, ph.numPhaseIqCons))).to(dev)
+    LO = torch.tensor([0.75], dtype=torch.float64, device=dev)
+    Ls = [{"equality": LE, "inequality": LI, "objective": LO}[k] for k, _ in members]
+
+    def outs():
+        return ([torch.full((e.nseg * e.OR,), np.nan, dtype=torch.float64, device=dev) for _, e in members],
+                [torch.full((e.nseg * e.IR,), np.nan, dtype=torch.float64, device=dev) for _, e in members],
+                [torch.full((e.nseg * e.NKKT,), np.nan, dtype=torch.float64, device=dev) for _, e in members])
+    for what in (JAC_ADJGRAD_HESS, JAC_ADJGRAD, CON):
+        fb, gb, kb = outs()
+        bundle.eval_device(what, X, Ls, fb, gb if what != CON else [None] * len(members), kb if what != CON else [None] * len(members))
+        fs, gs, ks = outs()
+        for (_, e), l, f, g_, k in zip(members, Ls, fs, gs, ks):
+            e.eval_device(what, X, l if what != CON else None, f, g_ if what != CON else None, k if what != CON else None)
+        torch.cuda.synchronize()
+        for one, two in zip(fb + (gb + kb if what != CON else []), fs + (gs + ks if what != CON else [])):
+            assert torch.equal(one, two) and not torch.isnan(one).any()
+    bundle.close()

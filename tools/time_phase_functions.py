@@ -47,6 +47,33 @@ def main():
         ms = ev.time_device(JAC_ADJGRAD_HESS, X, lam, fx, agx, kkt, warmup=5, iters=100)
         out[name] = {"applications": ev.nseg, "IR": ev.IR, "OR": ev.OR, "us": round(ms * 1e3, 2),
                      "block_MB": round(ev.nseg * (ev.NKKT + ev.IR + ev.OR) * 8 / 1e6, 2)}
+    # the same functions as ONE launch (Phase.function_bundle)
+    bundle, members = ph.function_bundle()
+    Ls = [Lo if kind == "objective" else L for kind, _ in members]
+    fxs = [torch.empty(e.nseg * e.OR, dtype=torch.float64, device=dev) for _, e in members]
+    agxs = [torch.empty(e.nseg * e.IR, dtype=torch.float64, device=dev) for _, e in members]
+    kkts = [torch.empty(e.nseg * e.NKKT, dtype=torch.float64, device=dev) for _, e in members]
+    st = torch.cuda.Stream()
+    call = bundle.bind_device(JAC_ADJGRAD_HESS, X, Ls, fxs, agxs, kkts, st)
+    with torch.cuda.stream(st):
+        for _ in range(20):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(200):
+            call()
+        e1.record(st)
+        e1.synchronize()
+    out["all functions beside the defects, one bundled launch"] = {"functions": len(members), "us": round(e0.elapsed_time(e1) / 200 * 1e3, 2)}
+    seq = [e.bind_device(JAC_ADJGRAD_HESS, X, l, f, g, k, st) for (_, e), l, f, g, k in zip(members, Ls, fxs, agxs, kkts)]
+    with torch.cuda.stream(st):
+        e0.record(st)
+        for _ in range(200):
+            for c in seq:
+                c()
+        e1.record(st)
+        e1.synchronize()
+    out["the same, one launch per function"] = {"us": round(e0.elapsed_time(e1) / 200 * 1e3, 2)}
     print(json.dumps(out))
 
 
