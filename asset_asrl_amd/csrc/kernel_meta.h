@@ -4,6 +4,7 @@
 // (hiprtc, rtc_device.h) carries it as the device constant `asset_rtc_meta`, which the loader copies back
 // (capi.hip: asset_hip_jit_plugin).  One launcher serves both.
 #pragma once
+#include "defect_adjgrad.h"
 #include "defect_kernels.h"
 #include "defect_units.h"
 #include "defect_wide.h"
@@ -26,6 +27,7 @@ enum MetaField {
   MF_FUSED, MF_GF, MF_FUSED2, MF_GF2, MF_BYTES_FUSED2,
   MF_NUNITS, MF_UNITS_BASE_BYTES, MF_UNITS_SLOT_BYTES, MF_CS,
   MF_LANE_BYTES1, MF_LANE_BYTES2,
+  MF_ADJ_GP, MF_ADJ_LDS_BYTES,   // value + adjoint gradient kernel (defect_adjgrad.h): segments per workgroup, its LDS
   MF_COUNT
 };
 
@@ -47,7 +49,8 @@ struct LglMeta {
       (D::lds_bytes_dense() * ASSET_WIDE_WGS <= 160 * 1024) ? ASSET_WIDE_WGS : 1,
       D::FUSED ? 1 : 0, D::GF, D::FUSED2 ? 1 : 0, D::GF2, (long long)D::lds_bytes_fused2(),
       Ode::NUNITS, (long long)D::TABSZ * 8, (long long)UD::MS * 8, D::CS,
-      lgl_lane_table_bytes<Ode, SCH, BLOCKED>(1), lgl_lane_table_bytes<Ode, SCH, BLOCKED>(2)};
+      lgl_lane_table_bytes<Ode, SCH, BLOCKED>(1), lgl_lane_table_bytes<Ode, SCH, BLOCKED>(2),
+      AdjDims<D>::GP, (long long)AdjDims<D>::lds_bytes()};
 };
 
 template <class F>

@@ -39,7 +39,8 @@ constexpr int K_WIDE_SETUP = 28, K_LANE_SETUP1 = 29, K_LANE_SETUP2 = 30, K_UNITS
 constexpr int K_MESH_YVEC = 33, K_MESH_ERROR = 34;
 constexpr int K_FUNC(int level, bool asmb) { return 35 + level * 2 + (asmb ? 1 : 0); }                           // 35..40
 constexpr int K_BUNDLE(int level) { return 41 + level; }                                                         // 41..43
-constexpr int K_COUNT = 44;
+constexpr int K_ADJGRAD = 44;   // value + adjoint gradient without a Jacobian (defect_adjgrad.h)
+constexpr int K_COUNT = 45;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -128,6 +129,12 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
     return klaunch(t.k[K_LGL(lv, 2, asmb)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);
   };
   hipError_t e;
+  // constraints_adjointgradient (evalRHS): value and J^T lam wanted, no Jacobian -- one launch of the vector-Jacobian kernel
+  static const bool no_adj = std::getenv("ASSET_HIP_NO_ADJGRAD_KERNEL") != nullptr;                            // tuning only
+  if (level == 1 && !a.KKT && !a.kmap && a.AGX && a.L && !no_adj && t.k[K_ADJGRAD]) {
+    const int gp = int(m[MF_ADJ_GP]);
+    return klaunch(t.k[K_ADJGRAD], dim3((a.nseg + gp - 1) / gp), dim3(64), size_t(m[MF_ADJ_LDS_BYTES]), st, kargs);
+  }
   switch (level) {
     case 0: return ode_stage(0);
     case 1:
@@ -250,6 +257,7 @@ const KernelTable* lgl_static_table() {
       r.k[K_UNITS0].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 0>);
       r.k[K_UNITS1].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 1>);
     }
+    r.k[K_ADJGRAD].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED>);
     r.k[K_MESH_YVEC].host = ASSET_KPTR(mesh_yvec_kernel<Ode, SCH, BLOCKED>);
     r.k[K_MESH_ERROR].host = ASSET_KPTR(mesh_error_kernel<0>);
     return r;
@@ -324,6 +332,7 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
   if (slot == K_LANE_SETUP2) return "asset_hip::lane_setup_kernel<" + lgl + ", 2>";
   if (slot == K_UNITS0) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 0>";
   if (slot == K_UNITS1) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 1>";
+  if (slot == K_ADJGRAD) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ">";
   if (slot == K_MESH_YVEC) return "asset_hip::mesh_yvec_kernel<" + lgl + ">";
   if (slot == K_MESH_ERROR) return "asset_hip::mesh_error_kernel<0>";
   return "";
