@@ -37,6 +37,8 @@ WORKLOADS = {
     "betts_lgl5_1k": ("betts_lowthrust", "LGL5", 1000, False),            # BASELINE.json configs[1]
     "twobody_lgl5_blocked_10k": ("twobody_lt", "LGL5", 10000, True),      # configs[3] dynamics as one phase
     "brachistochrone_lgl3_40": ("brachistochrone", "LGL3", 40, False),    # configs[0]
+    "twobody_lgl7_10k": ("twobody_lt", "LGL7", 10000, False),            # mid-width shapes (32 < IR < 64): IR = 40
+    "betts_lgl7_5k": ("betts_lowthrust", "LGL7", 5000, False),            #                                   IR = 45
     "reentry_lgl7_100k": ("reentry", "LGL7", 100000, False),
     "reentry_lgl7_1m": ("reentry", "LGL7", 1000000, False),               # HBM-resident (8.8 GB of blocks)
     "synthetic32_lgl7_100k": ("synthetic32", "LGL7", 100000, False),      # BASELINE.json configs[4]
