@@ -51,7 +51,9 @@ struct OdeOutG {    // only g (the value of a cardinal node is already in LDS)
   __device__ void save(int, double) {}
 };
 
-template <class Ode, int SCH, bool BLOCKED>
+// ADJ = false: the value-only kind (constraints, evalOCC) through the same phases without the gradient parts -- nothing
+// goes through the workspace (the value path of lgl_defect_kernel writes f_j and f^_i to the slots and reads them back).
+template <class Ode, int SCH, bool BLOCKED, bool ADJ = true>
 __global__ __launch_bounds__(64) void lgl_adjgrad_kernel(EvalArgs a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using AD = AdjDims<D>;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(64) void lgl_adjgrad_kernel(EvalArgs a) {
     }
     for (int e = lane; e < gcount * OR; e += 64) {
       const int g = e / OR, r = e - g * OR;
-      mir[g * MS + AD::m_lam + r] = a.L ? a.L[cseg[e]] : 0.0;
+      mir[g * MS + AD::m_lam + r] = (ADJ && a.L) ? a.L[cseg[e]] : 0.0;
     }
     if constexpr (D::TRAP) {   // no interior evaluation: its value and gradient read as zero
       for (int e = lane; e < gcount * (K * n + K * N); e += 64) {
@@ -123,13 +125,18 @@ __global__ __launch_bounds__(64) void lgl_adjgrad_kernel(EvalArgs a) {
 #pragma unroll
       for (int k = 0; k < n; k++) li[k] = M[AD::m_lam + i * n + k];
       RegIn<D> in{y, li};
-      OdeOutFG<true> out{M + AD::m_If + i * n, M + AD::m_Ig + i * N};
-      Ode::fjgh(in, out);
+      if constexpr (ADJ) {
+        OdeOutFG<true> out{M + AD::m_If + i * n, M + AD::m_Ig + i * N};
+        Ode::fjgh(in, out);
+      } else {
+        OdeOutFG<false> out{M + AD::m_If + i * n, nullptr};
+        Ode::f(in, out);
+      }
     }
     wave_lds_sync();
   }
   // ---- cardinal nodes: g_j = (d f_j)^T w_j
-  if (lane < gcount * CS) {
+  if (ADJ && lane < gcount * CS) {
     const int g = lane / CS, j = lane - g * CS;
     lds_double* M = mir + g * MS;
     const lds_double* z = M + AD::m_z;
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(64) void lgl_adjgrad_kernel(EvalArgs a) {
   }
   // ---- the two inner products per interior that the t_0 / t_f entries need (one lane per interior, straight-line: inside
   //      the entry loop below they were a 60-trip chain of dependent LDS reads that every pass of the wave waited for)
-  if (lane < gcount * K) {
+  if (ADJ && lane < gcount * K) {
     const int g = lane / K, i = lane - g * K;
     lds_double* M = mir + g * MS;
     double lsd = 0.0, gb = 0.0;
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(64) void lgl_adjgrad_kernel(EvalArgs a) {
     }
   }
   // ---- adjoint gradient
-  if (a.AGX) {
+  if (ADJ && a.AGX) {
     for (int e = lane; e < gcount * IR; e += 64) {
       const int g = e / IR, c = e - g * IR;
       const lds_double* M = mir + g * MS;

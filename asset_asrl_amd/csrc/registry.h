@@ -40,7 +40,8 @@ constexpr int K_MESH_YVEC = 33, K_MESH_ERROR = 34;
 constexpr int K_FUNC(int level, bool asmb) { return 35 + level * 2 + (asmb ? 1 : 0); }                           // 35..40
 constexpr int K_BUNDLE(int level) { return 41 + level; }                                                         // 41..43
 constexpr int K_ADJGRAD = 44;   // value + adjoint gradient without a Jacobian (defect_adjgrad.h)
-constexpr int K_COUNT = 45;
+constexpr int K_VALUE = 45;     // value only, the same kernel without the gradient parts
+constexpr int K_COUNT = 46;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -134,6 +135,10 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
   if (level == 1 && !a.KKT && !a.kmap && a.AGX && a.L && !no_adj && t.k[K_ADJGRAD]) {
     const int gp = int(m[MF_ADJ_GP]);
     return klaunch(t.k[K_ADJGRAD], dim3((a.nseg + gp - 1) / gp), dim3(64), size_t(m[MF_ADJ_LDS_BYTES]), st, kargs);
+  }
+  if (level == 0 && !no_adj && t.k[K_VALUE]) {   // constraints (evalOCC): the same kernel without its gradient parts
+    const int gp = int(m[MF_ADJ_GP]);
+    return klaunch(t.k[K_VALUE], dim3((a.nseg + gp - 1) / gp), dim3(64), size_t(m[MF_ADJ_LDS_BYTES]), st, kargs);
   }
   switch (level) {
     case 0: return ode_stage(0);
@@ -257,7 +262,8 @@ const KernelTable* lgl_static_table() {
       r.k[K_UNITS0].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 0>);
       r.k[K_UNITS1].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 1>);
     }
-    r.k[K_ADJGRAD].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED>);
+    r.k[K_ADJGRAD].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED, true>);
+    r.k[K_VALUE].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED, false>);
     r.k[K_MESH_YVEC].host = ASSET_KPTR(mesh_yvec_kernel<Ode, SCH, BLOCKED>);
     r.k[K_MESH_ERROR].host = ASSET_KPTR(mesh_error_kernel<0>);
     return r;
@@ -332,7 +338,8 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
   if (slot == K_LANE_SETUP2) return "asset_hip::lane_setup_kernel<" + lgl + ", 2>";
   if (slot == K_UNITS0) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 0>";
   if (slot == K_UNITS1) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 1>";
-  if (slot == K_ADJGRAD) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ">";
+  if (slot == K_ADJGRAD) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ", true>";
+  if (slot == K_VALUE) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ", false>";
   if (slot == K_MESH_YVEC) return "asset_hip::mesh_yvec_kernel<" + lgl + ">";
   if (slot == K_MESH_ERROR) return "asset_hip::mesh_error_kernel<0>";
   return "";
