@@ -282,8 +282,15 @@ def main():
     host_visible = None
     if nphases == 1 and nseg * (OR + IR + NKKT) * 8 <= 4 << 30:
         k3 = max(5, min(a.steps, 50))
+        ok = 1
         if use_dist:
-            sh.alloc_host_shared(barrier_group=gloo_group)
+            try:
+                sh.alloc_host_shared(barrier_group=gloo_group)
+            except Exception as exc:                      # (e.g. no /dev/shm, page-locking refused): report, do not lose the run
+                ok, host_visible = 0, {"error": f"shared host buffer unavailable: {exc}"}
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # every rank takes the same branch
+            ok = int(flag.item())
 
             def host_step():
                 evaluate()
@@ -300,12 +307,15 @@ def main():
                 hkkt.copy_(kkt, non_blocking=True)
                 stream.synchronize()
             bytes_rank = (fx.numel() + agx.numel() + kkt.numel()) * 8
-        th = timed(host_step, k3, 2) / k3
-        host_visible = {"ms_per_step": th * 1e3, "segments_per_s": total_segments / th, "bytes_per_rank": bytes_rank,
-                        "path": "evaluation, then every rank's FX/AGX/KKT blocks device-to-host over its own PCIe link into "
-                                "one page-locked host buffer shared by the ranks; barrier"}
-        if use_dist:
-            sh._host.close()
+        if ok:
+            th = timed(host_step, k3, 2) / k3
+            host_visible = {"ms_per_step": th * 1e3, "segments_per_s": total_segments / th, "bytes_per_rank": bytes_rank,
+                            "path": "evaluation, then every rank's FX/AGX/KKT blocks device-to-host over its own PCIe link into "
+                                    "one page-locked host buffer shared by the ranks; barrier"}
+            if use_dist:
+                sh._host.close()
+        elif host_visible is None:
+            host_visible = {"error": "shared host buffer unavailable on another rank"}
 
     bseg = algorithmic_bytes_per_segment(IR, OR)
     achieved = local_segments * bseg / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
