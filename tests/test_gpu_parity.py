@@ -118,6 +118,21 @@ def test_launch_form_boundaries(oracle, ode, mode, blocked, nseg):
     ev.close()
 
 
+@pytest.mark.parametrize("ode,mode,blocked,nseg", [("reentry", "LGL7", False, 1), ("reentry", "LGL7", False, 17),
+                                                   ("reentry", "LGL7", False, 4099), ("twobody_lt", "LGL5", True, 43),
+                                                   ("betts_lowthrust", "LGL5", True, 22), ("betts_lowthrust", "Trapezoidal", False, 33),
+                                                   ("synthetic32", "LGL7", False, 20), ("brachistochrone", "LGL3", False, 65)])
+def test_value_and_adjoint_gradient_kernel_on_ragged_groups(oracle, ode, mode, blocked, nseg):
+    """evalOCC / evalRHS go through the vector-Jacobian kernel (csrc/defect_adjgrad.h: no Jacobian is formed): group sizes
+    that leave a ragged last workgroup, controls as parameters, a phase parameter, the Trapezoidal form, a wide ODE."""
+    w = Workload(ode, mode, nseg, blocked, var_offset=2, con_offset=1, extra_vars=3)
+    nlp = w.oracle_nlp(oracle, threads=4)
+    ev = DefectEvaluator(ode, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    for what in (CON, CON_ADJGRAD):
+        _check_blocks(ev.eval(what, w.X, w.L if what == CON_ADJGRAD else None), nlp.eval_blocks(what, w.X, w.L), w, what)
+    ev.close()
+
+
 @pytest.mark.parametrize("mode,nseg", [("LGL7", 1), ("LGL7", 2), ("LGL7", 3), ("LGL7", 257), ("LGL5", 1), ("LGL5", 511), ("LGL3", 513)])
 def test_ragged_segment_counts_wide_shapes(oracle, mode, nseg):
     """The four-wave dense kernel (csrc/defect_wide.h): fewer segments than workgroups, one segment, counts that leave
