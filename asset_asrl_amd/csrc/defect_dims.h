@@ -191,7 +191,7 @@ constexpr bool lgl_variant_valid() {
   if (STAGE == 1) return true;                 // ODE stage (and the whole value-only kind): every shape
   if (D::WIDE) return false;                   // wide shapes: dense stage in defect_wide.h
   if (STAGE == 2) return LEVEL >= 1;
-  if (STAGE == 3) return D::FUSED && LEVEL == 2;
+  if (STAGE == 3) return D::FUSED && LEVEL >= 1;
   if (STAGE == 4) return D::FUSED2 && LEVEL == 2;
   return false;
 }

@@ -428,6 +428,73 @@ __device__ inline void pipe_ode_group(const EvalArgs& a, int lane, int seg0, int
   PTS();             // copy-out of P3 and of the mirror issued
 }
 
+// The ODE stage of one group for the Jacobian kinds (derivative level 1) inside the fused kernel: gather, cardinal f_j and
+// J_j, interior f^_i, J^_i and g^_i = J^_i^T lam_i (accumulated while J^_i is emitted) -- the phases of the plain ODE-stage
+// launch on the group's GP <= GF segments, rows and mirror in the LDS the dense phase uses afterwards.
+template <class Ode, class D, int GP, class Pub>
+__device__ inline void plain_ode_group_l1(const EvalArgs& a, int lane, int seg0, int gcount, double* Wg, double* stage,
+                                          lds_double* mirror, const LglTab* tabp, Pub&& publish_tables) {
+  constexpr int CS = D::CS, K = D::K, IR = D::IR, OR = D::OR, STG_LD = D::STG_LD;
+  static_assert(GP * CS <= 64 && D::STAGED && D::MIRROR, "one pass per phase, staged rows, mirror");
+  {   // P0: gather into the slots (the dense phase reads z, lam there) and the mirror (the interior phase does)
+    constexpr int NZ = (GP * IR + 63) / 64, NL = (GP * OR + 63) / 64;
+    const int* vseg = a.vindex + size_t(seg0) * IR;
+    const int* cseg = a.cindex + size_t(seg0) * OR;
+    int vi[NZ], ci[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) vi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : -1;
+#pragma unroll
+    for (int t = 0; t < NL; t++) ci[t] = (a.L && lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : -1;
+    double zv[NZ], lv[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) zv[t] = (vi[t] >= 0) ? a.X[vi[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NL; t++) lv[t] = (ci[t] >= 0) ? a.L[ci[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NZ; t++) {
+      const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
+      if (e < gcount * IR) {
+        Wg[g * D::WSLOT + D::w_z + r] = zv[t];
+        mirror[g * D::MSLOT + D::m_z + r] = zv[t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
+      if (e < gcount * OR) {
+        Wg[g * D::WSLOT + D::w_lam + r] = lv[t];
+        mirror[g * D::MSLOT + D::m_lam + r] = lv[t];
+      }
+    }
+  }
+  // P1: cardinal f_j (slot + mirror) and J_j (row), then the rows to the slots
+  if (lane < gcount * CS) {
+    const int g = lane / CS, j = lane - g * CS;
+    cardinal_eval1<Ode, D, 1, true>(Wg + g * D::WSLOT, mirror + g * D::MSLOT, j, (lds_double*)(stage + lane * STG_LD), a.X,
+                                    a.vindex + size_t(seg0 + g) * IR);
+  }
+  wave_lds_sync();
+  copy_rows<(D::NZJ > 0 ? D::NZJ : 1)>(stage, STG_LD, D::NZJ > 0 ? gcount * CS : 0, 0, lane, [&](int ee, int k) {
+    const int g = ee / CS, j = ee - g * CS;
+    return Wg + g * D::WSLOT + D::w_CJ + j * D::NZJ + k;
+  });
+  wave_lds_sync();
+  publish_tables();
+  // P2: interior f^_i, J^_i (row), g^_i (slot)
+  if constexpr (!D::TRAP) {
+    if (lane < gcount * K) {
+      const int g = lane / K, i = lane - g * K;
+      interior_eval<Ode, D, 1, true>(Wg + g * D::WSLOT, mirror + g * D::MSLOT, i, tabp, (lds_double*)(stage + lane * STG_LD));
+    }
+    wave_lds_sync();
+    copy_rows<(D::NZJ > 0 ? D::NZJ : 1)>(stage, STG_LD, D::NZJ > 0 ? gcount * K : 0, 0, lane, [&](int ee, int k) {
+      const int g = ee / K, i = ee - g * K;
+      return Wg + g * D::WSLOT + D::w_IJ + i * D::NZJ + k;
+    });
+    wave_lds_sync();
+  }
+}
+
 // The ODE stage of a TWO-WAVE workgroup (fused kernel, STAGE 4): the group is both waves' segments, wave 0 evaluates the
 // cardinal phases (P1, P3), wave 1 the interior phase (P2) and the copy-out of its rows.  The generated bodies are bound
 // by instruction issue, whatever the number of active lanes: one wave with 40 points costs the SIMD it runs on as much as
@@ -706,7 +773,7 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
   double* slotb = body;
   double* scr = body + D::WSLOTD;
   double* stage = body;
-  static_assert(STAGE != 3 || (D::FUSED && LEVEL == 2), "no fused kernel for this shape / level");
+  static_assert(STAGE != 3 || (D::FUSED && LEVEL >= 1), "no fused kernel for this shape / level");
   static_assert(STAGE != 4 || (D::FUSED2 && LEVEL == 2), "no two-wave fused kernel for this shape / level");
   constexpr bool MIR = D::MIRROR && LEVEL >= 1 && STAGE == 1;
 #ifndef ASSET_ODE_PIPE
@@ -775,8 +842,12 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
   if constexpr (STAGE == 3) {
     // the workgroup's segments are one group (the host sizes the grid so): ODE stage first, while the kernel holds
     // nothing else in registers; its results go to the slots and are read back below once the stores have landed
-    pipe_ode_group<Ode, D, D::GF>(a, lane, wg_first, min(wg_count, D::GF), a.work + size_t(wg_first) * D::WSLOT, stage, mirror,
-                                  &tab, publish_tables ASSET_PTS_ARGS);
+    if constexpr (LEVEL == 2)
+      pipe_ode_group<Ode, D, D::GF>(a, lane, wg_first, min(wg_count, D::GF), a.work + size_t(wg_first) * D::WSLOT, stage, mirror,
+                                    &tab, publish_tables ASSET_PTS_ARGS);
+    else   // the Jacobian kinds (evalSOE / evalAUG)
+      plain_ode_group_l1<Ode, D, D::GF>(a, lane, wg_first, min(wg_count, D::GF), a.work + size_t(wg_first) * D::WSLOT, stage, mirror,
+                                        &tab, publish_tables);
   }
   if constexpr (STAGE == 4) {
     const int s0 = share - wave, first0 = s0 * per + min(s0, rem);            // the pair's first segment and count

@@ -142,9 +142,13 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
   }
   switch (level) {
     case 0: return ode_stage(0);
-    case 1:
+    case 1: {
+      static const bool no_fuse1 = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                                // tuning only
+      if (m[MF_FUSED] && !no_fuse1 && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]) && t.k[K_LGL(1, 3, a.kmap != nullptr)])
+        return klaunch(t.k[K_LGL(1, 3, a.kmap != nullptr)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);   // one launch
       if ((e = ode_stage(1)) != hipSuccess || skip_dense) return e;
       return dense_stage(1);
+    }
     case 2: {
       if (m[MF_FUSED]) {
         // single launch when every workgroup's share fits one group of the fused kernel (defect_kernels.h, STAGE 3)
@@ -255,6 +259,8 @@ const KernelTable* lgl_static_table() {
       if constexpr (D::FUSED) {
         r.k[K_LGL(2, 3, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 3, false>);
         r.k[K_LGL(2, 3, true)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 3, true>);
+        r.k[K_LGL(1, 3, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 1, 3, false>);
+        r.k[K_LGL(1, 3, true)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 1, 3, true>);
       }
       if constexpr (D::FUSED2) r.k[K_LGL(2, 4, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 4, false>);
     }
@@ -325,7 +331,7 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
     for (int stg = 1; stg <= 4; stg++)
       for (int as = 0; as <= 1; as++) {
         if (slot != K_LGL(lv, stg, as != 0)) continue;
-        const bool used = (stg == 1 && !as) || (stg == 2 && lv >= 1) || (stg == 3 && lv == 2) || (stg == 4 && lv == 2 && !as);
+        const bool used = (stg == 1 && !as) || (stg == 2 && lv >= 1) || (stg == 3 && lv >= 1) || (stg == 4 && lv == 2 && !as);
         if (!used) return "";
         return "asset_hip::lgl_defect_kernel<" + lgl + ", " + std::to_string(g) + ", " + std::to_string(lv) + ", " +
                std::to_string(stg) + ", " + tf(as != 0) + ">";
