@@ -244,28 +244,27 @@ class Phase:
         units += [1.0] * (func.IRows() - len(units))
         return IOScaled(func, units, np.ones(func.ORows()))
 
-    def _make_function_evaluators(self, ix, build_only: bool = False):
-        from .pathfuncs import FunctionEvaluator as _FE
-
-        def FunctionEvaluator(F, name, *args, **kw):      # build_only: device code only (no handle: works without a GPU)
-            return jit.ensure_function(F, name) if build_only else _FE(F, name, *args, **kw)
-        self._eq_evs, self._iq_evs = [], []
-        next_eq, next_iq = ix.con_offset + ix.numPhaseEqCons, 0
-        # ---- what the phase registers itself, right after the defects (transcribe_phase, ODEPhaseBase.cpp:1371-1375:
-        #      dynamics, axis functions, control functions, integrals, user functions): mesh spacing, then control splines
+    def _function_tables(self, ix):
+        """Host-only: every function the phase hands the solver beside its defects, with its index tables, in the
+        reference's registration order (transcribe_phase, ODEPhaseBase.cpp:1371-1375: dynamics, axis functions, control
+        functions, integrals, user functions).  Returns (entries, numPhaseEqCons, numPhaseIqCons); an entry is
+        (kind, tag, function, device name, Vindex, Cindex, per-application constants or None), kind in
+        {"auto", "equality", "inequality", "objective"}."""
         from .pathfuncs import LGLControlSpline, LGLIntegral, LGLMeshSpacing, SingleMeshSpacing
+        next_eq, next_iq = ix.con_offset + ix.numPhaseEqCons, 0
         cs, D, tv = ix.DefectCardinalStates, ix.numDefects, [self.ode.TVar()]
-        auto = []
+        out = []
         if self.EnableMeshSpacing:
             if self.TranscriptionMode in ("LGL5", "LGL7"):     # transcribe_axis_funcs: LGLMeshSpacing<CS> over DefectPath
                 V, Cx, next_eq = ix.make_Vindex_Cindex("DefectPath", tv, (), (), cs - 2, next_eq)
-                auto.append(("mesh_spacing", LGLMeshSpacing(cs), f"lglmeshspacing{cs}", V, Cx))
+                out.append(("auto", "mesh_spacing", LGLMeshSpacing(cs), f"lglmeshspacing{cs}", V, Cx, None))
             if D >= 2:
                 # SingleMeshSpacing(i / D) at the inner nodal states i = 1..D-1 (FrontNodalBackPath; the reference adds one
                 # function object per state, addPartitionedEquality): ONE device function whose spacing is a constant of the
                 # application (vf.ApplConst), so the D - 1 relations are one batched evaluator
                 V, Cx, next_eq = ix.make_Vindex_Cindex("FrontNodalBackPath", tv, (), (), 1, next_eq)
-                auto.append(("nodal_spacing", SingleMeshSpacing(None), "nodalmeshspacing", V, Cx))
+                out.append(("auto", "nodal_spacing", SingleMeshSpacing(None), "nodalmeshspacing", V, Cx,
+                            (np.arange(1, D) / D)[:, None]))               # cspace of one bin (:963-970)
         if self.ode.UVars() > 0 and not self._blocked() and D >= 2:   # transcribe_control_funcs
             order = {("LGL7", "HighestOrderSpline"): 2, ("LGL7", "FirstOrderSpline"): 1, ("LGL5", "HighestOrderSpline"): 1,
                      ("LGL5", "FirstOrderSpline"): 1}.get((self.TranscriptionMode, self.ControlMode))
@@ -273,8 +272,13 @@ class Phase:
                 tu = tv + list(range(self.ode.TVar() + 1, self.ode.TVar() + 1 + self.ode.UVars()))
                 F = LGLControlSpline(cs, self.ode.UVars(), order)
                 V, Cx, next_eq = ix.make_Vindex_Cindex("DefectPairWisePath", tu, (), (), F.ORows(), next_eq)
-                auto.append(("control_spline", F, f"lglcontrolspline{cs}_{self.ode.UVars()}_{order}", V, Cx))
-        todo = []
+                out.append(("auto", "control_spline", F, f"lglcontrolspline{cs}_{self.ode.UVars()}_{order}", V, Cx, None))
+        # integral objectives: LGLIntegral over every defect (ODEPhaseBase.cpp:743-889)
+        for k, (integrand, xtuv, opv, spv) in enumerate(self._integral_objs):
+            f = LGLIntegral(integrand, cs, len(xtuv), len(opv) + len(spv))
+            V, _, _ = ix.make_Vindex_Cindex("DefectPath", xtuv + tv, opv, spv, 0, 0)
+            Cx = np.zeros((V.shape[0], 1), dtype=np.int32)           # every application reads multiplier 0 = ObjScale
+            out.append(("objective", f"obj{k}", f, f"obj{k}_integral{cs}", V, Cx, None))
         for store, is_eq in ((self._eq_funcs, True), (self._iq_funcs, False)):
             for k, (region, func, xtuv, opv, spv) in enumerate(store):
                 f = self._scaled_func(region, func, xtuv, opv)
@@ -283,24 +287,39 @@ class Phase:
                     next_eq = nxt
                 else:
                     next_iq = nxt
-                todo.append((is_eq, f, f"{'eq' if is_eq else 'iq'}{k}_{region.lower()}", V, Cx))
+                out.append(("equality" if is_eq else "inequality", f"{'eq' if is_eq else 'iq'}{k}", f,
+                            f"{'eq' if is_eq else 'iq'}{k}_{region.lower()}", V, Cx, None))
+        return out, next_eq - ix.con_offset, next_iq
+
+    def _make_function_evaluators(self, ix, build_only: bool = False):
+        from .pathfuncs import FunctionEvaluator as _FE
+
+        def FunctionEvaluator(F, name, *args, **kw):      # build_only: device code only (no handle: works without a GPU)
+            return jit.ensure_function(F, name) if build_only else _FE(F, name, *args, **kw)
+        entries, self.numPhaseEqCons, self.numPhaseIqCons = self._function_tables(ix)
         # every equality evaluator (the defects included) takes the phase's whole equality multiplier vector
-        self.numPhaseEqCons, self.numPhaseIqCons = next_eq - ix.con_offset, next_iq
-        for is_eq, f, name, V, Cx in todo:
-            ev = FunctionEvaluator(f, name, V, Cx, ix.numPhaseVars, next_eq if is_eq else next_iq, self.device)
-            (self._eq_evs if is_eq else self._iq_evs).append(ev)
-        self._auto_evs = {}
-        for tag, F, name, V, Cx in auto:
-            consts = (np.arange(1, D) / D)[:, None] if tag == "nodal_spacing" else None    # cspace of one bin (:963-970)
-            self._auto_evs[tag] = FunctionEvaluator(F, name, V, Cx, ix.numPhaseVars, next_eq, self.device, appl_consts=consts)
-        # ---- integral objectives: LGLIntegral over every defect (ODEPhaseBase.cpp:743-889)
-        self._obj_evs = []
-        for k, (integrand, xtuv, opv, spv) in enumerate(self._integral_objs):
-            f = LGLIntegral(integrand, cs, len(xtuv), len(opv) + len(spv))
-            V, _, _ = ix.make_Vindex_Cindex("DefectPath", xtuv + tv, opv, spv, 0, 0)
-            Cx = np.zeros((V.shape[0], 1), dtype=np.int32)           # every application reads multiplier 0 = ObjScale
-            self._obj_evs.append(FunctionEvaluator(f, f"obj{k}_integral{cs}", V, Cx, ix.numPhaseVars, 1,
-                                                   self.device))
+        n_eq, n_iq = ix.con_offset + self.numPhaseEqCons, self.numPhaseIqCons
+        self._eq_evs, self._iq_evs, self._obj_evs, self._auto_evs = [], [], [], {}
+        for kind, tag, F, name, V, Cx, consts in entries:
+            ncon = {"auto": n_eq, "equality": n_eq, "inequality": n_iq, "objective": 1}[kind]
+            kw = {"appl_consts": consts} if consts is not None else {}
+            ev = FunctionEvaluator(F, name, V, Cx, ix.numPhaseVars, ncon, self.device, **kw)
+            if kind == "auto":
+                self._auto_evs[tag] = ev
+            else:
+                {"equality": self._eq_evs, "inequality": self._iq_evs, "objective": self._obj_evs}[kind].append(ev)
+
+    def layout(self):
+        """Host-only description of what the phase hands the solver (no device needed): the PhaseIndexer, the defect
+        tables and the entries of ``_function_tables``.  -> (indexer, (Vindex, Cindex) of the defects, entries,
+        numPhaseEqCons, numPhaseIqCons)."""
+        if self.ActiveTraj is None:
+            raise RuntimeError("No trajectory set: call setTraj first")
+        ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
+        ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
+        ix.begin_indexing(0, 0)
+        entries, neq, niq = self._function_tables(ix)
+        return ix, ix.make_defect_Vindex_Cindex(), entries, neq, niq
 
     @property
     def equality_evaluators(self):

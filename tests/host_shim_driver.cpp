@@ -93,38 +93,76 @@ struct FnDesc {
   int mode, blocked, ir, orr, nappl;
   const int* vindex;   // [ir x nappl] column-major
   const int* cindex;   // [orr x nappl]; objectives: ignored (all applications read multiplier 0 = ObjScale)
+  const double* consts;   // per-application constants [nappl][nconst] of a function built with vf.ApplConst, or null
+  int nconst;
 };
 
-// level: 0 evalOCC, 1 evalRHS, 2 evalSOE, 3 evalAUG, 4 evalKKT.  Returns nnz (or -1); *val = objective value.
-extern "C" int fullnlp_run(const FnDesc* fns, int nfn, int primal, int equal, int inequal, int level, double ObjScale,
-                           const double* X, const double* LE, const double* LI, const double* solver_coeffs,
-                           int* outer, int* inner, int inner_cap, int* locs, int locs_cap, double* val, double* PGX,
-                           double* AGX, double* FXE, double* FXI, double* kkt_vals, char* err, int errcap) {
+// A program that stays alive between evaluations (a solver loop calls it once per iteration).
+struct FullNlp {
+  std::vector<SolverIndexingData> datas;
+  std::vector<std::unique_ptr<BatchedDefectConstraint>> cons;
+  std::unique_ptr<KktAssembly> nlp;
+};
+
+static void set_err(char* err, int errcap, const char* what) {
+  if (err && errcap > 0) { std::strncpy(err, what, errcap - 1); err[errcap - 1] = 0; }
+}
+
+extern "C" void* fullnlp_create(const FnDesc* fns, int nfn, int primal, int equal, int inequal, char* err, int errcap) {
   try {
-    std::vector<SolverIndexingData> datas(nfn);
-    std::vector<std::unique_ptr<BatchedDefectConstraint>> cons;
+    std::unique_ptr<FullNlp> p(new FullNlp);
+    p->datas.resize(nfn);
     for (int k = 0; k < nfn; k++) {
       const FnDesc& f = fns[k];
-      SolverIndexingData& d = datas[k];
+      SolverIndexingData& d = p->datas[k];
       d.input_size = f.ir, d.output_size = f.orr, d.num_funcappl = f.nappl;
       d.Vindex.assign(f.vindex, f.vindex + size_t(f.ir) * f.nappl);
       if (f.kind == 0) d.Cindex.assign(size_t(f.orr) * f.nappl, 0);
       else d.Cindex.assign(f.cindex, f.cindex + size_t(f.orr) * f.nappl);
       const int ncon = f.kind == 0 ? 1 : (f.kind == 1 ? equal : inequal);
-      cons.emplace_back(new BatchedDefectConstraint(f.name, f.mode, f.blocked != 0, d, primal, ncon, 0));
+      p->cons.emplace_back(new BatchedDefectConstraint(f.name, f.mode, f.blocked != 0, d, primal, ncon, 0));
+      if (f.consts && f.nconst > 0) p->cons.back()->set_appl_consts(f.consts, f.nconst);
     }
-    KktAssembly nlp(primal, equal, inequal);
+    p->nlp.reset(new KktAssembly(primal, equal, inequal));
     for (int k = 0; k < nfn; k++) {
-      if (fns[k].kind == 0) nlp.add_objective(*cons[k], datas[k]);
-      else if (fns[k].kind == 1) nlp.add_equality(*cons[k], datas[k]);
-      else nlp.add_inequality(*cons[k], datas[k]);
+      if (fns[k].kind == 0) p->nlp->add_objective(*p->cons[k], p->datas[k]);
+      else if (fns[k].kind == 1) p->nlp->add_equality(*p->cons[k], p->datas[k]);
+      else p->nlp->add_inequality(*p->cons[k], p->datas[k]);
     }
-    nlp.analyze();
-    if (nlp.nnz() > inner_cap || int(nlp.kkt_locations().size()) > locs_cap) throw std::runtime_error("capacity too small");
-    std::memcpy(outer, nlp.outer().data(), sizeof(int) * (nlp.kkt_dim() + 1));
-    std::memcpy(inner, nlp.inner().data(), sizeof(int) * nlp.nnz());
-    std::memcpy(locs, nlp.kkt_locations().data(), sizeof(int) * nlp.kkt_locations().size());
-    if (solver_coeffs) std::memcpy(nlp.solver_coeffs().data(), solver_coeffs, sizeof(double) * nlp.num_solver_kkt());
+    p->nlp->analyze();
+    return p.release();
+  } catch (const std::exception& e) {
+    set_err(err, errcap, e.what());
+    return nullptr;
+  }
+}
+
+extern "C" void fullnlp_destroy(void* h) { delete static_cast<FullNlp*>(h); }
+
+// sizes: [kkt_dim, nnz, number of KKT locations (user slots + solver slots), number of solver slots]
+extern "C" void fullnlp_sizes(void* h, int* out) {
+  KktAssembly& nlp = *static_cast<FullNlp*>(h)->nlp;
+  out[0] = nlp.kkt_dim(), out[1] = nlp.nnz(), out[2] = int(nlp.kkt_locations().size()), out[3] = nlp.num_solver_kkt();
+}
+
+extern "C" void fullnlp_structure(void* h, int* outer, int* inner, int* locs) {
+  KktAssembly& nlp = *static_cast<FullNlp*>(h)->nlp;
+  std::memcpy(outer, nlp.outer().data(), sizeof(int) * (nlp.kkt_dim() + 1));
+  std::memcpy(inner, nlp.inner().data(), sizeof(int) * nlp.nnz());
+  std::memcpy(locs, nlp.kkt_locations().data(), sizeof(int) * nlp.kkt_locations().size());
+}
+
+extern "C" void fullnlp_set_solver_coeffs(void* h, const double* c) {
+  KktAssembly& nlp = *static_cast<FullNlp*>(h)->nlp;
+  std::memcpy(nlp.solver_coeffs().data(), c, sizeof(double) * nlp.num_solver_kkt());
+}
+
+// level: 0 evalOCC, 1 evalRHS, 2 evalSOE, 3 evalAUG, 4 evalKKT.  Returns 0 (or -1); *val = objective value.
+extern "C" int fullnlp_eval(void* h, int level, double ObjScale, const double* X, const double* LE, const double* LI,
+                            double* val, double* PGX, double* AGX, double* FXE, double* FXI, double* kkt_vals, char* err,
+                            int errcap) {
+  try {
+    KktAssembly& nlp = *static_cast<FullNlp*>(h)->nlp;
     switch (level) {
       case 0: *val = nlp.evalOCC(ObjScale, X, FXE, FXI); break;
       case 1: *val = nlp.evalRHS(ObjScale, X, LE, LI, PGX, AGX, FXE, FXI); break;
@@ -132,10 +170,29 @@ extern "C" int fullnlp_run(const FnDesc* fns, int nfn, int primal, int equal, in
       case 3: *val = nlp.evalAUG(ObjScale, X, LE, LI, PGX, AGX, FXE, FXI, kkt_vals); break;
       default: *val = nlp.evalKKT(ObjScale, X, LE, LI, PGX, AGX, FXE, FXI, kkt_vals);
     }
-    return nlp.nnz();
+    return 0;
   } catch (const std::exception& e) {
-    std::strncpy(err, e.what(), errcap - 1);
-    err[errcap - 1] = 0;
+    set_err(err, errcap, e.what());
     return -1;
   }
+}
+
+// One-shot form: create, copy the structure out, evaluate once.  Returns nnz (or -1).
+extern "C" int fullnlp_run(const FnDesc* fns, int nfn, int primal, int equal, int inequal, int level, double ObjScale,
+                           const double* X, const double* LE, const double* LI, const double* solver_coeffs,
+                           int* outer, int* inner, int inner_cap, int* locs, int locs_cap, double* val, double* PGX,
+                           double* AGX, double* FXE, double* FXI, double* kkt_vals, char* err, int errcap) {
+  void* h = fullnlp_create(fns, nfn, primal, equal, inequal, err, errcap);
+  if (!h) return -1;
+  int sz[4];
+  fullnlp_sizes(h, sz);
+  int rc = -1;
+  if (sz[1] > inner_cap || sz[2] > locs_cap) set_err(err, errcap, "capacity too small");
+  else {
+    fullnlp_structure(h, outer, inner, locs);
+    if (solver_coeffs) fullnlp_set_solver_coeffs(h, solver_coeffs);
+    if (fullnlp_eval(h, level, ObjScale, X, LE, LI, val, PGX, AGX, FXE, FXI, kkt_vals, err, errcap) == 0) rc = sz[1];
+  }
+  fullnlp_destroy(h);
+  return rc;
 }

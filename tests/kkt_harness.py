@@ -1,0 +1,279 @@
+"""TEST HARNESS, not a product: a small primal-dual interior-point Newton loop that consumes the evalKKT / evalOCC
+results of a sparse assembly (the oracle's FullNlp here, the product's KktAssembly on the GPU box) and solves the shuttle
+re-entry problem of the reference's own full-problem test, so that the path can be checked against a number the REFERENCE
+holds: /root/reference/asset_asrl/test/test_FullProblems/test_Reentry.py:116-127 (objective -0.5958800738629952 +- 1e-2 for
+LGL3/5/7/Trapezoidal x {HighestOrderSpline, BlockConstant}; the problem set-up is :130-175).  PSIOPT itself stays out of
+scope; this loop is deliberately minimal (l1 merit, inertia-free curvature test, monotone barrier) and must not grow.
+
+The linear parts of the problem (boundary values, variable bounds, the upper bound on the final time, the objective
+-(theta_f - theta_0)) are handled here as fixed variables, bounds and a constant cost vector; every NONLINEAR function the
+phase registers -- defects, mesh spacing, control splines -- comes from the assembly under test: constraint values, the
+Jacobian (off-diagonal block of the upper-triangular KKT CSR) and the Lagrangian Hessian sum_k lam_k grad^2 c_k (its
+primal block)."""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+# ---------------------------------------------------------------------------------------------- the problem
+def reentry_problem(mode: str, control: str, nseg: int = 64):
+    """-> dict(phase, ix, x0, lb, ub, cost, V, Cx, entries, n_equal); constants of test_Reentry.py:14-47,130-175."""
+    from asset_asrl_amd.ode import ShuttleReentry
+    Lstar, Tstar = 100000.0, 60.0
+    Vstar = Lstar / Tstar
+    tmax, Re = 2500 / Tstar, 20902900 / Lstar
+    tf = 2000 / Tstar
+    ht0, htf, vt0, vtf = 260000 / Lstar, 80000 / Lstar, 25600 / Vstar, 2500 / Vstar
+    thetaf = (vt0 * tf + 0.5 * (vtf - vt0) * tf) / Re
+    g0, gf, psi0 = np.deg2rad(-1.0), np.deg2rad(-5.0), np.deg2rad(90.0)
+    ts = np.linspace(0, tf, 200)
+    s = ts / tf
+    traj = np.column_stack([ht0 * (1 - s) + htf * s, thetaf * s, vt0 * (1 - s) + vtf * s, g0 * (1 - s) + gf * s,
+                            np.full_like(s, psi0), ts, 0 * s, 0 * s])
+    ph = ShuttleReentry().phase(mode, traj, nseg)
+    ph.setControlMode(control)
+    ix, (V, Cx), entries, n_equal, _ = ph.layout()
+    x0 = ix.makeSolverInput(ph.ActiveTraj)
+    n, S, D = x0.size, ix.numStates, ix.numDefects
+    lb, ub, cost = np.full(n, -np.inf), np.full(n, np.inf), np.zeros(n)
+    d89, d90, d1 = np.deg2rad(89.0), np.deg2rad(90.0), np.deg2rad(1.0)
+    for k in range(S):                                           # addLUVarBounds("Path", [1, 3], -89deg, 89deg)
+        for v in (1, 3):
+            lb[ix.getXTUVarLoc(v, k)], ub[ix.getXTUVarLoc(v, k)] = -d89, d89
+    where_u = [(0, d) for d in range(D)] if ix.BlockedControls else [(k, None) for k in range(S)]
+    for k, d in where_u:                                         # controls: alpha in +-90deg, beta in [-90deg, 1deg]
+        la, lbeta = ix.getXTUVarLoc(6, k, d), ix.getXTUVarLoc(7, k, d)
+        lb[la], ub[la], lb[lbeta], ub[lbeta] = -d90, d90, -d90, d1
+    for v in range(6):                                           # addBoundaryValue("Front", range(0, 6), TrajIG[0][0:6])
+        lb[ix.getXTUVarLoc(v, 0)] = ub[ix.getXTUVarLoc(v, 0)] = traj[0, v]
+    for v, val in ((0, htf), (2, vtf), (3, gf)):                 # addBoundaryValue("Back", [0, 2, 3], ...)
+        lb[ix.getXTUVarLoc(v, S - 1)] = ub[ix.getXTUVarLoc(v, S - 1)] = val
+    ub[ix.getXTUVarLoc(5, S - 1)] = tmax                         # addUpperDeltaTimeBound(tmax) with t_0 fixed at 0
+    cost[ix.getXTUVarLoc(1, S - 1)] = -1.0                       # addDeltaVarObjective(1, -1.0); theta_0 is fixed at 0
+    return dict(phase=ph, ix=ix, x0=x0, lb=lb, ub=ub, cost=cost, V=V, Cx=Cx, entries=entries, n_equal=n_equal)
+
+
+class CsrKkt:
+    """Splits the value array of an upper-triangular row-major KKT CSR (NonLinearProgram.cpp:267-344) into the primal
+    Hessian block and the equality Jacobian (rows at primal + CLoc)."""
+
+    def __init__(self, outer, inner, n, m):
+        self.n, self.m, self.outer, self.inner = n, m, np.asarray(outer), np.asarray(inner)
+
+    def split(self, vals):
+        n, m = self.n, self.m
+        M = sp.csr_matrix((vals, self.inner, self.outer), shape=(len(self.outer) - 1,) * 2)
+        U = M[:n, :n]
+        W = U + sp.triu(U, 1).T
+        return W.tocsr(), M[:n, n:n + m].T.tocsr()
+
+
+class OracleProvider:
+    """The oracle's restatement of NonLinearProgram (oracle/fullnlp.cpp) as the assembly: the CPU path."""
+
+    def __init__(self, ob, prob):
+        from asset_asrl_amd import synth
+        ph, ix = prob["phase"], prob["ix"]
+        n, m = prob["x0"].size, prob["n_equal"]
+        nlp = ob.FullNlp(n, m, 0)
+        nlp.add(1, ob.get_ode("reentry", 0), ob.MODES[ph.TranscriptionMode], ix.BlockedControls, prob["V"], prob["Cx"])
+        cs = synth.MODE_CS[ph.TranscriptionMode]
+        for kind, tag, F, name, V, Cx, consts in prob["entries"]:
+            if tag == "mesh_spacing":
+                nlp.add_mesh_spacing(1, cs, V, Cx)
+            elif tag == "nodal_spacing":
+                nlp.add_single_mesh_spacing(1, consts.ravel(), V, Cx)
+            elif tag == "control_spline":
+                nlp.add_control_spline(1, cs, 2, V, Cx)
+            else:
+                raise ValueError(tag)
+        nlp.analyze()
+        nlp.set_solver_coeffs(np.zeros(nlp.num_solver_kkt))
+        self.nlp, self.n, self.m = nlp, n, m
+        self.csr = CsrKkt(*nlp.csr(), n, m)
+        self.calls = 0
+
+    def kkt(self, x, lam):
+        self.calls += 1
+        _, _, agx, fxe, _, vals = self.nlp.eval(4, 1.0, x, lam, np.zeros(1))
+        W, J = self.csr.split(vals)
+        return fxe, agx, W, J
+
+    def con(self, x):
+        return self.nlp.eval(0, 1.0, x, np.zeros(self.m), np.zeros(1))[3]
+
+
+# ---------------------------------------------------------------------------------------------- the loop
+def solve_ip(provider, x0, lb, ub, cost, tol=1e-7, maxit=400, mu=0.1, verbose=False, feasibility=False, step_cap=1.0):
+    """min cost.x  s.t. c(x) = 0, lb <= x <= ub (lb == ub: fixed).  -> (x, lam, info).  Primal-dual barrier Newton
+    steps on the KKT system [W + Sigma + dw I, J^T; J, 0]: dw is raised until the step has positive curvature (the
+    inertia-free test) and is no longer than step_cap; the step length is found by backtracking against a filter on
+    (constraint violation, barrier objective).  feasibility = True is the 'solve' half of the reference's solve_optimize
+    (test_Reentry.py:177): least-change Newton steps on c(x) = 0 inside the bounds (identity in place of the Lagrangian
+    Hessian, no cost), stopping when the constraints hold."""
+    if feasibility:
+        cost, step_cap = np.zeros_like(cost), np.inf
+    x = x0.copy()
+    fixed = lb == ub
+    x[fixed] = lb[fixed]
+    free = np.flatnonzero(~fixed)
+    hasl, hasu = np.isfinite(lb) & ~fixed, np.isfinite(ub) & ~fixed
+    gap = np.where(np.isfinite(ub - lb), 1e-2 * (ub - lb), 1e-2)   # push the start into the interior
+    x = np.where(hasl, np.maximum(x, lb + gap), x)
+    x = np.where(hasu, np.minimum(x, ub - gap), x)
+    m, nf = provider.m, free.size
+    lam = np.zeros(m)
+    sl = lambda v: np.where(hasl, v - lb, 1.0)
+    su = lambda v: np.where(hasu, ub - v, 1.0)
+    zl, zu = np.where(hasl, mu / sl(x), 0.0), np.where(hasu, mu / su(x), 0.0)
+    dw, filt = 0.0, []
+    phi = lambda xx: cost @ xx - mu * (np.log(sl(xx))[hasl].sum() + np.log(su(xx))[hasu].sum())
+    info = dict(iters=maxit, converged=False)
+    for it in range(maxit):
+        c, agx, W, J = provider.kkt(x, lam)
+        Jf = J[:, free]
+        if feasibility:
+            if np.abs(c).max() < tol:
+                info.update(iters=it, converged=True)
+                break
+            lam, agx, W = 0.0 * lam, 0.0 * agx, sp.identity(x.size, format="csr")
+        elif it == 0:                                            # least-squares multiplier estimate at the start
+            g0 = (cost - np.where(hasl, mu / sl(x), 0.0) + np.where(hasu, mu / su(x), 0.0))[free]
+            K0 = sp.bmat([[sp.identity(nf), Jf.T], [Jf, -1e-9 * sp.identity(m)]], format="csc")
+            lam = spla.splu(K0).solve(np.concatenate([-g0, np.zeros(m)]))[nf:]
+            c, agx, W, J = provider.kkt(x, lam)
+        gl = cost + agx - zl + zu
+        err = lambda mu_: max(np.abs(gl[free]).max(), np.abs(c).max(), np.abs(sl(x) * zl - mu_)[hasl].max(initial=0.0),
+                              np.abs(su(x) * zu - mu_)[hasu].max(initial=0.0))
+        if not feasibility and err(0.0) < tol:
+            info.update(iters=it, converged=True)
+            break
+        while err(mu) < 10.0 * mu and mu > tol / 10:
+            mu, filt = max(tol / 10, min(0.2 * mu, mu ** 1.5)), []
+        sig = zl / sl(x) + zu / su(x)
+        gphi = cost - np.where(hasl, mu / sl(x), 0.0) + np.where(hasu, mu / su(x), 0.0)
+        Wf = W[free][:, free]
+        rhs = -np.concatenate([(gphi + agx)[free], c])
+        tau = max(0.99, 1.0 - mu)
+        dw = dw / 3 if dw > 1e-6 else 0.0
+        for _try in range(60):
+            K = sp.bmat([[Wf + sp.diags(sig[free] + dw), Jf.T], [Jf, -1e-9 * sp.identity(m)]], format="csc")
+            try:
+                sol = spla.splu(K).solve(rhs)
+            except RuntimeError:
+                sol = np.full(nf + m, np.nan)
+            if np.all(np.isfinite(sol)):
+                dx = np.zeros_like(x)
+                dx[free] = sol[:nf]
+                curv = dx[free] @ (Wf @ dx[free]) + (sig + dw) @ (dx * dx)
+                if curv >= 1e-8 * (dx @ dx) and np.abs(dx).max() <= step_cap:
+                    break
+            dw = max(1e-4, 4.0 * dw)
+        dlam = sol[nf:]
+        a = 1.0                                                  # fraction to the boundary
+        neg, pos = hasl & (dx < 0), hasu & (dx > 0)
+        if neg.any():
+            a = min(a, (-tau * sl(x)[neg] / dx[neg]).min())
+        if pos.any():
+            a = min(a, (tau * su(x)[pos] / dx[pos]).min())
+        th0, ph0, lin = np.abs(c).sum(), phi(x), gphi @ dx
+        for _ls in range(40):                                    # backtracking against the filter
+            xt = x + a * dx
+            tht, pht = np.abs(provider.con(xt)).sum(), phi(xt)
+            armijo = lin < 0 and th0 < 1e-4 * max(1.0, filt[0][0] if filt else th0) and pht <= ph0 + 1e-4 * a * lin
+            if feasibility:
+                if tht <= (1 - 1e-4 * a) * th0:                  # (monotone in the violation)
+                    break
+            elif armijo or all(tht <= (1 - 1e-5) * tf or pht <= pf - 1e-5 * tf for tf, pf in filt + [(th0, ph0)]):
+                break
+            a *= 0.5
+        if not armijo:
+            filt.append((th0, ph0))
+        dzl = np.where(hasl, mu / sl(x) - zl - zl / sl(x) * dx, 0.0)
+        dzu = np.where(hasu, mu / su(x) - zu + zu / su(x) * dx, 0.0)
+        az = 1.0
+        if (dzl < 0).any():
+            az = min(az, (-tau * zl[dzl < 0] / dzl[dzl < 0]).min())
+        if (dzu < 0).any():
+            az = min(az, (-tau * zu[dzu < 0] / dzu[dzu < 0]).min())
+        x, lam = xt, lam + a * dlam
+        zl, zu = zl + az * dzl, zu + az * dzu
+        zl = np.where(hasl, np.clip(zl, mu / (1e10 * sl(x)), 1e10 * mu / sl(x)), 0.0)
+        zu = np.where(hasu, np.clip(zu, mu / (1e10 * su(x)), 1e10 * mu / su(x)), 0.0)
+        if verbose:
+            print(f"{it:4d} obj {cost @ x:+.8f} |c| {np.abs(c).max():.2e} |gl| {np.abs(gl[free]).max():.2e} mu {mu:.1e} "
+                  f"a {a:.2e} dw {dw:.1e} |dx| {np.abs(dx).max():.2e} tries {_try} ls {_ls} filt {len(filt)}")
+    info["objective"] = float(cost @ x)
+    return x, lam, info
+
+
+def solve_reentry(provider, prob, verbose=False):
+    """'solve' (feasibility) then 'optimize', as phase.solve_optimize() does in the reference's test.  -> (x, lam, info)."""
+    x, _, feas = solve_ip(provider, prob["x0"], prob["lb"], prob["ub"], prob["cost"], feasibility=True, mu=1e-6, verbose=verbose)
+    x, lam, info = solve_ip(provider, x, prob["lb"], prob["ub"], prob["cost"], verbose=verbose)
+    info["feasibility_iters"], info["feasible"] = feas["iters"], feas["converged"]
+    return x, lam, info
+
+
+class DeviceProvider:
+    """The product: every function evaluated on the GPU through the C ABI and assembled by the C++ host shim's
+    KktAssembly (asset_asrl_amd/host/kkt_assembly.h) -- `shim` is tests/host_shim_driver.cpp compiled by the test."""
+
+    def __init__(self, shim, prob):
+        import ctypes as C
+        from asset_asrl_amd import _lib, jit
+        ph, ix = prob["phase"], prob["ix"]
+        n, m = prob["x0"].size, prob["n_equal"]
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+
+        class FnDesc(C.Structure):
+            _fields_ = [("kind", C.c_int), ("name", C.c_char_p), ("mode", C.c_int), ("blocked", C.c_int), ("ir", C.c_int),
+                        ("orr", C.c_int), ("nappl", C.c_int), ("vindex", ip), ("cindex", ip), ("consts", dp), ("nconst", C.c_int)]
+        mode_id = {"LGL3": _lib.LGL3, "LGL5": _lib.LGL5, "LGL7": _lib.LGL7, "Trapezoidal": _lib.TRAPEZOIDAL}[ph.TranscriptionMode]
+        fns = [(jit.ensure_kernel(ph.ode, ph.TranscriptionMode, ix.BlockedControls), mode_id, int(ix.BlockedControls),
+                prob["V"], prob["Cx"], None)]
+        fns += [(jit.ensure_function(F, name), _lib.FUNCTION, 0, V, Cx, consts) for _, _, F, name, V, Cx, consts in prob["entries"]]
+        self._keep, descs = [], (FnDesc * len(fns))()
+        for k, (name, mode, blocked, V, Cx, consts) in enumerate(fns):
+            v, c = np.ascontiguousarray(V, dtype=np.int32), np.ascontiguousarray(Cx, dtype=np.int32)
+            cc = None if consts is None else np.ascontiguousarray(consts, dtype=float)
+            self._keep += [v, c, cc]
+            descs[k] = FnDesc(1, name.encode(), mode, blocked, v.shape[1], c.shape[1], v.shape[0], v.ctypes.data_as(ip),
+                              c.ctypes.data_as(ip), None if cc is None else cc.ctypes.data_as(dp), 0 if cc is None else cc.shape[1])
+        err = C.create_string_buffer(512)
+        shim.fullnlp_create.restype = C.c_void_p
+        self._h = C.c_void_p(shim.fullnlp_create(descs, len(fns), n, m, 0, err, 512))
+        assert self._h, err.value
+        sz = (C.c_int * 4)()
+        shim.fullnlp_sizes(self._h, sz)
+        self.nnz = sz[1]
+        outer, inner, locs = np.zeros(sz[0] + 1, np.int32), np.zeros(sz[1], np.int32), np.zeros(sz[2], np.int32)
+        shim.fullnlp_structure(self._h, outer.ctypes.data_as(ip), inner.ctypes.data_as(ip), locs.ctypes.data_as(ip))
+        shim.fullnlp_set_solver_coeffs(self._h, np.zeros(sz[3]).ctypes.data_as(dp))
+        self.shim, self.n, self.m, self.csr, self.calls, self._C = shim, n, m, CsrKkt(outer, inner, n, m), 0, C
+
+    def _eval(self, level, x, lam):
+        C, dp = self._C, self._C.POINTER(self._C.c_double)
+        x, lam = np.ascontiguousarray(x, dtype=float), np.ascontiguousarray(lam, dtype=float)
+        val, err = C.c_double(0.0), C.create_string_buffer(512)
+        pgx, agx, fxe, fxi, vals = np.zeros(self.n), np.zeros(self.n), np.zeros(self.m), np.zeros(1), np.zeros(self.nnz)
+        p = lambda a: a.ctypes.data_as(dp)
+        rc = self.shim.fullnlp_eval(self._h, level, C.c_double(1.0), p(x), p(lam), p(fxi), C.byref(val), p(pgx), p(agx), p(fxe),
+                                    p(fxi), p(vals), err, 512)
+        assert rc == 0, err.value
+        return fxe, agx, vals
+
+    def kkt(self, x, lam):
+        self.calls += 1
+        fxe, agx, vals = self._eval(4, x, lam)
+        return (fxe, agx) + self.csr.split(vals)
+
+    def con(self, x):
+        return self._eval(0, x, np.zeros(self.m))[0]
+
+    def close(self):
+        if self._h:
+            self.shim.fullnlp_destroy(self._h)
+            self._h = None

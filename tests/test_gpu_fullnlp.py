@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 class FnDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("name", C.c_char_p), ("mode", C.c_int), ("blocked", C.c_int), ("ir", C.c_int),
-                ("orr", C.c_int), ("nappl", C.c_int), ("vindex", C.POINTER(C.c_int)), ("cindex", C.POINTER(C.c_int))]
+                ("orr", C.c_int), ("nappl", C.c_int), ("vindex", C.POINTER(C.c_int)), ("cindex", C.POINTER(C.c_int)),
+                ("consts", C.POINTER(C.c_double)), ("nconst", C.c_int)]
 
 
 @pytest.fixture(scope="module")
@@ -44,7 +45,7 @@ def test_full_kkt_layout_matches_the_oracle(oracle, shim, nseg):
         c = np.ascontiguousarray(Cx if Cx is not None else np.zeros((V.shape[0], 1)), dtype=np.int32)
         keep += [v, c]
         descs[k] = FnDesc(kind, names[tag][0].encode(), names[tag][1], 0, v.shape[1], c.shape[1], v.shape[0],
-                          v.ctypes.data_as(ip), c.ctypes.data_as(ip))
+                          v.ctypes.data_as(ip), c.ctypes.data_as(ip), None, 0)
     r_outer, r_inner = ref.csr()
     r_locs = ref.kkt_locations()
     sc = np.ascontiguousarray(p.solver_coeffs)
