@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("ASSET_HIP_LIB") or os.path.join(_HERE, "libasset_hip.
 FUNCTION, TRAPEZOIDAL, LGL3, LGL5, LGL7 = 0, 1, 2, 3, 4
 MODES = {"Function": FUNCTION, "Trapezoidal": TRAPEZOIDAL, "LGL3": LGL3, "LGL5": LGL5, "LGL7": LGL7}
 CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS = range(5)
+KEEP_HESSIAN_SLOTS = 0x100   # OR into JAC / JAC_ADJGRAD: Hessian slots of the blocks left untouched (include/asset_hip.h)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

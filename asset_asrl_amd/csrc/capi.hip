@@ -89,7 +89,7 @@ const asset_hip::KernelEntry* find_entry(const char* ode, int mode, int blocked)
 }
 
 int level_of(int what) {
-  switch (what) {
+  switch (what & 0xff) {
     case ASSET_HIP_CON: return 0;
     case ASSET_HIP_CON_ADJGRAD:
     case ASSET_HIP_JAC:
@@ -481,6 +481,11 @@ static int fill_args(asset_hip_defect_t h, int what, const double* dX, const dou
                      double* dkkt, asset_hip::EvalArgs& a) {
   const int level = level_of(what);
   if (level < 0) return fail(ASSET_HIP_EINVAL, "unknown evaluation kind");
+  const int opts = what & ~0xff;
+  what &= 0xff;
+  if ((opts & ~ASSET_HIP_KEEP_HESSIAN_SLOTS) || (opts && what != ASSET_HIP_JAC && what != ASSET_HIP_JAC_ADJGRAD))
+    return fail(ASSET_HIP_EINVAL, "ASSET_HIP_KEEP_HESSIAN_SLOTS goes with ASSET_HIP_JAC / ASSET_HIP_JAC_ADJGRAD only");
+  a.flags = (opts & ASSET_HIP_KEEP_HESSIAN_SLOTS) ? 1 : 0;
   if (!dX) return fail(ASSET_HIP_EINVAL, "X is null");
   const bool needs_l = (what == ASSET_HIP_CON_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD_HESS);
   if (needs_l && !dL) return fail(ASSET_HIP_EINVAL, "L is null for an evaluation kind that contracts with multipliers");
@@ -626,6 +631,7 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
                   kkt ? h->d_kkt : nullptr, h->stream);
   if (rc) return rc;
   const int level = level_of(what);
+  what &= 0xff;
   if (fx) HIP_TRY(hipMemcpyAsync(fx, h->d_fx, sizeof(double) * nfx, hipMemcpyDeviceToHost, h->stream));
   if (agx && what != ASSET_HIP_CON && what != ASSET_HIP_JAC)
     HIP_TRY(hipMemcpyAsync(agx, h->d_agx, sizeof(double) * nagx, hipMemcpyDeviceToHost, h->stream));
@@ -846,6 +852,7 @@ int asset_hip_defect_set_kkt_map(asset_hip_defect_t h, const int32_t* slot_locat
 int asset_hip_defect_eval_assembled_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
                                            double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_values,
                                            void* stream) {
+  what &= 0xff;   // (no blocks are written: ASSET_HIP_KEEP_HESSIAN_SLOTS has nothing to act on)
   if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
   if (what < ASSET_HIP_JAC) return fail(ASSET_HIP_EINVAL, "assembled evaluation needs a kind that produces KKT entries");
   if (!h->d_map) return fail(ASSET_HIP_EINVAL, "no kkt map: call asset_hip_defect_set_kkt_map first");
@@ -887,6 +894,7 @@ static int build_rhs_csr(const std::vector<int32_t>& index, std::vector<int>& ro
 
 int asset_hip_defect_eval_kkt_device(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* d_FXE,
                                      double* d_AGX, double* d_kkt_values, void* stream) {
+  what &= 0xff;   // (no blocks are written: ASSET_HIP_KEEP_HESSIAN_SLOTS has nothing to act on)
   if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
   if (!d_FXE) return fail(ASSET_HIP_EINVAL, "FXE is null");
   const bool want_kkt = what >= ASSET_HIP_JAC;
@@ -946,6 +954,7 @@ int asset_hip_defect_eval_assembled_zeroed(asset_hip_defect_t h, int what, const
 
 static int eval_assembled_host(asset_hip_defect_t h, int what, const double* X, const double* L, double* fx_blocks,
                                double* agx_blocks, double* kkt_values, bool target_zeroed) {
+  what &= 0xff;
   if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
   if (!X || !kkt_values) return fail(ASSET_HIP_EINVAL, "X / kkt value array is null");
   if (what < ASSET_HIP_JAC) return fail(ASSET_HIP_EINVAL, "assembled evaluation needs a kind that produces KKT entries");

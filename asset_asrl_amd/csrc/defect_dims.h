@@ -57,6 +57,9 @@ struct EvalArgs {
   const void* lane_consts = nullptr;
   // plain functions (func_kernels.h): constants of every application, [nseg][F::NACONST] (vf.ApplConst) or null
   const double* appl_consts = nullptr;
+  // bit 0 (ASSET_HIP_KEEP_HESSIAN_SLOTS, Jacobian kinds): the Hessian slots of the KKT blocks are not written at all
+  // instead of being written as zeros -- KKTFillJac (DenseFunctionBase.h:1468-1523) never reads them
+  int flags = 0;
 };
 
 // ---------------------------------------------------------------------------------------------- sizes

@@ -299,7 +299,11 @@ template <class Ode, class D, int GP, bool COPY = true>
 __device__ __attribute__((noinline)) void pipe_cardinal_second(glb_double* Wg, lds_double* mirror, lds_double* stage,
                                                                const LglTab* tabp, int gcount, int lane) {
   constexpr int K = D::K, n = D::n, N = D::N, T = D::T, CS = D::CS;
+#if defined(ASSET_EXP_NOWS)
+  if constexpr (false) {
+#else
   if constexpr (!D::TRAP && COPY) {
+#endif
     if constexpr (D::NSTG > 0) pipe_copy_rows<D, K>(stage, gcount * K, lane, Wg, D::w_IJ, D::w_IH);
     if constexpr (PipeDims<D, GP>::IFROW) {
       for (int e = lane; e < gcount * K * n; e += 64) {
@@ -416,7 +420,12 @@ __device__ inline void pipe_ode_group(const EvalArgs& a, int lane, int seg0, int
   pipe_cardinal_second<Ode, D, GP>((glb_double*)Wg, mirror, (lds_double*)stage, tabp, gcount, lane);
   wave_lds_sync();
   PTS();                             // copy-out of P2 + P3
+#if !defined(ASSET_EXP_NOWS)
   pipe_copy_rows<D, CS>((const lds_double*)stage, D::NSTG > 0 ? gcount * CS : 0, lane, (glb_double*)Wg, D::w_CJ, D::w_CH);
+#endif
+#if defined(ASSET_EXP_NOWS)
+  if constexpr (false)
+#endif
   {   // what the dense stage reads of the mirror: [z | lam | f_j] (contiguous in both layouts) and g^_i
     constexpr int NA = IR + OR + CS * n, NB = K * N;
     static_assert(D::w_z == 0 && D::w_lam == IR && D::w_Cf == IR + OR && D::m_z == 0 && D::m_lam == IR && D::m_Cf == IR + OR,
@@ -1033,7 +1042,11 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
     constexpr int NPRE = (D::WSLOTD + 63) / 64;
     double pre[NPRE];                      // next segment's slot, in flight while the current one is processed
 #pragma unroll
+#if defined(ASSET_EXP_NOWS)
+    for (int t = 0; t < NPRE; t++) pre[t] = 0.001 * (lane + t) + 0.5;
+#else
     for (int t = 0; t < NPRE; t++) pre[t] = (t + 1 < NPRE || lane + 64 * t < D::WSLOTD) ? Wg[lane + 64 * t] : 0.0;
+#endif
     // (the first slot's loads fly while the constant tiles below are built)
     // ---- per-group constants of the dense scratch (the staging rows aliased it): the rows of DI_i that do not
     //      depend on the segment (tau row, control-interpolation rows, parameter identity rows, zero padding;
@@ -1075,11 +1088,13 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
       for (int t = 0; t < NPRE; t++)
         if (t + 1 < NPRE || lane + 64 * t < D::WSLOTD) slotb[lane + 64 * t] = pre[t];   // only the last row is partial
       wave_lds_sync();
+#if !defined(ASSET_EXP_NOWS)
       if (g + 1 < gcount) {
 #pragma unroll
         for (int t = 0; t < NPRE; t++)
           pre[t] = (t + 1 < NPRE || lane + 64 * t < D::WSLOTD) ? Wg[(g + 1) * D::WSLOT + lane + 64 * t] : 0.0;
       }
+#endif
       const double* S = slotb;
       const double* z = S + D::w_z;
       const double* lam = S + D::w_lam;
@@ -1500,7 +1515,7 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
       //      row (H) r = 16*rt + lr or (J) jr = 16*jt + lr; 16 consecutive lanes cover 128 contiguous bytes.
       if (kkt_dst) {
         if constexpr (!HOLD) {
-          if constexpr (LEVEL < 2 && !ASM) {               // Jacobian-only kinds write the Hessian slots as zero
+          if (LEVEL < 2 && !ASM && !(a.flags & 1)) {       // Jacobian-only kinds write the Hessian slots as zero (unless told not to)
             const d4 zero = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int rt = 0; rt < D::TI; rt++)
@@ -1526,7 +1541,7 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
               for (int ct = 0; ct < D::TI; ct++) store_J_tile(jt, ct, accJ[ct * D::TJ + jt]);
           }
         } else {
-        if constexpr (true) {                // Jacobian-only kinds write the Hessian slots as zero (adding zeros: skipped)
+        if (LEVEL >= 2 || !(a.flags & 1)) {   // Jacobian-only kinds write the Hessian slots as zero (unless told not to)
 #pragma unroll
           for (int rt = 0; rt < D::TI; rt++)
 #pragma unroll

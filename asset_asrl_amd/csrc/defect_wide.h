@@ -412,6 +412,7 @@ __device__ __forceinline__ void lgl_wide_dense_body(const EvalArgs& a) {
         const long long tu0 = clock64();
 #endif
         if (u < NHU) {
+          if (LEVEL < 2 && (a.flags & 1)) continue;        // Jacobian kinds, ASSET_HIP_KEEP_HESSIAN_SLOTS: nothing to store
           // ------------------------------------------------ tile row rt of H (lower triangle): tiles ct = 0..rt
           const int rt = TI - 1 - u;                       // largest first
           const int r = 16 * rt + lr;

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, MODES  # noqa: F401
+from ._lib import CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, KEEP_HESSIAN_SLOTS, MODES  # noqa: F401
 
 
 def _dptr(a):
@@ -76,14 +76,15 @@ class DefectEvaluator:
             L = np.ascontiguousarray(L, dtype=np.float64)
             if L.size != self.n_equal:
                 raise ValueError(f"L has {L.size} entries, expected {self.n_equal}")
+        kind = what & 0xFF                 # (what may carry KEEP_HESSIAN_SLOTS)
         if self._pinned is not None:       # persistent page-locked outputs (pin_outputs): views, overwritten by the next call
             fx, agx, kkt = self._pinned
-            agx = agx if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
-            kkt = kkt if what >= JAC else None
+            agx = agx if kind in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+            kkt = kkt if kind >= JAC else None
         else:
             fx = np.empty((self.nseg, self.OR))
-            agx = np.empty((self.nseg, self.IR)) if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
-            kkt = np.empty((self.nseg, self.NKKT)) if what >= JAC else None
+            agx = np.empty((self.nseg, self.IR)) if kind in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+            kkt = np.empty((self.nseg, self.NKKT)) if kind >= JAC else None
         _lib.check(_lib.lib().asset_hip_defect_eval(self._h, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx),
                                                     _dptr(kkt)), "asset_hip_defect_eval")
         return fx, agx, kkt

@@ -137,7 +137,9 @@ void BatchedDefectConstraint::eval(int what, const double* X, const double* L, d
     check(asset_hip_defect_eval_assembled(h_, what, X, L, fx_.data(), want_agx ? agx_.data() : nullptr, KKTvals),
           "asset_hip_defect_eval_assembled");
   } else {
-    check(asset_hip_defect_eval(h_, what, X, L, fx_.data(), want_agx ? agx_.data() : nullptr,
+    // the Jacobian kinds scatter with KKTFillJac below, which never reads the Hessian slots: do not have them written
+    const int keep = (what == ASSET_HIP_JAC || what == ASSET_HIP_JAC_ADJGRAD) ? ASSET_HIP_KEEP_HESSIAN_SLOTS : 0;
+    check(asset_hip_defect_eval(h_, what | keep, X, L, fx_.data(), want_agx ? agx_.data() : nullptr,
                                 want_kkt ? kkt_.data() : nullptr),
           "asset_hip_defect_eval");
   }

@@ -158,7 +158,8 @@ def main():
     from helpers import Workload
 
     from asset_asrl_amd.distributed import PhaseShardedEvaluator, ShardedDefectEvaluator
-    from asset_asrl_amd.evaluator import CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, DefectEvaluator
+    from asset_asrl_amd.evaluator import (CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, KEEP_HESSIAN_SLOTS,
+                                          DefectEvaluator)
 
     ode, mode, nseg, blocked = WORKLOADS[a.workload]
     nphases = MULTI_PHASE.get(a.workload, 1)
@@ -246,7 +247,7 @@ def main():
     # FIRST and until it settles: the part clocks up under load (the same kernel: 49.8 us over the first 100 launches after
     # an idle second, 45.2 after 300, 42.6 after 900), so the rounds below are repeated until two agree within 1 %.  The
     # timed region of the contract follows immediately, on a device that is already at its working clocks.
-    ms_kernel, kernel_rounds, ms_con, ms_rhs, ms_soe, ms_aug = 0.0, [], 0.0, 0.0, 0.0, 0.0
+    ms_kernel, kernel_rounds, ms_con, ms_rhs, ms_soe, ms_aug, ms_soe_keep, ms_aug_keep = 0.0, [], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0
     if evs:
         e0 = evs[0]
         n0 = e0.nseg
@@ -265,6 +266,9 @@ def main():
         ms_rhs = e0.time_device(CON_ADJGRAD, X, L, kfx, kagx, None, warmup=5, iters=iters)   # evalRHS: value + J^T lam
         ms_soe = e0.time_device(JAC, X, None, kfx, None, kkkt, warmup=5, iters=iters)         # evalSOE: value + Jacobian blocks
         ms_aug = e0.time_device(JAC_ADJGRAD, X, L, kfx, kagx, kkkt, warmup=5, iters=iters)    # evalAUG
+        # the same two with the Hessian slots of the blocks left untouched (KKTFillJac never reads them)
+        ms_soe_keep = e0.time_device(JAC | KEEP_HESSIAN_SLOTS, X, None, kfx, None, kkkt, warmup=5, iters=iters)
+        ms_aug_keep = e0.time_device(JAC_ADJGRAD | KEEP_HESSIAN_SLOTS, X, L, kfx, kagx, kkkt, warmup=5, iters=iters)
         del kfx, kagx, kkkt
 
     dt = timed(step, a.steps, a.warmup)                       # THE measurement: K steps, exchange included when N > 1
@@ -378,7 +382,9 @@ def main():
                 "ms": ms_rhs, "segments_per_s": local_segments / (ms_rhs * 1e-3) if ms_rhs > 0 else 0.0,
                 "algorithmic_bytes_per_segment": 8 * (IR + OR) + 8 * (OR + IR)},
                 "evalSOE (JAC: values + Jacobian blocks, Hessian slots zero), kernel ms": ms_soe,
-                "evalAUG (JAC_ADJGRAD), kernel ms": ms_aug},
+                "evalAUG (JAC_ADJGRAD), kernel ms": ms_aug,
+                "evalSOE with the Hessian slots left untouched (JAC | KEEP_HESSIAN_SLOTS), kernel ms": ms_soe_keep,
+                "evalAUG with the Hessian slots left untouched (JAC_ADJGRAD | KEEP_HESSIAN_SLOTS), kernel ms": ms_aug_keep},
         }
         out.update(extra)
         if host_visible is not None:

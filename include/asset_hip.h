@@ -53,6 +53,13 @@ enum {
   ASSET_HIP_JAC_ADJGRAD_HESS = 4
 };
 
+/* May be OR-ed into ASSET_HIP_JAC / ASSET_HIP_JAC_ADJGRAD: the Hessian slots of the KKT blocks are left untouched instead of
+ * being written as zeros.  The reference's Jacobian-only fill (DenseFunctionBase.h:1468-1523 KKTFillJac, used by evalSOE /
+ * evalAUG) steps over those slots without reading them, so a caller that scatters with it saves 44 MB of stores per
+ * evaluation of a 10 000-segment LGL7 phase.  The block kinds of the LGL / Trapezoidal defects honour it; plain functions
+ * (whole blocks are copied out of LDS) and the assembled kinds (no blocks) ignore it. */
+enum { ASSET_HIP_KEEP_HESSIAN_SLOTS = 0x100 };
+
 enum {
   ASSET_HIP_EINVAL = -1,      /* bad argument / null pointer / size mismatch          */
   ASSET_HIP_ENOODE = -2,      /* no device code for this (ode, mode, blocked) triple  */

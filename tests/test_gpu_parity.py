@@ -89,6 +89,41 @@ def test_all_evaluation_kinds_match_oracle(oracle, ode, mode, nseg, blocked):
     ev.close()
 
 
+@pytest.mark.parametrize("ode,mode,nseg,blocked", [
+    ("reentry", "LGL7", 1000, False),            # fused launch, tiles held until the stores
+    ("reentry", "LGL7", 14400, False),           # ODE-stage + dense-stage launches
+    ("twobody_lt", "LGL7", 300, False),          # tiles stored as they complete
+    ("reentry", "Trapezoidal", 500, False),
+    ("synthetic32", "LGL7", 9, False)])          # four-wave dense kernel
+def test_jacobian_kinds_can_leave_the_hessian_slots_untouched(ode, mode, nseg, blocked):
+    """KEEP_HESSIAN_SLOTS (include/asset_hip.h): the reference's Jacobian-only fill never reads the Hessian slots of a block
+    (DenseFunctionBase.h:1468-1523 KKTFillJac), so evalSOE / evalAUG need not have them written.  Device against device,
+    bit for bit: the Jacobian slots are those of the plain kind, the Hessian slots still hold what the evaluation before
+    left there (the handle's block buffer persists between host-pointer calls)."""
+    from asset_asrl_amd.evaluator import KEEP_HESSIAN_SLOTS
+    w = Workload(ode, mode, nseg, blocked)
+    ev = DefectEvaluator(ode, mode, blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    full = [a.copy() for a in ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)]
+    hmask = np.zeros(w.NKKT, dtype=bool)
+    k = 0
+    for i in range(w.IR):
+        hmask[k:k + w.IR - i] = True
+        k += (w.IR - i) + w.OR
+    for what in (JAC, JAC_ADJGRAD):
+        L = w.L if what == JAC_ADJGRAD else None
+        plain = [None if a is None else a.copy() for a in ev.eval(what, w.X, L)]
+        assert np.all(plain[2][:, hmask] == 0.0)
+        ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)                                   # refill the buffer with Hessians ...
+        kept = ev.eval(what | KEEP_HESSIAN_SLOTS, w.X, L)                      # ... which this evaluation leaves alone
+        assert np.array_equal(kept[2][:, hmask], full[2][:, hmask]) and np.abs(full[2][:, hmask]).max() > 0
+        assert np.array_equal(kept[2][:, ~hmask], plain[2][:, ~hmask]) and np.array_equal(kept[0], plain[0])
+        if what == JAC_ADJGRAD:
+            assert np.array_equal(kept[1], plain[1])
+    with pytest.raises(Exception):
+        ev.eval(CON | KEEP_HESSIAN_SLOTS, w.X)
+    ev.close()
+
+
 @pytest.mark.parametrize("nseg", [1, 2, 3, 4, 5, 63, 64, 65])
 def test_ragged_segment_counts(oracle, nseg):
     w = Workload("reentry", "LGL7", nseg)
