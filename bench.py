@@ -54,15 +54,33 @@ def algorithmic_bytes_per_segment(IR, OR):
     return 8 * ((IR + OR) + (OR + IR + IR * (IR + 1) // 2 + OR * IR))
 
 
-def cpu_baseline(w, budget_s=12.0):
+def physical_cores() -> int:
+    """Distinct cores behind the hardware threads this process may run on (SMT siblings counted once)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                seen.add(f.read().strip())
+        except OSError:
+            seen.add(str(c))
+    return max(1, len(seen))
+
+
+def cpu_baseline(w, budget_s=14.0):
     """Oracle evalKKT-equivalent (NLPTest protocol: zero CSR values, eval, scatter) on the host cores, built the way
-    the reference builds itself (-O2 -march=native -ffast-math), at the reference's default thread count
-    min(16, hw threads) and at every hardware thread."""
+    the reference builds itself (-O2 -march=native -ffast-math), evaluation threads kept alive between evaluations as the
+    reference's pool is (oracle/nlp.cpp: WorkerPool), at the reference's default thread count min(16, hw threads), at
+    every physical core and at every hardware thread; the zero-fill of the CSR value array (PSIOPT.cpp:107, one thread)
+    and the evaluation are timed separately and both reported."""
     import numpy as np
 
     from oracle import bindings as ob
     ob.use_native()
-    hw = os.cpu_count() or 1
+    hw, phys = os.cpu_count() or 1, physical_cores()
     try:
         ode = ob.get_ode(w.ode, 1)
         kind_note = "generated analytic ODE derivatives"
@@ -74,36 +92,45 @@ def cpu_baseline(w, budget_s=12.0):
     L = np.ascontiguousarray(w.L)
     dp = C.POINTER(C.c_double)
     runs = {}
-    for threads, batch4 in [(t, b) for t in sorted({min(16, hw), hw}) for b in (False, True)]:
+    configs = [(t, b) for t in sorted({min(16, hw), min(64, phys), phys, hw}) for b in (False, True)]
+    for threads, batch4 in configs:
         nlp = ob.Nlp(ode, ob.MODES[w.mode], w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal, threads)
         if batch4 and not nlp.set_batch4(True):            # four segments per pass (the reference's SuperScalar loop)
             continue
         FXE, AGX, vals = np.zeros(w.n_equal), np.zeros(w.n_primal), np.zeros(nlp.nnz)
         args = [a.ctypes.data_as(dp) for a in (X, L, FXE, AGX, vals)]
+        t_zero = t_eval = 0.0
 
         def one():
+            nonlocal t_zero, t_eval
+            t0 = time.perf_counter()
             vals.fill(0.0)
+            t1 = time.perf_counter()
             rc = ob.lib().oracle_nlp_eval(nlp.h, ob.JAC_ADJGRAD_HESS, *args)
+            t_eval += time.perf_counter() - t1
+            t_zero += t1 - t0
             assert rc == 0
         for _ in range(3):
             one()
         t0 = time.perf_counter()
         one()
         t1 = time.perf_counter() - t0
-        reps = int(max(20, min(400, budget_s / 4 / max(t1, 1e-6))))
+        reps = int(max(20, min(400, budget_s / len(configs) / max(t1, 1e-6))))
+        t_zero = t_eval = 0.0
         t0 = time.perf_counter()
         for _ in range(reps):
             one()
         dt = (time.perf_counter() - t0) / reps
         runs[(threads, batch4)] = {"threads": threads, "segments_per_pass": 4 if batch4 else 1,
-                                   "segments_per_s": w.nseg / dt, "ms_per_eval": dt * 1e3, "reps": reps}
+                                   "segments_per_s": w.nseg / dt, "ms_per_eval": dt * 1e3,
+                                   "ms_zero_fill": t_zero / reps * 1e3, "ms_eval_only": t_eval / reps * 1e3, "reps": reps}
         del nlp
     best = max(runs.values(), key=lambda r: r["segments_per_s"])
     return {"value": best["segments_per_s"], "unit": "segments/s", "cores": best["threads"], "kind": "port",
-            "cpu_model": ob.cpu_model(), "hw_threads": hw, "build": "g++ -O2 -march=native -ffast-math",
+            "cpu_model": ob.cpu_model(), "hw_threads": hw, "physical_cores": phys, "build": "g++ -O2 -march=native -ffast-math",
             "runs": list(runs.values()),
-            "sample": f"evalKKT-equivalents of the same {w.nseg}-segment phase ({kind_note}, std::thread ByApplication "
-                      f"split, CSR scatter; one segment per pass and four per pass in AVX registers, the reference's "
+            "sample": f"evalKKT-equivalents of the same {w.nseg}-segment phase ({kind_note}, persistent worker pool, "
+                      f"ByApplication split, CSR scatter, zero-fill of the value array included in ms_per_eval; one segment per pass and four per pass in AVX registers, the reference's "
                       f"SuperScalar loop); best of (threads, segments per pass) "
                       f"{sorted((r['threads'], r['segments_per_pass']) for r in runs.values())}: "
                       f"{best['threads']} threads x {best['segments_per_pass']}, {best['ms_per_eval']:.3f} ms each",
@@ -227,16 +254,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    last_event_ms = [0.0]
+
     def timed(fn, steps, warmup):
         with torch.cuda.stream(stream):
             for _ in range(warmup):
                 fn()
             fence()
             t0 = time.perf_counter()
+            ev_a.record(stream)              # HIP events on the stream the kernels are launched on, around the same K steps
             for _ in range(steps):
                 fn()
+            ev_b.record(stream)
             fence()
             dt = time.perf_counter() - t0
+            last_event_ms[0] = ev_a.elapsed_time(ev_b)
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -272,6 +305,7 @@ def main():
         del kfx, kagx, kkkt
 
     dt = timed(step, a.steps, a.warmup)                       # THE measurement: K steps, exchange included when N > 1
+    ms_timed_region = last_event_ms[0] / a.steps              # average launch-to-launch duration over the timed region
     extra = {}
     if exchange is not None and use_dist:
         k2 = max(10, min(a.steps, 200))
@@ -322,7 +356,10 @@ def main():
             host_visible = {"error": "shared host buffer unavailable on another rank"}
 
     bseg = algorithmic_bytes_per_segment(IR, OR)
-    achieved = local_segments * bseg / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
+    # roofline: the launch duration over the TIMED REGION (HIP events around the K steps, N = 1: one evaluation per step,
+    # nothing else on the stream); with an exchange in the step (N > 1) the kernel's own settled HIP-event figure
+    ms_roof = ms_timed_region if (world == 1 and exchange is None) else ms_kernel
+    achieved = local_segments * bseg / (ms_roof * 1e-3) / 1e9 if ms_roof > 0 else 0.0
     per_rank_ms = [ms_kernel]
     if dist is not None:
         t = torch.tensor([ms_kernel], dtype=torch.float64, device=dev)
@@ -331,8 +368,8 @@ def main():
         per_rank_ms = [float(x.item()) for x in allk]
 
     traffic, traffic_src = None, None
-    prof = os.path.join(ROOT, "profiles", f"r2_{a.workload}_pmc.json")
-    if world == 1 and os.path.exists(prof):   # NOT measured by this run: HBM bytes per evaluation from the committed rocprofv3 --pmc passes
+    prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_{a.workload}_pmc.json") for r in (3, 2)) if os.path.exists(q)), "")
+    if world == 1 and prof:   # NOT measured by this run: HBM bytes per evaluation from the committed rocprofv3 --pmc passes
         try:
             traffic = json.load(open(prof))["hbm"]["bytes_per_launch"]
             traffic_src = f"committed profile profiles/{os.path.basename(prof)} (separate rocprofv3 --pmc passes of this command)"
@@ -372,6 +409,8 @@ def main():
                          "kernel": ("lgl_defect_kernel (ODE stage) + lgl_wide_dense_kernel" if IR >= 64 else
                                     "lgl_defect_kernel (fused single launch up to 7 segments per workgroup, else ODE-stage + dense-stage launches)")
                                    + "; rank 0's share, all launches of one evaluation timed",
+                         "launch_ms": ms_roof, "launch_ms_source": ("HIP events around the K timed steps / K" if ms_roof is ms_timed_region
+                                                                     else "settled HIP-event rounds (the step also holds the exchange)"),
                          "kernel_ms": ms_kernel, "kernel_ms_rounds": kernel_rounds, "segments_in_kernel": local_segments,
                          "algorithmic_bytes_per_segment": bseg},
             "per_rank_kernel_ms": per_rank_ms,

@@ -13,7 +13,11 @@
 // The NLP here holds exactly one equality constraint (the phase's defect); objectives, inequalities
 // and slacks are absent, so KKTdim = PrimalVars + EqualCons.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -33,7 +37,57 @@ struct IndexData {  // SolverIndexingData
 
 }  // namespace
 
+// The reference keeps its evaluation threads alive between evaluations (a ctpl pool owned by the NonLinearProgram,
+// NonLinearProgram.h:38,126-130; jobs pushed per evaluation, NonLinearProgram.cpp:519-526): a persistent pool of
+// T - 1 workers, the caller runs the last slice itself.  Workers spin briefly on the job counter before they block, so a
+// back-to-back stream of evaluations (bench.py's cpu_baseline leg) pays no wake-up latency.
+class WorkerPool {
+ public:
+  explicit WorkerPool(int workers) : done_(0) {
+    for (int t = 0; t < workers; t++) th_.emplace_back([this, t] { loop(t); });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; gen_.fetch_add(1); }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int size() const { return int(th_.size()); }
+  // runs job(t) for t = 0..size()-1 on the workers; returns at once (wait() joins)
+  void post(std::function<void(int)> job) {
+    { std::lock_guard<std::mutex> g(m_); job_ = std::move(job); done_.store(0); gen_.fetch_add(1); }
+    cv_.notify_all();
+  }
+  void wait() {
+    for (int spin = 0; done_.load(std::memory_order_acquire) < size(); spin++)
+      if (spin > 2000) std::this_thread::yield();
+  }
+
+ private:
+  void loop(int t) {
+    unsigned seen = 0;
+    for (;;) {
+      for (int spin = 0; gen_.load(std::memory_order_acquire) == seen && spin < 20000; spin++) {}
+      if (gen_.load(std::memory_order_acquire) == seen) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return gen_.load() != seen; });
+      }
+      std::function<void(int)> job;
+      { std::lock_guard<std::mutex> g(m_); if (stop_) return; seen = gen_.load(); job = job_; }
+      job(t);
+      done_.fetch_add(1, std::memory_order_release);
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void(int)> job_;
+  std::atomic<unsigned> gen_{0};
+  std::atomic<int> done_;
+  bool stop_ = false;
+};
+
 struct oracle_nlp {
+  std::unique_ptr<WorkerPool> pool;          // created at the first multi-threaded evaluation
   oracle_ode ode;
   oracle_ode4 ode4 = {nullptr, nullptr};   // four-wide twin of `ode` (batch4.h), when the registry has one
   bool batch4 = false;                      // oracle_nlp_set_batch4: LGL evalKKT processes four applications at a time
@@ -377,13 +431,14 @@ void oracle_nlp_kkt_coords(const oracle_nlp* n, int* rows, int* cols) {
 static void run_threads(oracle_nlp* n, int what, const double* X, const double* LE, double* fx, double* agx,
                         double* kktvals, double* kkt_blocks, bool blocks) {
   const int T = (int)n->thr.size();
-  std::vector<std::thread> pool;
   std::vector<size_t> base(T, 0);
   for (int t = 1; t < T; t++) base[t] = base[t - 1] + n->thr[t - 1].nappl;
-  for (int t = 0; t < T - 1; t++)
-    pool.emplace_back(eval_slice, n, std::cref(n->thr[t]), what, X, LE, fx, agx, kktvals, kkt_blocks, blocks, base[t]);
+  if (T > 1) {
+    if (!n->pool || n->pool->size() != T - 1) n->pool.reset(new WorkerPool(T - 1));
+    n->pool->post([&, n](int t) { eval_slice(n, n->thr[t], what, X, LE, fx, agx, kktvals, kkt_blocks, blocks, base[t]); });
+  }
   if (T > 0) eval_slice(n, n->thr[T - 1], what, X, LE, fx, agx, kktvals, kkt_blocks, blocks, base[T - 1]);  // caller runs last slice
-  for (auto& th : pool) th.join();
+  if (T > 1) n->pool->wait();
 }
 
 int oracle_nlp_eval(oracle_nlp* n, int what, const double* X, const double* LE, double* FXE, double* AGX,
