@@ -126,6 +126,9 @@ struct asset_hip_defect {
   // device RHS fill (asset_hip_defect_eval_kkt_device): CSR by target row over the FX / AGX block entries
   int *d_fx_rows = nullptr, *d_fx_ptr = nullptr, *d_fx_src = nullptr, *d_gx_rows = nullptr, *d_gx_ptr = nullptr, *d_gx_src = nullptr;
   int n_fx_rows = 0, fx_long_from = 0, n_gx_rows = 0, gx_long_from = 0;
+  bool rhs_tables_ready = false;
+  int bundles = 0;                   // bundles that hold this handle (asset_hip_bundle_create)
+  bool destroy_pending = false;      // asset_hip_defect_destroy was called while a bundle held it: freed with the last bundle
   double *d_fxb = nullptr, *d_agxb = nullptr;    // block buffers of that entry point
   std::vector<int32_t> h_vindex, h_cindex;       // kept for the RHS tables (built on first use)
   hipStream_t stream = nullptr;
@@ -205,17 +208,26 @@ bool rtc_write(const std::string& path, const RtcBlob& b) {
 bool rtc_read(const std::string& path, RtcBlob& b) {
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) return false;
-  char line[1024];
+  // lines of any length: the mangled name of a bundle kernel over eight user-named functors runs to kilobytes
+  auto getline = [f](std::string& out) {
+    out.clear();
+    for (int c; (c = std::fgetc(f)) != EOF;) {
+      if (c == '\n') return true;
+      out.push_back(char(c));
+    }
+    return !out.empty();
+  };
+  std::string line;
   size_t n = 0, bytes = 0;
-  bool ok = std::fgets(line, sizeof line, f) && !std::strncmp(line, kRtcMagic, sizeof kRtcMagic - 1) &&
-            std::fgets(line, sizeof line, f) && std::sscanf(line, "%zu", &n) == 1;
+  bool ok = getline(line) && !std::strncmp(line.c_str(), kRtcMagic, sizeof kRtcMagic - 1) && getline(line) &&
+            std::sscanf(line.c_str(), "%zu", &n) == 1;
   for (size_t i = 0; ok && i < n; i++) {
-    int slot = -1;
-    char name[960];
-    ok = std::fgets(line, sizeof line, f) && std::sscanf(line, "%d %959s", &slot, name) == 2 && slot >= 0 && slot < asset_hip::K_COUNT;
-    if (ok) b.names.emplace_back(slot, name);
+    int slot = -1, used = 0;
+    ok = getline(line) && std::sscanf(line.c_str(), "%d %n", &slot, &used) == 1 && used > 0 && size_t(used) < line.size() &&
+         slot >= 0 && slot < asset_hip::K_COUNT && line.find(' ', used) == std::string::npos;
+    if (ok) b.names.emplace_back(slot, line.substr(used));
   }
-  ok = ok && std::fgets(line, sizeof line, f) && std::sscanf(line, "%zu", &bytes) == 1 && bytes > 0;
+  ok = ok && getline(line) && std::sscanf(line.c_str(), "%zu", &bytes) == 1 && bytes > 0;
   if (ok) {
     b.code.resize(bytes);
     ok = std::fread(b.code.data(), 1, bytes, f) == bytes;
@@ -291,34 +303,37 @@ int asset_hip_jit_plugin(const char* name, const char* source, const char* funct
     if (!source) return fail(ASSET_HIP_EINVAL, std::string("no compiled module at ") + (cache_path ? cache_path : "(null)") + " and no source");
     const int rc = rtc_compile(source, functor, kind, mode, blocked, seg_per_group, options, noptions, blob);
     if (rc) return rc;
-    if (cache_path && !rtc_write(cache_path, blob)) return fail(ASSET_HIP_EINVAL, std::string("cannot write ") + cache_path);
+    // (a cache that cannot be written -- a read-only install -- costs the next process a recompilation, nothing else)
+    if (cache_path && !rtc_write(cache_path, blob)) std::fprintf(stderr, "asset_hip: cannot write the module cache %s\n", cache_path);
   }
-  hipModule_t mod = nullptr;   // stays loaded for the life of the process: its entry and device code live in it
-  HIP_TRY(hipModuleLoadData(&mod, blob.code.data()));
+  // The module stays with the process: its code object is loaded on every device a handle uses it on (registry.h:
+  // RtcModule) -- here on the current one, to read its meta table.
+  auto* rtc = new asset_hip::RtcModule();
+  rtc->code.swap(blob.code);
+  rtc->names.swap(blob.names);
+  const asset_hip::RtcModule::PerDevice* pd = nullptr;
+  hipError_t e = rtc->on_current_device(&pd);
+  if (e != hipSuccess) {
+    delete rtc;
+    return hipfail(e, "loading the run-time module (hipModuleLoadData / hipModuleGetFunction)");
+  }
   auto* table = new asset_hip::KernelTable();
   hipDeviceptr_t dmeta = nullptr;
   size_t mbytes = 0;
-  hipError_t e = hipModuleGetGlobal(&dmeta, &mbytes, mod, "asset_rtc_meta");
+  e = hipModuleGetGlobal(&dmeta, &mbytes, pd->mod, "asset_rtc_meta");
   if (e != hipSuccess || mbytes != sizeof table->meta) {
     delete table;
-    hipModuleUnload(mod);
     return fail(ASSET_HIP_ECOMPILE, "the module has no asset_rtc_meta table of the expected size (rtc_device.h)");
   }
   HIP_TRY(hipMemcpy(table->meta, reinterpret_cast<void*>(dmeta), sizeof table->meta, hipMemcpyDeviceToHost));
   if (table->meta[asset_hip::MF_KIND] != kind || (kind == 1 && (table->meta[asset_hip::MF_MODE] != mode ||
                                                                table->meta[asset_hip::MF_BLOCKED] != (blocked ? 1 : 0)))) {
     delete table;
-    hipModuleUnload(mod);
     return fail(ASSET_HIP_EINVAL, "the module was compiled for another transcription / kind than requested");
   }
-  for (auto& n : blob.names) {
-    hipFunction_t fn = nullptr;
-    if ((e = hipModuleGetFunction(&fn, mod, n.second.c_str())) != hipSuccess) {
-      delete table;
-      hipModuleUnload(mod);
-      return hipfail(e, ("hipModuleGetFunction(" + n.second + ")").c_str());
-    }
-    table->k[n.first].mod = fn;
+  for (auto& n : rtc->names) {
+    table->k[n.first].rtc = rtc;
+    table->k[n.first].slot = n.first;
   }
   auto* ke = new asset_hip::KernelEntry();
   asset_hip::entry_from_table(*ke, strdup(name), table);
@@ -453,6 +468,10 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
 
 void asset_hip_defect_destroy(asset_hip_defect_t h) {
   if (!h) return;
+  if (h->bundles > 0) {   // a bundle launches through this handle's tables and buffers: it lives until that bundle is gone
+    h->destroy_pending = true;
+    return;
+  }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : {(void*)h->d_vindex, (void*)h->d_cindex, (void*)h->d_X, (void*)h->d_L, (void*)h->d_fx,
@@ -555,11 +574,17 @@ int asset_hip_bundle_create(const char* name, const asset_hip_defect_t* members,
   auto* b = new (std::nothrow) asset_hip_bundle();
   if (!b) return fail(ASSET_HIP_EINVAL, "out of memory");
   b->ke = ke, b->members.assign(members, members + n), b->device = members[0]->device;
+  for (asset_hip_defect_t h : b->members) h->bundles++;
   *out = b;
   return 0;
 }
 
-void asset_hip_bundle_destroy(asset_hip_bundle_t b) { delete b; }
+void asset_hip_bundle_destroy(asset_hip_bundle_t b) {
+  if (!b) return;
+  for (asset_hip_defect_t h : b->members)
+    if (--h->bundles == 0 && h->destroy_pending) asset_hip_defect_destroy(h);   // (its owner let go of it earlier)
+  delete b;
+}
 
 int asset_hip_bundle_eval_device(asset_hip_bundle_t b, int what, const double* dX, const double* const* dL,
                                  double* const* d_fx, double* const* d_agx, double* const* d_kkt, void* stream) {
@@ -904,24 +929,37 @@ int asset_hip_defect_eval_kkt_device(asset_hip_defect_t h, int what, const doubl
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
   const int IR = h->ke->ir, OR = h->ke->orr;
-  if (!h->d_fx_rows) {   // the gather tables, once per handle
-    std::vector<int> rows, ptr, src;
-    auto up = [&](int*& d, const std::vector<int>& v) -> hipError_t {
-      hipError_t e = hipMalloc(&d, (v.size() + 1) * sizeof(int));
-      return e != hipSuccess ? e : hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (!h->rhs_tables_ready) {   // the gather tables, once per handle: built into locals, committed only when all of them exist
+    int* d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *fxb = nullptr, *agxb = nullptr;
+    int n_fx = 0, n_gx = 0, fx_long = 0, gx_long = 0;
+    auto build = [&]() -> hipError_t {
+      std::vector<int> rows, ptr, src;
+      auto up = [&](int*& dst, const std::vector<int>& v) -> hipError_t {
+        hipError_t e = hipMalloc(&dst, (v.size() + 1) * sizeof(int));
+        return e != hipSuccess ? e : hipMemcpy(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+      };
+      hipError_t e;
+      fx_long = build_rhs_csr(h->h_cindex, rows, ptr, src);
+      n_fx = int(rows.size());
+      if ((e = up(d[0], rows)) != hipSuccess || (e = up(d[1], ptr)) != hipSuccess || (e = up(d[2], src)) != hipSuccess) return e;
+      gx_long = build_rhs_csr(h->h_vindex, rows, ptr, src);
+      n_gx = int(rows.size());
+      if ((e = up(d[3], rows)) != hipSuccess || (e = up(d[4], ptr)) != hipSuccess || (e = up(d[5], src)) != hipSuccess) return e;
+      if ((e = hipMalloc(&fxb, sizeof(double) * size_t(h->nseg) * OR)) != hipSuccess) return e;
+      return hipMalloc(&agxb, sizeof(double) * size_t(h->nseg) * IR);
     };
-    h->fx_long_from = build_rhs_csr(h->h_cindex, rows, ptr, src);
-    h->n_fx_rows = int(rows.size());
-    HIP_TRY(up(h->d_fx_rows, rows));
-    HIP_TRY(up(h->d_fx_ptr, ptr));
-    HIP_TRY(up(h->d_fx_src, src));
-    h->gx_long_from = build_rhs_csr(h->h_vindex, rows, ptr, src);
-    h->n_gx_rows = int(rows.size());
-    HIP_TRY(up(h->d_gx_rows, rows));
-    HIP_TRY(up(h->d_gx_ptr, ptr));
-    HIP_TRY(up(h->d_gx_src, src));
-    HIP_TRY(hipMalloc(&h->d_fxb, sizeof(double) * size_t(h->nseg) * OR));
-    HIP_TRY(hipMalloc(&h->d_agxb, sizeof(double) * size_t(h->nseg) * IR));
+    const hipError_t e = build();
+    if (e != hipSuccess) {   // nothing of a half-built set stays on the handle: the next call starts over
+      for (int* p : d) if (p) hipFree(p);
+      if (fxb) hipFree(fxb);
+      if (agxb) hipFree(agxb);
+      return hipfail(e, "building the RHS gather tables");
+    }
+    h->d_fx_rows = d[0], h->d_fx_ptr = d[1], h->d_fx_src = d[2], h->d_gx_rows = d[3], h->d_gx_ptr = d[4], h->d_gx_src = d[5];
+    h->d_fxb = fxb, h->d_agxb = agxb;
+    h->n_fx_rows = n_fx, h->fx_long_from = fx_long, h->n_gx_rows = n_gx, h->gx_long_from = gx_long;
+    h->rhs_tables_ready = true;
   }
   int rc = launch(h, what, dX, dL, h->d_fxb, want_agx ? h->d_agxb : nullptr, nullptr, st, want_kkt ? d_kkt_values : nullptr);
   if (rc) return rc;

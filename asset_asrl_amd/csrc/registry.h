@@ -8,7 +8,10 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "kernel_meta.h"
 #include "mesh_kernels.h"
@@ -16,14 +19,59 @@
 namespace asset_hip {
 
 // ---- kernel references ---------------------------------------------------------------------------------------------
+// A module compiled at run time: the code object and the lowered kernel names stay with it, and it is loaded on every
+// device it is used on -- a hipModule_t (and its hipFunction_t handles) belongs to the device that was current when it
+// was loaded, while a handle of the C ABI may live on any device (asset_hip_defect_desc::device).  Loading is lazy: the
+// first launch on a device loads the code object there.
+struct RtcModule {
+  std::vector<char> code;
+  std::vector<std::pair<int, std::string>> names;   // (kernel slot, lowered name)
+  struct PerDevice {
+    hipModule_t mod = nullptr;
+    std::vector<hipFunction_t> fn;                  // by kernel slot
+  };
+  std::mutex m;
+  std::vector<PerDevice> dev;                       // by device ordinal
+  // the functions of the CURRENT device (loads the module there at first use)
+  hipError_t on_current_device(const PerDevice** out) {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(m);
+    if (int(dev.size()) <= d) dev.resize(d + 1);
+    PerDevice& pd = dev[d];
+    if (!pd.mod) {
+      hipModule_t mod = nullptr;
+      if ((e = hipModuleLoadData(&mod, code.data())) != hipSuccess) return e;
+      int nslot = 0;
+      for (auto& n : names) nslot = n.first + 1 > nslot ? n.first + 1 : nslot;
+      std::vector<hipFunction_t> fn(nslot, nullptr);
+      for (auto& n : names)
+        if ((e = hipModuleGetFunction(&fn[n.first], mod, n.second.c_str())) != hipSuccess) {
+          hipModuleUnload(mod);
+          return e;
+        }
+      pd.fn.swap(fn);
+      pd.mod = mod;
+    }
+    *out = &pd;
+    return hipSuccess;
+  }
+};
+
 struct KRef {
   const void* host = nullptr;   // host stub of a kernel linked into this process (hipLaunchKernel)
-  hipFunction_t mod = nullptr;  // kernel of a run-time module (hipModuleLaunchKernel)
-  explicit operator bool() const { return host || mod; }
+  RtcModule* rtc = nullptr;     // kernel `slot` of a run-time module (hipModuleLaunchKernel on the current device)
+  int slot = -1;
+  explicit operator bool() const { return host || rtc; }
 };
 inline hipError_t klaunch(const KRef& k, dim3 grid, dim3 block, size_t shmem, hipStream_t st, void** args) {
-  if (k.mod)
-    return hipModuleLaunchKernel(k.mod, grid.x, grid.y, grid.z, block.x, block.y, block.z, unsigned(shmem), st, args, nullptr);
+  if (k.rtc) {
+    const RtcModule::PerDevice* pd = nullptr;
+    hipError_t e = k.rtc->on_current_device(&pd);
+    if (e != hipSuccess) return e;
+    return hipModuleLaunchKernel(pd->fn[k.slot], grid.x, grid.y, grid.z, block.x, block.y, block.z, unsigned(shmem), st, args, nullptr);
+  }
   if (!k.host) return hipErrorInvalidDeviceFunction;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(k.host, hipFuncAttributeMaxDynamicSharedMemorySize, int(shmem));

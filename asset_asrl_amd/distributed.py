@@ -65,21 +65,52 @@ class HostSharedBlocks:
             tag = box[0]
         self.path = os.path.join("/dev/shm", tag)
         n = self.slot * world
-        if rank == 0:
-            with open(self.path, "wb") as f:
-                f.truncate(n * 8)
-        self._barrier()
-        self.buf = torch.from_file(self.path, shared=True, size=n, dtype=torch.float64)
-        self._registered = False
-        if torch.cuda.is_available():         # page-lock the mapping: the D2H copies then run at the link's rate
-            rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), n * 8, 0)
-            if int(rc) != 0:
-                raise RuntimeError(f"cudaHostRegister of the shared block buffer failed (rc={int(rc)})")
-            self._registered = True
-        self.mine = self.buf[rank * self.slot:(rank + 1) * self.slot]
-        self._barrier()
-        if rank == 0:
-            os.unlink(self.path)              # every rank holds its mapping; the name is no longer needed
+        self.buf, self._registered = None, False
+        # Every local step that can fail is followed by an agreement among the ranks (an all-reduce of a success flag in
+        # place of a bare barrier): a failure on one rank raises on ALL of them at the same point, nobody is left waiting
+        # in a collective, and rank 0 removes the /dev/shm name whatever happened.
+        try:
+            err = None
+            if rank == 0:
+                try:
+                    with open(self.path, "wb") as f:
+                        f.truncate(n * 8)
+                except OSError as exc:
+                    err = exc
+            self._agree(err, "creating the shared block buffer")
+            try:
+                self.buf = torch.from_file(self.path, shared=True, size=n, dtype=torch.float64)
+                if torch.cuda.is_available():     # page-lock the mapping: the D2H copies then run at the link's rate
+                    rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), n * 8, 0)
+                    if int(rc) != 0:
+                        raise RuntimeError(f"cudaHostRegister of the shared block buffer failed (rc={int(rc)})")
+                    self._registered = True
+            except Exception as exc:              # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+                err = exc
+            self._agree(err, "mapping / page-locking the shared block buffer")
+            self.mine = self.buf[rank * self.slot:(rank + 1) * self.slot]
+        except Exception:
+            self.close()
+            raise
+        finally:
+            if rank == 0:                         # every rank holds its mapping (or the construction failed everywhere)
+                try:
+                    os.unlink(self.path)
+                except OSError:
+                    pass
+
+    def _agree(self, err, what: str):
+        """All ranks learn whether any of them failed; raises on every rank if so."""
+        ok = 0 if err is not None else 1
+        if self._dist is not None and self.world > 1:
+            import torch
+            g = self.barrier_group if self.barrier_group is not None else self.group
+            on_gpu = self._dist.get_backend(g) == "nccl"
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+            self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN, group=g)
+            ok = int(flag.item())
+        if not ok:
+            raise RuntimeError(f"HostSharedBlocks: {what} failed on " + ("this rank: " + repr(err) if err is not None else "another rank"))
 
     def _barrier(self):
         if self._dist is not None and self.world > 1:
@@ -103,9 +134,38 @@ class HostSharedBlocks:
         if self._registered:
             torch.cuda.cudart().cudaHostUnregister(self.buf.data_ptr())
             self._registered = False
+        self.buf = self.mine = None           # drops the mapping
 
 
-class ShardedDefectEvaluator:
+class _StreamOrder:
+    """Orders the exchange after the evaluation whatever streams the caller uses.  ``eval_device(stream=None)`` enqueues on
+    torch's CURRENT stream (not on the handle's private stream, which torch knows nothing about); every evaluation records
+    an event on the stream it went to, and ``gather_device`` / ``push_host`` make the stream they run on wait for it -- a
+    no-op on the same stream, a cross-stream dependency otherwise.  (c10d orders a collective after the current stream
+    only.)"""
+    _eval_event = None
+
+    def _eval_stream(self, stream):
+        import torch
+        if not torch.cuda.is_available():
+            return stream
+        return torch.cuda.current_stream() if stream is None else stream
+
+    def _mark_evaluated(self, stream):
+        import torch
+        if not torch.cuda.is_available() or stream is None or isinstance(stream, int):
+            return
+        if self._eval_event is None:
+            self._eval_event = torch.cuda.Event()
+        self._eval_event.record(stream)
+
+    def _after_evaluation(self):
+        import torch
+        if self._eval_event is not None and torch.cuda.is_available():
+            torch.cuda.current_stream().wait_event(self._eval_event)
+
+
+class ShardedDefectEvaluator(_StreamOrder):
     def __init__(self, ode: str, mode, blocked: bool, vindex, cindex, n_primal: int, n_equal: int,
                  rank: Optional[int] = None, world: Optional[int] = None, device: int = 0, group=None,
                  evaluator_factory: Optional[Callable] = None):
@@ -170,9 +230,11 @@ class ShardedDefectEvaluator:
         tensors (the whole solver vectors).  Returns the (fx, agx, kkt) views of the local shard."""
         if self._local is None:
             raise RuntimeError("call alloc_device() first")
+        stream = self._eval_stream(stream)
         if self.ev is not None:
             self.ev.eval_device(what, X, L, self.fx, self.agx if what in _ADJ else None,
                                 self.kkt if what >= 2 else None, stream)
+        self._mark_evaluated(stream)
         return self.fx[:self.count], self.agx[:self.count], self.kkt[:self.count]
 
     def gather_device(self, async_op: bool = False):
@@ -180,6 +242,7 @@ class ShardedDefectEvaluator:
         work already enqueued on the current stream (c10d semantics); returns the work handle when `async_op`."""
         if self.world == 1 and self._recv is None:
             return None
+        self._after_evaluation()
         out = list(self._recv.unbind(0)) if self.rank == self._dst else None
         return self.dist.gather(self._local, out, dst=self._dst, group=self.group, async_op=async_op)
 
@@ -191,6 +254,7 @@ class ShardedDefectEvaluator:
         return self
 
     def push_host(self):
+        self._after_evaluation()
         self._host.push(self._local)
 
     def wait_host(self, stream=None):
@@ -237,7 +301,7 @@ class ShardedDefectEvaluator:
         return torch.cat([o[:c] for o, (_, c) in zip(out, self.shards)], dim=0)
 
 
-class PhaseShardedEvaluator:
+class PhaseShardedEvaluator(_StreamOrder):
     """Several phases of one problem (same ODE / transcription / size), whole phases per rank: phase k belongs to rank
     k % world.  `phases` = list of (vindex, cindex) tables into the problem's X and L.
 
@@ -299,14 +363,16 @@ class PhaseShardedEvaluator:
         return self
 
     def eval_device(self, what: int, X, L=None, stream=None):
-        if self.ev is None:
-            return
-        fx, agx, kkt = self._views(self._local, len(self.mine))
-        self.ev.eval_device(what, X, L, fx, agx if what in _ADJ else None, kkt if what >= 2 else None, stream)
+        stream = self._eval_stream(stream)
+        if self.ev is not None:
+            fx, agx, kkt = self._views(self._local, len(self.mine))
+            self.ev.eval_device(what, X, L, fx, agx if what in _ADJ else None, kkt if what >= 2 else None, stream)
+        self._mark_evaluated(stream)
 
     def gather_device(self, async_op: bool = False):
         if self.world == 1 and self._recv is None:
             return None
+        self._after_evaluation()
         out = list(self._recv.unbind(0)) if self.rank == self._dst else None
         return self.dist.gather(self._local, out, dst=self._dst, group=self.group, async_op=async_op)
 

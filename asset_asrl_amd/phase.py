@@ -217,8 +217,9 @@ class Phase:
         xtuv, opv, spv = [int(v) for v in XtUVars], [int(v) for v in OPVars], [int(v) for v in SPVars]
         if integrand.ORows() != 1 or integrand.IRows() != len(xtuv) + len(opv) + len(spv):
             raise ValueError("an integrand has one output and takes the listed state variables and parameters")
-        if self.ode.TVar() in xtuv:
-            raise ValueError("list the time variable among the integrand's inputs only through a state variable copy")
+        # (the time variable may be among the integrand's inputs: the quadrature appends it again for the node times,
+        #  xtrap.head(xp) = XtUVars; xtrap[xp] = TVar, ODEPhaseBase.cpp:786-790 -- the Vindex row then names it twice and the
+        #  duplicate-location Hessian entries are summed by the assembly like any other shared location)
         self._integral_objs.append((integrand, xtuv, opv, spv))
         self._ev = None
         return len(self._integral_objs) - 1
@@ -244,14 +245,14 @@ class Phase:
         units += [1.0] * (func.IRows() - len(units))
         return IOScaled(func, units, np.ones(func.ORows()))
 
-    def _function_tables(self, ix):
+    def _function_tables(self, ix, iq_offset: int = 0):
         """Host-only: every function the phase hands the solver beside its defects, with its index tables, in the
         reference's registration order (transcribe_phase, ODEPhaseBase.cpp:1371-1375: dynamics, axis functions, control
         functions, integrals, user functions).  Returns (entries, numPhaseEqCons, numPhaseIqCons); an entry is
         (kind, tag, function, device name, Vindex, Cindex, per-application constants or None), kind in
         {"auto", "equality", "inequality", "objective"}."""
         from .pathfuncs import LGLControlSpline, LGLIntegral, LGLMeshSpacing, SingleMeshSpacing
-        next_eq, next_iq = ix.con_offset + ix.numPhaseEqCons, 0
+        next_eq, next_iq = ix.con_offset + ix.numPhaseEqCons, int(iq_offset)
         cs, D, tv = ix.DefectCardinalStates, ix.numDefects, [self.ode.TVar()]
         out = []
         if self.EnableMeshSpacing:
@@ -263,8 +264,13 @@ class Phase:
                 # function object per state, addPartitionedEquality): ONE device function whose spacing is a constant of the
                 # application (vf.ApplConst), so the D - 1 relations are one batched evaluator
                 V, Cx, next_eq = ix.make_Vindex_Cindex("FrontNodalBackPath", tv, (), (), 1, next_eq)
+                # the spacing constants are the mesh's own nodal spacing (the reference: the phase's DefBinSpacing, :963-970):
+                # i / D on the uniform mesh setTraj builds, whatever the active trajectory holds otherwise
+                tn = self.ActiveTraj[::cs - 1, self.ode.TVar()]
+                cspace = (tn[1:-1] - tn[0]) / (tn[-1] - tn[0])
+                uniform = np.arange(1, D) / D
                 out.append(("auto", "nodal_spacing", SingleMeshSpacing(None), "nodalmeshspacing", V, Cx,
-                            (np.arange(1, D) / D)[:, None]))               # cspace of one bin (:963-970)
+                            (uniform if np.allclose(cspace, uniform, rtol=0.0, atol=1e-13) else cspace)[:, None]))
         if self.ode.UVars() > 0 and not self._blocked() and D >= 2:   # transcribe_control_funcs
             order = {("LGL7", "HighestOrderSpline"): 2, ("LGL7", "FirstOrderSpline"): 1, ("LGL5", "HighestOrderSpline"): 1,
                      ("LGL5", "FirstOrderSpline"): 1}.get((self.TranscriptionMode, self.ControlMode))
@@ -289,7 +295,7 @@ class Phase:
                     next_iq = nxt
                 out.append(("equality" if is_eq else "inequality", f"{'eq' if is_eq else 'iq'}{k}", f,
                             f"{'eq' if is_eq else 'iq'}{k}_{region.lower()}", V, Cx, None))
-        return out, next_eq - ix.con_offset, next_iq
+        return out, next_eq - ix.con_offset, next_iq - int(iq_offset)
 
     def _make_function_evaluators(self, ix, build_only: bool = False):
         from .pathfuncs import FunctionEvaluator as _FE
@@ -309,16 +315,18 @@ class Phase:
             else:
                 {"equality": self._eq_evs, "inequality": self._iq_evs, "objective": self._obj_evs}[kind].append(ev)
 
-    def layout(self):
+    def layout(self, Vstart: int = 0, Estart: int = 0, Istart: int = 0):
         """Host-only description of what the phase hands the solver (no device needed): the PhaseIndexer, the defect
-        tables and the entries of ``_function_tables``.  -> (indexer, (Vindex, Cindex) of the defects, entries,
-        numPhaseEqCons, numPhaseIqCons)."""
+        tables and the entries of ``_function_tables``, with the phase's variables starting at ``Vstart`` of the solver
+        vector, its equality rows at ``Estart`` and its inequality rows at ``Istart`` -- the arguments of the reference's
+        ``transcribe_phase(Vstart, Estart, Istart, ...)`` (OptimalControlProblem.cpp:131-146).  -> (indexer, (Vindex, Cindex)
+        of the defects, entries, numPhaseEqCons, numPhaseIqCons)."""
         if self.ActiveTraj is None:
             raise RuntimeError("No trajectory set: call setTraj first")
         ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
         ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
-        ix.begin_indexing(0, 0)
-        entries, neq, niq = self._function_tables(ix)
+        ix.begin_indexing(Vstart, Estart)
+        entries, neq, niq = self._function_tables(ix, Istart)
         return ix, ix.make_defect_Vindex_Cindex(), entries, neq, niq
 
     @property

@@ -197,17 +197,22 @@ def main():
         n_primal, n_equal, Xh, Lh = w.n_primal, w.n_equal, w.X, w.L
         total_segments = nseg
     else:
-        ws, voff, coff = [], 0, 0
+        # configs[3]: linked phases in ONE solver vector, placed by the OptimalControlProblem mirror
+        # (asset_asrl_amd/ocp.py; OptimalControlProblem.cpp:115-155): defects only, no mesh-spacing rows
+        from asset_asrl_amd.ocp import OptimalControlProblem
+        from asset_asrl_amd.ode import ODE_LIBRARY
+        ocp, ws = OptimalControlProblem(), []
         for k in range(nphases):
-            wk = Workload(ode, mode, nseg, blocked, seed=100 + k, var_offset=voff, con_offset=coff)
+            wk = Workload(ode, mode, nseg, blocked, seed=100 + k)
+            ph = ODE_LIBRARY[ode]().phase(mode, wk.traj, nseg)
+            ph.setControlMode("BlockConstant" if blocked else "NoSpline")
+            ph.EnableMeshSpacing = False
+            ocp.addPhase(ph)
             ws.append(wk)
-            voff, coff = wk.n_primal, wk.n_equal
-        n_primal, n_equal = ws[-1].n_primal, ws[-1].n_equal
-        Xh, Lh = np.zeros(n_primal), np.zeros(n_equal)
-        for wk in ws:
-            v0, c0 = wk.indexer.var_offset, wk.indexer.con_offset
-            Xh[v0:v0 + wk.indexer.numPhaseVars] = wk.X[v0:v0 + wk.indexer.numPhaseVars]
-            Lh[c0:c0 + wk.indexer.numPhaseEqCons] = wk.L[c0:c0 + wk.indexer.numPhaseEqCons]
+        phase_tables = ocp.defect_tables()
+        n_primal, n_equal = ocp.n_primal, ocp.n_equal
+        Xh = ocp.solver_input()
+        Lh = np.concatenate([wk.L[:wk.indexer.numPhaseEqCons] for wk in ws])
         w = ws[0]
         total_segments = nphases * nseg
     blocked = w.blocked
@@ -223,7 +228,7 @@ def main():
             local_segments = sh.count
             evs = [sh.ev] if sh.ev is not None else []
         else:
-            sh = PhaseShardedEvaluator(ode, mode, blocked, [(wk.vindex, wk.cindex) for wk in ws], n_primal, n_equal,
+            sh = PhaseShardedEvaluator(ode, mode, blocked, phase_tables, n_primal, n_equal,
                                        rank=rank, world=world, device=local_rank)
             local_segments = len(sh.mine) * nseg
             evs = [sh.ev] if sh.ev is not None else []
@@ -360,12 +365,15 @@ def main():
     # nothing else on the stream); with an exchange in the step (N > 1) the kernel's own settled HIP-event figure
     ms_roof = ms_timed_region if (world == 1 and exchange is None) else ms_kernel
     achieved = local_segments * bseg / (ms_roof * 1e-3) / 1e9 if ms_roof > 0 else 0.0
-    per_rank_ms = [ms_kernel]
+    per_rank_ms, per_rank_segments = [ms_kernel], [local_segments]
     if dist is not None:
-        t = torch.tensor([ms_kernel], dtype=torch.float64, device=dev)
+        t = torch.tensor([ms_kernel, float(local_segments)], dtype=torch.float64, device=dev)
         allk = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allk, t)
-        per_rank_ms = [float(x.item()) for x in allk]
+        per_rank_ms = [float(x[0].item()) for x in allk]
+        per_rank_segments = [int(x[1].item()) for x in allk]
+    # every rank's own kernel against ITS roofline: algorithmic bytes of its share / its settled HIP-event kernel time
+    per_rank_frac = [(n * bseg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0 for n, ms in zip(per_rank_segments, per_rank_ms)]
 
     traffic, traffic_src = None, None
     prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_{a.workload}_pmc.json") for r in (3, 2)) if os.path.exists(q)), "")
@@ -413,7 +421,7 @@ def main():
                                                                      else "settled HIP-event rounds (the step also holds the exchange)"),
                          "kernel_ms": ms_kernel, "kernel_ms_rounds": kernel_rounds, "segments_in_kernel": local_segments,
                          "algorithmic_bytes_per_segment": bseg},
-            "per_rank_kernel_ms": per_rank_ms,
+            "per_rank_kernel_ms": per_rank_ms, "per_rank_segments": per_rank_segments, "per_rank_roofline_frac": per_rank_frac,
             "secondary": {"evalOCC (CON: defect values only), rank 0's share, kernel": {
                 "ms": ms_con, "segments_per_s": local_segments / (ms_con * 1e-3) if ms_con > 0 else 0.0,
                 "algorithmic_bytes_per_segment": 8 * (IR + OR) + 8 * OR},

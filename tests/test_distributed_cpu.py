@@ -95,13 +95,14 @@ def _worker(rank, world, port, nseg, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nseg", [9, 1])
-def test_two_rank_shard_and_gather(oracle, nseg):
+@pytest.mark.parametrize("nseg,world", [(9, 2), (1, 2), (10, 4), (3, 4)])   # uneven shards; fewer segments than ranks
+def test_shard_and_gather(oracle, nseg, world):
     import torch.multiprocessing as mp
+    from asset_asrl_amd.indexing import thread_split
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, nseg, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nseg, q)) for r in range(world)]
     for p in procs:
         p.start()
     tagged = q.get(timeout=120)
@@ -113,7 +114,9 @@ def test_two_rank_shard_and_gather(oracle, nseg):
         assert p.exitcode == 0
     w = Workload("reentry", "LGL5", nseg)
     rfx, ragx, rkkt = w.oracle_nlp(oracle).eval_blocks(oracle.JAC_ADJGRAD_HESS, w.X, w.L)
-    assert [c for _, c in shards] == ([5, 4] if nseg == 9 else [1, 0])
+    expect = [c for _, c in thread_split(nseg, world)]
+    assert [c for _, c in shards] == expect + [0] * (world - len(expect))
+    assert {(9, 2): [5, 4], (1, 2): [1, 0], (10, 4): [3, 3, 2, 2], (3, 4): [1, 1, 1, 0]}[(nseg, world)] == [c for _, c in shards]
     for got, ref in ((fx, rfx), (agx, ragx), (kkt, rkkt), (dfx, rfx), (dagx, ragx), (dkkt, rkkt), (hfx, rfx), (hagx, ragx),
                      (hkkt, rkkt)):
         np.testing.assert_array_equal(got, ref)
@@ -123,19 +126,28 @@ def _phase_worker(rank, world, port, nphases, nseg, q):
     import torch
     dist = _init(rank, world, port)
     from asset_asrl_amd.distributed import PhaseShardedEvaluator
-    ws, voff, coff = [], 0, 0
+    # the phases placed in one solver vector by the OptimalControlProblem mirror (OptimalControlProblem.cpp:115-155) ...
+    from asset_asrl_amd.ocp import OptimalControlProblem
+    from asset_asrl_amd.ode import TwoBody
+    ocp, ws, voff, coff = OptimalControlProblem(), [], 0, 0
     for k in range(nphases):
         wk = Workload("twobody_lt", "LGL5", nseg, True, seed=100 + k, var_offset=voff, con_offset=coff)
         ws.append(wk)
         voff, coff = wk.n_primal, wk.n_equal
-    n_primal, n_equal = ws[-1].n_primal, ws[-1].n_equal
-    X, L = np.zeros(n_primal), np.zeros(n_equal)
+        ph = TwoBody().phase("LGL5", wk.traj, nseg)
+        ph.setControlMode("BlockConstant")
+        ph.EnableMeshSpacing = False
+        ocp.addPhase(ph)
+    n_primal, n_equal = ocp.n_primal, ocp.n_equal
+    assert (n_primal, n_equal) == (ws[-1].n_primal, ws[-1].n_equal)     # ... where offsets rolled by hand put them
+    for wk, (V, Cx) in zip(ws, ocp.defect_tables()):
+        np.testing.assert_array_equal(V, wk.vindex)
+        np.testing.assert_array_equal(Cx, wk.cindex)
+    X, L = ocp.solver_input(), np.zeros(n_equal)
     for wk in ws:
-        v0, c0 = wk.indexer.var_offset, wk.indexer.con_offset
-        X[v0:v0 + wk.indexer.numPhaseVars] = wk.X[v0:v0 + wk.indexer.numPhaseVars]
+        c0 = wk.indexer.con_offset
         L[c0:c0 + wk.indexer.numPhaseEqCons] = wk.L[c0:c0 + wk.indexer.numPhaseEqCons]
-    sh = PhaseShardedEvaluator("twobody_lt", "LGL5", True, [(wk.vindex, wk.cindex) for wk in ws], n_primal, n_equal,
-                               evaluator_factory=_OracleShard)
+    sh = ocp.phase_sharded_evaluator(evaluator_factory=_OracleShard)
     assert sh.mine == list(range(rank, nphases, world))
     sh.alloc_device(torch.device("cpu"))
     sh.eval_device(4, torch.from_numpy(X), torch.from_numpy(L))
@@ -155,17 +167,57 @@ def _phase_worker(rank, world, port, nphases, nseg, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_phase_deal_and_gather(oracle):
+@pytest.mark.parametrize("nphases,world", [(3, 2), (5, 4), (3, 4)])
+def test_phase_deal_and_gather(oracle, nphases, world):
     """BASELINE.json configs[3] shape: linked phases dealt round-robin (three phases on two ranks: the last slot of
-    rank 1 stays unused)."""
+    rank 1 stays unused; five on four; fewer phases than ranks)."""
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_phase_worker, args=(r, 2, port, 3, 6, q)) for r in range(2)]
+    procs = [ctx.Process(target=_phase_worker, args=(r, world, port, nphases, 6, q)) for r in range(world)]
     for p in procs:
         p.start()
     assert q.get(timeout=120) == "ok"
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+
+
+def _failing_worker(rank, world, port, q):
+    """HostSharedBlocks when ONE rank cannot map the buffer: every rank raises, nobody hangs, the name is removed."""
+    import torch
+    dist = _init(rank, world, port)
+    from asset_asrl_amd import distributed as D
+    if rank == 1:
+        real = torch.from_file
+
+        def broken(*a, **k):
+            raise OSError("no mapping for you")
+        torch.from_file = broken
+    try:
+        D.HostSharedBlocks(64, rank, world, tag=f"asset_hip_test_fail_{port}")
+        q.put((rank, "constructed"))
+    except RuntimeError as exc:
+        q.put((rank, "raised", str(exc)))
+    if rank == 1:
+        torch.from_file = real
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_host_shared_blocks_fail_on_every_rank_together():
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == ["raised", "raised"], got
+    assert "another rank" in got[0][2] and "this rank" in got[1][2]
+    assert not os.path.exists(f"/dev/shm/asset_hip_test_fail_{port}")

@@ -33,6 +33,16 @@ with torch.cuda.stream(st):
 torch.cuda.synchronize()
 fx, agx, kkt = [t.cpu().numpy() for t in sh.blocks_on_root()]
 rfx, ragx, rkkt = w.oracle_nlp(ob, threads=4).eval_blocks(4, w.X, w.L)
+# evaluation and exchange on DIFFERENT streams, no stream argument: the exchange must still see the finished blocks
+sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+sh._local.zero_(); sh._recv.zero_()
+torch.cuda.synchronize()
+with torch.cuda.stream(sA):
+    sh.eval_device(4, X, L)
+with torch.cuda.stream(sB):
+    sh.gather_device()
+torch.cuda.synchronize()
+cross = bool(all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(sh.blocks_on_root(), (fx, agx, kkt))))
 # host-visible exchange: the flat buffer copied into this rank's range of the shared page-locked host buffer
 sh.alloc_host_shared()
 with torch.cuda.stream(st):
@@ -43,7 +53,7 @@ hfx, hagx, hkkt = sh.host_shard_blocks()[0]
 host_same = bool(np.array_equal(hfx, fx) and np.array_equal(hagx, agx) and np.array_equal(hkkt, kkt))
 sh._host.close()
 print(json.dumps({{"fx": float(np.abs(fx - rfx).max() / max(1.0, np.abs(w.X).max())), "agx": rel_err(agx, ragx),
-                  "kkt": rel_err(kkt, rkkt), "shape": list(kkt.shape), "host_same": host_same}}))
+                  "kkt": rel_err(kkt, rkkt), "shape": list(kkt.shape), "host_same": host_same, "cross_stream": cross}}))
 dist.destroy_process_group()
 """
 
@@ -56,6 +66,7 @@ def test_sharded_device_path_with_rccl_gather_matches_the_oracle(oracle):
     assert out["shape"] == [333, 1008]
     assert out["fx"] < 1e-10 and out["agx"] < 1e-8 and out["kkt"] < 1e-8, out
     assert out["host_same"]                  # the host-shared exchange delivers the same bits
+    assert out["cross_stream"]               # evaluation on one stream, gather on another: ordered by the evaluator
 
 
 @pytest.mark.gpu
@@ -69,6 +80,7 @@ def test_bench_runs_the_exchange_path_with_one_rank():
     assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 0
     assert "exchange_ms" in out and out["exchange_bytes_into_root"] > 8e7
     assert out["host_visible"]["ms_per_step"] > out["ms_per_step"] and out["host_visible"]["bytes_per_rank"] > 8e7
+    assert len(out["per_rank_roofline_frac"]) == 1 and 0.05 < out["per_rank_roofline_frac"][0] < 1.0
 
 
 @pytest.mark.gpu

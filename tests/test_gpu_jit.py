@@ -127,3 +127,23 @@ def test_cold_run_time_compilation_of_a_never_seen_ode(oracle):
         ev.close()
     finally:
         shutil.rmtree(wd, ignore_errors=True)                             # (the module stays loaded; its files need not stay)
+
+
+def test_run_time_module_follows_the_handle_to_another_device(oracle):
+    """A module compiled at run time is loaded on every device it is used on (registry.h: RtcModule): a handle created with
+    device = 1 while device 0 is current launches the module's kernels on device 1.  Needs two GPUs."""
+    from asset_asrl_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("one GPU visible")
+    ode = make_vanderpol()
+    ph = ode.phase("LGL5", Workload("vanderpol", "LGL5", 9, sizes=(2, 1, 1)).traj, 9)
+    ph.device = 1
+    ev = ph.evaluator
+    w = Workload("vanderpol", "LGL5", 9, sizes=(2, 1, 1))
+    X, L = ph.solver_input(), np.linspace(-1.0, 1.0, ev.n_equal)
+    got = ev.eval(JAC_ADJGRAD_HESS, X, L)
+    ph.device = 0
+    ph._ev = None
+    same = ph.evaluator.eval(JAC_ADJGRAD_HESS, X, L)
+    for a, b in zip(got, same):
+        np.testing.assert_array_equal(a, b)
