@@ -446,7 +446,7 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
   }
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   // per-lane constants of the dense stage: computed here, once
-    for (int level = 1; level <= 2; level++) {
+    for (int level = 0; level <= 2; level++) {   // (0: the record of the resident kernel)
       const size_t nb = asset_hip::entry_lane_bytes(ke, level);
       if (!nb) continue;
       // ASSET_LANE_REPLICAS copies: every workgroup of the dense stage loads the whole table when it starts, all at the
@@ -478,7 +478,7 @@ void asset_hip_defect_destroy(asset_hip_defect_t h) {
                   (void*)h->d_agx, (void*)h->d_kkt, (void*)h->d_work, (void*)h->d_map, (void*)h->d_values, (void*)h->d_aconst,
                   (void*)h->d_stage, (void*)h->d_multi_ptr, (void*)h->d_multi_loc, (void*)h->d_fx_rows, (void*)h->d_fx_ptr,
                   (void*)h->d_fx_src, (void*)h->d_gx_rows, (void*)h->d_gx_ptr, (void*)h->d_gx_src, (void*)h->d_fxb, (void*)h->d_agxb,
-                  h->d_lane[1], h->d_lane[2]})
+                  h->d_lane[0], h->d_lane[1], h->d_lane[2]})
     if (p) (void)hipFree(p);
   if (h->h_values) (void)hipHostFree(h->h_values);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -517,7 +517,8 @@ static int fill_args(asset_hip_defect_t h, int what, const double* dX, const dou
   a.AGX = (what == ASSET_HIP_CON || what == ASSET_HIP_JAC) ? nullptr : dagx;
   a.KKT = (what >= ASSET_HIP_JAC) ? dkkt : nullptr;
   a.work = h->d_work;
-  a.lane_consts = h->d_lane[level];
+  a.lane_consts = level >= 1 ? h->d_lane[level] : nullptr;
+  a.lane_consts_res = h->d_lane[0];
   a.appl_consts = h->d_aconst;
   if (h->ke->naconst > 0 && !h->d_aconst)
     return fail(ASSET_HIP_EINVAL, "this function reads constants of its applications: call asset_hip_defect_set_appl_consts first");

@@ -55,6 +55,7 @@ struct EvalArgs {
   int nvalues = 0;
   // per-lane constants of the dense stage, computed once per handle (defect_kernels.h: LaneConsts, lane_setup_kernel)
   const void* lane_consts = nullptr;
+  const void* lane_consts_res = nullptr;   // the record of the resident kernel (defect_resident.h: ResLane)
   // plain functions (func_kernels.h): constants of every application, [nseg][F::NACONST] (vf.ApplConst) or null
   const double* appl_consts = nullptr;
   // bit 0 (ASSET_HIP_KEEP_HESSIAN_SLOTS, Jacobian kinds): the Hessian slots of the KKT blocks are not written at all

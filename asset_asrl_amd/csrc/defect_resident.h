@@ -1,0 +1,663 @@
+// The RESIDENT form of one evaluation (value + Jacobian + adjoint gradient + adjoint Hessian) of narrow LGL shapes:
+// one launch, and the ODE results of a wave's segments never leave the chip.
+//
+// What the fused kernel of defect_kernels.h (STAGE 3) still pays, measured on the north-star phase (10 000 Reentry-LGL7
+// segments): the per-segment slot of ODE results (460 doubles) is written to the workspace in HBM by the ODE stage and read
+// back by the dense stage -- 37 MB each way beside 88 MB of blocks, plus the copy-out phases of the ODE stage (12 k of its
+// 32 k cycles).  The slots did not fit the 20 KiB of LDS a wave has at 8 waves per CU because the dense stage needs 14 KiB
+// of scratch tiles of its own (DI_i state rows / M^T, the constant rows of DI_i, the DC tile).  This kernel needs none of them:
+//   * the fragments of DI_i = d(x^_i, tau_i, u^_i)/dz are built in registers straight from the slot (one LDS read per
+//     fragment element and tile, shared by the K interiors: DI_i[b][c] = A_ij [cc == b] + h B_ij J_j[b][cc]);
+//   * M_i = (h E_i H^_i) DI_i is formed with H^_i as the A operand, so that accumulator entry v of a column tile IS the B
+//     operand of k-step v of  H += DI_i^T M_i  (the trick of defect_wide.h): M never goes through LDS;
+//   * the cardinal part of J (DC) is formed per accumulator entry from the slot, as the initial value of the J^T tiles;
+//   * J^T lam is taken column by column in closed form (no pass over a DC tile).
+// LDS of a wave: weight tables, GR slots, a few short vectors -- GR = 5 Reentry-LGL7 segments in 19.7 KiB.  The ODE stage
+// (lane <-> evaluation point, one pass per phase, generated bodies out of line) writes its results into the slots and
+// nowhere else; the only global traffic of the kernel is the gather of z / lam, the per-lane constant record and the
+// result blocks.  Reference: /root/reference/src/OptimalControl/LGLDefects.h:289-551 (phase order :341-412, the products
+// :414-506, the time rows / columns :508-511, adjgrad :512); slot order of the blocks DenseFunctionBase.h:1112-1123.
+//
+// Shapes: LGL3/5/7, no ODE parameters in the segment input (p == 0: not BlockConstant), N + 1 <= 16, defect rows in one
+// 16-row tile (K n <= 16), not a heavy right-hand side.  Meshes of at most GR segments per wave (10 240 Reentry-LGL7 segments
+// on 256 CUs); everything else takes the kernels of defect_kernels.h.
+#pragma once
+#include "defect_kernels.h"
+
+namespace asset_hip {
+
+template <class D>
+struct ResDims {
+  using Ode = typename D::ode_t;
+  static constexpr int K = D::K, CS = D::CS, n = D::n, N = D::N, q = D::q, IR = D::IR, OR = D::OR, IRP = D::IRP;
+  // slot of one segment (doubles): the sections of Dims (z | lam | Cf | CJ | Cg | CH | If | IJ | Ig | IH), a cell that always
+  // holds 0.0 (target of every "no entry" offset), then the saved transcendentals of the cardinal nodes -- which alias the Cg
+  // section when they fit (P1 writes them, P3 reads its own into registers before it writes g_j there)
+  static constexpr bool SV_ALIAS = Ode::NSAVE <= N;
+  static constexpr int s_Z0 = D::WSLOTD;
+  static constexpr int s_SV = SV_ALIAS ? D::w_Cg : D::WSLOTD + 1;
+  static constexpr int SV_LD = SV_ALIAS ? N : Ode::NSAVE;
+  static constexpr int SLOT = (D::WSLOTD + 1 + (SV_ALIAS ? 0 : CS * Ode::NSAVE)) | 1;   // odd: conflict-free across segments
+  // wave-level scratch behind the slots
+  static constexpr int x_AUX = 0;                  // [K][4]: 1 - s_i, s_i, 0, 0  (tau row of DI_i, same row stride as the tables)
+  static constexpr int x_HT = x_AUX + 4 * K;       // [IRP] full time-partial vector (rank-2 rows)
+  static constexpr int x_CL = x_HT + IRP;          // [CS][n]  sum_i C_ij lam_(i,r)
+  static constexpr int x_WL = x_CL + CS * n;       // [CS][n]  sum_i D_ij lam_(i,r)
+  static constexpr int XTRA = x_WL + CS * n;
+  static constexpr int LDS_WAVE = 20 * 1024;       // 160 KiB / 8 waves per CU
+  static constexpr int GR_FIT = (LDS_WAVE / 8 - D::TABSZ - XTRA) / SLOT;
+  static constexpr int GR = GR_FIT < 64 / CS ? GR_FIT : 64 / CS;
+  static constexpr size_t lds_bytes() { return size_t(D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA) * 8; }
+  static constexpr bool OK = !D::TRAP && !D::WIDE && D::p == 0 && D::TJ == 1 && N + 1 <= 16 && Ode::NUNITS == 1 && GR >= 2 &&
+                             D::STAGED;
+  static constexpr int lkN = N & 3, vN = N >> 2;   // accumulator entry that holds row N of an M tile (the E g^ row)
+  // lower-triangle H tiles that can hold a cardinal Hessian block (tiles_share_node), numbered among themselves
+  static constexpr int sh_index(int tix_want) {
+    int k = 0;
+    for (int rt = 0; rt < D::TI; rt++)
+      for (int ct = 0; ct <= rt; ct++) {
+        if (rt * (rt + 1) / 2 + ct == tix_want) return tiles_share_node<D>(ct, rt) ? k : -1;
+        if (tiles_share_node<D>(ct, rt)) k++;
+      }
+    return -1;
+  }
+  static constexpr int NSH = [] {
+    int k = 0;
+    for (int rt = 0; rt < D::TI; rt++)
+      for (int ct = 0; ct <= rt; ct++) k += tiles_share_node<D>(ct, rt) ? 1 : 0;
+    return k > 0 ? k : 1;
+  }();
+};
+
+// ---------------------------------------------------------------------------------------------- ODE stage: accessors
+template <class D>
+struct OdeOutRes {   // every result of an ODE body goes to the segment's LDS slot
+  lds_double* f_;
+  lds_double* J_;
+  lds_double* g_;
+  lds_double* H_;
+  lds_double* sv_;
+  __device__ void f(int k, double v) { if (f_) f_[k] = v; }
+  __device__ void J(int k, int i, double v) {
+    const int c = D::ode_t::JPOS[k * D::N + i];
+    if (c >= 0 && J_) J_[c] = v;
+  }
+  __device__ void g(int i, double v) { if (g_) g_[i] = v; }
+  __device__ void H(int i, int j, double v) {
+    const int c = D::ode_t::HPOS[i * (i + 1) / 2 + j];
+    if (c >= 0 && H_) H_[c] = v;
+  }
+  __device__ void save(int k, double v) { if (sv_) sv_[k] = v; }
+};
+template <class D>
+struct CardInRes {   // y = [z_j (q)] from the slot; lam = adjoint weights and saved transcendentals in registers
+  const lds_double* z;
+  const double* w;
+  const double* sv;
+  int j;
+  __device__ double y(int i) const { return z[j * D::q + i]; }
+  __device__ double lam(int k) const { return w[k]; }
+  __device__ double saved(int k) const { return sv[k]; }
+};
+
+// P1: f_j and its transcendental sub-expressions at cardinal node j (reads the solver vector itself: its loads overlap P0's)
+template <class Ode, class D>
+__device__ __attribute__((noinline, not_tail_called)) void res_cardinal_value(lds_double* S, int j, const double* X, const int* vi) {
+  using R = ResDims<D>;
+  OdeOutRes<D> out{S + D::w_Cf + j * D::n, nullptr, nullptr, nullptr, S + R::s_SV + j * R::SV_LD};
+  GatherIn<D> in{X, vi, j};
+  Ode::f_save(in, out);
+}
+
+// P2: interior point i: x^, tau, u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
+template <class Ode, class D>
+__device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_double* S, int i, const LglTab* tabp) {
+  constexpr int n = D::n, m = D::m, q = D::q, N = D::N, T = D::T, CS = D::CS;
+  const LglTab& tab = *tabp;
+  const lds_double* z = S + D::w_z;
+  const lds_double* Cf = S + D::w_Cf;
+  const lds_double* lam = S + D::w_lam;
+  const double h = z[D::TF] - z[T];
+  double y[N];
+  double li[n];
+#pragma unroll
+  for (int k = 0; k < n; k++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < CS; j++) acc += (tab.A[i][j] * z[j * q + k] + (tab.B[i][j] * h) * Cf[j * n + k]);
+    y[k] = acc;
+  }
+  y[T] = z[T] + h * tab.s[i];
+#pragma unroll
+  for (int k = 0; k < m; k++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < CS; j++) acc += tab.U[i][j] * z[j * q + n + 1 + k];
+    y[n + 1 + k] = acc;
+  }
+#pragma unroll
+  for (int k = 0; k < n; k++) li[k] = lam[i * n + k];
+  RegIn<D> in{y, li};
+  OdeOutRes<D> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH, nullptr};
+  Ode::fjgh(in, out);
+}
+
+// P3: cardinal node j: adjoint weights w_j (LGLDefects.h:369-374) ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f
+template <class Ode, class D>
+__device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(lds_double* S, int j, const LglTab* tabp) {
+  constexpr int K = D::K, n = D::n, N = D::N, T = D::T;
+  using R = ResDims<D>;
+  const LglTab& tab = *tabp;
+  const lds_double* z = S + D::w_z;
+  const double h = z[D::TF] - z[T];
+  double w[n];
+#pragma unroll
+  for (int k = 0; k < n; k++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      acc += S[D::w_Ig + i * N + k] * ((tab.E[i] * tab.B[i][j]) * h * h);
+      acc += S[D::w_lam + i * n + k] * (tab.D[i][j] * h);
+    }
+    w[k] = acc;
+  }
+  double sv[Ode::NSAVE > 0 ? Ode::NSAVE : 1];      // (read before g_j is written: the two may share their cells)
+#pragma unroll
+  for (int k = 0; k < Ode::NSAVE; k++) sv[k] = S[R::s_SV + j * R::SV_LD + k];
+  wave_lds_sync();
+  CardInRes<D> in{z, w, sv, j};
+  OdeOutRes<D> out{nullptr, S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
+  Ode::fjgh_load(in, out);
+}
+
+// ---------------------------------------------------------------------------------------------- per-lane constants
+// Everything of the dense part that depends on the lane and not on the segment: computed once per handle
+// (res_lane_setup_kernel), loaded by every wave after its ODE stage.  Offsets are relative to the segment's slot and
+// always readable ("no entry" -> the slot's zero cell), offsets into the weight tables are relative to the LDS copy of the
+// tables (`tab`, then ResDims::x_AUX) and address rows of stride 4 (LglTab: [K][4] arrays).
+template <class Ode, class D>
+struct ResLane {
+  using R = ResDims<D>;
+  static constexpr int K = D::K, n = D::n, q = D::q, N = D::N, CS = D::CS, KS = D::KS, TI = D::TI;
+  static constexpr int IR = D::IR, OR = D::OR, P0 = D::P0, T = D::T, TF = D::TF;
+  static constexpr int ZERO = R::s_Z0;
+  static constexpr bool QFAST = (q % 4 == 0);   // the node of column 16ct + lk + 4v does not depend on lk
+
+  // DI fragments (B operand of the M product, A operand of the H and J products): lane (lr, lk) <-> column c = 16ct + lr,
+  // row b = 4kk + lk:   dv[ct][i][kk] = tab[cao[ct][kk] + 4i] + h tab[cbo[ct] + 4i] * S[cjo[ct][kk]] -/+ sbv[i][kk] on columns T / TF
+  int cao[TI][KS];       // constant part: A_ij [cc == b], tau row, U_ij [cc == b] or a zero
+  int cbo[TI];           // B_ij of the column's node (or a zero row)
+  int cjo[TI][KS];       // J_j[b][cc]
+  int wlo[TI][KS];       // WL[j][b] (state rows) or a zero: this lane's share of  sum_r WL[j][r] J_j[r][cc]  (adjoint gradient)
+  // M product, A operand: lane (lr, lk) <-> row lr of [h E_i H^_i ; E_i g^_i], column 4kk + lk
+  int ao[KS], ast[KS];   // offset for i = 0, stride in i
+  // J product, B operand: lane (lr, lk) <-> defect row jr = lr = (il, rl), row 4kk + lk of (h E_il J^_il)^T
+  int jo[KS];
+  int il, rl;            // (lanes with lr >= OR: il = 0, rl = 0 and every weight below zero)
+  // defect row weights: sd = sum_jj tD[jj] f_jj[rl] + tE f^_il[rl];  fx = sum_jj tC[jj] z_jj[rl] + h sd
+  double tC[CS], tD[CS], tE;
+  // DC: initial value of J^T accumulator entry (ct, v), column c = 16ct + lk + 4v:
+  //   [cc == rl] C_il,j(c) + h D_il,j(c) S[dco[ct][v]] -/+ sd on the time columns
+  int dco[TI][4];
+  double dcC[QFAST ? 1 : TI][4];   // (QFAST: the node of the column is known at compile time: tC / tD of that node)
+  double dcD[QFAST ? 1 : TI][4];
+  // cardinal Hessian blocks: initial value of H accumulator entry (tile, v) of the tiles that can hold one (LGLDefects.h:386-402)
+  int cho[R::NSH][4];
+  // column role (lanes lk == lkN hold row N of the M tiles): column c = 16ct + lr
+  int cgg[TI];           // g_j[cc]
+  int clo[TI];           // CL[j][cc] (cc < n) or a zero
+
+  __device__ void compute(int lane) {
+    const int lr = lane & 15, lk = lane >> 4;
+    constexpr int oA = offsetof(LglTab, A) / 8, oB = offsetof(LglTab, B) / 8, oU = offsetof(LglTab, U) / 8;
+    constexpr int oAUX = D::TABSZ + R::GR * R::SLOT + R::x_AUX;   // (the scratch follows the slots)
+    constexpr int oZERO = oAUX + 2;                                // a row of zeros, same stride
+    auto jofs = [](int j, int r, int cc) { const int jp = Ode::JPOS[r * N + cc]; return jp >= 0 ? D::w_CJ + j * D::NZJ + jp : ZERO; };
+    constexpr int oXT = D::TABSZ + R::GR * R::SLOT;               // start of the wave-level scratch
+    for (int ct = 0; ct < TI; ct++) {
+      const int c = 16 * ct + lr;
+      const bool col = c < IR;                    // (p == 0: every column belongs to a node)
+      const int j = col ? c / q : 0, cc = col ? c - j * q : 0;
+      cbo[ct] = col ? oB + j : oZERO;
+      for (int kk = 0; kk < KS; kk++) {
+        const int b = 4 * kk + lk;
+        int ca = oZERO, cj = ZERO;
+        if (col && b < N) {
+          if (b < n) {
+            if (cc == b) ca = oA + j;
+            cj = jofs(j, b, cc);
+          } else if (b == T) {
+            if (c == T) ca = oAUX + 0;
+            else if (c == TF) ca = oAUX + 1;
+          } else if (cc == b) ca = oU + j;
+        }
+        cao[ct][kk] = ca;
+        cjo[ct][kk] = cj;
+        wlo[ct][kk] = (col && b < n) ? oXT + R::x_WL + j * n + b : oZERO;
+      }
+      cgg[ct] = col ? D::w_Cg + j * N + cc : ZERO;
+      clo[ct] = (col && cc < n) ? oXT + R::x_CL + j * n + cc : oZERO;
+    }
+    for (int kk = 0; kk < KS; kk++) {
+      const int b = 4 * kk + lk;
+      int o = ZERO, st = 0;
+      if (b < N) {
+        if (lr < N) {
+          const int hp = Ode::HPOS[(b >= lr) ? b * (b + 1) / 2 + lr : lr * (lr + 1) / 2 + b];
+          if (hp >= 0) { o = D::w_IH + hp; st = D::NZH; }
+        } else if (lr == N) { o = D::w_Ig + b; st = N; }
+      }
+      ao[kk] = o;
+      ast[kk] = st;
+    }
+    const bool row = lr < OR;
+    il = row ? lr / n : 0;
+    rl = row ? lr - il * n : 0;
+    for (int kk = 0; kk < KS; kk++) {
+      const int b = 4 * kk + lk;
+      const int jp = (row && b < N) ? Ode::JPOS[rl * N + b] : -1;
+      jo[kk] = jp >= 0 ? D::w_IJ + il * D::NZJ + jp : ZERO;
+    }
+    const LglTab& tab = d_lgl_tab[D::TAB];
+    for (int jj = 0; jj < CS; jj++) { tC[jj] = row ? tab.C[il][jj] : 0.0; tD[jj] = row ? tab.D[il][jj] : 0.0; }
+    tE = row ? tab.E[il] : 0.0;
+    for (int ct = 0; ct < TI; ct++)
+      for (int v = 0; v < 4; v++) {
+        const int c = 16 * ct + lk + 4 * v;
+        const bool ok = row && c < IR;
+        const int j = ok ? c / q : 0, cc = ok ? c - j * q : 0;
+        dco[ct][v] = ok ? jofs(j, rl, cc) : ZERO;
+        if constexpr (!QFAST) {
+          dcC[ct][v] = (ok && cc == rl) ? tab.C[il][j] : 0.0;
+          dcD[ct][v] = ok ? tab.D[il][j] : 0.0;
+        }
+      }
+    for (int ct = 0; ct < TI; ct++)
+      for (int rt = ct; rt < TI; rt++)
+        for (int v = 0; v < 4; v++) {
+          const int c = 16 * ct + lk + 4 * v, r = 16 * rt + lr, tix = rt * (rt + 1) / 2 + ct;
+          int ch = ZERO;
+          if (c < IR && r < IR && r >= c && r / q == c / q) {
+            const int jn = c / q, cc = c - jn * q, rr = r - jn * q, hp = Ode::HPOS[rr * (rr + 1) / 2 + cc];
+            if (hp >= 0) ch = D::w_CH + jn * D::NZH + hp;
+          }
+          if (R::sh_index(tix) >= 0) cho[R::sh_index(tix)][v] = ch;
+        }
+  }
+};
+
+template <class Ode, int SCH, bool BLOCKED>
+__global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
+  using D = Dims<Ode, SCH, BLOCKED>;
+  if constexpr (ResDims<D>::OK) {
+    using LC = ResLane<Ode, D>;
+    LaneRecord<LC> r;
+    for (int k = 0; k < LaneRecord<LC>::NW; k++) r.w[k] = 0u;
+    r.lc.compute(threadIdx.x);
+    for (int k = 0; k < LaneRecord<LC>::NW; k++) out[k * 64 + threadIdx.x] = r.w[k];
+  }
+}
+
+// sum over the 16 lanes of a row (lanes with the same lk): butterfly in DPP, every lane gets the total
+__device__ inline double row16_sum(double x) {
+  auto step = [](double v, auto ctrl) {
+    constexpr int C = decltype(ctrl)::value;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), C, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), C, 0xf, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+  };
+  x = step(x, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  x = step(x, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  x = step(x, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  x = step(x, std::integral_constant<int, 0x140>{});   // row_mirror
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------- kernel
+template <class Ode, int SCH, bool BLOCKED, bool ASM>
+__device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
+  using D = Dims<Ode, SCH, BLOCKED>;
+  using R = ResDims<D>;
+  using LCT = ResLane<Ode, D>;
+  constexpr int CS = D::CS, K = D::K, n = D::n, q = D::q, N = D::N, T = D::T, TF = D::TF;
+  constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, KS = D::KS, TI = D::TI, GR = R::GR, SLOT = R::SLOT;
+  constexpr bool CFULL = (IR == IRP);
+  static_assert(GR * CS <= 64, "one pass per phase");
+
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  lds_double* const tabL = (lds_double*)lds;                       // weight tables, then x_AUX ... behind the slots
+  lds_double* const slots = tabL + D::TABSZ;
+  lds_double* const xtra = slots + GR * SLOT;
+  const int lane = int(threadIdx.x), lr = lane & 15, lk = lane >> 4;
+  const LglTab& tab = *reinterpret_cast<const LglTab*>(lds);
+  const LglTab& ctab = d_lgl_tab[D::TAB];                           // compile-time indices: scalar loads
+
+  // this wave's share of the mesh: contiguous, balanced (same rule as IndexingData.h:117-146); the host sizes the grid so
+  // that it is at most GR segments
+  const int nshare = int(gridDim.x), share = int(blockIdx.x);
+  const int per = a.nseg / nshare, rem = a.nseg % nshare;
+  const int seg0 = share * per + min(share, rem);
+  const int gcount = min(per + (share < rem ? 1 : 0), GR);
+
+  // ------------------------------------------------------------------ ODE stage
+  {   // P0: gather z = X[Vindex], lam = L[Cindex] into the slots -- index loads, value loads, LDS writes
+    constexpr int NZ = (GR * IR + 63) / 64, NL = (GR * OR + 63) / 64, NTAB = (D::TABSZ + 63) / 64;
+    const int* vseg = a.vindex + size_t(seg0) * IR;
+    const int* cseg = a.cindex + size_t(seg0) * OR;
+    int vi[NZ], ci[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) vi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : -1;
+#pragma unroll
+    for (int t = 0; t < NL; t++) ci[t] = (lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : -1;
+    double tabv[NTAB];
+#pragma unroll
+    for (int t = 0; t < NTAB; t++)
+      tabv[t] = (lane + 64 * t < D::TABSZ) ? reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[lane + 64 * t] : 0.0;
+    double zv[NZ], lv[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) zv[t] = (vi[t] >= 0) ? a.X[vi[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NL; t++) lv[t] = (ci[t] >= 0) ? a.L[ci[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NTAB; t++)
+      if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
+    if (lane < 4 * K) {
+      const int i = lane >> 2, w = lane & 3;
+      xtra[R::x_AUX + lane] = w == 0 ? 1.0 - ctab.s[i] : (w == 1 ? ctab.s[i] : 0.0);
+    }
+    if (lane < GR) slots[lane * SLOT + R::s_Z0] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NZ; t++) {
+      const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
+      if (e < gcount * IR) slots[g * SLOT + D::w_z + r] = zv[t];
+    }
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
+      if (e < gcount * OR) slots[g * SLOT + D::w_lam + r] = lv[t];
+    }
+  }
+  if (lane < gcount * CS) {            // P1
+    const int g = lane / CS, j = lane - g * CS;
+    res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
+  }
+  wave_lds_sync();
+  if (lane < gcount * K) {             // P2
+    const int g = lane / K, i = lane - g * K;
+    res_interior<Ode, D>(slots + g * SLOT, i, &tab);
+  }
+  wave_lds_sync();
+  if (lane < gcount * CS) {            // P3
+    const int g = lane / CS, j = lane - g * CS;
+    res_cardinal_second<Ode, D>(slots + g * SLOT, j, &tab);
+  }
+  // the per-lane record of the dense part (its loads fly while P3's LDS writes land)
+  LaneRecord<LCT> lrec;
+  {
+    const unsigned int* rec = static_cast<const unsigned int*>(a.lane_consts_res) +
+                              size_t(blockIdx.x % ASSET_LANE_REPLICAS) * (LaneRecord<LCT>::NW * 64);
+#pragma unroll
+    for (int k = 0; k < LaneRecord<LCT>::NW; k++) lrec.w[k] = rec[k * 64 + lane];
+  }
+  const LCT& lc = lrec.lc;
+  wave_lds_sync();
+  wave_loads_landed();
+
+  // ------------------------------------------------------------------ dense part, one segment at a time
+  auto tabrow = [&](int o, int i) -> double { return tabL[o + 4 * i]; };   // row i of a [K][4] weight array (or of x_AUX)
+  // -1 on column T, +1 on column TF of the lane's column 16t + lr: the direction d = e_TF - e_T of the rank-2 update and the
+  // sign of the time-column terms
+  auto tsA = [&](int t) -> double { return (16 * t + lr == T) ? -1.0 : ((16 * t + lr == TF) ? 1.0 : 0.0); };
+  lds_double* const HT = xtra + R::x_HT;
+  lds_double* const CL = xtra + R::x_CL;
+  lds_double* const WL = xtra + R::x_WL;
+  constexpr int NFRAG = (D::NTH + TI) * 4;
+
+  for (int g = 0; g < gcount; g++) {
+    const lds_double* S = slots + g * SLOT;
+    const size_t seg = size_t(seg0 + g);
+    const double h = S[D::w_z + TF] - S[D::w_z + T];
+    double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr);
+    const int* const kmap_seg = ASM ? a.kmap + seg * size_t(NFRAG) * 64 + lane : nullptr;
+    int hmap[ASM ? D::NTH : 1][4], jmap[ASM ? TI : 1][4];
+    if constexpr (ASM) {                              // all of the segment's map entries, ahead of the products
+#pragma unroll
+      for (int t = 0; t < D::NTH; t++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) hmap[t][v] = kmap_seg[(t * 4 + v) * 64];
+#pragma unroll
+      for (int t = 0; t < TI; t++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) jmap[t][v] = kmap_seg[((D::NTH + t) * 4 + v) * 64];
+    }
+
+    // ---- R1: defect row (il, rl) of this lane: sd, value; the multiplier sums of the adjoint gradient
+    double sd, fxv;
+    {
+      double fj[CS], zj[CS];
+      const double fi = S[D::w_If + (lr < OR ? lr : 0)];   // f^_il[rl] (its weight tE is zero in the lanes without a row)
+#pragma unroll
+      for (int jj = 0; jj < CS; jj++) { fj[jj] = S[D::w_Cf + jj * n + lc.rl]; zj[jj] = S[D::w_z + jj * q + lc.rl]; }
+      sd = lc.tE * fi;
+      fxv = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < CS; jj++) { sd += lc.tD[jj] * fj[jj]; fxv += lc.tC[jj] * zj[jj]; }
+      fxv += h * sd;
+    }
+    int lkv = lk;                                     // (opaque per iteration: what is derived from it is recomputed, not kept)
+    asm volatile("" : "+v"(lkv));
+    const double lamr = (lr < OR) ? S[D::w_lam + lr] : 0.0;
+    const double sls = row16_sum(lamr * sd);          // sum_(i,r) lam_(i,r) sd_(i,r), in every lane
+    if (lane < CS * n) {                              // CL[j][r] = sum_i C_ij lam_(i,r), WL[j][r] = sum_i D_ij lam_(i,r)
+      const int j = lane / n, r = lane - j * n;
+      double cl = 0.0, wl = 0.0;
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        const double l = S[D::w_lam + i * n + r];
+        cl += tab.C[i][j] * l;
+        wl += tab.D[i][j] * l;
+      }
+      CL[lane] = cl;
+      WL[lane] = wl;
+    }
+
+    // ---- R2: fragments of DI_i, straight from the slot; this lane's rows of  sum_r WL[j][r] J_j[r][cc]
+    wave_lds_sync();                                  // (CL / WL)
+    double dv[TI][K][KS], agJ[TI];
+    {
+      double sbv[K][KS];
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) {
+        const int b = 4 * kk + lk;                    // f_jj[b] for the state rows, nothing for the others
+        double f[CS];
+#pragma unroll
+        for (int jj = 0; jj < CS; jj++) f[jj] = (b < n) ? S[D::w_Cf + jj * n + (b < n ? b : 0)] : 0.0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+          double s = 0.0;
+#pragma unroll
+          for (int jj = 0; jj < CS; jj++) s += ctab.B[i][jj] * f[jj];
+          sbv[i][kk] = s;
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < TI; ct++) {
+        double jv[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) jv[kk] = S[lc.cjo[ct][kk]];
+        const double tsa = tsA(ct);
+        double part = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) part = fma(tabL[lc.wlo[ct][kk]], jv[kk], part);
+        agJ[ct] = part;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+          const double hb = h * tabrow(lc.cbo[ct], i);
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++)
+            dv[ct][i][kk] = fma(tsa, sbv[i][kk], fma(hb, jv[kk], tabrow(lc.cao[ct][kk], i)));
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < TI; ct++) {              // the four lanes of a column (lk = 0..3) hold its row groups: add them up
+        agJ[ct] += __shfl_xor(agJ[ct], 16);
+        agJ[ct] += __shfl_xor(agJ[ct], 32);
+      }
+    }
+
+    // ---- R3: per interior: M_i tiles (A = [h E_i H^_i ; E_i g^_i], B = DI_i), then H += DI_i^T M_i and J^T += DI_i^T (h E_i J^_i)^T
+    d4 accH[D::NTH], accJ[TI];
+    double hi[TI];
+#pragma unroll
+    for (int ct = 0; ct < TI; ct++) hi[ct] = 0.0;
+    {   // initial values: cardinal Hessian blocks; cardinal part of J (DC)
+#pragma unroll
+      for (int rt = 0; rt < TI; rt++)
+#pragma unroll
+        for (int ct = 0; ct <= rt; ct++) {
+          const int tix = rt * (rt + 1) / 2 + ct;
+#pragma unroll
+          for (int v = 0; v < 4; v++) accH[tix][v] = R::sh_index(tix) >= 0 ? S[lc.cho[R::sh_index(tix) >= 0 ? R::sh_index(tix) : 0][v]] : 0.0;
+        }
+#pragma unroll
+      for (int ct = 0; ct < TI; ct++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int c0 = 16 * ct + 4 * v;                         // column = c0 + lk
+          double dd, cw;
+          if constexpr (LCT::QFAST) {                              // node and component of the column: (c0 + lk) / q, (c0 + lk) % q
+            const int jn = c0 / q < CS ? c0 / q : 0;
+            dd = (c0 < IR) ? lc.tD[jn] : 0.0;
+            cw = (c0 < IR && lk == lc.rl - c0 % q) ? lc.tC[jn] : 0.0;
+          } else {
+            dd = lc.dcD[ct][v];
+            cw = lc.dcC[ct][v];
+          }
+          double val = fma(h * dd, S[lc.dco[ct][v]], cw);
+          if (c0 <= T && T < c0 + 4) val -= (lk == T - c0) ? sd : 0.0;        // DC rows -+ (sum_j D_ij f_j + E_i f^_i)
+          if (c0 <= TF && TF < c0 + 4) val += (lk == TF - c0) ? sd : 0.0;     // (LGLDefects.h:484-500)
+          accJ[ct][v] = val;
+        }
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      const double he = h * ctab.E[i];
+      const double sc = (lr == N) ? ctab.E[i] : he;                // the g^ row is scaled by E_i, the H^ rows by h E_i
+      double ah[KS], bj[KS];
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) {
+        ah[kk] = sc * S[lc.ao[kk] + i * lc.ast[kk]];
+        bj[kk] = (lc.il == i) ? he * S[lc.jo[kk]] : 0.0;
+      }
+      d4 Mi[TI];
+#pragma unroll
+      for (int ct = 0; ct < TI; ct++) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[kk], dv[ct][i][kk], acc, 0, 0, 0);
+        Mi[ct] = acc;                    // entry v: row lk + 4v of M_i (row N: E_i g^_i . DI_i), column 16ct + lr
+        hi[ct] += acc[R::vN];            // (meaningful in the lanes lk == lkN)
+      }
+#pragma unroll
+      for (int ct = 0; ct < TI; ct++)
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) accJ[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], bj[kk], accJ[ct], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < TI; rt++)
+#pragma unroll
+        for (int ct = 0; ct <= rt; ct++) {
+          const int tix = rt * (rt + 1) / 2 + ct;
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++)
+            accH[tix] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], Mi[rt][kk], accH[tix], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- R4: column role (lanes lk == lkN): full time-partial vector HT (LGLDefects.h:403-411, 504-505) and the adjoint
+    //      gradient  g = J^T lam = h sum_i E_i g^_i^T DI_i + DC^T lam  (LGLDefects.h:512), column by column
+    wave_lds_sync();                                   // CL / WL written above
+    if (lk == R::lkN) {
+      const double ih = 1.0 / h;
+#pragma unroll
+      for (int ct = 0; ct < TI; ct++) {
+        const int c = 16 * ct + lr;
+        HT[c] = hi[ct] + S[lc.cgg[ct]] * ih;           // (padding columns: 0 + 0)
+        if (a.AGX && (CFULL || c < IR))
+          a.AGX[seg * IR + c] = fma(h, hi[ct] + agJ[ct], fma(tsA(ct), sls, tabL[lc.clo[ct]]));
+      }
+    }
+    if (a.FX && lane < OR) a.FX[seg * OR + lane] = fxv;
+    wave_lds_sync();
+    // rank-2 time update  H += d HT^T + HT d^T,  d = e_TF - e_T  (the four updates of LGLDefects.h:508-511)
+    {
+      double a2[TI], b2[TI];
+#pragma unroll
+      for (int t = 0; t < TI; t++) {
+        const double ht = HT[16 * t + lr];
+        a2[t] = lk == 0 ? tsA(t) : (lk == 1 ? ht : 0.0);
+        b2[t] = lk == 0 ? ht : (lk == 1 ? tsA(t) : 0.0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < TI; rt++)
+#pragma unroll
+        for (int ct = 0; ct <= rt; ct++) {
+          const int tix = rt * (rt + 1) / 2 + ct;
+          accH[tix] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[ct], b2[rt], accH[tix], 0, 0, 0);
+        }
+    }
+
+    // first slot of block column c = 16ct + 4v + lk, minus c: H(r, c) sits at cbv + r, J(jr, c) at cbv + IR + jr
+    auto cbv = [&](int ct, int v) { const int c = 16 * ct + 4 * v + lkv; return c * (IR + OR - 1) - ((c * (c - 1)) >> 1); };
+    // ---- R5: store.  Entry v of a tile: block column c = 16ct + lk + 4v, row (H) r = 16rt + lr or (J) jr = lr; 16
+    //      consecutive lanes cover 128 contiguous bytes of the reference's slot order (DenseFunctionBase.h:1112-1123)
+    if (kkt_dst) {
+      if constexpr (ASM) {
+#pragma unroll
+        for (int t = 0; t < D::NTH; t++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, hmap[t][v], accH[t][v]);
+#pragma unroll
+        for (int t = 0; t < TI; t++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, jmap[t][v], accJ[t][v]);
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < TI; rt++)
+#pragma unroll
+          for (int ct = 0; ct < rt; ct++) {                  // tiles left of the diagonal: every column < IR
+            const int tix = rt * (rt + 1) / 2 + ct;
+            if (CFULL || 16 * rt + lr < IR) {
+#pragma unroll
+              for (int v = 0; v < 4; v++) kkt_dst[cbv(ct, v) + 16 * rt + lr] = accH[tix][v];
+            }
+          }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          if (lr >= lk + 4 * v) {                            // diagonal tiles: r >= c
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+              const int tix = t * (t + 1) / 2 + t;
+              if (CFULL || t + 1 < TI || 16 * t + lr < IR) kkt_dst[cbv(t, v) + 16 * t + lr] = accH[tix][v];
+            }
+          }
+        }
+        if (lr < OR) {
+#pragma unroll
+          for (int ct = 0; ct < TI; ct++)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+              if (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR) kkt_dst[cbv(ct, v) + IR + lr] = accJ[ct][v];
+        }
+      }
+    }
+  }
+}
+
+template <class Ode, int SCH, bool BLOCKED, bool ASM = false>
+__global__ __launch_bounds__(64, 2) void lgl_resident_kernel(EvalArgs a) {
+  if constexpr (ResDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_resident_body<Ode, SCH, BLOCKED, ASM>(a);
+}
+
+}  // namespace asset_hip

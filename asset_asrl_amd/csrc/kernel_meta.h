@@ -6,6 +6,7 @@
 #pragma once
 #include "defect_adjgrad.h"
 #include "defect_kernels.h"
+#include "defect_resident.h"
 #include "defect_units.h"
 #include "defect_wide.h"
 #include "func_kernels.h"
@@ -28,6 +29,7 @@ enum MetaField {
   MF_NUNITS, MF_UNITS_BASE_BYTES, MF_UNITS_SLOT_BYTES, MF_CS,
   MF_LANE_BYTES1, MF_LANE_BYTES2,
   MF_ADJ_GP, MF_ADJ_LDS_BYTES,   // value + adjoint gradient kernel (defect_adjgrad.h): segments per workgroup, its LDS
+  MF_RES_GR, MF_RES_LDS_BYTES, MF_LANE_BYTES_RES,   // resident kernel (defect_resident.h): segments per wave (0: none), LDS, record table
   MF_COUNT
 };
 
@@ -37,6 +39,13 @@ constexpr long long lgl_lane_table_bytes(int level) {
   // bytes of the whole table: 64 word-interleaved records (defect_kernels.h: lane_setup_kernel; defect_wide.h: wide_setup_kernel)
   if constexpr (D::WIDE) return level >= 1 ? (long long)(D::TJ) * D::TI * 4 * 64 * sizeof(unsigned int) : 0;
   else return level >= 2 ? (long long)sizeof(LaneConsts<Ode, D, 2>) * 64 : (level == 1 ? (long long)sizeof(LaneConsts<Ode, D, 1>) * 64 : 0);
+}
+
+template <class Ode, int SCH, bool BLOCKED>
+constexpr long long res_lane_table_bytes() {
+  using D = Dims<Ode, SCH, BLOCKED>;
+  if constexpr (ResDims<D>::OK) return (long long)sizeof(ResLane<Ode, D>) * 64;
+  else return 0;
 }
 
 template <class Ode, int SCH, bool BLOCKED, int G>
@@ -50,7 +59,8 @@ struct LglMeta {
       D::FUSED ? 1 : 0, D::GF, D::FUSED2 ? 1 : 0, D::GF2, (long long)D::lds_bytes_fused2(),
       Ode::NUNITS, (long long)D::TABSZ * 8, (long long)UD::MS * 8, D::CS,
       lgl_lane_table_bytes<Ode, SCH, BLOCKED>(1), lgl_lane_table_bytes<Ode, SCH, BLOCKED>(2),
-      AdjDims<D>::GP, (long long)AdjDims<D>::lds_bytes()};
+      AdjDims<D>::GP, (long long)AdjDims<D>::lds_bytes(),
+      ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>()};
 };
 
 template <class F>

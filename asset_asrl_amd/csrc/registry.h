@@ -89,7 +89,9 @@ constexpr int K_FUNC(int level, bool asmb) { return 35 + level * 2 + (asmb ? 1 :
 constexpr int K_BUNDLE(int level) { return 41 + level; }                                                         // 41..43
 constexpr int K_ADJGRAD = 44;   // value + adjoint gradient without a Jacobian (defect_adjgrad.h)
 constexpr int K_VALUE = 45;     // value only, the same kernel without the gradient parts
-constexpr int K_COUNT = 46;
+constexpr int K_RES(bool asmb) { return 46 + (asmb ? 1 : 0); }   // resident single launch (defect_resident.h)
+constexpr int K_RES_SETUP = 48;
+constexpr int K_COUNT = 49;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -198,6 +200,13 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
       return dense_stage(1);
     }
     case 2: {
+      // resident kernel (defect_resident.h): the ODE results stay in LDS; meshes of at most GR segments per wave
+      static const bool no_res = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                              // tuning only
+      if (m[MF_RES_GR] > 0 && !no_res && !skip_dense && a.lane_consts_res && t.k[K_RES(a.kmap != nullptr)]) {
+        const int waves = cus * 8;
+        if ((a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]))
+          return klaunch(t.k[K_RES(a.kmap != nullptr)], dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
+      }
       if (m[MF_FUSED]) {
         // single launch when every workgroup's share fits one group of the fused kernel (defect_kernels.h, STAGE 3)
         static const bool no_fuse = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                               // tuning only
@@ -271,12 +280,16 @@ inline hipError_t entry_mesh(const KernelEntry* ke, const MeshArgs& a, hipStream
 }
 
 // per-lane constants of the dense stage for derivative level 1 / 2: table size in bytes (0: none) and the kernel filling it
+// (level 0 stands for the record of the resident kernel)
 inline size_t entry_lane_bytes(const KernelEntry* ke, int level) {
-  return level >= 2 ? size_t(ke->table->meta[MF_LANE_BYTES2]) : (level == 1 ? size_t(ke->table->meta[MF_LANE_BYTES1]) : 0);
+  if (ke->table->meta[MF_KIND] != 1) return 0;
+  return level >= 2 ? size_t(ke->table->meta[MF_LANE_BYTES2])
+                    : (level == 1 ? size_t(ke->table->meta[MF_LANE_BYTES1]) : size_t(ke->table->meta[MF_LANE_BYTES_RES]));
 }
 inline hipError_t entry_lane_setup(const KernelEntry* ke, int level, void* out, hipStream_t st) {
   void* kargs[] = {&out};
   const KernelTable& t = *ke->table;
+  if (level == 0) return klaunch(t.k[K_RES_SETUP], dim3(1), dim3(64), 0, st, kargs);
   return klaunch(t.meta[MF_WIDE] ? t.k[K_WIDE_SETUP] : (level >= 2 ? t.k[K_LANE_SETUP2] : t.k[K_LANE_SETUP1]), dim3(1), dim3(64), 0, st, kargs);
 }
 
@@ -311,6 +324,11 @@ const KernelTable* lgl_static_table() {
         r.k[K_LGL(1, 3, true)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 1, 3, true>);
       }
       if constexpr (D::FUSED2) r.k[K_LGL(2, 4, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 4, false>);
+      if constexpr (ResDims<D>::OK) {
+        r.k[K_RES(false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, false>);
+        r.k[K_RES(true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, true>);
+        r.k[K_RES_SETUP].host = ASSET_KPTR(res_lane_setup_kernel<Ode, SCH, BLOCKED>);
+      }
     }
     if constexpr (Ode::NUNITS > 1) {
       r.k[K_UNITS0].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 0>);
@@ -388,6 +406,9 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
     for (int as = 0; as <= 1; as++)
       if (slot == K_WIDE(lv, as != 0)) return "asset_hip::lgl_wide_dense_kernel<" + lgl + ", " + std::to_string(lv) + ", " + tf(as != 0) + ">";
   if (slot == K_WIDE_SETUP) return "asset_hip::wide_setup_kernel<" + lgl + ">";
+  if (slot == K_RES(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", false>";
+  if (slot == K_RES(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", true>";
+  if (slot == K_RES_SETUP) return "asset_hip::res_lane_setup_kernel<" + lgl + ">";
   if (slot == K_LANE_SETUP1) return "asset_hip::lane_setup_kernel<" + lgl + ", 1>";
   if (slot == K_LANE_SETUP2) return "asset_hip::lane_setup_kernel<" + lgl + ", 2>";
   if (slot == K_UNITS0) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 0>";
