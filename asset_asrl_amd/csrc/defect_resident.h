@@ -339,6 +339,16 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   const int seg0 = share * per + min(share, rem);
   const int gcount = min(per + (share < rem ? 1 : 0), GR);
 
+#if defined(ASSET_TIMING)
+  long long tstamp[24];
+  int nts = 0;
+#define RTS() do { if (nts < 24) tstamp[nts++] = clock64(); } while (0)
+#define RTSG() do { if (g == 1) RTS(); } while (0)
+#else
+#define RTS() do {} while (0)
+#define RTSG() do {} while (0)
+#endif
+  RTS();
   // ------------------------------------------------------------------ ODE stage
   {   // P0: gather z = X[Vindex], lam = L[Cindex] into the slots -- index loads, value loads, LDS writes
     constexpr int NZ = (GR * IR + 63) / 64, NL = (GR * OR + 63) / 64, NTAB = (D::TABSZ + 63) / 64;
@@ -377,20 +387,24 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       if (e < gcount * OR) slots[g * SLOT + D::w_lam + r] = lv[t];
     }
   }
+  RTS();
   if (lane < gcount * CS) {            // P1
     const int g = lane / CS, j = lane - g * CS;
     res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
   }
   wave_lds_sync();
+  RTS();
   if (lane < gcount * K) {             // P2
     const int g = lane / K, i = lane - g * K;
     res_interior<Ode, D>(slots + g * SLOT, i, &tab);
   }
   wave_lds_sync();
+  RTS();
   if (lane < gcount * CS) {            // P3
     const int g = lane / CS, j = lane - g * CS;
     res_cardinal_second<Ode, D>(slots + g * SLOT, j, &tab);
   }
+  RTS();
   // the per-lane record of the dense part (its loads fly while P3's LDS writes land)
   LaneRecord<LCT> lrec;
   {
@@ -402,6 +416,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   const LCT& lc = lrec.lc;
   wave_lds_sync();
   wave_loads_landed();
+  RTS();
 
   // ------------------------------------------------------------------ dense part, one segment at a time
   auto tabrow = [&](int o, int i) -> double { return tabL[o + 4 * i]; };   // row i of a [K][4] weight array (or of x_AUX)
@@ -431,6 +446,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         for (int v = 0; v < 4; v++) jmap[t][v] = kmap_seg[((D::NTH + t) * 4 + v) * 64];
     }
 
+    RTSG();
     // ---- R1: defect row (il, rl) of this lane: sd, value; the multiplier sums of the adjoint gradient
     double sd, fxv;
     {
@@ -461,6 +477,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       WL[lane] = wl;
     }
 
+    RTSG();
     // ---- R2: fragments of DI_i, straight from the slot; this lane's rows of  sum_r WL[j][r] J_j[r][cc]
     wave_lds_sync();                                  // (CL / WL)
     double dv[TI][K][KS], agJ[TI];
@@ -505,24 +522,34 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       }
     }
 
-    // ---- R3: per interior: M_i tiles (A = [h E_i H^_i ; E_i g^_i], B = DI_i), then H += DI_i^T M_i and J^T += DI_i^T (h E_i J^_i)^T
-    d4 accH[D::NTH], accJ[TI];
-    double hi[TI];
+    RTSG();
+    // The products are ordered so that every result is stored as soon as it is complete and its stores drain under the
+    // matrix instructions that follow (a wave's store phase is otherwise a stall at the rate the memory system accepts the
+    // data): J^T first, then one tile column rt of H at a time -- M_i[:, tile rt] is the B operand of the tiles (ct <= rt, rt)
+    // only, the rank-2 time rows of those tiles need HT on the tiles up to rt.
+    // Entry v of a tile: block column c = 16ct + lk + 4v, row (H) r = 16rt + lr or (J) jr = lr; 16 consecutive lanes cover
+    // 128 contiguous bytes of the reference's slot order (DenseFunctionBase.h:1112-1123); first slot of block column c,
+    // minus c: H(r, c) sits at cbv + r, J(jr, c) at cbv + IR + jr.
+    auto cbv = [&](int ct, int v) { const int c = 16 * ct + 4 * v + lkv; return c * (IR + OR - 1) - ((c * (c - 1)) >> 1); };
+    double ah[K][KS];                                  // A operand of the M products: [h E_i H^_i ; E_i g^_i]
 #pragma unroll
-    for (int ct = 0; ct < TI; ct++) hi[ct] = 0.0;
-    {   // initial values: cardinal Hessian blocks; cardinal part of J (DC)
+    for (int i = 0; i < K; i++) {
+      const double sc = (lr == N) ? ctab.E[i] : h * ctab.E[i];     // the g^ row is scaled by E_i, the H^ rows by h E_i
 #pragma unroll
-      for (int rt = 0; rt < TI; rt++)
+      for (int kk = 0; kk < KS; kk++) ah[i][kk] = sc * S[lc.ao[kk] + i * lc.ast[kk]];
+    }
+    __builtin_amdgcn_s_setprio(1);
+    {   // ---- R3: J^T = DC^T + sum_i DI_i^T (h E_i J^_i)^T
+      d4 accJ[TI];
+      double bj[KS], hel = 0.0;
 #pragma unroll
-        for (int ct = 0; ct <= rt; ct++) {
-          const int tix = rt * (rt + 1) / 2 + ct;
+      for (int i = 0; i < K; i++) hel = (lc.il == i) ? h * ctab.E[i] : hel;
 #pragma unroll
-          for (int v = 0; v < 4; v++) accH[tix][v] = R::sh_index(tix) >= 0 ? S[lc.cho[R::sh_index(tix) >= 0 ? R::sh_index(tix) : 0][v]] : 0.0;
-        }
+      for (int kk = 0; kk < KS; kk++) bj[kk] = hel * S[lc.jo[kk]];
 #pragma unroll
       for (int ct = 0; ct < TI; ct++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
+        for (int v = 0; v < 4; v++) {                              // cardinal part (DC): the initial value
           const int c0 = 16 * ct + 4 * v;                         // column = c0 + lk
           double dd, cw;
           if constexpr (LCT::QFAST) {                              // node and component of the column: (c0 + lk) / q, (c0 + lk) % q
@@ -538,112 +565,21 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           if (c0 <= TF && TF < c0 + 4) val += (lk == TF - c0) ? sd : 0.0;     // (LGLDefects.h:484-500)
           accJ[ct][v] = val;
         }
-    }
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < K; i++) {
-      const double he = h * ctab.E[i];
-      const double sc = (lr == N) ? ctab.E[i] : he;                // the g^ row is scaled by E_i, the H^ rows by h E_i
-      double ah[KS], bj[KS];
+      for (int i = 0; i < K; i++)
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) {
-        ah[kk] = sc * S[lc.ao[kk] + i * lc.ast[kk]];
-        bj[kk] = (lc.il == i) ? he * S[lc.jo[kk]] : 0.0;
-      }
-      d4 Mi[TI];
+        for (int kk = 0; kk < KS; kk++) {
+          const double b = (lc.il == i) ? bj[kk] : 0.0;
 #pragma unroll
-      for (int ct = 0; ct < TI; ct++) {
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[kk], dv[ct][i][kk], acc, 0, 0, 0);
-        Mi[ct] = acc;                    // entry v: row lk + 4v of M_i (row N: E_i g^_i . DI_i), column 16ct + lr
-        hi[ct] += acc[R::vN];            // (meaningful in the lanes lk == lkN)
-      }
-#pragma unroll
-      for (int ct = 0; ct < TI; ct++)
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) accJ[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], bj[kk], accJ[ct], 0, 0, 0);
-#pragma unroll
-      for (int rt = 0; rt < TI; rt++)
-#pragma unroll
-        for (int ct = 0; ct <= rt; ct++) {
-          const int tix = rt * (rt + 1) / 2 + ct;
-#pragma unroll
-          for (int kk = 0; kk < KS; kk++)
-            accH[tix] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], Mi[rt][kk], accH[tix], 0, 0, 0);
+          for (int ct = 0; ct < TI; ct++) accJ[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], b, accJ[ct], 0, 0, 0);
         }
-    }
-    __builtin_amdgcn_s_setprio(0);
-
-    // ---- R4: column role (lanes lk == lkN): full time-partial vector HT (LGLDefects.h:403-411, 504-505) and the adjoint
-    //      gradient  g = J^T lam = h sum_i E_i g^_i^T DI_i + DC^T lam  (LGLDefects.h:512), column by column
-    wave_lds_sync();                                   // CL / WL written above
-    if (lk == R::lkN) {
-      const double ih = 1.0 / h;
+      if (kkt_dst) {
+        if constexpr (ASM) {
 #pragma unroll
-      for (int ct = 0; ct < TI; ct++) {
-        const int c = 16 * ct + lr;
-        HT[c] = hi[ct] + S[lc.cgg[ct]] * ih;           // (padding columns: 0 + 0)
-        if (a.AGX && (CFULL || c < IR))
-          a.AGX[seg * IR + c] = fma(h, hi[ct] + agJ[ct], fma(tsA(ct), sls, tabL[lc.clo[ct]]));
-      }
-    }
-    if (a.FX && lane < OR) a.FX[seg * OR + lane] = fxv;
-    wave_lds_sync();
-    // rank-2 time update  H += d HT^T + HT d^T,  d = e_TF - e_T  (the four updates of LGLDefects.h:508-511)
-    {
-      double a2[TI], b2[TI];
+          for (int t = 0; t < TI; t++)
 #pragma unroll
-      for (int t = 0; t < TI; t++) {
-        const double ht = HT[16 * t + lr];
-        a2[t] = lk == 0 ? tsA(t) : (lk == 1 ? ht : 0.0);
-        b2[t] = lk == 0 ? ht : (lk == 1 ? tsA(t) : 0.0);
-      }
-#pragma unroll
-      for (int rt = 0; rt < TI; rt++)
-#pragma unroll
-        for (int ct = 0; ct <= rt; ct++) {
-          const int tix = rt * (rt + 1) / 2 + ct;
-          accH[tix] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[ct], b2[rt], accH[tix], 0, 0, 0);
-        }
-    }
-
-    // first slot of block column c = 16ct + 4v + lk, minus c: H(r, c) sits at cbv + r, J(jr, c) at cbv + IR + jr
-    auto cbv = [&](int ct, int v) { const int c = 16 * ct + 4 * v + lkv; return c * (IR + OR - 1) - ((c * (c - 1)) >> 1); };
-    // ---- R5: store.  Entry v of a tile: block column c = 16ct + lk + 4v, row (H) r = 16rt + lr or (J) jr = lr; 16
-    //      consecutive lanes cover 128 contiguous bytes of the reference's slot order (DenseFunctionBase.h:1112-1123)
-    if (kkt_dst) {
-      if constexpr (ASM) {
-#pragma unroll
-        for (int t = 0; t < D::NTH; t++)
-#pragma unroll
-          for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, hmap[t][v], accH[t][v]);
-#pragma unroll
-        for (int t = 0; t < TI; t++)
-#pragma unroll
-          for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, jmap[t][v], accJ[t][v]);
-      } else {
-#pragma unroll
-        for (int rt = 0; rt < TI; rt++)
-#pragma unroll
-          for (int ct = 0; ct < rt; ct++) {                  // tiles left of the diagonal: every column < IR
-            const int tix = rt * (rt + 1) / 2 + ct;
-            if (CFULL || 16 * rt + lr < IR) {
-#pragma unroll
-              for (int v = 0; v < 4; v++) kkt_dst[cbv(ct, v) + 16 * rt + lr] = accH[tix][v];
-            }
-          }
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-          if (lr >= lk + 4 * v) {                            // diagonal tiles: r >= c
-#pragma unroll
-            for (int t = 0; t < TI; t++) {
-              const int tix = t * (t + 1) / 2 + t;
-              if (CFULL || t + 1 < TI || 16 * t + lr < IR) kkt_dst[cbv(t, v) + 16 * t + lr] = accH[tix][v];
-            }
-          }
-        }
-        if (lr < OR) {
+            for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, jmap[t][v], accJ[t][v]);
+        } else if (lr < OR) {
 #pragma unroll
           for (int ct = 0; ct < TI; ct++)
 #pragma unroll
@@ -651,12 +587,86 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
               if (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR) kkt_dst[cbv(ct, v) + IR + lr] = accJ[ct][v];
         }
       }
+      if (a.FX && lane < OR) a.FX[seg * OR + lane] = fxv;
     }
+    RTSG();
+    // ---- R4: tile column rt of H: M_i[:, rt], H(ct, rt) += DI_i[:, ct]^T M_i[:, rt]; HT and the adjoint gradient on its columns;
+    //      rank-2 time update  H += d HT^T + HT d^T,  d = e_TF - e_T  (the four updates of LGLDefects.h:508-511)
+    double a2[TI];                                      // A-side rank-2 fragments of the tiles done so far
+#pragma unroll
+    for (int rt = 0; rt < TI; rt++) {
+      d4 accH[TI];                                      // tiles (ct, rt), ct <= rt
+#pragma unroll
+      for (int ct = 0; ct <= rt; ct++) {                // cardinal Hessian blocks (LGLDefects.h:386-402): the initial value
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int tix = rt * (rt + 1) / 2 + ct, sh = R::sh_index(tix);
+#pragma unroll
+        for (int v = 0; v < 4; v++) accH[ct][v] = sh >= 0 ? S[lc.cho[sh >= 0 ? sh : 0][v]] : 0.0;
+      }
+      double hi = 0.0;
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        d4 Mi = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) Mi = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i][kk], dv[rt][i][kk], Mi, 0, 0, 0);
+        hi += Mi[R::vN];                 // entry v: row lk + 4v of M_i (row N: E_i g^_i . DI_i), column 16rt + lr
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+          for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], Mi[kk], accH[ct], 0, 0, 0);
+      }
+      // column role (lanes lk == lkN hold row N of the M tiles): full time-partial vector HT (LGLDefects.h:403-411, 504-505)
+      // and the adjoint gradient  g = J^T lam = h sum_i E_i g^_i^T DI_i + DC^T lam  (LGLDefects.h:512) of column 16rt + lr
+      if (lk == R::lkN) {
+        const int c = 16 * rt + lr;
+        HT[c] = hi + S[lc.cgg[rt]] / h;                 // (padding columns: 0 + 0)
+        if (a.AGX && (CFULL || c < IR)) a.AGX[seg * IR + c] = fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]]));
+      }
+      wave_lds_sync();
+      {
+        const double ht = HT[16 * rt + lr];
+        a2[rt] = lk == 0 ? tsA(rt) : (lk == 1 ? ht : 0.0);
+        const double b2 = lk == 0 ? ht : (lk == 1 ? tsA(rt) : 0.0);
+#pragma unroll
+        for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[ct], b2, accH[ct], 0, 0, 0);
+      }
+      if (kkt_dst) {
+        if constexpr (ASM) {
+#pragma unroll
+          for (int ct = 0; ct <= rt; ct++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, hmap[rt * (rt + 1) / 2 + ct][v], accH[ct][v]);
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < rt; ct++)               // tiles left of the diagonal: every column < IR
+            if (CFULL || 16 * rt + lr < IR) {
+#pragma unroll
+              for (int v = 0; v < 4; v++) kkt_dst[cbv(ct, v) + 16 * rt + lr] = accH[ct][v];
+            }
+#pragma unroll
+          for (int v = 0; v < 4; v++)                   // diagonal tile: r >= c
+            if (lr >= lk + 4 * v && (CFULL || rt + 1 < TI || 16 * rt + lr < IR)) kkt_dst[cbv(rt, v) + 16 * rt + lr] = accH[rt][v];
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    RTSG();
   }
+  RTS();
+#if defined(ASSET_TIMING)
+  if (blockIdx.x == 7 && lane == 0 && a.FX)
+    for (int t = 0; t + 1 < nts; t++) a.FX[size_t(seg0) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
+#endif
+#undef RTS
+#undef RTSG
 }
 
 template <class Ode, int SCH, bool BLOCKED, bool ASM = false>
 __global__ __launch_bounds__(64, 2) void lgl_resident_kernel(EvalArgs a) {
+#if defined(ASSET_EXP_NULL)   // (experiment: the cost of the launch itself)
+  if (a.nseg > 0) return;
+#endif
   if constexpr (ResDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_resident_body<Ode, SCH, BLOCKED, ASM>(a);
 }
 
