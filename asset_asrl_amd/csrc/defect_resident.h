@@ -51,6 +51,26 @@ struct ResDims {
   static constexpr bool OK = !D::TRAP && !D::WIDE && D::p == 0 && D::TJ == 1 && N + 1 <= 16 && Ode::NUNITS == 1 && GR >= 2 &&
                              D::STAGED;
   static constexpr int lkN = N & 3, vN = N >> 2;   // accumulator entry that holds row N of an M tile (the E g^ row)
+  // JRIDE: the rows N+1 .. N+n of the A operand of the M product carry h E_i J^_i, so the interior part of J comes out of the
+  // same matrix instructions (as J_i[r][c] in the lanes of column c: transposed with respect to the store order).  It is
+  // turned through LDS, one 16-column tile and interior at a time, in buffers T_i [16][n] laid over sections of the segment's
+  // own slot that are dead by then: CJ (read into registers / the DC values before) and [If | IJ | Ig | IH] (all in the
+  // A operands and the row sums by then).  Buffers are placed greedily; without room the J product keeps its own instructions.
+  static constexpr int TB = 16 * n;
+  static constexpr int deadA0 = D::w_CJ, deadA1 = D::w_CJ + CS * D::NZJ, deadB0 = D::w_If, deadB1 = D::WSLOTD;
+  static constexpr int t_off(int i) {              // slot offset of T_i, or -1
+    int a = deadA0, b = deadB0;
+    for (int k = 0; k <= i; k++) {
+      if (a + TB <= deadA1) { if (k == i) return a; a += TB; }
+      else if (b + TB <= deadB1) { if (k == i) return b; b += TB; }
+      else return -1;
+    }
+    return -1;
+  }
+#ifndef ASSET_RES_JRIDE
+#define ASSET_RES_JRIDE 1
+#endif
+  static constexpr bool JRIDE = ASSET_RES_JRIDE && (N + 1 + n <= 16) && t_off(K - 1) >= 0;
   // lower-triangle H tiles that can hold a cardinal Hessian block (tiles_share_node), numbered among themselves
   static constexpr int sh_index(int tix_want) {
     int k = 0;
@@ -189,7 +209,7 @@ struct ResLane {
   int cbo[TI];           // B_ij of the column's node (or a zero row)
   int cjo[TI][KS];       // J_j[b][cc]
   int wlo[TI][KS];       // WL[j][b] (state rows) or a zero: this lane's share of  sum_r WL[j][r] J_j[r][cc]  (adjoint gradient)
-  // M product, A operand: lane (lr, lk) <-> row lr of [h E_i H^_i ; E_i g^_i], column 4kk + lk
+  // M product, A operand: lane (lr, lk) <-> row lr of [h E_i H^_i ; E_i g^_i ; h E_i J^_i (JRIDE)], column 4kk + lk
   int ao[KS], ast[KS];   // offset for i = 0, stride in i
   // J product, B operand: lane (lr, lk) <-> defect row jr = lr = (il, rl), row 4kk + lk of (h E_il J^_il)^T
   int jo[KS];
@@ -246,6 +266,10 @@ struct ResLane {
           const int hp = Ode::HPOS[(b >= lr) ? b * (b + 1) / 2 + lr : lr * (lr + 1) / 2 + b];
           if (hp >= 0) { o = D::w_IH + hp; st = D::NZH; }
         } else if (lr == N) { o = D::w_Ig + b; st = N; }
+        else if (R::JRIDE && lr <= N + n) {
+          const int jp = Ode::JPOS[(lr - N - 1) * N + b];
+          if (jp >= 0) { o = D::w_IJ + jp; st = D::NZJ; }
+        }
       }
       ao[kk] = o;
       ast[kk] = st;
@@ -539,32 +563,45 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       for (int kk = 0; kk < KS; kk++) ah[i][kk] = sc * S[lc.ao[kk] + i * lc.ast[kk]];
     }
     __builtin_amdgcn_s_setprio(1);
-    {   // ---- R3: J^T = DC^T + sum_i DI_i^T (h E_i J^_i)^T
-      d4 accJ[TI];
+    // ---- R3: cardinal part of J (DC): the initial value of the J^T tiles; without JRIDE the interior part right away
+    //      J^T = DC^T + sum_i DI_i^T (h E_i J^_i)^T, stored at once
+    d4 accJ[TI];
+#pragma unroll
+    for (int ct = 0; ct < TI; ct++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int c0 = 16 * ct + 4 * v;                         // column = c0 + lk
+        double dd, cw;
+        if constexpr (LCT::QFAST) {                              // node and component of the column: (c0 + lk) / q, (c0 + lk) % q
+          const int jn = c0 / q < CS ? c0 / q : 0;
+          dd = (c0 < IR) ? lc.tD[jn] : 0.0;
+          cw = (c0 < IR && lk == lc.rl - c0 % q) ? lc.tC[jn] : 0.0;
+        } else {
+          dd = lc.dcD[ct][v];
+          cw = lc.dcC[ct][v];
+        }
+        double val = fma(h * dd, S[lc.dco[ct][v]], cw);
+        if (c0 <= T && T < c0 + 4) val -= (lk == T - c0) ? sd : 0.0;        // DC rows -+ (sum_j D_ij f_j + E_i f^_i)
+        if (c0 <= TF && TF < c0 + 4) val += (lk == TF - c0) ? sd : 0.0;     // (LGLDefects.h:484-500)
+        accJ[ct][v] = val;
+      }
+    auto store_J_tile = [&](int ct, const d4& acc) {
+      if (!kkt_dst) return;
+      if constexpr (ASM) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, jmap[ct][v], acc[v]);
+      } else if (lr < OR) {
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+          if (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR) kkt_dst[cbv(ct, v) + IR + lr] = acc[v];
+      }
+    };
+    if constexpr (!R::JRIDE) {
       double bj[KS], hel = 0.0;
 #pragma unroll
       for (int i = 0; i < K; i++) hel = (lc.il == i) ? h * ctab.E[i] : hel;
 #pragma unroll
       for (int kk = 0; kk < KS; kk++) bj[kk] = hel * S[lc.jo[kk]];
-#pragma unroll
-      for (int ct = 0; ct < TI; ct++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {                              // cardinal part (DC): the initial value
-          const int c0 = 16 * ct + 4 * v;                         // column = c0 + lk
-          double dd, cw;
-          if constexpr (LCT::QFAST) {                              // node and component of the column: (c0 + lk) / q, (c0 + lk) % q
-            const int jn = c0 / q < CS ? c0 / q : 0;
-            dd = (c0 < IR) ? lc.tD[jn] : 0.0;
-            cw = (c0 < IR && lk == lc.rl - c0 % q) ? lc.tC[jn] : 0.0;
-          } else {
-            dd = lc.dcD[ct][v];
-            cw = lc.dcC[ct][v];
-          }
-          double val = fma(h * dd, S[lc.dco[ct][v]], cw);
-          if (c0 <= T && T < c0 + 4) val -= (lk == T - c0) ? sd : 0.0;        // DC rows -+ (sum_j D_ij f_j + E_i f^_i)
-          if (c0 <= TF && TF < c0 + 4) val += (lk == TF - c0) ? sd : 0.0;     // (LGLDefects.h:484-500)
-          accJ[ct][v] = val;
-        }
 #pragma unroll
       for (int i = 0; i < K; i++)
 #pragma unroll
@@ -573,22 +610,11 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
           for (int ct = 0; ct < TI; ct++) accJ[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], b, accJ[ct], 0, 0, 0);
         }
-      if (kkt_dst) {
-        if constexpr (ASM) {
 #pragma unroll
-          for (int t = 0; t < TI; t++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, jmap[t][v], accJ[t][v]);
-        } else if (lr < OR) {
-#pragma unroll
-          for (int ct = 0; ct < TI; ct++)
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-              if (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR) kkt_dst[cbv(ct, v) + IR + lr] = accJ[ct][v];
-        }
-      }
-      if (a.FX && lane < OR) a.FX[seg * OR + lane] = fxv;
+      for (int ct = 0; ct < TI; ct++) store_J_tile(ct, accJ[ct]);
     }
+    if (a.FX && lane < OR) a.FX[seg * OR + lane] = fxv;
+    wave_lds_sync();                                    // (every read of the sections the T buffers lie over has returned)
     RTSG();
     // ---- R4: tile column rt of H: M_i[:, rt], H(ct, rt) += DI_i[:, ct]^T M_i[:, rt]; HT and the adjoint gradient on its columns;
     //      rank-2 time update  H += d HT^T + HT d^T,  d = e_TF - e_T  (the four updates of LGLDefects.h:508-511)
@@ -611,10 +637,30 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) Mi = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i][kk], dv[rt][i][kk], Mi, 0, 0, 0);
         hi += Mi[R::vN];                 // entry v: row lk + 4v of M_i (row N: E_i g^_i . DI_i), column 16rt + lr
+        if constexpr (R::JRIDE) {        // rows N+1 .. N+n: J_i[r][16rt + lr] -> T_i[lr][r]
+          lds_double* const Ti = (lds_double*)S + R::t_off(i) + lr * n;
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            if (4 * v + 3 < N + 1 || 4 * v > N + n) continue;          // (no lane has such a row in this entry)
+            const int r = lk + 4 * v - N - 1;
+            if (r >= 0 && r < n) Ti[r] = Mi[v];
+          }
+        }
 #pragma unroll
         for (int kk = 0; kk < KS; kk++)
 #pragma unroll
           for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], Mi[kk], accH[ct], 0, 0, 0);
+      }
+      if constexpr (R::JRIDE) {          // J^T tile rt: entry v <-> (column 16rt + lk + 4v, defect row jr = lr = (il, rl))
+        wave_lds_sync();
+        int tb = R::t_off(0);
+#pragma unroll
+        for (int i = 1; i < K; i++) tb = (lc.il == i) ? R::t_off(i) : tb;
+        const lds_double* const Tr = S + tb + lk * n + lc.rl;
+        d4 acc = accJ[rt];
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[v] += (lr < OR) ? Tr[4 * v * n] : 0.0;
+        store_J_tile(rt, acc);
       }
       // column role (lanes lk == lkN hold row N of the M tiles): full time-partial vector HT (LGLDefects.h:403-411, 504-505)
       // and the adjoint gradient  g = J^T lam = h sum_i E_i g^_i^T DI_i + DC^T lam  (LGLDefects.h:512) of column 16rt + lr
