@@ -71,6 +71,11 @@ struct ResDims {
 #define ASSET_RES_JRIDE 1
 #endif
   static constexpr bool JRIDE = ASSET_RES_JRIDE && (N + 1 + n <= 16) && t_off(K - 1) >= 0;
+  // 16 dead cells behind the last buffer: where the lanes without a J row in an accumulator entry write instead (a store under
+  // a lane condition costs an exec-mask round trip each; 24 of them per segment)
+  static constexpr int t_end = t_off(K - 1) + TB;
+  static constexpr int t_dummy = (t_off(K - 1) >= deadB0 && t_end + 16 <= deadB1) ? t_end
+                                 : ((t_off(K - 1) < deadB0 && deadB0 + 16 <= deadB1) ? deadB0 : -1);
   // lower-triangle H tiles that can hold a cardinal Hessian block (tiles_share_node), numbered among themselves
   static constexpr int sh_index(int tix_want) {
     int k = 0;
@@ -484,8 +489,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       for (int jj = 0; jj < CS; jj++) { sd += lc.tD[jj] * fj[jj]; fxv += lc.tC[jj] * zj[jj]; }
       fxv += h * sd;
     }
-    int lkv = lk;                                     // (opaque per iteration: what is derived from it is recomputed, not kept)
-    asm volatile("" : "+v"(lkv));
+    int lkv = lk, lkb = lk * (IR + OR - 1) - ((lk * (lk - 1)) >> 1);   // (opaque per iteration: what is derived from them is
+    asm volatile("" : "+v"(lkv), "+v"(lkb));                              //  recomputed, not kept in registers across the loop)
     const double lamr = (lr < OR) ? S[D::w_lam + lr] : 0.0;
     const double sls = row16_sum(lamr * sd);          // sum_(i,r) lam_(i,r) sd_(i,r), in every lane
     if (lane < CS * n) {                              // CL[j][r] = sum_i C_ij lam_(i,r), WL[j][r] = sum_i D_ij lam_(i,r)
@@ -554,7 +559,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     // Entry v of a tile: block column c = 16ct + lk + 4v, row (H) r = 16rt + lr or (J) jr = lr; 16 consecutive lanes cover
     // 128 contiguous bytes of the reference's slot order (DenseFunctionBase.h:1112-1123); first slot of block column c,
     // minus c: H(r, c) sits at cbv + r, J(jr, c) at cbv + IR + jr.
-    auto cbv = [&](int ct, int v) { const int c = 16 * ct + 4 * v + lkv; return c * (IR + OR - 1) - ((c * (c - 1)) >> 1); };
+    auto cbv = [&](int ct, int v) {                  // c = c0 + lk:  cb(c) = cb(c0) + [lk (IR+OR-1) - lk (lk-1) / 2] - c0 lk
+      const int c0 = 16 * ct + 4 * v;
+      return c0 * (IR + OR - 1) - ((c0 * (c0 - 1)) >> 1) + lkb - c0 * lkv;
+    };
     double ah[K][KS];                                  // A operand of the M products: [h E_i H^_i ; E_i g^_i]
 #pragma unroll
     for (int i = 0; i < K; i++) {
@@ -593,7 +601,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       } else if (lr < OR) {
 #pragma unroll
         for (int v = 0; v < 4; v++)
-          if (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR) kkt_dst[cbv(ct, v) + IR + lr] = acc[v];
+          if (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR) kkt_dst[unsigned(cbv(ct, v) + IR + lr)] = acc[v];
       }
     };
     if constexpr (!R::JRIDE) {
@@ -643,7 +651,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           for (int v = 0; v < 4; v++) {
             if (4 * v + 3 < N + 1 || 4 * v > N + n) continue;          // (no lane has such a row in this entry)
             const int r = lk + 4 * v - N - 1;
-            if (r >= 0 && r < n) Ti[r] = Mi[v];
+            if constexpr (R::t_dummy >= 0) {
+              lds_double* const Sw = (lds_double*)S;
+              Sw[(r >= 0 && r < n) ? R::t_off(i) + lr * n + r : R::t_dummy + lr] = Mi[v];
+            } else if (r >= 0 && r < n) Ti[r] = Mi[v];
           }
         }
 #pragma unroll
@@ -688,11 +699,11 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           for (int ct = 0; ct < rt; ct++)               // tiles left of the diagonal: every column < IR
             if (CFULL || 16 * rt + lr < IR) {
 #pragma unroll
-              for (int v = 0; v < 4; v++) kkt_dst[cbv(ct, v) + 16 * rt + lr] = accH[ct][v];
+              for (int v = 0; v < 4; v++) kkt_dst[unsigned(cbv(ct, v) + 16 * rt + lr)] = accH[ct][v];
             }
 #pragma unroll
           for (int v = 0; v < 4; v++)                   // diagonal tile: r >= c
-            if (lr >= lk + 4 * v && (CFULL || rt + 1 < TI || 16 * rt + lr < IR)) kkt_dst[cbv(rt, v) + 16 * rt + lr] = accH[rt][v];
+            if (lr >= lk + 4 * v && (CFULL || rt + 1 < TI || 16 * rt + lr < IR)) kkt_dst[unsigned(cbv(rt, v) + 16 * rt + lr)] = accH[rt][v];
         }
       }
     }
