@@ -367,6 +367,9 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   const int per = a.nseg / nshare, rem = a.nseg % nshare;
   const int seg0 = share * per + min(share, rem);
   const int gcount = min(per + (share < rem ? 1 : 0), GR);
+  // (shifting segments from the younger wave of every SIMD to the older one -- 52 / 54 / 56 % to the first half of the grid --
+  //  changes nothing: 35.1-35.2 us each)
+  const bool young = 2 * int(blockIdx.x) >= int(gridDim.x);        // the second wave of its SIMD (workgroups are dealt breadth first)
 
 #if defined(ASSET_TIMING)
   long long tstamp[24];
@@ -376,6 +379,9 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #else
 #define RTS() do {} while (0)
 #define RTSG() do {} while (0)
+#endif
+#if defined(ASSET_WALLCLOCK)
+  const long long wall_t0 = wall_clock64();
 #endif
   RTS();
   // ------------------------------------------------------------------ ODE stage
@@ -570,7 +576,15 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
       for (int kk = 0; kk < KS; kk++) ah[i][kk] = sc * S[lc.ao[kk] + i * lc.ast[kk]];
     }
-    __builtin_amdgcn_s_setprio(1);
+#ifndef ASSET_RES_PRIO
+#define ASSET_RES_PRIO 1
+#endif
+    // The two waves of a SIMD are workgroups b and b + gridDim/2; left alone the older one wins every arbitration and ends
+    // ~5 us before the younger one (36.8 against 31.5 us), i.e. the kernel ends 2.5 us later than it would with both ending
+    // together.  ASSET_RES_PRIO 1: the younger wave runs its products at a higher priority than the older one.
+    if (ASSET_RES_PRIO == 1) { if (young) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+    else if (ASSET_RES_PRIO == 2) { if ((g & 1) == int(young)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+    else __builtin_amdgcn_s_setprio(1);
     // ---- R3: cardinal part of J (DC): the initial value of the J^T tiles; without JRIDE the interior part right away
     //      J^T = DC^T + sum_i DI_i^T (h E_i J^_i)^T, stored at once
     d4 accJ[TI];
@@ -714,6 +728,14 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #if defined(ASSET_TIMING)
   if (blockIdx.x == 7 && lane == 0 && a.FX)
     for (int t = 0; t + 1 < nts; t++) a.FX[size_t(seg0) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
+#endif
+#if defined(ASSET_WALLCLOCK)   // (tuning builds) 100 MHz wall-clock at the start and the end of every wave, left in FX
+  if (lane == 0 && a.FX && gcount > 0) {
+    a.FX[size_t(seg0) * OR + 0] = double(wall_t0);
+    a.FX[size_t(seg0) * OR + 1] = double(wall_clock64());
+    a.FX[size_t(seg0) * OR + 2] = double(__builtin_amdgcn_s_getreg(63492));   // HW_ID
+    a.FX[size_t(seg0) * OR + 3] = double(__builtin_amdgcn_s_getreg(63508));   // XCC_ID
+  }
 #endif
 #undef RTS
 #undef RTSG
