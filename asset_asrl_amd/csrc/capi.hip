@@ -127,6 +127,7 @@ struct asset_hip_defect {
   int *d_fx_rows = nullptr, *d_fx_ptr = nullptr, *d_fx_src = nullptr, *d_gx_rows = nullptr, *d_gx_ptr = nullptr, *d_gx_src = nullptr;
   int n_fx_rows = 0, fx_long_from = 0, n_gx_rows = 0, gx_long_from = 0;
   bool rhs_tables_ready = false;
+  int affine = 0, aff_v0 = 0, aff_vs = 0, aff_c0 = 0, aff_cs = 0;   // index rows that are runs (EvalArgs::affine)
   int bundles = 0;                   // bundles that hold this handle (asset_hip_bundle_create)
   bool destroy_pending = false;      // asset_hip_defect_destroy was called while a bundle held it: freed with the last bundle
   double *d_fxb = nullptr, *d_agxb = nullptr;    // block buffers of that entry point
@@ -437,6 +438,17 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
     return bail(e, "hipMemcpy(cindex)");
   h->h_vindex.assign(d->vindex, d->vindex + nv);
   h->h_cindex.assign(d->cindex, d->cindex + nc);
+  {   // rows that are runs with a constant stride between applications (EvalArgs::affine)
+    const int ir = ke->ir, orr = ke->orr, ns = d->nseg;
+    const int v0 = d->vindex[0], c0 = d->cindex[0];
+    const int vs = ns > 1 ? d->vindex[ir] - v0 : 0, cs = ns > 1 ? d->cindex[orr] - c0 : 0;
+    bool ok = true;
+    for (int s = 0; s < ns && ok; s++) {
+      for (int k = 0; k < ir && ok; k++) ok = d->vindex[size_t(s) * ir + k] == v0 + s * vs + k;
+      for (int k = 0; k < orr && ok; k++) ok = d->cindex[size_t(s) * orr + k] == c0 + s * cs + k;
+    }
+    h->affine = ok ? 1 : 0, h->aff_v0 = v0, h->aff_vs = vs, h->aff_c0 = c0, h->aff_cs = cs;
+  }
   if (ke->work_doubles) {
     if ((e = hipMalloc(&h->d_work, size_t(h->nseg) * ke->work_doubles * sizeof(double))) != hipSuccess)
       return bail(e, "hipMalloc(workspace)");
@@ -519,6 +531,8 @@ static int fill_args(asset_hip_defect_t h, int what, const double* dX, const dou
   a.work = h->d_work;
   a.lane_consts = level >= 1 ? h->d_lane[level] : nullptr;
   a.lane_consts_res = h->d_lane[0];
+  static const bool no_affine = std::getenv("ASSET_HIP_NO_AFFINE") != nullptr;                                 // tuning only
+  a.affine = no_affine ? 0 : h->affine, a.aff_v0 = h->aff_v0, a.aff_vs = h->aff_vs, a.aff_c0 = h->aff_c0, a.aff_cs = h->aff_cs;
   a.appl_consts = h->d_aconst;
   if (h->ke->naconst > 0 && !h->d_aconst)
     return fail(ASSET_HIP_EINVAL, "this function reads constants of its applications: call asset_hip_defect_set_appl_consts first");

@@ -56,6 +56,11 @@ struct EvalArgs {
   // per-lane constants of the dense stage, computed once per handle (defect_kernels.h: LaneConsts, lane_setup_kernel)
   const void* lane_consts = nullptr;
   const void* lane_consts_res = nullptr;   // the record of the resident kernel (defect_resident.h: ResLane)
+  // Index tables whose rows are runs -- vindex[s][k] = aff_v0 + s aff_vs + k, cindex[s][k] = aff_c0 + s aff_cs + k, what a
+  // phase without BlockConstant controls and ODE parameters produces (PhaseIndexer.cpp:361-372, 179-189) -- are recognised
+  // when the handle is created: the resident kernel then forms the addresses of z and lam itself instead of loading them
+  // (one dependent memory round trip less at the start of every wave).
+  int affine = 0, aff_v0 = 0, aff_vs = 0, aff_c0 = 0, aff_cs = 0;
   // plain functions (func_kernels.h): constants of every application, [nseg][F::NACONST] (vf.ApplConst) or null
   const double* appl_consts = nullptr;
   // bit 0 (ASSET_HIP_KEEP_HESSIAN_SLOTS, Jacobian kinds): the Hessian slots of the KKT blocks are not written at all

@@ -125,13 +125,28 @@ struct CardInRes {   // y = [z_j (q)] from the slot; lam = adjoint weights and s
   __device__ double saved(int k) const { return sv[k]; }
 };
 
-// P1: f_j and its transcendental sub-expressions at cardinal node j (reads the solver vector itself: its loads overlap P0's)
+template <class D>
+struct GatherRun {   // y = X[first index of the segment + j q + i]: index rows that are runs (EvalArgs::affine; p == 0)
+  const double* Xs;
+  int j;
+  __device__ double y(int i) const { return Xs[j * D::q + i]; }
+  __device__ double lam(int) const { return 0.0; }
+  __device__ double saved(int) const { return 0.0; }
+};
+
+// P1: f_j and its transcendental sub-expressions at cardinal node j (reads the solver vector itself: its loads overlap P0's);
+// vi == nullptr: the segment's inputs are the run of X that starts at Xs
 template <class Ode, class D>
-__device__ __attribute__((noinline, not_tail_called)) void res_cardinal_value(lds_double* S, int j, const double* X, const int* vi) {
+__device__ __attribute__((noinline, not_tail_called)) void res_cardinal_value(lds_double* S, int j, const double* Xs, const int* vi) {
   using R = ResDims<D>;
   OdeOutRes<D> out{S + D::w_Cf + j * D::n, nullptr, nullptr, nullptr, S + R::s_SV + j * R::SV_LD};
-  GatherIn<D> in{X, vi, j};
-  Ode::f_save(in, out);
+  if (vi) {
+    GatherIn<D> in{Xs, vi, j};
+    Ode::f_save(in, out);
+  } else {
+    GatherRun<D> in{Xs, j};
+    Ode::f_save(in, out);
+  }
 }
 
 // P2: interior point i: x^, tau, u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
@@ -390,10 +405,23 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     const int* vseg = a.vindex + size_t(seg0) * IR;
     const int* cseg = a.cindex + size_t(seg0) * OR;
     int vi[NZ], ci[NL];
+    if (a.affine) {                      // (uniform) the rows of the index tables are runs: no index loads
 #pragma unroll
-    for (int t = 0; t < NZ; t++) vi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : -1;
+      for (int t = 0; t < NZ; t++) {
+        const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
+        vi[t] = (e < gcount * IR) ? a.aff_v0 + (seg0 + g) * a.aff_vs + r : -1;
+      }
 #pragma unroll
-    for (int t = 0; t < NL; t++) ci[t] = (lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : -1;
+      for (int t = 0; t < NL; t++) {
+        const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
+        ci[t] = (e < gcount * OR) ? a.aff_c0 + (seg0 + g) * a.aff_cs + r : -1;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NZ; t++) vi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : -1;
+#pragma unroll
+      for (int t = 0; t < NL; t++) ci[t] = (lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : -1;
+    }
     double tabv[NTAB];
 #pragma unroll
     for (int t = 0; t < NTAB; t++)
@@ -425,7 +453,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   RTS();
   if (lane < gcount * CS) {            // P1
     const int g = lane / CS, j = lane - g * CS;
-    res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
+    if (a.affine) res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X + (a.aff_v0 + (seg0 + g) * a.aff_vs), nullptr);
+    else res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
   }
   wave_lds_sync();
   RTS();
