@@ -18,8 +18,8 @@
 // result blocks.  Reference: /root/reference/src/OptimalControl/LGLDefects.h:289-551 (phase order :341-412, the products
 // :414-506, the time rows / columns :508-511, adjgrad :512); slot order of the blocks DenseFunctionBase.h:1112-1123.
 //
-// Shapes: LGL3/5/7, no ODE parameters in the segment input (p == 0: not BlockConstant), N + 1 <= 16, defect rows in one
-// 16-row tile (K n <= 16), not a heavy right-hand side.  Meshes of at most GR segments per wave (10 240 Reentry-LGL7 segments
+// Shapes: LGL3/5/7 (segment parameters -- ODE parameters, BlockConstant controls -- included), N + 1 <= 16, defect rows in
+// one 16-row tile (K n <= 16), not a heavy right-hand side.  Meshes of at most GR segments per wave (10 240 Reentry-LGL7 segments
 // on 256 CUs); everything else takes the kernels of defect_kernels.h.
 #pragma once
 #include "defect_kernels.h"
@@ -39,7 +39,7 @@ struct ResDims {
   static constexpr int SV_LD = SV_ALIAS ? N : Ode::NSAVE;
   static constexpr int SLOT = (D::WSLOTD + 1 + (SV_ALIAS ? 0 : CS * Ode::NSAVE)) | 1;   // odd: conflict-free across segments
   // wave-level scratch behind the slots
-  static constexpr int x_AUX = 0;                  // [K][4]: 1 - s_i, s_i, 0, 0  (tau row of DI_i, same row stride as the tables)
+  static constexpr int x_AUX = 0;                  // [K][4]: 1 - s_i, s_i, 0, 1  (tau row / parameter rows of DI_i, same row stride as the tables)
   static constexpr int x_HT = x_AUX + 4 * K;       // [IRP] full time-partial vector (rank-2 rows)
   static constexpr int x_CL = x_HT + IRP;          // [CS][n]  sum_i C_ij lam_(i,r)
   static constexpr int x_WL = x_CL + CS * n;       // [CS][n]  sum_i D_ij lam_(i,r)
@@ -48,7 +48,7 @@ struct ResDims {
   static constexpr int GR_FIT = (LDS_WAVE / 8 - D::TABSZ - XTRA) / SLOT;
   static constexpr int GR = GR_FIT < 64 / CS ? GR_FIT : 64 / CS;
   static constexpr size_t lds_bytes() { return size_t(D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA) * 8; }
-  static constexpr bool OK = !D::TRAP && !D::WIDE && D::p == 0 && D::TJ == 1 && N + 1 <= 16 && Ode::NUNITS == 1 && GR >= 2 &&
+  static constexpr bool OK = !D::TRAP && !D::WIDE && D::TJ == 1 && N + 1 <= 16 && Ode::NUNITS == 1 && GR >= 2 &&
                              D::STAGED;
   static constexpr int lkN = N & 3, vN = N >> 2;   // accumulator entry that holds row N of an M tile (the E g^ row)
   // JRIDE: the rows N+1 .. N+n of the A operand of the M product carry h E_i J^_i, so the interior part of J comes out of the
@@ -120,7 +120,7 @@ struct CardInRes {   // y = [z_j (q)] from the slot; lam = adjoint weights and s
   const double* w;
   const double* sv;
   int j;
-  __device__ double y(int i) const { return z[j * D::q + i]; }
+  __device__ double y(int i) const { return i < D::q ? z[j * D::q + i] : z[D::P0 + (i - D::q)]; }
   __device__ double lam(int k) const { return w[k]; }
   __device__ double saved(int k) const { return sv[k]; }
 };
@@ -176,6 +176,8 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
     y[n + 1 + k] = acc;
   }
 #pragma unroll
+  for (int k = 0; k < D::p; k++) y[q + k] = z[D::P0 + k];
+#pragma unroll
   for (int k = 0; k < n; k++) li[k] = lam[i * n + k];
   RegIn<D> in{y, li};
   OdeOutRes<D> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH, nullptr};
@@ -221,7 +223,8 @@ struct ResLane {
   static constexpr int K = D::K, n = D::n, q = D::q, N = D::N, CS = D::CS, KS = D::KS, TI = D::TI;
   static constexpr int IR = D::IR, OR = D::OR, P0 = D::P0, T = D::T, TF = D::TF;
   static constexpr int ZERO = R::s_Z0;
-  static constexpr bool QFAST = (q % 4 == 0);   // the node of column 16ct + lk + 4v does not depend on lk
+  static constexpr int p = D::p;
+  static constexpr bool QFAST = (q % 4 == 0) && p == 0;   // the node of column 16ct + lk + 4v does not depend on lk
 
   // DI fragments (B operand of the M product, A operand of the H and J products): lane (lr, lk) <-> column c = 16ct + lr,
   // row b = 4kk + lk:   dv[ct][i][kk] = tab[cao[ct][kk] + 4i] + h tab[cbo[ct] + 4i] * S[cjo[ct][kk]] -/+ sbv[i][kk] on columns T / TF
@@ -229,6 +232,9 @@ struct ResLane {
   int cbo[TI];           // B_ij of the column's node (or a zero row)
   int cjo[TI][KS];       // J_j[b][cc]
   int wlo[TI][KS];       // WL[j][b] (state rows) or a zero: this lane's share of  sum_r WL[j][r] J_j[r][cc]  (adjoint gradient)
+  // parameter columns (c >= P0; p > 0): DI_i[b][c] = h sum_j B_ij J_j[b][q + pc], [b == q + pc] on the parameter rows
+  int cpo[p > 0 ? TI : 1][KS];   // J_0[b][q + pc] (stride NZJ in j) or the zero cell; the lane's column is a parameter column iff cpo differs from it
+  int wpo[p > 0 ? TI : 1][KS];   // WL[0][b] (stride n in j) or a zero
   // M product, A operand: lane (lr, lk) <-> row lr of [h E_i H^_i ; E_i g^_i ; h E_i J^_i (JRIDE)], column 4kk + lk
   int ao[KS], ast[KS];   // offset for i = 0, stride in i
   // J product, B operand: lane (lr, lk) <-> defect row jr = lr = (il, rl), row 4kk + lk of (h E_il J^_il)^T
@@ -244,7 +250,7 @@ struct ResLane {
   // cardinal Hessian blocks: initial value of H accumulator entry (tile, v) of the tiles that can hold one (LGLDefects.h:386-402)
   int cho[R::NSH][4];
   // column role (lanes lk == lkN hold row N of the M tiles): column c = 16ct + lr
-  int cgg[TI];           // g_j[cc]
+  int cgg[TI];           // g_j[cc]  (parameter column: g_0[q + pc], summed over the nodes with stride N)
   int clo[TI];           // CL[j][cc] (cc < n) or a zero
 
   __device__ void compute(int lane) {
@@ -256,12 +262,12 @@ struct ResLane {
     constexpr int oXT = D::TABSZ + R::GR * R::SLOT;               // start of the wave-level scratch
     for (int ct = 0; ct < TI; ct++) {
       const int c = 16 * ct + lr;
-      const bool col = c < IR;                    // (p == 0: every column belongs to a node)
-      const int j = col ? c / q : 0, cc = col ? c - j * q : 0;
+      const bool col = c < P0, par = c >= P0 && c < IR;   // a node's column / a parameter column
+      const int j = col ? c / q : 0, cc = col ? c - j * q : 0, pc = par ? c - P0 : 0;
       cbo[ct] = col ? oB + j : oZERO;
       for (int kk = 0; kk < KS; kk++) {
         const int b = 4 * kk + lk;
-        int ca = oZERO, cj = ZERO;
+        int ca = oZERO, cj = ZERO, cp = ZERO, wp = oZERO;
         if (col && b < N) {
           if (b < n) {
             if (cc == b) ca = oA + j;
@@ -269,13 +275,18 @@ struct ResLane {
           } else if (b == T) {
             if (c == T) ca = oAUX + 0;
             else if (c == TF) ca = oAUX + 1;
-          } else if (cc == b) ca = oU + j;
+          } else if (b < q && cc == b) ca = oU + j;
+        }
+        if (par && b < N) {
+          if (b < n) { cp = jofs(0, b, q + pc); wp = oXT + R::x_WL + b; }
+          else if (b == q + pc) ca = oAUX + 3;               // identity on the parameter rows
         }
         cao[ct][kk] = ca;
         cjo[ct][kk] = cj;
         wlo[ct][kk] = (col && b < n) ? oXT + R::x_WL + j * n + b : oZERO;
+        if constexpr (p > 0) { cpo[ct][kk] = cp; wpo[ct][kk] = wp; }
       }
-      cgg[ct] = col ? D::w_Cg + j * N + cc : ZERO;
+      cgg[ct] = col ? D::w_Cg + j * N + cc : (par ? D::w_Cg + q + pc : ZERO);
       clo[ct] = (col && cc < n) ? oXT + R::x_CL + j * n + cc : oZERO;
     }
     for (int kk = 0; kk < KS; kk++) {
@@ -308,9 +319,9 @@ struct ResLane {
     for (int ct = 0; ct < TI; ct++)
       for (int v = 0; v < 4; v++) {
         const int c = 16 * ct + lk + 4 * v;
-        const bool ok = row && c < IR;
+        const bool ok = row && c < P0, par = row && c >= P0 && c < IR;
         const int j = ok ? c / q : 0, cc = ok ? c - j * q : 0;
-        dco[ct][v] = ok ? jofs(j, rl, cc) : ZERO;
+        dco[ct][v] = ok ? jofs(j, rl, cc) : (par ? jofs(0, rl, q + (c - P0)) : ZERO);   // (parameter column: stride NZJ in j)
         if constexpr (!QFAST) {
           dcC[ct][v] = (ok && cc == rl) ? tab.C[il][j] : 0.0;
           dcD[ct][v] = ok ? tab.D[il][j] : 0.0;
@@ -321,9 +332,15 @@ struct ResLane {
         for (int v = 0; v < 4; v++) {
           const int c = 16 * ct + lk + 4 * v, r = 16 * rt + lr, tix = rt * (rt + 1) / 2 + ct;
           int ch = ZERO;
-          if (c < IR && r < IR && r >= c && r / q == c / q) {
-            const int jn = c / q, cc = c - jn * q, rr = r - jn * q, hp = Ode::HPOS[rr * (rr + 1) / 2 + cc];
-            if (hp >= 0) ch = D::w_CH + jn * D::NZH + hp;
+          if (c < IR && r < IR && r >= c) {
+            if (c < P0) {                       // a node's column: its own node's rows, or a parameter row (same node's Hessian)
+              const int jn = c / q, cc = c - jn * q;
+              const int rr = r < P0 ? (r / q == jn ? r - jn * q : -1) : q + (r - P0);
+              if (rr >= 0) { const int hp = Ode::HPOS[rr * (rr + 1) / 2 + cc]; if (hp >= 0) ch = D::w_CH + jn * D::NZH + hp; }
+            } else {                            // parameter-parameter: summed over the nodes (stride NZH) by the kernel
+              const int rr = q + (r - P0), c2 = q + (c - P0), hp = Ode::HPOS[rr * (rr + 1) / 2 + c2];
+              if (hp >= 0) ch = D::w_CH + hp;
+            }
           }
           if (R::sh_index(tix) >= 0) cho[R::sh_index(tix)][v] = ch;
         }
@@ -436,7 +453,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
     if (lane < 4 * K) {
       const int i = lane >> 2, w = lane & 3;
-      xtra[R::x_AUX + lane] = w == 0 ? 1.0 - ctab.s[i] : (w == 1 ? ctab.s[i] : 0.0);
+      xtra[R::x_AUX + lane] = w == 0 ? 1.0 - ctab.s[i] : (w == 1 ? ctab.s[i] : (w == 3 ? 1.0 : 0.0));
     }
     if (lane < GR) slots[lane * SLOT + R::s_Z0] = 0.0;
 #pragma unroll
@@ -453,7 +470,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   RTS();
   if (lane < gcount * CS) {            // P1
     const int g = lane / CS, j = lane - g * CS;
-    if (a.affine) res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X + (a.aff_v0 + (seg0 + g) * a.aff_vs), nullptr);
+    if (a.affine && D::p == 0) res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X + (a.aff_v0 + (seg0 + g) * a.aff_vs), nullptr);
     else res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
   }
   wave_lds_sync();
@@ -578,6 +595,28 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           for (int kk = 0; kk < KS; kk++)
             dv[ct][i][kk] = fma(tsa, sbv[i][kk], fma(hb, jv[kk], tabrow(lc.cao[ct][kk], i)));
         }
+        if constexpr (D::p > 0) {
+          if (16 * ct + 15 >= D::P0) {               // this tile has parameter columns: h sum_j B_ij J_j[b][q + pc] on the state rows
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) {
+              const bool par = lc.cpo[ct][kk] != LCT::ZERO;
+              const int jst = par ? D::NZJ : 0, wst = par ? n : 0;
+              double jp[CS];
+#pragma unroll
+              for (int jj = 0; jj < CS; jj++) {
+                jp[jj] = S[lc.cpo[ct][kk] + jj * jst];
+                agJ[ct] = fma(tabL[lc.wpo[ct][kk] + jj * wst], jp[jj], agJ[ct]);
+              }
+#pragma unroll
+              for (int i = 0; i < K; i++) {
+                double sp = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < CS; jj++) sp = fma(ctab.B[i][jj], jp[jj], sp);
+                dv[ct][i][kk] = fma(h, sp, dv[ct][i][kk]);
+              }
+            }
+          }
+        }
       }
 #pragma unroll
       for (int ct = 0; ct < TI; ct++) {              // the four lanes of a column (lk = 0..3) hold its row groups: add them up
@@ -632,6 +671,16 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           cw = lc.dcC[ct][v];
         }
         double val = fma(h * dd, S[lc.dco[ct][v]], cw);
+        if constexpr (D::p > 0) {
+          if (c0 + 3 >= D::P0 && c0 < IR) {            // parameter columns: h sum_j D_il,j J_j[rl][q + pc]
+            const bool par = c0 + lk >= D::P0 && lc.dco[ct][v] != LCT::ZERO;   // (no entry: the zero cell, no stride)
+            const int jst = par ? D::NZJ : 0;
+            double ps = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < CS; jj++) ps = fma(lc.tD[jj], S[lc.dco[ct][v] + jj * jst], ps);
+            val = par ? h * ps : val;
+          }
+        }
         if (c0 <= T && T < c0 + 4) val -= (lk == T - c0) ? sd : 0.0;        // DC rows -+ (sum_j D_ij f_j + E_i f^_i)
         if (c0 <= TF && TF < c0 + 4) val += (lk == TF - c0) ? sd : 0.0;     // (LGLDefects.h:484-500)
         accJ[ct][v] = val;
@@ -679,7 +728,20 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         (void)dummy;
         const int tix = rt * (rt + 1) / 2 + ct, sh = R::sh_index(tix);
 #pragma unroll
-        for (int v = 0; v < 4; v++) accH[ct][v] = sh >= 0 ? S[lc.cho[sh >= 0 ? sh : 0][v]] : 0.0;
+        for (int v = 0; v < 4; v++) {
+          double val = sh >= 0 ? S[lc.cho[sh >= 0 ? sh : 0][v]] : 0.0;
+          if constexpr (D::p > 0) {
+            if (sh >= 0 && 16 * ct + 4 * v + 3 >= D::P0) {     // parameter-parameter entries: summed over the cardinal nodes
+              const bool par = 16 * ct + 4 * v + lk >= D::P0 && lc.cho[sh >= 0 ? sh : 0][v] != LCT::ZERO;
+              const int hst = par ? D::NZH : 0;
+              double ps = 0.0;
+#pragma unroll
+              for (int jj = 1; jj < CS; jj++) ps += S[lc.cho[sh >= 0 ? sh : 0][v] + jj * hst];
+              val = par ? val + ps : val;
+            }
+          }
+          accH[ct][v] = val;
+        }
       }
       double hi = 0.0;
 #pragma unroll
@@ -720,7 +782,18 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       // and the adjoint gradient  g = J^T lam = h sum_i E_i g^_i^T DI_i + DC^T lam  (LGLDefects.h:512) of column 16rt + lr
       if (lk == R::lkN) {
         const int c = 16 * rt + lr;
-        HT[c] = hi + S[lc.cgg[rt]] / h;                 // (padding columns: 0 + 0)
+        double gs = S[lc.cgg[rt]];
+        if constexpr (D::p > 0) {
+          if (16 * rt + 15 >= D::P0) {                  // a parameter column: g_j summed over the nodes
+            const bool par = c >= D::P0 && c < IR;
+            const int gst = par ? N : 0;
+            double ps = 0.0;
+#pragma unroll
+            for (int jj = 1; jj < CS; jj++) ps += S[lc.cgg[rt] + jj * gst];
+            gs = par ? gs + ps : gs;
+          }
+        }
+        HT[c] = hi + gs / h;                            // (padding columns: 0 + 0)
         if (a.AGX && (CFULL || c < IR)) a.AGX[seg * IR + c] = fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]]));
       }
       wave_lds_sync();

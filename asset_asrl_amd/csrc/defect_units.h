@@ -84,7 +84,11 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
   lds_double* const tabL = (lds_double*)lds;
   lds_double* const mirror = (lds_double*)(lds + D::TABSZ);
   const int lane = threadIdx.x;
+#if defined(ASSET_EXP_ONEUNIT)
+  const int unit = ASSET_EXP_ONEUNIT;   // (experiment: every workgroup runs the same unit body)
+#else
   const int unit = blockIdx.y;
+#endif
   const int seg0 = int(blockIdx.x) * gp;
   const int gcount = min(gp, a.nseg - seg0);
   if (gcount <= 0) return;

@@ -17,11 +17,15 @@ for name in ("kernel_stats", "domain_stats"):
 
 def stage_of(kernel_name):
     """lgl_defect_kernel<Ode, CS, BLOCKED, G, LEVEL, STAGE[, ASM]>: STAGE is the sixth template argument."""
+    if "lgl_resident_kernel" in kernel_name:              # resident single launch (defect_resident.h)
+        return "resident"
     if "lgl_wide_dense_kernel" in kernel_name:            # four-wave dense stage of the wide shapes (defect_wide.h)
         return "dense_stage"
     if "lgl_ode_units_kernel" in kernel_name:             # ODE stage of heavy right-hand sides, one wave per output unit
         return "ode_units"
     args = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
+    if len(args) >= 6 and args[4] != "2":                 # derivative level 0 / 1: the secondary kinds bench.py also times
+        return "secondary"
     if len(args) >= 6 and args[5] == "3":                 # fused single launch (defect_kernels.h, STAGE 3)
         return "fused"
     if len(args) >= 6 and args[5] == "4":                 # fused, two-wave workgroups (STAGE 4)
@@ -36,7 +40,7 @@ def counters(sub):
     if not os.path.exists(path):
         return {}
     for r in csv.DictReader(open(path)):
-        if not any(k in r["Kernel_Name"] for k in ("lgl_defect_kernel", "lgl_wide_dense_kernel", "lgl_ode_units_kernel")):
+        if not any(k in r["Kernel_Name"] for k in ("lgl_defect_kernel", "lgl_wide_dense_kernel", "lgl_ode_units_kernel", "lgl_resident_kernel")):
             continue
         acc[stage_of(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
@@ -44,7 +48,7 @@ def counters(sub):
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 per_kernel, total = {}, 0.0
-for st in ("fused", "fused2", "ode_units", "ode_stage", "dense_stage"):
+for st in ("resident", "fused", "fused2", "ode_units", "ode_stage", "dense_stage"):
     if st not in fetch and st not in write:
         continue
     f_kb = fetch.get(st, {}).get("FETCH_SIZE", 0.0)
@@ -62,11 +66,12 @@ out = {
     "source": f"tools/collect_profiles.sh {tag} (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes "
               "of `python3 bench.py --no-cpu-baseline`)",
     "kernel_stats": [{"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])} for r in kernels
-                     if "defect_kernel" in r["Name"] or "wide_dense_kernel" in r["Name"] or "ode_units_kernel" in r["Name"]],
+                     if any(k in r["Name"] for k in ("defect_kernel", "wide_dense_kernel", "ode_units_kernel", "resident_kernel"))],
     "per_kernel": per_kernel,
     "hbm": {"fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section)", "bytes_per_launch": total,
-            "note": "one evaluation = the fused launch, or ODE-stage launch + dense-stage launch; traffic above the "
-                    "algorithmic bytes is the ODE-result workspace (written, and in the two-launch form read back from HBM)"},
+            "note": "one evaluation = the resident launch (no workspace traffic), the fused launch, or ODE-stage launch + dense-stage "
+                    "launch; traffic above the algorithmic bytes of the latter two is the ODE-result workspace (written, and "
+                    "in the two-launch form read back from HBM)"},
     "sq_counters_per_dispatch": sq,
 }
 json.dump(out, open(os.path.join(dst, f"{rnd}_{workload}_pmc.json"), "w"), indent=1)
