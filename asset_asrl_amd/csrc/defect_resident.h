@@ -255,7 +255,7 @@ struct ResLane {
 
   __device__ void compute(int lane) {
     const int lr = lane & 15, lk = lane >> 4;
-    constexpr int oA = offsetof(LglTab, A) / 8, oB = offsetof(LglTab, B) / 8, oU = offsetof(LglTab, U) / 8;
+    constexpr int oA = __builtin_offsetof(LglTab, A) / 8, oB = __builtin_offsetof(LglTab, B) / 8, oU = __builtin_offsetof(LglTab, U) / 8;
     constexpr int oAUX = D::TABSZ + R::GR * R::SLOT + R::x_AUX;   // (the scratch follows the slots)
     constexpr int oZERO = oAUX + 2;                                // a row of zeros, same stride
     auto jofs = [](int j, int r, int cc) { const int jp = Ode::JPOS[r * N + cc]; return jp >= 0 ? D::w_CJ + j * D::NZJ + jp : ZERO; };
