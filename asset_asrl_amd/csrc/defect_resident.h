@@ -95,17 +95,20 @@ struct ResDims {
 };
 
 // ---------------------------------------------------------------------------------------------- ODE stage: accessors
-template <class D>
+template <class D, bool ACCG = false>
 struct OdeOutRes {   // every result of an ODE body goes to the segment's LDS slot
   lds_double* f_;
   lds_double* J_;
   lds_double* g_;
   lds_double* H_;
   lds_double* sv_;
+  const double* lamv_ = nullptr;                 // ACCG (the Jacobian kinds: fj has no g output): multipliers of the point's
+  double gacc_[ACCG ? D::N : 1];                 // rows, and g^ = J^^T lam accumulated while J is emitted
   __device__ void f(int k, double v) { if (f_) f_[k] = v; }
   __device__ void J(int k, int i, double v) {
     const int c = D::ode_t::JPOS[k * D::N + i];
     if (c >= 0 && J_) J_[c] = v;
+    if constexpr (ACCG) { if (c >= 0) gacc_[i] += lamv_[k] * v; }
   }
   __device__ void g(int i, double v) { if (g_) g_[i] = v; }
   __device__ void H(int i, int j, double v) {
@@ -136,22 +139,24 @@ struct GatherRun {   // y = X[first index of the segment + j q + i]: index rows 
 
 // P1: f_j and its transcendental sub-expressions at cardinal node j (reads the solver vector itself: its loads overlap P0's);
 // vi == nullptr: the segment's inputs are the run of X that starts at Xs
-template <class Ode, class D>
+// (LEVEL 1, the Jacobian kinds: f_j and J_j, nothing saved -- there is no second cardinal phase)
+template <class Ode, class D, int LEVEL = 2>
 __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_value(lds_double* S, int j, const double* Xs, const int* vi) {
   using R = ResDims<D>;
-  OdeOutRes<D> out{S + D::w_Cf + j * D::n, nullptr, nullptr, nullptr, S + R::s_SV + j * R::SV_LD};
+  OdeOutRes<D> out{S + D::w_Cf + j * D::n, LEVEL == 1 ? S + D::w_CJ + j * D::NZJ : nullptr, nullptr, nullptr,
+                   LEVEL == 1 ? nullptr : S + R::s_SV + j * R::SV_LD};
   if (vi) {
     GatherIn<D> in{Xs, vi, j};
-    Ode::f_save(in, out);
+    if constexpr (LEVEL == 1) Ode::fj(in, out); else Ode::f_save(in, out);
   } else {
     GatherRun<D> in{Xs, j};
-    Ode::f_save(in, out);
+    if constexpr (LEVEL == 1) Ode::fj(in, out); else Ode::f_save(in, out);
   }
 }
 
 // P2: interior point i: x^, tau, u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
-template <class Ode, class D>
-__device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_double* S, int i, const LglTab* tabp) {
+template <class Ode, class D, int LEVEL = 2>
+__device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_double* S, int i, const LglTab* tabp, bool have_lam) {
   constexpr int n = D::n, m = D::m, q = D::q, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
   const lds_double* z = S + D::w_z;
@@ -178,10 +183,20 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
 #pragma unroll
   for (int k = 0; k < D::p; k++) y[q + k] = z[D::P0 + k];
 #pragma unroll
-  for (int k = 0; k < n; k++) li[k] = lam[i * n + k];
+  for (int k = 0; k < n; k++) li[k] = have_lam ? lam[i * n + k] : 0.0;
   RegIn<D> in{y, li};
-  OdeOutRes<D> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH, nullptr};
-  Ode::fjgh(in, out);
+  if constexpr (LEVEL == 1) {          // f^, J^ and g^ = J^^T lam_i (accumulated while J^ is emitted)
+    OdeOutRes<D, true> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, nullptr, nullptr, nullptr};
+    out.lamv_ = li;
+#pragma unroll
+    for (int b = 0; b < N; b++) out.gacc_[b] = 0.0;
+    Ode::fj(in, out);
+#pragma unroll
+    for (int b = 0; b < N; b++) S[D::w_Ig + i * N + b] = out.gacc_[b];
+  } else {
+    OdeOutRes<D> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH, nullptr};
+    Ode::fjgh(in, out);
+  }
 }
 
 // P3: cardinal node j: adjoint weights w_j (LGLDefects.h:369-374) ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f
@@ -375,7 +390,10 @@ __device__ inline double row16_sum(double x) {
 }
 
 // ---------------------------------------------------------------------------------------------- kernel
-template <class Ode, int SCH, bool BLOCKED, bool ASM>
+// LEVEL 2: value + Jacobian + adjoint gradient + adjoint Hessian.  LEVEL 1 (the Jacobian kinds, evalSOE / evalAUG): two ODE
+// phases (cardinal f_j, J_j; interior f^, J^, g^), no cardinal second derivatives, no Hessian products; the Hessian slots of
+// the blocks are written as zeros unless the caller says it never reads them (ASSET_HIP_KEEP_HESSIAN_SLOTS).
+template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM>
 __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using R = ResDims<D>;
@@ -447,7 +465,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
     for (int t = 0; t < NZ; t++) zv[t] = (vi[t] >= 0) ? a.X[vi[t]] : 0.0;
 #pragma unroll
-    for (int t = 0; t < NL; t++) lv[t] = (ci[t] >= 0) ? a.L[ci[t]] : 0.0;
+    for (int t = 0; t < NL; t++) lv[t] = (ci[t] >= 0 && a.L) ? a.L[ci[t]] : 0.0;
 #pragma unroll
     for (int t = 0; t < NTAB; t++)
       if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
@@ -470,20 +488,22 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   RTS();
   if (lane < gcount * CS) {            // P1
     const int g = lane / CS, j = lane - g * CS;
-    if (a.affine && D::p == 0) res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X + (a.aff_v0 + (seg0 + g) * a.aff_vs), nullptr);
-    else res_cardinal_value<Ode, D>(slots + g * SLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
+    if (a.affine && D::p == 0) res_cardinal_value<Ode, D, LEVEL>(slots + g * SLOT, j, a.X + (a.aff_v0 + (seg0 + g) * a.aff_vs), nullptr);
+    else res_cardinal_value<Ode, D, LEVEL>(slots + g * SLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
   }
   wave_lds_sync();
   RTS();
   if (lane < gcount * K) {             // P2
     const int g = lane / K, i = lane - g * K;
-    res_interior<Ode, D>(slots + g * SLOT, i, &tab);
+    res_interior<Ode, D, LEVEL>(slots + g * SLOT, i, &tab, a.L != nullptr);
   }
   wave_lds_sync();
   RTS();
-  if (lane < gcount * CS) {            // P3
-    const int g = lane / CS, j = lane - g * CS;
-    res_cardinal_second<Ode, D>(slots + g * SLOT, j, &tab);
+  if constexpr (LEVEL >= 2) {
+    if (lane < gcount * CS) {          // P3
+      const int g = lane / CS, j = lane - g * CS;
+      res_cardinal_second<Ode, D>(slots + g * SLOT, j, &tab);
+    }
   }
   RTS();
   // the per-lane record of the dense part (its loads fly while P3's LDS writes land)
@@ -642,7 +662,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     for (int i = 0; i < K; i++) {
       const double sc = (lr == N) ? ctab.E[i] : h * ctab.E[i];     // the g^ row is scaled by E_i, the H^ rows by h E_i
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) ah[i][kk] = sc * S[lc.ao[kk] + i * lc.ast[kk]];
+      for (int kk = 0; kk < KS; kk++)           // (LEVEL 1: no H^ -- its section of the slot holds nothing)
+        ah[i][kk] = (LEVEL >= 2 || lr >= N) ? sc * S[lc.ao[kk] + i * lc.ast[kk]] : 0.0;
     }
 #ifndef ASSET_RES_PRIO
 #define ASSET_RES_PRIO 1
@@ -724,8 +745,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       d4 accH[TI];                                      // tiles (ct, rt), ct <= rt
 #pragma unroll
       for (int ct = 0; ct <= rt; ct++) {                // cardinal Hessian blocks (LGLDefects.h:386-402): the initial value
-        constexpr int dummy = 0;
-        (void)dummy;
+        if constexpr (LEVEL < 2) { accH[ct] = d4{0.0, 0.0, 0.0, 0.0}; continue; }
         const int tix = rt * (rt + 1) / 2 + ct, sh = R::sh_index(tix);
 #pragma unroll
         for (int v = 0; v < 4; v++) {
@@ -744,8 +764,20 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         }
       }
       double hi = 0.0;
+      if constexpr (LEVEL < 2 && !R::JRIDE) {           // no M product to take row N from: E_i g^_i . DI_i over this lane's rows
+#pragma unroll
+        for (int i = 0; i < K; i++)
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++) {
+            const int b = 4 * kk + lk;
+            hi = fma(ctab.E[i] * ((b < N) ? S[D::w_Ig + i * N + (b < N ? b : 0)] : 0.0), dv[rt][i][kk], hi);
+          }
+        hi += __shfl_xor(hi, 16);
+        hi += __shfl_xor(hi, 32);
+      }
 #pragma unroll
       for (int i = 0; i < K; i++) {
+        if constexpr (LEVEL < 2 && !R::JRIDE) continue;
         d4 Mi = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) Mi = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i][kk], dv[rt][i][kk], Mi, 0, 0, 0);
@@ -762,10 +794,12 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
             } else if (r >= 0 && r < n) Ti[r] = Mi[v];
           }
         }
+        if constexpr (LEVEL >= 2) {
 #pragma unroll
-        for (int kk = 0; kk < KS; kk++)
+          for (int kk = 0; kk < KS; kk++)
 #pragma unroll
-          for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], Mi[kk], accH[ct], 0, 0, 0);
+            for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], Mi[kk], accH[ct], 0, 0, 0);
+        }
       }
       if constexpr (R::JRIDE) {          // J^T tile rt: entry v <-> (column 16rt + lk + 4v, defect row jr = lr = (il, rl))
         wave_lds_sync();
@@ -793,18 +827,18 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
             gs = par ? gs + ps : gs;
           }
         }
-        HT[c] = hi + gs / h;                            // (padding columns: 0 + 0)
-        if (a.AGX && (CFULL || c < IR)) a.AGX[seg * IR + c] = fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]]));
+        if constexpr (LEVEL >= 2) HT[c] = hi + gs / h;  // (padding columns: 0 + 0)
+        if (a.AGX && a.L && (CFULL || c < IR)) a.AGX[seg * IR + c] = fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]]));
       }
-      wave_lds_sync();
-      {
+      if constexpr (LEVEL >= 2) {
+        wave_lds_sync();
         const double ht = HT[16 * rt + lr];
         a2[rt] = lk == 0 ? tsA(rt) : (lk == 1 ? ht : 0.0);
         const double b2 = lk == 0 ? ht : (lk == 1 ? tsA(rt) : 0.0);
 #pragma unroll
         for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[ct], b2, accH[ct], 0, 0, 0);
       }
-      if (kkt_dst) {
+      if (kkt_dst && (LEVEL >= 2 || (!ASM && !(a.flags & 1)))) {   // (Jacobian kinds: zeros, unless the caller never reads them)
         if constexpr (ASM) {
 #pragma unroll
           for (int ct = 0; ct <= rt; ct++)
@@ -843,12 +877,12 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #undef RTSG
 }
 
-template <class Ode, int SCH, bool BLOCKED, bool ASM = false>
+template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false>
 __global__ __launch_bounds__(64, 2) void lgl_resident_kernel(EvalArgs a) {
 #if defined(ASSET_EXP_NULL)   // (experiment: the cost of the launch itself)
   if (a.nseg > 0) return;
 #endif
-  if constexpr (ResDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_resident_body<Ode, SCH, BLOCKED, ASM>(a);
+  if constexpr (ResDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM>(a);
 }
 
 }  // namespace asset_hip

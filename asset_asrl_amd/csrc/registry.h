@@ -89,9 +89,10 @@ constexpr int K_FUNC(int level, bool asmb) { return 35 + level * 2 + (asmb ? 1 :
 constexpr int K_BUNDLE(int level) { return 41 + level; }                                                         // 41..43
 constexpr int K_ADJGRAD = 44;   // value + adjoint gradient without a Jacobian (defect_adjgrad.h)
 constexpr int K_VALUE = 45;     // value only, the same kernel without the gradient parts
-constexpr int K_RES(bool asmb) { return 46 + (asmb ? 1 : 0); }   // resident single launch (defect_resident.h)
+constexpr int K_RES(bool asmb) { return 46 + (asmb ? 1 : 0); }   // resident single launch (defect_resident.h), level 2
 constexpr int K_RES_SETUP = 48;
-constexpr int K_COUNT = 49;
+constexpr int K_RES1(bool asmb) { return 49 + (asmb ? 1 : 0); }  // ... the Jacobian kinds
+constexpr int K_COUNT = 51;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -193,6 +194,12 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
   switch (level) {
     case 0: return ode_stage(0);
     case 1: {
+      static const bool no_res1 = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
+      if (m[MF_RES_GR] > 0 && !no_res1 && !skip_dense && a.lane_consts_res && t.k[K_RES1(a.kmap != nullptr)]) {
+        const int waves = cus * 8;   // resident kernel, Jacobian kinds (defect_resident.h, LEVEL 1)
+        if ((a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]))
+          return klaunch(t.k[K_RES1(a.kmap != nullptr)], dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
+      }
       static const bool no_fuse1 = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                                // tuning only
       if (m[MF_FUSED] && !no_fuse1 && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]) && t.k[K_LGL(1, 3, a.kmap != nullptr)])
         return klaunch(t.k[K_LGL(1, 3, a.kmap != nullptr)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);   // one launch
@@ -325,8 +332,10 @@ const KernelTable* lgl_static_table() {
       }
       if constexpr (D::FUSED2) r.k[K_LGL(2, 4, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 2, 4, false>);
       if constexpr (ResDims<D>::OK) {
-        r.k[K_RES(false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, false>);
-        r.k[K_RES(true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, true>);
+        r.k[K_RES(false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, false>);
+        r.k[K_RES(true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, true>);
+        r.k[K_RES1(false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, false>);
+        r.k[K_RES1(true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, true>);
         r.k[K_RES_SETUP].host = ASSET_KPTR(res_lane_setup_kernel<Ode, SCH, BLOCKED>);
       }
     }
@@ -406,8 +415,10 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
     for (int as = 0; as <= 1; as++)
       if (slot == K_WIDE(lv, as != 0)) return "asset_hip::lgl_wide_dense_kernel<" + lgl + ", " + std::to_string(lv) + ", " + tf(as != 0) + ">";
   if (slot == K_WIDE_SETUP) return "asset_hip::wide_setup_kernel<" + lgl + ">";
-  if (slot == K_RES(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", false>";
-  if (slot == K_RES(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", true>";
+  if (slot == K_RES(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, false>";
+  if (slot == K_RES(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, true>";
+  if (slot == K_RES1(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 1, false>";
+  if (slot == K_RES1(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 1, true>";
   if (slot == K_RES_SETUP) return "asset_hip::res_lane_setup_kernel<" + lgl + ">";
   if (slot == K_LANE_SETUP1) return "asset_hip::lane_setup_kernel<" + lgl + ", 1>";
   if (slot == K_LANE_SETUP2) return "asset_hip::lane_setup_kernel<" + lgl + ", 2>";

@@ -22,6 +22,7 @@ agx = torch.empty(nseg * ev.IR, dtype=torch.float64, device=dev)
 kkt = torch.empty(nseg * ev.NKKT, dtype=torch.float64, device=dev)
 ts = []
 for rep in range(6):
-    ts.append(ev.time_device(kind, X, L if kind in (1, 3, 4) else None, fx, agx if kind in (1, 3, 4) else None,
-                             kkt if kind >= 2 else None, warmup=5, iters=200))
+    k = kind & 0xFF
+    ts.append(ev.time_device(kind, X, L if k in (1, 3, 4) else None, fx, agx if k in (1, 3, 4) else None,
+                             kkt if k >= 2 else None, warmup=5, iters=200))
 print(f"{os.environ.get('ASSET_HIP_LIB', 'default')} {ode} {mode} x{nseg} kind {kind}: " + " ".join(f"{1e3 * t:.2f}" for t in ts) + " us")
