@@ -393,7 +393,9 @@ __device__ inline double row16_sum(double x) {
 // LEVEL 2: value + Jacobian + adjoint gradient + adjoint Hessian.  LEVEL 1 (the Jacobian kinds, evalSOE / evalAUG): two ODE
 // phases (cardinal f_j, J_j; interior f^, J^, g^), no cardinal second derivatives, no Hessian products; the Hessian slots of
 // the blocks are written as zeros unless the caller says it never reads them (ASSET_HIP_KEEP_HESSIAN_SLOTS).
-template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM>
+// LOOP: meshes of more than GR segments per wave (a second instantiation: the one-group form is the north-star case and
+// loses 1 us to the loop's bookkeeping).
+template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM, bool LOOP>
 __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using R = ResDims<D>;
@@ -407,16 +409,18 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   lds_double* const tabL = (lds_double*)lds;                       // weight tables, then x_AUX ... behind the slots
   lds_double* const slots = tabL + D::TABSZ;
   lds_double* const xtra = slots + GR * SLOT;
-  const int lane = int(threadIdx.x), lr = lane & 15, lk = lane >> 4;
+  const int lane0 = int(threadIdx.x);
   const LglTab& tab = *reinterpret_cast<const LglTab*>(lds);
   const LglTab& ctab = d_lgl_tab[D::TAB];                           // compile-time indices: scalar loads
 
-  // this wave's share of the mesh: contiguous, balanced (same rule as IndexingData.h:117-146); the host sizes the grid so
-  // that it is at most GR segments
+  // this wave's share of the mesh: contiguous, balanced (same rule as IndexingData.h:117-146), walked in groups of at most GR
+  // segments (equal groups: 7 segments are 4 + 3).  One group per wave up to GR segments per wave; on larger meshes the waves
+  // drift apart from group to group, so that the ODE stage of some runs under the block stores of the others.
   const int nshare = int(gridDim.x), share = int(blockIdx.x);
   const int per = a.nseg / nshare, rem = a.nseg % nshare;
-  const int seg0 = share * per + min(share, rem);
-  const int gcount = min(per + (share < rem ? 1 : 0), GR);
+  const int wg_first = share * per + min(share, rem), wg_count = per + (share < rem ? 1 : 0);
+  const int ngroups = LOOP ? (wg_count + GR - 1) / GR : (wg_count > 0 ? 1 : 0);
+  const int gbase = LOOP ? (ngroups > 0 ? wg_count / ngroups : 0) : min(wg_count, GR), gextra = (LOOP && ngroups > 0) ? wg_count % ngroups : 0;
   // (shifting segments from the younger wave of every SIMD to the older one -- 52 / 54 / 56 % to the first half of the grid --
   //  changes nothing: 35.1-35.2 us each)
   const bool young = 2 * int(blockIdx.x) >= int(gridDim.x);        // the second wave of its SIMD (workgroups are dealt breadth first)
@@ -433,6 +437,13 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #if defined(ASSET_WALLCLOCK)
   const long long wall_t0 = wall_clock64();
 #endif
+  for (int grp = 0, seg0 = wg_first; grp < ngroups; grp++) {
+  const int gcount = gbase + (grp < gextra ? 1 : 0);
+  // (the lane index is made opaque per group: what derives from it is then recomputed in every group instead of being
+  //  computed once before the loop and kept -- in scratch, there being no registers to keep it in across the ODE bodies)
+  int lane = lane0;
+  if constexpr (LOOP) asm volatile("" : "+v"(lane));
+  const int lr = lane & 15, lk = lane >> 4;
   RTS();
   // ------------------------------------------------------------------ ODE stage
   {   // P0: gather z = X[Vindex], lam = L[Cindex] into the slots -- index loads, value loads, LDS writes
@@ -510,8 +521,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   LaneRecord<LCT> lrec;
   {
     const unsigned int* rec = static_cast<const unsigned int*>(a.lane_consts_res) +
-                              size_t(blockIdx.x % ASSET_LANE_REPLICAS) * (LaneRecord<LCT>::NW * 64);
-#pragma unroll
+                              size_t((blockIdx.x + grp) % ASSET_LANE_REPLICAS) * (LaneRecord<LCT>::NW * 64);   // (reloaded per group:
+#pragma unroll                                                                                          //  the ODE bodies need the registers)
     for (int k = 0; k < LaneRecord<LCT>::NW; k++) lrec.w[k] = rec[k * 64 + lane];
   }
   const LCT& lc = lrec.lc;
@@ -861,28 +872,31 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     RTSG();
   }
   RTS();
+  seg0 += gcount;
+  wave_lds_sync();                     // (the next group's gather rewrites the slots)
+  }
 #if defined(ASSET_TIMING)
   if (blockIdx.x == 7 && lane == 0 && a.FX)
-    for (int t = 0; t + 1 < nts; t++) a.FX[size_t(seg0) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
+    for (int t = 0; t + 1 < nts; t++) a.FX[size_t(wg_first) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
 #endif
 #if defined(ASSET_WALLCLOCK)   // (tuning builds) 100 MHz wall-clock at the start and the end of every wave, left in FX
-  if (lane == 0 && a.FX && gcount > 0) {
-    a.FX[size_t(seg0) * OR + 0] = double(wall_t0);
-    a.FX[size_t(seg0) * OR + 1] = double(wall_clock64());
-    a.FX[size_t(seg0) * OR + 2] = double(__builtin_amdgcn_s_getreg(63492));   // HW_ID
-    a.FX[size_t(seg0) * OR + 3] = double(__builtin_amdgcn_s_getreg(63508));   // XCC_ID
+  if (lane == 0 && a.FX && wg_count > 0) {
+    a.FX[size_t(wg_first) * OR + 0] = double(wall_t0);
+    a.FX[size_t(wg_first) * OR + 1] = double(wall_clock64());
+    a.FX[size_t(wg_first) * OR + 2] = double(__builtin_amdgcn_s_getreg(63492));   // HW_ID
+    a.FX[size_t(wg_first) * OR + 3] = double(__builtin_amdgcn_s_getreg(63508));   // XCC_ID
   }
 #endif
 #undef RTS
 #undef RTSG
 }
 
-template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false>
+template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false, bool LOOP = false>
 __global__ __launch_bounds__(64, 2) void lgl_resident_kernel(EvalArgs a) {
 #if defined(ASSET_EXP_NULL)   // (experiment: the cost of the launch itself)
   if (a.nseg > 0) return;
 #endif
-  if constexpr (ResDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM>(a);
+  if constexpr (ResDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP>(a);
 }
 
 }  // namespace asset_hip

@@ -92,7 +92,8 @@ constexpr int K_VALUE = 45;     // value only, the same kernel without the gradi
 constexpr int K_RES(bool asmb) { return 46 + (asmb ? 1 : 0); }   // resident single launch (defect_resident.h), level 2
 constexpr int K_RES_SETUP = 48;
 constexpr int K_RES1(bool asmb) { return 49 + (asmb ? 1 : 0); }  // ... the Jacobian kinds
-constexpr int K_COUNT = 51;
+constexpr int K_RESL(int level, bool asmb) { return 51 + (level - 1) * 2 + (asmb ? 1 : 0); }   // ... looped over groups (large meshes)
+constexpr int K_COUNT = 55;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -197,8 +198,9 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
       static const bool no_res1 = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
       if (m[MF_RES_GR] > 0 && !no_res1 && !skip_dense && a.lane_consts_res && t.k[K_RES1(a.kmap != nullptr)]) {
         const int waves = cus * 8;   // resident kernel, Jacobian kinds (defect_resident.h, LEVEL 1)
-        if ((a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]))
-          return klaunch(t.k[K_RES1(a.kmap != nullptr)], dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
+        const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
+        const KRef& kr = one ? t.k[K_RES1(a.kmap != nullptr)] : t.k[K_RESL(1, a.kmap != nullptr)];
+        if (kr) return klaunch(kr, dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
       }
       static const bool no_fuse1 = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                                // tuning only
       if (m[MF_FUSED] && !no_fuse1 && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]) && t.k[K_LGL(1, 3, a.kmap != nullptr)])
@@ -210,9 +212,12 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
       // resident kernel (defect_resident.h): the ODE results stay in LDS; meshes of at most GR segments per wave
       static const bool no_res = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                              // tuning only
       if (m[MF_RES_GR] > 0 && !no_res && !skip_dense && a.lane_consts_res && t.k[K_RES(a.kmap != nullptr)]) {
-        const int waves = cus * 8;
-        if ((a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]))
-          return klaunch(t.k[K_RES(a.kmap != nullptr)], dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
+        const int waves = cus * 8;       // one group per wave up to GR segments per wave, the looped instantiation beyond
+        static const int env_max = std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS")) : 0;   // tuning only
+        const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
+        const KRef& kr = one ? t.k[K_RES(a.kmap != nullptr)] : t.k[K_RESL(2, a.kmap != nullptr)];
+        if (kr && (one || env_max <= 0 || (a.nseg + waves - 1) / waves <= env_max * int(m[MF_RES_GR])))
+          return klaunch(kr, dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
       }
       if (m[MF_FUSED]) {
         // single launch when every workgroup's share fits one group of the fused kernel (defect_kernels.h, STAGE 3)
@@ -336,6 +341,10 @@ const KernelTable* lgl_static_table() {
         r.k[K_RES(true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, true>);
         r.k[K_RES1(false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, false>);
         r.k[K_RES1(true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, true>);
+        r.k[K_RESL(2, false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, false, true>);
+        r.k[K_RESL(2, true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, true, true>);
+        r.k[K_RESL(1, false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, false, true>);
+        r.k[K_RESL(1, true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, true, true>);
         r.k[K_RES_SETUP].host = ASSET_KPTR(res_lane_setup_kernel<Ode, SCH, BLOCKED>);
       }
     }
@@ -419,6 +428,9 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
   if (slot == K_RES(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, true>";
   if (slot == K_RES1(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 1, false>";
   if (slot == K_RES1(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 1, true>";
+  for (int lv = 1; lv <= 2; lv++)
+    for (int as = 0; as <= 1; as++)
+      if (slot == K_RESL(lv, as != 0)) return "asset_hip::lgl_resident_kernel<" + lgl + ", " + std::to_string(lv) + ", " + tf(as != 0) + ", true>";
   if (slot == K_RES_SETUP) return "asset_hip::res_lane_setup_kernel<" + lgl + ">";
   if (slot == K_LANE_SETUP1) return "asset_hip::lane_setup_kernel<" + lgl + ", 1>";
   if (slot == K_LANE_SETUP2) return "asset_hip::lane_setup_kernel<" + lgl + ", 2>";
