@@ -65,6 +65,7 @@ AD2_ODE(pathcon, 2, 3, 0)
 AD2_ODE(integrand_quad2, 1, 0, 0)
 AD2_ODE(pairprod, 1, 2, 0)
 AD2_ODE(integrand_powp, 1, 2, 0)
+AD2_ODE(reentry_heating, 1, 1, 0)
 
 }  // namespace
 
@@ -96,6 +97,7 @@ GEN_DECL(pathcon)
 GEN_DECL(integrand_quad2)
 GEN_DECL(pairprod)
 GEN_DECL(integrand_powp)
+GEN_DECL(reentry_heating)
 
 extern "C" {
 
@@ -136,6 +138,7 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(integrand_quad2)
   TRY4(pairprod)
   TRY4(integrand_powp)
+  TRY4(reentry_heating)
   return -1;
 }
 
@@ -154,6 +157,7 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(integrand_quad2, 1, 0, 0, nullptr)
   TRY(pairprod, 1, 2, 0, nullptr)
   TRY(integrand_powp, 1, 2, 0, nullptr)
+  TRY(reentry_heating, 1, 1, 0, nullptr)
   return -1;
 }
 }

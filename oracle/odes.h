@@ -70,6 +70,26 @@ void pathcon(const S* y, S* f, const void*) {
   f[1] = u0 * u0 + u1 * u1 - 1.0 + t * x0 * exp(-x1);
 }
 
+// ------------------------------------------------------------------ the heating-rate bound of the shuttle re-entry problem
+// (q(h, v, alpha) - Qlimit) / Qlimit with q = qa(alpha) qr(h, v), the function the reference's full-problem test adds with
+// addUpperFuncBound("Path", QFunc(), [0, 2, 6], Qlimit, 1 / Qlimit)  (asset_asrl/test/test_FullProblems/test_Reentry.py:99-109,
+// 206; constants :14-47).  Record (1, 1, 0): one output of three inputs (h, v, alpha).  tests/kkt_harness.py defines the same
+// function in the product's expression DSL.
+template <class S>
+void reentry_heating(const S* y, S* f, const void*) {
+  const double g0 = 32.2, W = 203000.0, Lstar = 100000.0, Tstar = 60.0, Mstar = W / g0;
+  const double Vstar = Lstar / Tstar, Rhostar = Mstar / (Lstar * Lstar * Lstar);
+  const double rho0 = 0.002378 / Rhostar, h_ref = 23800.0 / Lstar;
+  const double c0 = 1.0672181, c1 = -0.19213774e-1, c2 = 0.21286289e-3, c3 = -0.10117e-5, Qlimit = 70.0;
+  const S &h = y[0], &v = y[1], &alpha = y[2];
+  const S alphadeg = (180.0 / M_PI) * alpha;
+  const S rhodim = (rho0 * Rhostar) * exp(-1.0 * h / h_ref);
+  const S vdim = v * Vstar;
+  const S qr = 17700.0 * sqrt(rhodim) * pow(0.0001 * vdim, 3.07);
+  const S qa = c0 + c1 * alphadeg + c2 * (alphadeg * alphadeg) + c3 * (alphadeg * alphadeg * alphadeg);
+  f[0] = (qa * qr - Qlimit) * (1.0 / Qlimit);
+}
+
 // ------------------------------------------------------------------ integrands (one output) for the segment quadrature
 // quad2: I(x0, x1) = x1^2 + x0 (the integrand of tests/test_gpu_function.py);  record (xv, uv, pv) = (1, 0, 0): 2 inputs.
 // powp: I(x0, x1, x2, p) = p x0^2 + sin(x1) x2 + exp(-x0 x2) / (1 + p^2): three node values and a phase parameter;
