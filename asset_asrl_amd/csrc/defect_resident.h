@@ -19,7 +19,7 @@
 // :414-506, the time rows / columns :508-511, adjgrad :512); slot order of the blocks DenseFunctionBase.h:1112-1123.
 //
 // Shapes: LGL3/5/7 (segment parameters -- ODE parameters, BlockConstant controls -- included), N + 1 <= 16, defect rows in
-// one 16-row tile (K n <= 16), not a heavy right-hand side.  Meshes of at most GR segments per wave (10 240 Reentry-LGL7 segments
+// one 16-row tile (K n <= 16; two tiles are implemented and measured slower, see ResDims::OK), not a heavy right-hand side.  Meshes of at most GR segments per wave (10 240 Reentry-LGL7 segments
 // on 256 CUs); everything else takes the kernels of defect_kernels.h.
 #pragma once
 #include "defect_kernels.h"
@@ -48,7 +48,13 @@ struct ResDims {
   static constexpr int GR_FIT = (LDS_WAVE / 8 - D::TABSZ - XTRA) / SLOT;
   static constexpr int GR = GR_FIT < 64 / CS ? GR_FIT : 64 / CS;
   static constexpr size_t lds_bytes() { return size_t(D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA) * 8; }
-  static constexpr bool OK = !D::TRAP && !D::WIDE && D::TJ == 1 && N + 1 <= 16 && Ode::NUNITS == 1 && GR >= 2 &&
+  // (two row tiles of defect rows -- TwoBody-LGL7, K n = 18 -- work and are parity-green, but with three column tiles beside
+  //  them the wave spills 650 bytes per lane: 149.5 us against 102.5 us for 10 000 segments (BlockConstant: 122 against 81) --
+  //  such shapes stay with defect_kernels.h)
+#ifndef ASSET_RES_MAX_TJ
+#define ASSET_RES_MAX_TJ 1
+#endif
+  static constexpr bool OK = !D::TRAP && !D::WIDE && D::TJ <= ASSET_RES_MAX_TJ && N + 1 <= 16 && Ode::NUNITS == 1 && GR >= 2 &&
                              D::STAGED;
   static constexpr int lkN = N & 3, vN = N >> 2;   // accumulator entry that holds row N of an M tile (the E g^ row)
   // JRIDE: the rows N+1 .. N+n of the A operand of the M product carry h E_i J^_i, so the interior part of J comes out of the
@@ -253,15 +259,18 @@ struct ResLane {
   // M product, A operand: lane (lr, lk) <-> row lr of [h E_i H^_i ; E_i g^_i ; h E_i J^_i (JRIDE)], column 4kk + lk
   int ao[KS], ast[KS];   // offset for i = 0, stride in i
   // J product, B operand: lane (lr, lk) <-> defect row jr = lr = (il, rl), row 4kk + lk of (h E_il J^_il)^T
-  int jo[KS];
-  int il, rl;            // (lanes with lr >= OR: il = 0, rl = 0 and every weight below zero)
+  // (defect rows: row tile jt, jr = 16jt + lr = (il, rl); lanes without a row: il = rl = 0 and every weight below zero)
+  static constexpr int TJ = D::TJ;
+  int jo[TJ][KS];
+  int il[TJ], rl[TJ];
   // defect row weights: sd = sum_jj tD[jj] f_jj[rl] + tE f^_il[rl];  fx = sum_jj tC[jj] z_jj[rl] + h sd
-  double tC[CS], tD[CS], tE;
-  // DC: initial value of J^T accumulator entry (ct, v), column c = 16ct + lk + 4v:
-  //   [cc == rl] C_il,j(c) + h D_il,j(c) S[dco[ct][v]] -/+ sd on the time columns
-  int dco[TI][4];
-  double dcC[QFAST ? 1 : TI][4];   // (QFAST: the node of the column is known at compile time: tC / tD of that node)
-  double dcD[QFAST ? 1 : TI][4];
+  double tC[TJ][CS], tD[TJ][CS], tE[TJ];
+  // DC: initial value of J^T accumulator entry (ct, jt, v), column c = 16ct + lk + 4v:
+  //   [cc == rl] C_il,j(c) + h D_il,j(c) S[dco[ct][jt][v]] -/+ sd on the time columns
+  // (QFAST: the node of the column is known at compile time; otherwise it is packed two bits per entry, and [cc == rl] one)
+  int dco[TI][TJ][4];
+  unsigned jnb[QFAST ? 1 : TI];
+  unsigned dbt[QFAST ? 1 : TI][TJ];
   // cardinal Hessian blocks: initial value of H accumulator entry (tile, v) of the tiles that can hold one (LGLDefects.h:386-402)
   int cho[R::NSH][4];
   // column role (lanes lk == lkN hold row N of the M tiles): column c = 16ct + lr
@@ -320,27 +329,39 @@ struct ResLane {
       ao[kk] = o;
       ast[kk] = st;
     }
-    const bool row = lr < OR;
-    il = row ? lr / n : 0;
-    rl = row ? lr - il * n : 0;
-    for (int kk = 0; kk < KS; kk++) {
-      const int b = 4 * kk + lk;
-      const int jp = (row && b < N) ? Ode::JPOS[rl * N + b] : -1;
-      jo[kk] = jp >= 0 ? D::w_IJ + il * D::NZJ + jp : ZERO;
-    }
     const LglTab& tab = d_lgl_tab[D::TAB];
-    for (int jj = 0; jj < CS; jj++) { tC[jj] = row ? tab.C[il][jj] : 0.0; tD[jj] = row ? tab.D[il][jj] : 0.0; }
-    tE = row ? tab.E[il] : 0.0;
-    for (int ct = 0; ct < TI; ct++)
-      for (int v = 0; v < 4; v++) {
-        const int c = 16 * ct + lk + 4 * v;
-        const bool ok = row && c < P0, par = row && c >= P0 && c < IR;
-        const int j = ok ? c / q : 0, cc = ok ? c - j * q : 0;
-        dco[ct][v] = ok ? jofs(j, rl, cc) : (par ? jofs(0, rl, q + (c - P0)) : ZERO);   // (parameter column: stride NZJ in j)
-        if constexpr (!QFAST) {
-          dcC[ct][v] = (ok && cc == rl) ? tab.C[il][j] : 0.0;
-          dcD[ct][v] = ok ? tab.D[il][j] : 0.0;
+    for (int jt = 0; jt < TJ; jt++) {
+      const int jr = 16 * jt + lr;
+      const bool row = jr < OR;
+      il[jt] = row ? jr / n : 0;
+      rl[jt] = row ? jr - il[jt] * n : 0;
+      for (int kk = 0; kk < KS; kk++) {
+        const int b = 4 * kk + lk;
+        const int jp = (row && b < N) ? Ode::JPOS[rl[jt] * N + b] : -1;
+        jo[jt][kk] = jp >= 0 ? D::w_IJ + il[jt] * D::NZJ + jp : ZERO;
+      }
+      for (int jj = 0; jj < CS; jj++) { tC[jt][jj] = row ? tab.C[il[jt]][jj] : 0.0; tD[jt][jj] = row ? tab.D[il[jt]][jj] : 0.0; }
+      tE[jt] = row ? tab.E[il[jt]] : 0.0;
+      for (int ct = 0; ct < TI; ct++) {
+        unsigned db = 0;
+        for (int v = 0; v < 4; v++) {
+          const int c = 16 * ct + lk + 4 * v;
+          const bool ok = row && c < P0, par = row && c >= P0 && c < IR;
+          const int j = ok ? c / q : 0, cc = ok ? c - j * q : 0;
+          dco[ct][jt][v] = ok ? jofs(j, rl[jt], cc) : (par ? jofs(0, rl[jt], q + (c - P0)) : ZERO);   // (parameter column: stride NZJ in j)
+          if (ok && cc == rl[jt]) db |= 1u << v;
         }
+        if constexpr (!QFAST) dbt[ct][jt] = db;
+      }
+    }
+    if constexpr (!QFAST)
+      for (int ct = 0; ct < TI; ct++) {
+        unsigned jb = 0;
+        for (int v = 0; v < 4; v++) {
+          const int c = 16 * ct + lk + 4 * v;
+          jb |= unsigned(c < P0 ? c / q : 0) << (2 * v);
+        }
+        jnb[ct] = jb;
       }
     for (int ct = 0; ct < TI; ct++)
       for (int rt = ct; rt < TI; rt++)
@@ -401,7 +422,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   using R = ResDims<D>;
   using LCT = ResLane<Ode, D>;
   constexpr int CS = D::CS, K = D::K, n = D::n, q = D::q, N = D::N, T = D::T, TF = D::TF;
-  constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, KS = D::KS, TI = D::TI, GR = R::GR, SLOT = R::SLOT;
+  constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, KS = D::KS, TI = D::TI, TJ = D::TJ, GR = R::GR, SLOT = R::SLOT;
   constexpr bool CFULL = (IR == IRP);
   static_assert(GR * CS <= 64, "one pass per phase");
 
@@ -538,7 +559,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   lds_double* const HT = xtra + R::x_HT;
   lds_double* const CL = xtra + R::x_CL;
   lds_double* const WL = xtra + R::x_WL;
-  constexpr int NFRAG = (D::NTH + TI) * 4;
+  constexpr int NFRAG = (D::NTH + TI * TJ) * 4;
 
   for (int g = 0; g < gcount; g++) {
     const lds_double* S = slots + g * SLOT;
@@ -546,36 +567,38 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     const double h = S[D::w_z + TF] - S[D::w_z + T];
     double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr);
     const int* const kmap_seg = ASM ? a.kmap + seg * size_t(NFRAG) * 64 + lane : nullptr;
-    int hmap[ASM ? D::NTH : 1][4], jmap[ASM ? TI : 1][4];
+    int hmap[ASM ? D::NTH : 1][4], jmap[ASM ? TI * TJ : 1][4];
     if constexpr (ASM) {                              // all of the segment's map entries, ahead of the products
 #pragma unroll
       for (int t = 0; t < D::NTH; t++)
 #pragma unroll
         for (int v = 0; v < 4; v++) hmap[t][v] = kmap_seg[(t * 4 + v) * 64];
 #pragma unroll
-      for (int t = 0; t < TI; t++)
+      for (int t = 0; t < TI * TJ; t++)
 #pragma unroll
         for (int v = 0; v < 4; v++) jmap[t][v] = kmap_seg[((D::NTH + t) * 4 + v) * 64];
     }
 
     RTSG();
-    // ---- R1: defect row (il, rl) of this lane: sd, value; the multiplier sums of the adjoint gradient
-    double sd, fxv;
-    {
+    // ---- R1: defect rows (il, rl) of this lane, one per row tile: sd, value; the multiplier sums of the adjoint gradient
+    double sd[TJ], fxv[TJ], lsd = 0.0;
+#pragma unroll
+    for (int jt = 0; jt < TJ; jt++) {
+      const int jr = 16 * jt + lr;
       double fj[CS], zj[CS];
-      const double fi = S[D::w_If + (lr < OR ? lr : 0)];   // f^_il[rl] (its weight tE is zero in the lanes without a row)
+      const double fi = S[D::w_If + (jr < OR ? jr : 0)];   // f^_il[rl] (its weight tE is zero in the lanes without a row)
 #pragma unroll
-      for (int jj = 0; jj < CS; jj++) { fj[jj] = S[D::w_Cf + jj * n + lc.rl]; zj[jj] = S[D::w_z + jj * q + lc.rl]; }
-      sd = lc.tE * fi;
-      fxv = 0.0;
+      for (int jj = 0; jj < CS; jj++) { fj[jj] = S[D::w_Cf + jj * n + lc.rl[jt]]; zj[jj] = S[D::w_z + jj * q + lc.rl[jt]]; }
+      double sdv = lc.tE[jt] * fi, fx = 0.0;
 #pragma unroll
-      for (int jj = 0; jj < CS; jj++) { sd += lc.tD[jj] * fj[jj]; fxv += lc.tC[jj] * zj[jj]; }
-      fxv += h * sd;
+      for (int jj = 0; jj < CS; jj++) { sdv += lc.tD[jt][jj] * fj[jj]; fx += lc.tC[jt][jj] * zj[jj]; }
+      sd[jt] = sdv;
+      fxv[jt] = fx + h * sdv;
+      lsd += ((jr < OR) ? S[D::w_lam + (jr < OR ? jr : 0)] : 0.0) * sdv;
     }
     int lkv = lk, lkb = lk * (IR + OR - 1) - ((lk * (lk - 1)) >> 1);   // (opaque per iteration: what is derived from them is
     asm volatile("" : "+v"(lkv), "+v"(lkb));                              //  recomputed, not kept in registers across the loop)
-    const double lamr = (lr < OR) ? S[D::w_lam + lr] : 0.0;
-    const double sls = row16_sum(lamr * sd);          // sum_(i,r) lam_(i,r) sd_(i,r), in every lane
+    const double sls = row16_sum(lsd);                // sum_(i,r) lam_(i,r) sd_(i,r), in every lane
     if (lane < CS * n) {                              // CL[j][r] = sum_i C_ij lam_(i,r), WL[j][r] = sum_i D_ij lam_(i,r)
       const int j = lane / n, r = lane - j * n;
       double cl = 0.0, wl = 0.0;
@@ -687,65 +710,79 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     else __builtin_amdgcn_s_setprio(1);
     // ---- R3: cardinal part of J (DC): the initial value of the J^T tiles; without JRIDE the interior part right away
     //      J^T = DC^T + sum_i DI_i^T (h E_i J^_i)^T, stored at once
-    d4 accJ[TI];
+    d4 accJ[TI][TJ];
 #pragma unroll
     for (int ct = 0; ct < TI; ct++)
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const int c0 = 16 * ct + 4 * v;                         // column = c0 + lk
-        double dd, cw;
-        if constexpr (LCT::QFAST) {                              // node and component of the column: (c0 + lk) / q, (c0 + lk) % q
-          const int jn = c0 / q < CS ? c0 / q : 0;
-          dd = (c0 < IR) ? lc.tD[jn] : 0.0;
-          cw = (c0 < IR && lk == lc.rl - c0 % q) ? lc.tC[jn] : 0.0;
-        } else {
-          dd = lc.dcD[ct][v];
-          cw = lc.dcC[ct][v];
-        }
-        double val = fma(h * dd, S[lc.dco[ct][v]], cw);
-        if constexpr (D::p > 0) {
-          if (c0 + 3 >= D::P0 && c0 < IR) {            // parameter columns: h sum_j D_il,j J_j[rl][q + pc]
-            const bool par = c0 + lk >= D::P0 && lc.dco[ct][v] != LCT::ZERO;   // (no entry: the zero cell, no stride)
-            const int jst = par ? D::NZJ : 0;
-            double ps = 0.0;
+      for (int jt = 0; jt < TJ; jt++)
 #pragma unroll
-            for (int jj = 0; jj < CS; jj++) ps = fma(lc.tD[jj], S[lc.dco[ct][v] + jj * jst], ps);
-            val = par ? h * ps : val;
+        for (int v = 0; v < 4; v++) {
+          const int c0 = 16 * ct + 4 * v;                         // column = c0 + lk
+          double dd, cw;
+          if constexpr (LCT::QFAST) {                              // node and component of the column: (c0 + lk) / q, (c0 + lk) % q
+            const int jn = c0 / q < CS ? c0 / q : 0;
+            dd = (c0 < IR) ? lc.tD[jt][jn] : 0.0;
+            cw = (c0 < IR && lk == lc.rl[jt] - c0 % q) ? lc.tC[jt][jn] : 0.0;
+          } else {                                                 // the node from its two bits; weights D_il,j / C_il,j by selection
+            const unsigned jn = (lc.jnb[ct] >> (2 * v)) & 3u;
+            const bool node = c0 + lk < D::P0;
+            double dsel = lc.tD[jt][0], csel = lc.tC[jt][0];
+#pragma unroll
+            for (int jj = 1; jj < CS; jj++) { dsel = (jn == unsigned(jj)) ? lc.tD[jt][jj] : dsel; csel = (jn == unsigned(jj)) ? lc.tC[jt][jj] : csel; }
+            dd = node ? dsel : 0.0;
+            cw = ((lc.dbt[ct][jt] >> v) & 1u) ? csel : 0.0;
           }
+          double val = fma(h * dd, S[lc.dco[ct][jt][v]], cw);
+          if constexpr (D::p > 0) {
+            if (c0 + 3 >= D::P0 && c0 < IR) {            // parameter columns: h sum_j D_il,j J_j[rl][q + pc]
+              const bool par = c0 + lk >= D::P0 && lc.dco[ct][jt][v] != LCT::ZERO;   // (no entry: the zero cell, no stride)
+              const int jst = par ? D::NZJ : 0;
+              double ps = 0.0;
+#pragma unroll
+              for (int jj = 0; jj < CS; jj++) ps = fma(lc.tD[jt][jj], S[lc.dco[ct][jt][v] + jj * jst], ps);
+              val = par ? h * ps : val;
+            }
+          }
+          if (c0 <= T && T < c0 + 4) val -= (lk == T - c0) ? sd[jt] : 0.0;        // DC rows -+ (sum_j D_ij f_j + E_i f^_i)
+          if (c0 <= TF && TF < c0 + 4) val += (lk == TF - c0) ? sd[jt] : 0.0;     // (LGLDefects.h:484-500)
+          accJ[ct][jt][v] = val;
         }
-        if (c0 <= T && T < c0 + 4) val -= (lk == T - c0) ? sd : 0.0;        // DC rows -+ (sum_j D_ij f_j + E_i f^_i)
-        if (c0 <= TF && TF < c0 + 4) val += (lk == TF - c0) ? sd : 0.0;     // (LGLDefects.h:484-500)
-        accJ[ct][v] = val;
-      }
-    auto store_J_tile = [&](int ct, const d4& acc) {
+    auto store_J_tile = [&](int ct, int jt, const d4& acc) {
       if (!kkt_dst) return;
       if constexpr (ASM) {
 #pragma unroll
-        for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, jmap[ct][v], acc[v]);
-      } else if (lr < OR) {
+        for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, jmap[ct * TJ + jt][v], acc[v]);
+      } else if (16 * jt + lr < OR) {
 #pragma unroll
         for (int v = 0; v < 4; v++)
-          if (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR) kkt_dst[unsigned(cbv(ct, v) + IR + lr)] = acc[v];
+          if (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR) kkt_dst[unsigned(cbv(ct, v) + IR + 16 * jt + lr)] = acc[v];
       }
     };
     if constexpr (!R::JRIDE) {
-      double bj[KS], hel = 0.0;
 #pragma unroll
-      for (int i = 0; i < K; i++) hel = (lc.il == i) ? h * ctab.E[i] : hel;
+      for (int jt = 0; jt < TJ; jt++) {
+        double bj[KS], hel = 0.0;
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) bj[kk] = hel * S[lc.jo[kk]];
+        for (int i = 0; i < K; i++) hel = (lc.il[jt] == i) ? h * ctab.E[i] : hel;
 #pragma unroll
-      for (int i = 0; i < K; i++)
+        for (int kk = 0; kk < KS; kk++) bj[kk] = hel * S[lc.jo[jt][kk]];
 #pragma unroll
-        for (int kk = 0; kk < KS; kk++) {
-          const double b = (lc.il == i) ? bj[kk] : 0.0;
+        for (int i = 0; i < K; i++) {
+          if (i * n >= 16 * jt + 16 || i * n + n <= 16 * jt) continue;      // (no defect row of interior i in this row tile)
 #pragma unroll
-          for (int ct = 0; ct < TI; ct++) accJ[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], b, accJ[ct], 0, 0, 0);
+          for (int kk = 0; kk < KS; kk++) {
+            const double b = (lc.il[jt] == i) ? bj[kk] : 0.0;
+#pragma unroll
+            for (int ct = 0; ct < TI; ct++) accJ[ct][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], b, accJ[ct][jt], 0, 0, 0);
+          }
         }
 #pragma unroll
-      for (int ct = 0; ct < TI; ct++) store_J_tile(ct, accJ[ct]);
+        for (int ct = 0; ct < TI; ct++) store_J_tile(ct, jt, accJ[ct][jt]);
+      }
     }
-    if (a.FX && lane < OR) a.FX[seg * OR + lane] = fxv;
+#pragma unroll
+    for (int jt = 0; jt < TJ; jt++)
+      if (a.FX && lk == 0 && 16 * jt + lr < OR) a.FX[seg * OR + 16 * jt + lr] = fxv[jt];
     wave_lds_sync();                                    // (every read of the sections the T buffers lie over has returned)
     RTSG();
     // ---- R4: tile column rt of H: M_i[:, rt], H(ct, rt) += DI_i[:, ct]^T M_i[:, rt]; HT and the adjoint gradient on its columns;
@@ -814,14 +851,17 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       }
       if constexpr (R::JRIDE) {          // J^T tile rt: entry v <-> (column 16rt + lk + 4v, defect row jr = lr = (il, rl))
         wave_lds_sync();
-        int tb = R::t_off(0);
 #pragma unroll
-        for (int i = 1; i < K; i++) tb = (lc.il == i) ? R::t_off(i) : tb;
-        const lds_double* const Tr = S + tb + lk * n + lc.rl;
-        d4 acc = accJ[rt];
+        for (int jt = 0; jt < TJ; jt++) {
+          int tb = R::t_off(0);
 #pragma unroll
-        for (int v = 0; v < 4; v++) acc[v] += (lr < OR) ? Tr[4 * v * n] : 0.0;
-        store_J_tile(rt, acc);
+          for (int i = 1; i < K; i++) tb = (lc.il[jt] == i) ? R::t_off(i) : tb;
+          const lds_double* const Tr = S + tb + lk * n + lc.rl[jt];
+          d4 acc = accJ[rt][jt];
+#pragma unroll
+          for (int v = 0; v < 4; v++) acc[v] += (16 * jt + lr < OR) ? Tr[4 * v * n] : 0.0;
+          store_J_tile(rt, jt, acc);
+        }
       }
       // column role (lanes lk == lkN hold row N of the M tiles): full time-partial vector HT (LGLDefects.h:403-411, 504-505)
       // and the adjoint gradient  g = J^T lam = h sum_i E_i g^_i^T DI_i + DC^T lam  (LGLDefects.h:512) of column 16rt + lr

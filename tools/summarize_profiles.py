@@ -17,8 +17,9 @@ for name in ("kernel_stats", "domain_stats"):
 
 def stage_of(kernel_name):
     """lgl_defect_kernel<Ode, CS, BLOCKED, G, LEVEL, STAGE[, ASM]>: STAGE is the sixth template argument."""
-    if "lgl_resident_kernel" in kernel_name:              # resident single launch (defect_resident.h)
-        return "resident"
+    if "lgl_resident_kernel" in kernel_name:              # resident single launch (defect_resident.h): <Ode, CS, BLOCKED, LEVEL, ASM, LOOP>
+        rargs = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
+        return "resident" if len(rargs) < 4 or rargs[3] == "2" else "secondary"
     if "lgl_wide_dense_kernel" in kernel_name:            # four-wave dense stage of the wide shapes (defect_wide.h)
         return "dense_stage"
     if "lgl_ode_units_kernel" in kernel_name:             # ODE stage of heavy right-hand sides, one wave per output unit
