@@ -144,6 +144,7 @@ class _StreamOrder:
     no-op on the same stream, a cross-stream dependency otherwise.  (c10d orders a collective after the current stream
     only.)"""
     _eval_event = None
+    _ordered = False          # set once there is an exchange to order (a receive buffer or a host-shared buffer exists)
 
     def _eval_stream(self, stream):
         import torch
@@ -153,8 +154,8 @@ class _StreamOrder:
 
     def _mark_evaluated(self, stream):
         import torch
-        if not torch.cuda.is_available() or stream is None or isinstance(stream, int):
-            return
+        if not self._ordered or not torch.cuda.is_available() or stream is None or isinstance(stream, int):
+            return                # (no exchange, nothing to order: an event record costs ~4 us per evaluation)
         if self._eval_event is None:
             self._eval_event = torch.cuda.Event()
         self._eval_event.record(stream)
@@ -223,6 +224,7 @@ class ShardedDefectEvaluator(_StreamOrder):
         self.fx, self.agx, self.kkt = self._views(self._local)
         if self.rank == dst and (self.world > 1 or always_exchange):
             self._recv = torch.empty((self.world, self.slot_doubles), dtype=torch.float64, device=device)
+        self._ordered = self.world > 1 or always_exchange
         return self
 
     def eval_device(self, what: int, X, L=None, stream=None):
@@ -251,6 +253,7 @@ class ShardedDefectEvaluator(_StreamOrder):
         ``eval_device(...); push_host(); wait_host()`` every rank's (fx, agx, kkt) blocks are in host memory;
         ``host_shard_blocks()`` returns them per shard as numpy views."""
         self._host = HostSharedBlocks(self.slot_doubles, self.rank, self.world, self.group, barrier_group, tag)
+        self._ordered = True
         return self
 
     def push_host(self):
@@ -360,6 +363,7 @@ class PhaseShardedEvaluator(_StreamOrder):
         if self.rank == dst and (self.world > 1 or always_exchange):
             self._recv = torch.empty((self.world, self.per_rank * self.nseg * self.width), dtype=torch.float64,
                                      device=device)
+        self._ordered = self.world > 1 or always_exchange
         return self
 
     def eval_device(self, what: int, X, L=None, stream=None):
