@@ -823,13 +823,20 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         hi += __shfl_xor(hi, 16);
         hi += __shfl_xor(hi, 32);
       }
+      // (all K M products first, then their uses: a result is read -- written to T_i, fed to the H products -- K - 1 products
+      //  after it was issued instead of right behind it, where the wave would sit out the 64 cycles of the instruction)
+      d4 Mi[K];
 #pragma unroll
       for (int i = 0; i < K; i++) {
         if constexpr (LEVEL < 2 && !R::JRIDE) continue;
-        d4 Mi = {0.0, 0.0, 0.0, 0.0};
+        Mi[i] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < KS; kk++) Mi = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i][kk], dv[rt][i][kk], Mi, 0, 0, 0);
-        hi += Mi[R::vN];                 // entry v: row lk + 4v of M_i (row N: E_i g^_i . DI_i), column 16rt + lr
+        for (int kk = 0; kk < KS; kk++) Mi[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i][kk], dv[rt][i][kk], Mi[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        if constexpr (LEVEL < 2 && !R::JRIDE) continue;
+        hi += Mi[i][R::vN];              // entry v: row lk + 4v of M_i (row N: E_i g^_i . DI_i), column 16rt + lr
         if constexpr (R::JRIDE) {        // rows N+1 .. N+n: J_i[r][16rt + lr] -> T_i[lr][r]
           lds_double* const Ti = (lds_double*)S + R::t_off(i) + lr * n;
 #pragma unroll
@@ -838,15 +845,15 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
             const int r = lk + 4 * v - N - 1;
             if constexpr (R::t_dummy >= 0) {
               lds_double* const Sw = (lds_double*)S;
-              Sw[(r >= 0 && r < n) ? R::t_off(i) + lr * n + r : R::t_dummy + lr] = Mi[v];
-            } else if (r >= 0 && r < n) Ti[r] = Mi[v];
+              Sw[(r >= 0 && r < n) ? R::t_off(i) + lr * n + r : R::t_dummy + lr] = Mi[i][v];
+            } else if (r >= 0 && r < n) Ti[r] = Mi[i][v];
           }
         }
         if constexpr (LEVEL >= 2) {
 #pragma unroll
           for (int kk = 0; kk < KS; kk++)
 #pragma unroll
-            for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], Mi[kk], accH[ct], 0, 0, 0);
+            for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], Mi[i][kk], accH[ct], 0, 0, 0);
         }
       }
       if constexpr (R::JRIDE) {          // J^T tile rt: entry v <-> (column 16rt + lk + 4v, defect row jr = lr = (il, rl))
