@@ -44,7 +44,14 @@ struct ResDims {
   static constexpr int x_CL = x_HT + IRP;          // [CS][n]  sum_i C_ij lam_(i,r)
   static constexpr int x_WL = x_CL + CS * n;       // [CS][n]  sum_i D_ij lam_(i,r)
   static constexpr int XTRA = x_WL + CS * n;
-  static constexpr int LDS_WAVE = 20 * 1024;       // 160 KiB / 8 waves per CU
+  // waves per SIMD the kernel is built for (registers: 512 / WPS per lane; LDS: 160 KiB / 4 WPS per wave).  Shapes with two
+  // row tiles of defect rows keep two more accumulators and a third column tile's fragments: at 256 registers they spill
+  // 650 bytes per lane (TwoBody-LGL7 x 10 000: 149.5 us), with the SIMD to themselves they do not (89.1 us; round 2's kernel 102.7)
+#ifndef ASSET_RES_WPS
+#define ASSET_RES_WPS (D::TJ > 1 ? 1 : 2)
+#endif
+  static constexpr int WPS = ASSET_RES_WPS;
+  static constexpr int LDS_WAVE = 160 * 1024 / (4 * WPS);
   static constexpr int GR_FIT = (LDS_WAVE / 8 - D::TABSZ - XTRA) / SLOT;
   static constexpr int GR = GR_FIT < 64 / CS ? GR_FIT : 64 / CS;
   static constexpr size_t lds_bytes() { return size_t(D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA) * 8; }
@@ -52,7 +59,7 @@ struct ResDims {
   //  them the wave spills 650 bytes per lane: 149.5 us against 102.5 us for 10 000 segments (BlockConstant: 122 against 81) --
   //  such shapes stay with defect_kernels.h)
 #ifndef ASSET_RES_MAX_TJ
-#define ASSET_RES_MAX_TJ 1
+#define ASSET_RES_MAX_TJ 2
 #endif
   static constexpr bool OK = !D::TRAP && !D::WIDE && D::TJ <= ASSET_RES_MAX_TJ && N + 1 <= 16 && Ode::NUNITS == 1 && GR >= 2 &&
                              D::STAGED;
@@ -927,7 +934,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     for (int t = 0; t + 1 < nts; t++) a.FX[size_t(wg_first) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
 #endif
 #if defined(ASSET_WALLCLOCK)   // (tuning builds) 100 MHz wall-clock at the start and the end of every wave, left in FX
-  if (lane == 0 && a.FX && wg_count > 0) {
+  if (lane0 == 0 && a.FX && wg_count > 0) {
     a.FX[size_t(wg_first) * OR + 0] = double(wall_t0);
     a.FX[size_t(wg_first) * OR + 1] = double(wall_clock64());
     a.FX[size_t(wg_first) * OR + 2] = double(__builtin_amdgcn_s_getreg(63492));   // HW_ID
@@ -939,7 +946,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 }
 
 template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false, bool LOOP = false>
-__global__ __launch_bounds__(64, 2) void lgl_resident_kernel(EvalArgs a) {
+__global__ __launch_bounds__(64, (ResDims<Dims<Ode, SCH, BLOCKED>>::WPS)) void lgl_resident_kernel(EvalArgs a) {
 #if defined(ASSET_EXP_NULL)   // (experiment: the cost of the launch itself)
   if (a.nseg > 0) return;
 #endif

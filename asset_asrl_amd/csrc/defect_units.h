@@ -71,8 +71,12 @@ __device__ inline void run_unit(int unit, const In& in, Out& out) {
 }
 
 // PHASE 0: gather, cardinal values (every unit's workgroup computes them for itself: the value body is light), interior
-//          points -- unit u = blockIdx.y.   PHASE 1 (second launch: it needs g^ of every unit's interior pass): cardinal
-//          second derivatives.  Single-wave workgroups at one wave per SIMD: each unit body has the whole register file
+//          points -- unit u = blockIdx.y.   PHASE 1 (second launch: it needs g^ of the interior pass): cardinal
+//          second derivatives.   (One launch for both, with g^ handed over through agent-scope stores and a counter
+//          per group of segments, was built and measured in round 3: 54.1 us against 43.5 us for 1 000 Betts-LGL5 segments --
+//          the unit bodies read their inputs through scratch memory, and the polling and the L2-bypassing traffic of the
+//          workgroups that are done stretch the interior pass of the others from 7.2 us to 9-23 us)
+//          Single-wave workgroups at one wave per SIMD: each unit body has the whole register file
 //          (512 with the accumulation registers as spill space), where seven waves in one workgroup had 256 each and
 //          spilled ~1 KB per lane to scratch (110 MB of scratch traffic per evaluation of 1 000 Betts segments).
 template <class Ode, int SCH, bool BLOCKED, int PHASE>
@@ -93,23 +97,50 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
   const int gcount = min(gp, a.nseg - seg0);
   if (gcount <= 0) return;
   glb_double* const Wg = (glb_double*)(a.work + size_t(seg0) * D::WSLOT);
+#if defined(ASSET_WALLCLOCK)   // (tuning builds, with ASSET_HIP_SKIP_DENSE: 100 MHz stamps of every workgroup, left in AGX)
+  double* const wstamp = a.AGX + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+  int wn = 0;
+#ifndef ASSET_WALLCLOCK_PHASE
+#define ASSET_WALLCLOCK_PHASE 0      // (two launches write the same cells: which one is kept)
+#endif
+#define UTS() do { if (lane == 0 && a.AGX && PHASE == ASSET_WALLCLOCK_PHASE) wstamp[wn] = double(wall_clock64()); wn++; } while (0)
+#else
+#define UTS() do {} while (0)
+#endif
+  UTS();
 
   // ---- P0: weight tables and the group's z, lam -> LDS (unit 0 of the first launch also fills the slots' copies)
   for (int e = lane; e < D::TABSZ; e += 64) tabL[e] = reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[e];
   {
     const int* vseg = a.vindex + size_t(seg0) * IR;
     const int* cseg = a.cindex + size_t(seg0) * OR;
-    for (int e = lane; e < gcount * IR; e += 64) {
-      const int g = e / IR, r = e - g * IR;
-      const double v = a.X[vseg[e]];
-      mirror[g * UD::MS + UD::m_z + r] = v;
-      if (PHASE == 0 && unit == 0) Wg[g * D::WSLOT + D::w_z + r] = v;
+    // (every index first, then every value: two trips to memory instead of two per pass)
+    constexpr int NZ = (UD::GP * IR + 63) / 64, NL = (UD::GP * OR + 63) / 64;
+    int zi[NZ], li[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) zi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : 0;
+#pragma unroll
+    for (int t = 0; t < NL; t++) li[t] = (lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : 0;
+    double zv[NZ], lv[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) zv[t] = (lane + 64 * t < gcount * IR) ? a.X[zi[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NL; t++) lv[t] = (lane + 64 * t < gcount * OR) ? a.L[li[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NZ; t++) {
+      const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
+      if (e < gcount * IR) {
+        mirror[g * UD::MS + UD::m_z + r] = zv[t];
+        if (PHASE == 0 && unit == 0) Wg[g * D::WSLOT + D::w_z + r] = zv[t];
+      }
     }
-    for (int e = lane; e < gcount * OR; e += 64) {
-      const int g = e / OR, r = e - g * OR;
-      const double v = a.L[cseg[e]];
-      mirror[g * UD::MS + UD::m_lam + r] = v;
-      if (PHASE == 0 && unit == 0) Wg[g * D::WSLOT + D::w_lam + r] = v;
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
+      if (e < gcount * OR) {
+        mirror[g * UD::MS + UD::m_lam + r] = lv[t];
+        if (PHASE == 0 && unit == 0) Wg[g * D::WSLOT + D::w_lam + r] = lv[t];
+      }
     }
     if constexpr (PHASE == 1 && !D::TRAP) {   // g^_i of the first launch (every unit contributed its share)
       for (int e = lane; e < gcount * K * N; e += 64) {
@@ -119,6 +150,7 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
     }
   }
   wave_lds_sync();
+  UTS();
   const LglTab& tab = *reinterpret_cast<const LglTab*>(lds);
 
   if constexpr (PHASE == 0) {
@@ -136,6 +168,7 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
       }
     }
     wave_lds_sync();
+    UTS();
     // ---- P2: interior points, this unit's share of [f^, J^, g^, H^]  (Trapezoidal: none)
     if constexpr (!D::TRAP) {
       if (lane < gcount * K) {
@@ -168,10 +201,15 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
         glb_double* S = Wg + g * D::WSLOT;
         OdeOutUnit<D, false, true> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH,
                                        nullptr};
+#if defined(ASSET_EXP_UNITREP)   // (experiment: the unit body again -- the second pass finds its code in the instruction cache)
+        for (int rep = 1; rep < ASSET_EXP_UNITREP; rep++) { run_unit<Ode>(unit, in, out); asm volatile("" ::: "memory"); }
+#endif
         run_unit<Ode>(unit, in, out);
       }
     }
-  } else {
+  }
+  UTS();
+  if constexpr (PHASE != 0) {
     // ---- P3: cardinal nodes with the adjoint weights w_j (LGLDefects.h:369-374), this unit's share of [J, g, H]
     if (lane < gcount * CS) {
       const int g = lane / CS, j = lane - g * CS;
@@ -193,9 +231,14 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
       glb_double* S = Wg + g * D::WSLOT;
       // (the unit that owns f emits f_j again: dropped, P1's value is the one every reader uses)
       OdeOutUnit<D, false, false> out{S + D::w_Cf + j * n, S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
+#if defined(ASSET_EXP_UNITREP)
+      for (int rep = 1; rep < ASSET_EXP_UNITREP; rep++) { run_unit<Ode>(unit, in, out); asm volatile("" ::: "memory"); }
+#endif
       run_unit<Ode>(unit, in, out);
     }
   }
+  UTS();
+#undef UTS
 }
 
 // The kernel proper (ODEs whose generated functor is cut into units; an empty kernel for the others, which a run-time

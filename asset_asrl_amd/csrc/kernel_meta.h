@@ -30,6 +30,7 @@ enum MetaField {
   MF_LANE_BYTES1, MF_LANE_BYTES2,
   MF_ADJ_GP, MF_ADJ_LDS_BYTES,   // value + adjoint gradient kernel (defect_adjgrad.h): segments per workgroup, its LDS
   MF_RES_GR, MF_RES_LDS_BYTES, MF_LANE_BYTES_RES,   // resident kernel (defect_resident.h): segments per wave (0: none), LDS, record table
+  MF_RES_WPS,                                       // ... and the waves per SIMD it is built for
   MF_COUNT
 };
 
@@ -60,7 +61,8 @@ struct LglMeta {
       Ode::NUNITS, (long long)D::TABSZ * 8, (long long)UD::MS * 8, D::CS,
       lgl_lane_table_bytes<Ode, SCH, BLOCKED>(1), lgl_lane_table_bytes<Ode, SCH, BLOCKED>(2),
       AdjDims<D>::GP, (long long)AdjDims<D>::lds_bytes(),
-      ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>()};
+      ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>(),
+      ResDims<D>::WPS};
 };
 
 template <class F>

@@ -197,7 +197,7 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
     case 1: {
       static const bool no_res1 = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
       if (m[MF_RES_GR] > 0 && !no_res1 && !skip_dense && a.lane_consts_res && t.k[K_RES1(a.kmap != nullptr)]) {
-        const int waves = cus * 8;   // resident kernel, Jacobian kinds (defect_resident.h, LEVEL 1)
+        const int waves = cus * 4 * int(m[MF_RES_WPS]);   // resident kernel, Jacobian kinds (defect_resident.h, LEVEL 1)
         const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
         const KRef& kr = one ? t.k[K_RES1(a.kmap != nullptr)] : t.k[K_RESL(1, a.kmap != nullptr)];
         if (kr) return klaunch(kr, dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
@@ -212,7 +212,7 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
       // resident kernel (defect_resident.h): the ODE results stay in LDS; meshes of at most GR segments per wave
       static const bool no_res = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                              // tuning only
       if (m[MF_RES_GR] > 0 && !no_res && !skip_dense && a.lane_consts_res && t.k[K_RES(a.kmap != nullptr)]) {
-        const int waves = cus * 8;       // one group per wave up to GR segments per wave, the looped instantiation beyond
+        const int waves = cus * 4 * int(m[MF_RES_WPS]);   // one group per wave up to GR segments per wave, the looped instantiation beyond
         static const int env_max = std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS")) : 0;   // tuning only
         const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
         const KRef& kr = one ? t.k[K_RES(a.kmap != nullptr)] : t.k[K_RESL(2, a.kmap != nullptr)];

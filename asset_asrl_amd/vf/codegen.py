@@ -99,6 +99,9 @@ def _cnum(v: float) -> str:
 SPLIT_OPS = 1500     # fjgh bodies above this many operations are emitted in two out-of-line parts
 LEVEL_ORDER = os.environ.get("ASSET_LEVEL_ORDER", "1") == "1"   # breadth-first statement schedule (experiment switch)
 UNIT_LEVEL_ORDER = os.environ.get("ASSET_UNIT_LEVEL_ORDER", "0") == "1"   # the same for the unit bodies of heavy ODEs
+UNIT_QUAL = os.environ.get("ASSET_UNIT_QUAL", "__attribute__((always_inline)) inline")   # qualifier of the unit bodies: inlined, their inputs
+#   and output pointers stay in registers (out of line they are read back from scratch memory in mid-body, and every such wait
+#   also waits for the stores before it: Betts-LGL5 x 1 000: 43.5 -> 41.6 us)
 
 TRANSCENDENTAL = ("sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "sinh", "cosh", "asin", "acos", "atan",
                   "atan2", "powr")
@@ -318,7 +321,7 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     # what they share.
     split = st["ops_fjgh"] > SPLIT_OPS
     level_order = LEVEL_ORDER and not split
-    sig = "template <class In, class Out> __host__ __device__ static {q} void {name}(const In& in, Out& out)"
+    sig = "template <class In, class Out> __host__ __device__ static {q} void {name}(const In& __restrict__ in, Out& __restrict__ out)"
 
     def outputs(level):
         """[(statement format, root)] in the order of _level_roots(d, level)."""
@@ -382,7 +385,7 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
         o.append("  }")
 
     # ---- units: a heavy fjgh body is also emitted as NUNITS bodies that partition its outputs by input direction --
-    #      unit "column k" = {J[:,k], H[i>=k,k]}, the cheap columns together with f and g -- so that the ODE stage can
+    #      unit "column k" = {J[:,k], g[k], H[i>=k,k]}, the cheap columns together with f -- so that the ODE stage can
     #      give every unit its own WAVE (csrc/defect_units.h): each evaluates all of a group's points for its share of the
     #      outputs, recomputing the forward values it needs.  Betts: 7 792 operations as one body (hundreds of spilled
     #      values) against at most ~2 300 per unit.
@@ -393,7 +396,7 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     body("fj", outputs(1))
     if units:
         for u, outs in enumerate(units):
-            body(f"fjgh_u{u}_", outs, q="__attribute__((noinline))", level_order=UNIT_LEVEL_ORDER)
+            body(f"fjgh_u{u}_", outs, q=UNIT_QUAL, level_order=UNIT_LEVEL_ORDER)
         o.append("  template <int U, class In, class Out> __host__ __device__ static inline void fjgh_unit(const In& in, Out& out) {")
         for u in range(len(units)):
             o.append(f"    {'if' if u == 0 else 'else if'} constexpr (U == {u}) fjgh_u{u}_(in, out);")
@@ -417,7 +420,8 @@ MAX_UNITS = 8
 
 
 def plan_units(d: OdeDerivatives, outs) -> List[list]:
-    """Partition the level-2 outputs ([(statement format, root)] in outputs(2) order) into units by input direction."""
+    """Partition the level-2 outputs ([(statement format, root)] in outputs(2) order) into units by input direction:
+    unit "column k" = {J[:, k], g[k], H[i >= k, k]} -- everything differentiated in direction k."""
     N, n = d.nin, d.xv
     f_outs = outs[:n]
     j_outs = outs[n:n + n * N]
@@ -435,10 +439,10 @@ def plan_units(d: OdeDerivatives, outs) -> List[list]:
 
     cols = []
     for k in range(N):
-        grp = [j_outs[r * N + k] for r in range(n)] + [h_outs[hpos[(i, k)]] for i in range(k, N)]
+        grp = [j_outs[r * N + k] for r in range(n)] + [g_outs[k]] + [h_outs[hpos[(i, k)]] for i in range(k, N)]
         cols.append((cost(grp), k, grp))
     top = max(c for c, _, _ in cols)
-    units, light = [], list(f_outs) + list(g_outs)
+    units, light = [], list(f_outs)
     for c, k, grp in sorted(cols, key=lambda t: -t[0]):
         if c >= 0.5 * top and len(units) < MAX_UNITS - 1:
             units.append(grp)
