@@ -43,12 +43,13 @@ struct ResDims {
   static constexpr int x_HT = x_AUX + 4 * K;       // [IRP] full time-partial vector (rank-2 rows)
   static constexpr int x_CL = x_HT + IRP;          // [CS][n]  sum_i C_ij lam_(i,r)
   static constexpr int x_WL = x_CL + CS * n;       // [CS][n]  sum_i D_ij lam_(i,r)
-  static constexpr int XTRA = x_WL + CS * n;
+  static constexpr int x_Z4 = x_WL + CS * n;       // four zeros (a weight row of the lanes without a defect row)
+  static constexpr int XTRA = x_Z4 + 4;
   // waves per SIMD the kernel is built for (registers: 512 / WPS per lane; LDS: 160 KiB / 4 WPS per wave).  Shapes with two
   // row tiles of defect rows keep two more accumulators and a third column tile's fragments: at 256 registers they spill
   // 650 bytes per lane (TwoBody-LGL7 x 10 000: 149.5 us), with the SIMD to themselves they do not (89.1 us; round 2's kernel 102.7)
 #ifndef ASSET_RES_WPS
-#define ASSET_RES_WPS (D::TJ > 1 ? 1 : 2)
+#define ASSET_RES_WPS ((D::TJ > 1 || Ode::NUNITS > 1) ? 1 : 2)
 #endif
   static constexpr int WPS = ASSET_RES_WPS;
   static constexpr int LDS_WAVE = 160 * 1024 / (4 * WPS);
@@ -61,8 +62,11 @@ struct ResDims {
 #ifndef ASSET_RES_MAX_TJ
 #define ASSET_RES_MAX_TJ 2
 #endif
-  static constexpr bool OK = !D::TRAP && !D::WIDE && D::TJ <= ASSET_RES_MAX_TJ && N + 1 <= 16 && Ode::NUNITS == 1 && GR >= 2 &&
-                             D::STAGED;
+  static constexpr bool DENSE_OK = !D::TRAP && !D::WIDE && D::TJ <= ASSET_RES_MAX_TJ && N + 1 <= 16 && GR >= 2 && D::STAGED;
+  static constexpr bool OK = DENSE_OK && Ode::NUNITS == 1;
+  // heavy right-hand sides (one workgroup per output unit, defect_units.h): the ODE results are in the workspace when the
+  // dense part starts -- the kernel's GIVEN form copies a group's slots from there and goes on as usual
+  static constexpr bool GIVEN_OK = DENSE_OK && Ode::NUNITS > 1;
   static constexpr int lkN = N & 3, vN = N >> 2;   // accumulator entry that holds row N of an M tile (the E g^ row)
   // JRIDE: the rows N+1 .. N+n of the A operand of the M product carry h E_i J^_i, so the interior part of J comes out of the
   // same matrix instructions (as J_i[r][c] in the lanes of column c: transposed with respect to the store order).  It is
@@ -271,7 +275,10 @@ struct ResLane {
   int jo[TJ][KS];
   int il[TJ], rl[TJ];
   // defect row weights: sd = sum_jj tD[jj] f_jj[rl] + tE f^_il[rl];  fx = sum_jj tC[jj] z_jj[rl] + h sd
-  double tC[TJ][CS], tD[TJ][CS], tE[TJ];
+  // (QFAST: in the record; otherwise rows of the weight tables in LDS, dCo / dDo: 32 registers less, and what is selected from
+  //  them per accumulator entry cannot be hoisted out of the segment loop into yet more registers)
+  double tC[QFAST ? TJ : 1][CS], tD[QFAST ? TJ : 1][CS], tE[TJ];
+  int dCo[QFAST ? 1 : TJ], dDo[QFAST ? 1 : TJ];
   // DC: initial value of J^T accumulator entry (ct, jt, v), column c = 16ct + lk + 4v:
   //   [cc == rl] C_il,j(c) + h D_il,j(c) S[dco[ct][jt][v]] -/+ sd on the time columns
   // (QFAST: the node of the column is known at compile time; otherwise it is packed two bits per entry, and [cc == rl] one)
@@ -347,7 +354,13 @@ struct ResLane {
         const int jp = (row && b < N) ? Ode::JPOS[rl[jt] * N + b] : -1;
         jo[jt][kk] = jp >= 0 ? D::w_IJ + il[jt] * D::NZJ + jp : ZERO;
       }
-      for (int jj = 0; jj < CS; jj++) { tC[jt][jj] = row ? tab.C[il[jt]][jj] : 0.0; tD[jt][jj] = row ? tab.D[il[jt]][jj] : 0.0; }
+      if constexpr (QFAST) {
+        for (int jj = 0; jj < CS; jj++) { tC[jt][jj] = row ? tab.C[il[jt]][jj] : 0.0; tD[jt][jj] = row ? tab.D[il[jt]][jj] : 0.0; }
+      } else {
+        constexpr int oC = __builtin_offsetof(LglTab, C) / 8, oD = __builtin_offsetof(LglTab, D) / 8;
+        dCo[jt] = row ? oC + 4 * il[jt] : oXT + R::x_Z4;
+        dDo[jt] = row ? oD + 4 * il[jt] : oXT + R::x_Z4;
+      }
       tE[jt] = row ? tab.E[il[jt]] : 0.0;
       for (int ct = 0; ct < TI; ct++) {
         unsigned db = 0;
@@ -393,7 +406,7 @@ struct ResLane {
 template <class Ode, int SCH, bool BLOCKED>
 __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
   using D = Dims<Ode, SCH, BLOCKED>;
-  if constexpr (ResDims<D>::OK) {
+  if constexpr (ResDims<D>::DENSE_OK) {
     using LC = ResLane<Ode, D>;
     LaneRecord<LC> r;
     for (int k = 0; k < LaneRecord<LC>::NW; k++) r.w[k] = 0u;
@@ -423,7 +436,7 @@ __device__ inline double row16_sum(double x) {
 // the blocks are written as zeros unless the caller says it never reads them (ASSET_HIP_KEEP_HESSIAN_SLOTS).
 // LOOP: meshes of more than GR segments per wave (a second instantiation: the one-group form is the north-star case and
 // loses 1 us to the loop's bookkeeping).
-template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM, bool LOOP>
+template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM, bool LOOP, bool GIVEN = false>
 __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using R = ResDims<D>;
@@ -473,6 +486,37 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   if constexpr (LOOP) asm volatile("" : "+v"(lane));
   const int lr = lane & 15, lk = lane >> 4;
   RTS();
+  if constexpr (GIVEN) {
+    // ------------------------------------------------------------------ slots from the workspace (defect_units.h wrote them)
+    constexpr int NTAB = (D::TABSZ + 63) / 64, CH = 8;
+    double tabv[NTAB];
+#pragma unroll
+    for (int t = 0; t < NTAB; t++)
+      tabv[t] = (lane + 64 * t < D::TABSZ) ? reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[lane + 64 * t] : 0.0;
+    const int total = gcount * D::WSLOTD;
+    for (int e0 = 0; e0 < total; e0 += 64 * CH) {       // CH requests in flight per lane
+      double v[CH];
+#pragma unroll
+      for (int t = 0; t < CH; t++) {
+        const int e = e0 + lane + 64 * t, g = e / D::WSLOTD, r = e - g * D::WSLOTD;
+        v[t] = (e < total) ? a.work[size_t(seg0 + g) * D::WSLOT + r] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < CH; t++) {
+        const int e = e0 + lane + 64 * t, g = e / D::WSLOTD, r = e - g * D::WSLOTD;
+        if (e < total) slots[g * SLOT + r] = v[t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NTAB; t++)
+      if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
+    if (lane < 4 * K) {
+      const int i = lane >> 2, w = lane & 3;
+      xtra[R::x_AUX + lane] = w == 0 ? 1.0 - ctab.s[i] : (w == 1 ? ctab.s[i] : (w == 3 ? 1.0 : 0.0));
+    }
+    if (lane < GR) slots[lane * SLOT + R::s_Z0] = 0.0;
+    if (lane < 4) xtra[R::x_Z4 + lane] = 0.0;
+  } else {
   // ------------------------------------------------------------------ ODE stage
   {   // P0: gather z = X[Vindex], lam = L[Cindex] into the slots -- index loads, value loads, LDS writes
     constexpr int NZ = (GR * IR + 63) / 64, NL = (GR * OR + 63) / 64, NTAB = (D::TABSZ + 63) / 64;
@@ -513,6 +557,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       xtra[R::x_AUX + lane] = w == 0 ? 1.0 - ctab.s[i] : (w == 1 ? ctab.s[i] : (w == 3 ? 1.0 : 0.0));
     }
     if (lane < GR) slots[lane * SLOT + R::s_Z0] = 0.0;
+    if (lane < 4) xtra[R::x_Z4 + lane] = 0.0;
 #pragma unroll
     for (int t = 0; t < NZ; t++) {
       const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
@@ -544,6 +589,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       res_cardinal_second<Ode, D>(slots + g * SLOT, j, &tab);
     }
   }
+  }   // (!GIVEN)
   RTS();
   // the per-lane record of the dense part (its loads fly while P3's LDS writes land)
   LaneRecord<LCT> lrec;
@@ -559,7 +605,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   RTS();
 
   // ------------------------------------------------------------------ dense part, one segment at a time
-  auto tabrow = [&](int o, int i) -> double { return tabL[o + 4 * i]; };   // row i of a [K][4] weight array (or of x_AUX)
+  auto tabrow = [&](int o, int i) -> double { return tabL[o + 4 * i]; };
+  // weights C_il,jj / D_il,jj of the lane's defect row of row tile jt (zeros without a row)
+  auto tCw = [&](int jt, int jj) -> double { if constexpr (LCT::QFAST) return lc.tC[jt][jj]; else return tabL[lc.dCo[jt] + jj]; };
+  auto tDw = [&](int jt, int jj) -> double { if constexpr (LCT::QFAST) return lc.tD[jt][jj]; else return tabL[lc.dDo[jt] + jj]; };   // row i of a [K][4] weight array (or of x_AUX)
   // -1 on column T, +1 on column TF of the lane's column 16t + lr: the direction d = e_TF - e_T of the rank-2 update and the
   // sign of the time-column terms
   auto tsA = [&](int t) -> double { return (16 * t + lr == T) ? -1.0 : ((16 * t + lr == TF) ? 1.0 : 0.0); };
@@ -598,7 +647,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       for (int jj = 0; jj < CS; jj++) { fj[jj] = S[D::w_Cf + jj * n + lc.rl[jt]]; zj[jj] = S[D::w_z + jj * q + lc.rl[jt]]; }
       double sdv = lc.tE[jt] * fi, fx = 0.0;
 #pragma unroll
-      for (int jj = 0; jj < CS; jj++) { sdv += lc.tD[jt][jj] * fj[jj]; fx += lc.tC[jt][jj] * zj[jj]; }
+      for (int jj = 0; jj < CS; jj++) { sdv += tDw(jt, jj) * fj[jj]; fx += tCw(jt, jj) * zj[jj]; }
       sd[jt] = sdv;
       fxv[jt] = fx + h * sdv;
       lsd += ((jr < OR) ? S[D::w_lam + (jr < OR ? jr : 0)] : 0.0) * sdv;
@@ -717,11 +766,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     else __builtin_amdgcn_s_setprio(1);
     // ---- R3: cardinal part of J (DC): the initial value of the J^T tiles; without JRIDE the interior part right away
     //      J^T = DC^T + sum_i DI_i^T (h E_i J^_i)^T, stored at once
-    d4 accJ[TI][TJ];
-#pragma unroll
-    for (int ct = 0; ct < TI; ct++)
-#pragma unroll
-      for (int jt = 0; jt < TJ; jt++)
+    auto dc_tile = [&](int ct, int jt) -> d4 {
+      d4 r;
 #pragma unroll
         for (int v = 0; v < 4; v++) {
           const int c0 = 16 * ct + 4 * v;                         // column = c0 + lk
@@ -731,13 +777,11 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
             dd = (c0 < IR) ? lc.tD[jt][jn] : 0.0;
             cw = (c0 < IR && lk == lc.rl[jt] - c0 % q) ? lc.tC[jt][jn] : 0.0;
           } else {                                                 // the node from its two bits; weights D_il,j / C_il,j by selection
-            const unsigned jn = (lc.jnb[ct] >> (2 * v)) & 3u;
+            const int jn = int((lc.jnb[ct] >> (2 * v)) & 3u);
+            constexpr int oZ4 = D::TABSZ + GR * SLOT + R::x_Z4;
             const bool node = c0 + lk < D::P0;
-            double dsel = lc.tD[jt][0], csel = lc.tC[jt][0];
-#pragma unroll
-            for (int jj = 1; jj < CS; jj++) { dsel = (jn == unsigned(jj)) ? lc.tD[jt][jj] : dsel; csel = (jn == unsigned(jj)) ? lc.tC[jt][jj] : csel; }
-            dd = node ? dsel : 0.0;
-            cw = ((lc.dbt[ct][jt] >> v) & 1u) ? csel : 0.0;
+            dd = tabL[node ? lc.dDo[jt] + jn : oZ4];
+            cw = tabL[((lc.dbt[ct][jt] >> v) & 1u) ? lc.dCo[jt] + jn : oZ4];
           }
           double val = fma(h * dd, S[lc.dco[ct][jt][v]], cw);
           if constexpr (D::p > 0) {
@@ -746,14 +790,23 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
               const int jst = par ? D::NZJ : 0;
               double ps = 0.0;
 #pragma unroll
-              for (int jj = 0; jj < CS; jj++) ps = fma(lc.tD[jt][jj], S[lc.dco[ct][jt][v] + jj * jst], ps);
+              for (int jj = 0; jj < CS; jj++) ps = fma(tDw(jt, jj), S[lc.dco[ct][jt][v] + jj * jst], ps);
               val = par ? h * ps : val;
             }
           }
           if (c0 <= T && T < c0 + 4) val -= (lk == T - c0) ? sd[jt] : 0.0;        // DC rows -+ (sum_j D_ij f_j + E_i f^_i)
           if (c0 <= TF && TF < c0 + 4) val += (lk == TF - c0) ? sd[jt] : 0.0;     // (LGLDefects.h:484-500)
-          accJ[ct][jt][v] = val;
+          r[v] = val;
         }
+      return r;
+    };
+    d4 accJ[TI][TJ];
+    if constexpr (R::JRIDE) {                           // (read now: the T buffers of R4 lie over the CJ section)
+#pragma unroll
+      for (int ct = 0; ct < TI; ct++)
+#pragma unroll
+        for (int jt = 0; jt < TJ; jt++) accJ[ct][jt] = dc_tile(ct, jt);
+    }
     auto store_J_tile = [&](int ct, int jt, const d4& acc) {
       if (!kkt_dst) return;
       if constexpr (ASM) {
@@ -769,6 +822,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
       for (int jt = 0; jt < TJ; jt++) {
         double bj[KS], hel = 0.0;
+#pragma unroll
+        for (int ct = 0; ct < TI; ct++) accJ[ct][jt] = dc_tile(ct, jt);     // (one row tile at a time: TI accumulators live, not TI TJ)
 #pragma unroll
         for (int i = 0; i < K; i++) hel = (lc.il[jt] == i) ? h * ctab.E[i] : hel;
 #pragma unroll
@@ -945,12 +1000,13 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #undef RTSG
 }
 
-template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false, bool LOOP = false>
+template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false, bool LOOP = false, bool GIVEN = false>
 __global__ __launch_bounds__(64, (ResDims<Dims<Ode, SCH, BLOCKED>>::WPS)) void lgl_resident_kernel(EvalArgs a) {
 #if defined(ASSET_EXP_NULL)   // (experiment: the cost of the launch itself)
   if (a.nseg > 0) return;
 #endif
-  if constexpr (ResDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP>(a);
+  using R = ResDims<Dims<Ode, SCH, BLOCKED>>;
+  if constexpr (GIVEN ? R::GIVEN_OK : R::OK) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN>(a);
 }
 
 }  // namespace asset_hip

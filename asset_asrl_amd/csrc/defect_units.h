@@ -110,22 +110,35 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
   UTS();
 
   // ---- P0: weight tables and the group's z, lam -> LDS (unit 0 of the first launch also fills the slots' copies)
-  for (int e = lane; e < D::TABSZ; e += 64) tabL[e] = reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[e];
+  constexpr int NTAB = (D::TABSZ + 63) / 64;
+  double tabv[NTAB];                    // (requested here, written behind the other requests)
+#pragma unroll
+  for (int t = 0; t < NTAB; t++) tabv[t] = (lane + 64 * t < D::TABSZ) ? reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[lane + 64 * t] : 0.0;
   {
     const int* vseg = a.vindex + size_t(seg0) * IR;
     const int* cseg = a.cindex + size_t(seg0) * OR;
     // (every index first, then every value: two trips to memory instead of two per pass)
     constexpr int NZ = (UD::GP * IR + 63) / 64, NL = (UD::GP * OR + 63) / 64;
     int zi[NZ], li[NL];
+    if (a.affine) {                     // index rows that are runs (EvalArgs::affine): the addresses without the tables
 #pragma unroll
-    for (int t = 0; t < NZ; t++) zi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : 0;
+      for (int t = 0; t < NZ; t++) { const int e = lane + 64 * t, g = e / IR; zi[t] = (e < gcount * IR) ? a.aff_v0 + (seg0 + g) * a.aff_vs + (e - g * IR) : 0; }
 #pragma unroll
-    for (int t = 0; t < NL; t++) li[t] = (lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : 0;
+      for (int t = 0; t < NL; t++) { const int e = lane + 64 * t, g = e / OR; li[t] = (e < gcount * OR) ? a.aff_c0 + (seg0 + g) * a.aff_cs + (e - g * OR) : 0; }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NZ; t++) zi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : 0;
+#pragma unroll
+      for (int t = 0; t < NL; t++) li[t] = (lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : 0;
+    }
     double zv[NZ], lv[NL];
 #pragma unroll
     for (int t = 0; t < NZ; t++) zv[t] = (lane + 64 * t < gcount * IR) ? a.X[zi[t]] : 0.0;
 #pragma unroll
     for (int t = 0; t < NL; t++) lv[t] = (lane + 64 * t < gcount * OR) ? a.L[li[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NTAB; t++)
+      if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
 #pragma unroll
     for (int t = 0; t < NZ; t++) {
       const int e = lane + 64 * t, g = e / IR, r = e - g * IR;

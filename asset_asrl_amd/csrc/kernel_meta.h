@@ -31,6 +31,7 @@ enum MetaField {
   MF_ADJ_GP, MF_ADJ_LDS_BYTES,   // value + adjoint gradient kernel (defect_adjgrad.h): segments per workgroup, its LDS
   MF_RES_GR, MF_RES_LDS_BYTES, MF_LANE_BYTES_RES,   // resident kernel (defect_resident.h): segments per wave (0: none), LDS, record table
   MF_RES_WPS,                                       // ... and the waves per SIMD it is built for
+  MF_RESD_GR,                                       // ... its dense part alone behind the unit kernels of a heavy ODE (0: none)
   MF_COUNT
 };
 
@@ -45,7 +46,7 @@ constexpr long long lgl_lane_table_bytes(int level) {
 template <class Ode, int SCH, bool BLOCKED>
 constexpr long long res_lane_table_bytes() {
   using D = Dims<Ode, SCH, BLOCKED>;
-  if constexpr (ResDims<D>::OK) return (long long)sizeof(ResLane<Ode, D>) * 64;
+  if constexpr (ResDims<D>::DENSE_OK) return (long long)sizeof(ResLane<Ode, D>) * 64;
   else return 0;
 }
 
@@ -62,7 +63,7 @@ struct LglMeta {
       lgl_lane_table_bytes<Ode, SCH, BLOCKED>(1), lgl_lane_table_bytes<Ode, SCH, BLOCKED>(2),
       AdjDims<D>::GP, (long long)AdjDims<D>::lds_bytes(),
       ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>(),
-      ResDims<D>::WPS};
+      ResDims<D>::WPS, ResDims<D>::GIVEN_OK ? ResDims<D>::GR : 0};
 };
 
 template <class F>

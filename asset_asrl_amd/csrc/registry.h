@@ -93,7 +93,8 @@ constexpr int K_RES(bool asmb) { return 46 + (asmb ? 1 : 0); }   // resident sin
 constexpr int K_RES_SETUP = 48;
 constexpr int K_RES1(bool asmb) { return 49 + (asmb ? 1 : 0); }  // ... the Jacobian kinds
 constexpr int K_RESL(int level, bool asmb) { return 51 + (level - 1) * 2 + (asmb ? 1 : 0); }   // ... looped over groups (large meshes)
-constexpr int K_COUNT = 55;
+constexpr int K_RESD(bool asmb) { return 55 + (asmb ? 1 : 0); }   // ... its dense part alone, slots from the workspace (heavy ODEs)
+constexpr int K_COUNT = 57;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -253,6 +254,11 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         return e;
       }
       if (skip_dense) return hipSuccess;
+      static const bool no_resd = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
+      if (m[MF_RESD_GR] > 0 && !no_resd && a.lane_consts_res && t.k[K_RESD(a.kmap != nullptr)]) {
+        const int waves = cus * 4 * int(m[MF_RES_WPS]);   // dense part of the resident kernel over the slots the units wrote
+        return klaunch(t.k[K_RESD(a.kmap != nullptr)], dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
+      }
       return dense_stage(2);
     }
   }
@@ -347,6 +353,11 @@ const KernelTable* lgl_static_table() {
         r.k[K_RESL(1, true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, true, true>);
         r.k[K_RES_SETUP].host = ASSET_KPTR(res_lane_setup_kernel<Ode, SCH, BLOCKED>);
       }
+      if constexpr (ResDims<D>::GIVEN_OK) {
+        r.k[K_RESD(false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, false, true, true>);
+        r.k[K_RESD(true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, true, true, true>);
+        r.k[K_RES_SETUP].host = ASSET_KPTR(res_lane_setup_kernel<Ode, SCH, BLOCKED>);
+      }
     }
     if constexpr (Ode::NUNITS > 1) {
       r.k[K_UNITS0].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 0>);
@@ -431,6 +442,8 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
   for (int lv = 1; lv <= 2; lv++)
     for (int as = 0; as <= 1; as++)
       if (slot == K_RESL(lv, as != 0)) return "asset_hip::lgl_resident_kernel<" + lgl + ", " + std::to_string(lv) + ", " + tf(as != 0) + ", true>";
+  if (slot == K_RESD(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, false, true, true>";
+  if (slot == K_RESD(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, true, true, true>";
   if (slot == K_RES_SETUP) return "asset_hip::res_lane_setup_kernel<" + lgl + ">";
   if (slot == K_LANE_SETUP1) return "asset_hip::lane_setup_kernel<" + lgl + ", 1>";
   if (slot == K_LANE_SETUP2) return "asset_hip::lane_setup_kernel<" + lgl + ", 2>";
