@@ -516,7 +516,10 @@ static int fill_args(asset_hip_defect_t h, int what, const double* dX, const dou
   what &= 0xff;
   if ((opts & ~ASSET_HIP_KEEP_HESSIAN_SLOTS) || (opts && what != ASSET_HIP_JAC && what != ASSET_HIP_JAC_ADJGRAD))
     return fail(ASSET_HIP_EINVAL, "ASSET_HIP_KEEP_HESSIAN_SLOTS goes with ASSET_HIP_JAC / ASSET_HIP_JAC_ADJGRAD only");
-  a.flags = (opts & ASSET_HIP_KEEP_HESSIAN_SLOTS) ? 1 : 0;
+  // (honoured while the phase's blocks stay in the Infinity Cache; see include/asset_hip.h)
+  // (wide shapes -- IR >= 64 -- skip whole lines: it pays at every size there)
+  const bool keep_pays = h->ke->ir >= 64 || size_t(h->nseg) * size_t(h->ke->nkkt) * sizeof(double) <= (size_t(192) << 20);
+  a.flags = ((opts & ASSET_HIP_KEEP_HESSIAN_SLOTS) && keep_pays) ? 1 : 0;
   if (!dX) return fail(ASSET_HIP_EINVAL, "X is null");
   const bool needs_l = (what == ASSET_HIP_CON_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD_HESS);
   if (needs_l && !dL) return fail(ASSET_HIP_EINVAL, "L is null for an evaluation kind that contracts with multipliers");

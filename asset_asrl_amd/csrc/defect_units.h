@@ -52,6 +52,22 @@ struct OdeOutUnit {
   }
 };
 
+// Jacobian kinds (evalSOE / evalAUG): f and the unit's columns of J; g^ = J^^T lam accumulated per owned column while the
+// column is emitted (the bodies are inlined: the accumulators are registers)
+template <class D>
+struct OdeOutUnitJ {
+  glb_double* f_;        // null: dropped
+  glb_double* J_;
+  const double* lam_;    // null: no g^
+  double gacc_[D::N];
+  __device__ void f(int k, double v) { if (f_) f_[k] = v; }
+  __device__ void J(int k, int i, double v) {
+    const int c = D::ode_t::JPOS[k * D::N + i];
+    if (c >= 0) J_[c] = v;
+    if (lam_) gacc_[i] = fma(lam_[k], v, gacc_[i]);
+  }
+};
+
 template <class D, bool SLOT>
 struct OdeOutValue {   // cardinal values: mirror (the interior points read them) and, from one unit, the slot (the dense stage does)
   lds_double* fm_;
@@ -61,6 +77,14 @@ struct OdeOutValue {   // cardinal values: mirror (the interior points read them
     if constexpr (SLOT) f_[k] = v;
   }
 };
+
+template <class Ode, class In, class Out, int U = 0>
+__device__ inline void run_unit_j(int unit, const In& in, Out& out) {
+  if constexpr (U < Ode::NUNITS) {
+    if (unit == U) Ode::template fj_unit<U>(in, out);
+    else run_unit_j<Ode, In, Out, U + 1>(unit, in, out);
+  }
+}
 
 template <class Ode, class In, class Out, int U = 0>
 __device__ inline void run_unit(int unit, const In& in, Out& out) {
@@ -135,7 +159,7 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
 #pragma unroll
     for (int t = 0; t < NZ; t++) zv[t] = (lane + 64 * t < gcount * IR) ? a.X[zi[t]] : 0.0;
 #pragma unroll
-    for (int t = 0; t < NL; t++) lv[t] = (lane + 64 * t < gcount * OR) ? a.L[li[t]] : 0.0;
+    for (int t = 0; t < NL; t++) lv[t] = (lane + 64 * t < gcount * OR && a.L) ? a.L[li[t]] : 0.0;
 #pragma unroll
     for (int t = 0; t < NTAB; t++)
       if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
@@ -144,7 +168,7 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
       const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
       if (e < gcount * IR) {
         mirror[g * UD::MS + UD::m_z + r] = zv[t];
-        if (PHASE == 0 && unit == 0) Wg[g * D::WSLOT + D::w_z + r] = zv[t];
+        if ((PHASE == 0 || PHASE == 3) && unit == 0) Wg[g * D::WSLOT + D::w_z + r] = zv[t];
       }
     }
 #pragma unroll
@@ -152,7 +176,7 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
       const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
       if (e < gcount * OR) {
         mirror[g * UD::MS + UD::m_lam + r] = lv[t];
-        if (PHASE == 0 && unit == 0) Wg[g * D::WSLOT + D::w_lam + r] = lv[t];
+        if ((PHASE == 0 || PHASE == 3) && unit == 0) Wg[g * D::WSLOT + D::w_lam + r] = lv[t];
       }
     }
     if constexpr (PHASE == 1 && !D::TRAP) {   // g^_i of the first launch (every unit contributed its share)
@@ -166,7 +190,7 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
   UTS();
   const LglTab& tab = *reinterpret_cast<const LglTab*>(lds);
 
-  if constexpr (PHASE == 0) {
+  if constexpr (PHASE == 0 || PHASE == 3) {
     // ---- P1: cardinal values f_j -> mirror (this unit's own copy); unit 0 writes the slots
     if (lane < gcount * CS) {
       const int g = lane / CS, j = lane - g * CS;
@@ -212,17 +236,37 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
         for (int k = 0; k < n; k++) li[k] = M[UD::m_lam + i * n + k];
         RegIn<D> in{y, li};
         glb_double* S = Wg + g * D::WSLOT;
+        if constexpr (PHASE == 3) {       // Jacobian kinds: f^ (from the unit that holds f), this unit's columns of J^ and of g^ = J^^T lam
+          OdeOutUnitJ<D> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, li, {}};
+#pragma unroll
+          for (int b = 0; b < N; b++) out.gacc_[b] = 0.0;
+          run_unit_j<Ode>(unit, in, out);
+          const unsigned own = Ode::UNIT_COLS[unit];
+#pragma unroll
+          for (int b = 0; b < N; b++)
+            if ((own >> b) & 1u) S[D::w_Ig + i * N + b] = out.gacc_[b];
+        } else {
         OdeOutUnit<D, false, true> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH,
                                        nullptr};
 #if defined(ASSET_EXP_UNITREP)   // (experiment: the unit body again -- the second pass finds its code in the instruction cache)
         for (int rep = 1; rep < ASSET_EXP_UNITREP; rep++) { run_unit<Ode>(unit, in, out); asm volatile("" ::: "memory"); }
 #endif
         run_unit<Ode>(unit, in, out);
+        }
       }
     }
   }
+  if constexpr (PHASE == 3) {
+    // ---- cardinal nodes, Jacobian kinds: this unit's columns of J_j (f_j is P1's)
+    if (lane < gcount * CS) {
+      const int g = lane / CS, j = lane - g * CS;
+      CardIn<D, const lds_double*> in{mirror + g * UD::MS + UD::m_z, nullptr, j, nullptr};
+      OdeOutUnitJ<D> out{nullptr, Wg + g * D::WSLOT + D::w_CJ + j * D::NZJ, nullptr, {}};
+      run_unit_j<Ode>(unit, in, out);
+    }
+  }
   UTS();
-  if constexpr (PHASE != 0) {
+  if constexpr (PHASE == 1) {
     // ---- P3: cardinal nodes with the adjoint weights w_j (LGLDefects.h:369-374), this unit's share of [J, g, H]
     if (lane < gcount * CS) {
       const int g = lane / CS, j = lane - g * CS;

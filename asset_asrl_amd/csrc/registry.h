@@ -94,7 +94,8 @@ constexpr int K_RES_SETUP = 48;
 constexpr int K_RES1(bool asmb) { return 49 + (asmb ? 1 : 0); }  // ... the Jacobian kinds
 constexpr int K_RESL(int level, bool asmb) { return 51 + (level - 1) * 2 + (asmb ? 1 : 0); }   // ... looped over groups (large meshes)
 constexpr int K_RESD(bool asmb) { return 55 + (asmb ? 1 : 0); }   // ... its dense part alone, slots from the workspace (heavy ODEs)
-constexpr int K_COUNT = 57;
+constexpr int K_UNITSJ = 57;   // heavy right-hand sides, Jacobian kinds: the unit kernel of the ODE stage (defect_units.h, PHASE 3)
+constexpr int K_COUNT = 58;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -206,7 +207,21 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
       static const bool no_fuse1 = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                                // tuning only
       if (m[MF_FUSED] && !no_fuse1 && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]) && t.k[K_LGL(1, 3, a.kmap != nullptr)])
         return klaunch(t.k[K_LGL(1, 3, a.kmap != nullptr)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);   // one launch
-      if ((e = ode_stage(1)) != hipSuccess || skip_dense) return e;
+      static const bool no_units1 = std::getenv("ASSET_HIP_NO_UNITS") != nullptr;                              // tuning only
+      if (m[MF_NUNITS] > 1 && !no_units1 && t.k[K_UNITSJ] && a.nseg * int(m[MF_CS]) <= 64 * cus) {
+        // heavy right-hand side: one wave per output unit (defect_units.h, PHASE 3), one launch -- while the mesh leaves SIMDs
+        // idle: the units recompute what they share, and from ~16 cardinal points per SIMD on the one-body-per-lane stage
+        // is the faster one (Betts-LGL5: 1 000 segments 21.5 against 48.1 us, 5 000: 48.8 / 53.8, 10 000: 85.0 / 72.7)
+        const int nunits = int(m[MF_NUNITS]), gpmax = 64 / int(m[MF_CS]);
+        int gp = (a.nseg * nunits + 4 * cus - 1) / (4 * cus);
+        gp = gp < 1 ? 1 : (gp > gpmax ? gpmax : gp);
+        const size_t bytes_units = size_t(m[MF_UNITS_BASE_BYTES]) + size_t(gp) * size_t(m[MF_UNITS_SLOT_BYTES]);
+        void* uargs[] = {&args, &gp};
+        if ((e = klaunch(t.k[K_UNITSJ], dim3((a.nseg + gp - 1) / gp, nunits), dim3(64), bytes_units, st, uargs)) != hipSuccess) return e;
+      } else if ((e = ode_stage(1)) != hipSuccess) {
+        return e;
+      }
+      if (skip_dense) return hipSuccess;
       return dense_stage(1);
     }
     case 2: {
@@ -362,6 +377,7 @@ const KernelTable* lgl_static_table() {
     if constexpr (Ode::NUNITS > 1) {
       r.k[K_UNITS0].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 0>);
       r.k[K_UNITS1].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 1>);
+      r.k[K_UNITSJ].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 3>);
     }
     r.k[K_ADJGRAD].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED, true>);
     r.k[K_VALUE].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED, false>);
@@ -449,6 +465,7 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
   if (slot == K_LANE_SETUP2) return "asset_hip::lane_setup_kernel<" + lgl + ", 2>";
   if (slot == K_UNITS0) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 0>";
   if (slot == K_UNITS1) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 1>";
+  if (slot == K_UNITSJ) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 3>";
   if (slot == K_ADJGRAD) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ", true>";
   if (slot == K_VALUE) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ", false>";
   if (slot == K_MESH_YVEC) return "asset_hip::mesh_yvec_kernel<" + lgl + ">";

@@ -401,6 +401,26 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
         for u in range(len(units)):
             o.append(f"    {'if' if u == 0 else 'else if'} constexpr (U == {u}) fjgh_u{u}_(in, out);")
         o.append("  }")
+        # the Jacobian kinds (evalSOE / evalAUG) use the same partition: unit u emits f (if it holds it) and its columns of J;
+        # UNIT_COLS[u] = the input directions it owns (every direction belongs to one unit: the one without a heavy column of
+        # its own goes to the unit that holds f)
+        f_fmts = {fmt for fmt, _ in outputs(0)}
+        j_fmt = {outputs(1)[n + k * N + i][0]: (k, i) for k in range(n) for i in range(N)}
+        masks, owned = [], set()
+        for u, outs in enumerate(units):
+            l1 = [(fmt, r) for fmt, r in outs if fmt in f_fmts or fmt in j_fmt]
+            cols = {j_fmt[fmt][1] for fmt, _ in l1 if fmt in j_fmt}
+            masks.append(cols)
+            owned |= cols
+            body(f"fj_u{u}_", l1, q=UNIT_QUAL, level_order=UNIT_LEVEL_ORDER)
+        f_unit = next(u for u, outs in enumerate(units) if any(fmt in f_fmts for fmt, _ in outs))
+        masks[f_unit] |= set(range(N)) - owned
+        o.append("  template <int U, class In, class Out> __host__ __device__ static inline void fj_unit(const In& in, Out& out) {")
+        for u in range(len(units)):
+            o.append(f"    {'if' if u == 0 else 'else if'} constexpr (U == {u}) fj_u{u}_(in, out);")
+        o.append("  }")
+        o.append(f"  static constexpr unsigned UNIT_COLS[{len(units)}] = {{" + ", ".join(str(sum(1 << c for c in m)) + "u" for m in masks) + "};")
+        o.append(f"  static constexpr int F_UNIT = {f_unit};")
     if split:
         two_parts("fjgh", False)
     else:

@@ -53,8 +53,11 @@ enum {
   ASSET_HIP_JAC_ADJGRAD_HESS = 4
 };
 
-/* May be OR-ed into ASSET_HIP_JAC / ASSET_HIP_JAC_ADJGRAD: the Hessian slots of the KKT blocks are left untouched instead of
- * being written as zeros.  The reference's Jacobian-only fill (DenseFunctionBase.h:1468-1523 KKTFillJac, used by evalSOE /
+/* May be OR-ed into ASSET_HIP_JAC / ASSET_HIP_JAC_ADJGRAD: the caller never reads the Hessian slots of the KKT blocks, so they
+ * need not be written -- afterwards they hold either what they held before or zeros (a permission, not a promise: while the
+ * blocks of a phase fit the 256 MB of Infinity Cache, or its block columns are long -- 64 inputs or more --, the kernels skip
+ * the slots; beyond that, scattered partial-line stores are slower than writing the whole block -- 100 000 Reentry-LGL7
+ * segments: 335 us skipped, 251 us written -- and the zeros are written).  The reference's Jacobian-only fill (DenseFunctionBase.h:1468-1523 KKTFillJac, used by evalSOE /
  * evalAUG) steps over those slots without reading them, so a caller that scatters with it saves 44 MB of stores per
  * evaluation of a 10 000-segment LGL7 phase.  The block kinds of the LGL / Trapezoidal defects honour it; plain functions
  * (whole blocks are copied out of LDS) and the assembled kinds (no blocks) ignore it. */

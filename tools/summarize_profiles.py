@@ -22,8 +22,9 @@ def stage_of(kernel_name):
         return "resident" if len(rargs) < 4 or rargs[3] == "2" else "secondary"
     if "lgl_wide_dense_kernel" in kernel_name:            # four-wave dense stage of the wide shapes (defect_wide.h)
         return "dense_stage"
-    if "lgl_ode_units_kernel" in kernel_name:             # ODE stage of heavy right-hand sides, one wave per output unit
-        return "ode_units"
+    if "lgl_ode_units_kernel" in kernel_name:             # ODE stage of heavy right-hand sides, one wave per output unit:
+        uargs = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]   # <Ode, CS, BLOCKED, PHASE>
+        return "ode_units" + (uargs[3] if len(uargs) >= 4 else "")     # two launches per evaluation
     args = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
     if len(args) >= 6 and args[4] != "2":                 # derivative level 0 / 1: the secondary kinds bench.py also times
         return "secondary"
@@ -49,7 +50,7 @@ def counters(sub):
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 per_kernel, total = {}, 0.0
-for st in ("resident", "fused", "fused2", "ode_units", "ode_stage", "dense_stage"):
+for st in ("resident", "fused", "fused2", "ode_units0", "ode_units1", "ode_stage", "dense_stage"):
     if st not in fetch and st not in write:
         continue
     f_kb = fetch.get(st, {}).get("FETCH_SIZE", 0.0)
