@@ -985,7 +985,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   wave_lds_sync();                     // (the next group's gather rewrites the slots)
   }
 #if defined(ASSET_TIMING)
-  if (blockIdx.x == 7 && lane == 0 && a.FX)
+  if (blockIdx.x == 7 && lane0 == 0 && a.FX)
     for (int t = 0; t + 1 < nts; t++) a.FX[size_t(wg_first) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
 #endif
 #if defined(ASSET_WALLCLOCK)   // (tuning builds) 100 MHz wall-clock at the start and the end of every wave, left in FX

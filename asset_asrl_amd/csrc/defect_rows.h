@@ -1,0 +1,460 @@
+// Dense stage for wide shapes, by output ROWS and without matrix instructions (round 3).
+//
+// On MI355X an f64 MFMA runs at the rate of f64 vector FMAs (78.6 TFLOP/s both), so the matrix form of
+//     H = sum_i DI_i^T (hE_i H^_i) DI_i,   J = DC + sum_i hE_i J^_i DI_i                      (LGLDefects.h:414-512)
+// buys operand delivery, not arithmetic -- and pays for padded tiles and for ignoring what DI_i is made of:
+//     DI_i[:, column (j, cc)] = w_i(j, cc) e_cc + h B_ij dfdy_j[:, cc]   (+ the time-column terms)  (LGLDefects.h:417-458)
+// an identity entry and one column of the SPARSE cardinal Jacobian of node j.  With a lane per output row r the products
+// collapse (H is symmetric: row r of the stored lower triangle is column r of M):
+//     d_i  = DI_i[:, r]                                 the lane's own column: n gathered values, two FMAs each
+//     M_i  = hE_i H^_i d_i                              one FMA per structural entry of H^ (uniform operand)
+//     WB_j = sum_i B_ij M_i[0:n]                        per node j
+//     H(r, (j, cc)) = sum_i w_i(j, cc) M_i[cc] + h sum_k dfdy_j[k][cc] WB_j[k] + time / rank-2 / cardinal terms
+// i.e. one FMA per structural entry of column cc of dfdy_j -- four on average for the 32-state BASELINE ODE, n for a dense
+// one -- where the matrix form spends K N / 4 = 27 k-steps of a padded 16 x 16 tile.  The operands that do not depend on
+// the lane (entries of dfdy_j, H^_i, g^_i) are read from the workspace through a restrict-qualified, read-only kernel
+// argument: uniform addresses, scalar loads, no LDS traffic (an LDS broadcast costs the LDS what a full read does, and four
+// waves would saturate it).  J the same way with a lane per defect row (i, r): its row of J^_i in registers,
+//     J((i, r), (j, cc)) = C_ij [cc == r] + h D_ij dfdy_j[r][cc] + hE_i (w J^_i[r][cc] + h B_ij sum_k J^_i[r][k] dfdy_j[k][cc]) + time terms.
+// Stores: for a fixed block column the lanes' rows are contiguous (DenseFunctionBase.h:1112-1123) -- 512-byte runs.
+//
+// One four-wave workgroup per CU, one segment at a time; per segment the sparse ODE results of the slot are scattered into
+// dense, oddly strided LDS arrays (what a lane gathers by its own row / column), then every wave runs the row blocks it
+// owns (H rows 64b .. 64b + 63; defect rows likewise), dealt at compile time by cost.
+#pragma once
+#include "defect_dims.h"
+#include "defect_wide.h"
+#include <utility>
+
+namespace asset_hip {
+
+#ifndef ASSET_EXP_ROWS
+#define ASSET_EXP_ROWS 0             // (experiments: bit 0 -- no H columns, bit 1 -- no defect-row columns, bit 2 -- no row preparation)
+#endif
+
+template <class D>
+struct RowsDims {
+  using Ode = typename D::ode_t;
+  static constexpr int K = D::K, CS = D::CS, n = D::n, q = D::q, N = D::N, IR = D::IR, OR = D::OR;
+  static constexpr bool OK = D::WIDE && !D::TRAP && D::p == 0;
+  static constexpr int WAVES = 4;
+  static constexpr int LDK = n | 1, LDH = q | 1, LDJ = N | 1;       // odd strides: a lane per row reads conflict-free
+  // (what is read with compile-time addresses -- the staged slots, the short vectors -- first: an LDS instruction's immediate
+  //  offset reaches 64 KB, an address beyond that needs a register of its own)
+  static constexpr int o_tab = 0;
+  static constexpr int o_ST = o_tab + D::TABSZ;                     // [2][WSLOTD] the slot of this segment and of the next one (prefetched)
+  static constexpr int o_SB = o_ST + 2 * D::WSLOTD;                 // [K][n]   sum_j B_ij f_j[k]
+  static constexpr int o_WL = o_SB + K * n;                         // [CS][n]  sum_i D_ij lam_(i,k)
+  static constexpr int o_CL = o_WL + CS * n;                        // [CS][n]  sum_i C_ij lam_(i,k)
+  static constexpr int o_SD = o_CL + CS * n;                        // [OR]     sum_j D_ij f_j[r] + E_i f^_i[r]
+  static constexpr int o_HT = o_SD + OR;                            // [IR]     full time-partial vector HTpar
+  static constexpr int o_X = o_HT + IR;                             // [0]: sum lam sd
+  static constexpr int o_Fd = o_X + 2;                              // [CS][q][LDK]   dfdy_j[k][cc]  at ((j q + cc) LDK + k)
+  static constexpr int o_Hd = o_Fd + CS * q * LDK;                  // [CS][q][LDH]   H_j[a][b]      at ((j q + a) LDH + b), both halves
+  static constexpr int o_Jd = o_Hd + CS * q * LDH;                  // [K][n][LDJ]    J^_i[r][a]     at ((i n + r) LDJ + a)
+  static constexpr int o_END = o_Jd + K * n * LDJ;
+  static constexpr int LDS_DOUBLES = o_END;
+  static constexpr size_t lds_bytes() { return size_t(LDS_DOUBLES) * 8; }
+  // row blocks: H blocks 0 .. NHB-1, then defect-row blocks; owner wave by greedy cost (H block b: its last row + 1 column
+  // steps, a defect-row block: IR)
+  static constexpr int NHB = (IR + 63) / 64, NJB = (OR + 63) / 64, NITEM = NHB + NJB;
+  static constexpr int RB = (IR + NHB - 1) / NHB;                   // rows of an H block (equal blocks: the last one, whose rows have
+                                                                    //  every column, is the critical one whatever its size)
+  static_assert(!OK || NHB <= WAVES, "one H block per wave");
+  static constexpr int item_cost(int it) { return it < NHB ? 4 * (RB * it + RB < IR ? RB * it + RB : IR) : 3 * IR; }   // (a column of H ~ 4/3 of one of J)
+  static constexpr int owner(int it) {                              // items are dealt in the order H_(NHB-1) .. H_0, J_0 ..
+    int load[WAVES] = {0, 0, 0, 0};
+    int own = 0;
+    for (int s = 0; s < NITEM; s++) {
+      const int cur = s < NHB ? NHB - 1 - s : s;
+      int w = 0;
+      for (int x = 1; x < WAVES; x++)
+        if (load[x] < load[w]) w = x;
+      load[w] += item_cost(cur);
+      if (cur == it) own = w;
+    }
+    return own;
+  }
+};
+
+// position -> (row, column) of the structural entries of dfdy (JPOS) and of the packed lower Hessian (HPOS)
+template <class Ode>
+struct NzIndex {
+  static constexpr int N = Ode::NIN, n = Ode::XV, NZJ = Ode::NNZ_J, NZH = Ode::NNZ_H;
+  struct Tab { short jr[NZJ > 0 ? NZJ : 1], jc[NZJ > 0 ? NZJ : 1], ha[NZH > 0 ? NZH : 1], hb[NZH > 0 ? NZH : 1]; };
+  static constexpr Tab make() {
+    Tab t{};
+    for (int k = 0; k < n; k++)
+      for (int c = 0; c < N; c++)
+        if (Ode::JPOS[k * N + c] >= 0) { t.jr[Ode::JPOS[k * N + c]] = short(k); t.jc[Ode::JPOS[k * N + c]] = short(c); }
+    for (int a = 0; a < N; a++)
+      for (int b = 0; b <= a; b++)
+        if (Ode::HPOS[a * (a + 1) / 2 + b] >= 0) { t.ha[Ode::HPOS[a * (a + 1) / 2 + b]] = short(a); t.hb[Ode::HPOS[a * (a + 1) / 2 + b]] = short(b); }
+    return t;
+  }
+  static constexpr Tab v = make();
+};
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<int, N - 1>{}) -- what indexes the sparsity tables has to
+// be a constant expression (a run-time index turns the register arrays below into indexed register accesses)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// value of lane `l` (compile time) of a double every lane holds one of: two v_readlane, the result a scalar operand.  How the
+// lane-independent operands reach the FMAs: a coalesced vector load puts 64 of them into one register, and nothing waits --
+// scalar loads return out of order and share their counter with the LDS, so every use of one would drain both
+__device__ __forceinline__ double lane_value(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <class Ode, int SCH, bool BLOCKED>
+__device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* __restrict__ work_ro, const double* __restrict__ work_ro2) {
+  using D = Dims<Ode, SCH, BLOCKED>;
+  using R = RowsDims<D>;
+  using NZ = NzIndex<Ode>;
+  constexpr int K = D::K, CS = D::CS, n = D::n, q = D::q, N = D::N, IR = D::IR, OR = D::OR, T = D::T, TF = D::TF;
+  constexpr int NZJ = D::NZJ, NZH = D::NZH, LDK = R::LDK, LDH = R::LDH, LDJ = R::LDJ;
+  static_assert(D::p == 0, "segment parameters: not in this form");
+  static_assert(N <= 64, "one register of lane-distributed values per vector of ODE inputs");
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  lds_double* const L = (lds_double*)lds;
+  const int tid = int(threadIdx.x), wave = tid >> 6, lane = tid & 63;
+  constexpr LglTab ctab = c_lgl_tab[D::TAB];                        // compile-time indices: constants in the code
+  const LglTab& tab = *reinterpret_cast<const LglTab*>(lds);        // lane-dependent indices: the LDS copy
+
+  // once per workgroup: tables, and zeros where the dense arrays have no structural entry
+  for (int e = tid; e < D::TABSZ; e += 256) L[R::o_tab + e] = reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[e];
+  for (int e = tid; e < R::o_END - R::o_Fd; e += 256) L[R::o_Fd + e] = 0.0;
+
+  const int nshare = int(gridDim.x), share = int(blockIdx.x);
+  const int per = a.nseg / nshare, rem = a.nseg % nshare;
+  const int wg_first = share * per + min(share, rem), wg_count = per + (share < rem ? 1 : 0);
+  if (wg_count > 0)                                                 // the first slot: everybody; the later ones: one wave, a segment ahead
+    for (int e = tid; e < D::WSLOTD; e += 256) L[R::o_ST + e] = work_ro[size_t(wg_first) * D::WSLOT + e];
+
+  for (int s = 0; s < wg_count; s++) {
+    const size_t seg = size_t(wg_first + s);
+    // the segment's slot, in LDS since the previous segment's row preparation: nothing below waits for global memory (a load
+    // behind this wave's block stores would wait for every one of them), and what every lane reads the same entry of --
+    // dfdy_j, H^_i, g^_i -- is an LDS broadcast: ~5 per block column, a third of the LDS's time with four waves at it
+    const lds_double* const ws = L + R::o_ST + (s & 1) * D::WSLOTD;
+    double* const kkt = a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr;
+#if defined(ASSET_TIMING)
+    long long rts[8]; int nrt = 0;
+#define RWTS() do { if (nrt < 8) rts[nrt++] = clock64(); } while (0)
+#else
+#define RWTS() do {} while (0)
+#endif
+    RWTS();
+    wg_lds_barrier();                                               // (the previous segment's readers are done; the first pass: the zeros)
+    RWTS();
+    // ---- S0: scatter the slot's sparse blocks into the dense arrays; the short vectors
+    for (int e = tid; e < CS * NZJ; e += 256) {
+      const int j = e / NZJ, pz = e - j * NZJ;
+      L[R::o_Fd + (j * q + NZ::v.jc[pz]) * LDK + NZ::v.jr[pz]] = ws[D::w_CJ + e];
+    }
+    for (int e = tid; e < CS * NZH; e += 256) {
+      const int j = e / NZH, pz = e - j * NZH;
+      const double v = ws[D::w_CH + e];
+      L[R::o_Hd + (j * q + NZ::v.ha[pz]) * LDH + NZ::v.hb[pz]] = v;
+      L[R::o_Hd + (j * q + NZ::v.hb[pz]) * LDH + NZ::v.ha[pz]] = v;
+    }
+    for (int e = tid; e < K * NZJ; e += 256) {
+      const int i = e / NZJ, pz = e - i * NZJ;
+      L[R::o_Jd + (i * n + NZ::v.jr[pz]) * LDJ + NZ::v.jc[pz]] = ws[D::w_IJ + e];
+    }
+    const double h = ws[D::w_z + TF] - ws[D::w_z + T];
+    for (int e = tid; e < K * n; e += 256) {                        // SB[i][k]
+      const int i = e / n, k = e - i * n;
+      double sb = 0.0;
+#pragma unroll
+      for (int j = 0; j < CS; j++) sb = fma(tab.B[i][j], ws[D::w_Cf + j * n + k], sb);
+      L[R::o_SB + e] = sb;
+    }
+    for (int e = tid; e < CS * n; e += 256) {                       // WL[j][k], CL[j][k]
+      const int j = e / n, k = e - j * n;
+      double wl = 0.0, cl = 0.0;
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        const double l = a.L ? ws[D::w_lam + i * n + k] : 0.0;
+        wl = fma(tab.D[i][j], l, wl);
+        cl = fma(tab.C[i][j], l, cl);
+      }
+      L[R::o_WL + e] = wl;
+      L[R::o_CL + e] = cl;
+    }
+    if (wave == R::WAVES - 1) {                                     // sd, the defect values, sum lam sd
+      double lsum = 0.0;
+      for (int jr = lane; jr < OR; jr += 64) {
+        const int i = jr / n, r = jr - i * n;
+        double sd = tab.E[i] * ws[D::w_If + jr], fx = 0.0;
+#pragma unroll
+        for (int j = 0; j < CS; j++) {
+          sd = fma(tab.D[i][j], ws[D::w_Cf + j * n + r], sd);
+          fx = fma(tab.C[i][j], ws[D::w_z + j * q + r], fx);
+        }
+        L[R::o_SD + jr] = sd;
+        if (a.FX) a.FX[seg * OR + jr] = fma(h, sd, fx);
+        lsum = fma(a.L ? ws[D::w_lam + jr] : 0.0, sd, lsum);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o);
+      if (lane == 0) L[R::o_X] = lsum;
+    }
+    RWTS();
+    wg_lds_barrier();
+    RWTS();
+
+    // ---- the next segment's slot -> the other staging buffer: the last wave, while the others prepare their rows (it has no H
+    //      block when there are fewer than WAVES of them, and its block stores of the previous segment are long acknowledged)
+    if (wave == R::WAVES - 1 && s + 1 < wg_count) {
+      constexpr int CH = 8;
+      const double* __restrict__ nxt = work_ro + (seg + 1) * D::WSLOT;
+      lds_double* const dst = L + R::o_ST + ((s + 1) & 1) * D::WSLOTD;
+      for (int e0 = 0; e0 < D::WSLOTD; e0 += 64 * CH) {
+        double v[CH];
+#pragma unroll
+        for (int t = 0; t < CH; t++) v[t] = (e0 + 64 * t + lane < D::WSLOTD) ? nxt[e0 + 64 * t + lane] : 0.0;
+#pragma unroll
+        for (int t = 0; t < CH; t++)
+          if (e0 + 64 * t + lane < D::WSLOTD) dst[e0 + 64 * t + lane] = v[t];
+      }
+    }
+    // ---- the row blocks of this wave
+    // (row preparation: the lane-independent operands H^_i, g^_i, SB_i as lane-distributed registers + v_readlane -- entry e of a
+    //  list in lane e % 64 of register e / 64; as LDS broadcasts the compiler issues them far ahead and spills the accumulators)
+    constexpr int NHV = (NZH + 63) / 64, NFV = (NZJ + 63) / 64, NTV = (IR + 63) / 64;
+    double Hv[K][NHV], gv[K], SBv[K], Fv[CS][NFV];
+#pragma unroll
+    for (int j = 0; j < CS; j++)
+#pragma unroll
+      for (int t = 0; t < NFV; t++) Fv[j][t] = (64 * t + lane < NZJ) ? ws[D::w_CJ + j * NZJ + 64 * t + lane] : 0.0;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+#pragma unroll
+      for (int t = 0; t < NHV; t++) Hv[i][t] = (64 * t + lane < NZH) ? ws[D::w_IH + i * NZH + 64 * t + lane] : 0.0;
+      gv[i] = (lane < N) ? ws[D::w_Ig + i * N + lane] : 0.0;
+      SBv[i] = (lane < n) ? L[R::o_SB + i * n + lane] : 0.0;
+    }
+    double Mi[K][N];                                                // H blocks: M_i[:, r]
+    double TX = 0.0, HTr = 0.0;
+    int hitem = -1;                                                 // (a wave owns at most one H block: NHB <= WAVES)
+#pragma unroll
+    for (int it = 0; it < R::NHB; it++)
+      if (R::owner(it) == wave) hitem = it;
+    if (hitem >= 0 && !(ASSET_EXP_ROWS & 4)) {
+      const int it = hitem;                                         // (run time: one copy of the code for every block)
+      const int r = R::RB * it + lane;
+      const bool rv = lane < R::RB && r < IR;
+      const int rc = rv ? r : IR - 1;
+      const int jn = rc / q, ccr = rc - jn * q;
+      const double tsr = !rv ? 0.0 : ((r == T) ? -1.0 : ((r == TF) ? 1.0 : 0.0));
+      const lds_double* const fcol = L + R::o_Fd + (jn * q + ccr) * LDK;   // the row's own column of dfdy (read where used: registers)
+      double ht = 0.0;
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        double d[N];
+        const double hb = h * tab.B[i][jn], ar = tab.A[i][jn], ur = tab.U[i][jn];
+#pragma unroll
+        for (int k = 0; k < n; k++) d[k] = fma(hb, fcol[k], (k == ccr) ? ar : 0.0);
+        if ((R::RB * it <= T && T < R::RB * it + R::RB) || (R::RB * it <= TF && TF < R::RB * it + R::RB)) {   // a time row: -+ sum_j B_ij f_j on it
+#pragma unroll
+          for (int k = 0; k < n; k++) d[k] = fma(tsr, lane_value(SBv[i], k), d[k]);
+        }
+        d[T] = !rv ? 0.0 : ((r == T) ? 1.0 - ctab.s[i] : ((r == TF) ? ctab.s[i] : 0.0));
+#pragma unroll
+        for (int cc = n + 1; cc < q; cc++) d[cc] = (ccr == cc) ? ur : 0.0;
+#pragma unroll
+        for (int b = 0; b < N; b++) ht = fma(ctab.E[i] * lane_value(gv[i], b), d[b], ht);
+#pragma unroll
+        for (int b = 0; b < N; b++) Mi[i][b] = 0.0;
+        static_for<N*(N + 1) / 2>([&](auto E) {
+          constexpr int e = decltype(E)::value;
+          constexpr int hp = Ode::HPOS[e];
+          if constexpr (hp >= 0) {
+            constexpr int b = NZ::v.ha[hp], l = NZ::v.hb[hp];
+            const double u = lane_value(Hv[i][hp >> 6], hp & 63);
+            Mi[i][b] = fma(u, d[l], Mi[i][b]);
+            if constexpr (b != l) Mi[i][l] = fma(u, d[b], Mi[i][l]);
+          }
+        });
+        const double he = h * ctab.E[i];
+#pragma unroll
+        for (int b = 0; b < N; b++) Mi[i][b] *= he;
+      }
+      // full time partial of the row (LGLDefects.h:403-411, 504-505), the adjoint gradient of its column (:512)
+      HTr = ht + ws[D::w_Cg + jn * N + ccr] / h;
+      if (rv) L[R::o_HT + r] = HTr;
+#pragma unroll
+      for (int i = 0; i < K; i++)
+#pragma unroll
+        for (int k = 0; k < n; k++) TX = fma(lane_value(SBv[i], k), Mi[i][k], TX);
+      if (a.AGX && a.L && rv) {
+        double wl = 0.0;
+#pragma unroll
+        for (int k = 0; k < n; k++) wl = fma(L[R::o_WL + jn * n + k], fcol[k], wl);
+        const double cl = (ccr < n) ? L[R::o_CL + jn * n + (ccr < n ? ccr : 0)] : 0.0;
+        a.AGX[seg * IR + r] = fma(h, ht + wl, fma(tsr, L[R::o_X], cl));
+      }
+    }
+    double jrow[N], he_l = 0.0, sd_l = 0.0, TXJ = 0.0, Al[CS], Bl[CS], Cl[CS], Dl[CS], Ul[CS], s_l = 0.0;
+    int jitem = -1;
+    // (the defect-row blocks of this wave start after the barrier: their loop reads nothing the H blocks write, but a wave
+    //  may own both kinds)
+    RWTS();
+    wg_lds_barrier();                                               // HT complete
+    RWTS();
+    double HTv[NTV];
+#pragma unroll
+    for (int t = 0; t < NTV; t++) HTv[t] = (64 * t + lane < IR) ? L[R::o_HT + 64 * t + lane] : 0.0;
+
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(kkt, 0, int(D::NKKT * 8), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;                           // an offset beyond the block: the store is dropped (no exec masking)
+    if (hitem >= 0 && kkt && !(ASSET_EXP_ROWS & 1)) {
+      const int r0 = R::RB * hitem + lane;
+      const bool rv = lane < R::RB && r0 < IR;
+      const int rc = rv ? r0 : IR - 1;
+      const int jn = rc / q, ccr = rc - jn * q;
+      const int rmax = min(R::RB * hitem + R::RB - 1, IR - 1);
+      const double tsrow = !rv ? 0.0 : ((r0 == T) ? -1.0 : ((r0 == TF) ? 1.0 : 0.0));   // rows T / TF: the transposed rank-2 rows -+ HTpar[c]
+      const double txh = TX + HTr;
+      int r = -1;
+      unsigned voff = 0;
+#ifndef ASSET_ROWS_WB
+#define ASSET_ROWS_WB 0              // 1: WB_j = sum_i B_ij M_i[0:n] formed once per node (64 more registers: the kernel spills with them)
+#endif
+      double indj = 0.0, WB[ASSET_ROWS_WB ? n : 1];
+      int hbase = R::o_Hd + ccr;                                    // (opaque: the column's offset then fits the instruction's immediate
+      asm volatile("" : "+v"(hbase));                             //  field instead of taking an address register per column)
+      double hcur = L[hbase];                                       // H_j[cc][ccr] of the column ahead: requested one column early
+      static_for<IR>([&](auto Ct) {
+        constexpr int c = decltype(Ct)::value, j = c / q, cc = c % q, CC = cc;
+        if (c <= rmax) {                                            // (uniform)
+          if constexpr (cc == 0) {                                  // a new node
+            r = rv ? r0 : -1;                                       // (opaque per node: the row >= column masks are formed where they
+            asm volatile("" : "+v"(r));                             //  are used, not all of them ahead of the loop)
+            voff = unsigned(r) * 8u;
+            indj = (jn == j) ? 1.0 : 0.0;                           // rows of node j take its cardinal block H_j
+            if constexpr (ASSET_ROWS_WB) {
+#pragma unroll
+              for (int k = 0; k < n; k++) {
+                double w = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; i++) w = fma(ctab.B[i][j], Mi[i][k], w);
+                WB[k] = w;
+              }
+            }
+          }
+          double val = 0.0;
+#pragma unroll
+          for (int i = 0; i < K; i++) {
+            const double w = cc < n ? ctab.A[i][j] : (cc == T ? (c == T ? 1.0 - ctab.s[i] : (c == TF ? ctab.s[i] : 0.0)) : ctab.U[i][j]);
+            if (w != 0.0) val = fma(w, Mi[i][cc], val);
+          }
+          if constexpr (ASSET_ROWS_WB) {
+            double acc = 0.0;
+            static_for<n>([&](auto KK) {
+              constexpr int k = decltype(KK)::value;
+              constexpr int jp = Ode::JPOS[k * N + CC];
+              if constexpr (jp >= 0) acc = fma(ws[D::w_CJ + j * NZJ + jp], WB[k], acc);
+            });
+            val = fma(h, acc, val);
+          } else {                                                  // h sum_i B_ij (dfdy_j[:, cc] . M_i)
+            double acci[K];
+#pragma unroll
+            for (int i = 0; i < K; i++) acci[i] = 0.0;
+            static_for<n>([&](auto KK) {
+              constexpr int k = decltype(KK)::value;
+              constexpr int jp = Ode::JPOS[k * N + CC];
+              if constexpr (jp >= 0) {
+                const double f = lane_value(Fv[j][jp >> 6], jp & 63);
+#pragma unroll
+                for (int i = 0; i < K; i++) acci[i] = fma(f, Mi[i][k], acci[i]);
+              }
+            });
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; i++) acc = fma(ctab.B[i][j], acci[i], acc);
+            val = fma(h, acc, val);
+          }
+          if constexpr (c == T) val -= txh;
+          if constexpr (c == TF) val += txh;
+          val = fma(tsrow, lane_value(HTv[c >> 6], c & 63), val);
+          const double hc = hcur;
+          if constexpr (c + 1 < IR) hcur = L[hbase + (c + 1) * LDH];
+          val = fma(indj, hc, val);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, val), rsrc, (r >= c) ? voff : OOB,
+                                                (c * (IR + OR - 1) - ((c * (c - 1)) >> 1)) * 8, 0);
+        }
+      });
+    }
+
+    RWTS();
+    for (int jb = 0; jb < R::NJB; jb++) {
+      bool mine = false;
+#pragma unroll
+      for (int x = 0; x < R::NJB; x++) mine = mine || (x == jb && R::owner(R::NHB + x) == wave);
+      if (!mine) continue;
+      jitem = jb;
+      const int jr = 64 * jb + lane;
+      const bool jv = jr < OR;
+      const int jc = jv ? jr : OR - 1;
+      const int i = jc / n, r = jc - i * n;
+#pragma unroll
+      for (int b = 0; b < N; b++) jrow[b] = L[R::o_Jd + (i * n + r) * LDJ + b];
+#pragma unroll
+      for (int j = 0; j < CS; j++) { Al[j] = tab.A[i][j]; Bl[j] = tab.B[i][j]; Cl[j] = tab.C[i][j]; Dl[j] = tab.D[i][j]; Ul[j] = tab.U[i][j]; }
+      s_l = tab.s[i];
+      he_l = h * tab.E[i];
+      sd_l = L[R::o_SD + jc];
+      TXJ = 0.0;
+#pragma unroll
+      for (int k = 0; k < n; k++) TXJ = fma(jrow[k], L[R::o_SB + i * n + k], TXJ);
+      if (!kkt || (ASSET_EXP_ROWS & 2)) continue;
+      int ro = r;
+      int fbase = R::o_Fd + r;
+      asm volatile("" : "+v"(fbase));
+      double fcur = L[fbase];                                       // dfdy_j[r][cc] of the column ahead
+      static_for<IR>([&](auto Ct) {
+        constexpr int c = decltype(Ct)::value, j = c / q, cc = c % q, CC = cc;
+        if constexpr (cc == 0) {                                    // (opaque per node: [cc == r] is formed where it is used)
+          ro = r;
+          asm volatile("" : "+v"(ro));
+        }
+        const double w = cc < n ? Al[j] : (cc == T ? (c == T ? 1.0 - s_l : (c == TF ? s_l : 0.0)) : Ul[j]);
+        double acc = 0.0;
+        static_for<n>([&](auto KK) {
+          constexpr int k = decltype(KK)::value;
+          constexpr int jp = Ode::JPOS[k * N + CC];
+          if constexpr (jp >= 0) acc = fma(lane_value(Fv[j][jp >> 6], jp & 63), jrow[k], acc);
+        });
+        constexpr double tsc = (c == T) ? -1.0 : ((c == TF) ? 1.0 : 0.0);
+        double val = he_l * fma(w, jrow[cc], fma(h * Bl[j], acc, tsc * TXJ));
+        const double fd = fcur;
+        if constexpr (c + 1 < IR) fcur = L[fbase + (c + 1) * LDK];
+        val = fma(h * Dl[j], fd, val);
+        if constexpr (cc < n) val += (ro == cc) ? Cl[j] : 0.0;
+        val = fma(tsc, sd_l, val);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, val), rsrc, jv ? unsigned(jr) * 8u : OOB,
+                                              (c * (IR + OR - 1) - ((c * (c - 1)) >> 1) + IR) * 8, 0);
+      });
+    }
+    (void)jitem;
+    RWTS();
+#if defined(ASSET_TIMING)
+    if (blockIdx.x == 7 && s == 2 && lane == 0 && a.FX)
+      for (int t = 0; t + 1 < nrt; t++) a.FX[seg * OR + wave * 8 + t] = double(rts[t + 1] - rts[t]);
+#endif
+#undef RWTS
+  }
+}
+
+template <class Ode, int SCH, bool BLOCKED>
+__global__ __launch_bounds__(256, 1) void lgl_rows_kernel(EvalArgs a, const double* __restrict__ work_ro, const double* __restrict__ work_ro2) {
+  if constexpr (RowsDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_rows_body<Ode, SCH, BLOCKED>(a, work_ro, work_ro2);
+}
+
+}  // namespace asset_hip

@@ -7,6 +7,7 @@
 #include "defect_adjgrad.h"
 #include "defect_kernels.h"
 #include "defect_resident.h"
+#include "defect_rows.h"
 #include "defect_units.h"
 #include "defect_wide.h"
 #include "func_kernels.h"
@@ -32,6 +33,7 @@ enum MetaField {
   MF_RES_GR, MF_RES_LDS_BYTES, MF_LANE_BYTES_RES,   // resident kernel (defect_resident.h): segments per wave (0: none), LDS, record table
   MF_RES_WPS,                                       // ... and the waves per SIMD it is built for
   MF_RESD_GR,                                       // ... its dense part alone behind the unit kernels of a heavy ODE (0: none)
+  MF_ROWS_LDS_BYTES,                                // wide shapes, dense stage by output rows (defect_rows.h): its LDS (0: none)
   MF_COUNT
 };
 
@@ -63,7 +65,8 @@ struct LglMeta {
       lgl_lane_table_bytes<Ode, SCH, BLOCKED>(1), lgl_lane_table_bytes<Ode, SCH, BLOCKED>(2),
       AdjDims<D>::GP, (long long)AdjDims<D>::lds_bytes(),
       ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>(),
-      ResDims<D>::WPS, ResDims<D>::GIVEN_OK ? ResDims<D>::GR : 0};
+      ResDims<D>::WPS, ResDims<D>::GIVEN_OK ? ResDims<D>::GR : 0,
+      RowsDims<D>::OK ? (long long)RowsDims<D>::lds_bytes() : 0};
 };
 
 template <class F>

@@ -81,5 +81,7 @@ struct LglTab {
 // clang-format on
 
 static const LglTab h_lgl_tab[4] = ASSET_LGL_TABLE_INIT;  // host copy (C-ABI table query, set-up code)
+// compile-time copy: entries read with constant indices fold into the instructions' constants (defect_rows.h)
+inline constexpr LglTab c_lgl_tab[4] = ASSET_LGL_TABLE_INIT;
 
 }  // namespace asset_hip

@@ -299,10 +299,12 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     nac = 1 + max([nd.value for nd in topo_order(_level_roots(d, 2)) if nd.op == "aconst"], default=-1)
     o.append(f"  static constexpr int NACONST = {nac};   // constants of the application the function reads (vf.ApplConst)")
     o.append(f"  static constexpr const char* name() {{ return \"{d.name}\"; }}")
-    # structural sparsity: compact position of every J (row-major) / H (packed lower) entry or -1, and its inverse.
-    # The LGL workspace stores only the non-zeros; the dense accessors ignore these tables.
+    # structural sparsity: compact position of every J / H (packed lower) entry or -1, and its inverse.  The LGL workspace
+    # stores only the non-zeros; the dense accessors ignore these tables.  J is numbered COLUMN by column (input direction
+    # by input direction): a column's entries are what one output unit of a heavy right-hand side writes (csrc/defect_units.h)
+    # and what one block column of the row-wise dense stage reads, as one run (csrc/defect_rows.h)
     z = G.zero
-    jnz = [k * N + i for k in range(n) for i in range(N) if d.J[k][i] is not z]
+    jnz = [k * N + i for i in range(N) for k in range(n) if d.J[k][i] is not z]
     hnz = [i * (i + 1) // 2 + j for i in range(N) for j in range(i + 1) if d.H[i][j] is not z]
     jpos = {e: c for c, e in enumerate(jnz)}
     hpos = {e: c for c, e in enumerate(hnz)}
