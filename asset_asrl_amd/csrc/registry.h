@@ -181,7 +181,9 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
   auto dense_stage = [&](int lv) {
     const bool asmb = a.kmap != nullptr;   // KKT entries added straight into the solver's value array
     static const bool no_rows = std::getenv("ASSET_HIP_NO_ROWS") != nullptr;                                   // tuning only
-    if (wide && lv == 2 && !asmb && !no_rows && m[MF_ROWS_LDS_BYTES] > 0 && t.k[K_ROWS]) {
+    // (LGL3: two nodes, IR = 2 q -- one of the two H blocks nearly empty: 487 against 399 us for 12 500 32-state segments; kept
+    //  with the tile kernel)
+    if (wide && lv == 2 && !asmb && !no_rows && m[MF_ROWS_LDS_BYTES] > 0 && m[MF_CS] >= 3 && t.k[K_ROWS]) {
       const double* work_ro = a.work;
       void* rargs[] = {&args, &work_ro, &work_ro};
       return klaunch(t.k[K_ROWS], dim3(a.nseg < cus ? a.nseg : cus), dim3(256), size_t(m[MF_ROWS_LDS_BYTES]), st, rargs);

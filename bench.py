@@ -414,7 +414,7 @@ def main():
                        "total_segments": total_segments, "sharding": sharding},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("lgl_defect_kernel (ODE stage) + lgl_wide_dense_kernel" if IR >= 64 else
+                         "kernel": ("lgl_defect_kernel (ODE stage) + lgl_rows_kernel (dense stage by output rows; LGL3: lgl_wide_dense_kernel)" if IR >= 64 else
                                     "lgl_resident_kernel (one launch, ODE results resident in LDS) for the narrow LGL shapes; otherwise "
                                     "lgl_defect_kernel (fused launch, or ODE-stage + dense-stage launches; ODE stage in units for heavy ODEs)")
                                    + "; rank 0's share, all launches of one evaluation timed",

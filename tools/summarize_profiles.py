@@ -20,7 +20,7 @@ def stage_of(kernel_name):
     if "lgl_resident_kernel" in kernel_name:              # resident single launch (defect_resident.h): <Ode, CS, BLOCKED, LEVEL, ASM, LOOP>
         rargs = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
         return "resident" if len(rargs) < 4 or rargs[3] == "2" else "secondary"
-    if "lgl_wide_dense_kernel" in kernel_name:            # four-wave dense stage of the wide shapes (defect_wide.h)
+    if "lgl_wide_dense_kernel" in kernel_name or "lgl_rows_kernel" in kernel_name:   # dense stage of the wide shapes (defect_wide.h / defect_rows.h)
         return "dense_stage"
     if "lgl_ode_units_kernel" in kernel_name:             # ODE stage of heavy right-hand sides, one wave per output unit:
         uargs = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]   # <Ode, CS, BLOCKED, PHASE>
@@ -42,7 +42,7 @@ def counters(sub):
     if not os.path.exists(path):
         return {}
     for r in csv.DictReader(open(path)):
-        if not any(k in r["Kernel_Name"] for k in ("lgl_defect_kernel", "lgl_wide_dense_kernel", "lgl_ode_units_kernel", "lgl_resident_kernel")):
+        if not any(k in r["Kernel_Name"] for k in ("lgl_defect_kernel", "lgl_wide_dense_kernel", "lgl_ode_units_kernel", "lgl_resident_kernel", "lgl_rows_kernel")):
             continue
         acc[stage_of(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
@@ -68,7 +68,7 @@ out = {
     "source": f"tools/collect_profiles.sh {tag} (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes "
               "of `python3 bench.py --no-cpu-baseline`)",
     "kernel_stats": [{"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])} for r in kernels
-                     if any(k in r["Name"] for k in ("defect_kernel", "wide_dense_kernel", "ode_units_kernel", "resident_kernel"))],
+                     if any(k in r["Name"] for k in ("defect_kernel", "wide_dense_kernel", "ode_units_kernel", "resident_kernel", "rows_kernel"))],
     "per_kernel": per_kernel,
     "hbm": {"fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section)", "bytes_per_launch": total,
             "note": "one evaluation = the resident launch (no workspace traffic), the fused launch, or ODE-stage launch + dense-stage "
