@@ -109,7 +109,7 @@ __device__ __forceinline__ double lane_value(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-template <class Ode, int SCH, bool BLOCKED>
+template <class Ode, int SCH, bool BLOCKED, int LEVEL>
 __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* __restrict__ work_ro, const double* __restrict__ work_ro2) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using R = RowsDims<D>;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       const int j = e / NZJ, pz = e - j * NZJ;
       L[R::o_Fd + (j * q + NZ::v.jc[pz]) * LDK + NZ::v.jr[pz]] = ws[D::w_CJ + e];
     }
-    for (int e = tid; e < CS * NZH; e += 256) {
+    for (int e = tid; LEVEL >= 2 && e < CS * NZH; e += 256) {
       const int j = e / NZH, pz = e - j * NZH;
       const double v = ws[D::w_CH + e];
       L[R::o_Hd + (j * q + NZ::v.ha[pz]) * LDH + NZ::v.hb[pz]] = v;
@@ -209,17 +209,19 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
 
     // ---- the next segment's slot -> the other staging buffer: the last wave, while the others prepare their rows (it has no H
     //      block when there are fewer than WAVES of them, and its block stores of the previous segment are long acknowledged)
-    if (wave == R::WAVES - 1 && s + 1 < wg_count) {
+    if ((LEVEL < 2 || wave == R::WAVES - 1) && s + 1 < wg_count) {  // (Jacobian kinds: no long row preparation to hide it behind -- a quarter per wave)
       constexpr int CH = 8;
+      constexpr int NW = LEVEL < 2 ? R::WAVES : 1;
+      const int pl = LEVEL < 2 ? tid : lane;
       const double* __restrict__ nxt = work_ro + (seg + 1) * D::WSLOT;
       lds_double* const dst = L + R::o_ST + ((s + 1) & 1) * D::WSLOTD;
-      for (int e0 = 0; e0 < D::WSLOTD; e0 += 64 * CH) {
+      for (int e0 = 0; e0 < D::WSLOTD; e0 += 64 * NW * CH) {
         double v[CH];
 #pragma unroll
-        for (int t = 0; t < CH; t++) v[t] = (e0 + 64 * t + lane < D::WSLOTD) ? nxt[e0 + 64 * t + lane] : 0.0;
+        for (int t = 0; t < CH; t++) v[t] = (e0 + 64 * NW * t + pl < D::WSLOTD) ? nxt[e0 + 64 * NW * t + pl] : 0.0;
 #pragma unroll
         for (int t = 0; t < CH; t++)
-          if (e0 + 64 * t + lane < D::WSLOTD) dst[e0 + 64 * t + lane] = v[t];
+          if (e0 + 64 * NW * t + pl < D::WSLOTD) dst[e0 + 64 * NW * t + pl] = v[t];
       }
     }
     // ---- the row blocks of this wave
@@ -234,7 +236,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
 #pragma unroll
     for (int i = 0; i < K; i++) {
 #pragma unroll
-      for (int t = 0; t < NHV; t++) Hv[i][t] = (64 * t + lane < NZH) ? ws[D::w_IH + i * NZH + 64 * t + lane] : 0.0;
+      for (int t = 0; t < NHV; t++) Hv[i][t] = (LEVEL >= 2 && 64 * t + lane < NZH) ? ws[D::w_IH + i * NZH + 64 * t + lane] : 0.0;
       gv[i] = (lane < N) ? ws[D::w_Ig + i * N + lane] : 0.0;
       SBv[i] = (lane < n) ? L[R::o_SB + i * n + lane] : 0.0;
     }
@@ -244,7 +246,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
 #pragma unroll
     for (int it = 0; it < R::NHB; it++)
       if (R::owner(it) == wave) hitem = it;
-    if (hitem >= 0 && !(ASSET_EXP_ROWS & 4)) {
+    if (hitem >= 0 && !(ASSET_EXP_ROWS & 4) && (LEVEL >= 2 || (a.AGX && a.L))) {   // (Jacobian kinds: only the adjoint gradient needs the rows)
       const int it = hitem;                                         // (run time: one copy of the code for every block)
       const int r = R::RB * it + lane;
       const bool rv = lane < R::RB && r < IR;
@@ -268,6 +270,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
         for (int cc = n + 1; cc < q; cc++) d[cc] = (ccr == cc) ? ur : 0.0;
 #pragma unroll
         for (int b = 0; b < N; b++) ht = fma(ctab.E[i] * lane_value(gv[i], b), d[b], ht);
+        if constexpr (LEVEL >= 2) {
 #pragma unroll
         for (int b = 0; b < N; b++) Mi[i][b] = 0.0;
         static_for<N*(N + 1) / 2>([&](auto E) {
@@ -283,14 +286,19 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
         const double he = h * ctab.E[i];
 #pragma unroll
         for (int b = 0; b < N; b++) Mi[i][b] *= he;
+        }
       }
       // full time partial of the row (LGLDefects.h:403-411, 504-505), the adjoint gradient of its column (:512)
-      HTr = ht + ws[D::w_Cg + jn * N + ccr] / h;
-      if (rv) L[R::o_HT + r] = HTr;
+      if constexpr (LEVEL >= 2) {
+        HTr = ht + ws[D::w_Cg + jn * N + ccr] / h;
+        if (rv) L[R::o_HT + r] = HTr;
+      }
+      if constexpr (LEVEL >= 2) {
 #pragma unroll
       for (int i = 0; i < K; i++)
 #pragma unroll
         for (int k = 0; k < n; k++) TX = fma(lane_value(SBv[i], k), Mi[i][k], TX);
+      }
       if (a.AGX && a.L && rv) {
         double wl = 0.0;
 #pragma unroll
@@ -308,12 +316,26 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
     RWTS();
     double HTv[NTV];
 #pragma unroll
-    for (int t = 0; t < NTV; t++) HTv[t] = (64 * t + lane < IR) ? L[R::o_HT + 64 * t + lane] : 0.0;
+    for (int t = 0; t < NTV; t++) HTv[t] = (LEVEL >= 2 && 64 * t + lane < IR) ? L[R::o_HT + 64 * t + lane] : 0.0;
 
     typedef __attribute__((ext_vector_type(2))) unsigned int u2;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(kkt, 0, int(D::NKKT * 8), 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;                           // an offset beyond the block: the store is dropped (no exec masking)
-    if (hitem >= 0 && kkt && !(ASSET_EXP_ROWS & 1)) {
+    if (LEVEL < 2 && hitem >= 0 && kkt && !(a.flags & 1)) {         // Jacobian kinds: the Hessian slots hold zeros, unless the caller never reads them
+      const int r0 = R::RB * hitem + lane;
+      const bool rv = lane < R::RB && r0 < IR;
+      const int rmax = min(R::RB * hitem + R::RB - 1, IR - 1);
+      int r = rv ? r0 : -1;
+      u2 zero2;
+      zero2.x = 0u; zero2.y = 0u;
+      static_for<IR>([&](auto Ct) {
+        constexpr int c = decltype(Ct)::value;
+        if constexpr ((c & 15) == 0) asm volatile("" : "+v"(r));     // (the row >= column masks where they are used)
+        if (c <= rmax)
+          __builtin_amdgcn_raw_buffer_store_b64(zero2, rsrc, (r >= c) ? unsigned(r) * 8u : OOB, (c * (IR + OR - 1) - ((c * (c - 1)) >> 1)) * 8, 0);
+      });
+    }
+    if (LEVEL >= 2 && hitem >= 0 && kkt && !(ASSET_EXP_ROWS & 1)) {
       const int r0 = R::RB * hitem + lane;
       const bool rv = lane < R::RB && r0 < IR;
       const int rc = rv ? r0 : IR - 1;
@@ -393,11 +415,16 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
     }
 
     RWTS();
-    for (int jb = 0; jb < R::NJB; jb++) {
+    // (Jacobian kinds: the H blocks cost next to nothing, so every defect-row block is split in two column halves and the four
+    //  halves dealt round robin)
+    constexpr int JH = LEVEL >= 2 ? 1 : 2;                          // column ranges per defect-row block
+    for (int jt = 0; jt < R::NJB * JH; jt++) {
+      const int jb = jt / JH, half = jt - jb * JH;
       bool mine = false;
 #pragma unroll
-      for (int x = 0; x < R::NJB; x++) mine = mine || (x == jb && R::owner(R::NHB + x) == wave);
+      for (int x = 0; x < R::NJB; x++) mine = mine || (x == jb && (LEVEL >= 2 ? R::owner(R::NHB + x) : jt % R::WAVES) == wave);
       if (!mine) continue;
+      const int cfirst = half * (IR / JH), clast = (half + 1 == JH) ? IR : (half + 1) * (IR / JH);
       jitem = jb;
       const int jr = 64 * jb + lane;
       const bool jv = jr < OR;
@@ -424,6 +451,9 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
           ro = r;
           asm volatile("" : "+v"(ro));
         }
+        const double fd = fcur;
+        if constexpr (c + 1 < IR) fcur = L[fbase + (c + 1) * LDK];
+        if (JH == 1 || (c >= cfirst && c < clast)) {                // (uniform)
         const double w = cc < n ? Al[j] : (cc == T ? (c == T ? 1.0 - s_l : (c == TF ? s_l : 0.0)) : Ul[j]);
         double acc = 0.0;
         static_for<n>([&](auto KK) {
@@ -433,13 +463,12 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
         });
         constexpr double tsc = (c == T) ? -1.0 : ((c == TF) ? 1.0 : 0.0);
         double val = he_l * fma(w, jrow[cc], fma(h * Bl[j], acc, tsc * TXJ));
-        const double fd = fcur;
-        if constexpr (c + 1 < IR) fcur = L[fbase + (c + 1) * LDK];
         val = fma(h * Dl[j], fd, val);
         if constexpr (cc < n) val += (ro == cc) ? Cl[j] : 0.0;
         val = fma(tsc, sd_l, val);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, val), rsrc, jv ? unsigned(jr) * 8u : OOB,
                                               (c * (IR + OR - 1) - ((c * (c - 1)) >> 1) + IR) * 8, 0);
+        }
       });
     }
     (void)jitem;
@@ -452,9 +481,9 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
   }
 }
 
-template <class Ode, int SCH, bool BLOCKED>
+template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2>
 __global__ __launch_bounds__(256, 1) void lgl_rows_kernel(EvalArgs a, const double* __restrict__ work_ro, const double* __restrict__ work_ro2) {
-  if constexpr (RowsDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_rows_body<Ode, SCH, BLOCKED>(a, work_ro, work_ro2);
+  if constexpr (RowsDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_rows_body<Ode, SCH, BLOCKED, LEVEL>(a, work_ro, work_ro2);
 }
 
 }  // namespace asset_hip

@@ -96,7 +96,8 @@ constexpr int K_RESL(int level, bool asmb) { return 51 + (level - 1) * 2 + (asmb
 constexpr int K_RESD(bool asmb) { return 55 + (asmb ? 1 : 0); }   // ... its dense part alone, slots from the workspace (heavy ODEs)
 constexpr int K_UNITSJ = 57;   // heavy right-hand sides, Jacobian kinds: the unit kernel of the ODE stage (defect_units.h, PHASE 3)
 constexpr int K_ROWS = 58;     // wide shapes: dense stage by output rows, no matrix instructions (defect_rows.h)
-constexpr int K_COUNT = 59;
+constexpr int K_ROWS1 = 59;    // ... the Jacobian kinds
+constexpr int K_COUNT = 60;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -183,10 +184,10 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
     static const bool no_rows = std::getenv("ASSET_HIP_NO_ROWS") != nullptr;                                   // tuning only
     // (LGL3: two nodes, IR = 2 q -- one of the two H blocks nearly empty: 487 against 399 us for 12 500 32-state segments; kept
     //  with the tile kernel)
-    if (wide && lv == 2 && !asmb && !no_rows && m[MF_ROWS_LDS_BYTES] > 0 && m[MF_CS] >= 3 && t.k[K_ROWS]) {
+    if (wide && lv >= 1 && !asmb && !no_rows && m[MF_ROWS_LDS_BYTES] > 0 && m[MF_CS] >= 3 && t.k[lv == 2 ? K_ROWS : K_ROWS1]) {
       const double* work_ro = a.work;
       void* rargs[] = {&args, &work_ro, &work_ro};
-      return klaunch(t.k[K_ROWS], dim3(a.nseg < cus ? a.nseg : cus), dim3(256), size_t(m[MF_ROWS_LDS_BYTES]), st, rargs);
+      return klaunch(t.k[lv == 2 ? K_ROWS : K_ROWS1], dim3(a.nseg < cus ? a.nseg : cus), dim3(256), size_t(m[MF_ROWS_LDS_BYTES]), st, rargs);
     }
     if (wide)
       return klaunch(t.k[K_WIDE(lv, asmb)], dim3(a.nseg < cus * wide_wgs ? a.nseg : cus * wide_wgs), dim3(256), bytes_dense, st, kargs);
@@ -352,7 +353,10 @@ const KernelTable* lgl_static_table() {
       r.k[K_WIDE(2, false)].host = ASSET_KPTR(lgl_wide_dense_kernel<Ode, SCH, BLOCKED, 2, false>);
       r.k[K_WIDE(2, true)].host = ASSET_KPTR(lgl_wide_dense_kernel<Ode, SCH, BLOCKED, 2, true>);
       r.k[K_WIDE_SETUP].host = ASSET_KPTR(wide_setup_kernel<Ode, SCH, BLOCKED>);
-      if constexpr (RowsDims<D>::OK) r.k[K_ROWS].host = ASSET_KPTR(lgl_rows_kernel<Ode, SCH, BLOCKED>);
+      if constexpr (RowsDims<D>::OK) {
+        r.k[K_ROWS].host = ASSET_KPTR(lgl_rows_kernel<Ode, SCH, BLOCKED, 2>);
+        r.k[K_ROWS1].host = ASSET_KPTR(lgl_rows_kernel<Ode, SCH, BLOCKED, 1>);
+      }
     } else {
       r.k[K_LGL(1, 2, false)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 1, 2, false>);
       r.k[K_LGL(1, 2, true)].host = ASSET_KPTR(lgl_defect_kernel<Ode, SCH, BLOCKED, G, 1, 2, true>);
@@ -461,7 +465,8 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
     for (int as = 0; as <= 1; as++)
       if (slot == K_WIDE(lv, as != 0)) return "asset_hip::lgl_wide_dense_kernel<" + lgl + ", " + std::to_string(lv) + ", " + tf(as != 0) + ">";
   if (slot == K_WIDE_SETUP) return "asset_hip::wide_setup_kernel<" + lgl + ">";
-  if (slot == K_ROWS) return "asset_hip::lgl_rows_kernel<" + lgl + ">";
+  if (slot == K_ROWS) return "asset_hip::lgl_rows_kernel<" + lgl + ", 2>";
+  if (slot == K_ROWS1) return "asset_hip::lgl_rows_kernel<" + lgl + ", 1>";
   if (slot == K_RES(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, false>";
   if (slot == K_RES(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, true>";
   if (slot == K_RES1(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 1, false>";
