@@ -12,15 +12,19 @@
 //     H(r, (j, cc)) = sum_i w_i(j, cc) M_i[cc] + h sum_k dfdy_j[k][cc] WB_j[k] + time / rank-2 / cardinal terms
 // i.e. one FMA per structural entry of column cc of dfdy_j -- four on average for the 32-state BASELINE ODE, n for a dense
 // one -- where the matrix form spends K N / 4 = 27 k-steps of a padded 16 x 16 tile.  The operands that do not depend on
-// the lane (entries of dfdy_j, H^_i, g^_i) are read from the workspace through a restrict-qualified, read-only kernel
-// argument: uniform addresses, scalar loads, no LDS traffic (an LDS broadcast costs the LDS what a full read does, and four
-// waves would saturate it).  J the same way with a lane per defect row (i, r): its row of J^_i in registers,
+// the lane (entries of dfdy_j, H^_i, g^_i) are held lane-distributed in registers -- entry e of a list in lane e % 64 of
+// register e / 64 -- and reach the FMAs through v_readlane pairs as scalar operands (scalar loads return out of order and
+// share their counter with the LDS, so every use drained both; an LDS broadcast costs the LDS what a full read does and,
+// with the compiler issuing them far ahead, the registers the accumulators need: DESIGN 4.4a has the numbers).  J the same
+// way with a lane per defect row (i, r): its row of J^_i in registers,
 //     J((i, r), (j, cc)) = C_ij [cc == r] + h D_ij dfdy_j[r][cc] + hE_i (w J^_i[r][cc] + h B_ij sum_k J^_i[r][k] dfdy_j[k][cc]) + time terms.
 // Stores: for a fixed block column the lanes' rows are contiguous (DenseFunctionBase.h:1112-1123) -- 512-byte runs.
 //
-// One four-wave workgroup per CU, one segment at a time; per segment the sparse ODE results of the slot are scattered into
-// dense, oddly strided LDS arrays (what a lane gathers by its own row / column), then every wave runs the row blocks it
-// owns (H rows 64b .. 64b + 63; defect rows likewise), dealt at compile time by cost.
+// One four-wave workgroup per CU, one segment at a time; the segment's slot is staged in LDS and the next one prefetched while
+// the rows are prepared (a global load behind a wave's block stores waits for every one of them); per segment the sparse
+// ODE results are scattered into dense, oddly strided LDS arrays (what a lane gathers by its own row / column), then every
+// wave runs the row blocks it owns (H rows in equal blocks, defect rows in blocks of 64), dealt at compile time by cost.
+// Block entries are written with raw buffer stores: a lane outside the triangle gets an out-of-range offset.
 #pragma once
 #include "defect_dims.h"
 #include "defect_wide.h"
@@ -110,7 +114,7 @@ __device__ __forceinline__ double lane_value(double v, int l) {
 }
 
 template <class Ode, int SCH, bool BLOCKED, int LEVEL>
-__device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* __restrict__ work_ro, const double* __restrict__ work_ro2) {
+__device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* __restrict__ work_ro) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using R = RowsDims<D>;
   using NZ = NzIndex<Ode>;
@@ -482,8 +486,8 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
 }
 
 template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2>
-__global__ __launch_bounds__(256, 1) void lgl_rows_kernel(EvalArgs a, const double* __restrict__ work_ro, const double* __restrict__ work_ro2) {
-  if constexpr (RowsDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_rows_body<Ode, SCH, BLOCKED, LEVEL>(a, work_ro, work_ro2);
+__global__ __launch_bounds__(256, 1) void lgl_rows_kernel(EvalArgs a, const double* __restrict__ work_ro) {
+  if constexpr (RowsDims<Dims<Ode, SCH, BLOCKED>>::OK) lgl_rows_body<Ode, SCH, BLOCKED, LEVEL>(a, work_ro);
 }
 
 }  // namespace asset_hip

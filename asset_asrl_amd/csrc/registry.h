@@ -186,7 +186,7 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
     //  with the tile kernel)
     if (wide && lv >= 1 && !asmb && !no_rows && m[MF_ROWS_LDS_BYTES] > 0 && m[MF_CS] >= 3 && t.k[lv == 2 ? K_ROWS : K_ROWS1]) {
       const double* work_ro = a.work;
-      void* rargs[] = {&args, &work_ro, &work_ro};
+      void* rargs[] = {&args, &work_ro};
       return klaunch(t.k[lv == 2 ? K_ROWS : K_ROWS1], dim3(a.nseg < cus ? a.nseg : cus), dim3(256), size_t(m[MF_ROWS_LDS_BYTES]), st, rargs);
     }
     if (wide)
