@@ -101,10 +101,18 @@ struct NzIndex {
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<int, N - 1>{}) -- what indexes the sparsity tables has to
 // be a constant expression (a run-time index turns the register arrays below into indexed register accesses)
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+// (by halves: a fold expression over a pack of several hundred indices exceeds the run-time compiler's bracket depth)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_range(F& f) {
+  if constexpr (E - B == 1) f(std::integral_constant<int, B>{});
+  else if constexpr (E - B > 1) {
+    constexpr int M = (B + E) / 2;
+    static_for_range<B, M>(f);
+    static_for_range<M, E>(f);
+  }
+}
 template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+__device__ __forceinline__ void static_for(F&& f) { static_for_range<0, N>(f); }
 
 // value of lane `l` (compile time) of a double every lane holds one of: two v_readlane, the result a scalar operand.  How the
 // lane-independent operands reach the FMAs: a coalesced vector load puts 64 of them into one register, and nothing waits --

@@ -61,6 +61,8 @@ AD2_ODE(synthetic32, 32, 0, 0)
 AD2_ODE(vanderpol, 2, 1, 1)
 AD2_ODE(coupled12, 12, 3, 2)
 AD2_ODE(coupled16, 16, 3, 2)
+AD2_ODE(driven14, 14, 3, 0)
+AD2_ODE(driven20, 20, 3, 0)
 AD2_ODE(pathcon, 2, 3, 0)
 AD2_ODE(integrand_quad2, 1, 0, 0)
 AD2_ODE(pairprod, 1, 2, 0)
@@ -93,6 +95,8 @@ GEN_DECL(synthetic32)
 GEN_DECL(vanderpol)
 GEN_DECL(coupled12)
 GEN_DECL(coupled16)
+GEN_DECL(driven14)
+GEN_DECL(driven20)
 GEN_DECL(pathcon)
 GEN_DECL(integrand_quad2)
 GEN_DECL(pairprod)
@@ -134,6 +138,8 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(vanderpol)
   TRY4(coupled12)
   TRY4(coupled16)
+  TRY4(driven14)
+  TRY4(driven20)
   TRY4(pathcon)
   TRY4(integrand_quad2)
   TRY4(pairprod)
@@ -153,6 +159,8 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(vanderpol, 2, 1, 1, nullptr)
   TRY(coupled12, 12, 3, 2, nullptr)
   TRY(coupled16, 16, 3, 2, nullptr)
+  TRY(driven14, 14, 3, 0, nullptr)
+  TRY(driven20, 20, 3, 0, nullptr)
   TRY(pathcon, 2, 3, 0, nullptr)
   TRY(integrand_quad2, 1, 0, 0, nullptr)
   TRY(pairprod, 1, 2, 0, nullptr)

@@ -60,6 +60,22 @@ void coupled12(const S* y, S* f, const void*) { coupled_n<12>(y, f); }
 template <class S>
 void coupled16(const S* y, S* f, const void*) { coupled_n<16>(y, f); }
 
+// ------------------------------------------------------------------ driven chains (n,3,0): wide shapes with controls, no parameters
+// Not a BASELINE config: (14,3,0) in LGL7 has IR = 72 and (20,3,0) in LGL5 IR = 72 -- run-time compiled ODEs WITH control rows
+// for the row-wise wide dense stage (csrc/defect_rows.h), which takes shapes without segment parameters
+// (tests/test_gpu_jit.py defines the same right-hand side in the DSL).
+template <int n, class S>
+void driven_n(const S* y, S* f) {
+  const S& t = y[n];
+  const S* u = y + n + 1;
+  for (int k = 0; k < n; k++)
+    f[k] = -0.5 * y[k] + sin(y[(k + 1) % n]) * y[(k + 5) % n] * u[k % 3] + 0.3 * cos(t) * y[(k + 3) % n] + 0.1 * u[(k + 1) % 3] * u[(k + 1) % 3];
+}
+template <class S>
+void driven14(const S* y, S* f, const void*) { driven_n<14>(y, f); }
+template <class S>
+void driven20(const S* y, S* f, const void*) { driven_n<20>(y, f); }
+
 // ------------------------------------------------------------------ a nonlinear path constraint, 2 outputs of 6 inputs
 // Not an ODE: the independent check for plain functions batched over applications (mode FUNCTION);
 // tests/test_gpu_function.py defines the same function in the product's expression DSL.

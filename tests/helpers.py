@@ -84,6 +84,27 @@ def make_coupled12():
     return make_coupled(12)
 
 
+def make_driven(n: int = 14):
+    """A wide user-defined ODE with controls and NO parameters, (n, 3, 0): x_k' = -x_k/2 + sin(x_{k+1}) x_{k+5} u_{k mod 3}
+    + 0.3 cos(t) x_{k+3} + 0.1 u_{(k+1) mod 3}^2 (indices mod n).  (14, 3, 0) in LGL7 and (20, 3, 0) in LGL5 / LGL7 are wide
+    shapes (IR = 72 / 72 / 96) without segment parameters: the row-wise dense stage (csrc/defect_rows.h) with control rows.
+    The oracle holds the same right-hand sides as ``driven14`` / ``driven20`` (oracle/odes.h)."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+
+    class Driven(ODEBase):
+        def __init__(self):
+            a = ODEArguments(n, 3, 0)
+            x = a.XVec().tolist()
+            t = a.TVar()
+            u = [a.UVar(k) for k in range(3)]
+            rhs = [-0.5 * x[k] + vf.sin(x[(k + 1) % n]) * x[(k + 5) % n] * u[k % 3] + 0.3 * vf.cos(t) * x[(k + 3) % n]
+                   + 0.1 * u[(k + 1) % 3] * u[(k + 1) % 3] for k in range(n)]
+            super().__init__(vf.stack(rhs), n, 3, 0, name=f"driven{n}")
+
+    return Driven()
+
+
 class FullProblem:
     """One Reentry LGL5 phase with everything a phase can hand the solver: the defect equality, a path equality at every
     state, the mesh-spacing equality of every segment, a pair-wise path inequality between neighbouring states and an

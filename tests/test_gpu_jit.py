@@ -6,7 +6,7 @@ import pytest
 
 from asset_asrl_amd import jit
 from asset_asrl_amd.evaluator import CON, CON_ADJGRAD, JAC, JAC_ADJGRAD, JAC_ADJGRAD_HESS, DefectEvaluator
-from helpers import Workload, make_coupled, make_coupled12, make_vanderpol, rel_err
+from helpers import Workload, make_coupled, make_coupled12, make_driven, make_vanderpol, rel_err
 from test_gpu_parity import _check_blocks
 
 pytestmark = pytest.mark.gpu
@@ -51,6 +51,29 @@ def test_wide_user_ode_with_controls_and_parameters(oracle, n, mode, blocked):
     vals = np.zeros(nlp.nnz)
     ev.eval_assembled(KIND, w.X, w.L, vals)
     assert rel_err(vals, nlp.eval(KIND, w.X, w.L)[2]) < 1e-8
+    ev.close()
+
+
+@pytest.mark.parametrize("n,mode", [(14, "LGL7"), (20, "LGL5"), (20, "LGL7"), (14, "LGL5"), (14, "LGL3")])
+def test_wide_user_ode_with_controls_and_no_parameters(oracle, n, mode):
+    """(14, 3, 0) in LGL7 (IR = 72), (20, 3, 0) in LGL5 (IR = 72) and LGL7 (IR = 96): wide shapes without segment parameters
+    -- the row-wise dense stage (csrc/defect_rows.h) with control-interpolation rows, which the 32-state BASELINE ODE does not
+    have; every evaluation kind, and the assembled kind through the tile kernel.  (14, 3, 0) in LGL5 / LGL3: the narrow
+    neighbours of the same right-hand side."""
+    name = jit.ensure_kernel(make_driven(n), mode, False)
+    w = Workload(f"driven{n}", mode, 31, False, sizes=(n, 3, 0), var_offset=2, con_offset=1, extra_vars=3)
+    nlp = oracle.Nlp(oracle.get_ode(f"driven{n}", 0), oracle.MODES[mode], False, w.vindex, w.cindex, w.n_primal, w.n_equal, 2)
+    ev = DefectEvaluator(name, mode, False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    assert ev.IR == {"LGL3": 2, "LGL5": 3, "LGL7": 4}[mode] * (n + 4)
+    for what in (JAC_ADJGRAD_HESS, CON, CON_ADJGRAD, JAC, JAC_ADJGRAD):
+        ref = nlp.eval_blocks(what, w.X, w.L)
+        got = ev.eval(what, w.X, w.L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
+        _check_blocks(got, ref, w, what)
+    locs = nlp.kkt_locations()[:nlp.num_user_kkt].reshape(w.nseg, ev.NKKT)
+    ev.set_kkt_map(locs, nlp.nnz)
+    vals = np.zeros(nlp.nnz)
+    ev.eval_assembled(JAC_ADJGRAD_HESS, w.X, w.L, vals)
+    assert rel_err(vals, nlp.eval(JAC_ADJGRAD_HESS, w.X, w.L)[2]) < 1e-8
     ev.close()
 
 
