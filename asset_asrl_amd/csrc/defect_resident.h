@@ -257,6 +257,10 @@ struct ResLane {
   static constexpr int ZERO = R::s_Z0;
   static constexpr int p = D::p;
   static constexpr bool QFAST = (q % 4 == 0) && p == 0;   // the node of column 16ct + lk + 4v does not depend on lk
+  // row weights C_il,j / D_il,j of the lane's defect rows in the record (registers), or as rows of the LDS tables: in registers
+  // where there is room -- QFAST shapes, and shapes built for one wave per SIMD that are not behind the unit kernels (TwoBody-LGL7:
+  // 82.1 us with the weights in registers, 83.4 us from the tables; TwoBody-LGL5 BlockConstant at two waves: 37.4 / 35.9 us)
+  static constexpr bool TREG = QFAST || (R::WPS == 1 && Ode::NUNITS == 1);
 
   // DI fragments (B operand of the M product, A operand of the H and J products): lane (lr, lk) <-> column c = 16ct + lr,
   // row b = 4kk + lk:   dv[ct][i][kk] = tab[cao[ct][kk] + 4i] + h tab[cbo[ct] + 4i] * S[cjo[ct][kk]] -/+ sbv[i][kk] on columns T / TF
@@ -277,8 +281,8 @@ struct ResLane {
   // defect row weights: sd = sum_jj tD[jj] f_jj[rl] + tE f^_il[rl];  fx = sum_jj tC[jj] z_jj[rl] + h sd
   // (QFAST: in the record; otherwise rows of the weight tables in LDS, dCo / dDo: 32 registers less, and what is selected from
   //  them per accumulator entry cannot be hoisted out of the segment loop into yet more registers)
-  double tC[QFAST ? TJ : 1][CS], tD[QFAST ? TJ : 1][CS], tE[TJ];
-  int dCo[QFAST ? 1 : TJ], dDo[QFAST ? 1 : TJ];
+  double tC[TREG ? TJ : 1][CS], tD[TREG ? TJ : 1][CS], tE[TJ];
+  int dCo[TREG ? 1 : TJ], dDo[TREG ? 1 : TJ];
   // DC: initial value of J^T accumulator entry (ct, jt, v), column c = 16ct + lk + 4v:
   //   [cc == rl] C_il,j(c) + h D_il,j(c) S[dco[ct][jt][v]] -/+ sd on the time columns
   // (QFAST: the node of the column is known at compile time; otherwise it is packed two bits per entry, and [cc == rl] one)
@@ -354,7 +358,7 @@ struct ResLane {
         const int jp = (row && b < N) ? Ode::JPOS[rl[jt] * N + b] : -1;
         jo[jt][kk] = jp >= 0 ? D::w_IJ + il[jt] * D::NZJ + jp : ZERO;
       }
-      if constexpr (QFAST) {
+      if constexpr (TREG) {
         for (int jj = 0; jj < CS; jj++) { tC[jt][jj] = row ? tab.C[il[jt]][jj] : 0.0; tD[jt][jj] = row ? tab.D[il[jt]][jj] : 0.0; }
       } else {
         constexpr int oC = __builtin_offsetof(LglTab, C) / 8, oD = __builtin_offsetof(LglTab, D) / 8;
@@ -607,8 +611,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   // ------------------------------------------------------------------ dense part, one segment at a time
   auto tabrow = [&](int o, int i) -> double { return tabL[o + 4 * i]; };
   // weights C_il,jj / D_il,jj of the lane's defect row of row tile jt (zeros without a row)
-  auto tCw = [&](int jt, int jj) -> double { if constexpr (LCT::QFAST) return lc.tC[jt][jj]; else return tabL[lc.dCo[jt] + jj]; };
-  auto tDw = [&](int jt, int jj) -> double { if constexpr (LCT::QFAST) return lc.tD[jt][jj]; else return tabL[lc.dDo[jt] + jj]; };   // row i of a [K][4] weight array (or of x_AUX)
+  auto tCw = [&](int jt, int jj) -> double { if constexpr (LCT::TREG) return lc.tC[jt][jj]; else return tabL[lc.dCo[jt] + jj]; };
+  auto tDw = [&](int jt, int jj) -> double { if constexpr (LCT::TREG) return lc.tD[jt][jj]; else return tabL[lc.dDo[jt] + jj]; };   // row i of a [K][4] weight array (or of x_AUX)
   // -1 on column T, +1 on column TF of the lane's column 16t + lr: the direction d = e_TF - e_T of the rank-2 update and the
   // sign of the time-column terms
   auto tsA = [&](int t) -> double { return (16 * t + lr == T) ? -1.0 : ((16 * t + lr == TF) ? 1.0 : 0.0); };
@@ -776,7 +780,15 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
             const int jn = c0 / q < CS ? c0 / q : 0;
             dd = (c0 < IR) ? lc.tD[jt][jn] : 0.0;
             cw = (c0 < IR && lk == lc.rl[jt] - c0 % q) ? lc.tC[jt][jn] : 0.0;
-          } else {                                                 // the node from its two bits; weights D_il,j / C_il,j by selection
+          } else if constexpr (LCT::TREG) {                        // the node from its two bits; weights D_il,j / C_il,j by selection
+            const unsigned jn = (lc.jnb[ct] >> (2 * v)) & 3u;
+            const bool node = c0 + lk < D::P0;
+            double dsel = lc.tD[jt][0], csel = lc.tC[jt][0];
+#pragma unroll
+            for (int jj = 1; jj < CS; jj++) { dsel = (jn == unsigned(jj)) ? lc.tD[jt][jj] : dsel; csel = (jn == unsigned(jj)) ? lc.tC[jt][jj] : csel; }
+            dd = node ? dsel : 0.0;
+            cw = ((lc.dbt[ct][jt] >> v) & 1u) ? csel : 0.0;
+          } else {                                                 // ... or read from the tables' rows
             const int jn = int((lc.jnb[ct] >> (2 * v)) & 3u);
             constexpr int oZ4 = D::TABSZ + GR * SLOT + R::x_Z4;
             const bool node = c0 + lk < D::P0;
