@@ -40,9 +40,9 @@ template <class D>
 struct RowsDims {
   using Ode = typename D::ode_t;
   static constexpr int K = D::K, CS = D::CS, n = D::n, q = D::q, N = D::N, IR = D::IR, OR = D::OR;
-  static constexpr bool OK = D::WIDE && !D::TRAP && D::p == 0;
+  static constexpr bool OK_SHAPE = D::WIDE && !D::TRAP;
   static constexpr int WAVES = 4;
-  static constexpr int LDK = n | 1, LDH = q | 1, LDJ = N | 1;       // odd strides: a lane per row reads conflict-free
+  static constexpr int LDK = n | 1, LDH = N | 1, LDJ = N | 1;       // odd strides: a lane per row reads conflict-free
   // (what is read with compile-time addresses -- the staged slots, the short vectors -- first: an LDS instruction's immediate
   //  offset reaches 64 KB, an address beyond that needs a register of its own)
   static constexpr int o_tab = 0;
@@ -53,12 +53,13 @@ struct RowsDims {
   static constexpr int o_SD = o_CL + CS * n;                        // [OR]     sum_j D_ij f_j[r] + E_i f^_i[r]
   static constexpr int o_HT = o_SD + OR;                            // [IR]     full time-partial vector HTpar
   static constexpr int o_X = o_HT + IR;                             // [0]: sum lam sd
-  static constexpr int o_Fd = o_X + 2;                              // [CS][q][LDK]   dfdy_j[k][cc]  at ((j q + cc) LDK + k)
-  static constexpr int o_Hd = o_Fd + CS * q * LDK;                  // [CS][q][LDH]   H_j[a][b]      at ((j q + a) LDH + b), both halves
-  static constexpr int o_Jd = o_Hd + CS * q * LDH;                  // [K][n][LDJ]    J^_i[r][a]     at ((i n + r) LDJ + a)
+  static constexpr int o_Fd = o_X + 2;                              // [CS][N][LDK]   dfdy_j[k][cc]  at ((j N + cc) LDK + k)   (cc >= q: parameter columns)
+  static constexpr int o_Hd = o_Fd + CS * N * LDK;                  // [CS][N][LDH]   H_j[a][b]      at ((j N + a) LDH + b), both halves
+  static constexpr int o_Jd = o_Hd + CS * N * LDH;                  // [K][n][LDJ]    J^_i[r][a]     at ((i n + r) LDJ + a)
   static constexpr int o_END = o_Jd + K * n * LDJ;
   static constexpr int LDS_DOUBLES = o_END;
   static constexpr size_t lds_bytes() { return size_t(LDS_DOUBLES) * 8; }
+  static constexpr bool OK = OK_SHAPE && lds_bytes() <= 160 * 1024 && N <= 64;
   // row blocks: H blocks 0 .. NHB-1, then defect-row blocks; owner wave by greedy cost (H block b: its last row + 1 column
   // steps, a defect-row block: IR)
   static constexpr int NHB = (IR + 63) / 64, NJB = (OR + 63) / 64, NITEM = NHB + NJB;
@@ -128,7 +129,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
   using NZ = NzIndex<Ode>;
   constexpr int K = D::K, CS = D::CS, n = D::n, q = D::q, N = D::N, IR = D::IR, OR = D::OR, T = D::T, TF = D::TF;
   constexpr int NZJ = D::NZJ, NZH = D::NZH, LDK = R::LDK, LDH = R::LDH, LDJ = R::LDJ;
-  static_assert(D::p == 0, "segment parameters: not in this form");
+  constexpr int p = D::p, P0 = D::P0;
   static_assert(N <= 64, "one register of lane-distributed values per vector of ODE inputs");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   lds_double* const L = (lds_double*)lds;
@@ -165,13 +166,13 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
     // ---- S0: scatter the slot's sparse blocks into the dense arrays; the short vectors
     for (int e = tid; e < CS * NZJ; e += 256) {
       const int j = e / NZJ, pz = e - j * NZJ;
-      L[R::o_Fd + (j * q + NZ::v.jc[pz]) * LDK + NZ::v.jr[pz]] = ws[D::w_CJ + e];
+      L[R::o_Fd + (j * N + NZ::v.jc[pz]) * LDK + NZ::v.jr[pz]] = ws[D::w_CJ + e];
     }
     for (int e = tid; LEVEL >= 2 && e < CS * NZH; e += 256) {
       const int j = e / NZH, pz = e - j * NZH;
       const double v = ws[D::w_CH + e];
-      L[R::o_Hd + (j * q + NZ::v.ha[pz]) * LDH + NZ::v.hb[pz]] = v;
-      L[R::o_Hd + (j * q + NZ::v.hb[pz]) * LDH + NZ::v.ha[pz]] = v;
+      L[R::o_Hd + (j * N + NZ::v.ha[pz]) * LDH + NZ::v.hb[pz]] = v;
+      L[R::o_Hd + (j * N + NZ::v.hb[pz]) * LDH + NZ::v.ha[pz]] = v;
     }
     for (int e = tid; e < K * NZJ; e += 256) {
       const int i = e / NZJ, pz = e - i * NZJ;
@@ -263,23 +264,38 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       const int r = R::RB * it + lane;
       const bool rv = lane < R::RB && r < IR;
       const int rc = rv ? r : IR - 1;
-      const int jn = rc / q, ccr = rc - jn * q;
+      // a node's row (jn, ccr), or (segment parameters) a parameter row: component ccr = q + pa of EVERY node
+      const bool par = p > 0 && rc >= P0;
+      const int jn = par ? 0 : rc / q, ccr = par ? q + (rc - P0) : rc - jn * q;
+      const bool pblock = p > 0 && R::RB * it + R::RB > P0;          // (uniform) the block holds parameter rows
       const double tsr = !rv ? 0.0 : ((r == T) ? -1.0 : ((r == TF) ? 1.0 : 0.0));
-      const lds_double* const fcol = L + R::o_Fd + (jn * q + ccr) * LDK;   // the row's own column of dfdy (read where used: registers)
+      const lds_double* const fcol = L + R::o_Fd + (jn * N + ccr) * LDK;   // the row's own column of dfdy (read where used: registers)
       double ht = 0.0;
 #pragma unroll
       for (int i = 0; i < K; i++) {
         double d[N];
-        const double hb = h * tab.B[i][jn], ar = tab.A[i][jn], ur = tab.U[i][jn];
+        const double hb = par ? 0.0 : h * tab.B[i][jn], ar = par ? 0.0 : tab.A[i][jn], ur = par ? 0.0 : tab.U[i][jn];
 #pragma unroll
         for (int k = 0; k < n; k++) d[k] = fma(hb, fcol[k], (k == ccr) ? ar : 0.0);
+        if constexpr (p > 0) {
+          if (pblock) {                                             // parameter rows: h sum_j B_ij dfdy_j[:, q + pa] (LGLDefects.h:440-444)
+#pragma unroll
+            for (int j = 0; j < CS; j++) {
+              const double hbj = par ? h * ctab.B[i][j] : 0.0;
+#pragma unroll
+              for (int k = 0; k < n; k++) d[k] = fma(hbj, L[R::o_Fd + (j * N + ccr) * LDK + k], d[k]);
+            }
+          }
+#pragma unroll
+          for (int pb = 0; pb < p; pb++) d[q + pb] = (par && ccr == q + pb) ? 1.0 : 0.0;
+        }
         if ((R::RB * it <= T && T < R::RB * it + R::RB) || (R::RB * it <= TF && TF < R::RB * it + R::RB)) {   // a time row: -+ sum_j B_ij f_j on it
 #pragma unroll
           for (int k = 0; k < n; k++) d[k] = fma(tsr, lane_value(SBv[i], k), d[k]);
         }
-        d[T] = !rv ? 0.0 : ((r == T) ? 1.0 - ctab.s[i] : ((r == TF) ? ctab.s[i] : 0.0));
+        d[T] = !rv ? 0.0 : ((r == T) ? 1.0 - ctab.s[i] : ((r == TF) ? ctab.s[i] : 0.0));   // (T, TF < P0: never a parameter row)
 #pragma unroll
-        for (int cc = n + 1; cc < q; cc++) d[cc] = (ccr == cc) ? ur : 0.0;
+        for (int cc = n + 1; cc < q; cc++) d[cc] = (!par && ccr == cc) ? ur : 0.0;
 #pragma unroll
         for (int b = 0; b < N; b++) ht = fma(ctab.E[i] * lane_value(gv[i], b), d[b], ht);
         if constexpr (LEVEL >= 2) {
@@ -302,7 +318,14 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       }
       // full time partial of the row (LGLDefects.h:403-411, 504-505), the adjoint gradient of its column (:512)
       if constexpr (LEVEL >= 2) {
-        HTr = ht + ws[D::w_Cg + jn * N + ccr] / h;
+        double gs = ws[D::w_Cg + jn * N + ccr];
+        if constexpr (p > 0) {
+          if (pblock) {                                             // a parameter row: g_j[q + pa] summed over the nodes
+#pragma unroll
+            for (int j = 1; j < CS; j++) gs += par ? ws[D::w_Cg + j * N + ccr] : 0.0;
+          }
+        }
+        HTr = ht + gs / h;
         if (rv) L[R::o_HT + r] = HTr;
       }
       if constexpr (LEVEL >= 2) {
@@ -315,6 +338,14 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
         double wl = 0.0;
 #pragma unroll
         for (int k = 0; k < n; k++) wl = fma(L[R::o_WL + jn * n + k], fcol[k], wl);
+        if constexpr (p > 0) {
+          if (pblock) {
+#pragma unroll
+            for (int j = 1; j < CS; j++)
+#pragma unroll
+              for (int k = 0; k < n; k++) wl = fma(par ? L[R::o_WL + j * n + k] : 0.0, L[R::o_Fd + (j * N + ccr) * LDK + k], wl);
+          }
+        }
         const double cl = (ccr < n) ? L[R::o_CL + jn * n + (ccr < n ? ccr : 0)] : 0.0;
         a.AGX[seg * IR + r] = fma(h, ht + wl, fma(tsr, L[R::o_X], cl));
       }
@@ -351,52 +382,40 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       const int r0 = R::RB * hitem + lane;
       const bool rv = lane < R::RB && r0 < IR;
       const int rc = rv ? r0 : IR - 1;
-      const int jn = rc / q, ccr = rc - jn * q;
+      const bool par = p > 0 && rc >= P0;                           // a parameter row: component ccr = q + pa of every node
+      const int jn = par ? -1 : rc / q, ccr = par ? q + (rc - P0) : rc - (rc / q) * q;
       const int rmax = min(R::RB * hitem + R::RB - 1, IR - 1);
       const double tsrow = !rv ? 0.0 : ((r0 == T) ? -1.0 : ((r0 == TF) ? 1.0 : 0.0));   // rows T / TF: the transposed rank-2 rows -+ HTpar[c]
       const double txh = TX + HTr;
       int r = -1;
       unsigned voff = 0;
-#ifndef ASSET_ROWS_WB
-#define ASSET_ROWS_WB 0              // 1: WB_j = sum_i B_ij M_i[0:n] formed once per node (64 more registers: the kernel spills with them)
-#endif
-      double indj = 0.0, WB[ASSET_ROWS_WB ? n : 1];
+      double indj = 0.0;
       int hbase = R::o_Hd + ccr;                                    // (opaque: the column's offset then fits the instruction's immediate
       asm volatile("" : "+v"(hbase));                             //  field instead of taking an address register per column)
       double hcur = L[hbase];                                       // H_j[cc][ccr] of the column ahead: requested one column early
+      // the block row (j N + cc) of the dense arrays that block column c reads: node columns (j, cc), parameter columns (0, q + pc)
+      auto brow = [](int c) constexpr { return c < P0 ? (c / q) * N + (c % q) : q + (c - P0); };
       static_for<IR>([&](auto Ct) {
-        constexpr int c = decltype(Ct)::value, j = c / q, cc = c % q, CC = cc;
+        constexpr int c = decltype(Ct)::value;
+        constexpr bool pcol = c >= P0;                              // a parameter column (segment parameters)
+        constexpr int j = pcol ? 0 : c / q, cc = pcol ? q + (c - P0) : c % q, CC = cc;
         if (c <= rmax) {                                            // (uniform)
-          if constexpr (cc == 0) {                                  // a new node
+          if constexpr (cc == 0 || c == P0) {                       // a new node (or the parameter columns)
             r = rv ? r0 : -1;                                       // (opaque per node: the row >= column masks are formed where they
             asm volatile("" : "+v"(r));                             //  are used, not all of them ahead of the loop)
             voff = unsigned(r) * 8u;
-            indj = (jn == j) ? 1.0 : 0.0;                           // rows of node j take its cardinal block H_j
-            if constexpr (ASSET_ROWS_WB) {
-#pragma unroll
-              for (int k = 0; k < n; k++) {
-                double w = 0.0;
-#pragma unroll
-                for (int i = 0; i < K; i++) w = fma(ctab.B[i][j], Mi[i][k], w);
-                WB[k] = w;
-              }
-            }
+            indj = (par || jn == j) ? 1.0 : 0.0;                    // rows of node j take its cardinal block H_j; parameter rows every node's
           }
           double val = 0.0;
 #pragma unroll
           for (int i = 0; i < K; i++) {
-            const double w = cc < n ? ctab.A[i][j] : (cc == T ? (c == T ? 1.0 - ctab.s[i] : (c == TF ? ctab.s[i] : 0.0)) : ctab.U[i][j]);
+            const double w = pcol ? 1.0 : (cc < n ? ctab.A[i][j] : (cc == T ? (c == T ? 1.0 - ctab.s[i] : (c == TF ? ctab.s[i] : 0.0)) : ctab.U[i][j]));
             if (w != 0.0) val = fma(w, Mi[i][cc], val);
           }
-          if constexpr (ASSET_ROWS_WB) {
-            double acc = 0.0;
-            static_for<n>([&](auto KK) {
-              constexpr int k = decltype(KK)::value;
-              constexpr int jp = Ode::JPOS[k * N + CC];
-              if constexpr (jp >= 0) acc = fma(ws[D::w_CJ + j * NZJ + jp], WB[k], acc);
-            });
-            val = fma(h, acc, val);
-          } else {                                                  // h sum_i B_ij (dfdy_j[:, cc] . M_i)
+          // h sum_i B_ij (dfdy_j[:, cc] . M_i); a parameter column: summed over the nodes
+          double acc = 0.0;
+          static_for<(pcol ? CS : 1)>([&](auto Jt) {
+            constexpr int jj = pcol ? decltype(Jt)::value : j;
             double acci[K];
 #pragma unroll
             for (int i = 0; i < K; i++) acci[i] = 0.0;
@@ -404,22 +423,27 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
               constexpr int k = decltype(KK)::value;
               constexpr int jp = Ode::JPOS[k * N + CC];
               if constexpr (jp >= 0) {
-                const double f = lane_value(Fv[j][jp >> 6], jp & 63);
+                const double f = lane_value(Fv[jj][jp >> 6], jp & 63);
 #pragma unroll
                 for (int i = 0; i < K; i++) acci[i] = fma(f, Mi[i][k], acci[i]);
               }
             });
-            double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < K; i++) acc = fma(ctab.B[i][j], acci[i], acc);
-            val = fma(h, acc, val);
-          }
+            for (int i = 0; i < K; i++) acc = fma(ctab.B[i][jj], acci[i], acc);
+          });
+          val = fma(h, acc, val);
           if constexpr (c == T) val -= txh;
           if constexpr (c == TF) val += txh;
           val = fma(tsrow, lane_value(HTv[c >> 6], c & 63), val);
           const double hc = hcur;
-          if constexpr (c + 1 < IR) hcur = L[hbase + (c + 1) * LDH];
-          val = fma(indj, hc, val);
+          if constexpr (c + 1 < IR) hcur = L[hbase + brow(c + 1) * LDH];
+          if constexpr (!pcol) val = fma(indj, hc, val);
+          else {                                                    // parameter-parameter entries: H_j[q + pc][q + pa] summed over the nodes
+            double hs = hc;
+#pragma unroll
+            for (int jj = 1; jj < CS; jj++) hs += L[hbase + (jj * N + cc) * LDH];
+            val += par ? hs : 0.0;
+          }
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, val), rsrc, (r >= c) ? voff : OOB,
                                                 (c * (IR + OR - 1) - ((c * (c - 1)) >> 1)) * 8, 0);
         }
@@ -457,25 +481,34 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       int fbase = R::o_Fd + r;
       asm volatile("" : "+v"(fbase));
       double fcur = L[fbase];                                       // dfdy_j[r][cc] of the column ahead
+      auto brow = [](int c) constexpr { return c < P0 ? (c / q) * N + (c % q) : q + (c - P0); };   // (as for the H blocks)
       static_for<IR>([&](auto Ct) {
-        constexpr int c = decltype(Ct)::value, j = c / q, cc = c % q, CC = cc;
+        constexpr int c = decltype(Ct)::value;
+        constexpr bool pcol = c >= P0;
+        constexpr int j = pcol ? 0 : c / q, cc = pcol ? q + (c - P0) : c % q, CC = cc;
         if constexpr (cc == 0) {                                    // (opaque per node: [cc == r] is formed where it is used)
           ro = r;
           asm volatile("" : "+v"(ro));
         }
         const double fd = fcur;
-        if constexpr (c + 1 < IR) fcur = L[fbase + (c + 1) * LDK];
+        if constexpr (c + 1 < IR) fcur = L[fbase + brow(c + 1) * LDK];
         if (JH == 1 || (c >= cfirst && c < clast)) {                // (uniform)
-        const double w = cc < n ? Al[j] : (cc == T ? (c == T ? 1.0 - s_l : (c == TF ? s_l : 0.0)) : Ul[j]);
-        double acc = 0.0;
-        static_for<n>([&](auto KK) {
-          constexpr int k = decltype(KK)::value;
-          constexpr int jp = Ode::JPOS[k * N + CC];
-          if constexpr (jp >= 0) acc = fma(lane_value(Fv[j][jp >> 6], jp & 63), jrow[k], acc);
+        const double w = pcol ? 1.0 : (cc < n ? Al[j] : (cc == T ? (c == T ? 1.0 - s_l : (c == TF ? s_l : 0.0)) : Ul[j]));
+        double acc = 0.0, fdd = h * Dl[j] * fd;                     // h B_il,j (J^_i[r][:] . dfdy_j[:, cc]),  h D_il,j dfdy_j[r][cc]
+        static_for<(pcol ? CS : 1)>([&](auto Jt) {                  // (a parameter column: summed over the nodes)
+          constexpr int jj = pcol ? decltype(Jt)::value : j;
+          double a1 = 0.0;
+          static_for<n>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            constexpr int jp = Ode::JPOS[k * N + CC];
+            if constexpr (jp >= 0) a1 = fma(lane_value(Fv[jj][jp >> 6], jp & 63), jrow[k], a1);
+          });
+          acc = fma(Bl[jj], a1, acc);
+          if constexpr (pcol && jj > 0) fdd = fma(h * Dl[jj], L[fbase + (jj * N + cc) * LDK], fdd);
         });
         constexpr double tsc = (c == T) ? -1.0 : ((c == TF) ? 1.0 : 0.0);
-        double val = he_l * fma(w, jrow[cc], fma(h * Bl[j], acc, tsc * TXJ));
-        val = fma(h * Dl[j], fd, val);
+        double val = he_l * fma(w, jrow[cc], fma(h, acc, tsc * TXJ));
+        val += fdd;
         if constexpr (cc < n) val += (ro == cc) ? Cl[j] : 0.0;
         val = fma(tsc, sd_l, val);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, val), rsrc, jv ? unsigned(jr) * 8u : OOB,
