@@ -59,13 +59,15 @@ struct RowsDims {
   static constexpr int o_END = o_Jd + K * n * LDJ;
   static constexpr int LDS_DOUBLES = o_END;
   static constexpr size_t lds_bytes() { return size_t(LDS_DOUBLES) * 8; }
-  static constexpr bool OK = OK_SHAPE && lds_bytes() <= 160 * 1024 && N <= 64;
+  // (what the form is built for: at most four H blocks, the lane-independent operands of a segment in a few lane-distributed
+  //  registers -- a dense 32-state Jacobian would take 68 of them and spill; such shapes stay with the tile kernel)
+  static constexpr bool OK = OK_SHAPE && lds_bytes() <= 160 * 1024 && N <= 64 && (IR + 63) / 64 <= WAVES &&
+                             Ode::NNZ_J <= 256 && Ode::NNZ_H <= 256;
   // row blocks: H blocks 0 .. NHB-1, then defect-row blocks; owner wave by greedy cost (H block b: its last row + 1 column
   // steps, a defect-row block: IR)
   static constexpr int NHB = (IR + 63) / 64, NJB = (OR + 63) / 64, NITEM = NHB + NJB;
   static constexpr int RB = (IR + NHB - 1) / NHB;                   // rows of an H block (equal blocks: the last one, whose rows have
                                                                     //  every column, is the critical one whatever its size)
-  static_assert(!OK || NHB <= WAVES, "one H block per wave");
   static constexpr int item_cost(int it) { return it < NHB ? 4 * (RB * it + RB < IR ? RB * it + RB : IR) : 3 * IR; }   // (a column of H ~ 4/3 of one of J)
   static constexpr int owner(int it) {                              // items are dealt in the order H_(NHB-1) .. H_0, J_0 ..
     int load[WAVES] = {0, 0, 0, 0};
