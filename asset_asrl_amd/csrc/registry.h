@@ -238,8 +238,10 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
       // resident kernel (defect_resident.h): the ODE results stay in LDS; meshes of at most GR segments per wave
       static const bool no_res = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                              // tuning only
       if (m[MF_RES_GR] > 0 && !no_res && !skip_dense && a.lane_consts_res && t.k[K_RES(a.kmap != nullptr)]) {
-        const int waves = cus * 4 * int(m[MF_RES_WPS]);   // one group per wave up to GR segments per wave, the looped instantiation beyond
+        int waves = cus * 4 * int(m[MF_RES_WPS]);   // one group per wave up to GR segments per wave, the looped instantiation beyond
         static const int env_max = std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS")) : 0;   // tuning only
+        static const int env_grid = std::getenv("ASSET_HIP_RESIDENT_GRID") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_GRID")) : 0;   // tuning only
+        if (env_grid > 0) waves = env_grid;
         const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
         const KRef& kr = one ? t.k[K_RES(a.kmap != nullptr)] : t.k[K_RESL(2, a.kmap != nullptr)];
         if (kr && (one || env_max <= 0 || (a.nseg + waves - 1) / waves <= env_max * int(m[MF_RES_GR])))
