@@ -120,8 +120,17 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_range<0, N>(f); }
 // value of lane `l` (compile time) of a double every lane holds one of: two v_readlane, the result a scalar operand.  How the
 // lane-independent operands reach the FMAs: a coalesced vector load puts 64 of them into one register, and nothing waits --
 // scalar loads return out of order and share their counter with the LDS, so every use of one would drain both
-__device__ __forceinline__ double lane_value(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+// ... and read WHERE it is used: as volatile assembly with a fake input `after` -- the result of the FMA that precedes the use in
+// program order.  As plain builtins the compiler issues every v_readlane of a loop ahead of the FMAs (they have no inputs to wait
+// for), runs out of scalar registers and parks the values in the lanes of spare registers -- v_readlane, v_writelane, v_readlane
+// per operand: 1 100 of the row preparation's 4 900 instructions (25.7 k -> 16.6 k cycles without them; a dependence on the
+// FMA's OTHER operand is not enough: those are all ready before the loop starts).  A wave issues in order anyway.
+template <int l>
+__device__ __forceinline__ double lane_value_at(double v, double after) {
+  int lo, hi;
+  asm volatile("v_readlane_b32 %0, %2, %4\n\tv_readlane_b32 %1, %3, %4"
+               : "=s"(lo), "=s"(hi) : "v"(__double2loint(v)), "v"(__double2hiint(v)), "n"(l), "v"(after));
+  return __hiloint2double(hi, lo);
 }
 
 template <class Ode, int SCH, bool BLOCKED, int LEVEL>
@@ -272,7 +281,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       const bool pblock = p > 0 && R::RB * it + R::RB > P0;          // (uniform) the block holds parameter rows
       const double tsr = !rv ? 0.0 : ((r == T) ? -1.0 : ((r == TF) ? 1.0 : 0.0));
       const lds_double* const fcol = L + R::o_Fd + (jn * N + ccr) * LDK;   // the row's own column of dfdy (read where used: registers)
-      double ht = 0.0;
+      double ht = 0.0, tok = 0.0;
 #pragma unroll
       for (int i = 0; i < K; i++) {
         double d[N];
@@ -292,14 +301,12 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
           for (int pb = 0; pb < p; pb++) d[q + pb] = (par && ccr == q + pb) ? 1.0 : 0.0;
         }
         if ((R::RB * it <= T && T < R::RB * it + R::RB) || (R::RB * it <= TF && TF < R::RB * it + R::RB)) {   // a time row: -+ sum_j B_ij f_j on it
-#pragma unroll
-          for (int k = 0; k < n; k++) d[k] = fma(tsr, lane_value(SBv[i], k), d[k]);
+          static_for<n>([&](auto KK) { constexpr int k = decltype(KK)::value; d[k] = fma(tsr, lane_value_at<k>(SBv[i], tok), d[k]); tok = d[k]; });
         }
         d[T] = !rv ? 0.0 : ((r == T) ? 1.0 - ctab.s[i] : ((r == TF) ? ctab.s[i] : 0.0));   // (T, TF < P0: never a parameter row)
 #pragma unroll
         for (int cc = n + 1; cc < q; cc++) d[cc] = (!par && ccr == cc) ? ur : 0.0;
-#pragma unroll
-        for (int b = 0; b < N; b++) ht = fma(ctab.E[i] * lane_value(gv[i], b), d[b], ht);
+        static_for<N>([&](auto BB) { constexpr int b = decltype(BB)::value; ht = fma(ctab.E[i] * lane_value_at<b>(gv[i], tok), d[b], ht); tok = ht; });
         if constexpr (LEVEL >= 2) {
 #pragma unroll
         for (int b = 0; b < N; b++) Mi[i][b] = 0.0;
@@ -308,9 +315,10 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
           constexpr int hp = Ode::HPOS[e];
           if constexpr (hp >= 0) {
             constexpr int b = NZ::v.ha[hp], l = NZ::v.hb[hp];
-            const double u = lane_value(Hv[i][hp >> 6], hp & 63);
+            const double u = lane_value_at<(hp & 63)>(Hv[i][hp >> 6], tok);   // (the token: the FMA before, in program order)
             Mi[i][b] = fma(u, d[l], Mi[i][b]);
-            if constexpr (b != l) Mi[i][l] = fma(u, d[b], Mi[i][l]);
+            tok = Mi[i][b];
+            if constexpr (b != l) { Mi[i][l] = fma(u, d[b], Mi[i][l]); tok = Mi[i][l]; }
           }
         });
         const double he = h * ctab.E[i];
@@ -333,8 +341,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       if constexpr (LEVEL >= 2) {
 #pragma unroll
       for (int i = 0; i < K; i++)
-#pragma unroll
-        for (int k = 0; k < n; k++) TX = fma(lane_value(SBv[i], k), Mi[i][k], TX);
+        static_for<n>([&](auto KK) { constexpr int k = decltype(KK)::value; TX = fma(lane_value_at<k>(SBv[i], TX), Mi[i][k], TX); });
       }
       if (a.AGX && a.L && rv) {
         double wl = 0.0;
@@ -425,7 +432,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
               constexpr int k = decltype(KK)::value;
               constexpr int jp = Ode::JPOS[k * N + CC];
               if constexpr (jp >= 0) {
-                const double f = lane_value(Fv[jj][jp >> 6], jp & 63);
+                const double f = lane_value_at<(jp & 63)>(Fv[jj][jp >> 6], acci[K - 1]);
 #pragma unroll
                 for (int i = 0; i < K; i++) acci[i] = fma(f, Mi[i][k], acci[i]);
               }
@@ -436,7 +443,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
           val = fma(h, acc, val);
           if constexpr (c == T) val -= txh;
           if constexpr (c == TF) val += txh;
-          val = fma(tsrow, lane_value(HTv[c >> 6], c & 63), val);
+          val = fma(tsrow, lane_value_at<(c & 63)>(HTv[c >> 6], val), val);
           const double hc = hcur;
           if constexpr (c + 1 < IR) hcur = L[hbase + brow(c + 1) * LDH];
           if constexpr (!pcol) val = fma(indj, hc, val);
@@ -503,7 +510,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
           static_for<n>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
             constexpr int jp = Ode::JPOS[k * N + CC];
-            if constexpr (jp >= 0) a1 = fma(lane_value(Fv[jj][jp >> 6], jp & 63), jrow[k], a1);
+            if constexpr (jp >= 0) a1 = fma(lane_value_at<(jp & 63)>(Fv[jj][jp >> 6], a1), jrow[k], a1);
           });
           acc = fma(Bl[jj], a1, acc);
           if constexpr (pcol && jj > 0) fdd = fma(h * Dl[jj], L[fbase + (jj * N + cc) * LDK], fdd);
