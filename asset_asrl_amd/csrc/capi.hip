@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <memory>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -309,35 +311,31 @@ int asset_hip_jit_plugin(const char* name, const char* source, const char* funct
   }
   // The module stays with the process: its code object is loaded on every device a handle uses it on (registry.h:
   // RtcModule) -- here on the current one, to read its meta table.
-  auto* rtc = new asset_hip::RtcModule();
+  // (owned here until the entry is registered: every failure path below unloads the module and frees the code object)
+  std::unique_ptr<asset_hip::RtcModule> rtc(new asset_hip::RtcModule());
   rtc->code.swap(blob.code);
   rtc->names.swap(blob.names);
-  const asset_hip::RtcModule::PerDevice* pd = nullptr;
-  hipError_t e = rtc->on_current_device(&pd);
-  if (e != hipSuccess) {
-    delete rtc;
-    return hipfail(e, "loading the run-time module (hipModuleLoadData / hipModuleGetFunction)");
-  }
-  auto* table = new asset_hip::KernelTable();
+  hipModule_t mod = nullptr;
+  hipError_t e = rtc->module_on_current_device(&mod);
+  if (e != hipSuccess) return hipfail(e, "loading the run-time module (hipModuleLoadData / hipModuleGetFunction)");
+  std::unique_ptr<asset_hip::KernelTable> table(new asset_hip::KernelTable());
   hipDeviceptr_t dmeta = nullptr;
   size_t mbytes = 0;
-  e = hipModuleGetGlobal(&dmeta, &mbytes, pd->mod, "asset_rtc_meta");
-  if (e != hipSuccess || mbytes != sizeof table->meta) {
-    delete table;
+  e = hipModuleGetGlobal(&dmeta, &mbytes, mod, "asset_rtc_meta");
+  if (e != hipSuccess || mbytes != sizeof table->meta)
     return fail(ASSET_HIP_ECOMPILE, "the module has no asset_rtc_meta table of the expected size (rtc_device.h)");
-  }
-  HIP_TRY(hipMemcpy(table->meta, reinterpret_cast<void*>(dmeta), sizeof table->meta, hipMemcpyDeviceToHost));
+  if ((e = hipMemcpy(table->meta, reinterpret_cast<void*>(dmeta), sizeof table->meta, hipMemcpyDeviceToHost)) != hipSuccess)
+    return hipfail(e, "reading asset_rtc_meta");
   if (table->meta[asset_hip::MF_KIND] != kind || (kind == 1 && (table->meta[asset_hip::MF_MODE] != mode ||
-                                                               table->meta[asset_hip::MF_BLOCKED] != (blocked ? 1 : 0)))) {
-    delete table;
+                                                               table->meta[asset_hip::MF_BLOCKED] != (blocked ? 1 : 0))))
     return fail(ASSET_HIP_EINVAL, "the module was compiled for another transcription / kind than requested");
-  }
   for (auto& n : rtc->names) {
-    table->k[n.first].rtc = rtc;
+    table->k[n.first].rtc = rtc.get();
     table->k[n.first].slot = n.first;
   }
+  rtc.release();                        // the module and its table stay with the process from here on
   auto* ke = new asset_hip::KernelEntry();
-  asset_hip::entry_from_table(*ke, strdup(name), table);
+  asset_hip::entry_from_table(*ke, strdup(name), table.release());
   ke->next = asset_hip::registry_head();
   asset_hip::registry_head() = ke;
   return 0;
@@ -534,7 +532,7 @@ static int fill_args(asset_hip_defect_t h, int what, const double* dX, const dou
   a.work = h->d_work;
   a.lane_consts = level >= 1 ? h->d_lane[level] : nullptr;
   a.lane_consts_res = h->d_lane[0];
-  static const bool no_affine = std::getenv("ASSET_HIP_NO_AFFINE") != nullptr;                                 // tuning only
+  static const bool no_affine = asset_hip::tuning_env("ASSET_HIP_NO_AFFINE") != nullptr;                                // tuning only
   a.affine = no_affine ? 0 : h->affine, a.aff_v0 = h->aff_v0, a.aff_vs = h->aff_vs, a.aff_c0 = h->aff_c0, a.aff_cs = h->aff_cs;
   a.appl_consts = h->d_aconst;
   if (h->ke->naconst > 0 && !h->d_aconst)

@@ -22,6 +22,15 @@
 #define ASSET_LANE_REPLICAS 64        // copies of the dense stage's per-lane constant table (capi.hip)
 #endif
 
+// Measurement builds (tools/build_one.py with -DASSET_TUNING_BUILD): clock stamps written over FX / AGX (ASSET_TIMING,
+// ASSET_WALLCLOCK, ASSET_FUNC_TIMING) and elimination experiments that compute WRONG results on purpose (ASSET_EXP_*).  A
+// production build that defines one of them -- through ASSET_HIP_JIT flags or a build environment -- is refused.
+#if (defined(ASSET_TIMING) || defined(ASSET_WALLCLOCK) || defined(ASSET_FUNC_TIMING) || defined(ASSET_EXP_NOWS) ||       \
+     defined(ASSET_EXP_NULL) || defined(ASSET_EXP_ONEUNIT) || defined(ASSET_EXP_UNITREP) || defined(ASSET_EXP_ROWS)) && \
+    !defined(ASSET_TUNING_BUILD)
+#error "ASSET_TIMING / ASSET_WALLCLOCK / ASSET_EXP_* change what the kernels write: measurement builds only (-DASSET_TUNING_BUILD)"
+#endif
+
 namespace asset_hip {
 
 static __constant__ LglTab d_lgl_tab[4] = ASSET_LGL_TABLE_INIT;

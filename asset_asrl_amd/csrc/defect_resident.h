@@ -30,6 +30,10 @@ template <class D>
 struct ResDims {
   using Ode = typename D::ode_t;
   static constexpr int K = D::K, CS = D::CS, n = D::n, N = D::N, q = D::q, IR = D::IR, OR = D::OR, IRP = D::IRP;
+  // interior points that are evaluated: none for Trapezoidal (TrapezoidalDefects.h:263-435 has no interior point; Dims carries
+  // one of weight E = 0 so that the sizes and the tables keep their shape) -- its sections of the slot are never written, and
+  // nothing below may read them
+  static constexpr int KE = D::TRAP ? 0 : K;
   // slot of one segment (doubles): the sections of Dims (z | lam | Cf | CJ | Cg | CH | If | IJ | Ig | IH), a cell that always
   // holds 0.0 (target of every "no entry" offset), then the saved transcendentals of the cardinal nodes -- which alias the Cg
   // section when they fit (P1 writes them, P3 reads its own into registers before it writes g_j there)
@@ -62,7 +66,7 @@ struct ResDims {
 #ifndef ASSET_RES_MAX_TJ
 #define ASSET_RES_MAX_TJ 2
 #endif
-  static constexpr bool DENSE_OK = !D::TRAP && !D::WIDE && D::TJ <= ASSET_RES_MAX_TJ && N + 1 <= 16 && GR >= 2 && D::STAGED;
+  static constexpr bool DENSE_OK = !D::WIDE && D::TJ <= ASSET_RES_MAX_TJ && N + 1 <= 16 && GR >= 2 && D::STAGED;
   static constexpr bool OK = DENSE_OK && Ode::NUNITS == 1;
   // heavy right-hand sides (one workgroup per output unit, defect_units.h): the ODE results are in the workspace when the
   // dense part starts -- the kernel's GIVEN form copies a group's slots from there and goes on as usual
@@ -87,7 +91,7 @@ struct ResDims {
 #ifndef ASSET_RES_JRIDE
 #define ASSET_RES_JRIDE 1
 #endif
-  static constexpr bool JRIDE = ASSET_RES_JRIDE && (N + 1 + n <= 16) && t_off(K - 1) >= 0;
+  static constexpr bool JRIDE = ASSET_RES_JRIDE && !D::TRAP && (N + 1 + n <= 16) && t_off(K - 1) >= 0;
   // 16 dead cells behind the last buffer: where the lanes without a J row in an accumulator entry write instead (a store under
   // a lane condition costs an exec-mask round trip each; 24 of them per segment)
   static constexpr int t_end = t_off(K - 1) + TB;
@@ -242,6 +246,23 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(l
   CardInRes<D> in{z, w, sv, j};
   OdeOutRes<D> out{nullptr, S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
   Ode::fjgh_load(in, out);
+}
+
+// Trapezoidal, all derivatives (TrapezoidalDefects.h:263-435): there is no interior point, so the adjoint weights of the
+// cardinal nodes do not wait for anything -- w_j = lam D_j h (:300-305 with D = 1/2) -- and ONE phase evaluates f_j, J_j,
+// g_j = J_j^T w_j and H_j = w_j^T d2f at node j (the whole body: nothing is saved, nothing reloaded)
+template <class Ode, class D>
+__device__ __attribute__((noinline, not_tail_called)) void res_cardinal_all(lds_double* S, int j, const LglTab* tabp, bool have_lam) {
+  constexpr int n = D::n, N = D::N, T = D::T;
+  const LglTab& tab = *tabp;
+  const lds_double* z = S + D::w_z;
+  const double h = z[D::TF] - z[T];
+  double w[n];
+#pragma unroll
+  for (int k = 0; k < n; k++) w[k] = have_lam ? S[D::w_lam + k] * (tab.D[0][j] * h) : 0.0;
+  CardInRes<D> in{z, w, nullptr, j};
+  OdeOutRes<D> out{S + D::w_Cf + j * n, S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
+  Ode::fjgh(in, out);
 }
 
 // ---------------------------------------------------------------------------------------------- per-lane constants
@@ -445,7 +466,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using R = ResDims<D>;
   using LCT = ResLane<Ode, D>;
-  constexpr int CS = D::CS, K = D::K, n = D::n, q = D::q, N = D::N, T = D::T, TF = D::TF;
+  constexpr int CS = D::CS, K = D::K, KE = R::KE, n = D::n, q = D::q, N = D::N, T = D::T, TF = D::TF;
   constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, KS = D::KS, TI = D::TI, TJ = D::TJ, GR = R::GR, SLOT = R::SLOT;
   constexpr bool CFULL = (IR == IRP);
   static_assert(GR * CS <= 64, "one pass per phase");
@@ -574,6 +595,13 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     }
   }
   RTS();
+  if constexpr (D::TRAP && LEVEL >= 2) {   // Trapezoidal: one phase (the weights w_j need lam and h: after the gather)
+    wave_lds_sync();
+    if (lane < gcount * CS) {
+      const int g = lane / CS, j = lane - g * CS;
+      res_cardinal_all<Ode, D>(slots + g * SLOT, j, &tab, a.L != nullptr);
+    }
+  } else {
   if (lane < gcount * CS) {            // P1
     const int g = lane / CS, j = lane - g * CS;
     if (a.affine && D::p == 0) res_cardinal_value<Ode, D, LEVEL>(slots + g * SLOT, j, a.X + (a.aff_v0 + (seg0 + g) * a.aff_vs), nullptr);
@@ -581,17 +609,20 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   }
   wave_lds_sync();
   RTS();
-  if (lane < gcount * K) {             // P2
-    const int g = lane / K, i = lane - g * K;
-    res_interior<Ode, D, LEVEL>(slots + g * SLOT, i, &tab, a.L != nullptr);
+  if constexpr (!D::TRAP) {
+    if (lane < gcount * K) {           // P2
+      const int g = lane / K, i = lane - g * K;
+      res_interior<Ode, D, LEVEL>(slots + g * SLOT, i, &tab, a.L != nullptr);
+    }
+    wave_lds_sync();
   }
-  wave_lds_sync();
   RTS();
   if constexpr (LEVEL >= 2) {
     if (lane < gcount * CS) {          // P3
       const int g = lane / CS, j = lane - g * CS;
       res_cardinal_second<Ode, D>(slots + g * SLOT, j, &tab);
     }
+  }
   }
   }   // (!GIVEN)
   RTS();
@@ -646,7 +677,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     for (int jt = 0; jt < TJ; jt++) {
       const int jr = 16 * jt + lr;
       double fj[CS], zj[CS];
-      const double fi = S[D::w_If + (jr < OR ? jr : 0)];   // f^_il[rl] (its weight tE is zero in the lanes without a row)
+      const double fi = KE > 0 ? S[D::w_If + (jr < OR ? jr : 0)] : 0.0;   // f^_il[rl] (its weight tE is zero in the lanes without a row)
 #pragma unroll
       for (int jj = 0; jj < CS; jj++) { fj[jj] = S[D::w_Cf + jj * n + lc.rl[jt]]; zj[jj] = S[D::w_z + jj * q + lc.rl[jt]]; }
       double sdv = lc.tE[jt] * fi, fx = 0.0;
@@ -685,7 +716,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
         for (int jj = 0; jj < CS; jj++) f[jj] = (b < n) ? S[D::w_Cf + jj * n + (b < n ? b : 0)] : 0.0;
 #pragma unroll
-        for (int i = 0; i < K; i++) {
+        for (int i = 0; i < KE; i++) {
           double s = 0.0;
 #pragma unroll
           for (int jj = 0; jj < CS; jj++) s += ctab.B[i][jj] * f[jj];
@@ -703,7 +734,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         for (int kk = 0; kk < KS; kk++) part = fma(tabL[lc.wlo[ct][kk]], jv[kk], part);
         agJ[ct] = part;
 #pragma unroll
-        for (int i = 0; i < K; i++) {
+        for (int i = 0; i < KE; i++) {
           const double hb = h * tabrow(lc.cbo[ct], i);
 #pragma unroll
           for (int kk = 0; kk < KS; kk++)
@@ -722,7 +753,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
                 agJ[ct] = fma(tabL[lc.wpo[ct][kk] + jj * wst], jp[jj], agJ[ct]);
               }
 #pragma unroll
-              for (int i = 0; i < K; i++) {
+              for (int i = 0; i < KE; i++) {
                 double sp = 0.0;
 #pragma unroll
                 for (int jj = 0; jj < CS; jj++) sp = fma(ctab.B[i][jj], jp[jj], sp);
@@ -753,7 +784,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     };
     double ah[K][KS];                                  // A operand of the M products: [h E_i H^_i ; E_i g^_i]
 #pragma unroll
-    for (int i = 0; i < K; i++) {
+    for (int i = 0; i < KE; i++) {
       const double sc = (lr == N) ? ctab.E[i] : h * ctab.E[i];     // the g^ row is scaled by E_i, the H^ rows by h E_i
 #pragma unroll
       for (int kk = 0; kk < KS; kk++)           // (LEVEL 1: no H^ -- its section of the slot holds nothing)
@@ -837,11 +868,11 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
         for (int ct = 0; ct < TI; ct++) accJ[ct][jt] = dc_tile(ct, jt);     // (one row tile at a time: TI accumulators live, not TI TJ)
 #pragma unroll
-        for (int i = 0; i < K; i++) hel = (lc.il[jt] == i) ? h * ctab.E[i] : hel;
+        for (int i = 0; i < KE; i++) hel = (lc.il[jt] == i) ? h * ctab.E[i] : hel;
 #pragma unroll
-        for (int kk = 0; kk < KS; kk++) bj[kk] = hel * S[lc.jo[jt][kk]];
+        for (int kk = 0; kk < KS; kk++) bj[kk] = KE > 0 ? hel * S[lc.jo[jt][kk]] : 0.0;
 #pragma unroll
-        for (int i = 0; i < K; i++) {
+        for (int i = 0; i < KE; i++) {
           if (i * n >= 16 * jt + 16 || i * n + n <= 16 * jt) continue;      // (no defect row of interior i in this row tile)
 #pragma unroll
           for (int kk = 0; kk < KS; kk++) {
@@ -888,7 +919,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       double hi = 0.0;
       if constexpr (LEVEL < 2 && !R::JRIDE) {           // no M product to take row N from: E_i g^_i . DI_i over this lane's rows
 #pragma unroll
-        for (int i = 0; i < K; i++)
+        for (int i = 0; i < KE; i++)
 #pragma unroll
           for (int kk = 0; kk < KS; kk++) {
             const int b = 4 * kk + lk;
@@ -901,14 +932,14 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       //  after it was issued instead of right behind it, where the wave would sit out the 64 cycles of the instruction)
       d4 Mi[K];
 #pragma unroll
-      for (int i = 0; i < K; i++) {
+      for (int i = 0; i < KE; i++) {
         if constexpr (LEVEL < 2 && !R::JRIDE) continue;
         Mi[i] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) Mi[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[i][kk], dv[rt][i][kk], Mi[i], 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < K; i++) {
+      for (int i = 0; i < KE; i++) {
         if constexpr (LEVEL < 2 && !R::JRIDE) continue;
         hi += Mi[i][R::vN];              // entry v: row lk + 4v of M_i (row N: E_i g^_i . DI_i), column 16rt + lr
         if constexpr (R::JRIDE) {        // rows N+1 .. N+n: J_i[r][16rt + lr] -> T_i[lr][r]

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -31,14 +32,24 @@ struct RtcModule {
     std::vector<hipFunction_t> fn;                  // by kernel slot
   };
   std::mutex m;
-  std::vector<PerDevice> dev;                       // by device ordinal
-  // the functions of the CURRENT device (loads the module there at first use)
-  hipError_t on_current_device(const PerDevice** out) {
+  std::vector<PerDevice> dev;                       // by device ordinal; sized ONCE (hipGetDeviceCount) and never resized
+  ~RtcModule() {
+    for (auto& pd : dev)
+      if (pd.mod) (void)hipModuleUnload(pd.mod);
+  }
+  // kernel `slot` on the CURRENT device (loads the module there at first use).  The function handle is copied out under the
+  // lock: no pointer into `dev` outlives it.
+  hipError_t on_current_device(int slot, hipFunction_t* out) {
     int d = 0;
     hipError_t e = hipGetDevice(&d);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> g(m);
-    if (int(dev.size()) <= d) dev.resize(d + 1);
+    if (dev.empty()) {
+      int nd = 0;
+      if ((e = hipGetDeviceCount(&nd)) != hipSuccess) return e;
+      dev.resize(nd > d + 1 ? nd : d + 1);
+    }
+    if (d >= int(dev.size())) return hipErrorInvalidDevice;
     PerDevice& pd = dev[d];
     if (!pd.mod) {
       hipModule_t mod = nullptr;
@@ -54,7 +65,25 @@ struct RtcModule {
       pd.fn.swap(fn);
       pd.mod = mod;
     }
-    *out = &pd;
+    if (slot < 0 || slot >= int(pd.fn.size()) || !pd.fn[slot]) return hipErrorInvalidDeviceFunction;
+    *out = pd.fn[slot];
+    return hipSuccess;
+  }
+  // the module handle of the current device (loaded if need be): for reading the module's constants
+  hipError_t module_on_current_device(hipModule_t* out) {
+    int first = -1;
+    for (auto& n : names) { first = n.first; break; }
+    hipFunction_t f = nullptr;
+    if (first >= 0) {
+      hipError_t e = on_current_device(first, &f);
+      if (e != hipSuccess) return e;
+    }
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> g(m);
+    if (d >= int(dev.size()) || !dev[d].mod) return hipErrorInvalidValue;
+    *out = dev[d].mod;
     return hipSuccess;
   }
 };
@@ -67,10 +96,10 @@ struct KRef {
 };
 inline hipError_t klaunch(const KRef& k, dim3 grid, dim3 block, size_t shmem, hipStream_t st, void** args) {
   if (k.rtc) {
-    const RtcModule::PerDevice* pd = nullptr;
-    hipError_t e = k.rtc->on_current_device(&pd);
+    hipFunction_t fn = nullptr;
+    hipError_t e = k.rtc->on_current_device(k.slot, &fn);
     if (e != hipSuccess) return e;
-    return hipModuleLaunchKernel(pd->fn[k.slot], grid.x, grid.y, grid.z, block.x, block.y, block.z, unsigned(shmem), st, args, nullptr);
+    return hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, unsigned(shmem), st, args, nullptr);
   }
   if (!k.host) return hipErrorInvalidDeviceFunction;
   if (shmem > 64 * 1024) {
@@ -157,6 +186,16 @@ struct Registrar {
 #endif
 
 // ---- the launcher ---------------------------------------------------------------------------------------------------
+// Dispatch knobs of the measurement scripts (tools/): read ONLY when the process opts in with ASSET_HIP_TUNING=1, so that a
+// stray variable in a production environment cannot change which kernels run.  With the opt-in, every knob that takes effect is
+// reported once on stderr.
+inline const char* tuning_env(const char* name) {
+  static const bool on = [] { const char* v = std::getenv("ASSET_HIP_TUNING"); return v && std::atoi(v) != 0; }();
+  if (!on) return nullptr;
+  const char* v = std::getenv(name);
+  if (v) std::fprintf(stderr, "asset_hip: tuning knob %s=%s is in effect (ASSET_HIP_TUNING=1)\n", name, v);
+  return v;
+}
 inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalArgs& a, int cus, hipStream_t st) {
   const long long* m = t.meta;
   const size_t bytes_ode = size_t(m[MF_BYTES_ODE]), bytes_dense = size_t(m[MF_BYTES_DENSE]);
@@ -174,14 +213,14 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
   per_cu_b = per_cu_b < 1 ? 1 : (per_cu_b >= 8 ? 8 : (per_cu_b >= 6 ? 6 : (per_cu_b >= 4 ? 4 : per_cu_b)));
   int grid_b = a.nseg < cus * per_cu_b ? a.nseg : cus * per_cu_b;
   const int wide_wgs = int(m[MF_WIDE_WGS]);   // four-wave workgroups per CU (defect_wide.h)
-  static const int env_b = std::getenv("ASSET_HIP_GRID_B") ? std::atoi(std::getenv("ASSET_HIP_GRID_B")) : 0;  // tuning only
+  static const int env_b = tuning_env("ASSET_HIP_GRID_B") ? std::atoi(std::getenv("ASSET_HIP_GRID_B")) : 0;  // tuning only
   if (env_b > 0) grid_b = env_b < a.nseg ? env_b : a.nseg;
-  static const bool skip_dense = std::getenv("ASSET_HIP_SKIP_DENSE") != nullptr;                               // tuning only
+  static const bool skip_dense = tuning_env("ASSET_HIP_SKIP_DENSE") != nullptr;                               // tuning only
   auto ode_stage = [&](int lv) { return klaunch(t.k[K_LGL(lv, 1, false)], dim3(grid_a), dim3(64), bytes_ode, st, kargs); };
   // dense stage: single-wave workgroups, or (wide shapes, defect_wide.h) one four-wave workgroup per CU
   auto dense_stage = [&](int lv) {
     const bool asmb = a.kmap != nullptr;   // KKT entries added straight into the solver's value array
-    static const bool no_rows = std::getenv("ASSET_HIP_NO_ROWS") != nullptr;                                   // tuning only
+    static const bool no_rows = tuning_env("ASSET_HIP_NO_ROWS") != nullptr;                                   // tuning only
     // (LGL3: two nodes, IR = 2 q -- one of the two H blocks nearly empty: 487 against 399 us for 12 500 32-state segments; kept
     //  with the tile kernel)
     if (wide && lv >= 1 && !asmb && !no_rows && m[MF_ROWS_LDS_BYTES] > 0 && m[MF_CS] >= 3 && t.k[lv == 2 ? K_ROWS : K_ROWS1]) {
@@ -195,7 +234,7 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
   };
   hipError_t e;
   // constraints_adjointgradient (evalRHS): value and J^T lam wanted, no Jacobian -- one launch of the vector-Jacobian kernel
-  static const bool no_adj = std::getenv("ASSET_HIP_NO_ADJGRAD_KERNEL") != nullptr;                            // tuning only
+  static const bool no_adj = tuning_env("ASSET_HIP_NO_ADJGRAD_KERNEL") != nullptr;                            // tuning only
   if (level == 1 && !a.KKT && !a.kmap && a.AGX && a.L && !no_adj && t.k[K_ADJGRAD]) {
     const int gp = int(m[MF_ADJ_GP]);
     return klaunch(t.k[K_ADJGRAD], dim3((a.nseg + gp - 1) / gp), dim3(64), size_t(m[MF_ADJ_LDS_BYTES]), st, kargs);
@@ -207,17 +246,17 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
   switch (level) {
     case 0: return ode_stage(0);
     case 1: {
-      static const bool no_res1 = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
+      static const bool no_res1 = tuning_env("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
       if (m[MF_RES_GR] > 0 && !no_res1 && !skip_dense && a.lane_consts_res && t.k[K_RES1(a.kmap != nullptr)]) {
         const int waves = cus * 4 * int(m[MF_RES_WPS]);   // resident kernel, Jacobian kinds (defect_resident.h, LEVEL 1)
         const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
         const KRef& kr = one ? t.k[K_RES1(a.kmap != nullptr)] : t.k[K_RESL(1, a.kmap != nullptr)];
         if (kr) return klaunch(kr, dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
       }
-      static const bool no_fuse1 = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                                // tuning only
+      static const bool no_fuse1 = tuning_env("ASSET_HIP_NO_FUSE") != nullptr;                                // tuning only
       if (m[MF_FUSED] && !no_fuse1 && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]) && t.k[K_LGL(1, 3, a.kmap != nullptr)])
         return klaunch(t.k[K_LGL(1, 3, a.kmap != nullptr)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);   // one launch
-      static const bool no_units1 = std::getenv("ASSET_HIP_NO_UNITS") != nullptr;                              // tuning only
+      static const bool no_units1 = tuning_env("ASSET_HIP_NO_UNITS") != nullptr;                              // tuning only
       if (m[MF_NUNITS] > 1 && !no_units1 && t.k[K_UNITSJ] && a.nseg * int(m[MF_CS]) <= 64 * cus) {
         // heavy right-hand side: one wave per output unit (defect_units.h, PHASE 3), one launch -- while the mesh leaves SIMDs
         // idle: the units recompute what they share, and from ~16 cardinal points per SIMD on the one-body-per-lane stage
@@ -236,11 +275,11 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
     }
     case 2: {
       // resident kernel (defect_resident.h): the ODE results stay in LDS; meshes of at most GR segments per wave
-      static const bool no_res = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                              // tuning only
+      static const bool no_res = tuning_env("ASSET_HIP_NO_RESIDENT") != nullptr;                              // tuning only
       if (m[MF_RES_GR] > 0 && !no_res && !skip_dense && a.lane_consts_res && t.k[K_RES(a.kmap != nullptr)]) {
         int waves = cus * 4 * int(m[MF_RES_WPS]);   // one group per wave up to GR segments per wave, the looped instantiation beyond
-        static const int env_max = std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS")) : 0;   // tuning only
-        static const int env_grid = std::getenv("ASSET_HIP_RESIDENT_GRID") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_GRID")) : 0;   // tuning only
+        static const int env_max = tuning_env("ASSET_HIP_RESIDENT_MAX_GROUPS") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS")) : 0;   // tuning only
+        static const int env_grid = tuning_env("ASSET_HIP_RESIDENT_GRID") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_GRID")) : 0;   // tuning only
         if (env_grid > 0) waves = env_grid;
         const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
         const KRef& kr = one ? t.k[K_RES(a.kmap != nullptr)] : t.k[K_RESL(2, a.kmap != nullptr)];
@@ -249,10 +288,10 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
       }
       if (m[MF_FUSED]) {
         // single launch when every workgroup's share fits one group of the fused kernel (defect_kernels.h, STAGE 3)
-        static const bool no_fuse = std::getenv("ASSET_HIP_NO_FUSE") != nullptr;                               // tuning only
+        static const bool no_fuse = tuning_env("ASSET_HIP_NO_FUSE") != nullptr;                               // tuning only
         if (m[MF_FUSED2]) {
           // two-wave workgroups: the ODE bodies are issued once per pair of waves (defect_kernels.h, STAGE 4)
-          static const bool no_fuse2 = std::getenv("ASSET_HIP_NO_FUSE2") != nullptr;                           // tuning only
+          static const bool no_fuse2 = tuning_env("ASSET_HIP_NO_FUSE2") != nullptr;                           // tuning only
           const int pairs = grid_b / 2;
           // (measured, 10 000 segments: TwoBody-LGL5-BlockConstant 42.2 -> 39.6 us, Reentry-LGL7 43.2 -> 43.0 us; with 2-3
           //  segments per wave -- Reentry-LGL7 x 5 000 -- the pair's barriers cost more than the shared bodies save:
@@ -265,7 +304,7 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         if (!no_fuse && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]))
           return klaunch(t.k[K_LGL(2, 3, a.kmap != nullptr)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);
       }
-      static const bool no_units = std::getenv("ASSET_HIP_NO_UNITS") != nullptr;                               // tuning only
+      static const bool no_units = tuning_env("ASSET_HIP_NO_UNITS") != nullptr;                               // tuning only
       if (m[MF_NUNITS] > 1 && !no_units) {
         // heavy right-hand side: the ODE stage runs one wave per output unit (defect_units.h)
         const int nunits = int(m[MF_NUNITS]), gpmax = 64 / int(m[MF_CS]);
@@ -281,7 +320,7 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         return e;
       }
       if (skip_dense) return hipSuccess;
-      static const bool no_resd = std::getenv("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
+      static const bool no_resd = tuning_env("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
       if (m[MF_RESD_GR] > 0 && !no_resd && a.lane_consts_res && t.k[K_RESD(a.kmap != nullptr)]) {
         const int waves = cus * 4 * int(m[MF_RES_WPS]);   // dense part of the resident kernel over the slots the units wrote
         return klaunch(t.k[K_RESD(a.kmap != nullptr)], dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);

@@ -13,6 +13,20 @@ def _dptr(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+_STREAM_LEGACY = 1      # include/asset_hip.h: ASSET_HIP_STREAM_LEGACY = hipStreamLegacy, the null stream named explicitly
+
+
+def _stream_arg(stream):
+    """The `stream` argument of the C ABI: None -> NULL (the handle's own stream); a raw hipStream_t (int) as it is; a
+    torch stream by its handle -- except that torch's DEFAULT stream has handle 0, which the C ABI would read as "no
+    stream given" and launch on the handle's private stream, where nothing torch enqueues afterwards is ordered behind
+    it.  The null stream is therefore passed by its explicit name."""
+    if stream is None:
+        return None
+    h = stream if isinstance(stream, int) else stream.cuda_stream
+    return C.c_void_p(h if h else _STREAM_LEGACY)
+
+
 class DefectEvaluator:
     """Evaluates the defect constraint of ``nseg`` mesh segments on a HIP device.
 
@@ -137,7 +151,7 @@ class DefectEvaluator:
         return fx, agx
 
     def eval_assembled_device(self, what: int, X, L, fx, agx, kkt_values, stream=None):
-        st = None if stream is None else C.c_void_p(stream if isinstance(stream, int) else stream.cuda_stream)
+        st = _stream_arg(stream)
         _lib.check(_lib.lib().asset_hip_defect_eval_assembled_device(self._h, what, self._p(X), self._p(L), self._p(fx),
                                                                      self._p(agx), self._p(kkt_values), st),
                    "asset_hip_defect_eval_assembled_device")
@@ -145,7 +159,7 @@ class DefectEvaluator:
     def eval_kkt_device(self, what: int, X, L, FXE, AGX, kkt_values, stream=None):
         """Constraint values ADDED into FXE[n_equal], adjoint gradient into AGX[n_primal], KKT entries into kkt_values
         (as eval_assembled_device): the constraint's whole share of an evalKKT on the device, bitwise repeatable."""
-        st = None if stream is None else C.c_void_p(stream if isinstance(stream, int) else stream.cuda_stream)
+        st = _stream_arg(stream)
         _lib.check(_lib.lib().asset_hip_defect_eval_kkt_device(self._h, what, self._p(X), self._p(L), self._p(FXE),
                                                                self._p(AGX), self._p(kkt_values), st),
                    "asset_hip_defect_eval_kkt_device")
@@ -158,7 +172,7 @@ class DefectEvaluator:
         return C.c_void_p(t if isinstance(t, int) else t.data_ptr())
 
     def eval_device(self, what: int, X, L, fx, agx, kkt, stream=None):
-        st = None if stream is None else C.c_void_p(stream if isinstance(stream, int) else stream.cuda_stream)
+        st = _stream_arg(stream)
         _lib.check(_lib.lib().asset_hip_defect_eval_device(self._h, what, self._p(X), self._p(L), self._p(fx),
                                                            self._p(agx), self._p(kkt), st),
                    "asset_hip_defect_eval_device")
@@ -168,7 +182,7 @@ class DefectEvaluator:
         loop (or bench.py) pays about a microsecond of host time per call instead of the ~20 us of `eval_device`.  The
         tensors must stay alive (and in place) while the callable is used."""
         fn = _lib.lib().asset_hip_defect_eval_device
-        st = None if stream is None else C.c_void_p(stream if isinstance(stream, int) else stream.cuda_stream)
+        st = _stream_arg(stream)
         args = (self._h, what, self._p(X), self._p(L), self._p(fx), self._p(agx), self._p(kkt), st)
         keep = (X, L, fx, agx, kkt)
 

@@ -95,6 +95,7 @@ class Phase:
         self.switchTranscriptionMode(mode)
         self.ActiveTraj = None
         self.numDefects = 0
+        self.DefBinSpacing, self.DefsPerBin = np.array([0.0, 1.0]), np.array([1], dtype=int)
         self._ev = None
         self._indexer = None
         self.AutoScaling = False
@@ -151,34 +152,72 @@ class Phase:
         return self.ControlMode == "BlockConstant" and self.ode.UVars() > 0
 
     # ---- trajectory -------------------------------------------------------------------------
-    def setTraj(self, traj: Sequence, nsegs: int):
-        """Resample `traj` (rows [x,t,u,p]) onto `nsegs` equal segments with the scheme's cardinal spacing
-        (linear interpolation in time, as the reference's default LerpIG does)."""
+    def setTraj(self, traj: Sequence, nsegs, DefsPerBin=None):
+        """Resample `traj` (rows [x,t,u,p]) onto the phase's mesh with the scheme's cardinal spacing (linear interpolation
+        in time, as the reference's default LerpIG does).  ``setTraj(traj, nsegs)``: `nsegs` equal segments;
+        ``setTraj(traj, DefBinSpacing, DefsPerBin)``: bins with non-dimensional edges DefBinSpacing[0..nbins] (0 ... 1,
+        increasing) holding DefsPerBin[i] equal segments each (ODEPhaseBase.cpp:523-620)."""
         T = np.asarray(traj, dtype=float)
         if T.ndim != 2 or T.shape[1] != self.ode.XtUPVars():
             raise ValueError(f"Input trajectory states must have {self.ode.XtUPVars()} columns")
         if not np.all(np.isfinite(T)):
             raise ValueError("NaN or Inf detected in input trajectory")   # ODEPhaseBase.cpp:560-564
-        if nsegs < 1:
-            raise ValueError("Number of segments must be positive")
+        if DefsPerBin is None:
+            if int(nsegs) < 1:
+                raise ValueError("Number of segments must be positive")
+            DBS, DPB = np.array([0.0, 1.0]), np.array([int(nsegs)], dtype=int)
+        else:
+            DBS, DPB = np.asarray(nsegs, dtype=float).ravel(), np.asarray(DefsPerBin, dtype=int).ravel()
+        self._check_bins(DBS, DPB)
         tcol = self.ode.TVar()
         t = T[:, tcol]
         if np.any(np.diff(t) <= 0) and np.any(np.diff(t) >= 0):
             raise ValueError("Trajectory time must be strictly monotonic")
-        cs = synth.MODE_CS[self.TranscriptionMode]
-        tc = _lib.lgl_table(cs, "tc")
-        K = cs - 1
-        edges = np.linspace(t[0], t[-1], nsegs + 1)
-        nodes = np.empty(K * nsegs + 1)
-        for j in range(K):
-            nodes[j:-1:K] = edges[:-1] + tc[j] * (edges[1:] - edges[:-1])
-        nodes[-1] = t[-1]
+        if t[-1] == t[0]:
+            raise ValueError("Trajectory spans no time")
+        nodes = self._mesh_times(DBS, DPB, t[0], t[-1])
         order = np.argsort(t)
         out = np.column_stack([np.interp(nodes, t[order], T[order, c]) for c in range(T.shape[1])])
         out[:, tcol] = nodes
         self.ActiveTraj = out
-        self.numDefects = int(nsegs)
+        self.DefBinSpacing, self.DefsPerBin = DBS.copy(), DPB.copy()
+        self.numDefects = int(DPB.sum())
         self._ev = None
+
+    @staticmethod
+    def _check_bins(DBS, DPB):
+        if DBS.size - 1 != DPB.size:                                      # ODEPhaseBase.cpp:664-669
+            raise ValueError(f"Size of Defect Bin Spacing({DBS.size}) not consistent with size of Defects Per Bin({DPB.size})")
+        if DPB.size < 1 or np.any(DPB < 1) or np.any(np.diff(DBS) <= 0) or not np.all(np.isfinite(DBS)):
+            raise ValueError("Defect bins must be increasing and hold at least one defect each")
+
+    def _mesh_times(self, DBS, DPB, t0, tf):
+        """Times of the K * numDefects + 1 states of the mesh: bin i spans [DBS[i], DBS[i+1]] of [t0, tf], its DPB[i]
+        segments are equal, the states of a segment sit at the scheme's cardinal spacing."""
+        cs = synth.MODE_CS[self.TranscriptionMode]
+        tc, K = _lib.lgl_table(cs, "tc"), cs - 1
+        edges = np.concatenate([np.linspace(DBS[i], DBS[i + 1], DPB[i] + 1)[(1 if i else 0):] for i in range(DPB.size)])
+        edges = t0 + (edges - DBS[0]) / (DBS[-1] - DBS[0]) * (tf - t0)
+        nodes = np.empty(K * (edges.size - 1) + 1)
+        for j in range(K):
+            nodes[j:-1:K] = edges[:-1] + tc[j] * (edges[1:] - edges[:-1])
+        nodes[-1] = tf
+        return nodes
+
+    def refineTrajManual(self, DefBinSpacing, DefsPerBin):
+        """Re-distribute the active trajectory on new bins (ODEPhaseBase.cpp:662-677; the adaptive mesh loop's re-meshing step,
+        :1443-1542 -- the interpolation is linear here, the reference's is the transcription's own polynomial)."""
+        if self.ActiveTraj is None:
+            raise RuntimeError("No trajectory set: call setTraj first")
+        self.setTraj(self.ActiveTraj, DefBinSpacing, DefsPerBin)
+        return self.returnTraj()
+
+    def _nodal_spacing(self):
+        """Non-dimensional times of the nodal states (segment boundaries), from the phase's own bins -- whatever the active
+        trajectory holds (transcribe_axis_funcs, ODEPhaseBase.cpp:962-970: linspace inside every bin)."""
+        DBS, DPB = self.DefBinSpacing, self.DefsPerBin
+        c = np.concatenate([np.linspace(DBS[i], DBS[i + 1], DPB[i] + 1)[(1 if i else 0):] for i in range(DPB.size)])
+        return (c - DBS[0]) / (DBS[-1] - DBS[0])
 
     def returnTraj(self):
         return [row.copy() for row in self.ActiveTraj]
@@ -264,13 +303,10 @@ class Phase:
                 # function object per state, addPartitionedEquality): ONE device function whose spacing is a constant of the
                 # application (vf.ApplConst), so the D - 1 relations are one batched evaluator
                 V, Cx, next_eq = ix.make_Vindex_Cindex("FrontNodalBackPath", tv, (), (), 1, next_eq)
-                # the spacing constants are the mesh's own nodal spacing (the reference: the phase's DefBinSpacing, :963-970):
-                # i / D on the uniform mesh setTraj builds, whatever the active trajectory holds otherwise
-                tn = self.ActiveTraj[::cs - 1, self.ode.TVar()]
-                cspace = (tn[1:-1] - tn[0]) / (tn[-1] - tn[0])
-                uniform = np.arange(1, D) / D
-                out.append(("auto", "nodal_spacing", SingleMeshSpacing(None), "nodalmeshspacing", V, Cx,
-                            (uniform if np.allclose(cspace, uniform, rtol=0.0, atol=1e-13) else cspace)[:, None]))
+                # the spacing constants come from the phase's DefBinSpacing / DefsPerBin (:963-970), not from the times the
+                # active trajectory happens to hold: i / D on the uniform mesh setTraj(traj, n) builds
+                cspace = self._nodal_spacing()[1:-1]
+                out.append(("auto", "nodal_spacing", SingleMeshSpacing(None), "nodalmeshspacing", V, Cx, cspace[:, None]))
         if self.ode.UVars() > 0 and not self._blocked() and D >= 2:   # transcribe_control_funcs
             order = {("LGL7", "HighestOrderSpline"): 2, ("LGL7", "FirstOrderSpline"): 1, ("LGL5", "HighestOrderSpline"): 1,
                      ("LGL5", "FirstOrderSpline"): 1}.get((self.TranscriptionMode, self.ControlMode))

@@ -44,6 +44,8 @@ WORKLOADS = {
     "synthetic32_lgl7_100k": ("synthetic32", "LGL7", 100000, False),      # BASELINE.json configs[4]
     "synthetic32_lgl7_12500": ("synthetic32", "LGL7", 12500, False),      # its per-GPU share on 8 GPUs
     "multispacecraft_8x1250": ("twobody_lt", "LGL5", 1250, True),         # configs[3]: 8 linked phases, dealt to the ranks
+    "reentry_trap_10k": ("reentry", "Trapezoidal", 10000, False),         # north_star names "LGL/Trapezoidal": the two-node scheme
+    "twobody_trap_blocked_10k": ("twobody_lt", "Trapezoidal", 10000, True),
 }
 MULTI_PHASE = {"multispacecraft_8x1250": 8}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
@@ -376,7 +378,7 @@ def main():
     per_rank_frac = [(n * bseg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0 for n, ms in zip(per_rank_segments, per_rank_ms)]
 
     traffic, traffic_src = None, None
-    prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_{a.workload}_pmc.json") for r in (3, 2)) if os.path.exists(q)), "")
+    prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_{a.workload}_pmc.json") for r in (4, 3, 2)) if os.path.exists(q)), "")
     if world == 1 and prof:   # NOT measured by this run: HBM bytes per evaluation from the committed rocprofv3 --pmc passes
         try:
             traffic = json.load(open(prof))["hbm"]["bytes_per_launch"]

@@ -97,7 +97,10 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
                           double* agx_blocks, double* kkt_blocks);
 
 /* Device-pointer evaluation: everything already resident in HBM; enqueued on `stream` (a hipStream_t, NULL =
- * the handle's own stream) and NOT synchronised. */
+ * the handle's own stream) and NOT synchronised.  NULL never means the legacy default stream: a caller whose work is on
+ * that stream names it, ASSET_HIP_STREAM_LEGACY (= hipStreamLegacy) -- otherwise the evaluation would run on the handle's
+ * private non-blocking stream and nothing the caller enqueues on the default stream afterwards would be ordered behind it. */
+#define ASSET_HIP_STREAM_LEGACY ((void*)1)
 int asset_hip_defect_eval_device(asset_hip_defect_t h, int what, const double* dX, const double* dL,
                                  double* d_fx_blocks, double* d_agx_blocks, double* d_kkt_blocks, void* stream);
 

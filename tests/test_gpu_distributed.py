@@ -43,6 +43,15 @@ with torch.cuda.stream(sB):
     sh.gather_device()
 torch.cuda.synchronize()
 cross = bool(all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(sh.blocks_on_root(), (fx, agx, kkt))))
+# the same on torch's DEFAULT stream (handle 0, which the C ABI reads as "the handle's own stream": the evaluator names
+# the null stream explicitly, hipStreamLegacy) -- evaluation and gather with no stream argument and no stream context
+sh._local.zero_(); sh._recv.zero_()
+torch.cuda.synchronize()
+for _ in range(3):
+    sh.eval_device(4, X, L)
+    sh.gather_device()
+torch.cuda.synchronize()
+default_stream = bool(all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(sh.blocks_on_root(), (fx, agx, kkt))))
 # host-visible exchange: the flat buffer copied into this rank's range of the shared page-locked host buffer
 sh.alloc_host_shared()
 with torch.cuda.stream(st):
@@ -53,7 +62,8 @@ hfx, hagx, hkkt = sh.host_shard_blocks()[0]
 host_same = bool(np.array_equal(hfx, fx) and np.array_equal(hagx, agx) and np.array_equal(hkkt, kkt))
 sh._host.close()
 print(json.dumps({{"fx": float(np.abs(fx - rfx).max() / max(1.0, np.abs(w.X).max())), "agx": rel_err(agx, ragx),
-                  "kkt": rel_err(kkt, rkkt), "shape": list(kkt.shape), "host_same": host_same, "cross_stream": cross}}))
+                  "kkt": rel_err(kkt, rkkt), "shape": list(kkt.shape), "host_same": host_same, "cross_stream": cross,
+                  "default_stream": default_stream}}))
 dist.destroy_process_group()
 """
 
@@ -67,6 +77,7 @@ def test_sharded_device_path_with_rccl_gather_matches_the_oracle(oracle):
     assert out["fx"] < 1e-10 and out["agx"] < 1e-8 and out["kkt"] < 1e-8, out
     assert out["host_same"]                  # the host-shared exchange delivers the same bits
     assert out["cross_stream"]               # evaluation on one stream, gather on another: ordered by the evaluator
+    assert out["default_stream"]             # ... and both on torch's default stream
 
 
 @pytest.mark.gpu

@@ -10,6 +10,9 @@ from asset_asrl_amd import build as B
 
 tu, out = sys.argv[1], os.path.join(ROOT, sys.argv[2])
 extra = sys.argv[3:]
+# stamps and elimination experiments are refused by the headers unless the build says it is a measurement build
+if any(f.startswith(("-DASSET_TIMING", "-DASSET_WALLCLOCK", "-DASSET_FUNC_TIMING", "-DASSET_EXP_")) for f in extra):
+    extra.append("-DASSET_TUNING_BUILD")
 B.generate(verbose=False)
 os.makedirs(os.path.dirname(out), exist_ok=True)
 objs = []

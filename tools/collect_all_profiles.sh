@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: rocprofv3 stats + PMC passes (tools/collect_profiles.sh) for every bench workload, summarised on the box
 # (tools/summarize_profiles.py); only the summaries travel back: gpurun_out/profiles_<round>/ -> copy them into profiles/.
-rnd=${1:-r3}
+rnd=${1:-r4}
 shift
-wls=${@:-reentry_lgl7_10k reentry_lgl7_5k reentry_lgl7_1m betts_lgl5_1k twobody_lgl5_blocked_10k multispacecraft_8x1250 synthetic32_lgl7_12500 twobody_lgl7_10k betts_lgl7_5k}
+wls=${@:-reentry_lgl7_10k reentry_lgl7_5k reentry_lgl7_1m betts_lgl5_1k twobody_lgl5_blocked_10k multispacecraft_8x1250 synthetic32_lgl7_12500 twobody_lgl7_10k betts_lgl7_5k reentry_trap_10k twobody_trap_blocked_10k}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/profiles_$rnd
 for wl in $wls; do
