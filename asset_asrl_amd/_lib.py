@@ -32,6 +32,7 @@ class DefectDesc(C.Structure):
 SYMBOLS = {
     "asset_hip_defect_create": (C.c_int, [C.POINTER(DefectDesc), C.POINTER(C.c_void_p)]),
     "asset_hip_defect_destroy": (None, [C.c_void_p]),
+    "asset_hip_defect_rebind": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int]),
     "asset_hip_defect_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "asset_hip_defect_eval": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "asset_hip_defect_eval_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),

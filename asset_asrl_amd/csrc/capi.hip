@@ -107,6 +107,8 @@ struct asset_hip_defect {
   const asset_hip::KernelEntry* ke = nullptr;
   int nseg = 0, n_primal = 0, n_equal = 0, device = 0;
   int cus = 256;
+  // what the buffers below were sized for (asset_hip_defect_rebind keeps them while the new mesh fits)
+  int cap_seg = 0, cap_primal = 0, cap_equal = 0;
   int* d_vindex = nullptr;
   int* d_cindex = nullptr;
   // staging for the host-pointer entry point (allocated lazily)
@@ -392,6 +394,57 @@ int asset_hip_lgl_table(int cs, const char* which, double* out, int cap) {
   return rows * cols;
 }
 
+// Index tables of a handle: bounds check (the kernels trust them), upload, run detection; buffers that depend on the number of
+// applications are kept while they fit and re-allocated otherwise; everything derived from the OLD tables is dropped.
+static int bind_tables(asset_hip_defect_t h, int nseg, const int32_t* vindex, const int32_t* cindex, int n_primal, int n_equal) {
+  const asset_hip::KernelEntry* ke = h->ke;
+  const size_t nv = size_t(ke->ir) * nseg, nc = size_t(ke->orr) * nseg;
+  for (size_t i = 0; i < nv; i++)
+    if (vindex[i] < 0 || vindex[i] >= n_primal) return fail(ASSET_HIP_ERANGE, "vindex entry out of range");
+  for (size_t i = 0; i < nc; i++)
+    if (cindex[i] < 0 || cindex[i] >= n_equal) return fail(ASSET_HIP_ERANGE, "cindex entry out of range");
+  auto drop = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));       // (nothing of the old mesh is in flight)
+  if (nseg > h->cap_seg) {                                       // grow: index tables, workspace, block staging
+    drop(h->d_vindex), drop(h->d_cindex), drop(h->d_work), drop(h->d_fx), drop(h->d_agx), drop(h->d_kkt);
+    const int cap = h->cap_seg > 0 ? std::max(nseg, h->cap_seg + h->cap_seg / 4) : nseg;   // (re-meshing grows by steps)
+    HIP_TRY(hipMalloc(&h->d_vindex, size_t(ke->ir) * cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_cindex, size_t(ke->orr) * cap * sizeof(int)));
+    if (ke->work_doubles) {
+      HIP_TRY(hipMalloc(&h->d_work, size_t(cap) * ke->work_doubles * sizeof(double)));
+      // sections no kernel writes must read as zero (the interior-point sections of a Trapezoidal slot, defect_dims.h)
+      HIP_TRY(hipMemset(h->d_work, 0, size_t(cap) * ke->work_doubles * sizeof(double)));
+    }
+    h->cap_seg = cap;
+  }
+  if (n_primal > h->cap_primal) drop(h->d_X), h->cap_primal = n_primal;
+  if (n_equal > h->cap_equal) drop(h->d_L), h->cap_equal = n_equal;
+  HIP_TRY(hipMemcpy(h->d_vindex, vindex, nv * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_cindex, cindex, nc * sizeof(int), hipMemcpyHostToDevice));
+  h->h_vindex.assign(vindex, vindex + nv);
+  h->h_cindex.assign(cindex, cindex + nc);
+  {   // rows that are runs with a constant stride between applications (EvalArgs::affine)
+    const int ir = ke->ir, orr = ke->orr, ns = nseg;
+    const int v0 = vindex[0], c0 = cindex[0];
+    const int vs = ns > 1 ? vindex[ir] - v0 : 0, cs = ns > 1 ? cindex[orr] - c0 : 0;
+    bool ok = true;
+    for (int s = 0; s < ns && ok; s++) {
+      for (int k = 0; k < ir && ok; k++) ok = vindex[size_t(s) * ir + k] == v0 + s * vs + k;
+      for (int k = 0; k < orr && ok; k++) ok = cindex[size_t(s) * orr + k] == c0 + s * cs + k;
+    }
+    h->affine = ok ? 1 : 0, h->aff_v0 = v0, h->aff_vs = vs, h->aff_c0 = c0, h->aff_cs = cs;
+  }
+  // derived from the old tables: the KKT map and its staging, the RHS gather tables, per-application constants, block buffers
+  drop(h->d_map), drop(h->d_values), drop(h->d_stage), drop(h->d_multi_ptr), drop(h->d_multi_loc), drop(h->d_aconst);
+  drop(h->d_fx_rows), drop(h->d_fx_ptr), drop(h->d_fx_src), drop(h->d_gx_rows), drop(h->d_gx_ptr), drop(h->d_gx_src);
+  drop(h->d_fxb), drop(h->d_agxb);
+  if (h->h_values) { (void)hipHostFree(h->h_values); h->h_values = nullptr; }
+  h->map_len = 0, h->value_lo = h->value_hi = h->nvalues = 0, h->nmulti = 0, h->nstage = 0;
+  h->n_fx_rows = h->fx_long_from = h->n_gx_rows = h->gx_long_from = 0, h->rhs_tables_ready = false;
+  h->nseg = nseg, h->n_primal = n_primal, h->n_equal = n_equal;
+  return 0;
+}
+
 int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* out) {
   if (!d || !out) return fail(ASSET_HIP_EINVAL, "null descriptor / output");
   *out = nullptr;
@@ -405,12 +458,13 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
     return fail(ASSET_HIP_ENOODE, buf);
   }
   if (ke->table->meta[asset_hip::MF_KIND] == 3) return fail(ASSET_HIP_EINVAL, "a bundle is launched through asset_hip_bundle_*, it is not a function");
-  // bounds-check the index tables once, on the host (the kernels trust them)
-  const size_t nv = size_t(ke->ir) * d->nseg, nc = size_t(ke->orr) * d->nseg;
-  for (size_t i = 0; i < nv; i++)
-    if (d->vindex[i] < 0 || d->vindex[i] >= d->n_primal) return fail(ASSET_HIP_ERANGE, "vindex entry out of range");
-  for (size_t i = 0; i < nc; i++)
-    if (d->cindex[i] < 0 || d->cindex[i] >= d->n_equal) return fail(ASSET_HIP_ERANGE, "cindex entry out of range");
+  {   // (before anything is allocated: the commonest set-up error)
+    const size_t nv = size_t(ke->ir) * d->nseg, nc = size_t(ke->orr) * d->nseg;
+    for (size_t i = 0; i < nv; i++)
+      if (d->vindex[i] < 0 || d->vindex[i] >= d->n_primal) return fail(ASSET_HIP_ERANGE, "vindex entry out of range");
+    for (size_t i = 0; i < nc; i++)
+      if (d->cindex[i] < 0 || d->cindex[i] >= d->n_equal) return fail(ASSET_HIP_ERANGE, "cindex entry out of range");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(ASSET_HIP_ENODEV, "no HIP device visible: the evaluator has no CPU fallback");
@@ -418,7 +472,7 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
   HIP_TRY(hipSetDevice(d->device));
   asset_hip_defect* h = new (std::nothrow) asset_hip_defect;
   if (!h) return fail(ASSET_HIP_EINVAL, "out of host memory");
-  h->ke = ke, h->nseg = d->nseg, h->n_primal = d->n_primal, h->n_equal = d->n_equal, h->device = d->device;
+  h->ke = ke, h->device = d->device;
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, d->device);
   const int cus = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -428,33 +482,14 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
     asset_hip_defect_destroy(h);
     return rc;
   };
-  if ((e = hipMalloc(&h->d_vindex, nv * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(vindex)");
-  if ((e = hipMalloc(&h->d_cindex, nc * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(cindex)");
-  if ((e = hipMemcpy(h->d_vindex, d->vindex, nv * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess)
-    return bail(e, "hipMemcpy(vindex)");
-  if ((e = hipMemcpy(h->d_cindex, d->cindex, nc * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess)
-    return bail(e, "hipMemcpy(cindex)");
-  h->h_vindex.assign(d->vindex, d->vindex + nv);
-  h->h_cindex.assign(d->cindex, d->cindex + nc);
-  {   // rows that are runs with a constant stride between applications (EvalArgs::affine)
-    const int ir = ke->ir, orr = ke->orr, ns = d->nseg;
-    const int v0 = d->vindex[0], c0 = d->cindex[0];
-    const int vs = ns > 1 ? d->vindex[ir] - v0 : 0, cs = ns > 1 ? d->cindex[orr] - c0 : 0;
-    bool ok = true;
-    for (int s = 0; s < ns && ok; s++) {
-      for (int k = 0; k < ir && ok; k++) ok = d->vindex[size_t(s) * ir + k] == v0 + s * vs + k;
-      for (int k = 0; k < orr && ok; k++) ok = d->cindex[size_t(s) * orr + k] == c0 + s * cs + k;
-    }
-    h->affine = ok ? 1 : 0, h->aff_v0 = v0, h->aff_vs = vs, h->aff_c0 = c0, h->aff_cs = cs;
-  }
-  if (ke->work_doubles) {
-    if ((e = hipMalloc(&h->d_work, size_t(h->nseg) * ke->work_doubles * sizeof(double))) != hipSuccess)
-      return bail(e, "hipMalloc(workspace)");
-    // sections no kernel writes must read as zero (the interior-point sections of a Trapezoidal slot, defect_dims.h)
-    if ((e = hipMemset(h->d_work, 0, size_t(h->nseg) * ke->work_doubles * sizeof(double))) != hipSuccess)
-      return bail(e, "hipMemset(workspace)");
-  }
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  {
+    const int rc = bind_tables(h, d->nseg, d->vindex, d->cindex, d->n_primal, d->n_equal);
+    if (rc) {
+      asset_hip_defect_destroy(h);
+      return rc;
+    }
+  }
   // per-lane constants of the dense stage: computed here, once
     for (int level = 0; level <= 2; level++) {   // (0: the record of the resident kernel)
       const size_t nb = asset_hip::entry_lane_bytes(ke, level);
@@ -474,6 +509,13 @@ int asset_hip_defect_create(const asset_hip_defect_desc* d, asset_hip_defect_t* 
   if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
   *out = h;
   return 0;
+}
+
+int asset_hip_defect_rebind(asset_hip_defect_t h, int nseg, const int32_t* vindex, const int32_t* cindex, int n_primal, int n_equal) {
+  if (!h || !vindex || !cindex || nseg <= 0 || n_primal <= 0 || n_equal <= 0) return fail(ASSET_HIP_EINVAL, "bad rebind arguments");
+  if (h->bundles > 0) return fail(ASSET_HIP_EINVAL, "the handle is a member of a bundle: destroy the bundle before re-binding");
+  HIP_TRY(hipSetDevice(h->device));
+  return bind_tables(h, nseg, vindex, cindex, n_primal, n_equal);
 }
 
 void asset_hip_defect_destroy(asset_hip_defect_t h) {
@@ -661,11 +703,11 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
   HIP_TRY(hipSetDevice(h->device));
   const size_t nfx = size_t(h->nseg) * h->ke->orr, nagx = size_t(h->nseg) * h->ke->ir,
                nkkt = size_t(h->nseg) * h->ke->nkkt;
-  if (!h->d_X) HIP_TRY(hipMalloc(&h->d_X, sizeof(double) * h->n_primal));
-  if (!h->d_L) HIP_TRY(hipMalloc(&h->d_L, sizeof(double) * h->n_equal));
-  if (fx && !h->d_fx) HIP_TRY(hipMalloc(&h->d_fx, sizeof(double) * nfx));
-  if (agx && !h->d_agx) HIP_TRY(hipMalloc(&h->d_agx, sizeof(double) * nagx));
-  if (kkt && !h->d_kkt) HIP_TRY(hipMalloc(&h->d_kkt, sizeof(double) * nkkt));
+  if (!h->d_X) HIP_TRY(hipMalloc(&h->d_X, sizeof(double) * h->cap_primal));
+  if (!h->d_L) HIP_TRY(hipMalloc(&h->d_L, sizeof(double) * h->cap_equal));
+  if (fx && !h->d_fx) HIP_TRY(hipMalloc(&h->d_fx, sizeof(double) * size_t(h->cap_seg) * h->ke->orr));   // (sized for the handle's capacity: asset_hip_defect_rebind)
+  if (agx && !h->d_agx) HIP_TRY(hipMalloc(&h->d_agx, sizeof(double) * size_t(h->cap_seg) * h->ke->ir));
+  if (kkt && !h->d_kkt) HIP_TRY(hipMalloc(&h->d_kkt, sizeof(double) * size_t(h->cap_seg) * h->ke->nkkt));
   HIP_TRY(hipMemcpyAsync(h->d_X, X, sizeof(double) * h->n_primal, hipMemcpyHostToDevice, h->stream));
   if (L) HIP_TRY(hipMemcpyAsync(h->d_L, L, sizeof(double) * h->n_equal, hipMemcpyHostToDevice, h->stream));
   int rc = launch(h, what, h->d_X, L ? h->d_L : nullptr, fx ? h->d_fx : nullptr, agx ? h->d_agx : nullptr,
@@ -1016,10 +1058,10 @@ static int eval_assembled_host(asset_hip_defect_t h, int what, const double* X, 
   HIP_TRY(hipSetDevice(h->device));
   const size_t nfx = size_t(h->nseg) * h->ke->orr, nagx = size_t(h->nseg) * h->ke->ir;
   const size_t nval = size_t(h->value_hi - h->value_lo);
-  if (!h->d_X) HIP_TRY(hipMalloc(&h->d_X, sizeof(double) * h->n_primal));
-  if (!h->d_L) HIP_TRY(hipMalloc(&h->d_L, sizeof(double) * h->n_equal));
-  if (fx_blocks && !h->d_fx) HIP_TRY(hipMalloc(&h->d_fx, sizeof(double) * nfx));
-  if (agx_blocks && !h->d_agx) HIP_TRY(hipMalloc(&h->d_agx, sizeof(double) * nagx));
+  if (!h->d_X) HIP_TRY(hipMalloc(&h->d_X, sizeof(double) * h->cap_primal));
+  if (!h->d_L) HIP_TRY(hipMalloc(&h->d_L, sizeof(double) * h->cap_equal));
+  if (fx_blocks && !h->d_fx) HIP_TRY(hipMalloc(&h->d_fx, sizeof(double) * size_t(h->cap_seg) * h->ke->orr));
+  if (agx_blocks && !h->d_agx) HIP_TRY(hipMalloc(&h->d_agx, sizeof(double) * size_t(h->cap_seg) * h->ke->ir));
   if (!h->d_values) {
     HIP_TRY(hipMalloc(&h->d_values, sizeof(double) * nval));
     HIP_TRY(hipHostMalloc(&h->h_values, sizeof(double) * nval, hipHostMallocDefault));

@@ -58,8 +58,21 @@ struct ResDims {
   static constexpr int WPS = ASSET_RES_WPS;
   static constexpr int LDS_WAVE = 160 * 1024 / (4 * WPS);
   static constexpr int GR_FIT = (LDS_WAVE / 8 - D::TABSZ - XTRA) / SLOT;
-  static constexpr int GR = GR_FIT < 64 / CS ? GR_FIT : 64 / CS;
-  static constexpr size_t lds_bytes() { return size_t(D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA) * 8; }
+  // PAIR: two-wave workgroups whose waves share the ODE stage.  A wave's ODE phases keep 15-20 of 64 lanes busy, and two waves
+  // of a SIMD issue them at the SIMD's f64 rate (tools/ubench_issue.hip: 7.5 cycles per instruction and wave in pairs, 4.5-6
+  // alone) -- the lane count costs nothing, the instruction count does.  In a pair ONE wave runs a phase for both waves'
+  // segments (40 / 30 lanes for Reentry-LGL7) while the other loads its lane record or waits at the barrier: half the ODE
+  // instructions per SIMD.  Shapes built for two waves per SIMD that run their own ODE stage; each wave keeps its own LDS
+  // region [tables | GR slots | scratch], so every offset of the lane record holds for both.
+#ifndef ASSET_RES_PAIR
+#define ASSET_RES_PAIR 1
+#endif
+  static constexpr bool PAIR = ASSET_RES_PAIR && WPS == 2 && Ode::NUNITS == 1;
+  static constexpr int NWV = PAIR ? 2 : 1;                          // waves per workgroup
+  static constexpr int GR_PASS = 64 / (CS * NWV);                   // one pass per phase covers the workgroup's group
+  static constexpr int GR = GR_FIT < GR_PASS ? GR_FIT : GR_PASS;
+  static constexpr int REGION = D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA;   // a wave's LDS (doubles)
+  static constexpr size_t lds_bytes() { return size_t(NWV * REGION) * 8; }
   // (two row tiles of defect rows -- TwoBody-LGL7, K n = 18 -- work and are parity-green, but with three column tiles beside
   //  them the wave spills 650 bytes per lane: 149.5 us against 102.5 us for 10 000 segments (BlockConstant: 122 against 81) --
   //  such shapes stay with defect_kernels.h)
@@ -469,27 +482,59 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   constexpr int CS = D::CS, K = D::K, KE = R::KE, n = D::n, q = D::q, N = D::N, T = D::T, TF = D::TF;
   constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, KS = D::KS, TI = D::TI, TJ = D::TJ, GR = R::GR, SLOT = R::SLOT;
   constexpr bool CFULL = (IR == IRP);
-  static_assert(GR * CS <= 64, "one pass per phase");
+  static_assert(GR * CS * R::NWV <= 64, "one pass per phase");
 
+  // (the pair form is the one-group kernel's: the looped instantiation keeps single-wave workgroups -- as a pair it ran 100 000
+  //  Reentry-LGL7 segments 2.7 % faster, 328 against 337 us, but its TwoBody-LGL5-BlockConstant instantiation came out of the
+  //  compiler wrong with the per-group opaque lane index and 25 % slower without it)
+  constexpr bool PAIR = R::PAIR && !GIVEN && !LOOP;
+  constexpr int NWV = PAIR ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  lds_double* const tabL = (lds_double*)lds;                       // weight tables, then x_AUX ... behind the slots
+  const int wv = PAIR ? __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6) : 0;   // this wave of the workgroup
+  lds_double* const tabL = (lds_double*)lds + wv * R::REGION;      // weight tables, then x_AUX ... behind the slots
   lds_double* const slots = tabL + D::TABSZ;
   lds_double* const xtra = slots + GR * SLOT;
-  const int lane0 = int(threadIdx.x);
-  const LglTab& tab = *reinterpret_cast<const LglTab*>(lds);
+  const int lane0 = int(threadIdx.x) & 63;
+  const LglTab& tab = *reinterpret_cast<const LglTab*>((double*)tabL);
   const LglTab& ctab = d_lgl_tab[D::TAB];                           // compile-time indices: scalar loads
 
   // this wave's share of the mesh: contiguous, balanced (same rule as IndexingData.h:117-146), walked in groups of at most GR
   // segments (equal groups: 7 segments are 4 + 3).  One group per wave up to GR segments per wave; on larger meshes the waves
   // drift apart from group to group, so that the ODE stage of some runs under the block stores of the others.
-  const int nshare = int(gridDim.x), share = int(blockIdx.x);
+  const int nshare = int(gridDim.x) * NWV, share = int(blockIdx.x) * NWV + wv;
   const int per = a.nseg / nshare, rem = a.nseg % nshare;
   const int wg_first = share * per + min(share, rem), wg_count = per + (share < rem ? 1 : 0);
-  const int ngroups = LOOP ? (wg_count + GR - 1) / GR : (wg_count > 0 ? 1 : 0);
+  // (PAIR: the partner's share -- the waves of a pair walk the same number of groups, they meet at barriers)
+  const int oshare = share ^ 1;
+  const int o_first = oshare * per + min(oshare, rem), o_count = per + (oshare < rem ? 1 : 0);
+  const int cmax = PAIR ? max(wg_count, o_count) : wg_count;
+  const int ngroups = LOOP ? (cmax + GR - 1) / GR : (cmax > 0 ? 1 : 0);
   const int gbase = LOOP ? (ngroups > 0 ? wg_count / ngroups : 0) : min(wg_count, GR), gextra = (LOOP && ngroups > 0) ? wg_count % ngroups : 0;
+  const int o_gbase = LOOP ? (ngroups > 0 ? o_count / ngroups : 0) : min(o_count, GR), o_gextra = (LOOP && ngroups > 0) ? o_count % ngroups : 0;
+  // roles of the pair's waves in the ODE stage: wave 0 runs the cardinal phases (P1, P3), wave 1 the interior phase (P2).  At two
+  // 256-register waves per SIMD the dispatcher puts wave 1 of workgroup b and wave 0 of workgroup b + gridDim/4 on one SIMD
+  // (tools/ubench_place.hip: 1 002 of 1 024 SIMDs host one wave 0 and one wave 1), so with the roles fixed by the wave index a
+  // SIMD runs one ODE phase at a time -- one workgroup's P1, the other's P2, the first one's P3 -- at a lone wave's issue rate.
+  // (ASSET_RES_PAIR_FLIP: roles swapped in the upper half of the grid; measured slower, 33.1 against 32.6 us.)
+#ifndef ASSET_RES_PAIR_FLIP
+#define ASSET_RES_PAIR_FLIP 0
+#endif
+  const int wa = (ASSET_RES_PAIR_FLIP && 2 * int(blockIdx.x) >= int(gridDim.x)) ? 1 : 0;
+  const bool roleA = !PAIR || wv == wa, roleB = !PAIR || wv != wa;
+  auto pair_sync = [&]() {   // LDS hand-over between the pair's waves (no wait for stores in flight)
+    if constexpr (PAIR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else wave_lds_sync();
+  };
   // (shifting segments from the younger wave of every SIMD to the older one -- 52 / 54 / 56 % to the first half of the grid --
   //  changes nothing: 35.1-35.2 us each)
-  const bool young = 2 * int(blockIdx.x) >= int(gridDim.x);        // the second wave of its SIMD (workgroups are dealt breadth first)
+#ifndef ASSET_RES_PAIR_YOUNG
+#define ASSET_RES_PAIR_YOUNG 1
+#endif
+  // the second wave of its SIMD (workgroups are dealt breadth first: b and b + gridDim/2 share a SIMD; in the pair form b's wave 1
+  // and (b + gridDim/4)'s wave 0 do)
+  const bool young = (PAIR && ASSET_RES_PAIR_YOUNG) ? (((4 * int(blockIdx.x)) / max(int(gridDim.x), 1)) & 1) != 0
+                                                    : 2 * int(blockIdx.x) >= int(gridDim.x);
+  lds_double* const region0 = (lds_double*)lds;                     // (PAIR) wave 0's region; wave 1's follows
 
 #if defined(ASSET_TIMING)
   long long tstamp[24];
@@ -503,16 +548,35 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #if defined(ASSET_WALLCLOCK)
   const long long wall_t0 = wall_clock64();
 #endif
-  for (int grp = 0, seg0 = wg_first; grp < ngroups; grp++) {
+  for (int grp = 0, seg0 = wg_first, o_seg0 = o_first; grp < ngroups; grp++) {
   const int gcount = gbase + (grp < gextra ? 1 : 0);
+  const int o_gcount = PAIR ? o_gbase + (grp < o_gextra ? 1 : 0) : 0;
+  // (PAIR) the workgroup's group: wave 0's segments, then wave 1's; segment g of it -> slot and mesh segment
+  const int gc0 = wv == 0 ? gcount : o_gcount, gc1 = PAIR ? (wv == 0 ? o_gcount : gcount) : 0;
+  const int sg0 = wv == 0 ? seg0 : o_seg0, sg1 = wv == 0 ? o_seg0 : seg0;
+  auto pslot = [&](int g) -> lds_double* {
+    if constexpr (PAIR) return region0 + D::TABSZ + (g < gc0 ? g * SLOT : R::REGION + (g - gc0) * SLOT);
+    else return slots + g * SLOT;
+  };
+  auto pseg = [&](int g) -> int { if constexpr (PAIR) return g < gc0 ? sg0 + g : sg1 + (g - gc0); else return seg0 + g; };
+  const int gall = PAIR ? gc0 + gc1 : gcount;
   // (the lane index is made opaque per group: what derives from it is then recomputed in every group instead of being
   //  computed once before the loop and kept -- in scratch, there being no registers to keep it in across the ODE bodies)
   int lane = lane0;
   if constexpr (LOOP) asm volatile("" : "+v"(lane));
   const int lr = lane & 15, lk = lane >> 4;
   RTS();
+  LaneRecord<LCT> lrec;
+  auto load_record = [&]() {
+    const unsigned int* rec = static_cast<const unsigned int*>(a.lane_consts_res) +
+                              size_t((blockIdx.x + grp) % ASSET_LANE_REPLICAS) * (LaneRecord<LCT>::NW * 64);   // (reloaded per group:
+#pragma unroll                                                                                          //  the ODE bodies need the registers)
+    for (int k = 0; k < LaneRecord<LCT>::NW; k++) lrec.w[k] = rec[k * 64 + lane];
+  };
   if constexpr (GIVEN) {
     // ------------------------------------------------------------------ slots from the workspace (defect_units.h wrote them)
+    // (the record first: there is no ODE body here that needs the registers, and its round trip to memory runs under the slots')
+    load_record();
     constexpr int NTAB = (D::TABSZ + 63) / 64, CH = 8;
     double tabv[NTAB];
 #pragma unroll
@@ -543,27 +607,39 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     if (lane < 4) xtra[R::x_Z4 + lane] = 0.0;
   } else {
   // ------------------------------------------------------------------ ODE stage
-  {   // P0: gather z = X[Vindex], lam = L[Cindex] into the slots -- index loads, value loads, LDS writes
-    constexpr int NZ = (GR * IR + 63) / 64, NL = (GR * OR + 63) / 64, NTAB = (D::TABSZ + 63) / 64;
-    const int* vseg = a.vindex + size_t(seg0) * IR;
-    const int* cseg = a.cindex + size_t(seg0) * OR;
+#if defined(ASSET_EXP_ODEREP)   // (measurement build: the stage twice -- the second pass finds its code in the instruction cache)
+  for (int oderep = 0; oderep < ASSET_EXP_ODEREP; oderep++) {
+  if (oderep > 0) { pair_sync(); RTS(); }
+#endif
+  // P0: gather z = X[Vindex], lam = L[Cindex] into the slots -- index loads, value loads, LDS writes.  In a pair wave 1 gathers for
+  // both waves (and fills both regions' tables) while wave 0 is already in P1, which reads the solver vector itself and writes
+  // nothing P0 writes: the gather's round trip to memory -- 2.7 k cycles, 6.6 k at the cold start of a launch -- is off the
+  // critical path of the stage.
+  if (roleB) {
+    constexpr int NZ = (NWV * GR * IR + 63) / 64, NL = (NWV * GR * OR + 63) / 64, NTAB = (D::TABSZ + 63) / 64;
     int vi[NZ], ci[NL];
     if (a.affine) {                      // (uniform) the rows of the index tables are runs: no index loads
 #pragma unroll
       for (int t = 0; t < NZ; t++) {
         const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
-        vi[t] = (e < gcount * IR) ? a.aff_v0 + (seg0 + g) * a.aff_vs + r : -1;
+        vi[t] = (e < gall * IR) ? a.aff_v0 + pseg(g) * a.aff_vs + r : -1;
       }
 #pragma unroll
       for (int t = 0; t < NL; t++) {
         const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
-        ci[t] = (e < gcount * OR) ? a.aff_c0 + (seg0 + g) * a.aff_cs + r : -1;
+        ci[t] = (e < gall * OR) ? a.aff_c0 + pseg(g) * a.aff_cs + r : -1;
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < NZ; t++) vi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : -1;
+      for (int t = 0; t < NZ; t++) {
+        const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
+        vi[t] = (e < gall * IR) ? a.vindex[size_t(pseg(g)) * IR + r] : -1;
+      }
 #pragma unroll
-      for (int t = 0; t < NL; t++) ci[t] = (lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : -1;
+      for (int t = 0; t < NL; t++) {
+        const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
+        ci[t] = (e < gall * OR) ? a.cindex[size_t(pseg(g)) * OR + r] : -1;
+      }
     }
     double tabv[NTAB];
 #pragma unroll
@@ -575,67 +651,70 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
     for (int t = 0; t < NL; t++) lv[t] = (ci[t] >= 0 && a.L) ? a.L[ci[t]] : 0.0;
 #pragma unroll
-    for (int t = 0; t < NTAB; t++)
-      if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
-    if (lane < 4 * K) {
-      const int i = lane >> 2, w = lane & 3;
-      xtra[R::x_AUX + lane] = w == 0 ? 1.0 - ctab.s[i] : (w == 1 ? ctab.s[i] : (w == 3 ? 1.0 : 0.0));
+    for (int w = 0; w < NWV; w++) {      // every region of the workgroup: tables, constant rows, zero cells
+      lds_double* const tb = PAIR ? region0 + w * R::REGION : tabL;
+      lds_double* const xt = tb + D::TABSZ + GR * SLOT;
+#pragma unroll
+      for (int t = 0; t < NTAB; t++)
+        if (lane + 64 * t < D::TABSZ) tb[lane + 64 * t] = tabv[t];
+      if (lane < 4 * K) {
+        const int i = lane >> 2, wq = lane & 3;
+        xt[R::x_AUX + lane] = wq == 0 ? 1.0 - ctab.s[i] : (wq == 1 ? ctab.s[i] : (wq == 3 ? 1.0 : 0.0));
+      }
+      if (lane < GR) tb[D::TABSZ + lane * SLOT + R::s_Z0] = 0.0;
+      if (lane < 4) xt[R::x_Z4 + lane] = 0.0;
     }
-    if (lane < GR) slots[lane * SLOT + R::s_Z0] = 0.0;
-    if (lane < 4) xtra[R::x_Z4 + lane] = 0.0;
 #pragma unroll
     for (int t = 0; t < NZ; t++) {
       const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
-      if (e < gcount * IR) slots[g * SLOT + D::w_z + r] = zv[t];
+      if (e < gall * IR) pslot(g)[D::w_z + r] = zv[t];
     }
 #pragma unroll
     for (int t = 0; t < NL; t++) {
       const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
-      if (e < gcount * OR) slots[g * SLOT + D::w_lam + r] = lv[t];
+      if (e < gall * OR) pslot(g)[D::w_lam + r] = lv[t];
     }
   }
   RTS();
   if constexpr (D::TRAP && LEVEL >= 2) {   // Trapezoidal: one phase (the weights w_j need lam and h: after the gather)
-    wave_lds_sync();
-    if (lane < gcount * CS) {
+    pair_sync();
+    if (roleA && lane < gall * CS) {
       const int g = lane / CS, j = lane - g * CS;
-      res_cardinal_all<Ode, D>(slots + g * SLOT, j, &tab, a.L != nullptr);
+      res_cardinal_all<Ode, D>(pslot(g), j, &tab, a.L != nullptr);
     }
   } else {
-  if (lane < gcount * CS) {            // P1
+  if (roleA && lane < gall * CS) {     // P1 (reads X itself, writes f_j and the saved values: nothing of P0's)
     const int g = lane / CS, j = lane - g * CS;
-    if (a.affine && D::p == 0) res_cardinal_value<Ode, D, LEVEL>(slots + g * SLOT, j, a.X + (a.aff_v0 + (seg0 + g) * a.aff_vs), nullptr);
-    else res_cardinal_value<Ode, D, LEVEL>(slots + g * SLOT, j, a.X, a.vindex + size_t(seg0 + g) * IR);
+    if (a.affine && D::p == 0) res_cardinal_value<Ode, D, LEVEL>(pslot(g), j, a.X + (a.aff_v0 + pseg(g) * a.aff_vs), nullptr);
+    else res_cardinal_value<Ode, D, LEVEL>(pslot(g), j, a.X, a.vindex + size_t(pseg(g)) * IR);
   }
-  wave_lds_sync();
+  pair_sync();
   RTS();
   if constexpr (!D::TRAP) {
-    if (lane < gcount * K) {           // P2
+    if (roleB && lane < gall * K) {    // P2
       const int g = lane / K, i = lane - g * K;
-      res_interior<Ode, D, LEVEL>(slots + g * SLOT, i, &tab, a.L != nullptr);
+      res_interior<Ode, D, LEVEL>(pslot(g), i, &tab, a.L != nullptr);
     }
-    wave_lds_sync();
+    if constexpr (LEVEL >= 2) pair_sync();
   }
   RTS();
   if constexpr (LEVEL >= 2) {
-    if (lane < gcount * CS) {          // P3
+    if (roleA && lane < gall * CS) {   // P3
       const int g = lane / CS, j = lane - g * CS;
-      res_cardinal_second<Ode, D>(slots + g * SLOT, j, &tab);
+      res_cardinal_second<Ode, D>(pslot(g), j, &tab);
     }
   }
   }
+#if defined(ASSET_EXP_ODEREP)
+  }
+#endif
   }   // (!GIVEN)
   RTS();
-  // the per-lane record of the dense part (its loads fly while P3's LDS writes land)
-  LaneRecord<LCT> lrec;
-  {
-    const unsigned int* rec = static_cast<const unsigned int*>(a.lane_consts_res) +
-                              size_t((blockIdx.x + grp) % ASSET_LANE_REPLICAS) * (LaneRecord<LCT>::NW * 64);   // (reloaded per group:
-#pragma unroll                                                                                          //  the ODE bodies need the registers)
-    for (int k = 0; k < LaneRecord<LCT>::NW; k++) lrec.w[k] = rec[k * 64 + lane];
-  }
+  // the per-lane record of the dense part (its loads fly while P3's LDS writes land; in a pair the wave that is not in the
+  // last phase loads it while the other computes)
+  if constexpr (!GIVEN) load_record();
   const LCT& lc = lrec.lc;
-  wave_lds_sync();
+  if constexpr (!GIVEN) pair_sync(); else wave_lds_sync();   // (the last ODE phase's results, for both waves)
   wave_loads_landed();
   RTS();
 
@@ -1025,10 +1104,11 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   }
   RTS();
   seg0 += gcount;
+  o_seg0 += o_gcount;
   wave_lds_sync();                     // (the next group's gather rewrites the slots)
   }
 #if defined(ASSET_TIMING)
-  if (blockIdx.x == 7 && lane0 == 0 && a.FX)
+  if (blockIdx.x == 7 && wv == 0 && lane0 == 0 && a.FX)
     for (int t = 0; t + 1 < nts; t++) a.FX[size_t(wg_first) * OR + t] = double(tstamp[t + 1] - tstamp[t]);
 #endif
 #if defined(ASSET_WALLCLOCK)   // (tuning builds) 100 MHz wall-clock at the start and the end of every wave, left in FX
@@ -1044,7 +1124,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 }
 
 template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false, bool LOOP = false, bool GIVEN = false>
-__global__ __launch_bounds__(64, (ResDims<Dims<Ode, SCH, BLOCKED>>::WPS)) void lgl_resident_kernel(EvalArgs a) {
+__global__ __launch_bounds__((!GIVEN && !LOOP && ResDims<Dims<Ode, SCH, BLOCKED>>::PAIR) ? 128 : 64, (ResDims<Dims<Ode, SCH, BLOCKED>>::WPS))
+void lgl_resident_kernel(EvalArgs a) {
 #if defined(ASSET_EXP_NULL)   // (experiment: the cost of the launch itself)
   if (a.nseg > 0) return;
 #endif

@@ -68,6 +68,12 @@ struct OdeOutUnitJ {
   }
 };
 
+template <class D>
+struct OdeOutGx {   // g^_i[0:n] of an interior point -> the group's mirror (PHASE 4: the cardinal units form it themselves)
+  lds_double* gm_;
+  __device__ void g(int i, double v) { gm_[i] = v; }
+};
+
 template <class D, bool SLOT>
 struct OdeOutValue {   // cardinal values: mirror (the interior points read them) and, from one unit, the slot (the dense stage does)
   lds_double* fm_;
@@ -100,6 +106,11 @@ __device__ inline void run_unit(int unit, const In& in, Out& out) {
 //          per group of segments, was built and measured in round 3: 54.1 us against 43.5 us for 1 000 Betts-LGL5 segments --
 //          the unit bodies read their inputs through scratch memory, and the polling and the L2-bypassing traffic of the
 //          workgroups that are done stretch the interior pass of the others from 7.2 us to 9-23 us)
+//          PHASE 4 (round 4): the whole stage in ONE launch without a hand-over -- the grid is (groups) x (2 NUNITS); the upper
+//          half are the cardinal units, and each of their workgroups forms g^_i[0:n] of its group's interior points ITSELF
+//          (Ode::gx, a vector-Jacobian product: 782 operations for Betts against ~1 700 of a column unit) instead of waiting
+//          for the interior units: what they need of the interior pass is that vector and nothing else (LGLDefects.h:369-374).
+//          The units recompute what they share, so the form pays while the mesh leaves SIMDs idle (registry.h).
 //          Single-wave workgroups at one wave per SIMD: each unit body has the whole register file
 //          (512 with the accumulation registers as spill space), where seven waves in one workgroup had 256 each and
 //          spilled ~1 KB per lane to scratch (110 MB of scratch traffic per evaluation of 1 000 Betts segments).
@@ -113,9 +124,12 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
   lds_double* const mirror = (lds_double*)(lds + D::TABSZ);
   const int lane = threadIdx.x;
 #if defined(ASSET_EXP_ONEUNIT)
+  const bool cardinal_wg = false;
   const int unit = ASSET_EXP_ONEUNIT;   // (experiment: every workgroup runs the same unit body)
 #else
-  const int unit = blockIdx.y;
+  // PHASE 4 (one launch for the whole stage): blockIdx.y < NUNITS -- interior unit y; otherwise cardinal unit y - NUNITS
+  const bool cardinal_wg = PHASE == 4 && int(blockIdx.y) >= Ode::NUNITS;
+  const int unit = cardinal_wg ? int(blockIdx.y) - Ode::NUNITS : int(blockIdx.y);
 #endif
   const int seg0 = int(blockIdx.x) * gp;
   const int gcount = min(gp, a.nseg - seg0);
@@ -168,7 +182,7 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
       const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
       if (e < gcount * IR) {
         mirror[g * UD::MS + UD::m_z + r] = zv[t];
-        if ((PHASE == 0 || PHASE == 3) && unit == 0) Wg[g * D::WSLOT + D::w_z + r] = zv[t];
+        if ((PHASE == 0 || PHASE == 3 || PHASE == 4) && unit == 0 && !cardinal_wg) Wg[g * D::WSLOT + D::w_z + r] = zv[t];
       }
     }
 #pragma unroll
@@ -176,7 +190,7 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
       const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
       if (e < gcount * OR) {
         mirror[g * UD::MS + UD::m_lam + r] = lv[t];
-        if ((PHASE == 0 || PHASE == 3) && unit == 0) Wg[g * D::WSLOT + D::w_lam + r] = lv[t];
+        if ((PHASE == 0 || PHASE == 3 || PHASE == 4) && unit == 0 && !cardinal_wg) Wg[g * D::WSLOT + D::w_lam + r] = lv[t];
       }
     }
     if constexpr (PHASE == 1 && !D::TRAP) {   // g^_i of the first launch (every unit contributed its share)
@@ -190,13 +204,13 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
   UTS();
   const LglTab& tab = *reinterpret_cast<const LglTab*>(lds);
 
-  if constexpr (PHASE == 0 || PHASE == 3) {
+  if constexpr (PHASE == 0 || PHASE == 3 || PHASE == 4) {
     // ---- P1: cardinal values f_j -> mirror (this unit's own copy); unit 0 writes the slots
     if (lane < gcount * CS) {
       const int g = lane / CS, j = lane - g * CS;
       const lds_double* M = mirror + g * UD::MS;
       CardIn<D, const lds_double*> in{M + UD::m_z, nullptr, j, nullptr};
-      if (unit == 0) {
+      if (unit == 0 && !cardinal_wg) {
         OdeOutValue<D, true> out{mirror + g * UD::MS + UD::m_Cf + j * n, Wg + g * D::WSLOT + D::w_Cf + j * n};
         Ode::f(in, out);
       } else {
@@ -236,6 +250,12 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
         for (int k = 0; k < n; k++) li[k] = M[UD::m_lam + i * n + k];
         RegIn<D> in{y, li};
         glb_double* S = Wg + g * D::WSLOT;
+        if (cardinal_wg) {                // PHASE 4, a cardinal unit's workgroup: g^_i[0:n] for its own adjoint weights
+          if constexpr (PHASE == 4) {
+            OdeOutGx<D> out{mirror + g * UD::MS + UD::m_Ig + i * N};
+            Ode::gx(in, out);
+          }
+        } else
         if constexpr (PHASE == 3) {       // Jacobian kinds: f^ (from the unit that holds f), this unit's columns of J^ and of g^ = J^^T lam
           OdeOutUnitJ<D> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, li, {}};
 #pragma unroll
@@ -266,9 +286,10 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
     }
   }
   UTS();
-  if constexpr (PHASE == 1) {
+  if constexpr (PHASE == 4) wave_lds_sync();     // (g^_i in the mirror)
+  if constexpr (PHASE == 1 || PHASE == 4) {
     // ---- P3: cardinal nodes with the adjoint weights w_j (LGLDefects.h:369-374), this unit's share of [J, g, H]
-    if (lane < gcount * CS) {
+    if ((PHASE == 1 || cardinal_wg) && lane < gcount * CS) {
       const int g = lane / CS, j = lane - g * CS;
       const lds_double* M = mirror + g * UD::MS;
       const lds_double* z = M + UD::m_z;

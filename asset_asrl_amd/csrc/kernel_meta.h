@@ -34,6 +34,7 @@ enum MetaField {
   MF_RES_WPS,                                       // ... and the waves per SIMD it is built for
   MF_RESD_GR,                                       // ... its dense part alone behind the unit kernels of a heavy ODE (0: none)
   MF_ROWS_LDS_BYTES,                                // wide shapes, dense stage by output rows (defect_rows.h): its LDS (0: none)
+  MF_RES_NWV,                                       // resident kernel: waves per workgroup (2: the pair form, ResDims::PAIR)
   MF_COUNT
 };
 
@@ -66,7 +67,7 @@ struct LglMeta {
       AdjDims<D>::GP, (long long)AdjDims<D>::lds_bytes(),
       ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>(),
       ResDims<D>::WPS, ResDims<D>::GIVEN_OK ? ResDims<D>::GR : 0,
-      RowsDims<D>::OK ? (long long)RowsDims<D>::lds_bytes() : 0};
+      RowsDims<D>::OK ? (long long)RowsDims<D>::lds_bytes() : 0, ResDims<D>::NWV};
 };
 
 template <class F>

@@ -126,7 +126,8 @@ constexpr int K_RESD(bool asmb) { return 55 + (asmb ? 1 : 0); }   // ... its den
 constexpr int K_UNITSJ = 57;   // heavy right-hand sides, Jacobian kinds: the unit kernel of the ODE stage (defect_units.h, PHASE 3)
 constexpr int K_ROWS = 58;     // wide shapes: dense stage by output rows, no matrix instructions (defect_rows.h)
 constexpr int K_ROWS1 = 59;    // ... the Jacobian kinds
-constexpr int K_COUNT = 60;
+constexpr int K_UNITS4 = 60;   // heavy right-hand sides: interior and cardinal units in one launch (defect_units.h, PHASE 4)
+constexpr int K_COUNT = 61;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -186,6 +187,10 @@ struct Registrar {
 #endif
 
 // ---- the launcher ---------------------------------------------------------------------------------------------------
+#ifndef ASSET_UNITS_ONE_LAUNCH_ROUNDS
+#define ASSET_UNITS_ONE_LAUNCH_ROUNDS 1000   // heavy ODEs: the one-launch unit stage up to this many rounds of the SIMDs -- measured faster at every size
+                                            // tried (Betts-LGL5 x 1 000: 30.3 against 41.5 us, x 10 000: 191.7 / 200.0; Betts-LGL7 x 5 000: 145.1 / 151.1)
+#endif
 // Dispatch knobs of the measurement scripts (tools/): read ONLY when the process opts in with ASSET_HIP_TUNING=1, so that a
 // stray variable in a production environment cannot change which kernels run.  With the opt-in, every knob that takes effect is
 // reported once on stderr.
@@ -251,7 +256,10 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         const int waves = cus * 4 * int(m[MF_RES_WPS]);   // resident kernel, Jacobian kinds (defect_resident.h, LEVEL 1)
         const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
         const KRef& kr = one ? t.k[K_RES1(a.kmap != nullptr)] : t.k[K_RESL(1, a.kmap != nullptr)];
-        if (kr) return klaunch(kr, dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
+        // (the one-group kernel of a pair shape: two waves per workgroup, a region of LDS each; the looped one: single waves)
+        const int nwv = (one && m[MF_RES_NWV] > 1) ? 2 : 1, nw = a.nseg < waves ? a.nseg : waves;
+        const size_t lds = size_t(m[MF_RES_LDS_BYTES]) / size_t(m[MF_RES_NWV] > 1 ? 2 : 1) * size_t(nwv);
+        if (kr) return klaunch(kr, dim3((nw + nwv - 1) / nwv), dim3(64 * nwv), lds, st, kargs);
       }
       static const bool no_fuse1 = tuning_env("ASSET_HIP_NO_FUSE") != nullptr;                                // tuning only
       if (m[MF_FUSED] && !no_fuse1 && !skip_dense && (a.nseg + grid_b - 1) / grid_b <= int(m[MF_GF]) && t.k[K_LGL(1, 3, a.kmap != nullptr)])
@@ -284,7 +292,11 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
         const KRef& kr = one ? t.k[K_RES(a.kmap != nullptr)] : t.k[K_RESL(2, a.kmap != nullptr)];
         if (kr && (one || env_max <= 0 || (a.nseg + waves - 1) / waves <= env_max * int(m[MF_RES_GR])))
-          return klaunch(kr, dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
+        {
+          const int nwv = (one && m[MF_RES_NWV] > 1) ? 2 : 1, nw = a.nseg < waves ? a.nseg : waves;
+          const size_t lds = size_t(m[MF_RES_LDS_BYTES]) / size_t(m[MF_RES_NWV] > 1 ? 2 : 1) * size_t(nwv);
+          return klaunch(kr, dim3((nw + nwv - 1) / nwv), dim3(64 * nwv), lds, st, kargs);
+        }
       }
       if (m[MF_FUSED]) {
         // single launch when every workgroup's share fits one group of the fused kernel (defect_kernels.h, STAGE 3)
@@ -312,10 +324,23 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         int gp = (a.nseg * nunits + 4 * cus - 1) / (4 * cus);
         gp = gp < 1 ? 1 : (gp > gpmax ? gpmax : gp);
         const size_t bytes_units = size_t(m[MF_UNITS_BASE_BYTES]) + size_t(gp) * size_t(m[MF_UNITS_SLOT_BYTES]);
+        // One launch (PHASE 4: every cardinal unit forms the interior gradients it needs itself) while its 2 x units x groups
+        // workgroups are about one round of the device's SIMDs; two launches (interior units, then cardinal units) beyond
+        static const int units1 = tuning_env("ASSET_HIP_UNITS_ONE_LAUNCH") ? std::atoi(std::getenv("ASSET_HIP_UNITS_ONE_LAUNCH")) : -1;   // tuning only
+        int gp4 = (a.nseg * 2 * nunits + 4 * cus - 1) / (4 * cus);
+        gp4 = gp4 < 1 ? 1 : (gp4 > gpmax ? gpmax : gp4);
+        const long long wgs4 = (long long)((a.nseg + gp4 - 1) / gp4) * 2 * nunits;
+        const bool one_launch = t.k[K_UNITS4] && (units1 >= 0 ? units1 != 0 : wgs4 <= (long long)(ASSET_UNITS_ONE_LAUNCH_ROUNDS * 4) * cus);
+        if (one_launch) {
+          const size_t bytes4 = size_t(m[MF_UNITS_BASE_BYTES]) + size_t(gp4) * size_t(m[MF_UNITS_SLOT_BYTES]);
+          void* uargs4[] = {&args, &gp4};
+          if ((e = klaunch(t.k[K_UNITS4], dim3((a.nseg + gp4 - 1) / gp4, 2 * nunits), dim3(64), bytes4, st, uargs4)) != hipSuccess) return e;
+        } else {
         const dim3 grid((a.nseg + gp - 1) / gp, nunits);
         void* uargs[] = {&args, &gp};
         if ((e = klaunch(t.k[K_UNITS0], grid, dim3(64), bytes_units, st, uargs)) != hipSuccess) return e;
         if ((e = klaunch(t.k[K_UNITS1], grid, dim3(64), bytes_units, st, uargs)) != hipSuccess) return e;
+        }
       } else if ((e = ode_stage(2)) != hipSuccess) {
         return e;
       }
@@ -433,6 +458,7 @@ const KernelTable* lgl_static_table() {
       r.k[K_UNITS0].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 0>);
       r.k[K_UNITS1].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 1>);
       r.k[K_UNITSJ].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 3>);
+      r.k[K_UNITS4].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 4>);
     }
     r.k[K_ADJGRAD].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED, true>);
     r.k[K_VALUE].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED, false>);
@@ -523,6 +549,7 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
   if (slot == K_UNITS0) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 0>";
   if (slot == K_UNITS1) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 1>";
   if (slot == K_UNITSJ) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 3>";
+  if (slot == K_UNITS4) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 4>";
   if (slot == K_ADJGRAD) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ", true>";
   if (slot == K_VALUE) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ", false>";
   if (slot == K_MESH_YVEC) return "asset_hip::mesh_yvec_kernel<" + lgl + ">";

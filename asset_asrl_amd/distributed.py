@@ -51,7 +51,8 @@ class HostSharedBlocks:
     rank's flat device buffer into its range; ``wait`` completes it and meets the other ranks at a barrier, after which
     the root (any rank) reads every shard from ``.buf`` -- host memory, no collective in the data path."""
 
-    def __init__(self, slot_doubles: int, rank: int, world: int, group=None, barrier_group=None, tag: Optional[str] = None):
+    def __init__(self, slot_doubles: int, rank: int, world: int, group=None, barrier_group=None, tag: Optional[str] = None,
+                 total_doubles: Optional[int] = None):
         import os
         import torch
         import torch.distributed as dist
@@ -64,7 +65,7 @@ class HostSharedBlocks:
                 self._dist.broadcast_object_list(box, src=0, group=group)
             tag = box[0]
         self.path = os.path.join("/dev/shm", tag)
-        n = self.slot * world
+        n = self.slot * world if total_doubles is None else int(total_doubles)   # (total_doubles: a layout of the caller's own)
         self.buf, self._registered = None, False
         # Every local step that can fail is followed by an agreement among the ranks (an all-reduce of a success flag in
         # place of a bare barrier): a failure on one rank raises on ALL of them at the same point, nobody is left waiting
@@ -88,7 +89,7 @@ class HostSharedBlocks:
             except Exception as exc:              # noqa: BLE001 -- whatever it is, the other ranks must hear of it
                 err = exc
             self._agree(err, "mapping / page-locking the shared block buffer")
-            self.mine = self.buf[rank * self.slot:(rank + 1) * self.slot]
+            self.mine = self.buf[rank * self.slot:(rank + 1) * self.slot] if total_doubles is None else None
         except Exception:
             self.close()
             raise
@@ -283,6 +284,128 @@ class ShardedDefectEvaluator(_StreamOrder):
         if len(per) == 1:
             return per[0]
         return tuple(torch.cat([p[k] for p in per], dim=0) for k in range(3))
+
+    # ---- sharded on-device assembly (SURVEY section 8 rows f-1 x e) ---------------------------------
+    # Every rank assembles ITS shard into a compact value array on its device -- the locations its slots name, sorted -- and
+    # pushes it over its own PCIe link straight into the solver's value array in shared page-locked host memory: segments are
+    # contiguous in the variable order, so a shard's locations are one long run of the CSR value array
+    # (NonLinearProgram.cpp:316-330) plus a few short pieces around the nodes it shares with its neighbours and in the rows of
+    # phase parameters.  Long runs that only this rank touches are copied to their place directly; everything else (short runs,
+    # locations two or more ranks contribute to) travels as one packed side vector per rank, and the root adds those -- a few
+    # hundred entries per shard boundary -- after the barrier.  The host-side scatter of the reference
+    # (DenseFunctionBase.h:1449-1465, one indexed += per slot) is gone; no block array leaves a device.
+    SIDE_RUN = 4096          # runs of fewer locations than this go through the packed side vector
+
+    def set_kkt_map(self, slot_locations, nvalues: int):
+        """slot_locations[nseg_total, NKKT] = KKTLocations[InnerKKTStarts[V] + k] of the WHOLE constraint (every rank passes the
+        same table, as it passes the same index tables), nvalues = length of the solver's value array; -1 drops a slot."""
+        m = np.ascontiguousarray(slot_locations, dtype=np.int64).reshape(self.nseg_total, self.NKKT)
+        self._nvalues = int(nvalues)
+        locs = []
+        for s, c in self.shards:
+            l = np.unique(m[s:s + c]) if c > 0 else np.zeros(0, dtype=np.int64)
+            locs.append(l[l >= 0])
+        cnt = np.zeros(self._nvalues, dtype=np.int16)            # ranks that contribute to a location
+        for l in locs:
+            cnt[l] += 1
+        plans = []
+        for l in locs:                                           # the same plan on every rank: the root needs all of them
+            if l.size == 0:
+                plans.append((np.zeros((0, 3), dtype=np.int64), np.zeros(0, dtype=np.int64)))
+                continue
+            ex = cnt[l] == 1
+            brk = np.nonzero((np.diff(l) != 1) | (ex[1:] != ex[:-1]))[0] + 1
+            a, b = np.r_[0, brk], np.r_[brk, l.size]
+            direct = ex[a] & (b - a >= self.SIDE_RUN)
+            runs = np.stack([a[direct], b[direct], l[a[direct]]], axis=1) if direct.any() else np.zeros((0, 3), dtype=np.int64)
+            side = np.ones(l.size, dtype=bool)
+            for pa, pb, _ in runs:
+                side[pa:pb] = False
+            plans.append((runs, np.nonzero(side)[0]))
+        self._asm_locs, self._asm_plans = locs, plans
+        self._side_off = np.r_[0, np.cumsum([p[1].size for p in plans])].astype(np.int64)
+        mine = locs[self.rank]
+        if self.ev is not None:
+            mr = m[self.start:self.start + self.count]
+            lm = np.full(mr.shape, -1, dtype=np.int32)
+            sel = mr >= 0
+            lm[sel] = np.searchsorted(mine, mr[sel]).astype(np.int32)
+            self.ev.set_kkt_map(lm, int(mine.size))
+        return self
+
+    def alloc_assembled(self, device, barrier_group=None, tag: Optional[str] = None):
+        """Device buffers of the assembled evaluation -- this rank's compact value array, its FX / AGX blocks -- and the shared
+        page-locked host layout [values (nvalues) | side vectors | FX, AGX blocks of every rank]."""
+        import torch
+        mine, (runs, side_pos) = self._asm_locs[self.rank], self._asm_plans[self.rank]
+        self._vals = torch.zeros(max(1, mine.size), dtype=torch.float64, device=device)
+        self._side_pos = torch.from_numpy(side_pos).to(device)
+        self._side_dev = torch.zeros(max(1, side_pos.size), dtype=torch.float64, device=device)
+        self._fa = torch.zeros(self.max_count * (self.OR + self.IR), dtype=torch.float64, device=device)
+        self._afx = self._fa[:self.max_count * self.OR].view(self.max_count, self.OR)
+        self._aagx = self._fa[self.max_count * self.OR:].view(self.max_count, self.IR)
+        self._fa_off = self._nvalues + int(self._side_off[-1])
+        total = self._fa_off + self.world * self._fa.numel()
+        self._hostv = HostSharedBlocks(0, self.rank, self.world, self.group, barrier_group, tag, total_doubles=total)
+        self._ordered = True
+        return self
+
+    def eval_assembled_device(self, what: int, X, L=None, stream=None):
+        """This rank's shard of an evalKKT: KKT entries summed into its compact value array, FX / AGX blocks beside them."""
+        stream = self._eval_stream(stream)
+        if self.ev is not None:
+            import torch
+            ctx = torch.cuda.stream(stream) if (stream is not None and not isinstance(stream, int) and torch.cuda.is_available()) else None
+            if ctx is not None:
+                with ctx:
+                    self._vals.zero_()
+            else:
+                self._vals.zero_()
+            self.ev.eval_assembled_device(what, X, L, self._afx, self._aagx if what in _ADJ else None, self._vals, stream)
+        self._mark_evaluated(stream)
+
+    def push_assembled(self):
+        """Enqueue this rank's copies into the shared host layout (on the current stream, after the evaluation)."""
+        import torch
+        self._after_evaluation()
+        host = self._hostv.buf
+        runs, side_pos = self._asm_plans[self.rank]
+        for pa, pb, loc in runs:                                 # long runs only this rank touches: straight to their place
+            host[int(loc):int(loc) + int(pb - pa)].copy_(self._vals[int(pa):int(pb)], non_blocking=True)
+        if side_pos.size:
+            self._side_dev[:side_pos.size].copy_(self._vals.index_select(0, self._side_pos))   # one packed vector per rank
+            o = self._nvalues + int(self._side_off[self.rank])
+            host[o:o + side_pos.size].copy_(self._side_dev[:side_pos.size], non_blocking=True)
+        o = self._fa_off + self.rank * self._fa.numel()
+        host[o:o + self._fa.numel()].copy_(self._fa, non_blocking=True)
+
+    def wait_assembled(self, stream=None, dst: int = 0):
+        """Completes this rank's copies, meets the other ranks, and -- on `dst` -- adds the side vectors into the value array.
+        Afterwards ``host_values()`` holds the constraint's whole contribution at its locations (other locations untouched)."""
+        self._hostv.wait(stream)
+        if self.rank == dst:
+            host = self._hostv.buf.numpy()
+            vals = host[:self._nvalues]
+            sides = [(self._asm_locs[r][self._asm_plans[r][1]], host[self._nvalues + int(self._side_off[r]):self._nvalues + int(self._side_off[r + 1])])
+                     for r in range(self.world) if self._asm_plans[r][1].size]
+            for l, _ in sides:
+                vals[l] = 0.0
+            for l, v in sides:                                   # (a rank's side locations are distinct: a plain indexed +=)
+                vals[l] += v
+        self._hostv._barrier()                                   # (nobody reads, nobody overwrites, before the root is done)
+
+    def host_values(self):
+        return self._hostv.buf.numpy()[:self._nvalues]
+
+    def host_assembled_blocks(self):
+        """[(fx, agx)] per rank from the shared host layout."""
+        out, n = [], self._fa.numel()
+        host = self._hostv.buf.numpy()
+        for r, (_, c) in enumerate(self.shards):
+            f = host[self._fa_off + r * n:self._fa_off + (r + 1) * n]
+            out.append((f[:self.max_count * self.OR].reshape(self.max_count, self.OR)[:c],
+                        f[self.max_count * self.OR:].reshape(self.max_count, self.IR)[:c]))
+        return out
 
     # ---- exchange of host blocks (kept for callers that evaluate through host pointers) -----
     def gather_blocks(self, blocks, dst: int = 0, device=None):

@@ -61,6 +61,25 @@ class DefectEvaluator:
             raise ValueError(f"index tables are [{self.vindex.shape[1]}],[{self.cindex.shape[1]}] wide, "
                              f"the defect needs IR={self.IR}, OR={self.OR}")
 
+    def rebind(self, vindex, cindex, n_primal: int, n_equal: int):
+        """New index tables for the same (ODE, transcription, control mode): the re-meshing step of the adaptive mesh loop
+        (asset_hip_defect_rebind; ODEPhaseBase.cpp:1443-1542).  Keeps the device code, the per-lane tables, the stream and
+        every buffer that still fits; a KKT map, per-application constants and pinned outputs must be set again."""
+        v = np.ascontiguousarray(vindex, dtype=np.int32)
+        c = np.ascontiguousarray(cindex, dtype=np.int32)
+        if v.ndim != 2 or c.ndim != 2 or v.shape[0] != c.shape[0] or v.shape[1] != self.IR or c.shape[1] != self.OR:
+            raise ValueError(f"vindex/cindex must be [nseg, {self.IR}] / [nseg, {self.OR}]")
+        for b in (self._pinned or ()):
+            _lib.lib().asset_hip_host_unregister(b.ctypes.data)
+        self._pinned = None
+        _lib.check(_lib.lib().asset_hip_defect_rebind(self._h, v.shape[0], v.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                      c.ctypes.data_as(C.POINTER(C.c_int32)), int(n_primal), int(n_equal)),
+                   "asset_hip_defect_rebind")
+        self.vindex, self.cindex, self.nseg = v, c, v.shape[0]
+        self.n_primal, self.n_equal = int(n_primal), int(n_equal)
+        self._nvalues = -1
+        return self
+
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None and getattr(_lib, "lib", None) is not None:   # module globals vanish at interpreter exit

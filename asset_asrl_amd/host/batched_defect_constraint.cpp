@@ -1,5 +1,7 @@
 #include "batched_defect_constraint.h"
 
+#include <memory>
+
 #include <cstring>
 #include <stdexcept>
 
@@ -27,7 +29,7 @@ static void check(int rc, const char* what) {
 BatchedDefectConstraint::BatchedDefectConstraint(const std::string& ode, int mode, bool blocked,
                                                  const SolverIndexingData& data, int primal_vars, int equal_cons,
                                                  int device)
-    : ode_(ode), mode_(mode), nappl_(data.NumAppl()), n_equal_(equal_cons) {
+    : ode_(ode), mode_(mode), nappl_(data.NumAppl()), n_equal_(equal_cons), blocked_(blocked), n_primal_(primal_vars), device_(device) {
   if (data.NumAppl() <= 0) throw std::invalid_argument("BatchedDefectConstraint: no function applications");
   asset_hip_defect_desc d;
   std::memset(&d, 0, sizeof d);
@@ -60,12 +62,48 @@ BatchedDefectConstraint::BatchedDefectConstraint(const std::string& ode, int mod
 }
 
 BatchedDefectConstraint::~BatchedDefectConstraint() {
+  unpin();
+  asset_hip_defect_destroy(h_);
+}
+
+void BatchedDefectConstraint::unpin() {
   if (pinned_) {
     (void)asset_hip_host_unregister(fx_.data());
     (void)asset_hip_host_unregister(agx_.data());
     (void)asset_hip_host_unregister(kkt_.data());
+    pinned_ = false;
   }
-  asset_hip_defect_destroy(h_);
+}
+
+// New index data for the same function: the re-meshing step of the adaptive mesh loop (ODEPhaseBase.cpp:1443-1542).  The
+// device handle keeps its code, lane tables, stream and every buffer that still fits (asset_hip_defect_rebind).
+void BatchedDefectConstraint::rebind(const SolverIndexingData& data, int primal_vars, int equal_cons) {
+  if (data.NumAppl() <= 0 || data.input_size != ir_ || data.output_size != or_)
+    throw std::invalid_argument("BatchedDefectConstraint::rebind: index data does not fit this function");
+  const int rc = asset_hip_defect_rebind(h_, data.NumAppl(), data.Vindex.data(), data.Cindex.data(), primal_vars, equal_cons);
+  if (rc == ASSET_HIP_EINVAL || rc == ASSET_HIP_ERANGE)
+    throw std::invalid_argument(std::string("BatchedDefectConstraint::rebind: ") + asset_hip_last_error());
+  check(rc, "asset_hip_defect_rebind");
+  unpin();
+  nappl_ = data.NumAppl(), n_primal_ = primal_vars, n_equal_ = equal_cons;
+  fx_.resize(size_t(nappl_) * or_);
+  agx_.resize(size_t(nappl_) * ir_);
+  kkt_.resize(size_t(nappl_) * nkkt_);
+  pinned_ = asset_hip_host_register(fx_.data(), fx_.size() * sizeof(double)) == 0 &&
+            asset_hip_host_register(agx_.data(), agx_.size() * sizeof(double)) == 0 &&
+            asset_hip_host_register(kkt_.data(), kkt_.size() * sizeof(double)) == 0;
+  map_source_ = nullptr;          // (the KKT map was the old tables': gathered and uploaded again at the next evaluation)
+  map_.clear();
+}
+
+// DeepCopySpecs.h:36-60: an independent function object -- a device handle of its own, created from the same descriptor.
+// (Copying the object itself is deleted: ConstraintFunction copies its function by value, ConstraintFunction.h:40-62, and two
+// copies must not release one handle twice; an adapter that needs value semantics holds this class -- or the raw handle --
+// in a std::shared_ptr)
+std::unique_ptr<BatchedDefectConstraint> BatchedDefectConstraint::deep_copy(const SolverIndexingData& data) const {
+  auto c = std::make_unique<BatchedDefectConstraint>(ode_, mode_, blocked_, data, n_primal_, n_equal_, device_);
+  if (nvalues_ > 0) c->enable_device_assembly(nvalues_);
+  return c;
 }
 
 void BatchedDefectConstraint::set_appl_consts(const double* consts, int per_application) {

@@ -12,6 +12,7 @@
 // on the calling thread, i.e. it is meant to be registered with ThreadMode = MainThread
 // (Solvers/NonLinearProgram.cpp:86-104), as SURVEY.md section 8(b) prescribes.
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -40,6 +41,11 @@ class BatchedDefectConstraint {
   ~BatchedDefectConstraint();
   BatchedDefectConstraint(const BatchedDefectConstraint&) = delete;
   BatchedDefectConstraint& operator=(const BatchedDefectConstraint&) = delete;
+
+  // new index data for the same function (adaptive mesh refinement: another number of applications); keeps the device handle
+  void rebind(const SolverIndexingData& data, int primal_vars, int equal_cons);
+  // DeepCopySpecs.h:36-60 (deep_copy_into): an independent object with a device handle of its own
+  std::unique_ptr<BatchedDefectConstraint> deep_copy(const SolverIndexingData& data) const;
 
   // constants of the function's applications (a plain function built with vf.ApplConst): [NumAppl][per_application]
   void set_appl_consts(const double* consts, int per_application);
@@ -95,9 +101,12 @@ class BatchedDefectConstraint {
  private:
   void eval(int what, const double* X, const double* L, double* FX, double* AGX, double* KKTvals,
             const int* KKTLocations, const SolverIndexingData& data, bool hess_only = false);
+  void unpin();
   asset_hip_defect_t h_ = nullptr;
   std::string ode_;
   int mode_, ir_ = 0, or_ = 0, nkkt_ = 0, nappl_ = 0, n_equal_ = 0;
+  bool blocked_ = false;
+  int n_primal_ = 0, device_ = 0;
   std::vector<double> fx_, agx_, kkt_;
   bool pinned_ = false;
   // device assembly state

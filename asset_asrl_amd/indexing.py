@@ -212,3 +212,31 @@ def thread_split(nappl: int, parts: int):
         out.append((start, cnt))
         start += cnt
     return out
+
+
+def kkt_slot_locations(vindex, cindex, n_primal: int, con_offset: int = 0):
+    """``KKTLocations`` of ONE equality constraint alone in its program: for every application V and block slot k (slot order
+    ``for i < IR {H(j,i), j >= i ; J(j,i), j < OR}``, DenseFunctionBase.h:1112-1123) the offset of its entry in the value array
+    of the upper-triangular row-major CSR KKT matrix (NonLinearProgram.cpp:267-344: lower-triangle triplets are transposed,
+    equality rows live behind the primal variables and the slacks -- none here -- so J(c, v) is stored at (v, n_primal + c)).
+    Structure only: the matrix holds exactly the entries the constraint's slots name, columns sorted within a row, as
+    ``analyzeSparsity`` leaves them.  Returns (locations[nappl, NKKT] int64, nnz)."""
+    V = np.ascontiguousarray(vindex, dtype=np.int64)
+    C = np.ascontiguousarray(cindex, dtype=np.int64)
+    nappl, IR = V.shape
+    OR = C.shape[1]
+    dim = int(n_primal) + int(con_offset) + int(C.max()) + 1
+    cols_h, rows_h = [], []
+    keys = np.empty((nappl, IR * (IR + 1) // 2 + OR * IR), dtype=np.int64)
+    k = 0
+    for i in range(IR):
+        vi = V[:, i]
+        for j in range(i, IR):                      # H(j, i), lower triangle: stored at (min, max)
+            vj = V[:, j]
+            keys[:, k] = np.minimum(vi, vj) * dim + np.maximum(vi, vj)
+            k += 1
+        for j in range(OR):                         # J(j, i): row of the variable, column of the constraint
+            keys[:, k] = vi * dim + (n_primal + con_offset + C[:, j])
+            k += 1
+    uniq, inv = np.unique(keys.ravel(), return_inverse=True)
+    return inv.reshape(keys.shape), int(uniq.size)

@@ -97,6 +97,7 @@ class Phase:
         self.numDefects = 0
         self.DefBinSpacing, self.DefsPerBin = np.array([0.0, 1.0]), np.array([1], dtype=int)
         self._ev = None
+        self._ev_kept = None      # (key, evaluator): survives re-meshing, see transcribe()
         self._indexer = None
         self.AutoScaling = False
         self.XtUPUnits = np.ones(ode.XtUPVars())
@@ -418,8 +419,19 @@ class Phase:
         V, Cx = ix.make_defect_Vindex_Cindex()
         self._indexer = ix
         self._make_function_evaluators(ix)
-        self._ev = DefectEvaluator(name, self.TranscriptionMode, self._blocked(), V, Cx, ix.numPhaseVars,
-                                   self.numPhaseEqCons, self.device)
+        # a re-meshed phase (refineTrajManual: another number of segments, same dynamics and transcription) keeps its device
+        # handle and gives it new index tables (asset_hip_defect_rebind) instead of creating one: the re-meshing step of the
+        # adaptive mesh loop, ODEPhaseBase.cpp:1443-1542
+        key = (name, self.TranscriptionMode, self._blocked(), self.device)
+        kept = self._ev_kept
+        if kept is not None and kept[0] == key and kept[1]._h:
+            self._ev = kept[1].rebind(V, Cx, ix.numPhaseVars, self.numPhaseEqCons)
+        else:
+            if kept is not None:
+                kept[1].close()
+            self._ev = DefectEvaluator(name, self.TranscriptionMode, self._blocked(), V, Cx, ix.numPhaseVars,
+                                       self.numPhaseEqCons, self.device)
+            self._ev_kept = (key, self._ev)
         return self
 
     def prebuild_device_code(self):

@@ -423,6 +423,11 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
         o.append("  }")
         o.append(f"  static constexpr unsigned UNIT_COLS[{len(units)}] = {{" + ", ".join(str(sum(1 << c for c in m)) + "u" for m in masks) + "};")
         o.append(f"  static constexpr int F_UNIT = {f_unit};")
+        # the state components of g = J^T lam alone (a vector-Jacobian product: about three value bodies).  The cardinal adjoint
+        # weights w_j (LGLDefects.h:369-374) need g^_i[0:n] of the interior points and nothing else of them, so a workgroup that
+        # evaluates a cardinal unit forms it itself instead of waiting for the interior units of a launch before
+        # (csrc/defect_units.h, PHASE 4)
+        body("gx", [(f"out.g({i}, {{}});", d.g[i]) for i in range(n)], q=UNIT_QUAL, level_order=UNIT_LEVEL_ORDER)
     if split:
         two_parts("fjgh", False)
     else:

@@ -362,6 +362,44 @@ def main():
         elif host_visible is None:
             host_visible = {"error": "shared host buffer unavailable on another rank"}
 
+    # the same with the KKT entries ASSEMBLED on the device(s) (SURVEY section 8 rows f-1 x e): every rank sums its shard into a
+    # compact value array and pushes it into ONE shared page-locked value array -- nnz values instead of nseg * NKKT block
+    # slots, no host-side scatter.  N = 1: asset_hip_defect_eval_assembled_zeroed's path on device pointers + one copy.
+    host_visible_assembled = None
+    if nphases == 1 and host_visible is not None and "error" not in host_visible and nseg * NKKT <= 60_000_000:
+        from asset_asrl_amd.indexing import kkt_slot_locations
+        locs, nnz = kkt_slot_locations(w.vindex, w.cindex, n_primal)
+        k3 = max(5, min(a.steps, 50))
+        if use_dist:
+            sh.set_kkt_map(locs, nnz).alloc_assembled(dev, barrier_group=gloo_group)
+
+            def asm_step():
+                sh.eval_assembled_device(JAC_ADJGRAD_HESS, X, L, stream)
+                sh.push_assembled()
+                sh.wait_assembled(stream)
+            bytes_rank = (sh._asm_locs[rank].size + sh._fa.numel()) * 8
+        else:
+            ev.set_kkt_map(locs, nnz)
+            dvals = torch.zeros(nnz, dtype=torch.float64, device=dev)
+            hvals = torch.empty(nnz, dtype=torch.float64, pin_memory=True)
+
+            def asm_step():
+                dvals.zero_()
+                ev.eval_assembled_device(JAC_ADJGRAD_HESS, X, L, fx, agx, dvals, stream)
+                hvals.copy_(dvals, non_blocking=True)
+                hfx.copy_(fx, non_blocking=True)
+                hagx.copy_(agx, non_blocking=True)
+                stream.synchronize()
+            bytes_rank = (nnz + fx.numel() + agx.numel()) * 8
+        th = timed(asm_step, k3, 2) / k3
+        host_visible_assembled = {"ms_per_step": th * 1e3, "segments_per_s": total_segments / th, "bytes_per_rank": bytes_rank,
+                                  "kkt_values": nnz, "block_slots": nseg * NKKT,
+                                  "path": "every rank assembles its shard's KKT entries on its device and pushes the values over its own "
+                                          "PCIe link into one shared page-locked value array (+ FX / AGX blocks); the root adds the few "
+                                          "entries shard boundaries share; barrier"}
+        if use_dist:
+            sh._hostv.close()
+
     bseg = algorithmic_bytes_per_segment(IR, OR)
     # roofline: the launch duration over the TIMED REGION (HIP events around the K steps, N = 1: one evaluation per step,
     # nothing else on the stream); with an exchange in the step (N > 1) the kernel's own settled HIP-event figure
@@ -439,6 +477,8 @@ def main():
         out.update(extra)
         if host_visible is not None:
             out["host_visible"] = host_visible
+        if host_visible_assembled is not None:
+            out["host_visible_assembled"] = host_visible_assembled
         if world == 1 and not a.no_cpu_baseline:
             # bounded sample: the oracle's CSR scatter needs 12 B per KKT slot on the host -- cap it at 2e8 slots
             cap = max(1, int(2e8) // NKKT)

@@ -88,6 +88,15 @@ typedef struct asset_hip_defect_desc {
 int asset_hip_defect_create(const asset_hip_defect_desc* desc, asset_hip_defect_t* out);
 void asset_hip_defect_destroy(asset_hip_defect_t h);
 
+/* New index tables for an existing handle: what the adaptive mesh loop needs after every re-meshing step
+ * (OptimalControl/ODEPhaseBase.cpp:1443-1542: refineTrajAuto -> resetTranscription -> transcribe; :1639-1673 the loop) -- the
+ * number of segments changes, the ODE, the transcription and the device code do not.  Keeps the handle's module, per-lane
+ * constant tables, stream and every buffer that still fits (index tables, workspace and block staging grow in steps of a
+ * quarter); drops what was derived from the old tables (KKT map, RHS gather tables, per-application constants).  Same
+ * argument meaning and checks as asset_hip_defect_create; synchronises the handle's stream. */
+int asset_hip_defect_rebind(asset_hip_defect_t h, int nseg, const int32_t* vindex, const int32_t* cindex, int n_primal,
+                            int n_equal);
+
 /* IRows, ORows, per-application KKT slots */
 int asset_hip_defect_sizes(asset_hip_defect_t h, int* irows, int* orows, int* nkkt);
 

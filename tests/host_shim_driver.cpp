@@ -50,6 +50,48 @@ extern "C" int shim_run(const char* ode, int mode, int blocked, int ir, int orr,
   }
 }
 
+// The same evaluation through a constraint that was created for another mesh (the first nappl0 applications of a smaller
+// program), re-bound to this one (BatchedDefectConstraint::rebind, the adaptive mesh loop's step), and then deep-copied
+// (DeepCopySpecs.h:36-60): the COPY evaluates, with the original destroyed first -- it must own a handle of its own.
+extern "C" int shim_rebind_run(const char* ode, int mode, int blocked, int ir, int orr, int nappl, const int* vindex,
+                               const int* cindex, int primal, int equal, int nappl0, const double* X, const double* L,
+                               const int* kkt_locations, double* kkt_vals, double* FXE, double* AGX, char* err, int errcap,
+                               long long assembly_nvalues) {
+  try {
+    SolverIndexingData small, data;
+    small.input_size = ir, small.output_size = orr, small.num_funcappl = nappl0;
+    small.Vindex.assign(vindex, vindex + size_t(ir) * nappl0);
+    small.Cindex.assign(cindex, cindex + size_t(orr) * nappl0);
+    data.input_size = ir, data.output_size = orr, data.num_funcappl = nappl;
+    data.Vindex.assign(vindex, vindex + size_t(ir) * nappl);
+    data.Cindex.assign(cindex, cindex + size_t(orr) * nappl);
+    auto con = std::make_unique<BatchedDefectConstraint>(ode, mode, blocked != 0, small, primal, equal, 0);
+    if (assembly_nvalues > 0) con->enable_device_assembly(assembly_nvalues);
+    {
+      std::vector<double> f0(size_t(orr) * nappl0);
+      con->constraints(X, f0.data(), small);                      // (the handle has been used on the old mesh)
+    }
+    con->rebind(data, primal, equal);
+    std::vector<int> gxrows(size_t(ir) * nappl), fxrows(size_t(orr) * nappl), krows(size_t(con->numKKTEles(true, true)) * nappl),
+        kcols(krows.size());
+    int gfree = 0, cfree = 0, kfree = 0;
+    data.getGradientSpace(gxrows.data(), gfree);
+    data.getConstraintSpace(fxrows.data(), cfree);
+    con->getKKTSpace(krows.data(), kcols.data(), kfree, primal, true, true, data);
+    std::unique_ptr<BatchedDefectConstraint> copy = con->deep_copy(data);
+    con.reset();
+    std::vector<double> fxc(size_t(orr) * nappl, 0.0), agxc(size_t(ir) * nappl, 0.0);
+    copy->constraints_jacobian_adjointgradient_adjointhessian(X, L, fxc.data(), agxc.data(), kkt_vals, kkt_locations, data);
+    for (size_t i = 0; i < fxc.size(); i++) FXE[fxrows[i]] += fxc[i];
+    for (size_t i = 0; i < agxc.size(); i++) AGX[gxrows[i]] += agxc[i];
+    return 0;
+  } catch (const std::exception& e) {
+    std::strncpy(err, e.what(), errcap - 1);
+    err[errcap - 1] = 0;
+    return 1;
+  }
+}
+
 // ---- KktAssembly (asset_asrl_amd/host/kkt_assembly.h): structure + the four evaluation entry points -------------
 #include "../asset_asrl_amd/host/kkt_assembly.h"
 

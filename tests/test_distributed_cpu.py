@@ -36,6 +36,23 @@ class _OracleShard:
             kkt[: self.nseg].copy_(torch.from_numpy(rkkt))
 
 
+    # on-device assembly, stand-in: the oracle's blocks added into the (compact) value array through the map the sharded
+    # evaluator hands over -- what asset_hip_defect_set_kkt_map / _eval_assembled_device do on a GPU
+    def set_kkt_map(self, local_map, nvalues):
+        self._map, self._nv = np.asarray(local_map), int(nvalues)
+
+    def eval_assembled_device(self, what, X, L, fx, agx, vals, stream=None):
+        import torch
+        rfx, ragx, rkkt = self.nlp.eval_blocks(what, X.numpy(), None if L is None else L.numpy())
+        fx[: self.nseg].copy_(torch.from_numpy(rfx))
+        if agx is not None:
+            agx[: self.nseg].copy_(torch.from_numpy(ragx))
+        v = vals.numpy()
+        assert not v[: self._nv].any()                               # (the caller hands over zeros)
+        sel = self._map >= 0
+        np.add.at(v, self._map[sel], rkkt[sel])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -221,3 +238,61 @@ def test_host_shared_blocks_fail_on_every_rank_together():
     assert [g[1] for g in got] == ["raised", "raised"], got
     assert "another rank" in got[0][2] and "this rank" in got[1][2]
     assert not os.path.exists(f"/dev/shm/asset_hip_test_fail_{port}")
+
+
+def _asm_worker(rank, world, port, nseg, side_run, q):
+    import torch
+    dist = _init(rank, world, port)
+    from asset_asrl_amd.distributed import ShardedDefectEvaluator
+    from asset_asrl_amd.indexing import kkt_slot_locations
+    w = Workload("reentry", "LGL5", nseg)
+    sh = ShardedDefectEvaluator("reentry", "LGL5", False, w.vindex, w.cindex, w.n_primal, w.n_equal,
+                                evaluator_factory=_OracleShard)
+    sh.SIDE_RUN = side_run
+    locs, nnz = kkt_slot_locations(w.vindex, w.cindex, w.n_primal)
+    nvalues = nnz + 11                                                # (the solver's own slots behind the constraint's)
+    sh.set_kkt_map(locs, nvalues).alloc_assembled(torch.device("cpu"))
+    X, L = torch.from_numpy(w.X), torch.from_numpy(w.L)
+    for it in range(2):                                               # twice: every solver iteration re-uses the layout
+        if rank == 0:
+            sh.host_values()[:] = 7.0                                 # what other functions / the solver left there
+        dist.barrier()
+        sh.eval_assembled_device(4, X, L)
+        sh.push_assembled()
+        sh.wait_assembled()
+    if rank == 0:
+        q.put((sh.host_values().copy(), [tuple(a.copy() for a in b) for b in sh.host_assembled_blocks()], sh.shards,
+               [int(p[0].shape[0]) for p in sh._asm_plans]))
+    sh._hostv.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nseg,world,side_run", [(9, 2, 4096), (10, 4, 16), (3, 4, 4), (40, 4, 64)])
+def test_sharded_assembly_on_the_device_is_bitwise_the_single_scatter(oracle, nseg, world, side_run):
+    """SURVEY section 8 rows f-1 x e: every rank assembles its shard, pushes its long runs straight into the shared value array
+    and the rest as one side vector; the root's result is bit for bit the scatter of all blocks by one process
+    (NonLinearProgram.cpp:316-330, DenseFunctionBase.h:1449-1465), other locations keep what they held."""
+    import torch.multiprocessing as mp
+    from asset_asrl_amd.indexing import kkt_slot_locations
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_asm_worker, args=(r, world, port, nseg, side_run, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    vals, blocks, shards, ndirect = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = Workload("reentry", "LGL5", nseg)
+    rfx, ragx, rkkt = w.oracle_nlp(oracle).eval_blocks(oracle.JAC_ADJGRAD_HESS, w.X, w.L)
+    locs, nnz = kkt_slot_locations(w.vindex, w.cindex, w.n_primal)
+    ref = np.full(nnz + 11, 7.0)
+    ref[np.unique(locs)] = 0.0
+    np.add.at(ref, locs.ravel(), rkkt.ravel())                        # one process, segment order
+    np.testing.assert_array_equal(vals, ref)
+    np.testing.assert_array_equal(np.concatenate([b[0] for b in blocks]), rfx)
+    np.testing.assert_array_equal(np.concatenate([b[1] for b in blocks]), ragx)
+    if side_run <= 64 and nseg >= 10:
+        assert sum(ndirect) > 0                                       # the direct copies were exercised too

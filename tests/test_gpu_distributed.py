@@ -111,3 +111,6 @@ def test_two_ranks_sharing_one_gpu_match_the_oracle(oracle):
     assert out["shards"] == [[0, 167], [167, 166]]
     assert out["host_fx"] < 1e-10 and out["host_agx"] < 1e-8 and out["host_kkt"] < 1e-8, out
     assert out.get("gather_kkt", 1.0) < 1e-8, out
+    # sharded on-device assembly (f-1 x e): bitwise the single-GPU assembled values, direct copies and side vectors both used
+    assert out["asm_same"], out
+    assert sum(out["asm_direct_runs"]) >= 2

@@ -55,6 +55,26 @@ def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg, device_
             assert rel_err(vals, rvals) < 1e-8
 
 
+@pytest.mark.parametrize("device_assembly", [False, True])
+def test_shim_rebind_and_deep_copy(oracle, shim, device_assembly):
+    """A constraint created for a smaller mesh, re-bound (the re-meshing step, ODEPhaseBase.cpp:1443-1542) and deep-copied
+    (DeepCopySpecs.h:36-60; the original destroyed before the copy evaluates) scatters what the oracle's NLP does."""
+    w = Workload("reentry", "LGL5", 29, var_offset=2, con_offset=1, extra_vars=3)
+    nlp = w.oracle_nlp(oracle, threads=1)
+    locs = nlp.kkt_locations()
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    FXE, AGX, vals = np.zeros(w.n_equal), np.zeros(w.n_primal), np.zeros(nlp.nnz)
+    err = C.create_string_buffer(512)
+    rc = shim.shim_rebind_run(b"reentry", oracle.MODES["LGL5"], 0, w.IR, w.OR, w.nseg, w.vindex.ctypes.data_as(ip),
+                              w.cindex.ctypes.data_as(ip), w.n_primal, w.n_equal, 11, w.X.ctypes.data_as(dp),
+                              w.L.ctypes.data_as(dp), locs.ctypes.data_as(ip), vals.ctypes.data_as(dp), FXE.ctypes.data_as(dp),
+                              AGX.ctypes.data_as(dp), err, 512, C.c_longlong(nlp.nnz if device_assembly else 0))
+    assert rc == 0, err.value
+    rFXE, rAGX, rvals = nlp.eval(oracle.JAC_ADJGRAD_HESS, w.X, w.L)
+    assert np.abs(FXE - rFXE).max() / max(1.0, np.abs(w.X).max()) < 1e-10
+    assert rel_err(AGX, rAGX) < 1e-8 and rel_err(vals, rvals) < 1e-8
+
+
 @pytest.mark.parametrize("ode,mode,blocked,nseg", [("reentry", "LGL7", False, 41), ("twobody_lt", "LGL5", True, 23),
                                                    ("betts_lowthrust", "Trapezoidal", False, 12)])
 def test_kkt_assembly_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg):

@@ -33,6 +33,27 @@ if rank == 0:
     out={"host_kkt": rel_err(hk, rkkt), "host_agx": rel_err(ha, ragx), "host_fx": float(np.abs(hf-rfx).max()), "shards": sh.shards, "how": how}
     if blocks is not None:
         out["gather_kkt"]=rel_err(blocks[2].cpu().numpy(), rkkt)
-    print(json.dumps(out))
 sh._host.close()
+# sharded on-device assembly: every rank's compact value array pushed into the shared value array, against ONE device's
+# asset_hip_defect_eval_assembled_zeroed, bit for bit
+from asset_asrl_amd.indexing import kkt_slot_locations
+locs, nnz = kkt_slot_locations(w.vindex, w.cindex, w.n_primal)
+sh.SIDE_RUN = 1024
+sh.set_kkt_map(locs, nnz).alloc_assembled(torch.device("cuda", 0))
+for _ in range(2):
+    sh.eval_assembled_device(4, X, L)
+    sh.push_assembled()
+    sh.wait_assembled()
+if rank == 0:
+    from asset_asrl_amd.evaluator import DefectEvaluator
+    ev = DefectEvaluator("reentry", "LGL7", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    ev.set_kkt_map(locs, nnz)
+    ref = np.zeros(nnz)
+    ev.eval_assembled(4, w.X, w.L, ref, target_zeroed=True)
+    got = sh.host_values()
+    out["asm_same"] = bool(np.array_equal(got, ref))
+    out["asm_err"] = rel_err(got, ref)
+    out["asm_direct_runs"] = [int(p[0].shape[0]) for p in sh._asm_plans]
+    print(json.dumps(out))
+sh._hostv.close()
 dist.barrier(); dist.destroy_process_group()

@@ -1,0 +1,11 @@
+import sys, os, numpy as np
+ROOT='/root/repo'
+sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
+from helpers import Workload
+from asset_asrl_amd.evaluator import *
+nseg=10000
+w=Workload("reentry","LGL7",nseg,False)
+ev=DefectEvaluator("reentry","LGL7",False,w.vindex,w.cindex,w.n_primal,w.n_equal)
+for rep in range(3): fx,agx,kkt=ev.eval(4,w.X,w.L)
+G=2048; per=nseg//G; rem=nseg%G; sh=14; first=sh*per+min(sh,rem)
+print(fx.ravel()[first*15:first*15+15].astype(int))
