@@ -16,6 +16,14 @@
 #define ASSET_MATH_FN inline
 #endif
 
+// Scheduling fence of the generated bodies (vf/codegen.py: TRANS_FENCE): nothing moves across it, so the elementary-function
+// evaluations of a body that has dozens of them run one after the other instead of all at once.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ASSET_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ASSET_SCHED_FENCE() ((void)0)
+#endif
+
 ASSET_MATH_FN void asset_sincos(double x, double* sp, double* cp) {
   const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi
   double r = fma(-fn, 1.57079632673412561417e+00, x);              // pi/2, first 33 bits: the product is exact

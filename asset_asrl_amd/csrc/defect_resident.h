@@ -42,20 +42,65 @@ struct ResDims {
   static constexpr int s_SV = SV_ALIAS ? D::w_Cg : D::WSLOTD + 1;
   static constexpr int SV_LD = SV_ALIAS ? N : Ode::NSAVE;
   static constexpr int SLOT = (D::WSLOTD + 1 + (SV_ALIAS ? 0 : CS * Ode::NSAVE)) | 1;   // odd: conflict-free across segments
+#ifndef ASSET_RES_WPS
+#define ASSET_RES_WPS ((D::TJ > 1 || Ode::NUNITS > 1) ? 1 : 2)
+#endif
+  static constexpr int WPS = ASSET_RES_WPS;
+  // JRIDE: the rows behind the H^ rows of the A operand of the M product carry h E_i J^_i, so the interior part of J comes out of
+  // the same matrix instructions (as J_i[r][c] in the lanes of column c: transposed with respect to the store order).  It is
+  // turned through LDS, one 16-column tile and interior at a time, in buffers T_i [16][n] laid over sections of the segment's
+  // own slot that are dead by then: CJ (read into registers / the DC values before) and [If | IJ | Ig | IH] (all in the
+  // A operands and the row sums by then).  Buffers are placed greedily in the slot; shapes whose slot has no room (TwoBody: 15
+  // structural entries of J^) keep them in the wave's scratch behind the slots instead (T_XTRA).
+  static constexpr int TB = 16 * n;
+  static constexpr int deadA0 = D::w_CJ, deadA1 = D::w_CJ + CS * D::NZJ, deadB0 = D::w_If, deadB1 = D::WSLOTD;
+  static constexpr int t_off_slot(int i) {         // slot offset of T_i, or -1
+    int a = deadA0, b = deadB0;
+    for (int k = 0; k <= i; k++) {
+      if (a + TB <= deadA1) { if (k == i) return a; a += TB; }
+      else if (b + TB <= deadB1) { if (k == i) return b; b += TB; }
+      else return -1;
+    }
+    return -1;
+  }
+#ifndef ASSET_RES_JRIDE
+#define ASSET_RES_JRIDE 1
+#endif
+  // GROW: row N of the A operand carries E_i g^_i, so that sum_i E_i g^_i . DI_i falls out of the M product too.  Shapes where the
+  // H^ rows, that row and the J^ rows do not fit 16 rows together but the first and the last do (TwoBody: N = 10, n = 6) give the
+  // g^ row up -- the sum is then K KS vector FMAs and two cross-lane adds per column tile -- and keep the ride: 12 of 45 matrix
+  // instructions per TwoBody-LGL5 segment gone.
+#ifndef ASSET_RES_GROWLESS
+#define ASSET_RES_GROWLESS 1
+#endif
+  // (only where the wave has a SIMD's registers to itself: at two waves per SIMD the TwoBody-LGL5-BlockConstant kernel, which
+  //  then keeps its J^T accumulators through the H tile columns, spills 48 values into the segment loop and runs 71.5 us
+  //  instead of 35.6 -- every scratch reload there waits for the block stores in flight; TwoBody-LGL7: 81.4 -> 79.6 us)
+  static constexpr bool GROW = (N + 1 + n <= 16) || !ASSET_RES_GROWLESS || N + n > 16 || WPS != 1;
+  static constexpr int JR0 = GROW ? N + 1 : N;    // first J^ row of the A operand
+  static constexpr bool JRIDE_ROWS = ASSET_RES_JRIDE && !D::TRAP && (JR0 + n <= 16);
+  // (without the g^ row the sum reads g^_i from the slot while the buffers are in use: no buffer may lie over it)
+  static constexpr bool T_XTRA = JRIDE_ROWS && (t_off_slot(K - 1) < 0 || !GROW);
+  static constexpr bool JRIDE = JRIDE_ROWS && (T_XTRA || t_off_slot(K - 1) >= 0);
+  static constexpr int t_off(int i) { return T_XTRA ? i * TB : t_off_slot(i); }   // relative to the slot, or (T_XTRA) to x_T
+  // 16 dead cells behind the last buffer: where the lanes without a J row in an accumulator entry write instead (a store under
+  // a lane condition costs an exec-mask round trip each; 24 of them per segment)
+  static constexpr int t_end = t_off(K - 1) + TB;
+  static constexpr int t_dummy = T_XTRA ? K * TB
+                                 : ((t_off(K - 1) >= deadB0 && t_end + 16 <= deadB1) ? t_end
+                                    : ((t_off(K - 1) < deadB0 && deadB0 + 16 <= deadB1) ? deadB0 : -1));
   // wave-level scratch behind the slots
   static constexpr int x_AUX = 0;                  // [K][4]: 1 - s_i, s_i, 0, 1  (tau row / parameter rows of DI_i, same row stride as the tables)
   static constexpr int x_HT = x_AUX + 4 * K;       // [IRP] full time-partial vector (rank-2 rows)
   static constexpr int x_CL = x_HT + IRP;          // [CS][n]  sum_i C_ij lam_(i,r)
   static constexpr int x_WL = x_CL + CS * n;       // [CS][n]  sum_i D_ij lam_(i,r)
   static constexpr int x_Z4 = x_WL + CS * n;       // four zeros (a weight row of the lanes without a defect row)
-  static constexpr int XTRA = x_Z4 + 4;
+  static constexpr int x_T = x_Z4 + 4;             // (T_XTRA) [K][16][n] the J^ buffers of the ride + 16 dummy cells
+  static constexpr int XTRA = x_T + (T_XTRA ? K * TB + 16 : 0);
   // waves per SIMD the kernel is built for (registers: 512 / WPS per lane; LDS: 160 KiB / 4 WPS per wave).  Shapes with two
   // row tiles of defect rows keep two more accumulators and a third column tile's fragments: at 256 registers they spill
   // 650 bytes per lane (TwoBody-LGL7 x 10 000: 149.5 us), with the SIMD to themselves they do not (89.1 us; round 2's kernel 102.7)
-#ifndef ASSET_RES_WPS
-#define ASSET_RES_WPS ((D::TJ > 1 || Ode::NUNITS > 1) ? 1 : 2)
-#endif
-  static constexpr int WPS = ASSET_RES_WPS;
+
   static constexpr int LDS_WAVE = 160 * 1024 / (4 * WPS);
   static constexpr int GR_FIT = (LDS_WAVE / 8 - D::TABSZ - XTRA) / SLOT;
   // PAIR: two-wave workgroups whose waves share the ODE stage.  A wave's ODE phases keep 15-20 of 64 lanes busy, and two waves
@@ -85,31 +130,6 @@ struct ResDims {
   // dense part starts -- the kernel's GIVEN form copies a group's slots from there and goes on as usual
   static constexpr bool GIVEN_OK = DENSE_OK && Ode::NUNITS > 1;
   static constexpr int lkN = N & 3, vN = N >> 2;   // accumulator entry that holds row N of an M tile (the E g^ row)
-  // JRIDE: the rows N+1 .. N+n of the A operand of the M product carry h E_i J^_i, so the interior part of J comes out of the
-  // same matrix instructions (as J_i[r][c] in the lanes of column c: transposed with respect to the store order).  It is
-  // turned through LDS, one 16-column tile and interior at a time, in buffers T_i [16][n] laid over sections of the segment's
-  // own slot that are dead by then: CJ (read into registers / the DC values before) and [If | IJ | Ig | IH] (all in the
-  // A operands and the row sums by then).  Buffers are placed greedily; without room the J product keeps its own instructions.
-  static constexpr int TB = 16 * n;
-  static constexpr int deadA0 = D::w_CJ, deadA1 = D::w_CJ + CS * D::NZJ, deadB0 = D::w_If, deadB1 = D::WSLOTD;
-  static constexpr int t_off(int i) {              // slot offset of T_i, or -1
-    int a = deadA0, b = deadB0;
-    for (int k = 0; k <= i; k++) {
-      if (a + TB <= deadA1) { if (k == i) return a; a += TB; }
-      else if (b + TB <= deadB1) { if (k == i) return b; b += TB; }
-      else return -1;
-    }
-    return -1;
-  }
-#ifndef ASSET_RES_JRIDE
-#define ASSET_RES_JRIDE 1
-#endif
-  static constexpr bool JRIDE = ASSET_RES_JRIDE && !D::TRAP && (N + 1 + n <= 16) && t_off(K - 1) >= 0;
-  // 16 dead cells behind the last buffer: where the lanes without a J row in an accumulator entry write instead (a store under
-  // a lane condition costs an exec-mask round trip each; 24 of them per segment)
-  static constexpr int t_end = t_off(K - 1) + TB;
-  static constexpr int t_dummy = (t_off(K - 1) >= deadB0 && t_end + 16 <= deadB1) ? t_end
-                                 : ((t_off(K - 1) < deadB0 && deadB0 + 16 <= deadB1) ? deadB0 : -1);
   // lower-triangle H tiles that can hold a cardinal Hessian block (tiles_share_node), numbered among themselves
   static constexpr int sh_index(int tix_want) {
     int k = 0;
@@ -372,9 +392,9 @@ struct ResLane {
         if (lr < N) {
           const int hp = Ode::HPOS[(b >= lr) ? b * (b + 1) / 2 + lr : lr * (lr + 1) / 2 + b];
           if (hp >= 0) { o = D::w_IH + hp; st = D::NZH; }
-        } else if (lr == N) { o = D::w_Ig + b; st = N; }
-        else if (R::JRIDE && lr <= N + n) {
-          const int jp = Ode::JPOS[(lr - N - 1) * N + b];
+        } else if (lr == N && R::GROW) { o = D::w_Ig + b; st = N; }
+        else if (R::JRIDE && lr >= R::JR0 && lr < R::JR0 + n) {
+          const int jp = Ode::JPOS[(lr - R::JR0) * N + b];
           if (jp >= 0) { o = D::w_IJ + jp; st = D::NZJ; }
         }
       }
@@ -503,10 +523,30 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   // drift apart from group to group, so that the ODE stage of some runs under the block stores of the others.
   const int nshare = int(gridDim.x) * NWV, share = int(blockIdx.x) * NWV + wv;
   const int per = a.nseg / nshare, rem = a.nseg % nshare;
-  const int wg_first = share * per + min(share, rem), wg_count = per + (share < rem ? 1 : 0);
+  // Which shares take the `rem` segments that do not divide evenly.  Workgroup b runs on XCD b % 8, and XCDs 4-7 start 2-4 us
+  // after XCDs 0-3 in every launch: the one-group kernel hands the extra segments to the workgroups of the early
+  // XCDs first (ASSET_RES_XCD_EARLY), so that the late ones have the shorter shares.  extras_before(s) = how many of the shares
+  // 0 .. s-1 have an extra segment -- the shares stay contiguous ranges of the mesh.
+#ifndef ASSET_RES_XCD_EARLY
+#define ASSET_RES_XCD_EARLY 1
+#endif
+  auto extras_before = [&](int s) -> int {
+    if (!(ASSET_RES_XCD_EARLY && !LOOP && !GIVEN) || (int(gridDim.x) & 7)) return min(s, rem);
+    const int b = s / NWV, w = s - b * NWV;                          // shares of early workgroups (b % 8 < 4) before s, then late ones
+    const int early = NWV * (4 * (b >> 3) + min(b & 7, 4)) + ((b & 7) < 4 ? w : 0);
+    const int late = s - early, nearly = nshare / 2;
+    return min(early, rem) + min(late, max(rem - nearly, 0));
+  };
+  auto share_range = [&](int s, int& first, int& count) {
+    first = s * per + extras_before(s);
+    count = per + (extras_before(s + 1) - extras_before(s));
+  };
+  int wg_first, wg_count;
+  share_range(share, wg_first, wg_count);
   // (PAIR: the partner's share -- the waves of a pair walk the same number of groups, they meet at barriers)
   const int oshare = share ^ 1;
-  const int o_first = oshare * per + min(oshare, rem), o_count = per + (oshare < rem ? 1 : 0);
+  int o_first, o_count;
+  share_range(oshare, o_first, o_count);
   const int cmax = PAIR ? max(wg_count, o_count) : wg_count;
   const int ngroups = LOOP ? (cmax + GR - 1) / GR : (cmax > 0 ? 1 : 0);
   const int gbase = LOOP ? (ngroups > 0 ? wg_count / ngroups : 0) : min(wg_count, GR), gextra = (LOOP && ngroups > 0) ? wg_count % ngroups : 0;
@@ -676,31 +716,37 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     }
   }
   RTS();
+  // lane <-> evaluation point, NODE-major: lane = j PW + g.  A ds_write_b64 is serviced in four groups of 16 consecutive lanes over 16
+  // 8-byte banks (MI355X_MICROARCH.md, LDS): with the segments of a node in consecutive lanes a group's addresses differ by the odd
+  // slot stride -- distinct banks -- whereas segment-major order put the nodes of one segment, N = 8 or NZH = 24 doubles apart, two
+  // to a bank in every write of g / H (SQ_LDS_BANK_CONFLICT 497 -> cycles per wave, profiles/r4_*).
+  constexpr int PW = (CS * 16 <= 64 && NWV * GR <= 16) ? 16 : NWV * GR;
+  const int pj = lane / PW, pg = lane - pj * PW;       // node (or interior point) and segment of the group this lane evaluates
   if constexpr (D::TRAP && LEVEL >= 2) {   // Trapezoidal: one phase (the weights w_j need lam and h: after the gather)
     pair_sync();
-    if (roleA && lane < gall * CS) {
-      const int g = lane / CS, j = lane - g * CS;
+    if (roleA && pj < CS && pg < gall) {
+      const int g = pg, j = pj;
       res_cardinal_all<Ode, D>(pslot(g), j, &tab, a.L != nullptr);
     }
   } else {
-  if (roleA && lane < gall * CS) {     // P1 (reads X itself, writes f_j and the saved values: nothing of P0's)
-    const int g = lane / CS, j = lane - g * CS;
+  if (roleA && pj < CS && pg < gall) { // P1 (reads X itself, writes f_j and the saved values: nothing of P0's)
+    const int g = pg, j = pj;
     if (a.affine && D::p == 0) res_cardinal_value<Ode, D, LEVEL>(pslot(g), j, a.X + (a.aff_v0 + pseg(g) * a.aff_vs), nullptr);
     else res_cardinal_value<Ode, D, LEVEL>(pslot(g), j, a.X, a.vindex + size_t(pseg(g)) * IR);
   }
   pair_sync();
   RTS();
   if constexpr (!D::TRAP) {
-    if (roleB && lane < gall * K) {    // P2
-      const int g = lane / K, i = lane - g * K;
+    if (roleB && pj < K && pg < gall) {   // P2
+      const int g = pg, i = pj;
       res_interior<Ode, D, LEVEL>(pslot(g), i, &tab, a.L != nullptr);
     }
     if constexpr (LEVEL >= 2) pair_sync();
   }
   RTS();
   if constexpr (LEVEL >= 2) {
-    if (roleA && lane < gall * CS) {   // P3
-      const int g = lane / CS, j = lane - g * CS;
+    if (roleA && pj < CS && pg < gall) {  // P3
+      const int g = pg, j = pj;
       res_cardinal_second<Ode, D>(pslot(g), j, &tab);
     }
   }
@@ -864,7 +910,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     double ah[K][KS];                                  // A operand of the M products: [h E_i H^_i ; E_i g^_i]
 #pragma unroll
     for (int i = 0; i < KE; i++) {
-      const double sc = (lr == N) ? ctab.E[i] : h * ctab.E[i];     // the g^ row is scaled by E_i, the H^ rows by h E_i
+      const double sc = (R::GROW && lr == N) ? ctab.E[i] : h * ctab.E[i];     // the g^ row is scaled by E_i, the H^ / J^ rows by h E_i
 #pragma unroll
       for (int kk = 0; kk < KS; kk++)           // (LEVEL 1: no H^ -- its section of the slot holds nothing)
         ah[i][kk] = (LEVEL >= 2 || lr >= N) ? sc * S[lc.ao[kk] + i * lc.ast[kk]] : 0.0;
@@ -996,7 +1042,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         }
       }
       double hi = 0.0;
-      if constexpr (LEVEL < 2 && !R::JRIDE) {           // no M product to take row N from: E_i g^_i . DI_i over this lane's rows
+      if constexpr ((LEVEL < 2 && !R::JRIDE) || !R::GROW) {   // no M product (or no g^ row in it) to take the sum from: E_i g^_i . DI_i over this lane's rows
 #pragma unroll
         for (int i = 0; i < KE; i++)
 #pragma unroll
@@ -1020,16 +1066,16 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
       for (int i = 0; i < KE; i++) {
         if constexpr (LEVEL < 2 && !R::JRIDE) continue;
-        hi += Mi[i][R::vN];              // entry v: row lk + 4v of M_i (row N: E_i g^_i . DI_i), column 16rt + lr
-        if constexpr (R::JRIDE) {        // rows N+1 .. N+n: J_i[r][16rt + lr] -> T_i[lr][r]
-          lds_double* const Ti = (lds_double*)S + R::t_off(i) + lr * n;
+        if constexpr (R::GROW) hi += Mi[i][R::vN];   // entry v: row lk + 4v of M_i (row N: E_i g^_i . DI_i), column 16rt + lr
+        if constexpr (R::JRIDE) {        // rows JR0 .. JR0 + n - 1: J_i[r][16rt + lr] -> T_i[lr][r]
+          lds_double* const Tbase = R::T_XTRA ? xtra + R::x_T : (lds_double*)S;   // the buffers: in the slot's dead sections, or the wave's own
+          lds_double* const Ti = Tbase + R::t_off(i) + lr * n;
 #pragma unroll
           for (int v = 0; v < 4; v++) {
-            if (4 * v + 3 < N + 1 || 4 * v > N + n) continue;          // (no lane has such a row in this entry)
-            const int r = lk + 4 * v - N - 1;
+            if (4 * v + 3 < R::JR0 || 4 * v > R::JR0 + n - 1) continue;   // (no lane has such a row in this entry)
+            const int r = lk + 4 * v - R::JR0;
             if constexpr (R::t_dummy >= 0) {
-              lds_double* const Sw = (lds_double*)S;
-              Sw[(r >= 0 && r < n) ? R::t_off(i) + lr * n + r : R::t_dummy + lr] = Mi[i][v];
+              Tbase[(r >= 0 && r < n) ? R::t_off(i) + lr * n + r : R::t_dummy + lr] = Mi[i][v];
             } else if (r >= 0 && r < n) Ti[r] = Mi[i][v];
           }
         }
@@ -1047,7 +1093,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           int tb = R::t_off(0);
 #pragma unroll
           for (int i = 1; i < K; i++) tb = (lc.il[jt] == i) ? R::t_off(i) : tb;
-          const lds_double* const Tr = S + tb + lk * n + lc.rl[jt];
+          const lds_double* const Tr = (R::T_XTRA ? (const lds_double*)(xtra + R::x_T) : S) + tb + lk * n + lc.rl[jt];
           d4 acc = accJ[rt][jt];
 #pragma unroll
           for (int v = 0; v < 4; v++) acc[v] += (16 * jt + lr < OR) ? Tr[4 * v * n] : 0.0;

@@ -97,6 +97,11 @@ def _cnum(v: float) -> str:
 
 
 SPLIT_OPS = 1500     # fjgh bodies above this many operations are emitted in two out-of-line parts
+# Bodies with many elementary-function calls (the 32-state BASELINE ODE: 33 sincos): a scheduling fence behind each call.  The
+# calls are independent of each other, and the compiler's scheduler, which has the whole body as one block, interleaves all
+# of them -- ~20 temporaries each -- until the 512 registers of a one-wave-per-SIMD kernel are full and 340 more values
+# live in scratch memory (csrc/asset_math.h: ASSET_SCHED_FENCE).  0: never.
+TRANS_FENCE = int(os.environ.get("ASSET_TRANS_FENCE", "8"))
 LEVEL_ORDER = os.environ.get("ASSET_LEVEL_ORDER", "1") == "1"   # breadth-first statement schedule (experiment switch)
 UNIT_LEVEL_ORDER = os.environ.get("ASSET_UNIT_LEVEL_ORDER", "0") == "1"   # the same for the unit bodies of heavy ODEs
 UNIT_QUAL = os.environ.get("ASSET_UNIT_QUAL", "__attribute__((always_inline)) inline")   # qualifier of the unit bodies: inlined, their inputs
@@ -192,6 +197,8 @@ class _Printer:
                 if len(pr) == 2:
                     partner[pr["sin"].id] = pr["cos"]
                     partner[pr["cos"].id] = pr["sin"]
+        ncalls = sum(1 for n in order if n.op in TRANSCENDENTAL and n.id not in loaded) - len(partner) // 2
+        fence = " ASSET_SCHED_FENCE();" if (self.device_math and TRANS_FENCE > 0 and ncalls > TRANS_FENCE) else ""
         for n in order:
             if n.op == "var":
                 self.used_y.add(n.value)
@@ -208,12 +215,12 @@ class _Printer:
                 other = partner[n.id]
                 k = len(self.lines)
                 sn, cn = f"t{k}s", f"t{k}c"
-                self.lines.append(f"double {sn}, {cn}; asset_sincos({self.ref(n.args[0])}, &{sn}, &{cn});")
+                self.lines.append(f"double {sn}, {cn}; asset_sincos({self.ref(n.args[0])}, &{sn}, &{cn});{fence}")
                 self.names[n.id] = sn if n.op == "sin" else cn
                 self.names[other.id] = cn if n.op == "sin" else sn
                 continue
             nm = f"t{len(self.lines)}"
-            self.lines.append(f"const double {nm} = {self._expr(n)};")
+            self.lines.append(f"const double {nm} = {self._expr(n)};{fence if n.op in TRANSCENDENTAL else ''}")
             self.names[n.id] = nm
 
     def ref(self, n: Node) -> str:

@@ -68,6 +68,9 @@ extern "C" int shim_rebind_run(const char* ode, int mode, int blocked, int ir, i
     auto con = std::make_unique<BatchedDefectConstraint>(ode, mode, blocked != 0, small, primal, equal, 0);
     if (assembly_nvalues > 0) con->enable_device_assembly(assembly_nvalues);
     {
+      std::vector<int> fr0(size_t(orr) * nappl0);
+      int c0 = 0;
+      small.getConstraintSpace(fr0.data(), c0);
       std::vector<double> f0(size_t(orr) * nappl0);
       con->constraints(X, f0.data(), small);                      // (the handle has been used on the old mesh)
     }

@@ -170,3 +170,49 @@ def test_run_time_module_follows_the_handle_to_another_device(oracle):
     same = ph.evaluator.eval(JAC_ADJGRAD_HESS, X, L)
     for a, b in zip(got, same):
         np.testing.assert_array_equal(a, b)
+
+
+def test_cached_code_object_loads_as_a_second_module_and_both_launch_from_two_threads(oracle):
+    """What the two-GPU test above checks needs a second device; what it rests on does not: a run-time module is an object of its
+    own (registry.h: RtcModule -- code object, lowered names, one lazily loaded hipModule_t per device), several of them live in
+    one process, and their first launches may come from different threads at once (the per-device table is
+    sized once and the function handle copied out under the lock).  Here the cached code object of the Van der Pol ODE is
+    registered a second time under another name -- a distinct RtcModule, loaded from the cache file without a compiler -- and
+    the two are evaluated concurrently from two threads: same bits, and the oracle's blocks."""
+    import ctypes as C
+    import glob
+    import os
+    import threading
+    from asset_asrl_amd import _lib
+    ode = make_vanderpol()
+    name = jit.ensure_kernel(ode, "LGL5", False)
+    caches = sorted(glob.glob(os.path.join(jit.JIT_DIR, name, "module_lgl5_0_*.rtc")), key=os.path.getmtime)
+    assert caches, "the module cache of the Van der Pol ODE"
+    alias = (name + "_again").encode()
+    rc = _lib.lib().asset_hip_jit_plugin(alias, None, b"unused", 1, _lib.MODES["LGL5"], 0, 0, None, 0, caches[-1].encode())
+    assert rc == 0, _lib.lib().asset_hip_last_error()
+    assert _lib.has_kernel(alias.decode(), _lib.MODES["LGL5"], False)
+    w = Workload("vanderpol", "LGL5", 2049, False, sizes=SIZES)
+    ref = oracle.Nlp(oracle.get_ode("vanderpol", 0), oracle.MODES["LGL5"], False, w.vindex, w.cindex, w.n_primal, w.n_equal,
+                     4).eval_blocks(JAC_ADJGRAD_HESS, w.X, w.L)
+    out, errs = {}, []
+
+    def run(nm):                       # (handle creation and the first launch of a module happen inside the thread)
+        try:
+            ev = DefectEvaluator(nm, "LGL5", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+            res = None
+            for _ in range(5):
+                res = [a.copy() for a in ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)]
+            out[nm] = res
+            ev.close()
+        except Exception as exc:       # noqa: BLE001
+            errs.append(exc)
+    ts = [threading.Thread(target=run, args=(nm,)) for nm in (name, alias.decode())]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for a, b in zip(out[name], out[alias.decode()]):
+        np.testing.assert_array_equal(a, b)
+    _check_blocks(out[name], ref, w, JAC_ADJGRAD_HESS)

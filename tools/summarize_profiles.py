@@ -50,7 +50,7 @@ def counters(sub):
 
 fetch, write = counters("pmc_fetch"), counters("pmc_write")
 per_kernel, total = {}, 0.0
-for st in ("resident", "fused", "fused2", "ode_units0", "ode_units1", "ode_stage", "dense_stage"):
+for st in ("resident", "fused", "fused2", "ode_units0", "ode_units1", "ode_units4", "ode_stage", "dense_stage"):
     if st not in fetch and st not in write:
         continue
     f_kb = fetch.get(st, {}).get("FETCH_SIZE", 0.0)
