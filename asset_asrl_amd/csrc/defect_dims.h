@@ -75,6 +75,9 @@ struct EvalArgs {
   // bit 0 (ASSET_HIP_KEEP_HESSIAN_SLOTS, Jacobian kinds): the Hessian slots of the KKT blocks are not written at all
   // instead of being written as zeros -- KKTFillJac (DenseFunctionBase.h:1468-1523) never reads them
   int flags = 0;
+  // Heavy right-hand sides: segments per group of the unit kernels that wrote the workspace slots (0: unknown).  The dense
+  // part behind them then takes every group's segments on the XCD whose L2 holds them (defect_resident.h, GIVEN).
+  int units_gp = 0;
 };
 
 // ---------------------------------------------------------------------------------------------- sizes

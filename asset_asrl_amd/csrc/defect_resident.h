@@ -523,30 +523,48 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   // drift apart from group to group, so that the ODE stage of some runs under the block stores of the others.
   const int nshare = int(gridDim.x) * NWV, share = int(blockIdx.x) * NWV + wv;
   const int per = a.nseg / nshare, rem = a.nseg % nshare;
-  // Which shares take the `rem` segments that do not divide evenly.  Workgroup b runs on XCD b % 8, and XCDs 4-7 start 2-4 us
-  // after XCDs 0-3 in every launch: the one-group kernel hands the extra segments to the workgroups of the early
-  // XCDs first (ASSET_RES_XCD_EARLY), so that the late ones have the shorter shares.  extras_before(s) = how many of the shares
-  // 0 .. s-1 have an extra segment -- the shares stay contiguous ranges of the mesh.
-#ifndef ASSET_RES_XCD_EARLY
-#define ASSET_RES_XCD_EARLY 1
+  int wg_first = share * per + min(share, rem), wg_count = per + (share < rem ? 1 : 0);
+  // (PAIR) which shares take the `rem` segments of an uneven split: wave 0 of every workgroup first, then wave 1.  A SIMD hosts wave 1
+  // of one workgroup and wave 0 of another (tools/ubench_place.hip), so the longer shares are spread one to a SIMD instead of two
+  // to the SIMDs of the first rem / 2 workgroups: at 5 000 Reentry-LGL7 segments (shares of 3 and 2) the busiest SIMD has 5
+  // segments instead of 6.
+#ifndef ASSET_RES_PAIR_W0FIRST
+#define ASSET_RES_PAIR_W0FIRST 1
 #endif
-  auto extras_before = [&](int s) -> int {
-    if (!(ASSET_RES_XCD_EARLY && !LOOP && !GIVEN) || (int(gridDim.x) & 7)) return min(s, rem);
-    const int b = s / NWV, w = s - b * NWV;                          // shares of early workgroups (b % 8 < 4) before s, then late ones
-    const int early = NWV * (4 * (b >> 3) + min(b & 7, 4)) + ((b & 7) < 4 ? w : 0);
-    const int late = s - early, nearly = nshare / 2;
-    return min(early, rem) + min(late, max(rem - nearly, 0));
+  auto pair_range = [&](int s, int& first, int& count) {
+    const int b = s >> 1, w = s & 1, nwg = int(gridDim.x);
+    const int rem0 = min(rem, nwg), rem1 = max(rem - nwg, 0);      // extras of the waves 0 / of the waves 1, workgroups in order
+    first = s * per + min(b, rem0) + min(b, rem1) + ((w == 1 && b < rem0) ? 1 : 0);
+    count = per + ((w == 0 ? b < rem0 : b < rem1) ? 1 : 0);
   };
-  auto share_range = [&](int s, int& first, int& count) {
-    first = s * per + extras_before(s);
-    count = per + (extras_before(s + 1) - extras_before(s));
-  };
-  int wg_first, wg_count;
-  share_range(share, wg_first, wg_count);
+  // (measured, Reentry-LGL7: 3 000 segments 18.8 -> 18.2 us, 5 000: 23.5 -> 22.8, 7 000: 27.6 -> 26.7, 9 000: 31.7 -> 30.7; with more
+  //  extras than workgroups -- 10 000: 1 808 for 1 024 -- the busiest SIMD has two long shares either way and the plain rule is
+  //  0.15 us faster)
+  const bool w0first = ASSET_RES_PAIR_W0FIRST && rem <= int(gridDim.x);
+  if constexpr (PAIR) { if (w0first) pair_range(share, wg_first, wg_count); }
+  if constexpr (GIVEN) {
+    // Behind the one-launch unit stage (registry.h): group g of units_gp segments was evaluated on XCD g % 8, and this workgroup runs
+    // on XCD blockIdx % 8 -- it takes its segments from that XCD's groups (every group split evenly among the waves the XCD has
+    // for it), so the slots come out of the L2 they were written into instead of from memory: the copy of a Betts-LGL5 slot was
+    // 4-5 us of the dense part's 13.
+    if (a.units_gp > 0 && (int(gridDim.x) & 7) == 0) {
+      const int gp = a.units_gp, x = int(blockIdx.x) & 7, k = int(blockIdx.x) >> 3, nW = int(gridDim.x) >> 3;
+      const int G = (a.nseg + gp - 1) / gp, Gx = x < G ? (G - x + 7) >> 3 : 0;     // groups of this XCD: x, x + 8, ...
+      const int wpg = Gx > 0 ? nW / Gx : 0, gi = wpg > 0 ? k / wpg : 0, wi = wpg > 0 ? k - gi * wpg : 0;
+      wg_first = 0, wg_count = 0;
+      if (wpg > 0 && gi < Gx) {
+        const int g = x + 8 * gi, gfirst = g * gp, gcnt = min(gp, a.nseg - gfirst);
+        const int p2 = gcnt / wpg, r2 = gcnt - p2 * wpg;
+        wg_first = gfirst + wi * p2 + min(wi, r2), wg_count = p2 + (wi < r2 ? 1 : 0);
+      }
+    }
+  }
+  // (the extra segments of an uneven split to the workgroups of XCDs 0-3 first -- they start 2-4 us before XCDs 4-7 in every launch --
+  //  was measured again in round 4 and is slower at every size: 10 000 segments 32.26 against 31.93 us, 5 000: 24.0 / 23.5, 3 000: 19.7 / 18.9)
   // (PAIR: the partner's share -- the waves of a pair walk the same number of groups, they meet at barriers)
   const int oshare = share ^ 1;
-  int o_first, o_count;
-  share_range(oshare, o_first, o_count);
+  int o_first = oshare * per + min(oshare, rem), o_count = per + (oshare < rem ? 1 : 0);
+  if constexpr (PAIR) { if (w0first) pair_range(oshare, o_first, o_count); }
   const int cmax = PAIR ? max(wg_count, o_count) : wg_count;
   const int ngroups = LOOP ? (cmax + GR - 1) / GR : (cmax > 0 ? 1 : 0);
   const int gbase = LOOP ? (ngroups > 0 ? wg_count / ngroups : 0) : min(wg_count, GR), gextra = (LOOP && ngroups > 0) ? wg_count % ngroups : 0;
@@ -617,6 +635,9 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     // ------------------------------------------------------------------ slots from the workspace (defect_units.h wrote them)
     // (the record first: there is no ODE body here that needs the registers, and its round trip to memory runs under the slots')
     load_record();
+    // (eight requests in flight per lane; 32 -- the slots of two Betts-LGL5 segments in one round trip instead of four -- changes
+    //  nothing: 30.6 against 30.1 us for 1 000 segments, 106.1 / 106.7 for 5 000: the 11.8 k cycles of this copy are the slots arriving
+    //  from where the unit kernels of seven other workgroups, on other XCDs, have just written them)
     constexpr int NTAB = (D::TABSZ + 63) / 64, CH = 8;
     double tabv[NTAB];
 #pragma unroll
@@ -781,6 +802,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     const lds_double* S = slots + g * SLOT;
     const size_t seg = size_t(seg0 + g);
     const double h = S[D::w_z + TF] - S[D::w_z + T];
+#ifndef ASSET_RES_FASTHT
+#define ASSET_RES_FASTHT 1
+#endif
+    const double rh = ASSET_RES_FASTHT ? 1.0 / h : 0.0;   // (one division per segment, off the tile columns' critical chain)
     double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr);
     const int* const kmap_seg = ASM ? a.kmap + seg * size_t(NFRAG) * 64 + lane : nullptr;
     int hmap[ASM ? D::NTH : 1][4], jmap[ASM ? TI * TJ : 1][4];
@@ -1096,12 +1121,18 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           const lds_double* const Tr = (R::T_XTRA ? (const lds_double*)(xtra + R::x_T) : S) + tb + lk * n + lc.rl[jt];
           d4 acc = accJ[rt][jt];
 #pragma unroll
-          for (int v = 0; v < 4; v++) acc[v] += (16 * jt + lr < OR) ? Tr[4 * v * n] : 0.0;
+          for (int v = 0; v < 4; v++) {
+            if constexpr (ASSET_RES_FASTHT) {           // (a lane without a defect row has il = rl = 0: a valid address -- read, then select,
+              const double tv = Tr[4 * v * n];          //  instead of four loads under an exec mask each)
+              acc[v] += (16 * jt + lr < OR) ? tv : 0.0;
+            } else acc[v] += (16 * jt + lr < OR) ? Tr[4 * v * n] : 0.0;
+          }
           store_J_tile(rt, jt, acc);
         }
       }
       // column role (lanes lk == lkN hold row N of the M tiles): full time-partial vector HT (LGLDefects.h:403-411, 504-505)
       // and the adjoint gradient  g = J^T lam = h sum_i E_i g^_i^T DI_i + DC^T lam  (LGLDefects.h:512) of column 16rt + lr
+      double htv = 0.0;
       if (lk == R::lkN) {
         const int c = 16 * rt + lr;
         double gs = S[lc.cgg[rt]];
@@ -1115,12 +1146,20 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
             gs = par ? gs + ps : gs;
           }
         }
-        if constexpr (LEVEL >= 2) HT[c] = hi + gs / h;  // (padding columns: 0 + 0)
+        if constexpr (LEVEL >= 2) {
+          if constexpr (ASSET_RES_FASTHT) htv = fma(gs, rh, hi);
+          else HT[c] = hi + gs / h;                     // (padding columns: 0 + 0)
+        }
         if (a.AGX && a.L && (CFULL || c < IR)) a.AGX[seg * IR + c] = fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]]));
       }
       if constexpr (LEVEL >= 2) {
-        wave_lds_sync();
-        const double ht = HT[16 * rt + lr];
+        double ht;
+        if constexpr (ASSET_RES_FASTHT) {               // the column's value from its lk == lkN lane: one cross-lane read instead of an
+          ht = __shfl(htv, 16 * R::lkN + lr);           //  LDS write, a wait and a read
+        } else {
+          wave_lds_sync();
+          ht = HT[16 * rt + lr];
+        }
         a2[rt] = lk == 0 ? tsA(rt) : (lk == 1 ? ht : 0.0);
         const double b2 = lk == 0 ? ht : (lk == 1 ? tsA(rt) : 0.0);
 #pragma unroll

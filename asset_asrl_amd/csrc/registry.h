@@ -332,9 +332,19 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         const long long wgs4 = (long long)((a.nseg + gp4 - 1) / gp4) * 2 * nunits;
         const bool one_launch = t.k[K_UNITS4] && (units1 >= 0 ? units1 != 0 : wgs4 <= (long long)(ASSET_UNITS_ONE_LAUNCH_ROUNDS * 4) * cus);
         if (one_launch) {
+          // XCD-aware placement: workgroups go to the eight XCDs round robin in launch order (x fastest), so with the number of
+          // groups padded to a multiple of eight every unit of group g runs on XCD g % 8 -- its slot is assembled in ONE L2 (no
+          // 32-byte sector written back half-filled by several of them) -- and the dense part reads it there (units_gp below)
           const size_t bytes4 = size_t(m[MF_UNITS_BASE_BYTES]) + size_t(gp4) * size_t(m[MF_UNITS_SLOT_BYTES]);
           void* uargs4[] = {&args, &gp4};
-          if ((e = klaunch(t.k[K_UNITS4], dim3((a.nseg + gp4 - 1) / gp4, 2 * nunits), dim3(64), bytes4, st, uargs4)) != hipSuccess) return e;
+          const int ng4 = (a.nseg + gp4 - 1) / gp4, ng4p = (ng4 + 7) & ~7;
+          if ((e = klaunch(t.k[K_UNITS4], dim3(ng4p, 2 * nunits), dim3(64), bytes4, st, uargs4)) != hipSuccess) return e;
+          static const bool no_xcd = tuning_env("ASSET_HIP_NO_XCD_PLACEMENT") != nullptr;                       // tuning only
+          // (the dense part follows only while its shares stay as even as the plain split's -- every group is divided among a whole
+          //  number of waves: Betts-LGL5 x 1 000: 29.9 -> 28.6 us; x 2 000, where that leaves 3 segments to some waves and 2 to others:
+          //  51.3 -> 55.7 us.  The padded unit grid alone: Betts-LGL5 x 5 000 106.7 -> 101.2 us, Betts-LGL7 x 5 000 145.4 -> 138.0 us)
+          const int dwaves = cus * 4 * int(m[MF_RES_WPS]), gx = (ng4 + 7) / 8, wpg = gx > 0 ? (dwaves / 8) / gx : 0;
+          if (!no_xcd && dwaves % 8 == 0 && wpg > 0 && (gp4 + wpg - 1) / wpg <= (a.nseg + dwaves - 1) / dwaves) args.units_gp = gp4;
         } else {
         const dim3 grid((a.nseg + gp - 1) / gp, nunits);
         void* uargs[] = {&args, &gp};
@@ -348,7 +358,9 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
       static const bool no_resd = tuning_env("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
       if (m[MF_RESD_GR] > 0 && !no_resd && a.lane_consts_res && t.k[K_RESD(a.kmap != nullptr)]) {
         const int waves = cus * 4 * int(m[MF_RES_WPS]);   // dense part of the resident kernel over the slots the units wrote
-        return klaunch(t.k[K_RESD(a.kmap != nullptr)], dim3(a.nseg < waves ? a.nseg : waves), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
+        // (XCD-aware placement: the whole grid, a wave's segments follow from its XCD; otherwise a wave per segment at most)
+        const int nwg = args.units_gp > 0 ? waves : (a.nseg < waves ? a.nseg : waves);
+        return klaunch(t.k[K_RESD(a.kmap != nullptr)], dim3(nwg), dim3(64), size_t(m[MF_RES_LDS_BYTES]), st, kargs);
       }
       return dense_stage(2);
     }
