@@ -18,9 +18,11 @@
 // result blocks.  Reference: /root/reference/src/OptimalControl/LGLDefects.h:289-551 (phase order :341-412, the products
 // :414-506, the time rows / columns :508-511, adjgrad :512); slot order of the blocks DenseFunctionBase.h:1112-1123.
 //
-// Shapes: LGL3/5/7 (segment parameters -- ODE parameters, BlockConstant controls -- included), N + 1 <= 16, defect rows in
-// one 16-row tile (K n <= 16; two tiles are implemented and measured slower, see ResDims::OK), not a heavy right-hand side.  Meshes of at most GR segments per wave (10 240 Reentry-LGL7 segments
-// on 256 CUs); everything else takes the kernels of defect_kernels.h.
+// Shapes: LGL3/5/7 and (round 4) Trapezoidal -- segment parameters (ODE parameters, BlockConstant controls) included --, N + 1 <= 16,
+// defect rows in at most two 16-row tiles (two tiles: built for one wave per SIMD, ResDims::WPS).  Every mesh size: one group of
+// at most GR segments per wave in the one-group kernel -- since round 4 two-wave workgroups that share the ODE stage (ResDims::PAIR) --
+// and the looped instantiation beyond.  Heavy right-hand sides (defect_units.h) take the dense part alone (GIVEN).  Wide shapes
+// (IR >= 64) take defect_rows.h / defect_wide.h.
 #pragma once
 #include "defect_kernels.h"
 
@@ -118,9 +120,8 @@ struct ResDims {
   static constexpr int GR = GR_FIT < GR_PASS ? GR_FIT : GR_PASS;
   static constexpr int REGION = D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA;   // a wave's LDS (doubles)
   static constexpr size_t lds_bytes() { return size_t(NWV * REGION) * 8; }
-  // (two row tiles of defect rows -- TwoBody-LGL7, K n = 18 -- work and are parity-green, but with three column tiles beside
-  //  them the wave spills 650 bytes per lane: 149.5 us against 102.5 us for 10 000 segments (BlockConstant: 122 against 81) --
-  //  such shapes stay with defect_kernels.h)
+  // (two row tiles of defect rows -- TwoBody-LGL7, K n = 18: with three column tiles beside them a wave needs ~420 registers; such
+  //  shapes are built for one wave per SIMD, WPS above: 78 us for 10 000 segments against 149.5 us spilling at two)
 #ifndef ASSET_RES_MAX_TJ
 #define ASSET_RES_MAX_TJ 2
 #endif
@@ -461,15 +462,25 @@ struct ResLane {
   }
 };
 
+// The record as the kernel loads it: in quads of words -- table entry [quad][lane] is 16 bytes, one load per four words (77 single-word
+// loads took 1.7 k cycles of a wave, 0.7 k in the pair form)
+template <class LC>
+struct ResRecord {
+  static_assert(sizeof(LC) % 4 == 0, "record must be a whole number of words");
+  static constexpr int NW = int(sizeof(LC) / 4), NQ = (NW + 3) / 4;
+  union { LC lc; unsigned int w[NQ * 4]; };
+  __device__ ResRecord() {}
+};
+
 template <class Ode, int SCH, bool BLOCKED>
 __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
   using D = Dims<Ode, SCH, BLOCKED>;
   if constexpr (ResDims<D>::DENSE_OK) {
     using LC = ResLane<Ode, D>;
-    LaneRecord<LC> r;
-    for (int k = 0; k < LaneRecord<LC>::NW; k++) r.w[k] = 0u;
+    ResRecord<LC> r;
+    for (int k = 0; k < ResRecord<LC>::NQ * 4; k++) r.w[k] = 0u;
     r.lc.compute(threadIdx.x);
-    for (int k = 0; k < LaneRecord<LC>::NW; k++) out[k * 64 + threadIdx.x] = r.w[k];
+    for (int k = 0; k < ResRecord<LC>::NQ * 4; k++) out[(k >> 2) * 256 + threadIdx.x * 4 + (k & 3)] = r.w[k];
   }
 }
 
@@ -624,12 +635,16 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   if constexpr (LOOP) asm volatile("" : "+v"(lane));
   const int lr = lane & 15, lk = lane >> 4;
   RTS();
-  LaneRecord<LCT> lrec;
+  ResRecord<LCT> lrec;
   auto load_record = [&]() {
-    const unsigned int* rec = static_cast<const unsigned int*>(a.lane_consts_res) +
-                              size_t((blockIdx.x + grp) % ASSET_LANE_REPLICAS) * (LaneRecord<LCT>::NW * 64);   // (reloaded per group:
-#pragma unroll                                                                                          //  the ODE bodies need the registers)
-    for (int k = 0; k < LaneRecord<LCT>::NW; k++) lrec.w[k] = rec[k * 64 + lane];
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    const u4* rec = reinterpret_cast<const u4*>(static_cast<const unsigned int*>(a.lane_consts_res) +
+                                                size_t((blockIdx.x + grp) % ASSET_LANE_REPLICAS) * (ResRecord<LCT>::NQ * 256));   // (reloaded per
+#pragma unroll                                                                                                             //  group: the ODE bodies need the registers)
+    for (int k = 0; k < ResRecord<LCT>::NQ; k++) {
+      const u4 v = rec[k * 64 + lane];
+      lrec.w[4 * k] = v.x, lrec.w[4 * k + 1] = v.y, lrec.w[4 * k + 2] = v.z, lrec.w[4 * k + 3] = v.w;
+    }
   };
   if constexpr (GIVEN) {
     // ------------------------------------------------------------------ slots from the workspace (defect_units.h wrote them)

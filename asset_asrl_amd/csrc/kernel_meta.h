@@ -49,7 +49,7 @@ constexpr long long lgl_lane_table_bytes(int level) {
 template <class Ode, int SCH, bool BLOCKED>
 constexpr long long res_lane_table_bytes() {
   using D = Dims<Ode, SCH, BLOCKED>;
-  if constexpr (ResDims<D>::DENSE_OK) return (long long)sizeof(ResLane<Ode, D>) * 64;
+  if constexpr (ResDims<D>::DENSE_OK) return (long long)ResRecord<ResLane<Ode, D>>::NQ * 16 * 64;   // quads of words, one per lane
   else return 0;
 }
 
