@@ -198,7 +198,9 @@ class _Printer:
                     partner[pr["sin"].id] = pr["cos"]
                     partner[pr["cos"].id] = pr["sin"]
         ncalls = sum(1 for n in order if n.op in TRANSCENDENTAL and n.id not in loaded) - len(partner) // 2
-        fence = " ASSET_SCHED_FENCE();" if (self.device_math and TRANS_FENCE > 0 and ncalls > TRANS_FENCE) else ""
+        self.fenced = bool(self.device_math and TRANS_FENCE > 0 and ncalls > TRANS_FENCE)
+        fence = " ASSET_SCHED_FENCE();" if self.fenced else ""
+        self.pos: Dict[int, int] = {}        # node id -> index of the line that defines it (absent: an input, a constant, a loaded value)
         for n in order:
             if n.op == "var":
                 self.used_y.add(n.value)
@@ -218,10 +220,12 @@ class _Printer:
                 self.lines.append(f"double {sn}, {cn}; asset_sincos({self.ref(n.args[0])}, &{sn}, &{cn});{fence}")
                 self.names[n.id] = sn if n.op == "sin" else cn
                 self.names[other.id] = cn if n.op == "sin" else sn
+                self.pos[n.id] = self.pos[other.id] = len(self.lines) - 1
                 continue
             nm = f"t{len(self.lines)}"
             self.lines.append(f"const double {nm} = {self._expr(n)};{fence if n.op in TRANSCENDENTAL else ''}")
             self.names[n.id] = nm
+            self.pos[n.id] = len(self.lines) - 1
 
     def ref(self, n: Node) -> str:
         if n.op == "const":
@@ -312,7 +316,9 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     # and what one block column of the row-wise dense stage reads, as one run (csrc/defect_rows.h)
     z = G.zero
     jnz = [k * N + i for i in range(N) for k in range(n) if d.J[k][i] is not z]
-    hnz = [i * (i + 1) // 2 + j for i in range(N) for j in range(i + 1) if d.H[i][j] is not z]
+    # ... and the packed lower Hessian COLUMN by column too (round 4): column j = {H[i][j], i >= j} is what the unit of input
+    # direction j writes -- one run of its slot section instead of one entry per row
+    hnz = [i * (i + 1) // 2 + j for j in range(N) for i in range(j, N) if d.H[i][j] is not z]
     jpos = {e: c for c, e in enumerate(jnz)}
     hpos = {e: c for c, e in enumerate(hnz)}
     def arr(name, vals):
@@ -342,7 +348,19 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
             outs += [(f"out.H({i}, {j}, {{}});", d.H[i][j]) for i in range(N) for j in range(i + 1)]
         return outs
 
+    def many_calls(outs, extra_roots):
+        nodes = topo_order([r for _, r in outs] + list(extra_roots))
+        return TRANS_FENCE > 0 and sum(1 for x in nodes if x.op in TRANSCENDENTAL) > 2 * TRANS_FENCE
+
     def body(name, outs, extra_roots=(), extra_stmt=None, use_saved=False, q="inline", level_order=level_order):
+        # STREAMED bodies (many elementary-function calls: the 32-state BASELINE ODE has 33 sincos): the outputs in sharing order,
+        # statements depth-first, every output written where its value is complete, a scheduling fence behind it, the saved
+        # values loaded where they are first used -- the live set is then the inputs plus one output's sub-expressions.  As one
+        # block the compiler hoists every call and every load to the top and sinks every store to the bottom: 512 registers and
+        # 1 368 bytes of scratch per lane for the interior body (csrc/asset_math.h: ASSET_SCHED_FENCE).
+        stream = many_calls(outs, extra_roots)
+        if stream:
+            outs, level_order = share_order(outs), False
         roots = [r for _, r in outs] + list(extra_roots)
         if use_saved:
             low = lower_reciprocals(roots + saved)       # lowering rebuilds nodes: locate the saved ones afterwards
@@ -358,15 +376,40 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
             o.append(f"    const double l{k} = in.lam({k});")
         for k in sorted(p.used_c):
             o.append(f"    const double c{k} = in.aconst({k});")   # constants of the application (vf.ApplConst)
-        if use_saved:
-            for k in range(len(saved)):
-                o.append(f"    const double s{k} = in.saved({k});")
-        o.extend("    " + ln for ln in p.lines)
-        for (fmt, _), node in zip(outs, low):
-            o.append("    " + fmt.format(p.ref(node)))
+        stmts = [fmt.format(p.ref(node)) for (fmt, _), node in zip(outs, low)]
+        nodes = list(low[:len(outs)])
         if extra_stmt:
-            for k, node in enumerate(low[len(outs):]):
-                o.append("    " + extra_stmt.format(k, p.ref(node)))
+            stmts += [extra_stmt.format(k, p.ref(node)) for k, node in enumerate(low[len(outs):])]
+            nodes += list(low[len(outs):])
+        if stream and p.fenced:
+            import re as _re
+            have = set()
+
+            def need_saved(text):
+                for mm in _re.finditer(r"\bs(\d+)\b", text):
+                    k = int(mm.group(1))
+                    if use_saved and k < len(saved) and k not in have:
+                        have.add(k)
+                        o.append(f"    const double s{k} = in.saved({k});")
+            at = {}
+            for st, node in zip(stmts, nodes):
+                at.setdefault(p.pos.get(node.id, -1), []).append(st)
+            for st in at.get(-1, []):
+                need_saved(st)
+                o.append("    " + st)
+            for i, ln in enumerate(p.lines):
+                need_saved(ln)
+                o.append("    " + ln)
+                for st in at.get(i, []):
+                    o.append("    " + st)
+                if i in at:
+                    o.append("    ASSET_SCHED_FENCE();")
+        else:
+            if use_saved:
+                for k in range(len(saved)):
+                    o.append(f"    const double s{k} = in.saved({k});")
+            o.extend("    " + ln for ln in p.lines)
+            o.extend("    " + st for st in stmts)
         o.append("  }")
 
     def share_order(outs):
