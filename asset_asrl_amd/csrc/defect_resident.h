@@ -462,6 +462,8 @@ struct ResLane {
   }
 };
 
+typedef __attribute__((ext_vector_type(2))) unsigned int res_u2;
+
 // The record as the kernel loads it: in quads of words -- table entry [quad][lane] is 16 bytes, one load per four words (77 single-word
 // loads took 1.7 k cycles of a wave, 0.7 k in the pair form)
 template <class LC>
@@ -482,6 +484,47 @@ __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
     r.lc.compute(threadIdx.x);
     for (int k = 0; k < ResRecord<LC>::NQ * 4; k++) out[(k >> 2) * 256 + threadIdx.x * 4 + (k & 3)] = r.w[k];
   }
+}
+
+// Exchanges between the four rows of a wave (row = 16 lanes) in the vector ALU: gfx950's v_permlane16_swap_b32 (old, src) returns
+// { [old.r0, src.r0, old.r2, src.r2], [old.r1, src.r1, old.r3, src.r3] } and v_permlane32_swap_b32
+// { [old.lo, src.lo], [old.hi, src.hi] } (tools/ubench_permlane.hip) -- no LDS round trip as with ds_bpermute (__shfl).
+#ifndef ASSET_RES_PERMLANE
+#define ASSET_RES_PERMLANE 1
+#endif
+template <int W>   // W = 16: rows 2k, 2k+1 exchanged;  W = 32: the halves
+__device__ inline void rows_split(double x, double& even, double& odd) {
+  res_u2 lo, hi;
+  if constexpr (W == 16) {
+    lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+    hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+  } else {
+    lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+    hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+  }
+  even = __hiloint2double(hi[0], lo[0]);
+  odd = __hiloint2double(hi[1], lo[1]);
+}
+// x summed over the four rows (the lanes with the same lr), every lane gets the total; bitwise what the two __shfl_xor steps give
+__device__ inline double rows4_sum(double x) {
+  if constexpr (ASSET_RES_PERMLANE) {
+    double e, o;
+    rows_split<16>(x, e, o); x = e + o;
+    rows_split<32>(x, e, o); return e + o;
+  } else {
+    x += __shfl_xor(x, 16);
+    return x + __shfl_xor(x, 32);
+  }
+}
+// the value row ROW's lane lr holds, in rows 0 and 1 (the other rows: unspecified)
+template <int ROW>
+__device__ inline double row_to_rows01(double x, int lr) {
+  if constexpr (ASSET_RES_PERMLANE) {
+    double e, o;
+    if constexpr (ROW >= 2) { rows_split<32>(x, e, o); x = o; }   // [r2, r3, r2, r3]
+    rows_split<16>(x, e, o);
+    return (ROW & 1) ? o : e;
+  } else return __shfl(x, 16 * ROW + lr);
 }
 
 // sum over the 16 lanes of a row (lanes with the same lk): butterfly in DPP, every lane gets the total
@@ -813,15 +856,26 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   lds_double* const WL = xtra + R::x_WL;
   constexpr int NFRAG = (D::NTH + TI * TJ) * 4;
 
+  const int nb_kkt = (!ASM && a.KKT) ? int(D::NKKT * 8) : 0, nb_fx = a.FX ? OR * 8 : 0, nb_agx = (a.AGX && a.L) ? IR * 8 : 0;
+  const int nb_h = (LEVEL >= 2 || !(a.flags & 1)) ? nb_kkt : 0;   // (Jacobian kinds: zeros, unless the caller never reads them)
   for (int g = 0; g < gcount; g++) {
     const lds_double* S = slots + g * SLOT;
-    const size_t seg = size_t(seg0 + g);
+    const size_t seg = size_t(__builtin_amdgcn_readfirstlane(seg0 + g));   // (wave-uniform, and the compiler must know: buffer resources)
     const double h = S[D::w_z + TF] - S[D::w_z + T];
 #ifndef ASSET_RES_FASTHT
 #define ASSET_RES_FASTHT 1
 #endif
     const double rh = ASSET_RES_FASTHT ? 1.0 / h : 0.0;   // (one division per segment, off the tile columns' critical chain)
     double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr);
+    // lane-masked block stores as raw buffer stores whose masked lanes carry an out-of-range offset (dropped by the bounds check):
+    // no exec-mask region, no basic-block boundary per store group; an output the caller did not ask for is a resource of zero
+    // records (sizes nb_* formed once, ahead of the loop) -- no branch on the pointers inside the segment either
+    auto seg_rsrc = [&](double* seg_base, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(seg_base, 0, bytes, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t rs_kkt = seg_rsrc(a.KKT + seg * size_t(D::NKKT), nb_kkt), rs_h = seg_rsrc(a.KKT + seg * size_t(D::NKKT), nb_h);
+    const __amdgpu_buffer_rsrc_t rs_fx = seg_rsrc(a.FX + seg * size_t(OR), nb_fx), rs_agx = seg_rsrc(a.AGX + seg * size_t(IR), nb_agx);
+    auto bst = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned idx, bool ok, double v) {
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(res_u2, v), rs, ok ? idx * 8u : 0xFFFFFFF0u, 0, 0);
+    };
     const int* const kmap_seg = ASM ? a.kmap + seg * size_t(NFRAG) * 64 + lane : nullptr;
     int hmap[ASM ? D::NTH : 1][4], jmap[ASM ? TI * TJ : 1][4];
     if constexpr (ASM) {                              // all of the segment's map entries, ahead of the products
@@ -850,7 +904,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       for (int jj = 0; jj < CS; jj++) { sdv += tDw(jt, jj) * fj[jj]; fx += tCw(jt, jj) * zj[jj]; }
       sd[jt] = sdv;
       fxv[jt] = fx + h * sdv;
-      lsd += ((jr < OR) ? S[D::w_lam + (jr < OR ? jr : 0)] : 0.0) * sdv;
+      const double lamr = S[D::w_lam + (jr < OR ? jr : 0)];      // (read, then select: a load under a lane condition is an exec-mask
+      lsd += ((jr < OR) ? lamr : 0.0) * sdv;                       //  region of its own, and a basic-block boundary for the scheduler)
     }
     int lkv = lk, lkb = lk * (IR + OR - 1) - ((lk * (lk - 1)) >> 1);   // (opaque per iteration: what is derived from them is
     asm volatile("" : "+v"(lkv), "+v"(lkb));                              //  recomputed, not kept in registers across the loop)
@@ -879,7 +934,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         const int b = 4 * kk + lk;                    // f_jj[b] for the state rows, nothing for the others
         double f[CS];
 #pragma unroll
-        for (int jj = 0; jj < CS; jj++) f[jj] = (b < n) ? S[D::w_Cf + jj * n + (b < n ? b : 0)] : 0.0;
+        for (int jj = 0; jj < CS; jj++) {
+          const double fv = S[D::w_Cf + jj * n + (b < n ? b : 0)];
+          f[jj] = (b < n) ? fv : 0.0;
+        }
 #pragma unroll
         for (int i = 0; i < KE; i++) {
           double s = 0.0;
@@ -930,8 +988,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       }
 #pragma unroll
       for (int ct = 0; ct < TI; ct++) {              // the four lanes of a column (lk = 0..3) hold its row groups: add them up
-        agJ[ct] += __shfl_xor(agJ[ct], 16);
-        agJ[ct] += __shfl_xor(agJ[ct], 32);
+        agJ[ct] = rows4_sum(agJ[ct]);
       }
     }
 
@@ -1016,14 +1073,14 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         for (int jt = 0; jt < TJ; jt++) accJ[ct][jt] = dc_tile(ct, jt);
     }
     auto store_J_tile = [&](int ct, int jt, const d4& acc) {
-      if (!kkt_dst) return;
       if constexpr (ASM) {
+        if (!kkt_dst) return;
 #pragma unroll
         for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, jmap[ct * TJ + jt][v], acc[v]);
-      } else if (16 * jt + lr < OR) {
+      } else {
 #pragma unroll
         for (int v = 0; v < 4; v++)
-          if (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR) kkt_dst[unsigned(cbv(ct, v) + IR + 16 * jt + lr)] = acc[v];
+          bst(rs_kkt, unsigned(cbv(ct, v) + IR + 16 * jt + lr), 16 * jt + lr < OR && (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR), acc[v]);
       }
     };
     if constexpr (!R::JRIDE) {
@@ -1052,7 +1109,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     }
 #pragma unroll
     for (int jt = 0; jt < TJ; jt++)
-      if (a.FX && lk == 0 && 16 * jt + lr < OR) a.FX[seg * OR + 16 * jt + lr] = fxv[jt];
+      bst(rs_fx, unsigned(16 * jt + lr), lk == 0 && 16 * jt + lr < OR, fxv[jt]);
     wave_lds_sync();                                    // (every read of the sections the T buffers lie over has returned)
     RTSG();
     // ---- R4: tile column rt of H: M_i[:, rt], H(ct, rt) += DI_i[:, ct]^T M_i[:, rt]; HT and the adjoint gradient on its columns;
@@ -1090,8 +1147,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
             const int b = 4 * kk + lk;
             hi = fma(ctab.E[i] * ((b < N) ? S[D::w_Ig + i * N + (b < N ? b : 0)] : 0.0), dv[rt][i][kk], hi);
           }
-        hi += __shfl_xor(hi, 16);
-        hi += __shfl_xor(hi, 32);
+        hi = rows4_sum(hi);
       }
       // (all K M products first, then their uses: a result is read -- written to T_i, fed to the H products -- K - 1 products
       //  after it was issued instead of right behind it, where the wave would sit out the 64 cycles of the instruction)
@@ -1148,8 +1204,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       // column role (lanes lk == lkN hold row N of the M tiles): full time-partial vector HT (LGLDefects.h:403-411, 504-505)
       // and the adjoint gradient  g = J^T lam = h sum_i E_i g^_i^T DI_i + DC^T lam  (LGLDefects.h:512) of column 16rt + lr
       double htv = 0.0;
-      if (lk == R::lkN) {
-        const int c = 16 * rt + lr;
+      {                                                 // (computed by every lane -- the loads are in range for all of them -- and
+        const int c = 16 * rt + lr;                     //  used / stored from the lanes lk == lkN only)
         double gs = S[lc.cgg[rt]];
         if constexpr (D::p > 0) {
           if (16 * rt + 15 >= D::P0) {                  // a parameter column: g_j summed over the nodes
@@ -1163,40 +1219,41 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         }
         if constexpr (LEVEL >= 2) {
           if constexpr (ASSET_RES_FASTHT) htv = fma(gs, rh, hi);
-          else HT[c] = hi + gs / h;                     // (padding columns: 0 + 0)
+          else if (lk == R::lkN) HT[c] = hi + gs / h;                     // (padding columns: 0 + 0)
         }
-        if (a.AGX && a.L && (CFULL || c < IR)) a.AGX[seg * IR + c] = fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]]));
+        bst(rs_agx, unsigned(c), lk == R::lkN && (CFULL || c < IR), fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]])));
       }
       if constexpr (LEVEL >= 2) {
         double ht;
         if constexpr (ASSET_RES_FASTHT) {               // the column's value from its lk == lkN lane: one cross-lane read instead of an
-          ht = __shfl(htv, 16 * R::lkN + lr);           //  LDS write, a wait and a read
+          ht = row_to_rows01<R::lkN>(htv, lr);          //  LDS write, a wait and a read (only lanes lk = 0, 1 use it)
         } else {
           wave_lds_sync();
           ht = HT[16 * rt + lr];
         }
-        a2[rt] = lk == 0 ? tsA(rt) : (lk == 1 ? ht : 0.0);
-        const double b2 = lk == 0 ? ht : (lk == 1 ? tsA(rt) : 0.0);
+        // k-step of the rank-2 product: lanes lk == 0 carry (d, HT), lanes lk == 1 (HT, d), the others zeros -- as arithmetic with
+        // the lane's 0 / 1 weights (nested selects on doubles came out of the compiler as branches)
+        const double w0 = lk == 0 ? 1.0 : 0.0, w1 = lk == 1 ? 1.0 : 0.0, ts = tsA(rt);
+        a2[rt] = fma(w0, ts, w1 * ht);
+        const double b2 = fma(w0, ht, w1 * ts);
 #pragma unroll
         for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[ct], b2, accH[ct], 0, 0, 0);
       }
-      if (kkt_dst && (LEVEL >= 2 || (!ASM && !(a.flags & 1)))) {   // (Jacobian kinds: zeros, unless the caller never reads them)
-        if constexpr (ASM) {
+      if constexpr (ASM) {
+        if (kkt_dst && LEVEL >= 2) {
 #pragma unroll
           for (int ct = 0; ct <= rt; ct++)
 #pragma unroll
             for (int v = 0; v < 4; v++) asm_put(a, kkt_dst, hmap[rt * (rt + 1) / 2 + ct][v], accH[ct][v]);
-        } else {
-#pragma unroll
-          for (int ct = 0; ct < rt; ct++)               // tiles left of the diagonal: every column < IR
-            if (CFULL || 16 * rt + lr < IR) {
-#pragma unroll
-              for (int v = 0; v < 4; v++) kkt_dst[unsigned(cbv(ct, v) + 16 * rt + lr)] = accH[ct][v];
-            }
-#pragma unroll
-          for (int v = 0; v < 4; v++)                   // diagonal tile: r >= c
-            if (lr >= lk + 4 * v && (CFULL || rt + 1 < TI || 16 * rt + lr < IR)) kkt_dst[unsigned(cbv(rt, v) + 16 * rt + lr)] = accH[rt][v];
         }
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < rt; ct++)                 // tiles left of the diagonal: every column < IR
+#pragma unroll
+          for (int v = 0; v < 4; v++) bst(rs_h, unsigned(cbv(ct, v) + 16 * rt + lr), CFULL || 16 * rt + lr < IR, accH[ct][v]);
+#pragma unroll
+        for (int v = 0; v < 4; v++)                     // diagonal tile: r >= c
+          bst(rs_h, unsigned(cbv(rt, v) + 16 * rt + lr), lr >= lk + 4 * v && (CFULL || rt + 1 < TI || 16 * rt + lr < IR), accH[rt][v]);
       }
     }
     __builtin_amdgcn_s_setprio(0);
