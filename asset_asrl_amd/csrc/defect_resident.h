@@ -115,6 +115,19 @@ struct ResDims {
 #define ASSET_RES_PAIR 1
 #endif
   static constexpr bool PAIR = ASSET_RES_PAIR && WPS == 2 && Ode::NUNITS == 1;
+  // masked stores of the segment loop as raw buffer stores (out-of-range offsets for the masked lanes) and the column role computed by
+  // every lane: the loop is one basic block.  Not the two-row-tile shapes at one wave per SIMD: at 500 of 512 registers the freer
+  // schedule spills (TwoBody-LGL7: 13 registers into the loop, 78.3 -> 81.4 us)
+#ifndef ASSET_RES_BSTORE
+#define ASSET_RES_BSTORE (!(WPS == 1 && D::TJ > 1 && Ode::NUNITS == 1))
+#endif
+  static constexpr bool BSTORE = ASSET_RES_BSTORE;
+  // one copy of the segment's code per slot: the slot's base becomes the instruction offset of every LDS read instead of an addition
+  // per lane offset (62 of Reentry-LGL7's 524 instructions per segment)
+#ifndef ASSET_RES_UNROLL
+#define ASSET_RES_UNROLL 0
+#endif
+  static constexpr bool UNROLL = ASSET_RES_UNROLL;
   static constexpr int NWV = PAIR ? 2 : 1;                          // waves per workgroup
   static constexpr int GR_PASS = 64 / (CS * NWV);                   // one pass per phase covers the workgroup's group
   static constexpr int GR = GR_FIT < GR_PASS ? GR_FIT : GR_PASS;
@@ -463,6 +476,10 @@ struct ResLane {
 };
 
 typedef __attribute__((ext_vector_type(2))) unsigned int res_u2;
+template <int N, int I = 0, class F>
+__device__ __attribute__((always_inline)) inline void res_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); res_static_for<N, I + 1>(f); }
+}
 
 // The record as the kernel loads it: in quads of words -- table entry [quad][lane] is 16 bytes, one load per four words (77 single-word
 // loads took 1.7 k cycles of a wave, 0.7 k in the pair form)
@@ -484,6 +501,23 @@ __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
     r.lc.compute(threadIdx.x);
     for (int k = 0; k < ResRecord<LC>::NQ * 4; k++) out[(k >> 2) * 256 + threadIdx.x * 4 + (k & 3)] = r.w[k];
   }
+}
+
+// Rows of 64 dwords from global memory straight into LDS, no registers in between: global_load_lds_dword -- M0 holds the LDS byte
+// address of lane 0's dword, lane l's lands 4 l behind it, the instruction offset moves both sides (tools/ubench_ldsdma.hip).
+// gbase wave-uniform; completion is counted by vmcnt like any load's.  (Inline assembly: the compiler would not know which LDS
+// reads the transfer may alias and would wait for all memory operations in flight ahead of each of them.)
+__device__ inline void lds_dma_rows4(unsigned lds_addr, const void* gbase, unsigned voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+               "global_load_lds_dword %2, %3\n\tglobal_load_lds_dword %2, %3 offset:256\n\t"
+               "global_load_lds_dword %2, %3 offset:512\n\tglobal_load_lds_dword %2, %3 offset:768\n\t"
+               "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(gbase) : "memory");
+}
+__device__ inline void lds_dma_row(unsigned lds_addr, const void* gbase, unsigned voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(gbase) : "memory");
 }
 
 // Exchanges between the four rows of a wave (row = 16 lanes) in the vector ALU: gfx950's v_permlane16_swap_b32 (old, src) returns
@@ -653,13 +687,32 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   int nts = 0;
 #define RTS() do { if (nts < 24) tstamp[nts++] = clock64(); } while (0)
 #define RTSG() do { if (g == 1) RTS(); } while (0)
+#if defined(ASSET_TIMING_FINE)          // (inside the tile columns: products + T writes | LDS hand-over | J^T tile + stores | column role, rank-2 | H stores)
+#define RTSF() do { if (g == 1) RTS(); } while (0)
+#else
+#define RTSF() do {} while (0)
+#endif
 #else
 #define RTS() do {} while (0)
-#define RTSG() do {} while (0)
+#define RTSF() do {} while (0)
+#ifndef ASSET_RES_PHASE_FENCE
+#define ASSET_RES_PHASE_FENCE 0
+#endif
+// (phase boundaries of the segment: optionally a scheduling fence -- the loop is one basic block and the scheduler hoists the next
+//  phase's loads over the current one, which the shapes already at their register limit pay for in spills)
+#define RTSG() do { if constexpr (ASSET_RES_PHASE_FENCE) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 #if defined(ASSET_WALLCLOCK)
   const long long wall_t0 = wall_clock64();
 #endif
+  // (GIVEN) the slots arrive one segment ahead of their use, global -> LDS without registers: segment g's dense part starts by asking
+  // for slot g + 1 (the last segment of a group: for slot 0 of the next group), and the wait at the top of the next segment is for
+  // loads issued a segment's worth of stores ago.  Before: all of a group's slots copied through registers ahead of its first
+  // segment, 8 loads per lane in flight -- 22 k cycles per group of four Betts-LGL7 slots at one wave per SIMD, nothing to run under them.
+#ifndef ASSET_RES_SLOT_DMA
+#define ASSET_RES_SLOT_DMA 1
+#endif
+  bool slot0_ahead = false;
   for (int grp = 0, seg0 = wg_first, o_seg0 = o_first; grp < ngroups; grp++) {
   const int gcount = gbase + (grp < gextra ? 1 : 0);
   const int o_gcount = PAIR ? o_gbase + (grp < o_gextra ? 1 : 0) : 0;
@@ -678,6 +731,16 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   if constexpr (LOOP) asm volatile("" : "+v"(lane));
   const int lr = lane & 15, lk = lane >> 4;
   RTS();
+  auto slot_dma = [&](int slot, int seg_) {             // slot <- the workspace's slot of mesh segment seg_ (WSLOTD doubles)
+    const void* src = a.work + size_t(__builtin_amdgcn_readfirstlane(seg_)) * D::WSLOT;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(slots + slot * SLOT));
+    constexpr int ROWS = D::WSLOTD * 2 / 64, TAIL = D::WSLOTD * 2 % 64;
+#pragma unroll
+    for (int r = 0; r + 4 <= ROWS; r += 4) lds_dma_rows4(dst + r * 256, src, lane * 4 + r * 256);
+#pragma unroll
+    for (int r = ROWS / 4 * 4; r < ROWS; r++) lds_dma_row(dst + r * 256, src, lane * 4 + r * 256);
+    if (TAIL > 0 && lane < TAIL) lds_dma_row(dst + ROWS * 256, src, lane * 4 + ROWS * 256);
+  };
   ResRecord<LCT> lrec;
   auto load_record = [&]() {
     typedef __attribute__((ext_vector_type(4))) unsigned int u4;
@@ -692,6 +755,9 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   if constexpr (GIVEN) {
     // ------------------------------------------------------------------ slots from the workspace (defect_units.h wrote them)
     // (the record first: there is no ODE body here that needs the registers, and its round trip to memory runs under the slots')
+    if constexpr (ASSET_RES_SLOT_DMA) {
+      if (!slot0_ahead) slot_dma(0, seg0);              // (later groups: the last segment of the group before has asked for it)
+    }
     load_record();
     // (eight requests in flight per lane; 32 -- the slots of two Betts-LGL5 segments in one round trip instead of four -- changes
     //  nothing: 30.6 against 30.1 us for 1 000 segments, 106.1 / 106.7 for 5 000: the 11.8 k cycles of this copy are the slots arriving
@@ -701,18 +767,20 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
     for (int t = 0; t < NTAB; t++)
       tabv[t] = (lane + 64 * t < D::TABSZ) ? reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[lane + 64 * t] : 0.0;
-    const int total = gcount * D::WSLOTD;
-    for (int e0 = 0; e0 < total; e0 += 64 * CH) {       // CH requests in flight per lane
-      double v[CH];
+    if constexpr (!ASSET_RES_SLOT_DMA) {
+      const int total = gcount * D::WSLOTD;
+      for (int e0 = 0; e0 < total; e0 += 64 * CH) {       // CH requests in flight per lane
+        double v[CH];
 #pragma unroll
-      for (int t = 0; t < CH; t++) {
-        const int e = e0 + lane + 64 * t, g = e / D::WSLOTD, r = e - g * D::WSLOTD;
-        v[t] = (e < total) ? a.work[size_t(seg0 + g) * D::WSLOT + r] : 0.0;
-      }
+        for (int t = 0; t < CH; t++) {
+          const int e = e0 + lane + 64 * t, g = e / D::WSLOTD, r = e - g * D::WSLOTD;
+          v[t] = (e < total) ? a.work[size_t(seg0 + g) * D::WSLOT + r] : 0.0;
+        }
 #pragma unroll
-      for (int t = 0; t < CH; t++) {
-        const int e = e0 + lane + 64 * t, g = e / D::WSLOTD, r = e - g * D::WSLOTD;
-        if (e < total) slots[g * SLOT + r] = v[t];
+        for (int t = 0; t < CH; t++) {
+          const int e = e0 + lane + 64 * t, g = e / D::WSLOTD, r = e - g * D::WSLOTD;
+          if (e < total) slots[g * SLOT + r] = v[t];
+        }
       }
     }
 #pragma unroll
@@ -858,9 +926,20 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 
   const int nb_kkt = (!ASM && a.KKT) ? int(D::NKKT * 8) : 0, nb_fx = a.FX ? OR * 8 : 0, nb_agx = (a.AGX && a.L) ? IR * 8 : 0;
   const int nb_h = (LEVEL >= 2 || !(a.flags & 1)) ? nb_kkt : 0;   // (Jacobian kinds: zeros, unless the caller never reads them)
-  for (int g = 0; g < gcount; g++) {
+  auto segment = [&](const int g) __attribute__((always_inline)) {
     const lds_double* S = slots + g * SLOT;
     const size_t seg = size_t(__builtin_amdgcn_readfirstlane(seg0 + g));   // (wave-uniform, and the compiler must know: buffer resources)
+    if constexpr (GIVEN && ASSET_RES_SLOT_DMA) {
+      // this segment's slot: asked for at the top of the segment before -- every store of that segment was issued behind it, and
+      // memory operations complete in the order of issue -- or, the first one, just now.  NST store instructions per segment,
+      // none under a branch (BSTORE): vmcnt(NST) is "the slot has landed" without a wait for the stores themselves.
+      constexpr int NST = (R::BSTORE && !ASM) ? (TI * TJ + D::NTH) * 4 : 0, NW = NST > 63 ? 63 : NST;
+      if (g == 0 && !slot0_ahead) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NW) : "memory");
+      slot0_ahead = false;
+      if (g + 1 < gcount) slot_dma(g + 1, seg0 + g + 1);
+      else if (LOOP && grp + 1 < ngroups && g >= 1) { slot_dma(0, seg0 + gcount); slot0_ahead = true; }
+    }
     const double h = S[D::w_z + TF] - S[D::w_z + T];
 #ifndef ASSET_RES_FASTHT
 #define ASSET_RES_FASTHT 1
@@ -870,11 +949,13 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     // lane-masked block stores as raw buffer stores whose masked lanes carry an out-of-range offset (dropped by the bounds check):
     // no exec-mask region, no basic-block boundary per store group; an output the caller did not ask for is a resource of zero
     // records (sizes nb_* formed once, ahead of the loop) -- no branch on the pointers inside the segment either
-    auto seg_rsrc = [&](double* seg_base, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(seg_base, 0, bytes, 0x00020000); };
-    const __amdgpu_buffer_rsrc_t rs_kkt = seg_rsrc(a.KKT + seg * size_t(D::NKKT), nb_kkt), rs_h = seg_rsrc(a.KKT + seg * size_t(D::NKKT), nb_h);
-    const __amdgpu_buffer_rsrc_t rs_fx = seg_rsrc(a.FX + seg * size_t(OR), nb_fx), rs_agx = seg_rsrc(a.AGX + seg * size_t(IR), nb_agx);
-    auto bst = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned idx, bool ok, double v) {
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(res_u2, v), rs, ok ? idx * 8u : 0xFFFFFFF0u, 0, 0);
+    struct SegOut { __amdgpu_buffer_rsrc_t rs; double* p; int nb; };
+    auto seg_out = [&](double* seg_base, int bytes) { return SegOut{__builtin_amdgcn_make_buffer_rsrc(seg_base, 0, bytes, 0x00020000), seg_base, bytes}; };
+    const SegOut o_kkt = seg_out(a.KKT + seg * size_t(D::NKKT), nb_kkt), o_h = seg_out(a.KKT + seg * size_t(D::NKKT), nb_h);
+    const SegOut o_fx = seg_out(a.FX + seg * size_t(OR), nb_fx), o_agx = seg_out(a.AGX + seg * size_t(IR), nb_agx);
+    auto bst = [&](const SegOut& o, unsigned idx, bool ok, double v) {
+      if constexpr (R::BSTORE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(res_u2, v), o.rs, ok ? idx * 8u : 0xFFFFFFF0u, 0, 0);
+      else if (o.nb != 0 && ok) o.p[idx] = v;
     };
     const int* const kmap_seg = ASM ? a.kmap + seg * size_t(NFRAG) * 64 + lane : nullptr;
     int hmap[ASM ? D::NTH : 1][4], jmap[ASM ? TI * TJ : 1][4];
@@ -910,8 +991,11 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     int lkv = lk, lkb = lk * (IR + OR - 1) - ((lk * (lk - 1)) >> 1);   // (opaque per iteration: what is derived from them is
     asm volatile("" : "+v"(lkv), "+v"(lkb));                              //  recomputed, not kept in registers across the loop)
     const double sls = row16_sum(lsd);                // sum_(i,r) lam_(i,r) sd_(i,r), in every lane
-    if (lane < CS * n) {                              // CL[j][r] = sum_i C_ij lam_(i,r), WL[j][r] = sum_i D_ij lam_(i,r)
-      const int j = lane / n, r = lane - j * n;
+    {                                                 // CL[j][r] = sum_i C_ij lam_(i,r), WL[j][r] = sum_i D_ij lam_(i,r)
+      // (by every lane: the ones past the CS n entries compute entry 0 again and write it to two cells nobody reads -- the HT
+      //  vector of the old time-row path -- instead of sitting out an exec-mask region)
+      const bool own = lane < CS * n;
+      const int e = own ? lane : 0, j = e / n, r = e - j * n;
       double cl = 0.0, wl = 0.0;
 #pragma unroll
       for (int i = 0; i < K; i++) {
@@ -919,8 +1003,13 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         cl += tab.C[i][j] * l;
         wl += tab.D[i][j] * l;
       }
-      CL[lane] = cl;
-      WL[lane] = wl;
+      if constexpr (ASSET_RES_FASTHT && R::BSTORE) {
+        xtra[own ? R::x_CL + lane : R::x_HT] = cl;
+        xtra[own ? R::x_WL + lane : R::x_HT + 1] = wl;
+      } else if (own) {
+        CL[lane] = cl;
+        WL[lane] = wl;
+      }
     }
 
     RTSG();
@@ -934,16 +1023,13 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         const int b = 4 * kk + lk;                    // f_jj[b] for the state rows, nothing for the others
         double f[CS];
 #pragma unroll
-        for (int jj = 0; jj < CS; jj++) {
-          const double fv = S[D::w_Cf + jj * n + (b < n ? b : 0)];
-          f[jj] = (b < n) ? fv : 0.0;
-        }
-#pragma unroll
+        for (int jj = 0; jj < CS; jj++) f[jj] = S[D::w_Cf + jj * n + (b < n ? b : 0)];   // (in range for every lane; selected below:
+#pragma unroll                                                                      //  KE selects per k-step instead of CS)
         for (int i = 0; i < KE; i++) {
           double s = 0.0;
 #pragma unroll
           for (int jj = 0; jj < CS; jj++) s += ctab.B[i][jj] * f[jj];
-          sbv[i][kk] = s;
+          sbv[i][kk] = (b < n) ? s : 0.0;
         }
       }
 #pragma unroll
@@ -1080,7 +1166,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       } else {
 #pragma unroll
         for (int v = 0; v < 4; v++)
-          bst(rs_kkt, unsigned(cbv(ct, v) + IR + 16 * jt + lr), 16 * jt + lr < OR && (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR), acc[v]);
+          bst(o_kkt, unsigned(cbv(ct, v) + IR + 16 * jt + lr), 16 * jt + lr < OR && (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR), acc[v]);
       }
     };
     if constexpr (!R::JRIDE) {
@@ -1109,7 +1195,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     }
 #pragma unroll
     for (int jt = 0; jt < TJ; jt++)
-      bst(rs_fx, unsigned(16 * jt + lr), lk == 0 && 16 * jt + lr < OR, fxv[jt]);
+      bst(o_fx, unsigned(16 * jt + lr), lk == 0 && 16 * jt + lr < OR, fxv[jt]);
     wave_lds_sync();                                    // (every read of the sections the T buffers lie over has returned)
     RTSG();
     // ---- R4: tile column rt of H: M_i[:, rt], H(ct, rt) += DI_i[:, ct]^T M_i[:, rt]; HT and the adjoint gradient on its columns;
@@ -1182,8 +1268,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
             for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ct][i][kk], Mi[i][kk], accH[ct], 0, 0, 0);
         }
       }
+      RTSF();
       if constexpr (R::JRIDE) {          // J^T tile rt: entry v <-> (column 16rt + lk + 4v, defect row jr = lr = (il, rl))
         wave_lds_sync();
+        RTSF();
 #pragma unroll
         for (int jt = 0; jt < TJ; jt++) {
           int tb = R::t_off(0);
@@ -1193,18 +1281,17 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           d4 acc = accJ[rt][jt];
 #pragma unroll
           for (int v = 0; v < 4; v++) {
-            if constexpr (ASSET_RES_FASTHT) {           // (a lane without a defect row has il = rl = 0: a valid address -- read, then select,
-              const double tv = Tr[4 * v * n];          //  instead of four loads under an exec mask each)
-              acc[v] += (16 * jt + lr < OR) ? tv : 0.0;
-            } else acc[v] += (16 * jt + lr < OR) ? Tr[4 * v * n] : 0.0;
+            if constexpr (ASSET_RES_FASTHT) acc[v] += Tr[4 * v * n];   // (a lane without a defect row has il = rl = 0: a valid address, and
+            else acc[v] += (16 * jt + lr < OR) ? Tr[4 * v * n] : 0.0;    //  what it adds up is never stored -- no load under an exec mask, no select)
           }
           store_J_tile(rt, jt, acc);
         }
       }
+      RTSF();
       // column role (lanes lk == lkN hold row N of the M tiles): full time-partial vector HT (LGLDefects.h:403-411, 504-505)
       // and the adjoint gradient  g = J^T lam = h sum_i E_i g^_i^T DI_i + DC^T lam  (LGLDefects.h:512) of column 16rt + lr
       double htv = 0.0;
-      {                                                 // (computed by every lane -- the loads are in range for all of them -- and
+      if (R::BSTORE || lk == R::lkN) {                   // (computed by every lane -- the loads are in range for all of them -- and
         const int c = 16 * rt + lr;                     //  used / stored from the lanes lk == lkN only)
         double gs = S[lc.cgg[rt]];
         if constexpr (D::p > 0) {
@@ -1221,7 +1308,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           if constexpr (ASSET_RES_FASTHT) htv = fma(gs, rh, hi);
           else if (lk == R::lkN) HT[c] = hi + gs / h;                     // (padding columns: 0 + 0)
         }
-        bst(rs_agx, unsigned(c), lk == R::lkN && (CFULL || c < IR), fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]])));
+        bst(o_agx, unsigned(c), lk == R::lkN && (CFULL || c < IR), fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]])));
       }
       if constexpr (LEVEL >= 2) {
         double ht;
@@ -1239,6 +1326,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
         for (int ct = 0; ct <= rt; ct++) accH[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[ct], b2, accH[ct], 0, 0, 0);
       }
+      RTSF();
       if constexpr (ASM) {
         if (kkt_dst && LEVEL >= 2) {
 #pragma unroll
@@ -1250,14 +1338,19 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
         for (int ct = 0; ct < rt; ct++)                 // tiles left of the diagonal: every column < IR
 #pragma unroll
-          for (int v = 0; v < 4; v++) bst(rs_h, unsigned(cbv(ct, v) + 16 * rt + lr), CFULL || 16 * rt + lr < IR, accH[ct][v]);
+          for (int v = 0; v < 4; v++) bst(o_h, unsigned(cbv(ct, v) + 16 * rt + lr), CFULL || 16 * rt + lr < IR, accH[ct][v]);
 #pragma unroll
         for (int v = 0; v < 4; v++)                     // diagonal tile: r >= c
-          bst(rs_h, unsigned(cbv(rt, v) + 16 * rt + lr), lr >= lk + 4 * v && (CFULL || rt + 1 < TI || 16 * rt + lr < IR), accH[rt][v]);
+          bst(o_h, unsigned(cbv(rt, v) + 16 * rt + lr), lr >= lk + 4 * v && (CFULL || rt + 1 < TI || 16 * rt + lr < IR), accH[rt][v]);
       }
     }
     __builtin_amdgcn_s_setprio(0);
     RTSG();
+  };
+  if constexpr (R::UNROLL) {            // (the loop itself cannot be unrolled: its trip count is the wave's, and the body holds convergent operations)
+    res_static_for<GR>([&](auto gc) __attribute__((always_inline)) { if (decltype(gc)::value < gcount) segment(decltype(gc)::value); });
+  } else {
+    for (int g = 0; g < gcount; g++) segment(g);
   }
   RTS();
   seg0 += gcount;
