@@ -142,7 +142,11 @@ def test_ragged_segment_counts(oracle, nseg):
     ("twobody_lt", "LGL5", True, 6143), ("twobody_lt", "LGL5", True, 8193), ("twobody_lt", "LGL5", True, 20481),
     ("twobody_lt", "LGL5", True, 30719), ("twobody_lt", "LGL5", True, 30721),
     # Betts (ODE stage in units): fewer segments than one group, a ragged last group
-    ("betts_lowthrust", "LGL5", False, 3), ("betts_lowthrust", "LGL5", False, 1031)])
+    ("betts_lowthrust", "LGL5", False, 3), ("betts_lowthrust", "LGL5", False, 1031),
+    # ... whose dense part takes its slots one segment ahead (global -> LDS): one segment per wave (nothing ahead), two, groups of
+    # 3 + 2 (slot 0 of the second group asked for by the last segment of the first), three groups
+    ("betts_lowthrust", "LGL7", False, 1000), ("betts_lowthrust", "LGL7", False, 1031), ("betts_lowthrust", "LGL7", False, 4500),
+    ("betts_lowthrust", "LGL7", False, 9001)])
 def test_launch_form_boundaries(oracle, ode, mode, blocked, nseg):
     """Mesh sizes on either side of every switch of the launcher (csrc/registry.h: launch_lgl_table): one-wave fused,
     two-wave fused, ODE stage + dense stage, units -- every block against the oracle."""
