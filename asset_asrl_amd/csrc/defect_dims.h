@@ -309,6 +309,11 @@ __device__ inline void asm_put(const EvalArgs& a, double* values, int m, double 
 // need the compiler kept from reordering (and the reads returned); crucially this does NOT wait for outstanding
 // global stores the way __syncthreads() (vmcnt(0)) does -- the block stores of a segment drain behind the next one.
 __device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// The same hand-off as an ordering only: the LDS unit executes a wave's instructions in issue order -- a read issued after a write
+// sees it, a write issued after a read does not disturb it, whether or not the read's data has come back -- so nothing has to be
+// waited for; the compiler must keep the order of issue, and the fence (wavefront scope: no instruction) tells it to.  Unlike
+// wave_lds_sync() it does not drain the wave's LDS reads in flight: each of those was a full LDS latency with nothing to issue.
+__device__ inline void wave_lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 // Waits until every outstanding vector-memory operation of the wave has completed (s_waitcnt vmcnt(0) as a compiler
 // builtin, so the waitcnt insertion pass knows that no load is pending afterwards).  gfx9 counts loads and stores in
 // the one in-order vmcnt: a wait for a load that was issued before some stores whose number the compiler cannot count

@@ -289,7 +289,7 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(l
   double sv[Ode::NSAVE > 0 ? Ode::NSAVE : 1];      // (read before g_j is written: the two may share their cells)
 #pragma unroll
   for (int k = 0; k < Ode::NSAVE; k++) sv[k] = S[R::s_SV + j * R::SV_LD + k];
-  wave_lds_sync();
+  wave_lds_order();
   CardInRes<D> in{z, w, sv, j};
   OdeOutRes<D> out{nullptr, S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
   Ode::fjgh_load(in, out);
@@ -926,6 +926,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 
   const int nb_kkt = (!ASM && a.KKT) ? int(D::NKKT * 8) : 0, nb_fx = a.FX ? OR * 8 : 0, nb_agx = (a.AGX && a.L) ? IR * 8 : 0;
   const int nb_h = (LEVEL >= 2 || !(a.flags & 1)) ? nb_kkt : 0;   // (Jacobian kinds: zeros, unless the caller never reads them)
+#ifndef ASSET_RES_LDS_ORDER
+#define ASSET_RES_LDS_ORDER 1
+#endif
+  auto seg_lds_sync = [&]() { if constexpr (ASSET_RES_LDS_ORDER) wave_lds_order(); else wave_lds_sync(); };   // (hand-offs inside a segment: one wave)
   auto segment = [&](const int g) __attribute__((always_inline)) {
     const lds_double* S = slots + g * SLOT;
     const size_t seg = size_t(__builtin_amdgcn_readfirstlane(seg0 + g));   // (wave-uniform, and the compiler must know: buffer resources)
@@ -1014,7 +1018,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 
     RTSG();
     // ---- R2: fragments of DI_i, straight from the slot; this lane's rows of  sum_r WL[j][r] J_j[r][cc]
-    wave_lds_sync();                                  // (CL / WL)
+    seg_lds_sync();                                   // (CL / WL)
     double dv[TI][K][KS], agJ[TI];
     {
       double sbv[K][KS];
@@ -1196,7 +1200,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
     for (int jt = 0; jt < TJ; jt++)
       bst(o_fx, unsigned(16 * jt + lr), lk == 0 && 16 * jt + lr < OR, fxv[jt]);
-    wave_lds_sync();                                    // (every read of the sections the T buffers lie over has returned)
+    seg_lds_sync();                                     // (every read of the sections the T buffers lie over is issued)
     RTSG();
     // ---- R4: tile column rt of H: M_i[:, rt], H(ct, rt) += DI_i[:, ct]^T M_i[:, rt]; HT and the adjoint gradient on its columns;
     //      rank-2 time update  H += d HT^T + HT d^T,  d = e_TF - e_T  (the four updates of LGLDefects.h:508-511)
@@ -1270,7 +1274,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       }
       RTSF();
       if constexpr (R::JRIDE) {          // J^T tile rt: entry v <-> (column 16rt + lk + 4v, defect row jr = lr = (il, rl))
-        wave_lds_sync();
+        seg_lds_sync();
         RTSF();
 #pragma unroll
         for (int jt = 0; jt < TJ; jt++) {

@@ -18,7 +18,7 @@ os.makedirs(os.path.dirname(out), exist_ok=True)
 objs = []
 for src in (os.path.join(B.GEN, tu + ".hip"), os.path.join(B.CSRC, "capi.hip")):
     obj = os.path.join(os.path.dirname(out), os.path.basename(src) + ".o")
-    subprocess.check_call([B.HIPCC] + B.FLAGS + extra + ["-c", src, "-o", obj])
+    subprocess.check_call([B.HIPCC] + B.FLAGS + B.tu_flags(src) + extra + ["-c", src, "-o", obj])
     objs.append(obj)
 subprocess.check_call([B.HIPCC, "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs + ["-lhiprtc"])
 print(out)
