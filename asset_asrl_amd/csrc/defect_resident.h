@@ -122,12 +122,6 @@ struct ResDims {
 #define ASSET_RES_BSTORE (!(WPS == 1 && D::TJ > 1 && Ode::NUNITS == 1))
 #endif
   static constexpr bool BSTORE = ASSET_RES_BSTORE;
-  // one copy of the segment's code per slot: the slot's base becomes the instruction offset of every LDS read instead of an addition
-  // per lane offset (62 of Reentry-LGL7's 524 instructions per segment)
-#ifndef ASSET_RES_UNROLL
-#define ASSET_RES_UNROLL 0
-#endif
-  static constexpr bool UNROLL = ASSET_RES_UNROLL;
   static constexpr int NWV = PAIR ? 2 : 1;                          // waves per workgroup
   static constexpr int GR_PASS = 64 / (CS * NWV);                   // one pass per phase covers the workgroup's group
   static constexpr int GR = GR_FIT < GR_PASS ? GR_FIT : GR_PASS;
@@ -476,10 +470,6 @@ struct ResLane {
 };
 
 typedef __attribute__((ext_vector_type(2))) unsigned int res_u2;
-template <int N, int I = 0, class F>
-__device__ __attribute__((always_inline)) inline void res_static_for(F&& f) {
-  if constexpr (I < N) { f(std::integral_constant<int, I>{}); res_static_for<N, I + 1>(f); }
-}
 
 // The record as the kernel loads it: in quads of words -- table entry [quad][lane] is 16 bytes, one load per four words (77 single-word
 // loads took 1.7 k cycles of a wave, 0.7 k in the pair form)
@@ -695,12 +685,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #else
 #define RTS() do {} while (0)
 #define RTSF() do {} while (0)
-#ifndef ASSET_RES_PHASE_FENCE
-#define ASSET_RES_PHASE_FENCE 0
-#endif
-// (phase boundaries of the segment: optionally a scheduling fence -- the loop is one basic block and the scheduler hoists the next
-//  phase's loads over the current one, which the shapes already at their register limit pay for in spills)
-#define RTSG() do { if constexpr (ASSET_RES_PHASE_FENCE) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RTSG() do {} while (0)
 #endif
 #if defined(ASSET_WALLCLOCK)
   const long long wall_t0 = wall_clock64();
@@ -1351,11 +1336,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     __builtin_amdgcn_s_setprio(0);
     RTSG();
   };
-  if constexpr (R::UNROLL) {            // (the loop itself cannot be unrolled: its trip count is the wave's, and the body holds convergent operations)
-    res_static_for<GR>([&](auto gc) __attribute__((always_inline)) { if (decltype(gc)::value < gcount) segment(decltype(gc)::value); });
-  } else {
-    for (int g = 0; g < gcount; g++) segment(g);
-  }
+  for (int g = 0; g < gcount; g++) segment(g);
   RTS();
   seg0 += gcount;
   o_seg0 += o_gcount;
