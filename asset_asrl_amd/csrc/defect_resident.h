@@ -1088,11 +1088,15 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         ah[i][kk] = (LEVEL >= 2 || lr >= N) ? sc * S[lc.ao[kk] + i * lc.ast[kk]] : 0.0;
     }
 #ifndef ASSET_RES_PRIO
-#define ASSET_RES_PRIO 1
+#define ASSET_RES_PRIO (PAIR ? 0 : 1)
 #endif
     // The two waves of a SIMD are workgroups b and b + gridDim/2; left alone the older one wins every arbitration and ends
     // ~5 us before the younger one (36.8 against 31.5 us), i.e. the kernel ends 2.5 us later than it would with both ending
-    // together.  ASSET_RES_PRIO 1: the younger wave runs its products at a higher priority than the older one.
+    // together.  ASSET_RES_PRIO 1: the younger wave runs its products at a higher priority than the older one -- the looped
+    // kernel (100 000 Reentry segments: 308.3 against 313.5 us with equal priorities).  The pair form, whose waves meet at barriers
+    // through the ODE stage and start their segments together, runs them at equal priority since the segment loop is one block
+    // (10 000 segments 28.65 against 29.15 us, 5 000: 20.79 / 20.94, Trapezoidal 11.1 / 11.3, TwoBody-LGL5 33.13 / 33.32), and
+    // the loop body exists once instead of once per priority.
     if (ASSET_RES_PRIO == 1) { if (young) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
     else if (ASSET_RES_PRIO == 2) { if ((g & 1) == int(young)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
     else __builtin_amdgcn_s_setprio(1);
