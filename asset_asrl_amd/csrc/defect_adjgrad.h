@@ -65,18 +65,52 @@ __global__ __launch_bounds__(64) void lgl_adjgrad_kernel(EvalArgs a) {
   const int lane = threadIdx.x;
   const int seg0 = int(blockIdx.x) * GP;
   const int gcount = min(GP, a.nseg - seg0);
-  for (int e = lane; e < D::TABSZ; e += 64) tabL[e] = reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[e];
-  // ---- gather (the group's Vindex / Cindex columns are contiguous)
+  // ---- gather: every index of the group first, then every value, then the LDS writes -- two trips to memory for the whole group
+  //      (index rows that are runs, EvalArgs::affine: one).  As loops over the entries with an index -> value chain inside, the
+  //      compiler had left 8 + 4 + 2 iterations of load, wait, load, wait: 26 dependent round trips at the head of a 6 us kernel.
   {
-    const int* vseg = a.vindex + size_t(seg0) * IR;
-    const int* cseg = a.cindex + size_t(seg0) * OR;
-    for (int e = lane; e < gcount * IR; e += 64) {
-      const int g = e / IR, r = e - g * IR;
-      mir[g * MS + AD::m_z + r] = a.X[vseg[e]];
+    constexpr int NZ = (GP * IR + 63) / 64, NL = (GP * OR + 63) / 64, NTAB = (D::TABSZ + 63) / 64;
+    int vi[NZ], ci[NL];
+    if (a.affine) {
+#pragma unroll
+      for (int t = 0; t < NZ; t++) {
+        const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
+        vi[t] = (e < gcount * IR) ? a.aff_v0 + (seg0 + g) * a.aff_vs + r : -1;
+      }
+#pragma unroll
+      for (int t = 0; t < NL; t++) {
+        const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
+        ci[t] = (e < gcount * OR) ? a.aff_c0 + (seg0 + g) * a.aff_cs + r : -1;
+      }
+    } else {
+      const int* vseg = a.vindex + size_t(seg0) * IR;      // (the group's Vindex / Cindex columns are contiguous)
+      const int* cseg = a.cindex + size_t(seg0) * OR;
+#pragma unroll
+      for (int t = 0; t < NZ; t++) vi[t] = (lane + 64 * t < gcount * IR) ? vseg[lane + 64 * t] : -1;
+#pragma unroll
+      for (int t = 0; t < NL; t++) ci[t] = (lane + 64 * t < gcount * OR) ? cseg[lane + 64 * t] : -1;
     }
-    for (int e = lane; e < gcount * OR; e += 64) {
-      const int g = e / OR, r = e - g * OR;
-      mir[g * MS + AD::m_lam + r] = (ADJ && a.L) ? a.L[cseg[e]] : 0.0;
+    double tabv[NTAB];
+#pragma unroll
+    for (int t = 0; t < NTAB; t++)
+      tabv[t] = (lane + 64 * t < D::TABSZ) ? reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[lane + 64 * t] : 0.0;
+    double zv[NZ], lv[NL];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) zv[t] = (vi[t] >= 0) ? a.X[vi[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NL; t++) lv[t] = (ADJ && a.L && ci[t] >= 0) ? a.L[ci[t]] : 0.0;
+#pragma unroll
+    for (int t = 0; t < NTAB; t++)
+      if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
+#pragma unroll
+    for (int t = 0; t < NZ; t++) {
+      const int e = lane + 64 * t, g = e / IR, r = e - g * IR;
+      if (e < gcount * IR) mir[g * MS + AD::m_z + r] = zv[t];
+    }
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      const int e = lane + 64 * t, g = e / OR, r = e - g * OR;
+      if (e < gcount * OR) mir[g * MS + AD::m_lam + r] = lv[t];
     }
     if constexpr (D::TRAP) {   // no interior evaluation: its value and gradient read as zero
       for (int e = lane; e < gcount * (K * n + K * N); e += 64) {
