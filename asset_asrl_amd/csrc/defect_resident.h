@@ -981,7 +981,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     asm volatile("" : "+v"(lkv), "+v"(lkb));                              //  recomputed, not kept in registers across the loop)
     const double sls = row16_sum(lsd);                // sum_(i,r) lam_(i,r) sd_(i,r), in every lane
     {                                                 // CL[j][r] = sum_i C_ij lam_(i,r), WL[j][r] = sum_i D_ij lam_(i,r)
-      // (by every lane: the ones past the CS n entries compute entry 0 again and write it to two cells nobody reads -- the HT
+      // (by every lane: the ones past the CS n entries compute entry 0 again and write it to cells nobody reads -- the HT
       //  vector of the old time-row path -- instead of sitting out an exec-mask region)
       const bool own = lane < CS * n;
       const int e = own ? lane : 0, j = e / n, r = e - j * n;
@@ -993,8 +993,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         wl += tab.D[i][j] * l;
       }
       if constexpr (ASSET_RES_FASTHT && R::BSTORE) {
-        xtra[own ? R::x_CL + lane : R::x_HT] = cl;
-        xtra[own ? R::x_WL + lane : R::x_HT + 1] = wl;
+        xtra[own ? R::x_CL + lane : R::x_HT + (lane & 15)] = cl;      // (sixteen dead cells, one per lane of a write's 16-lane group:
+        xtra[own ? R::x_WL + lane : R::x_HT + (lane & 15)] = wl;      //  forty lanes on ONE cell were forty bank-conflict cycles per write)
       } else if (own) {
         CL[lane] = cl;
         WL[lane] = wl;
