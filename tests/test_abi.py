@@ -58,3 +58,26 @@ def test_create_rejects_bad_arguments_and_has_no_cpu_fallback():
     if _lib.device_count() == 0:
         with pytest.raises(_lib.AssetHipError, match="no HIP device"):
             DefectEvaluator("brachistochrone", "LGL3", False, w.vindex, w.cindex, w.n_primal, w.n_equal)
+
+
+def test_scheduler_choice_by_translation_unit(monkeypatch):
+    """asset_asrl_amd/build.py: tu_flags -- the max-ilp scheduler for the Reentry and Trapezoidal units only (measured per unit,
+    DESIGN 4.0a), never for capi.hip, and off altogether with ASSET_HIP_NO_MAX_ILP."""
+    from asset_asrl_amd import build as b
+    monkeypatch.delenv("ASSET_HIP_NO_MAX_ILP", raising=False)
+    assert b.tu_flags("/x/gen/tu_reentry_lgl4_0.hip") == b.MAX_ILP
+    assert b.tu_flags("/x/gen/tu_twobody_lt_trap_1.hip") == b.MAX_ILP
+    assert b.tu_flags("/x/gen/tu_twobody_lt_lgl3_1.hip") == []
+    assert b.tu_flags("/x/gen/tu_synthetic32_lgl4_0.hip") == []
+    assert b.tu_flags("/x/csrc/capi.hip") == []
+    monkeypatch.setenv("ASSET_HIP_NO_MAX_ILP", "1")
+    assert b.tu_flags("/x/gen/tu_reentry_lgl4_0.hip") == []
+    # the flags are part of an object's digest: a unit is recompiled when its scheduler changes
+    monkeypatch.delenv("ASSET_HIP_NO_MAX_ILP")
+    import tempfile, os
+    with tempfile.NamedTemporaryFile("w", suffix=".h", delete=False) as f:
+        f.write("x")
+    try:
+        assert b._digest([f.name], b.MAX_ILP) != b._digest([f.name], [])
+    finally:
+        os.unlink(f.name)
