@@ -127,16 +127,27 @@ def cpu_baseline(w, budget_s=14.0):
                                    "segments_per_s": w.nseg / dt, "ms_per_eval": dt * 1e3,
                                    "ms_zero_fill": t_zero / reps * 1e3, "ms_eval_only": t_eval / reps * 1e3, "reps": reps}
         del nlp
-    best = max(runs.values(), key=lambda r: r["segments_per_s"])
-    return {"value": best["segments_per_s"], "unit": "segments/s", "cores": best["threads"], "kind": "port",
+    for r in runs.values():
+        r["segments_per_s_eval_only"] = w.nseg / (r["ms_eval_only"] * 1e-3)
+    # `value` is the evaluation ALONE, as the reference's own NLPTest times it (NonLinearProgram.cpp:741-752: the timer starts
+    # after the KKT values are zeroed); PSIOPT's convention -- the single-threaded zero-fill of the value array inside the
+    # timed call (PSIOPT.cpp:107) -- is reported beside it as `with_fill`.
+    best = max(runs.values(), key=lambda r: r["segments_per_s_eval_only"])
+    return {"value": best["segments_per_s_eval_only"], "unit": "segments/s", "cores": best["threads"], "kind": "port",
+            "eval_only": {"segments_per_s": best["segments_per_s_eval_only"], "ms": best["ms_eval_only"],
+                          "convention": "NLPTest: timer around evalKKT, value array zeroed before it starts"},
+            "with_fill": {"segments_per_s": best["segments_per_s"], "ms": best["ms_per_eval"], "ms_zero_fill": best["ms_zero_fill"],
+                          "convention": "PSIOPT: one thread zero-fills the CSR value array, then evalKKT"},
             "cpu_model": ob.cpu_model(), "hw_threads": hw, "physical_cores": phys, "build": "g++ -O2 -march=native -ffast-math",
             "runs": list(runs.values()),
             "sample": f"evalKKT-equivalents of the same {w.nseg}-segment phase ({kind_note}, persistent worker pool, "
-                      f"ByApplication split, CSR scatter, zero-fill of the value array included in ms_per_eval; one segment per pass and four per pass in AVX registers, the reference's "
+                      f"ByApplication split, CSR scatter; value = the evaluation alone, the zero-fill of the value array timed "
+                      f"separately (with_fill); one segment per pass and four per pass in AVX registers, the reference's "
                       f"SuperScalar loop); best of (threads, segments per pass) "
                       f"{sorted((r['threads'], r['segments_per_pass']) for r in runs.values())}: "
-                      f"{best['threads']} threads x {best['segments_per_pass']}, {best['ms_per_eval']:.3f} ms each",
-            "ms_per_eval": best["ms_per_eval"]}
+                      f"{best['threads']} threads x {best['segments_per_pass']}, {best['ms_eval_only']:.3f} ms each "
+                      f"({best['ms_per_eval']:.3f} ms with the fill)",
+            "ms_per_eval": best["ms_eval_only"]}
 
 
 def main():
@@ -416,7 +427,7 @@ def main():
     per_rank_frac = [(n * bseg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0 for n, ms in zip(per_rank_segments, per_rank_ms)]
 
     traffic, traffic_src = None, None
-    prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_{a.workload}_pmc.json") for r in (4, 3, 2)) if os.path.exists(q)), "")
+    prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_{a.workload}_pmc.json") for r in (5, 4, 3, 2)) if os.path.exists(q)), "")
     if world == 1 and prof:   # NOT measured by this run: HBM bytes per evaluation from the committed rocprofv3 --pmc passes
         try:
             traffic = json.load(open(prof))["hbm"]["bytes_per_launch"]
