@@ -137,6 +137,10 @@ struct asset_hip_defect {
   double *d_fxb = nullptr, *d_agxb = nullptr;    // block buffers of that entry point
   std::vector<int32_t> h_vindex, h_cindex;       // kept for the RHS tables (built on first use)
   hipStream_t stream = nullptr;
+  // the caller's stream of the last *_device entry point (asset_hip_defect_rebind drains it before it touches the tables those
+  // launches read: a torch side stream or hipStreamLegacy is not ordered with the handle's own stream)
+  hipStream_t last_stream = nullptr;
+  bool last_stream_used = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -404,23 +408,45 @@ static int bind_tables(asset_hip_defect_t h, int nseg, const int32_t* vindex, co
   for (size_t i = 0; i < nc; i++)
     if (cindex[i] < 0 || cindex[i] >= n_equal) return fail(ASSET_HIP_ERANGE, "cindex entry out of range");
   auto drop = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));       // (nothing of the old mesh is in flight)
-  if (nseg > h->cap_seg) {                                       // grow: index tables, workspace, block staging
-    drop(h->d_vindex), drop(h->d_cindex), drop(h->d_work), drop(h->d_fx), drop(h->d_agx), drop(h->d_kkt);
-    const int cap = h->cap_seg > 0 ? std::max(nseg, h->cap_seg + h->cap_seg / 4) : nseg;   // (re-meshing grows by steps)
-    HIP_TRY(hipMalloc(&h->d_vindex, size_t(ke->ir) * cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->d_cindex, size_t(ke->orr) * cap * sizeof(int)));
+  if (h->stream) HIP_TRY(hipStreamSynchronize(h->stream));       // (nothing of the old mesh is in flight on the handle's own stream ...
+  if (h->last_stream_used) {                                     //  ... nor on the caller's stream of the last *_device call;
+    if (hipStreamSynchronize(h->last_stream) != hipSuccess) (void)hipGetLastError();   //  a stream the caller has destroyed since is drained)
+    h->last_stream_used = false;
+  }
+  // FAILURE-ATOMIC: every new buffer is allocated and filled through locals; the handle is touched only once all of that has succeeded.
+  // A failed re-bind (out of device memory on a grown mesh) leaves the handle exactly as it was -- old mesh, old tables, still usable.
+  int* nvi = nullptr;
+  int* nci = nullptr;
+  double* nwork = nullptr;
+  int cap = h->cap_seg;
+  const bool grow = nseg > h->cap_seg;
+  auto undo = [&](hipError_t e, const char* what) {
+    if (grow) { if (nvi) (void)hipFree(nvi); if (nci) (void)hipFree(nci); if (nwork) (void)hipFree(nwork); }
+    return hipfail(e, what);
+  };
+  hipError_t e;
+  if (grow) {                                                    // grow: index tables, workspace, block staging
+    cap = h->cap_seg > 0 ? std::max(nseg, h->cap_seg + h->cap_seg / 4) : nseg;   // (re-meshing grows by steps)
+    if ((e = hipMalloc(&nvi, size_t(ke->ir) * cap * sizeof(int))) != hipSuccess) return undo(e, "hipMalloc(vindex)");
+    if ((e = hipMalloc(&nci, size_t(ke->orr) * cap * sizeof(int))) != hipSuccess) return undo(e, "hipMalloc(cindex)");
     if (ke->work_doubles) {
-      HIP_TRY(hipMalloc(&h->d_work, size_t(cap) * ke->work_doubles * sizeof(double)));
+      if ((e = hipMalloc(&nwork, size_t(cap) * ke->work_doubles * sizeof(double))) != hipSuccess) return undo(e, "hipMalloc(workspace)");
       // sections no kernel writes must read as zero (the interior-point sections of a Trapezoidal slot, defect_dims.h)
-      HIP_TRY(hipMemset(h->d_work, 0, size_t(cap) * ke->work_doubles * sizeof(double)));
+      if ((e = hipMemset(nwork, 0, size_t(cap) * ke->work_doubles * sizeof(double))) != hipSuccess) return undo(e, "hipMemset(workspace)");
     }
-    h->cap_seg = cap;
+  } else {
+    nvi = h->d_vindex, nci = h->d_cindex;
+  }
+  // (when the mesh still fits the kept tables are overwritten in place: both streams were drained above, and a failed copy into them
+  //  poisons the handle -- nseg = 0 -- instead of leaving half-written tables behind an old segment count)
+  if ((e = hipMemcpy(nvi, vindex, nv * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) { if (!grow) h->nseg = 0; return undo(e, "hipMemcpy(vindex)"); }
+  if ((e = hipMemcpy(nci, cindex, nc * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) { if (!grow) h->nseg = 0; return undo(e, "hipMemcpy(cindex)"); }
+  if (grow) {
+    drop(h->d_vindex), drop(h->d_cindex), drop(h->d_work), drop(h->d_fx), drop(h->d_agx), drop(h->d_kkt);
+    h->d_vindex = nvi, h->d_cindex = nci, h->d_work = nwork, h->cap_seg = cap;
   }
   if (n_primal > h->cap_primal) drop(h->d_X), h->cap_primal = n_primal;
   if (n_equal > h->cap_equal) drop(h->d_L), h->cap_equal = n_equal;
-  HIP_TRY(hipMemcpy(h->d_vindex, vindex, nv * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->d_cindex, cindex, nc * sizeof(int), hipMemcpyHostToDevice));
   h->h_vindex.assign(vindex, vindex + nv);
   h->h_cindex.assign(cindex, cindex + nc);
   {   // rows that are runs with a constant stride between applications (EvalArgs::affine)
@@ -552,6 +578,7 @@ static int fill_args(asset_hip_defect_t h, int what, const double* dX, const dou
                      double* dkkt, asset_hip::EvalArgs& a) {
   const int level = level_of(what);
   if (level < 0) return fail(ASSET_HIP_EINVAL, "unknown evaluation kind");
+  if (h->nseg <= 0) return fail(ASSET_HIP_EINVAL, "the handle holds no mesh (a failed asset_hip_defect_rebind): re-bind it first");
   const int opts = what & ~0xff;
   what &= 0xff;
   if ((opts & ~ASSET_HIP_KEEP_HESSIAN_SLOTS) || (opts && what != ASSET_HIP_JAC && what != ASSET_HIP_JAC_ADJGRAD))
@@ -584,6 +611,7 @@ static int fill_args(asset_hip_defect_t h, int what, const double* dX, const dou
 
 static int launch(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx, double* dagx,
                   double* dkkt, hipStream_t st, double* d_values = nullptr) {
+  if (st != h->stream) h->last_stream = st, h->last_stream_used = true;
   asset_hip::EvalArgs a;
   const int rc = fill_args(h, what, dX, dL, dfx, dagx, dkkt, a);
   if (rc) return rc;

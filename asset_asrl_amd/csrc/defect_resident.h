@@ -43,11 +43,30 @@ struct ResDims {
   static constexpr int s_Z0 = D::WSLOTD;
   static constexpr int s_SV = SV_ALIAS ? D::w_Cg : D::WSLOTD + 1;
   static constexpr int SV_LD = SV_ALIAS ? N : Ode::NSAVE;
-  static constexpr int SLOT = (D::WSLOTD + 1 + (SV_ALIAS ? 0 : CS * Ode::NSAVE)) | 1;   // odd: conflict-free across segments
 #ifndef ASSET_RES_WPS
 #define ASSET_RES_WPS ((D::TJ > 1 || Ode::NUNITS > 1) ? 1 : 2)
 #endif
   static constexpr int WPS = ASSET_RES_WPS;
+#ifndef ASSET_RES_PAIR
+#define ASSET_RES_PAIR 1
+#endif
+  // ROWDPP (round 5, defect_rowdpp.h): the dense part of the one-group pair kernel by output rows, sixteen lanes to a row group, the
+  // lane-independent operands broadcast inside the FMA (v_fmac_f64_dpp row_newbcast) -- no matrix instructions.  Its time rows need
+  // FB_i[a] = sum_j B_ij f_j[a], which the interior phase leaves in a section of its own behind the saved values.
+  // Which shapes take it -- measured per shape, 10 000 segments, both forms built from the same tree (tools/r5_shapes.sh; us, row-wise /
+  // tile): TwoBody-LGL3 19.1 / 22.1, BlockConstant 18.5 / 30.2; TwoBody-LGL5 26.3 / 30.8, BlockConstant 24.0 / 33.1; Brachistochrone-LGL7
+  // 17.7 / 25.6, -LGL5 BlockConstant 11.7 / 16.0; Reentry-LGL5 BlockConstant 22.7 / 27.2, -LGL7 BlockConstant 29.5 / 33.5 -- and
+  // Reentry without segment parameters 15.4 / 15.3 (LGL3), 24.3 / 23.4 (LGL5), 31.5 / 28.4 (LGL7): the shapes whose node stride is a
+  // multiple of four and that have no parameter columns (ResLane::QFAST) fill their 16-column tiles without padding and keep their row
+  // weights in registers; there the tile form issues 500 instructions and 33 matrix instructions per segment against ~ 800 vector
+  // instructions of the row-wise form, and both end at the drain of the block stores.  ASSET_RES_ROWDPP: 0 never, 1 by that rule, 2 always.
+#ifndef ASSET_RES_ROWDPP
+#define ASSET_RES_ROWDPP 1
+#endif
+  static constexpr bool RD_SHAPE = ASSET_RES_ROWDPP == 2 || (ASSET_RES_ROWDPP == 1 && !((q % 4 == 0) && D::p == 0));
+  static constexpr bool ROWDPP = RD_SHAPE && ASSET_RES_PAIR && !D::TRAP && WPS == 2 && Ode::NUNITS == 1;
+  static constexpr int s_FB = D::WSLOTD + 1 + (SV_ALIAS ? 0 : CS * Ode::NSAVE);
+  static constexpr int SLOT = (s_FB + (ROWDPP ? K * n + 1 : 0)) | 1;   // odd: conflict-free across segments
   // JRIDE: the rows behind the H^ rows of the A operand of the M product carry h E_i J^_i, so the interior part of J comes out of
   // the same matrix instructions (as J_i[r][c] in the lanes of column c: transposed with respect to the store order).  It is
   // turned through LDS, one 16-column tile and interior at a time, in buffers T_i [16][n] laid over sections of the segment's
@@ -111,9 +130,6 @@ struct ResDims {
   // segments (40 / 30 lanes for Reentry-LGL7) while the other loads its lane record or waits at the barrier: half the ODE
   // instructions per SIMD.  Shapes built for two waves per SIMD that run their own ODE stage; each wave keeps its own LDS
   // region [tables | GR slots | scratch], so every offset of the lane record holds for both.
-#ifndef ASSET_RES_PAIR
-#define ASSET_RES_PAIR 1
-#endif
   static constexpr bool PAIR = ASSET_RES_PAIR && WPS == 2 && Ode::NUNITS == 1;
   // masked stores of the segment loop as raw buffer stores (out-of-range offsets for the masked lanes) and the column role computed by
   // every lane: the loop is one basic block.  Not the two-row-tile shapes at one wave per SIMD: at 500 of 512 registers the freer
@@ -246,6 +262,16 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
   for (int k = 0; k < D::p; k++) y[q + k] = z[D::P0 + k];
 #pragma unroll
   for (int k = 0; k < n; k++) li[k] = have_lam ? lam[i * n + k] : 0.0;
+  if constexpr (ResDims<D>::ROWDPP && LEVEL == 2) {   // FB_i[k] = sum_j B_ij f_j[k]: the time rows of the row-wise dense part (defect_rowdpp.h)
+#pragma unroll
+    for (int k = 0; k < n; k++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < CS; j++) acc = fma(tab.B[i][j], Cf[j * n + k], acc);
+      S[ResDims<D>::s_FB + i * n + k] = acc;
+    }
+    if (i == 0) S[ResDims<D>::s_FB + D::K * n] = h;   // (the step: the C pass of a segment lays the gradient row over z, which the H passes would read it from)
+  }
   RegIn<D> in{y, li};
   if constexpr (LEVEL == 1) {          // f^, J^ and g^ = J^^T lam_i (accumulated while J^ is emitted)
     OdeOutRes<D, true> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, nullptr, nullptr, nullptr};
@@ -481,6 +507,23 @@ struct ResRecord {
   __device__ ResRecord() {}
 };
 
+}  // namespace asset_hip
+#include "defect_rowdpp.h"
+namespace asset_hip {
+
+// The handle's table of the resident kernel (one of ASSET_LANE_REPLICAS copies): the ResLane records of the tile form, then --
+// shapes with the row-wise dense part -- the row records of defect_rowdpp.h.  Sizes in 32-bit words.
+template <class Ode, class D>
+constexpr long long res_table_words_tile() {
+  if constexpr (ResDims<D>::DENSE_OK) return (long long)ResRecord<ResLane<Ode, D>>::NQ * 256;
+  else return 0;
+}
+template <class Ode, class D>
+constexpr long long res_table_words() {
+  if constexpr (ResDims<D>::DENSE_OK && ResDims<D>::ROWDPP) return res_table_words_tile<Ode, D>() + RdDims<Ode, D>::table_bytes() / 4;
+  else return res_table_words_tile<Ode, D>();
+}
+
 template <class Ode, int SCH, bool BLOCKED>
 __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
   using D = Dims<Ode, SCH, BLOCKED>;
@@ -490,6 +533,10 @@ __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
     for (int k = 0; k < ResRecord<LC>::NQ * 4; k++) r.w[k] = 0u;
     r.lc.compute(threadIdx.x);
     for (int k = 0; k < ResRecord<LC>::NQ * 4; k++) out[(k >> 2) * 256 + threadIdx.x * 4 + (k & 3)] = r.w[k];
+    if constexpr (ResDims<D>::ROWDPP) {
+      for (int rec = threadIdx.x; rec < RdDims<Ode, D>::NRECH; rec += 64)
+        rd_lane_setup<Ode, D, ResDims<D>::s_Z0>(out + res_table_words_tile<Ode, D>(), rec);
+    }
   }
 }
 
@@ -730,7 +777,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   auto load_record = [&]() {
     typedef __attribute__((ext_vector_type(4))) unsigned int u4;
     const u4* rec = reinterpret_cast<const u4*>(static_cast<const unsigned int*>(a.lane_consts_res) +
-                                                size_t((blockIdx.x + grp) % ASSET_LANE_REPLICAS) * (ResRecord<LCT>::NQ * 256));   // (reloaded per
+                                                size_t((blockIdx.x + grp) % ASSET_LANE_REPLICAS) * size_t(res_table_words<Ode, D>()));   // (reloaded per
 #pragma unroll                                                                                                             //  group: the ODE bodies need the registers)
     for (int k = 0; k < ResRecord<LCT>::NQ; k++) {
       const u4 v = rec[k * 64 + lane];
@@ -888,6 +935,28 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #endif
   }   // (!GIVEN)
   RTS();
+  if constexpr (R::ROWDPP && LEVEL == 2 && !ASM && !GIVEN) {
+    // ------------------------------------------------------------------ dense part by output rows (defect_rowdpp.h): the workgroup's
+    // (segment, row group) tasks in passes of four, dealt to the two waves alternately
+    pair_sync();                       // (the last ODE phase's results, for both waves)
+    RTS();
+    int seg_lo = 0x7fffffff, seg_hi = 0;
+    if (gc0 > 0) { seg_lo = min(seg_lo, sg0); seg_hi = max(seg_hi, sg0 + gc0); }
+    if (gc1 > 0) { seg_lo = min(seg_lo, sg1); seg_hi = max(seg_hi, sg1 + gc1); }
+    const unsigned int* const rectab = static_cast<const unsigned int*>(a.lane_consts_res) +
+                                       size_t(blockIdx.x % ASSET_LANE_REPLICAS) * size_t(res_table_words<Ode, D>()) + res_table_words_tile<Ode, D>();
+    rowdpp_dense<Ode, D, R::s_Z0, R::s_FB>(a, (const lds_double*)tabL, rectab, gall, seg_lo, seg_hi, wv, NWV, lane,
+                                           [&](int g) -> const lds_double* { return pslot(g); }, pseg
+#if defined(ASSET_TIMING)
+                                           , tstamp, &nts
+#endif
+                                           );
+    RTS();
+    seg0 += gcount;
+    o_seg0 += o_gcount;
+    wave_lds_sync();                   // (the next group's gather rewrites the slots)
+    continue;
+  }
   // the per-lane record of the dense part (its loads fly while P3's LDS writes land; in a pair the wave that is not in the
   // last phase loads it while the other computes)
   if constexpr (!GIVEN) load_record();

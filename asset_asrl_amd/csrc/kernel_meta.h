@@ -49,8 +49,7 @@ constexpr long long lgl_lane_table_bytes(int level) {
 template <class Ode, int SCH, bool BLOCKED>
 constexpr long long res_lane_table_bytes() {
   using D = Dims<Ode, SCH, BLOCKED>;
-  if constexpr (ResDims<D>::DENSE_OK) return (long long)ResRecord<ResLane<Ode, D>>::NQ * 16 * 64;   // quads of words, one per lane
-  else return 0;
+  return res_table_words<Ode, D>() * 4;   // quads of words, one per lane (+ the row records of defect_rowdpp.h)
 }
 
 template <class Ode, int SCH, bool BLOCKED, int G>

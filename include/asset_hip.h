@@ -93,7 +93,11 @@ void asset_hip_defect_destroy(asset_hip_defect_t h);
  * number of segments changes, the ODE, the transcription and the device code do not.  Keeps the handle's module, per-lane
  * constant tables, stream and every buffer that still fits (index tables, workspace and block staging grow in steps of a
  * quarter); drops what was derived from the old tables (KKT map, RHS gather tables, per-application constants).  Same
- * argument meaning and checks as asset_hip_defect_create; synchronises the handle's stream. */
+ * argument meaning and checks as asset_hip_defect_create; synchronises the handle's stream AND the caller's stream of the last
+ * *_device call (evaluations the caller enqueued on any OTHER stream before that must be drained by the caller).
+ * Failure-atomic: when it returns an error from a grown mesh (out of device memory) the handle still holds the old mesh and
+ * evaluates it; only a failed upload into the kept tables leaves it empty (every eval returns ASSET_HIP_EINVAL until a re-bind
+ * succeeds). */
 int asset_hip_defect_rebind(asset_hip_defect_t h, int nseg, const int32_t* vindex, const int32_t* cindex, int n_primal,
                             int n_equal);
 

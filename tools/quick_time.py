@@ -21,8 +21,8 @@ fx = torch.empty(nseg * ev.OR, dtype=torch.float64, device=dev)
 agx = torch.empty(nseg * ev.IR, dtype=torch.float64, device=dev)
 kkt = torch.empty(nseg * ev.NKKT, dtype=torch.float64, device=dev)
 ts = []
-for rep in range(6):
+for rep in range(int(os.environ.get('QT_REPS', '6'))):
     k = kind & 0xFF
     ts.append(ev.time_device(kind, X, L if k in (1, 3, 4) else None, fx, agx if k in (1, 3, 4) else None,
-                             kkt if k >= 2 else None, warmup=5, iters=200))
+                             kkt if k >= 2 else None, warmup=int(os.environ.get('QT_WARMUP', '5')), iters=int(os.environ.get('QT_ITERS', '200'))))
 print(f"{os.environ.get('ASSET_HIP_LIB', 'default')} {ode} {mode} x{nseg} kind {kind}: " + " ".join(f"{1e3 * t:.2f}" for t in ts) + " us")
