@@ -52,6 +52,14 @@ SYMBOLS = {
     "asset_hip_defect_eval_assembled_zeroed": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "asset_hip_defect_eval_assembled_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "asset_hip_defect_eval_kkt_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),
+    "asset_hip_defect_create_sharded": (C.c_int, [C.POINTER(DefectDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "asset_hip_sharded_destroy": (None, [C.c_void_p]),
+    "asset_hip_sharded_shards": (C.c_int, [C.c_void_p]),
+    "asset_hip_sharded_range": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "asset_hip_sharded_handle": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "asset_hip_sharded_eval": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "asset_hip_sharded_set_kkt_map": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_longlong]),
+    "asset_hip_sharded_eval_assembled": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "asset_hip_mesh_error_deboor": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]),
     "asset_hip_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
     "asset_hip_host_unregister": (C.c_int, [C.c_void_p]),

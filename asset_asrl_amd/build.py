@@ -168,7 +168,7 @@ def build(verbose=True, jobs=None) -> str:
         for f in os.listdir(OBJ):
             if f.startswith("tu_") and f.split(".")[0] + ".hip" not in keep:
                 os.remove(os.path.join(OBJ, f))
-    srcs = tus + [os.path.join(CSRC, "capi.hip")]
+    srcs = tus + [os.path.join(CSRC, "capi.hip"), os.path.join(CSRC, "capi_sharded.hip")]
     jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2)))
     with ThreadPoolExecutor(jobs) as ex:
         res = list(ex.map(_compile, srcs))

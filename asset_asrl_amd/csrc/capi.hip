@@ -147,6 +147,8 @@ struct asset_hip_defect {
 extern "C" {
 
 const char* asset_hip_last_error(void) { return g_err.c_str(); }
+// (for the other translation units of the library -- capi_sharded.hip; not part of the public interface)
+__attribute__((visibility("hidden"))) void asset_hip_set_last_error(const char* msg) { g_err = msg ? msg : ""; }
 const char* asset_hip_version(void) { return "asset_hip 0.1 (gfx950)"; }
 
 int asset_hip_device_count(void) {

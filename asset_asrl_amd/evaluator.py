@@ -231,3 +231,76 @@ def unpack_kkt_block(blk: np.ndarray, IR: int, OR: int):
         k += OR
     H = H + np.tril(H, -1).T
     return H, J
+
+
+class ShardedDefectEvaluator:
+    """One constraint as several device handles in ONE process (include/asset_hip.h: asset_hip_defect_create_sharded): the
+    reference's ``ConstraintFunction.thread_split`` (ConstraintFunction.h:55-62, IndexingData.h:117-146) with a device per
+    chunk instead of a CPU thread.  ``devices``: one HIP ordinal per shard; naming a device several times gives several
+    handles on it.  Host-pointer evaluation only: every shard's blocks land in the caller's arrays over its own PCIe link."""
+
+    def __init__(self, ode: str, mode, blocked: bool, vindex, cindex, n_primal: int, n_equal: int, devices):
+        L = _lib.lib()
+        self.mode = MODES[mode] if isinstance(mode, str) else int(mode)
+        self.vindex = np.ascontiguousarray(vindex, dtype=np.int32)
+        self.cindex = np.ascontiguousarray(cindex, dtype=np.int32)
+        self.nseg = self.vindex.shape[0]
+        self.n_primal, self.n_equal = int(n_primal), int(n_equal)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        desc = _lib.DefectDesc(self.mode, int(bool(blocked)), ode.encode(), self.nseg,
+                               self.vindex.ctypes.data_as(C.POINTER(C.c_int32)), self.cindex.ctypes.data_as(C.POINTER(C.c_int32)),
+                               self.n_primal, self.n_equal, 0)
+        self._s = C.c_void_p()
+        _lib.check(L.asset_hip_defect_create_sharded(C.byref(desc), len(devices), devs, C.byref(self._s)), "asset_hip_defect_create_sharded")
+        ir, orr, nk = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(L.asset_hip_defect_sizes(C.c_void_p(L.asset_hip_sharded_handle(self._s, 0)), C.byref(ir), C.byref(orr), C.byref(nk)))
+        self.IR, self.OR, self.NKKT = ir.value, orr.value, nk.value
+        self._nvalues = -1
+
+    @property
+    def ranges(self):
+        """[(first application, count, device)] of the shards (the ByApplication split)."""
+        L, out = _lib.lib(), []
+        for i in range(L.asset_hip_sharded_shards(self._s)):
+            f, c, d = C.c_int(), C.c_int(), C.c_int()
+            _lib.check(L.asset_hip_sharded_range(self._s, i, C.byref(f), C.byref(c), C.byref(d)))
+            out.append((f.value, c.value, d.value))
+        return out
+
+    def eval(self, what: int, X, L=None):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        L = None if L is None else np.ascontiguousarray(L, dtype=np.float64)
+        kind = what & 0xFF
+        fx = np.empty((self.nseg, self.OR))
+        agx = np.empty((self.nseg, self.IR)) if kind in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+        kkt = np.empty((self.nseg, self.NKKT)) if kind >= JAC else None
+        _lib.check(_lib.lib().asset_hip_sharded_eval(self._s, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx), _dptr(kkt)),
+                   "asset_hip_sharded_eval")
+        return fx, agx, kkt
+
+    def set_kkt_map(self, slot_locations, nvalues: int):
+        m = np.ascontiguousarray(slot_locations, dtype=np.int32).reshape(self.nseg, self.NKKT)
+        _lib.check(_lib.lib().asset_hip_sharded_set_kkt_map(self._s, m.ctypes.data_as(C.POINTER(C.c_int32)), int(nvalues)),
+                   "asset_hip_sharded_set_kkt_map")
+        self._nvalues = int(nvalues)
+        return self
+
+    def eval_assembled(self, what: int, X, L, values):
+        """``values[nvalues]`` is accumulated into; returns (fx, agx or None)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        L = None if L is None else np.ascontiguousarray(L, dtype=np.float64)
+        if values.dtype != np.float64 or not values.flags.c_contiguous or values.size != self._nvalues:
+            raise ValueError("values must be a contiguous float64 array of the map's length")
+        kind = what & 0xFF
+        fx = np.empty((self.nseg, self.OR))
+        agx = np.empty((self.nseg, self.IR)) if kind in (JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+        _lib.check(_lib.lib().asset_hip_sharded_eval_assembled(self._s, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx), _dptr(values)),
+                   "asset_hip_sharded_eval_assembled")
+        return fx, agx
+
+    def close(self):
+        s, self._s = getattr(self, "_s", None), None
+        if s and _lib is not None and getattr(_lib, "lib", None) is not None:
+            _lib.lib().asset_hip_sharded_destroy(s)
+
+    __del__ = close

@@ -26,30 +26,67 @@ static void check(int rc, const char* what) {
   if (rc != 0) throw std::runtime_error(std::string(what) + ": " + asset_hip_last_error());
 }
 
+std::vector<SolverIndexingData> SolverIndexingData::thread_split(int Threads) const {
+  std::vector<SolverIndexingData> split;
+  if (Threads <= 0) return split;
+  const int cols = num_funcappl, per = cols / Threads, rem = cols % Threads, range = per > 0 ? Threads : rem;
+  int start = 0;
+  for (int i = 0; i < range; i++) {
+    const int cnt = per + (i < rem ? 1 : 0);
+    SolverIndexingData d;
+    d.input_size = input_size, d.output_size = output_size, d.num_funcappl = cnt;
+    d.Vindex.assign(Vindex.begin() + size_t(start) * input_size, Vindex.begin() + size_t(start + cnt) * input_size);
+    if (!Cindex.empty()) d.Cindex.assign(Cindex.begin() + size_t(start) * output_size, Cindex.begin() + size_t(start + cnt) * output_size);
+    split.push_back(std::move(d));
+    start += cnt;
+  }
+  return split;
+}
+
 BatchedDefectConstraint::BatchedDefectConstraint(const std::string& ode, int mode, bool blocked,
                                                  const SolverIndexingData& data, int primal_vars, int equal_cons,
                                                  int device)
     : ode_(ode), mode_(mode), nappl_(data.NumAppl()), n_equal_(equal_cons), blocked_(blocked), n_primal_(primal_vars), device_(device) {
+  create(data);
+}
+
+BatchedDefectConstraint::BatchedDefectConstraint(const std::string& ode, int mode, bool blocked,
+                                                 const SolverIndexingData& data, int primal_vars, int equal_cons,
+                                                 const std::vector<int>& devices)
+    : ode_(ode), mode_(mode), nappl_(data.NumAppl()), n_equal_(equal_cons), blocked_(blocked), n_primal_(primal_vars),
+      device_(devices.empty() ? 0 : devices[0]), devices_(devices) {
+  if (devices.empty()) throw std::invalid_argument("BatchedDefectConstraint: no devices");
+  create(data);
+}
+
+int BatchedDefectConstraint::num_shards() const { return hs_ ? asset_hip_sharded_shards(hs_) : 1; }
+
+void BatchedDefectConstraint::create(const SolverIndexingData& data) {
   if (data.NumAppl() <= 0) throw std::invalid_argument("BatchedDefectConstraint: no function applications");
   asset_hip_defect_desc d;
   std::memset(&d, 0, sizeof d);
-  d.mode = mode;
-  d.blocked = blocked ? 1 : 0;
+  d.mode = mode_;
+  d.blocked = blocked_ ? 1 : 0;
   d.ode = ode_.c_str();
   d.nseg = data.NumAppl();
   d.vindex = data.Vindex.data();
   d.cindex = data.Cindex.data();
-  d.n_primal = primal_vars;
-  d.n_equal = equal_cons;
-  d.device = device;
-  int rc = asset_hip_defect_create(&d, &h_);
+  d.n_primal = n_primal_;
+  d.n_equal = n_equal_;
+  d.device = device_;
+  int rc;
+  if (devices_.empty()) rc = asset_hip_defect_create(&d, &h_);
+  else {
+    rc = asset_hip_defect_create_sharded(&d, int(devices_.size()), devices_.data(), &hs_);
+    if (rc == 0) h_ = asset_hip_sharded_handle(hs_, 0);
+  }
   if (rc == ASSET_HIP_EINVAL || rc == ASSET_HIP_ENOODE || rc == ASSET_HIP_ERANGE)
     throw std::invalid_argument(std::string("BatchedDefectConstraint: ") + asset_hip_last_error());
-  check(rc, "asset_hip_defect_create");
+  check(rc, devices_.empty() ? "asset_hip_defect_create" : "asset_hip_defect_create_sharded");
   check(asset_hip_defect_sizes(h_, &ir_, &or_, &nkkt_), "asset_hip_defect_sizes");
   if (ir_ != data.input_size || or_ != data.output_size) {
-    asset_hip_defect_destroy(h_);
-    h_ = nullptr;
+    if (hs_) asset_hip_sharded_destroy(hs_); else asset_hip_defect_destroy(h_);
+    h_ = nullptr, hs_ = nullptr;
     throw std::invalid_argument("BatchedDefectConstraint: index data rows do not match the defect's IRows/ORows");
   }
   fx_.resize(size_t(nappl_) * or_);
@@ -63,7 +100,8 @@ BatchedDefectConstraint::BatchedDefectConstraint(const std::string& ode, int mod
 
 BatchedDefectConstraint::~BatchedDefectConstraint() {
   unpin();
-  asset_hip_defect_destroy(h_);
+  if (hs_) asset_hip_sharded_destroy(hs_);
+  else asset_hip_defect_destroy(h_);
 }
 
 void BatchedDefectConstraint::unpin() {
@@ -80,6 +118,16 @@ void BatchedDefectConstraint::unpin() {
 void BatchedDefectConstraint::rebind(const SolverIndexingData& data, int primal_vars, int equal_cons) {
   if (data.NumAppl() <= 0 || data.input_size != ir_ || data.output_size != or_)
     throw std::invalid_argument("BatchedDefectConstraint::rebind: index data does not fit this function");
+  if (hs_) {   // the sharded form: another split of the applications -- new shards (the device code stays loaded in the library)
+    unpin();
+    asset_hip_sharded_destroy(hs_);
+    hs_ = nullptr, h_ = nullptr;
+    nappl_ = data.NumAppl(), n_primal_ = primal_vars, n_equal_ = equal_cons;
+    map_source_ = nullptr;
+    map_.clear();
+    create(data);
+    return;
+  }
   const int rc = asset_hip_defect_rebind(h_, data.NumAppl(), data.Vindex.data(), data.Cindex.data(), primal_vars, equal_cons);
   if (rc == ASSET_HIP_EINVAL || rc == ASSET_HIP_ERANGE)
     throw std::invalid_argument(std::string("BatchedDefectConstraint::rebind: ") + asset_hip_last_error());
@@ -101,12 +149,22 @@ void BatchedDefectConstraint::rebind(const SolverIndexingData& data, int primal_
 // copies must not release one handle twice; an adapter that needs value semantics holds this class -- or the raw handle --
 // in a std::shared_ptr)
 std::unique_ptr<BatchedDefectConstraint> BatchedDefectConstraint::deep_copy(const SolverIndexingData& data) const {
-  auto c = std::make_unique<BatchedDefectConstraint>(ode_, mode_, blocked_, data, n_primal_, n_equal_, device_);
+  auto c = devices_.empty() ? std::make_unique<BatchedDefectConstraint>(ode_, mode_, blocked_, data, n_primal_, n_equal_, device_)
+                            : std::make_unique<BatchedDefectConstraint>(ode_, mode_, blocked_, data, n_primal_, n_equal_, devices_);
   if (nvalues_ > 0) c->enable_device_assembly(nvalues_);
   return c;
 }
 
 void BatchedDefectConstraint::set_appl_consts(const double* consts, int per_application) {
+  if (hs_) {
+    for (int i = 0; i < asset_hip_sharded_shards(hs_); i++) {
+      int first = 0, count = 0;
+      check(asset_hip_sharded_range(hs_, i, &first, &count, nullptr), "asset_hip_sharded_range");
+      check(asset_hip_defect_set_appl_consts(asset_hip_sharded_handle(hs_, i), consts + size_t(first) * per_application, per_application),
+            "asset_hip_defect_set_appl_consts");
+    }
+    return;
+  }
   check(asset_hip_defect_set_appl_consts(h_, consts, per_application), "asset_hip_defect_set_appl_consts");
 }
 
@@ -172,14 +230,17 @@ void BatchedDefectConstraint::eval(int what, const double* X, const double* L, d
   const bool assembled = want_kkt && nvalues_ > 0;
   if (assembled) {
     ensure_kkt_map(KKTLocations, data, hess_only);
-    check(asset_hip_defect_eval_assembled(h_, what, X, L, fx_.data(), want_agx ? agx_.data() : nullptr, KKTvals),
-          "asset_hip_defect_eval_assembled");
+    if (hs_) check(asset_hip_sharded_eval_assembled(hs_, what, X, L, fx_.data(), want_agx ? agx_.data() : nullptr, KKTvals),
+                   "asset_hip_sharded_eval_assembled");
+    else check(asset_hip_defect_eval_assembled(h_, what, X, L, fx_.data(), want_agx ? agx_.data() : nullptr, KKTvals),
+               "asset_hip_defect_eval_assembled");
   } else {
     // the Jacobian kinds scatter with KKTFillJac below, which never reads the Hessian slots: do not have them written
     const int keep = (what == ASSET_HIP_JAC || what == ASSET_HIP_JAC_ADJGRAD) ? ASSET_HIP_KEEP_HESSIAN_SLOTS : 0;
-    check(asset_hip_defect_eval(h_, what | keep, X, L, fx_.data(), want_agx ? agx_.data() : nullptr,
-                                want_kkt ? kkt_.data() : nullptr),
-          "asset_hip_defect_eval");
+    if (hs_) check(asset_hip_sharded_eval(hs_, what | keep, X, L, fx_.data(), want_agx ? agx_.data() : nullptr,
+                                          want_kkt ? kkt_.data() : nullptr), "asset_hip_sharded_eval");
+    else check(asset_hip_defect_eval(h_, what | keep, X, L, fx_.data(), want_agx ? agx_.data() : nullptr,
+                                     want_kkt ? kkt_.data() : nullptr), "asset_hip_defect_eval");
   }
   for (int V = 0; V < nappl_; V++) {  // callee overwrites its FX / AGX slots (fx.setZero(); compute)
     std::memcpy(FX + data.InnerConstraintStarts[V], fx_.data() + size_t(V) * or_, sizeof(double) * or_);
@@ -261,7 +322,8 @@ void BatchedDefectConstraint::ensure_kkt_map(const int* lpt, const SolverIndexin
       for (int j = 0; j < or_; j++) m[k++] = space_slot(V, i, -1, j);
     }
   }
-  check(asset_hip_defect_set_kkt_map(h_, map_.data(), nvalues_, 0), "asset_hip_defect_set_kkt_map");
+  if (hs_) check(asset_hip_sharded_set_kkt_map(hs_, map_.data(), nvalues_), "asset_hip_sharded_set_kkt_map");
+  else check(asset_hip_defect_set_kkt_map(h_, map_.data(), nvalues_, 0), "asset_hip_defect_set_kkt_map");
   map_source_ = lpt;
   map_hess_only_ = hess_only;
 }

@@ -31,6 +31,10 @@ struct SolverIndexingData {
   // IndexingData.h:96-115
   void getGradientSpace(int* GXrows, int& freeloc);
   void getConstraintSpace(int* FXrows, int& freeloc);
+  // IndexingData.h:117-146: contiguous chunks of the applications, the first num_funcappl % Threads one longer; fewer chunks
+  // than Threads when there are fewer applications.  (The sharded constraint below splits by the same rule inside the library;
+  // this is for callers that keep one index-data object per shard, as the reference's ConstraintFunction::thread_split does.)
+  std::vector<SolverIndexingData> thread_split(int Threads) const;
 };
 
 class BatchedDefectConstraint {
@@ -38,7 +42,15 @@ class BatchedDefectConstraint {
   // mode: ASSET_HIP_LGL3/5/7 or ASSET_HIP_TRAPEZOIDAL; throws std::invalid_argument / std::runtime_error
   BatchedDefectConstraint(const std::string& ode, int mode, bool blocked, const SolverIndexingData& data,
                           int primal_vars, int equal_cons, int device = 0);
+  // The same constraint as one handle per device IN THIS PROCESS (include/asset_hip.h: asset_hip_defect_create_sharded): the
+  // applications are split by the ByApplication rule (SolverIndexingData::thread_split) over devices[0..n), every evaluation
+  // enqueues all shards and every shard's blocks come back over its own PCIe link.  The method set, the index data and the
+  // results are those of the single-handle object (the blocks bitwise) -- this is what stands where the reference registers a
+  // constraint with ThreadMode::ByApplication (Solvers/NonLinearProgram.cpp:71-109), still called from ONE solver thread.
+  BatchedDefectConstraint(const std::string& ode, int mode, bool blocked, const SolverIndexingData& data,
+                          int primal_vars, int equal_cons, const std::vector<int>& devices);
   ~BatchedDefectConstraint();
+  int num_shards() const;
   BatchedDefectConstraint(const BatchedDefectConstraint&) = delete;
   BatchedDefectConstraint& operator=(const BatchedDefectConstraint&) = delete;
 
@@ -102,7 +114,10 @@ class BatchedDefectConstraint {
   void eval(int what, const double* X, const double* L, double* FX, double* AGX, double* KKTvals,
             const int* KKTLocations, const SolverIndexingData& data, bool hess_only = false);
   void unpin();
+  void create(const SolverIndexingData& data);
   asset_hip_defect_t h_ = nullptr;
+  asset_hip_sharded_t hs_ = nullptr;   // the sharded form (then h_ is the first shard's handle, owned by hs_)
+  std::vector<int> devices_;
   std::string ode_;
   int mode_, ir_ = 0, or_ = 0, nkkt_ = 0, nappl_ = 0, n_equal_ = 0;
   bool blocked_ = false;

@@ -101,6 +101,32 @@ void asset_hip_defect_destroy(asset_hip_defect_t h);
 int asset_hip_defect_rebind(asset_hip_defect_t h, int nseg, const int32_t* vindex, const int32_t* cindex, int n_primal,
                             int n_equal);
 
+/* ---- one constraint, several handles in one process: the reference's thread_split as device shards ----
+ * Replaces ConstraintFunction::thread_split (Solvers/ConstraintFunction.h:55-62) -> SolverIndexingData::thread_split
+ * (VectorFunctions/IndexingData.h:117-146: contiguous chunks of the applications, the first nseg % nshards one longer; fewer shards
+ * when there are fewer applications than shards) and the per-thread placement and launch of Solvers/NonLinearProgram.cpp:71-109,
+ * 519-526: shard i is a handle of its own on HIP device devices[i] (a device may be named more than once) with its own stream.
+ * An evaluation copies X / L to every shard's device over that device's PCIe link, enqueues ALL shards, and lets every shard
+ * copy its slice of the blocks (rows [first, first + count) of the arrays a single handle would fill) straight into the
+ * caller's arrays; it returns when every shard has finished.  Page-lock the arrays (asset_hip_host_register) for DMA rate.
+ * No collective library and no second process are involved.  The blocks are bitwise those of a single handle. */
+typedef struct asset_hip_sharded* asset_hip_sharded_t;
+int asset_hip_defect_create_sharded(const asset_hip_defect_desc* desc, int nshards, const int* devices, asset_hip_sharded_t* out);   /* desc->device is ignored */
+void asset_hip_sharded_destroy(asset_hip_sharded_t s);
+int asset_hip_sharded_shards(asset_hip_sharded_t s);                     /* shards actually created */
+int asset_hip_sharded_range(asset_hip_sharded_t s, int shard, int* first, int* count, int* device);
+asset_hip_defect_t asset_hip_sharded_handle(asset_hip_sharded_t s, int shard);   /* the shard's own handle (owned by s) */
+int asset_hip_sharded_eval(asset_hip_sharded_t s, int what, const double* X, const double* L, double* fx_blocks,
+                           double* agx_blocks, double* kkt_blocks);
+/* On-device assembly per shard (see asset_hip_defect_set_kkt_map below): slot_locations[nseg * NKKT] as for a single handle.
+ * Every shard assembles its entries into its own range [lowest, highest location] of the value array on its device; the range
+ * crosses PCIe into page-locked staging and is ADDED into kkt_values[nvalues] in shard order (kkt_values is accumulated into,
+ * as asset_hip_defect_eval_assembled does).  Entries two neighbouring shards share are a + b as with a single handle (bitwise
+ * equal for a phase without parameters); entries between phase parameters are summed per shard first (equal to rounding). */
+int asset_hip_sharded_set_kkt_map(asset_hip_sharded_t s, const int32_t* slot_locations, long long nvalues);
+int asset_hip_sharded_eval_assembled(asset_hip_sharded_t s, int what, const double* X, const double* L, double* fx_blocks,
+                                     double* agx_blocks, double* kkt_values);
+
 /* IRows, ORows, per-application KKT slots */
 int asset_hip_defect_sizes(asset_hip_defect_t h, int* irows, int* orows, int* nkkt);
 

@@ -10,6 +10,14 @@
 
 using namespace asset_hip_host;
 
+// 0: one handle on device 0; n > 0: the constraint as n in-process shards, all on device 0 (one GPU on the test box)
+static int g_shards = 0;
+extern "C" void shim_set_shards(int n) { g_shards = n; }
+static std::unique_ptr<BatchedDefectConstraint> make_con(const char* ode, int mode, bool blocked, const SolverIndexingData& d, int primal, int equal) {
+  if (g_shards > 0) return std::make_unique<BatchedDefectConstraint>(ode, mode, blocked, d, primal, equal, std::vector<int>(size_t(g_shards), 0));
+  return std::make_unique<BatchedDefectConstraint>(ode, mode, blocked, d, primal, equal, 0);
+}
+
 extern "C" int shim_run(const char* ode, int mode, int blocked, int ir, int orr, int nappl, const int* vindex,
                         const int* cindex, int primal, int equal, int what, const double* X, const double* L,
                         const int* kkt_locations, int* kkt_rows_out, int* kkt_cols_out, double* kkt_vals,
@@ -19,7 +27,14 @@ extern "C" int shim_run(const char* ode, int mode, int blocked, int ir, int orr,
     data.input_size = ir, data.output_size = orr, data.num_funcappl = nappl;
     data.Vindex.assign(vindex, vindex + size_t(ir) * nappl);
     data.Cindex.assign(cindex, cindex + size_t(orr) * nappl);
-    BatchedDefectConstraint con(ode, mode, blocked != 0, data, primal, equal, 0);
+    auto conp = make_con(ode, mode, blocked != 0, data, primal, equal);
+    BatchedDefectConstraint& con = *conp;
+    if (g_shards > 0) {   // the split is the reference's (IndexingData.h:117-146)
+      auto parts = data.thread_split(g_shards);
+      int tot = 0;
+      for (auto& q : parts) tot += q.NumAppl();
+      if (int(parts.size()) != con.num_shards() || tot != nappl) throw std::runtime_error("thread_split / shard count mismatch");
+    }
     std::vector<int> gxrows(size_t(ir) * nappl), fxrows(size_t(orr) * nappl);
     int gfree = 0, cfree = 0, kfree = 0;
     data.getGradientSpace(gxrows.data(), gfree);
@@ -65,7 +80,7 @@ extern "C" int shim_rebind_run(const char* ode, int mode, int blocked, int ir, i
     data.input_size = ir, data.output_size = orr, data.num_funcappl = nappl;
     data.Vindex.assign(vindex, vindex + size_t(ir) * nappl);
     data.Cindex.assign(cindex, cindex + size_t(orr) * nappl);
-    auto con = std::make_unique<BatchedDefectConstraint>(ode, mode, blocked != 0, small, primal, equal, 0);
+    auto con = make_con(ode, mode, blocked != 0, small, primal, equal);
     if (assembly_nvalues > 0) con->enable_device_assembly(assembly_nvalues);
     {
       std::vector<int> fr0(size_t(orr) * nappl0);

@@ -25,7 +25,11 @@ def shim(tmp_path_factory):
 @pytest.mark.parametrize("ode,mode,blocked,nseg", [("reentry", "LGL7", False, 37), ("twobody_lt", "LGL5", True, 20),
                                                    ("betts_lowthrust", "LGL3", False, 9), ("reentry", "Trapezoidal", False, 11)])
 @pytest.mark.parametrize("device_assembly", [False, True])
-def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg, device_assembly):
+@pytest.mark.parametrize("shards", [0, 3])
+def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg, device_assembly, shards):
+    """shards = 3: the same object built as three in-process shards on device 0 (BatchedDefectConstraint's device-list
+    constructor over asset_hip_defect_create_sharded) -- the ByApplication form of ConstraintFunction::thread_split."""
+    shim.shim_set_shards(shards)
     w = Workload(ode, mode, nseg, blocked, var_offset=2, con_offset=1, extra_vars=3)
     nlp = w.oracle_nlp(oracle, threads=1)
     locs = nlp.kkt_locations()
@@ -56,9 +60,11 @@ def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg, device_
 
 
 @pytest.mark.parametrize("device_assembly", [False, True])
-def test_shim_rebind_and_deep_copy(oracle, shim, device_assembly):
+@pytest.mark.parametrize("shards", [0, 2])
+def test_shim_rebind_and_deep_copy(oracle, shim, device_assembly, shards):
     """A constraint created for a smaller mesh, re-bound (the re-meshing step, ODEPhaseBase.cpp:1443-1542) and deep-copied
     (DeepCopySpecs.h:36-60; the original destroyed before the copy evaluates) scatters what the oracle's NLP does."""
+    shim.shim_set_shards(shards)
     w = Workload("reentry", "LGL5", 29, var_offset=2, con_offset=1, extra_vars=3)
     nlp = w.oracle_nlp(oracle, threads=1)
     locs = nlp.kkt_locations()
@@ -80,6 +86,7 @@ def test_shim_rebind_and_deep_copy(oracle, shim, device_assembly):
 def test_kkt_assembly_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg):
     """Product-side sparsity analysis and eval* drivers (host/kkt_assembly.h) against the oracle's restatement of
     NonLinearProgram: same CSR structure, same KKTLocations, same values for evalOCC / evalRHS / evalSOE / evalAUG / evalKKT."""
+    shim.shim_set_shards(0)
     w = Workload(ode, mode, nseg, blocked, var_offset=2, con_offset=1, extra_vars=3)
     nlp = w.oracle_nlp(oracle, threads=1)
     r_outer, r_inner = nlp.csr()

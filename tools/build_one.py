@@ -16,7 +16,7 @@ if any(f.startswith(("-DASSET_TIMING", "-DASSET_WALLCLOCK", "-DASSET_FUNC_TIMING
 B.generate(verbose=False)
 os.makedirs(os.path.dirname(out), exist_ok=True)
 objs = []
-for src in (os.path.join(B.GEN, tu + ".hip"), os.path.join(B.CSRC, "capi.hip")):
+for src in (os.path.join(B.GEN, tu + ".hip"), os.path.join(B.CSRC, "capi.hip"), os.path.join(B.CSRC, "capi_sharded.hip")):
     obj = os.path.join(os.path.dirname(out), os.path.basename(src) + ".o")
     subprocess.check_call([B.HIPCC] + B.FLAGS + B.tu_flags(src) + extra + ["-c", src, "-o", obj])
     objs.append(obj)
