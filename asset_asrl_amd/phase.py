@@ -105,9 +105,12 @@ class Phase:
         self._eq_funcs = []       # (region, func, xtuv, opv, spv) -- addEqualCon
         self._iq_funcs = []       # addInequalCon
         self._integral_objs = []  # (integrand, xtuv, opv, spv) -- addIntegralObjective
+        self._integral_params = []  # (integrand, xtuv, opv, spv, accumulating static parameter) -- addIntegralParamFunction
+        self.ActiveStaticParams = np.zeros(0)   # setStaticParams
         self._eq_evs = []
         self._iq_evs = []
         self._obj_evs = []
+        self._ipf_evs = {}        # k -> {"acc": evaluator, "int": evaluator}: addIntegralParamFunction
         self._auto_evs = {}       # "mesh_spacing", "nodal_spacing", "control_spline": evaluators the phase adds itself
         self.EnableMeshSpacing = True      # (the reference always adds them; the switch is for callers that only want the defects)
 
@@ -264,6 +267,29 @@ class Phase:
         self._ev = None
         return len(self._integral_objs) - 1
 
+    def setStaticParams(self, params):
+        """Static parameters of the phase: solver variables behind the trajectory and the ODE parameters that user functions may
+        name in their ``SPVars`` (ODEPhaseBase.h setStaticParams; PhaseIndexer.cpp: StaticParamLoc)."""
+        self.ActiveStaticParams = np.asarray(params, dtype=float).ravel().copy()
+        self._ev = None
+
+    def addIntegralParamFunction(self, integrand, XtUVars=(), OPVars=(), SPVars=(), accum_param: int = 0, scale: float = 1.0) -> int:
+        """``int integrand(x, t, u, p) dt - scale * StaticParams[accum_param] = 0`` (ODEPhaseBase.cpp:835-889 with
+        PhaseIndexer::addAccumulation, PhaseIndexer.cpp:41-76): the static parameter is made to equal the integral.  TWO equality
+        functions share ONE constraint row -- the linear accumulation ``-scale * p`` over the Params region, and the segment
+        quadrature of the integrand (the one ``addIntegralObjective`` uses) over every defect, all of whose applications carry
+        the accumulation's row: their values, multiplier and Jacobian entries add up in the solver's row.  Returns the index of
+        the pair among the phase's integral parameter functions; the two evaluators are
+        ``integral_param_evaluators[index] = (accumulation, quadrature)``."""
+        xtuv, opv, spv = [int(v) for v in XtUVars], [int(v) for v in OPVars], [int(v) for v in SPVars]
+        if integrand.ORows() != 1 or integrand.IRows() != len(xtuv) + len(opv) + len(spv):
+            raise ValueError("an integrand has one output and takes the listed state variables and parameters")
+        if not 0 <= int(accum_param) < len(self.ActiveStaticParams):
+            raise ValueError("accum_param names no static parameter of the phase (setStaticParams first)")
+        self._integral_params.append((integrand, xtuv, opv, spv, int(accum_param), float(scale)))
+        self._ev = None
+        return len(self._integral_params) - 1
+
     def removeEqualCon(self, index: int):
         del self._eq_funcs[index]
         self._ev = None
@@ -322,6 +348,16 @@ class Phase:
             V, _, _ = ix.make_Vindex_Cindex("DefectPath", xtuv + tv, opv, spv, 0, 0)
             Cx = np.zeros((V.shape[0], 1), dtype=np.int32)           # every application reads multiplier 0 = ObjScale
             out.append(("objective", f"obj{k}", f, f"obj{k}_integral{cs}", V, Cx, None))
+        # integral parameter functions (ODEPhaseBase.cpp:835-889; addAccumulation, PhaseIndexer.cpp:41-76): the accumulation
+        # -scale * p over Params claims the row, every application of the quadrature carries that same row
+        for k, (integrand, xtuv, opv, spv, acc, scale) in enumerate(self._integral_params):
+            from .vf import Arguments
+            Va, Ca, next_eq = ix.make_Vindex_Cindex("Params", (), (), [acc], 1, next_eq)
+            out.append(("equality", f"ipf{k}_acc", Arguments(1) * (-scale), f"ipf{k}_accumulate", Va, Ca, None))
+            f = LGLIntegral(integrand, cs, len(xtuv), len(opv) + len(spv))
+            V, _, _ = ix.make_Vindex_Cindex("DefectPath", xtuv + tv, opv, spv, 0, 0)
+            Cx = np.full((V.shape[0], 1), int(Ca[0, 0]), dtype=np.int32)
+            out.append(("equality", f"ipf{k}_int", f, f"ipf{k}_integral{cs}", V, Cx, None))
         for store, is_eq in ((self._eq_funcs, True), (self._iq_funcs, False)):
             for k, (region, func, xtuv, opv, spv) in enumerate(store):
                 f = self._scaled_func(region, func, xtuv, opv)
@@ -343,12 +379,15 @@ class Phase:
         # every equality evaluator (the defects included) takes the phase's whole equality multiplier vector
         n_eq, n_iq = ix.con_offset + self.numPhaseEqCons, self.numPhaseIqCons
         self._eq_evs, self._iq_evs, self._obj_evs, self._auto_evs = [], [], [], {}
+        self._ipf_evs = {}
         for kind, tag, F, name, V, Cx, consts in entries:
             ncon = {"auto": n_eq, "equality": n_eq, "inequality": n_iq, "objective": 1}[kind]
             kw = {"appl_consts": consts} if consts is not None else {}
             ev = FunctionEvaluator(F, name, V, Cx, ix.numPhaseVars, ncon, self.device, **kw)
             if kind == "auto":
                 self._auto_evs[tag] = ev
+            elif tag.startswith("ipf"):
+                self._ipf_evs.setdefault(int(tag[3:].split("_")[0]), {})[tag.split("_")[1]] = ev
             else:
                 {"equality": self._eq_evs, "inequality": self._iq_evs, "objective": self._obj_evs}[kind].append(ev)
 
@@ -360,7 +399,7 @@ class Phase:
         of the defects, entries, numPhaseEqCons, numPhaseIqCons)."""
         if self.ActiveTraj is None:
             raise RuntimeError("No trajectory set: call setTraj first")
-        ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
+        ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), len(self.ActiveStaticParams))
         ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
         ix.begin_indexing(Vstart, Estart)
         entries, neq, niq = self._function_tables(ix, Istart)
@@ -372,6 +411,14 @@ class Phase:
         if self._ev is None:
             self.transcribe()
         return list(self._eq_evs)
+
+    @property
+    def integral_param_evaluators(self):
+        """[(accumulation evaluator, quadrature evaluator)] of the integral parameter functions: two equality functions on
+        one constraint row each (addIntegralParamFunction)."""
+        if self._ev is None:
+            self.transcribe()
+        return [(self._ipf_evs[k]["acc"], self._ipf_evs[k]["int"]) for k in sorted(self._ipf_evs)]
 
     @property
     def objective_evaluators(self):
@@ -413,7 +460,7 @@ class Phase:
             raise RuntimeError("No trajectory set: call setTraj first")
         # library ODEs are compiled into libasset_hip.so; any other ODEBase gets device code on first use (jit.py)
         name = jit.ensure_kernel(self._active_ode(), self.TranscriptionMode, self._blocked())
-        ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
+        ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), len(self.ActiveStaticParams))
         ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
         ix.begin_indexing(0, 0)
         V, Cx = ix.make_defect_Vindex_Cindex()
@@ -441,21 +488,21 @@ class Phase:
         if self.ActiveTraj is None:
             raise RuntimeError("No trajectory set: call setTraj first")
         jit.ensure_kernel(self._active_ode(), self.TranscriptionMode, self._blocked())
-        ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), 0)
+        ix = PhaseIndexer(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), len(self.ActiveStaticParams))
         ix.set_dimensions(synth.MODE_CS[self.TranscriptionMode], self.numDefects, self._blocked())
         ix.begin_indexing(0, 0)
         self._make_function_evaluators(ix, build_only=True)      # (build_only: the lists hold device names, not evaluators)
         names = list(self._auto_evs.values()) + list(self._eq_evs) + list(self._iq_evs) + list(self._obj_evs)
         if 1 <= len(names) <= 8:
             jit.ensure_bundle(names)                              # function_bundle(): the same list in one launch
-        self._eq_evs, self._iq_evs, self._obj_evs, self._auto_evs = [], [], [], {}
+        self._eq_evs, self._iq_evs, self._obj_evs, self._auto_evs, self._ipf_evs = [], [], [], {}, {}
         return self
 
     def solver_input(self) -> np.ndarray:
         if self._indexer is None:
             self.transcribe()
         traj = self.ActiveTraj / self.XtUPUnits if self.AutoScaling else self.ActiveTraj   # variables in scaled units
-        return self._indexer.makeSolverInput(traj)
+        return self._indexer.makeSolverInput(traj, self.ActiveStaticParams if len(self.ActiveStaticParams) else None)
 
     @property
     def evaluator(self) -> DefectEvaluator:

@@ -141,3 +141,40 @@ def test_function_bundle_gives_the_blocks_of_the_separate_launches():
         for one, two in zip(fb + (gb + kb if what != CON else []), fs + (gs + ks if what != CON else [])):
             assert torch.equal(one, two) and not torch.isnan(one).any()
     bundle.close()
+
+
+def test_integral_param_function_shares_one_row_between_accumulation_and_quadrature(oracle):
+    """addIntegralParamFunction (ODEPhaseBase.cpp:835-889 / PhaseIndexer::addAccumulation, PhaseIndexer.cpp:41-76): the
+    accumulation -scale * p over the Params region claims a row; every application of the segment quadrature carries that row.
+    Summed over the row: int (h^2 + v) dt - scale * p."""
+    nseg = 13
+    w = Workload("reentry", "LGL7", nseg)
+    ph = ShuttleReentry().phase("LGL7", w.traj, nseg)
+    ph.setStaticParams([0.25, -1.5])
+    g = vf.Arguments(2)
+    assert ph.addIntegralParamFunction(g.coeff(1) * g.coeff(1) + g.coeff(0), [2, 0], accum_param=1, scale=2.0) == 0
+    ph.transcribe()
+    ((acc, quad),) = ph.integral_param_evaluators
+    ix, cs, xtu, tcol = ph._indexer, 4, ph._indexer.XtUVars(), ph.ode.TVar()
+    row = int(acc.cindex[0, 0])
+    assert acc.vindex.tolist() == [[ix.StaticParamLoc0 + 1]] and acc.cindex.shape == (1, 1)
+    np.testing.assert_array_equal(quad.cindex, np.full((nseg, 1), row))
+    np.testing.assert_array_equal(quad.vindex, [[(i * 3 + j) * xtu + v for j in range(cs) for v in (2, 0, tcol)] for i in range(nseg)])
+    # rows: defects, mesh spacing, nodal spacing, control spline, then the ONE row of the pair; nothing after it here
+    assert ph.numPhaseEqCons == row + 1 == ph.evaluator.n_equal
+    X = ph.solver_input()
+    assert X[ix.StaticParamLoc0 + 1] == -1.5
+    rng = np.random.default_rng(11)
+    L = rng.uniform(-2, 2, ph.numPhaseEqCons)
+    quad2 = oracle.get_ode("integrand_quad2", 0)
+    _check(quad, X, L, lambda V, x, l: oracle.lgl_integral_all(quad2, 4, 2, 0, x, l), scale=np.abs(X).max() ** 2)
+    fa, ga, ka = acc.eval(JAC_ADJGRAD_HESS, X, L)
+    assert fa.shape == (1, 1) and fa[0, 0] == -2.0 * -1.5 and ga[0, 0] == -2.0 * L[row]
+    # the row's value: the quadrature of every defect plus the accumulation
+    import json
+    import os
+    wts = np.array(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lgl_tables.json")))["tables"]["4"]["Reduced_Integral_Weights"])
+    T = ph.ActiveTraj
+    integral = sum((T[3 * i + 3, tcol] - T[3 * i, tcol]) * np.dot(wts, T[3 * i:3 * i + 4, 0] ** 2 + T[3 * i:3 * i + 4, 2]) for i in range(nseg))
+    total = quad.eval(0, X)[0].sum() + fa[0, 0]
+    assert abs(total - (integral + 3.0)) < 1e-11 * max(1.0, abs(integral))
