@@ -173,8 +173,34 @@ std::string BatchedDefectConstraint::name() const {
   return std::string("HIP_") + m + "Defects<" + ode_ + ">";
 }
 
-int BatchedDefectConstraint::numKKTEles(bool dojac, bool dohess) const {
-  return (dohess ? ir_ * (ir_ + 1) / 2 : 0) + (dojac ? or_ * ir_ : 0);
+void BatchedDefectConstraint::EnableHessianSparsity(bool on) {
+  hess_nz_.clear();
+  map_source_ = nullptr;
+  if (!on || mode_ != ASSET_HIP_TRAPEZOIDAL) return;
+  // TrapezoidalDefects::setODE, TrapezoidalDefects.h:75-121: IR = 2 q + p; ones on the two node blocks, on everything that touches
+  // a parameter, and on the rows and columns of the two node times
+  int xv = 0, uv = 0, pv = 0;
+  check(asset_hip_ode_sizes(ode_.c_str(), &xv, &uv, &pv), "asset_hip_ode_sizes");
+  const int q = xv + 1 + (blocked_ ? 0 : uv), p = blocked_ ? uv + pv : pv, T = xv;
+  if (2 * q + p != ir_) throw std::runtime_error("EnableHessianSparsity: sizes do not add up");
+  hess_nz_.assign(size_t(ir_) * ir_, 0);
+  auto set = [&](int r, int c) { hess_nz_[size_t(r) + size_t(ir_) * c] = 1; };
+  for (int r = 0; r < q; r++)
+    for (int c = 0; c < q; c++) { set(r, c); set(q + r, q + c); }
+  for (int r = 0; r < p; r++)
+    for (int c = 0; c < p; c++) set(2 * q + r, 2 * q + c);
+  for (int j = 0; j < 2; j++)
+    for (int r = 0; r < q; r++)
+      for (int c = 0; c < p; c++) { set(j * q + r, 2 * q + c); set(2 * q + c, j * q + r); }
+  for (int k = 0; k < ir_; k++) { set(k, T); set(k, T + q); set(T, k); set(T + q, k); }
+}
+
+int BatchedDefectConstraint::numKKTEles(bool dojac, bool dohess) const {   // DenseFunctionBase.h:1070-1088
+  int h = 0;
+  if (dohess)
+    for (int i = 0; i < ir_; i++)
+      for (int j = i; j < ir_; j++) h += HessianElemIsNonZero(j, i) ? 1 : 0;
+  return h + (dojac ? or_ * ir_ : 0);
 }
 
 void BatchedDefectConstraint::getKKTSpace(int* KKTrows, int* KKTcols, int& freeloc, int conoffset, bool dojac,
@@ -185,6 +211,7 @@ void BatchedDefectConstraint::getKKTSpace(int* KKTrows, int* KKTcols, int& freel
     for (int i = 0; i < ir_; i++) {
       if (dohess)
         for (int j = i; j < ir_; j++) {
+          if (!HessianElemIsNonZero(j, i)) continue;
           KKTrows[freeloc] = data.VLoc(j, V);
           KKTcols[freeloc] = data.VLoc(i, V);
           freeloc++;
@@ -200,16 +227,19 @@ void BatchedDefectConstraint::getKKTSpace(int* KKTrows, int* KKTcols, int& freel
 }
 
 void BatchedDefectConstraint::scatter_kkt(const double* blocks, int nkkt, int ir, int orr, bool dohess,
-                                          double* KKTvals, const int* lpt, const SolverIndexingData& data, bool dojac) {
+                                          double* KKTvals, const int* lpt, const SolverIndexingData& data, bool dojac,
+                                          const char* hess_nz) {
   for (int V = 0; V < data.NumAppl(); V++) {
     const double* blk = blocks + size_t(V) * nkkt;
     int freeloc = data.InnerKKTStarts[V];
     int k = 0;
     for (int i = 0; i < ir; i++) {
       if (dohess) {
-        for (int j = i; j < ir; j++) KKTvals[lpt[freeloc++]] += blk[k++];
+        if (!hess_nz) for (int j = i; j < ir; j++) KKTvals[lpt[freeloc++]] += blk[k++];
+        else for (int j = i; j < ir; j++, k++) { if (hess_nz[size_t(j) + size_t(ir) * i]) KKTvals[lpt[freeloc++]] += blk[k]; }   // AddHessianElem
       } else {  // KKTFillJac: the Hessian slots exist in the layout but are skipped
-        freeloc += ir - i;
+        if (!hess_nz) freeloc += ir - i;
+        else for (int j = i; j < ir; j++) freeloc += hess_nz[size_t(j) + size_t(ir) * i] ? 1 : 0;
         k += ir - i;
       }
       if (dojac) {
@@ -247,7 +277,8 @@ void BatchedDefectConstraint::eval(int what, const double* X, const double* L, d
     if (want_agx) std::memcpy(AGX + data.InnerGradientStarts[V], agx_.data() + size_t(V) * ir_, sizeof(double) * ir_);
   }
   if (want_kkt && !assembled)
-    scatter_kkt(kkt_.data(), nkkt_, ir_, or_, what == ASSET_HIP_JAC_ADJGRAD_HESS, KKTvals, KKTLocations, data, !hess_only);
+    scatter_kkt(kkt_.data(), nkkt_, ir_, or_, what == ASSET_HIP_JAC_ADJGRAD_HESS, KKTvals, KKTLocations, data, !hess_only,
+                hess_nz_.empty() ? nullptr : hess_nz_.data());
 }
 
 // ---- objective: the function's single output weighted by ObjScale (DenseScalarFunctionBase.h:14-80)
@@ -296,15 +327,31 @@ void BatchedDefectConstraint::ensure_kkt_map(const int* lpt, const SolverIndexin
   if (int(data.InnerKKTStarts.size()) != nappl_) throw std::invalid_argument("InnerKKTStarts not filled: call getKKTSpace first");
   // where block slot k of application V lives in the caller's KKT space: slot order `for i: {H(j>=i,i); J(:,i)}`; with
   // hess_only the space holds the Hessian slots alone (an objective) and the block's Jacobian slots are dropped (-1)
+  // (with a Hessian mask -- EnableHessianSparsity -- the claimed slots of a block column are fewer: hoff[i] = claimed Hessian slots
+  //  ahead of column i, hidx(j, i) = position of (j, i) among column i's claimed slots, -1 when it claims none)
+  std::vector<int> hoff(ir_ + 1, 0);
+  for (int i = 0; i < ir_; i++) {
+    int c = 0;
+    for (int j = i; j < ir_; j++) c += HessianElemIsNonZero(j, i) ? 1 : 0;
+    hoff[i + 1] = hoff[i] + c;
+  }
+  auto hidx = [&](int j, int i) -> int {
+    if (hess_nz_.empty()) return j - i;
+    if (!HessianElemIsNonZero(j, i)) return -1;
+    int c = 0;
+    for (int jj = i; jj < j; jj++) c += HessianElemIsNonZero(jj, i) ? 1 : 0;
+    return c;
+  };
   auto space_slot = [&](int V, int i, int j_h, int j_j) -> int {   // exactly one of j_h / j_j is >= 0
     int off = data.InnerKKTStarts[V];
     if (!hess_only) {
-      off += i * (ir_ + or_) - i * (i - 1) / 2;                   // first slot of block column i
-      return lpt[off + (j_h >= 0 ? j_h - i : (ir_ - i) + j_j)];
+      off += hoff[i] + i * or_;                                   // first slot of block column i
+      if (j_h >= 0) { const int k = hidx(j_h, i); return k < 0 ? -1 : lpt[off + k]; }
+      return lpt[off + (hoff[i + 1] - hoff[i]) + j_j];
     }
     if (j_h < 0) return -1;
-    off += i * ir_ - i * (i - 1) / 2;
-    return lpt[off + (j_h - i)];
+    const int k = hidx(j_h, i);
+    return k < 0 ? -1 : lpt[off + hoff[i] + k];
   };
   bool fresh = (lpt == map_source_) && map_.size() == size_t(nappl_) * nkkt_ && map_hess_only_ == hess_only;
   if (fresh) {  // same array: make sure the solver did not re-fill it in place (cheap sample)

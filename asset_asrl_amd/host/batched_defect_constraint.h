@@ -51,6 +51,14 @@ class BatchedDefectConstraint {
                           int primal_vars, int equal_cons, const std::vector<int>& devices);
   ~BatchedDefectConstraint();
   int num_shards() const;
+  // EnableHessianSparsity of the Trapezoidal defects (OptimalControl/TrapezoidalDefects.h:39, 75-141): the block of the adjoint
+  // Hessian that couples the two nodes of a segment -- without the rows / columns of their times and of the parameters -- is
+  // structurally zero; with the switch on it claims no KKT slots (numKKTEles / getKKTSpace via HessianElemIsNonZero) and the fill
+  // steps over it (AddHessianElem).  The device still evaluates whole blocks; the masked slots are dropped by the scatter, or by
+  // the slot map of the on-device assembly.  Set before getKKTSpace; ignored for the LGL transcriptions (the reference has no
+  // such mask there).
+  void EnableHessianSparsity(bool on);
+  bool HessianElemIsNonZero(int row, int col) const { return hess_nz_.empty() || hess_nz_[size_t(row) + size_t(ir_) * col] != 0; }
   BatchedDefectConstraint(const BatchedDefectConstraint&) = delete;
   BatchedDefectConstraint& operator=(const BatchedDefectConstraint&) = delete;
 
@@ -97,7 +105,8 @@ class BatchedDefectConstraint {
   // dojac = false: KKTFillHess of a scalar objective (DenseScalarFunctionBase.h:82-126), whose space holds no
   // Jacobian slots
   static void scatter_kkt(const double* kkt_blocks, int nkkt, int ir, int orr, bool dohess, double* KKTvals,
-                          const int* KKTLocations, const SolverIndexingData& data, bool dojac = true);
+                          const int* KKTLocations, const SolverIndexingData& data, bool dojac = true,
+                          const char* hess_nz = nullptr /* [row + ir * col] or null: every entry */);
 
   // ---- the same function used as an OBJECTIVE (one output): SolverObjectiveSpec::Concept, SolverInterfaceSpecs.h:252-281;
   //      bodies DenseScalarFunctionBase.h:14-80.  Val is accumulated (+= ObjScale * f over the applications), the GX
@@ -118,6 +127,7 @@ class BatchedDefectConstraint {
   asset_hip_defect_t h_ = nullptr;
   asset_hip_sharded_t hs_ = nullptr;   // the sharded form (then h_ is the first shard's handle, owned by hs_)
   std::vector<int> devices_;
+  std::vector<char> hess_nz_;          // empty: every Hessian entry claims a slot
   std::string ode_;
   int mode_, ir_ = 0, or_ = 0, nkkt_ = 0, nappl_ = 0, n_equal_ = 0;
   bool blocked_ = false;

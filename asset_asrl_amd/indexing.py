@@ -214,13 +214,30 @@ def thread_split(nappl: int, parts: int):
     return out
 
 
-def kkt_slot_locations(vindex, cindex, n_primal: int, con_offset: int = 0):
+def trapezoidal_hessian_mask(xv: int, uv: int, pv: int, blocked: bool) -> np.ndarray:
+    """``HessianElemIsNonZero`` of the Trapezoidal defects with ``EnableHessianSparsity`` (TrapezoidalDefects.h:75-130): bool
+    [IR, IR], IR = 2 q + p -- true on the two node blocks, on every row / column of a parameter and of the two node times; false
+    on the rest of the cross-node block."""
+    q = xv + 1 + (0 if blocked else uv)
+    p = (uv + pv) if blocked else pv
+    IR, T = 2 * q + p, xv
+    m = np.zeros((IR, IR), dtype=bool)
+    m[:q, :q] = m[q:2 * q, q:2 * q] = True
+    m[2 * q:, :] = m[:, 2 * q:] = True
+    for k in (T, T + q):
+        m[k, :] = m[:, k] = True
+    return m
+
+
+def kkt_slot_locations(vindex, cindex, n_primal: int, con_offset: int = 0, hess_mask=None):
     """``KKTLocations`` of ONE equality constraint alone in its program: for every application V and block slot k (slot order
     ``for i < IR {H(j,i), j >= i ; J(j,i), j < OR}``, DenseFunctionBase.h:1112-1123) the offset of its entry in the value array
     of the upper-triangular row-major CSR KKT matrix (NonLinearProgram.cpp:267-344: lower-triangle triplets are transposed,
     equality rows live behind the primal variables and the slacks -- none here -- so J(c, v) is stored at (v, n_primal + c)).
     Structure only: the matrix holds exactly the entries the constraint's slots name, columns sorted within a row, as
-    ``analyzeSparsity`` leaves them.  Returns (locations[nappl, NKKT] int64, nnz)."""
+    ``analyzeSparsity`` leaves them.  Returns (locations[nappl, NKKT] int64, nnz).  ``hess_mask[IR, IR]`` (bool, optional:
+    ``trapezoidal_hessian_mask``): Hessian slots whose entry is False claim no location -- their map entry is -1, which the
+    device assembly drops (include/asset_hip.h: asset_hip_defect_set_kkt_map)."""
     V = np.ascontiguousarray(vindex, dtype=np.int64)
     C = np.ascontiguousarray(cindex, dtype=np.int64)
     nappl, IR = V.shape
@@ -238,5 +255,17 @@ def kkt_slot_locations(vindex, cindex, n_primal: int, con_offset: int = 0):
         for j in range(OR):                         # J(j, i): row of the variable, column of the constraint
             keys[:, k] = vi * dim + (n_primal + con_offset + C[:, j])
             k += 1
-    uniq, inv = np.unique(keys.ravel(), return_inverse=True)
-    return inv.reshape(keys.shape), int(uniq.size)
+    if hess_mask is None:
+        uniq, inv = np.unique(keys.ravel(), return_inverse=True)
+        return inv.reshape(keys.shape), int(uniq.size)
+    keep = np.ones(keys.shape[1], dtype=bool)
+    k = 0
+    for i in range(IR):
+        for j in range(i, IR):
+            keep[k] = bool(hess_mask[j, i])
+            k += 1
+        k += OR
+    uniq, inv = np.unique(keys[:, keep].ravel(), return_inverse=True)
+    out = np.full(keys.shape, -1, dtype=np.int64)
+    out[:, keep] = inv.reshape(nappl, int(keep.sum()))
+    return out, int(uniq.size)

@@ -112,6 +112,7 @@ class Phase:
         self._obj_evs = []
         self._ipf_evs = {}        # k -> {"acc": evaluator, "int": evaluator}: addIntegralParamFunction
         self._auto_evs = {}       # "mesh_spacing", "nodal_spacing", "control_spline": evaluators the phase adds itself
+        self.EnableHessianSparsity = False   # Trapezoidal only (ODEPhase.h:43, TrapezoidalDefects.h:39): see hessian_mask()
         self.EnableMeshSpacing = True      # (the reference always adds them; the switch is for callers that only want the defects)
 
     # ---- configuration ---------------------------------------------------------------------
@@ -266,6 +267,15 @@ class Phase:
         self._integral_objs.append((integrand, xtuv, opv, spv))
         self._ev = None
         return len(self._integral_objs) - 1
+
+    def hessian_mask(self):
+        """``HessianElemIsNonZero`` of the phase's defects: None (every entry claims a KKT slot) unless the phase is
+        Trapezoidal with ``EnableHessianSparsity`` set (ODEPhase.h:43; TrapezoidalDefects.h:75-141) -- then the bool [IR, IR]
+        mask for ``indexing.kkt_slot_locations(..., hess_mask=)``, whose dropped slots the device assembly skips."""
+        if not self.EnableHessianSparsity or self.TranscriptionMode != "Trapezoidal":
+            return None
+        from .indexing import trapezoidal_hessian_mask
+        return trapezoidal_hessian_mask(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), self._blocked())
 
     def setStaticParams(self, params):
         """Static parameters of the phase: solver variables behind the trajectory and the ODE parameters that user functions may

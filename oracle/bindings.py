@@ -104,6 +104,8 @@ def lib(path=None):
         L.oracle_nlp_create.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int,
                                         C.c_int]
         L.oracle_nlp_create.restype = C.c_void_p
+        L.oracle_nlp_create_ex.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.oracle_nlp_create_ex.restype = C.c_void_p
         L.oracle_nlp_destroy.argtypes = [C.c_void_p]
         L.oracle_nlp_set_batch4.argtypes = [C.c_void_p, C.c_int]
         L.oracle_nlp_set_batch4.restype = C.c_int
@@ -240,15 +242,15 @@ def phase_defect_index(xv, uv, pv, spv, cs, nd, blocked, var_offset=0, con_offse
 
 
 class Nlp:
-    def __init__(self, ode, mode, blocked, vindex, cindex, primal, equal, threads=1):
+    def __init__(self, ode, mode, blocked, vindex, cindex, primal, equal, threads=1, hessian_sparsity=False):
         self.ode = ode
         self.vindex = np.ascontiguousarray(vindex, dtype=np.int32)
         self.cindex = np.ascontiguousarray(cindex, dtype=np.int32)
         self.nappl, self.ir = self.vindex.shape
         self.orr = self.cindex.shape[1]
         self.primal, self.equal = primal, equal
-        self.h = lib().oracle_nlp_create(C.byref(ode), mode, int(blocked), self.nappl, _i(self.vindex),
-                                         _i(self.cindex), primal, equal, threads)
+        self.h = lib().oracle_nlp_create_ex(C.byref(ode), mode, int(blocked), self.nappl, _i(self.vindex),
+                                            _i(self.cindex), primal, equal, threads, 1 if hessian_sparsity else 0)
         if not self.h:
             raise ValueError("oracle_nlp_create failed")
         self.kkt_dim = lib().oracle_nlp_kkt_dim(self.h)

@@ -93,6 +93,10 @@ struct oracle_nlp {
   bool batch4 = false;                      // oracle_nlp_set_batch4: LGL evalKKT processes four applications at a time
   int mode, blocked;
   int ir, orr, nkkt_per_appl;
+  // HessianElemIsNonZero (TrapezoidalDefects.h:124-130 with EnableHessianSparsity; all ones otherwise): [row + IR * col], and the
+  // number of claimed Hessian slots of block column i (rows j >= i)
+  std::vector<char> hess_nz;
+  std::vector<int> hess_count;
   int primal, equal, threads;
   int kktdim;
   std::vector<IndexData> thr;  // one slice per thread (thread_split)
@@ -109,13 +113,30 @@ struct oracle_nlp {
 
 namespace {
 
-int num_kkt_eles(int ir, int orr, bool dojac, bool dohess) {  // DenseFunctionBase.h:1070-1088 (all dense)
+int num_kkt_eles(const oracle_nlp* n, int ir, int orr, bool dojac, bool dohess) {  // DenseFunctionBase.h:1070-1088
   int e = 0;
   for (int i = 0; i < ir; i++) {
-    if (dohess) e += ir - i;
+    if (dohess) e += n->hess_count[i];
     if (dojac) e += orr;
   }
   return e;
+}
+
+// TrapezoidalDefects::setODE (TrapezoidalDefects.h:75-121): the structural non-zeros of the defect's adjoint Hessian -- the two
+// node blocks, everything that touches a parameter, the rows and columns of the two node times; i.e. every entry but the
+// cross-node block without its time rows / columns
+void trapezoidal_hessian_mask(oracle_nlp* n, int q, int p, int T) {
+  const int IR = n->ir;
+  std::fill(n->hess_nz.begin(), n->hess_nz.end(), 0);
+  auto set = [&](int r, int c) { n->hess_nz[r + (size_t)IR * c] = 1; };
+  for (int r = 0; r < q; r++)
+    for (int c = 0; c < q; c++) { set(r, c); set(q + r, q + c); }
+  for (int r = 0; r < p; r++)
+    for (int c = 0; c < p; c++) set(2 * q + r, 2 * q + c);
+  for (int j = 0; j < 2; j++)
+    for (int r = 0; r < q; r++)
+      for (int c = 0; c < p; c++) { set(j * q + r, 2 * q + c); set(2 * q + c, j * q + r); }
+  for (int k = 0; k < IR; k++) { set(k, T); set(k, T + q); set(T, k); set(T + q, k); }
 }
 
 // DenseFunctionBase::getKKTSpace, dojac = dohess = true
@@ -125,6 +146,7 @@ void get_kkt_space(oracle_nlp* n, IndexData& d, int& freeloc, int conoffset) {
     d.kkt_starts[V] = freeloc;
     for (int i = 0; i < d.ir; i++) {
       for (int j = i; j < d.ir; j++) {
+        if (!n->hess_nz[j + (size_t)d.ir * i]) continue;
         n->kkt_rows[freeloc] = d.VLoc(j, V);
         n->kkt_cols[freeloc] = d.VLoc(i, V);
         freeloc++;
@@ -214,7 +236,7 @@ void eval_slice(oracle_nlp* n, const IndexData& d, int what, const double* X, co
     const bool dohess = (what == ORACLE_JAC_ADJGRAD_HESS);
     if (blocks) {
       if (!kkt_blocks) return;
-      double* blk = kkt_blocks + a * n->nkkt_per_appl;
+      double* blk = kkt_blocks + a * (size_t)(IR * (IR + 1) / 2 + OR * IR);   // (blocks are always dense: the mask is the NLP's)
       int k = 0;
       for (int i = 0; i < IR; i++) {
         for (int j = i; j < IR; j++) blk[k++] = dohess ? hx[j + (size_t)i * IR] : 0.0;
@@ -230,10 +252,11 @@ void eval_slice(oracle_nlp* n, const IndexData& d, int what, const double* X, co
       if (dohess) {
         const int lk = n->clashes[var];
         if (lk >= 0) n->locks[lk].lock();
-        for (int j = i; j < IR; j++) kktvals[lpt[freeloc++]] += hx[j + (size_t)i * IR];
+        for (int j = i; j < IR; j++)
+          if (n->hess_nz[j + (size_t)IR * i]) kktvals[lpt[freeloc++]] += hx[j + (size_t)i * IR];   // AddHessianElem, TrapezoidalDefects.h:131-141
         if (lk >= 0) n->locks[lk].unlock();
       } else {
-        freeloc += IR - i;
+        freeloc += n->hess_count[i];
       }
       for (int j = 0; j < OR; j++) kktvals[lpt[freeloc++]] += jx[j + (size_t)i * OR];
     }
@@ -335,6 +358,12 @@ int oracle_phase_defect_index(int xv, int uv, int pv, int spv, int cs, int ndefe
 // ------------------------------------------------------------------------------------ NLP
 oracle_nlp* oracle_nlp_create(const oracle_ode* ode, int mode, int blocked, int nappl, const int* vindex,
                               const int* cindex, int primal_vars, int equal_cons, int threads) {
+  return oracle_nlp_create_ex(ode, mode, blocked, nappl, vindex, cindex, primal_vars, equal_cons, threads, 0);
+}
+
+// flags bit 0: EnableHessianSparsity of the Trapezoidal defects (TrapezoidalDefects.h:39, 124-141)
+oracle_nlp* oracle_nlp_create_ex(const oracle_ode* ode, int mode, int blocked, int nappl, const int* vindex,
+                                 const int* cindex, int primal_vars, int equal_cons, int threads, int flags) {
   int ir, orr;
   if (oracle_defect_sizes(mode, ode->xv, ode->uv, ode->pv, blocked, &ir, &orr)) return nullptr;
   oracle_nlp* n = new oracle_nlp;
@@ -342,7 +371,15 @@ oracle_nlp* oracle_nlp_create(const oracle_ode* ode, int mode, int blocked, int 
   n->mode = mode, n->blocked = blocked, n->ir = ir, n->orr = orr;
   n->primal = primal_vars, n->equal = equal_cons, n->threads = std::max(1, threads);
   n->kktdim = primal_vars + equal_cons;                                   // setMATDimensions (no slacks / inequalities)
-  n->nkkt_per_appl = num_kkt_eles(ir, orr, true, true);
+  n->hess_nz.assign((size_t)ir * ir, 1);
+  if ((flags & 1) && mode == ORACLE_TRAPEZOIDAL) {
+    const int nn = ode->xv, m = blocked ? 0 : ode->uv, p = blocked ? ode->uv + ode->pv : ode->pv;
+    trapezoidal_hessian_mask(n, nn + 1 + m, p, nn);
+  }
+  n->hess_count.assign(ir, 0);
+  for (int i = 0; i < ir; i++)
+    for (int j = i; j < ir; j++) n->hess_count[i] += n->hess_nz[j + (size_t)ir * i] ? 1 : 0;
+  n->nkkt_per_appl = num_kkt_eles(n, ir, orr, true, true);
   IndexData all;
   all.ir = ir, all.orr = orr, all.nappl = nappl;
   all.vindex.assign(vindex, vindex + (size_t)ir * nappl);

@@ -30,9 +30,9 @@ class Workload:
         self.L = synth.make_multipliers(self.n_equal, seed=seed + 1)
         self.NKKT = self.IR * (self.IR + 1) // 2 + self.OR * self.IR
 
-    def oracle_nlp(self, ob, threads: int = 1, provider: int = 0):
+    def oracle_nlp(self, ob, threads: int = 1, provider: int = 0, hessian_sparsity: bool = False):
         return ob.Nlp(ob.get_ode(self.ode, provider), ob.MODES[self.mode], self.blocked, self.vindex, self.cindex,
-                      self.n_primal, self.n_equal, threads)
+                      self.n_primal, self.n_equal, threads, hessian_sparsity=hessian_sparsity)
 
 
 def rel_err(a, b, floor=1.0):

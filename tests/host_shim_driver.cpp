@@ -11,6 +11,8 @@
 using namespace asset_hip_host;
 
 // 0: one handle on device 0; n > 0: the constraint as n in-process shards, all on device 0 (one GPU on the test box)
+static int g_hess_sparsity = 0;   // EnableHessianSparsity of the Trapezoidal defects (TrapezoidalDefects.h:39)
+extern "C" void shim_set_hessian_sparsity(int on) { g_hess_sparsity = on; }
 static int g_shards = 0;
 extern "C" void shim_set_shards(int n) { g_shards = n; }
 static std::unique_ptr<BatchedDefectConstraint> make_con(const char* ode, int mode, bool blocked, const SolverIndexingData& d, int primal, int equal) {
@@ -29,6 +31,7 @@ extern "C" int shim_run(const char* ode, int mode, int blocked, int ir, int orr,
     data.Cindex.assign(cindex, cindex + size_t(orr) * nappl);
     auto conp = make_con(ode, mode, blocked != 0, data, primal, equal);
     BatchedDefectConstraint& con = *conp;
+    con.EnableHessianSparsity(g_hess_sparsity != 0);
     if (g_shards > 0) {   // the split is the reference's (IndexingData.h:117-146)
       auto parts = data.thread_split(g_shards);
       int tot = 0;

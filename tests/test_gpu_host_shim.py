@@ -114,3 +114,41 @@ def test_kkt_assembly_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg)
             assert rel_err(AGX, rAGX) < 1e-8
         if what in (2, 3, 4):
             assert rel_err(vals, rvals) < 1e-8
+
+
+@pytest.mark.parametrize("ode,blocked,nseg", [("reentry", False, 11), ("twobody_lt", True, 9), ("betts_lowthrust", False, 7)])
+@pytest.mark.parametrize("device_assembly", [False, True])
+def test_trapezoidal_hessian_sparsity_mask(oracle, shim, ode, blocked, nseg, device_assembly):
+    """EnableHessianSparsity of the Trapezoidal defects (TrapezoidalDefects.h:39-141): the cross-node block of the adjoint Hessian
+    claims no KKT slots and the fill steps over it -- the shim's KKT space, CSR locations and values against the oracle's
+    restatement with the same switch, scattered on the host and assembled on the device."""
+    shim.shim_set_shards(0)
+    shim.shim_set_hessian_sparsity(1)
+    try:
+        w = Workload(ode, "Trapezoidal", nseg, blocked, var_offset=2, con_offset=1, extra_vars=3)
+        nlp = w.oracle_nlp(oracle, threads=1, hessian_sparsity=True)
+        dense = w.oracle_nlp(oracle, threads=1)
+        assert nlp.num_user_kkt < dense.num_user_kkt
+        locs = nlp.kkt_locations()
+        rows_ref, cols_ref = nlp.kkt_coords()
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        for what in (oracle.JAC_ADJGRAD_HESS, oracle.JAC_ADJGRAD):
+            FXE, AGX, vals = np.zeros(w.n_equal), np.zeros(w.n_primal), np.zeros(nlp.nnz)
+            rows = np.zeros(nlp.num_user_kkt, dtype=np.int32)
+            cols = np.zeros(nlp.num_user_kkt, dtype=np.int32)
+            err = C.create_string_buffer(512)
+            rc = shim.shim_run(ode.encode(), oracle.MODES["Trapezoidal"], int(w.blocked), w.IR, w.OR, w.nseg,
+                               w.vindex.ctypes.data_as(ip), w.cindex.ctypes.data_as(ip), w.n_primal, w.n_equal, what,
+                               w.X.ctypes.data_as(dp), w.L.ctypes.data_as(dp), locs.ctypes.data_as(ip),
+                               rows.ctypes.data_as(ip), cols.ctypes.data_as(ip), vals.ctypes.data_as(dp),
+                               FXE.ctypes.data_as(dp), AGX.ctypes.data_as(dp), err, 512,
+                               C.c_longlong(nlp.nnz if device_assembly else 0))
+            assert rc == 0, err.value
+            lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+            np.testing.assert_array_equal(hi, rows_ref[: nlp.num_user_kkt])
+            np.testing.assert_array_equal(lo, cols_ref[: nlp.num_user_kkt])
+            rFXE, rAGX, rvals = nlp.eval(what, w.X, w.L)
+            assert np.abs(FXE - rFXE).max() / max(1.0, np.abs(w.X).max()) < 1e-10
+            assert rel_err(AGX, rAGX) < 1e-8 and rel_err(vals, rvals) < 1e-8
+    finally:
+        shim.shim_set_hessian_sparsity(0)
