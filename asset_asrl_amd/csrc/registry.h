@@ -196,7 +196,16 @@ struct Registrar {
 // reported once on stderr.
 inline const char* tuning_env(const char* name) {
   static const bool on = [] { const char* v = std::getenv("ASSET_HIP_TUNING"); return v && std::atoi(v) != 0; }();
-  if (!on) return nullptr;
+  if (!on) {
+    // a knob that is set but not in effect: say so once, so that a measurement script which forgot the opt-in does not quote
+    // the default path under the knob's name
+    static bool warned = false;
+    if (!warned && std::getenv(name)) {
+      warned = true;
+      std::fprintf(stderr, "asset_hip: %s is set but IGNORED (dispatch knobs need ASSET_HIP_TUNING=1)\n", name);
+    }
+    return nullptr;
+  }
   const char* v = std::getenv(name);
   if (v) std::fprintf(stderr, "asset_hip: tuning knob %s=%s is in effect (ASSET_HIP_TUNING=1)\n", name, v);
   return v;

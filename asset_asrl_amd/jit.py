@@ -25,6 +25,7 @@ from .vf.codegen import emit_hip_functor, saved_nodes
 JIT_DIR = os.path.join(build.GEN, "jit")
 _MODE_CS = {"LGL3": 2, "LGL5": 3, "LGL7": 4}
 _loaded: set = set()
+_TOUCHED: set = set()     # cache files this process compiled or found (prune_unused drops the rest)
 _FUNCTORS: dict = {}        # device name of a plain function -> (functor struct name, its derivatives)
 # The build step (__graft_entry__.build) runs where there is no device: it compiles and caches the modules the test suite
 # will ask for and registers nothing.  Set through compile_only_mode().
@@ -134,6 +135,7 @@ def _build_and_load(name, hdr_name, hdr, tag, reg_line, mode_id, blocked, what, 
         opts = rtc_options()
         src = hdr + f'\n#include "{os.path.join(build.CSRC, "rtc_device.h")}"\n{rtc_line}\n'
         mod = os.path.join(wd, f"module_{tag}_{key_of(src, opts)}.rtc")
+        _TOUCHED.add(mod)
         copts = (C.c_char_p * len(opts))(*[o.encode() for o in opts])
         args = (src.encode(), functor.encode(), kind, cs_id, int(blocked), G, copts, len(opts), mod.encode())
         if compile_only:                    # (the build step, which has no device: compile and cache)
@@ -149,6 +151,7 @@ def _build_and_load(name, hdr_name, hdr, tag, reg_line, mode_id, blocked, what, 
         src = (f'#include "{hdr_name}"\n#include "{os.path.join(build.CSRC, "registry.h")}"\n' + reg_line
                + "\nASSET_PLUGIN_EXPORT()\n")
         so = os.path.join(wd, f"plugin_{tag}_{key_of(src, build.FLAGS)}.so")
+        _TOUCHED.add(so)
         if not os.path.exists(so):
             build._write_if_changed(os.path.join(wd, hdr_name), hdr)
             tu = os.path.join(wd, f"tu_{tag}.hip")
@@ -218,3 +221,30 @@ def ensure_bundle(dev_names, compile_only=None) -> str:
     flist = ", ".join(snames)
     return _build_and_load(name, "bundle.h", hdr, "bundle_0", "", _lib.FUNCTION, False, f"bundle of {len(dev_names)} functions",
                            rtc=(flist, 3, 0, 0, f"ASSET_RTC_BUNDLE({flist})"), compile_only=compile_only)
+
+
+def prune_unused(verbose: bool = False) -> int:
+    """Remove every entry of the in-tree module cache that this process has neither compiled nor found: the cache is keyed by
+    content, so code objects of older sources are never loaded again, but they travel with every snapshot of the tree.  Called by
+    ``__graft_entry__.build()`` after it has asked for everything the GPU tests use.  Returns the number of files removed."""
+    import shutil
+    removed = 0
+    if not os.path.isdir(JIT_DIR):
+        return 0
+    for d in sorted(os.listdir(JIT_DIR)):
+        wd = os.path.join(JIT_DIR, d)
+        if not os.path.isdir(wd):
+            continue
+        files = [os.path.join(wd, f) for f in os.listdir(wd)]
+        keep = [f for f in files if f in _TOUCHED]
+        if not keep:
+            removed += len(files)
+            shutil.rmtree(wd, ignore_errors=True)
+            continue
+        for f in files:
+            if f not in _TOUCHED and (f.endswith(".rtc") or (f.endswith(".so") and os.path.basename(f).startswith("plugin_"))):
+                os.remove(f)
+                removed += 1
+    if verbose:
+        print(f"[asset_hip] module cache: {removed} stale files removed, {len(_TOUCHED)} in use", flush=True)
+    return removed

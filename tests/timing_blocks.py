@@ -1,5 +1,5 @@
 """Times one workload's evaluation on the GPU and checks it against the oracle.
-usage: [ASSET_HIP_LIB=..] [ASSET_HIP_SKIP_DENSE=1] python tests/timing_blocks.py [ode mode nseg blocked what]"""
+usage: [ASSET_HIP_LIB=..] [ASSET_HIP_TUNING=1 ASSET_HIP_SKIP_DENSE=1] python tests/timing_blocks.py [ode mode nseg blocked what]"""
 import sys, os, numpy as np, torch
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives under tests/: it checks against the oracle)
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))

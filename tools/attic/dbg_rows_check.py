@@ -1,6 +1,6 @@
 """Which part of the blocks of the 32-state LGL7 shape differs from the tile kernel (ASSET_HIP_NO_ROWS=1 reference file)."""
 import sys, os, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from helpers import Workload
 from asset_asrl_amd.evaluator import DefectEvaluator

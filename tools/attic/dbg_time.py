@@ -2,10 +2,10 @@
 
   python tools/build_one.py tu_reentry_lgl4_0 build_dbg/libdbgT.so -DASSET_TIMING
   ASSET_HIP_LIB=build_dbg/libdbgT.so python tools/dbg_time.py 2048                      # dense stage (its grid)
-  ASSET_HIP_SKIP_DENSE=1 ASSET_HIP_LIB=build_dbg/libdbgT.so python tools/dbg_time.py 1024   # ODE stage
+  ASSET_HIP_TUNING=1 ASSET_HIP_SKIP_DENSE=1 ASSET_HIP_LIB=build_dbg/libdbgT.so python tools/dbg_time.py 1024   # ODE stage
 """
 import sys, os, numpy as np
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 from helpers import Workload
 from asset_asrl_amd.evaluator import *

@@ -1,6 +1,6 @@
 """Raw clock64() deltas of a -DASSET_TIMING build (workgroup 7, wave 0), as many as the kernel left: python tools/dbg_time_raw.py nseg ode mode blocked [share]"""
 import sys, os, numpy as np
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 from helpers import Workload
 from asset_asrl_amd.evaluator import *

@@ -4,7 +4,7 @@
   ASSET_HIP_LIB=build_dbg/rt/lib.so python tools/dbg_time_rows.py
 """
 import sys, os, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from helpers import Workload
 from asset_asrl_amd.evaluator import DefectEvaluator

@@ -1,10 +1,10 @@
 """Phase stamps (100 MHz wall clock) of every workgroup of the heavy-ODE unit kernels, from a -DASSET_WALLCLOCK build.
 
   python tools/build_one.py tu_betts_lowthrust_lgl3_0 build_dbg/uw/lib.so -DASSET_WALLCLOCK
-  ASSET_HIP_SKIP_DENSE=1 ASSET_HIP_LIB=build_dbg/uw/lib.so python tools/dbg_units_wall.py [nseg]
+  ASSET_HIP_TUNING=1 ASSET_HIP_SKIP_DENSE=1 ASSET_HIP_LIB=build_dbg/uw/lib.so python tools/dbg_units_wall.py [nseg]
 """
 import sys, os, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from helpers import Workload
 from asset_asrl_amd.evaluator import DefectEvaluator

@@ -9,7 +9,7 @@ for a in "reentry Trapezoidal 10000 0" "twobody_lt Trapezoidal 10000 1" "reentry
   python3 tools/quick_time.py $a 2>&1 | tail -1
 done | tee $O/times.log
 for a in "reentry Trapezoidal 10000 0" "twobody_lt Trapezoidal 10000 1"; do
-  ASSET_HIP_NO_RESIDENT=1 python3 tools/quick_time.py $a 2>&1 | tail -1 | sed 's/^/NO_RESIDENT /'
+  ASSET_HIP_TUNING=1 ASSET_HIP_NO_RESIDENT=1 python3 tools/quick_time.py $a 2>&1 | tail -1 | sed 's/^/NO_RESIDENT /'
   python3 tools/quick_time.py $a 2 2>&1 | tail -1
   python3 tools/quick_time.py $a 3 2>&1 | tail -1
 done | tee -a $O/times.log
