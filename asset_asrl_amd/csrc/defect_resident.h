@@ -139,6 +139,10 @@ struct ResDims {
 #endif
   static constexpr bool BSTORE = ASSET_RES_BSTORE;
   static constexpr int NWV = PAIR ? 2 : 1;                          // waves per workgroup
+#ifndef ASSET_RES_LOOP_PAIR
+#define ASSET_RES_LOOP_PAIR 1
+#endif
+  static constexpr bool LOOP_PAIR = ASSET_RES_LOOP_PAIR && ROWDPP;   // the looped level-2 kernel in two-wave workgroups too
   static constexpr int GR_PASS = 64 / (CS * NWV);                   // one pass per phase covers the workgroup's group
   static constexpr int GR = GR_FIT < GR_PASS ? GR_FIT : GR_PASS;
   static constexpr int REGION = D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA;   // a wave's LDS (doubles)
@@ -619,7 +623,7 @@ __device__ inline double row16_sum(double x) {
 // the blocks are written as zeros unless the caller says it never reads them (ASSET_HIP_KEEP_HESSIAN_SLOTS).
 // LOOP: meshes of more than GR segments per wave (a second instantiation: the one-group form is the north-star case and
 // loses 1 us to the loop's bookkeeping).
-template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM, bool LOOP, bool GIVEN = false>
+template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM, bool LOOP, bool GIVEN = false, bool LPAIR = false>
 __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using R = ResDims<D>;
@@ -632,7 +636,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   // (the pair form is the one-group kernel's: the looped instantiation keeps single-wave workgroups -- as a pair it ran 100 000
   //  Reentry-LGL7 segments 2.7 % faster, 328 against 337 us, but its TwoBody-LGL5-BlockConstant instantiation came out of the
   //  compiler wrong with the per-group opaque lane index and 25 % slower without it)
-  constexpr bool PAIR = R::PAIR && !GIVEN && !LOOP;
+  // (round 5: with the row-wise dense part the looped level-2 kernel exists as a pair as well -- LPAIR, ResDims::LOOP_PAIR: the launcher
+  //  takes it on the large meshes; the tile form's looped instantiations stay single waves)
+  static_assert(!LPAIR || (LOOP && R::LOOP_PAIR && LEVEL == 2 && !ASM && !GIVEN), "the looped pair form: row-wise dense part, level 2, blocks");
+  constexpr bool PAIR = R::PAIR && !GIVEN && (!LOOP || LPAIR);
   constexpr int NWV = PAIR ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int wv = PAIR ? __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6) : 0;   // this wave of the workgroup
@@ -954,7 +961,11 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     RTS();
     seg0 += gcount;
     o_seg0 += o_gcount;
-    wave_lds_sync();                   // (the next group's gather rewrites the slots)
+    // (the next group's gather rewrites the slots: in a pair BOTH waves must be through with this group's passes first -- without
+    //  the barrier wave 1 gathers group g + 1 into slots wave 0 still reads: wrong blocks from the third group on, 100 003 TwoBody
+    //  segments; very likely what round 4 saw as a "miscompiling" looped pair form of the tile kernel, whose group end has the
+    //  same wave-local wait)
+    pair_sync();
     continue;
   }
   // the per-lane record of the dense part (its loads fly while P3's LDS writes land; in a pair the wave that is not in the
@@ -1431,14 +1442,16 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #undef RTSG
 }
 
-template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false, bool LOOP = false, bool GIVEN = false>
-__global__ __launch_bounds__((!GIVEN && !LOOP && ResDims<Dims<Ode, SCH, BLOCKED>>::PAIR) ? 128 : 64, (ResDims<Dims<Ode, SCH, BLOCKED>>::WPS))
+template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false, bool LOOP = false, bool GIVEN = false, bool LPAIR = false>
+__global__ __launch_bounds__((!GIVEN && ResDims<Dims<Ode, SCH, BLOCKED>>::PAIR && (!LOOP || LPAIR)) ? 128 : 64, (ResDims<Dims<Ode, SCH, BLOCKED>>::WPS))
 void lgl_resident_kernel(EvalArgs a) {
 #if defined(ASSET_EXP_NULL)   // (experiment: the cost of the launch itself)
   if (a.nseg > 0) return;
 #endif
   using R = ResDims<Dims<Ode, SCH, BLOCKED>>;
-  if constexpr (GIVEN ? R::GIVEN_OK : R::OK) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN>(a);
+  if constexpr (LPAIR) {
+    if constexpr (R::OK && R::LOOP_PAIR) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN, true>(a);
+  } else if constexpr (GIVEN ? R::GIVEN_OK : R::OK) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN>(a);
 }
 
 }  // namespace asset_hip

@@ -28,6 +28,7 @@
 #pragma once
 #include "defect_dims.h"
 #include "defect_wide.h"
+#include "defect_rowdpp.h"
 #include <utility>
 
 namespace asset_hip {
@@ -251,19 +252,20 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
     // ---- the row blocks of this wave
     // (row preparation: the lane-independent operands H^_i, g^_i, SB_i as lane-distributed registers + v_readlane -- entry e of a
     //  list in lane e % 64 of register e / 64; as LDS broadcasts the compiler issues them far ahead and spills the accumulators)
-    constexpr int NHV = (NZH + 63) / 64, NFV = (NZJ + 63) / 64, NTV = (IR + 63) / 64;
-    double Hv[K][NHV], gv[K], SBv[K], Fv[CS][NFV];
+    // (round 5) the lane-independent operands sixteen to a register, entry e in lane e % 16 of EVERY 16-lane row, and broadcast
+    // inside the FMA: v_fmac_f64_dpp row_newbcast (defect_rowdpp.h: fmac_bc) -- where rounds 3-4 read them with a v_readlane pair
+    // and a hazard s_nop per use.  They are loaded where they are used (a node's dfdy_j list ahead of its columns, an interior's
+    // H^_i / g^_i / SB_i lists ahead of its products): five to eight registers live at a time.
+    constexpr int NH16 = (NZH + 15) / 16, NF16 = (NZJ + 15) / 16, NG16 = (N + 15) / 16, NS16 = (n + 15) / 16;
+    const int l16 = lane & 15;
+    auto load_F = [&](double (&Fr)[NF16], int j) {
 #pragma unroll
-    for (int j = 0; j < CS; j++)
+      for (int t = 0; t < NF16; t++) Fr[t] = ws[D::w_CJ + j * NZJ + 16 * t + l16];     // (past the list: the next section's entries, never broadcast)
+    };
+    auto load_S = [&](double (&sr)[NS16], int i) {
 #pragma unroll
-      for (int t = 0; t < NFV; t++) Fv[j][t] = (64 * t + lane < NZJ) ? ws[D::w_CJ + j * NZJ + 64 * t + lane] : 0.0;
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-#pragma unroll
-      for (int t = 0; t < NHV; t++) Hv[i][t] = (LEVEL >= 2 && 64 * t + lane < NZH) ? ws[D::w_IH + i * NZH + 64 * t + lane] : 0.0;
-      gv[i] = (lane < N) ? ws[D::w_Ig + i * N + lane] : 0.0;
-      SBv[i] = (lane < n) ? L[R::o_SB + i * n + lane] : 0.0;
-    }
+      for (int t = 0; t < NS16; t++) sr[t] = L[R::o_SB + i * n + 16 * t + l16];
+    };
     double Mi[K][N];                                                // H blocks: M_i[:, r]
     double TX = 0.0, HTr = 0.0;
     int hitem = -1;                                                 // (a wave owns at most one H block: NHB <= WAVES)
@@ -281,7 +283,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       const bool pblock = p > 0 && R::RB * it + R::RB > P0;          // (uniform) the block holds parameter rows
       const double tsr = !rv ? 0.0 : ((r == T) ? -1.0 : ((r == TF) ? 1.0 : 0.0));
       const lds_double* const fcol = L + R::o_Fd + (jn * N + ccr) * LDK;   // the row's own column of dfdy (read where used: registers)
-      double ht = 0.0, tok = 0.0;
+      double ht = 0.0;
 #pragma unroll
       for (int i = 0; i < K; i++) {
         double d[N];
@@ -301,24 +303,33 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
           for (int pb = 0; pb < p; pb++) d[q + pb] = (par && ccr == q + pb) ? 1.0 : 0.0;
         }
         if ((R::RB * it <= T && T < R::RB * it + R::RB) || (R::RB * it <= TF && TF < R::RB * it + R::RB)) {   // a time row: -+ sum_j B_ij f_j on it
-          static_for<n>([&](auto KK) { constexpr int k = decltype(KK)::value; d[k] = fma(tsr, lane_value_at<k>(SBv[i], tok), d[k]); tok = d[k]; });
+          double sr[NS16];
+          load_S(sr, i);
+          static_for<n>([&](auto KK) { constexpr int k = decltype(KK)::value; fmac_bc<(k & 15)>(d[k], sr[k >> 4], tsr); });
         }
         d[T] = !rv ? 0.0 : ((r == T) ? 1.0 - ctab.s[i] : ((r == TF) ? ctab.s[i] : 0.0));   // (T, TF < P0: never a parameter row)
 #pragma unroll
         for (int cc = n + 1; cc < q; cc++) d[cc] = (!par && ccr == cc) ? ur : 0.0;
-        static_for<N>([&](auto BB) { constexpr int b = decltype(BB)::value; ht = fma(ctab.E[i] * lane_value_at<b>(gv[i], tok), d[b], ht); tok = ht; });
+        {
+          double gr[NG16], hti[2] = {0.0, 0.0};                     // (two partial sums: a dependent v_fmac_f64 issues every 9 cycles)
+#pragma unroll
+          for (int t = 0; t < NG16; t++) gr[t] = ws[D::w_Ig + i * N + 16 * t + l16];
+          static_for<N>([&](auto BB) { constexpr int b = decltype(BB)::value; fmac_bc<(b & 15)>(hti[b & 1], gr[b >> 4], d[b]); });
+          ht = fma(ctab.E[i], hti[0] + hti[1], ht);
+        }
         if constexpr (LEVEL >= 2) {
 #pragma unroll
         for (int b = 0; b < N; b++) Mi[i][b] = 0.0;
+        double Hr[NH16];
+#pragma unroll
+        for (int t = 0; t < NH16; t++) Hr[t] = ws[D::w_IH + i * NZH + 16 * t + l16];
         static_for<N*(N + 1) / 2>([&](auto E) {
           constexpr int e = decltype(E)::value;
           constexpr int hp = Ode::HPOS[e];
           if constexpr (hp >= 0) {
             constexpr int b = NZ::v.ha[hp], l = NZ::v.hb[hp];
-            const double u = lane_value_at<(hp & 63)>(Hv[i][hp >> 6], tok);   // (the token: the FMA before, in program order)
-            Mi[i][b] = fma(u, d[l], Mi[i][b]);
-            tok = Mi[i][b];
-            if constexpr (b != l) { Mi[i][l] = fma(u, d[b], Mi[i][l]); tok = Mi[i][l]; }
+            fmac_bc<(hp & 15)>(Mi[i][b], Hr[hp >> 4], d[l]);
+            if constexpr (b != l) fmac_bc<(hp & 15)>(Mi[i][l], Hr[hp >> 4], d[b]);
           }
         });
         const double he = h * ctab.E[i];
@@ -340,8 +351,12 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       }
       if constexpr (LEVEL >= 2) {
 #pragma unroll
-      for (int i = 0; i < K; i++)
-        static_for<n>([&](auto KK) { constexpr int k = decltype(KK)::value; TX = fma(lane_value_at<k>(SBv[i], TX), Mi[i][k], TX); });
+      for (int i = 0; i < K; i++) {
+        double sr[NS16], txp[2] = {0.0, 0.0};
+        load_S(sr, i);
+        static_for<n>([&](auto KK) { constexpr int k = decltype(KK)::value; fmac_bc<(k & 15)>(txp[k & 1], sr[k >> 4], Mi[i][k]); });
+        TX += txp[0] + txp[1];
+      }
       }
       if (a.AGX && a.L && rv) {
         double wl = 0.0;
@@ -366,9 +381,6 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
     RWTS();
     wg_lds_barrier();                                               // HT complete
     RWTS();
-    double HTv[NTV];
-#pragma unroll
-    for (int t = 0; t < NTV; t++) HTv[t] = (LEVEL >= 2 && 64 * t + lane < IR) ? L[R::o_HT + 64 * t + lane] : 0.0;
 
     typedef __attribute__((ext_vector_type(2))) unsigned int u2;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(kkt, 0, int(D::NKKT * 8), 0x00020000);
@@ -404,11 +416,33 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       double hcur = L[hbase];                                       // H_j[cc][ccr] of the column ahead: requested one column early
       // the block row (j N + cc) of the dense arrays that block column c reads: node columns (j, cc), parameter columns (0, q + pc)
       auto brow = [](int c) constexpr { return c < P0 ? (c / q) * N + (c % q) : q + (c - P0); };
+      double Fr[NF16], htr = 0.0;                                   // the node's dfdy_j list; HTpar of sixteen columns
+      // BM_j[k] = h sum_i B_ij M_i[k], formed when the loop reaches node j: a column of the node is then ONE FMA per structural entry
+      // of its dfdy column instead of K (and K more to combine them) -- K n FMAs per node bought, ~ 2 K nnz(dfdy_j) saved
+      // -- OFF: its n doubles are the registers the kernel does not have (512 of 512 and 340 bytes of scratch per lane instead of 482
+      // and none; a scratch reload behind block stores waits for them all: 12 500 32-state segments 1.78 ms against 1.08 ms)
+#ifndef ASSET_ROWS_NODE_BM
+#define ASSET_ROWS_NODE_BM 0
+#endif
+      double BMn[ASSET_ROWS_NODE_BM ? n : 1];
       static_for<IR>([&](auto Ct) {
         constexpr int c = decltype(Ct)::value;
         constexpr bool pcol = c >= P0;                              // a parameter column (segment parameters)
         constexpr int j = pcol ? 0 : c / q, cc = pcol ? q + (c - P0) : c % q, CC = cc;
         if (c <= rmax) {                                            // (uniform)
+          if constexpr ((c & 15) == 0) htr = L[R::o_HT + c + l16];
+          if constexpr (cc == 0 && !pcol) {
+            load_F(Fr, j);
+            if constexpr (ASSET_ROWS_NODE_BM) {
+              static_for<n>([&](auto KK) {
+                constexpr int k = decltype(KK)::value;
+                double b = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; i++) b = fma(ctab.B[i][j], Mi[i][k], b);
+                BMn[k] = h * b;
+              });
+            }
+          }
           if constexpr (cc == 0 || c == P0) {                       // a new node (or the parameter columns)
             r = rv ? r0 : -1;                                       // (opaque per node: the row >= column masks are formed where they
             asm volatile("" : "+v"(r));                             //  are used, not all of them ahead of the loop)
@@ -423,18 +457,32 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
           }
           // h sum_i B_ij (dfdy_j[:, cc] . M_i); a parameter column: summed over the nodes
           double acc = 0.0;
+          if constexpr (ASSET_ROWS_NODE_BM && !pcol) {
+            double a2[2] = {0.0, 0.0};
+            int cnt = 0;
+            static_for<n>([&](auto KK) {
+              constexpr int k = decltype(KK)::value;
+              constexpr int jp = Ode::JPOS[k * N + CC];
+              if constexpr (jp >= 0) { fmac_bc<(jp & 15)>(a2[cnt & 1], Fr[jp >> 4], BMn[k]); cnt++; }
+            });
+            val += a2[0] + a2[1];
+          } else
           static_for<(pcol ? CS : 1)>([&](auto Jt) {
             constexpr int jj = pcol ? decltype(Jt)::value : j;
             double acci[K];
 #pragma unroll
             for (int i = 0; i < K; i++) acci[i] = 0.0;
+            double Fp[pcol ? NF16 : 1];
+            if constexpr (pcol) load_F(Fp, jj);
             static_for<n>([&](auto KK) {
               constexpr int k = decltype(KK)::value;
               constexpr int jp = Ode::JPOS[k * N + CC];
               if constexpr (jp >= 0) {
-                const double f = lane_value_at<(jp & 63)>(Fv[jj][jp >> 6], acci[K - 1]);
-#pragma unroll
-                for (int i = 0; i < K; i++) acci[i] = fma(f, Mi[i][k], acci[i]);
+                static_for<K>([&](auto II) {
+                  constexpr int i = decltype(II)::value;
+                  if constexpr (pcol) fmac_bc<(jp & 15)>(acci[i], Fp[jp >> 4], Mi[i][k]);
+                  else fmac_bc<(jp & 15)>(acci[i], Fr[jp >> 4], Mi[i][k]);
+                });
               }
             });
 #pragma unroll
@@ -443,7 +491,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
           val = fma(h, acc, val);
           if constexpr (c == T) val -= txh;
           if constexpr (c == TF) val += txh;
-          val = fma(tsrow, lane_value_at<(c & 63)>(HTv[c >> 6], val), val);
+          fmac_bc<(c & 15)>(val, htr, tsrow);
           const double hc = hcur;
           if constexpr (c + 1 < IR) hcur = L[hbase + brow(c + 1) * LDH];
           if constexpr (!pcol) val = fma(indj, hc, val);
@@ -491,10 +539,14 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       asm volatile("" : "+v"(fbase));
       double fcur = L[fbase];                                       // dfdy_j[r][cc] of the column ahead
       auto brow = [](int c) constexpr { return c < P0 ? (c / q) * N + (c % q) : q + (c - P0); };   // (as for the H blocks)
+      double Fr[NF16];
       static_for<IR>([&](auto Ct) {
         constexpr int c = decltype(Ct)::value;
         constexpr bool pcol = c >= P0;
         constexpr int j = pcol ? 0 : c / q, cc = pcol ? q + (c - P0) : c % q, CC = cc;
+        if constexpr (cc == 0 && !pcol) {
+          if (JH == 1 || (c + q > cfirst && c < clast)) load_F(Fr, j);   // (uniform: the node has columns in this wave's range)
+        }
         if constexpr (cc == 0) {                                    // (opaque per node: [cc == r] is formed where it is used)
           ro = r;
           asm volatile("" : "+v"(ro));
@@ -507,10 +559,15 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
         static_for<(pcol ? CS : 1)>([&](auto Jt) {                  // (a parameter column: summed over the nodes)
           constexpr int jj = pcol ? decltype(Jt)::value : j;
           double a1 = 0.0;
+          double Fp[pcol ? NF16 : 1];
+          if constexpr (pcol) load_F(Fp, jj);
           static_for<n>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
             constexpr int jp = Ode::JPOS[k * N + CC];
-            if constexpr (jp >= 0) a1 = fma(lane_value_at<(jp & 63)>(Fv[jj][jp >> 6], a1), jrow[k], a1);
+            if constexpr (jp >= 0) {
+              if constexpr (pcol) fmac_bc<(jp & 15)>(a1, Fp[jp >> 4], jrow[k]);
+              else fmac_bc<(jp & 15)>(a1, Fr[jp >> 4], jrow[k]);
+            }
           });
           acc = fma(Bl[jj], a1, acc);
           if constexpr (pcol && jj > 0) fdd = fma(h * Dl[jj], L[fbase + (jj * N + cc) * LDK], fdd);

@@ -35,6 +35,7 @@ enum MetaField {
   MF_RESD_GR,                                       // ... its dense part alone behind the unit kernels of a heavy ODE (0: none)
   MF_ROWS_LDS_BYTES,                                // wide shapes, dense stage by output rows (defect_rows.h): its LDS (0: none)
   MF_RES_NWV,                                       // resident kernel: waves per workgroup (2: the pair form, ResDims::PAIR)
+  MF_RES_LOOP_NWV,                                  // ... of its looped level-2 block kernel (2 with the row-wise dense part)
   MF_COUNT
 };
 
@@ -66,7 +67,7 @@ struct LglMeta {
       AdjDims<D>::GP, (long long)AdjDims<D>::lds_bytes(),
       ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>(),
       ResDims<D>::WPS, ResDims<D>::GIVEN_OK ? ResDims<D>::GR : 0,
-      RowsDims<D>::OK ? (long long)RowsDims<D>::lds_bytes() : 0, ResDims<D>::NWV};
+      RowsDims<D>::OK ? (long long)RowsDims<D>::lds_bytes() : 0, ResDims<D>::NWV, ResDims<D>::LOOP_PAIR ? 2 : 1};
 };
 
 template <class F>

@@ -127,7 +127,8 @@ constexpr int K_UNITSJ = 57;   // heavy right-hand sides, Jacobian kinds: the un
 constexpr int K_ROWS = 58;     // wide shapes: dense stage by output rows, no matrix instructions (defect_rows.h)
 constexpr int K_ROWS1 = 59;    // ... the Jacobian kinds
 constexpr int K_UNITS4 = 60;   // heavy right-hand sides: interior and cardinal units in one launch (defect_units.h, PHASE 4)
-constexpr int K_COUNT = 61;
+constexpr int K_RESLP = 61;   // resident kernel, looped, level 2, blocks, as two-wave workgroups (row-wise dense part: defect_rowdpp.h)
+constexpr int K_COUNT = 62;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -302,9 +303,14 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         const KRef& kr = one ? t.k[K_RES(a.kmap != nullptr)] : t.k[K_RESL(2, a.kmap != nullptr)];
         if (kr && (one || env_max <= 0 || (a.nseg + waves - 1) / waves <= env_max * int(m[MF_RES_GR])))
         {
-          const int nwv = (one && m[MF_RES_NWV] > 1) ? 2 : 1, nw = a.nseg < waves ? a.nseg : waves;
+          // two-wave workgroups: the one-group kernel of a pair shape -- and, on meshes of four or more groups per wave, the looped block
+          // kernel of the shapes with the row-wise dense part (TwoBody-LGL5-BlockConstant: 100 000 segments 244 -> 220 us as pairs, but
+          // 30 000 -- two groups per wave -- 65 -> 76 us: the pair's barriers cost what the shared ODE stage saves until the waves drift)
+          const bool lpair = !one && !a.kmap && m[MF_RES_LOOP_NWV] > 1 && t.k[K_RESLP] &&
+                             (a.nseg + waves - 1) / waves >= 4 * int(m[MF_RES_GR]);
+          const int nwv = ((one && m[MF_RES_NWV] > 1) || lpair) ? 2 : 1, nw = a.nseg < waves ? a.nseg : waves;
           const size_t lds = size_t(m[MF_RES_LDS_BYTES]) / size_t(m[MF_RES_NWV] > 1 ? 2 : 1) * size_t(nwv);
-          return klaunch(kr, dim3((nw + nwv - 1) / nwv), dim3(64 * nwv), lds, st, kargs);
+          return klaunch(lpair ? t.k[K_RESLP] : kr, dim3((nw + nwv - 1) / nwv), dim3(64 * nwv), lds, st, kargs);
         }
       }
       if (m[MF_FUSED]) {
@@ -468,6 +474,7 @@ const KernelTable* lgl_static_table() {
         r.k[K_RESL(1, false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, false, true>);
         r.k[K_RESL(1, true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, true, true>);
         r.k[K_RES_SETUP].host = ASSET_KPTR(res_lane_setup_kernel<Ode, SCH, BLOCKED>);
+        if constexpr (ResDims<D>::LOOP_PAIR) r.k[K_RESLP].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, false, true, false, true>);
       }
       if constexpr (ResDims<D>::GIVEN_OK) {
         r.k[K_RESD(false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, false, true, true>);
@@ -562,6 +569,7 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
   for (int lv = 1; lv <= 2; lv++)
     for (int as = 0; as <= 1; as++)
       if (slot == K_RESL(lv, as != 0)) return "asset_hip::lgl_resident_kernel<" + lgl + ", " + std::to_string(lv) + ", " + tf(as != 0) + ", true>";
+  if (slot == K_RESLP) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, false, true, false, true>";
   if (slot == K_RESD(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, false, true, true>";
   if (slot == K_RESD(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, true, true, true>";
   if (slot == K_RES_SETUP) return "asset_hip::res_lane_setup_kernel<" + lgl + ">";
