@@ -266,7 +266,7 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
   for (int k = 0; k < D::p; k++) y[q + k] = z[D::P0 + k];
 #pragma unroll
   for (int k = 0; k < n; k++) li[k] = have_lam ? lam[i * n + k] : 0.0;
-  if constexpr (ResDims<D>::ROWDPP && LEVEL == 2) {   // FB_i[k] = sum_j B_ij f_j[k]: the time rows of the row-wise dense part (defect_rowdpp.h)
+  if constexpr (ResDims<D>::ROWDPP && LEVEL >= 1) {   // FB_i[k] = sum_j B_ij f_j[k]: the time rows of the row-wise dense part (defect_rowdpp.h)
 #pragma unroll
     for (int k = 0; k < n; k++) {
       double acc = 0.0;
@@ -942,7 +942,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #endif
   }   // (!GIVEN)
   RTS();
-  if constexpr (R::ROWDPP && LEVEL == 2 && !ASM && !GIVEN) {
+  if constexpr (R::ROWDPP && LEVEL >= 1 && !ASM && !GIVEN) {
     // ------------------------------------------------------------------ dense part by output rows (defect_rowdpp.h): the workgroup's
     // (segment, row group) tasks in passes of four, dealt to the two waves alternately
     pair_sync();                       // (the last ODE phase's results, for both waves)
@@ -952,7 +952,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     if (gc1 > 0) { seg_lo = min(seg_lo, sg1); seg_hi = max(seg_hi, sg1 + gc1); }
     const unsigned int* const rectab = static_cast<const unsigned int*>(a.lane_consts_res) +
                                        size_t(blockIdx.x % ASSET_LANE_REPLICAS) * size_t(res_table_words<Ode, D>()) + res_table_words_tile<Ode, D>();
-    rowdpp_dense<Ode, D, R::s_Z0, R::s_FB>(a, (const lds_double*)tabL, rectab, gall, seg_lo, seg_hi, wv, NWV, lane,
+    rowdpp_dense<Ode, D, R::s_Z0, R::s_FB, LEVEL>(a, (const lds_double*)tabL, rectab, gall, seg_lo, seg_hi, wv, NWV, lane,
                                            [&](int g) -> const lds_double* { return pslot(g); }, pseg
 #if defined(ASSET_TIMING)
                                            , tstamp, &nts

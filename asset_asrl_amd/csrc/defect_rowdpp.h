@@ -149,7 +149,7 @@ __device__ void rd_lane_setup(unsigned int* out, int rec) {
 // ---------------------------------------------------------------------------------------------------------------- the passes
 // Ctx: what the kernel hands over -- the workgroup's segments (slot pointer and mesh segment of group member g), the LDS copy of
 // the weight tables, the outputs.
-template <class Ode, class D, int SLOTZERO, int S_FB, class PSlot, class PSeg>
+template <class Ode, class D, int SLOTZERO, int S_FB, int LEVEL, class PSlot, class PSeg>
 __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double* tabL, const unsigned int* rectab, int gall, int seg_lo,
                                             int seg_hi, int wv, int nwv, int lane, PSlot pslot, PSeg pseg, long long* tsp = nullptr, int* ntsp = nullptr) {
 #define RDTS() do { if (tsp && *ntsp < 24) tsp[(*ntsp)++] = clock64(); } while (0)
@@ -196,7 +196,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
   union RecH { typename X::LaneH h; unsigned int w[X::NQH * 4]; __device__ RecH() {} };
   const int hsub = rs / RG, rg = rs - hsub * RG;
   RecH rec;
-  {
+  if constexpr (LEVEL >= 2) {
     const u4* src = reinterpret_cast<const u4*>(rectab) + (16 * rg + lr);
 #pragma unroll
     for (int k = 0; k < X::NQH; k++) {
@@ -213,6 +213,15 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
     const lds_double* const S = pslot(g);
     const lds_double* const Sl = S + lr;
     const unsigned kb = rv ? unsigned((pseg(g) - seg_lo) * (NKKT * 8) + 8 * r) : INVALID;   // slot (r, c) at kb + 8 (colstart(c) - c)
+    if constexpr (LEVEL < 2) {
+      // the Jacobian kinds (evalSOE / evalAUG): the Hessian slots hold zeros -- unless the caller never reads them
+      // (ASSET_HIP_KEEP_HESSIAN_SLOTS: the pass is not run at all, below)
+      rd_for<IR>([&](auto CC) {
+        constexpr int c = decltype(CC)::value;
+        bst(rs_kkt, (c <= r) ? kb : INVALID, 8 * (X::colstart(c) - c), 0.0);
+      });
+      return;
+    }
     const typename X::LaneH& L = rec.h;
     const double h = S[S_FB + K * n];                  // (t_f - t_0, left there by the interior phase)
     const double rh = 1.0 / h;
@@ -559,11 +568,11 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
   // the workgroup's passes in segment order -- the H passes of four segments, then their C pass(es) -- each to the wave with less to do
   // so far (cost: the instructions of a pass, tools/isa_count.py); both waves walk the same list
   int load0 = 0, load1 = 0, hp = 0, cp = 0;
-  const int nHP = (gall + SPP - 1) / SPP, nCP = (gall + SPC - 1) / SPC;
+  const int nHP = (LEVEL < 2 && (a.flags & 1)) ? 0 : (gall + SPP - 1) / SPP, nCP = (gall + SPC - 1) / SPC;
   while (hp < nHP || cp < nCP) {
     const bool isH = hp < nHP && (cp >= nCP || SPP * hp < SPC * (cp + 1));     // H passes up to the segments of the next C pass first
     const int w = (nwv > 1 && load1 < load0) ? 1 : 0;
-    (w ? load1 : load0) += isH ? 640 : 540;
+    (w ? load1 : load0) += isH ? (LEVEL >= 2 ? 640 : 40) : 540;
     if (w == wv) {
       RDTS();
       if (isH) hpass(hp); else cpass(cp);
