@@ -237,7 +237,10 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_value(ld
 }
 
 // P2: interior point i: x^, tau, u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
-template <class Ode, class D, int LEVEL = 2>
+// HALF >= 0 (round 5, pair workgroups, LEVEL 2): this wave emits only one of the two halves of the outputs (Ode::fjgh_half<HALF>: the
+// generated bodies partition {J[:, k], g[k], H[i >= k, k]} by input direction in two sets of about equal cost) -- the pair's other wave
+// evaluates the same points for the other half at the same time, on another SIMD: the phase is 700 instructions deep instead of 930
+template <class Ode, class D, int LEVEL = 2, int HALF = -1>
 __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_double* S, int i, const LglTab* tabp, bool have_lam) {
   constexpr int n = D::n, m = D::m, q = D::q, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
@@ -266,7 +269,7 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
   for (int k = 0; k < D::p; k++) y[q + k] = z[D::P0 + k];
 #pragma unroll
   for (int k = 0; k < n; k++) li[k] = have_lam ? lam[i * n + k] : 0.0;
-  if constexpr (ResDims<D>::ROWDPP && LEVEL >= 1) {   // FB_i[k] = sum_j B_ij f_j[k]: the time rows of the row-wise dense part (defect_rowdpp.h)
+  if constexpr (ResDims<D>::ROWDPP && LEVEL >= 1 && HALF <= 0) {   // FB_i[k] = sum_j B_ij f_j[k]: the time rows of the row-wise dense part (defect_rowdpp.h)
 #pragma unroll
     for (int k = 0; k < n; k++) {
       double acc = 0.0;
@@ -287,12 +290,13 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
     for (int b = 0; b < N; b++) S[D::w_Ig + i * N + b] = out.gacc_[b];
   } else {
     OdeOutRes<D> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH, nullptr};
-    Ode::fjgh(in, out);
+    if constexpr (HALF >= 0) Ode::template fjgh_half<HALF>(in, out);
+    else Ode::fjgh(in, out);
   }
 }
 
 // P3: cardinal node j: adjoint weights w_j (LGLDefects.h:369-374) ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f
-template <class Ode, class D>
+template <class Ode, class D, int HALF = -1>
 __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(lds_double* S, int j, const LglTab* tabp) {
   constexpr int K = D::K, n = D::n, N = D::N, T = D::T;
   using R = ResDims<D>;
@@ -313,10 +317,16 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(l
   double sv[Ode::NSAVE > 0 ? Ode::NSAVE : 1];      // (read before g_j is written: the two may share their cells)
 #pragma unroll
   for (int k = 0; k < Ode::NSAVE; k++) sv[k] = S[R::s_SV + j * R::SV_LD + k];
-  wave_lds_order();
+  if constexpr (HALF >= 0) {
+    // both waves of the pair are in this phase, for the same points: the saved values may share their cells with g_j (SV_ALIAS), which
+    // the OTHER wave writes too -- every read of them, in both waves, comes first (both waves have the same lanes active here, so
+    // both reach the barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  } else wave_lds_order();
   CardInRes<D> in{z, w, sv, j};
   OdeOutRes<D> out{nullptr, S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
-  Ode::fjgh_load(in, out);
+  if constexpr (HALF >= 0) Ode::template fjgh_load_half<HALF>(in, out);
+  else Ode::fjgh_load(in, out);
 }
 
 // Trapezoidal, all derivatives (TrapezoidalDefects.h:263-435): there is no interior point, so the adjoint weights of the
@@ -922,8 +932,22 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   }
   pair_sync();
   RTS();
+  // HALVED (round 5, OFF): in a pair BOTH waves run the interior phase and the cardinal second-derivative phase, each for one half of the
+  // outputs (res_interior / res_cardinal_second, HALF) -- instead of one wave running the phase while its partner waits at the barrier.
+  // Built, parity-green, and slower: Reentry-LGL7 x 10 000 29.9-30.2 against 28.8-28.9 us, x 5 000 21.9 / 20.6.  The halves recompute what
+  // they share (2 x 700 instructions for 930), and the wave that used to wait shared its SIMD with ANOTHER workgroup's phase: the
+  // ODE stage is bound by what a SIMD issues, which the pair form had already halved, not by the depth of one wave's chain.
+#ifndef ASSET_RES_HALVES
+#define ASSET_RES_HALVES 0
+#endif
+  constexpr bool HALVED = ASSET_RES_HALVES && PAIR && LEVEL >= 2 && Ode::HALVES == 2;
   if constexpr (!D::TRAP) {
-    if (roleB && pj < K && pg < gall) {   // P2
+    if constexpr (HALVED) {
+      if (pj < K && pg < gall) {          // P2, both waves
+        if (roleB) res_interior<Ode, D, LEVEL, 0>(pslot(pg), pj, &tab, a.L != nullptr);
+        else res_interior<Ode, D, LEVEL, 1>(pslot(pg), pj, &tab, a.L != nullptr);
+      }
+    } else if (roleB && pj < K && pg < gall) {   // P2
       const int g = pg, i = pj;
       res_interior<Ode, D, LEVEL>(pslot(g), i, &tab, a.L != nullptr);
     }
@@ -931,7 +955,12 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   }
   RTS();
   if constexpr (LEVEL >= 2) {
-    if (roleA && pj < CS && pg < gall) {  // P3
+    if constexpr (HALVED) {
+      if (pj < CS && pg < gall) {         // P3, both waves
+        if (roleA) res_cardinal_second<Ode, D, 0>(pslot(pg), pj, &tab);
+        else res_cardinal_second<Ode, D, 1>(pslot(pg), pj, &tab);
+      }
+    } else if (roleA && pj < CS && pg < gall) {  // P3
       const int g = pg, j = pj;
       res_cardinal_second<Ode, D>(pslot(g), j, &tab);
     }

@@ -23,8 +23,10 @@
 // For a fixed block column the lanes' rows are contiguous in the reference's slot order (DenseFunctionBase.h:1112-1123): a row
 // group stores 128 contiguous bytes per column.  Lanes above the diagonal carry an out-of-range buffer offset.
 //
-// Counted on the ISA of Reentry-LGL7 (tools/isa_count.py): an H pass of four row groups is ~ 600 vector instructions, a C pass
-// ~ 530 -- 370 per segment where the tile form issues 500 per segment AND 33 matrix instructions of 64 cycles each.
+// Counted on the ISA of Reentry-LGL7 (tools/isa_count.py): an H pass (the lower triangles of two segments) is ~ 1 000 vector
+// instructions, 473 of them v_fmac_f64_dpp; a C pass (the Jacobian and gradient rows of four segments) ~ 1 000 with 456: ~ 800 per
+// segment, no matrix instruction -- the tile form issues 500 per segment AND 33 matrix instructions of 64 cycles each.  Which shapes
+// take which form is decided by measurement (ResDims::RD_SHAPE).
 #pragma once
 #include <utility>
 

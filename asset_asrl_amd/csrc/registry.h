@@ -189,7 +189,7 @@ struct Registrar {
 
 // ---- the launcher ---------------------------------------------------------------------------------------------------
 #ifndef ASSET_UNITS_ONE_LAUNCH_ROUNDS
-#define ASSET_UNITS_ONE_LAUNCH_ROUNDS 1000   // heavy ODEs: the one-launch unit stage up to this many rounds of the SIMDs -- measured faster at every size
+#define ASSET_UNITS_ONE_LAUNCH_ROUNDS 1000   // heavy ODEs: the one-launch unit stage ALWAYS (the limit, in rounds of the SIMDs, is beyond every mesh) -- measured faster at every size
                                             // tried (Betts-LGL5 x 1 000: 30.3 against 41.5 us, x 10 000: 191.7 / 200.0; Betts-LGL7 x 5 000: 145.1 / 151.1)
 #endif
 // Dispatch knobs of the measurement scripts (tools/): read ONLY when the process opts in with ASSET_HIP_TUNING=1, so that a
@@ -347,7 +347,8 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         const long long wgs4 = (long long)((a.nseg + gp4 - 1) / gp4) * 2 * nunits;
         const bool one_launch = t.k[K_UNITS4] && (units1 >= 0 ? units1 != 0 : wgs4 <= (long long)(ASSET_UNITS_ONE_LAUNCH_ROUNDS * 4) * cus);
         if (one_launch) {
-          // XCD-aware placement: workgroups go to the eight XCDs round robin in launch order (x fastest), so with the number of
+          // XCD-aware placement (MI355X: 8 XCDs; on a part with another count the mapping below is still a valid split of the work --
+          // it only stops coinciding with the L2s): workgroups go to the eight XCDs round robin in launch order (x fastest), so with the number of
           // groups padded to a multiple of eight every unit of group g runs on XCD g % 8 -- its slot is assembled in ONE L2 (no
           // 32-byte sector written back half-filled by several of them) -- and the dense part reads it there (units_gp below)
           const size_t bytes4 = size_t(m[MF_UNITS_BASE_BYTES]) + size_t(gp4) * size_t(m[MF_UNITS_SLOT_BYTES]);

@@ -481,10 +481,18 @@ class Phase:
         # adaptive mesh loop, ODEPhaseBase.cpp:1443-1542
         key = (name, self.TranscriptionMode, self._blocked(), self.device)
         kept = self._ev_kept
+        self._ev = None
         if kept is not None and kept[0] == key and kept[1]._h:
-            self._ev = kept[1].rebind(V, Cx, ix.numPhaseVars, self.numPhaseEqCons)
-        else:
-            if kept is not None:
+            # NOTE the aliasing: the kept evaluator is re-pointed IN PLACE -- a reference handed out earlier through ``phase.evaluator``
+            # (a pre-refinement evaluator kept for comparison, a handle given to an adapter) now evaluates the NEW mesh and has lost its
+            # KKT map, per-application constants and pinned outputs.  A handle that cannot be re-bound (it is a member of a function
+            # bundle: EINVAL) or a failed re-bind gets a fresh evaluator instead; the old object is left to its holders.
+            try:
+                self._ev = kept[1].rebind(V, Cx, ix.numPhaseVars, self.numPhaseEqCons)
+            except Exception:
+                self._ev_kept = None
+        if self._ev is None:
+            if kept is not None and self._ev_kept is not None:
                 kept[1].close()
             self._ev = DefectEvaluator(name, self.TranscriptionMode, self._blocked(), V, Cx, ix.numPhaseVars,
                                        self.numPhaseEqCons, self.device)

@@ -478,10 +478,25 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
         # evaluates a cardinal unit forms it itself instead of waiting for the interior units of a launch before
         # (csrc/defect_units.h, PHASE 4)
         body("gx", [(f"out.g({i}, {{}});", d.g[i]) for i in range(n)], q=UNIT_QUAL, level_order=UNIT_LEVEL_ORDER)
+    # ---- halves (round 5): the level-2 outputs of a body that is NOT split into units, in two sets of about equal cost -- by input
+    #      direction, like the units: {J[:, k], g[k], H[i >= k, k]}, the value outputs with the first set; each half recomputes the
+    #      forward values it needs.  The two waves of a pair workgroup run the halves of an ODE phase side by side (csrc/
+    #      defect_resident.h): the interior phase of the resident kernel is a lone wave's chain of ~ 930 instructions otherwise, the
+    #      cardinal second-derivative phase one of ~ 510, and nothing can be stored before they end.
+    halves = None if units else plan_halves(d, outputs(2))
+    o.append(f"  static constexpr int HALVES = {2 if halves else 1};   // bodies fjgh_half<H> / fjgh_load_half<H> (1: none)")
     if split:
         two_parts("fjgh", False)
     else:
         body("fjgh", outputs(2))
+    if halves:
+        for hx, outs_h in enumerate(halves):
+            body(f"fjgh_half{hx}_", outs_h)
+            body(f"fjgh_load_half{hx}_", outs_h, use_saved=True)
+        for nm in ("fjgh_half", "fjgh_load_half"):
+            o.append(f"  template <int H, class In, class Out> __host__ __device__ static inline void {nm}(const In& in, Out& out) {{")
+            o.append(f"    if constexpr (H == 0) {nm}0_(in, out); else {nm}1_(in, out);")
+            o.append("  }")
     # ---- f_save / fjgh_load: the value pass stores every transcendental sub-expression of f; the second-derivative
     #      pass at the SAME point (cardinal nodes: LGLDefects.h:336 then :383-384) loads them instead of recomputing
     body("f_save", outputs(0), extra_roots=saved, extra_stmt="out.save({}, {});")
@@ -494,6 +509,40 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
 
 
 MAX_UNITS = 8
+
+
+def plan_halves(d: OdeDerivatives, outs):
+    """The level-2 outputs ([(statement format, root)] in outputs(2) order) in two sets of about equal operation count: columns
+    {J[:, k], g[k], H[i >= k, k]} dealt, heaviest first, to the set whose cost grows less; f goes with the first set.  None when a
+    set would come out empty (tiny bodies)."""
+    N, n = d.nin, d.xv
+    f_outs = outs[:n]
+    j_outs = outs[n:n + n * N]
+    g_outs = outs[n + n * N:n + n * N + N]
+    h_outs = outs[n + n * N + N:]
+    hpos, e = {}, 0
+    for i in range(N):
+        for j in range(i + 1):
+            hpos[(i, j)] = e
+            e += 1
+
+    def cost(group):
+        return sum(1 for x in topo_order(lower_reciprocals([r for _, r in group])) if x.args)
+
+    cols = []
+    for k in range(N):
+        grp = [j_outs[r * N + k] for r in range(n)] + [g_outs[k]] + [h_outs[hpos[(i, k)]] for i in range(k, N)]
+        cols.append((cost(grp), k, grp))
+    A, B = list(f_outs), []
+    for c, k, grp in sorted(cols, key=lambda t: (-t[0], t[1])):
+        ca, cb = cost(A + grp), cost(B + grp)
+        if (ca, len(A)) <= (cb, len(B)):
+            A = A + grp
+        else:
+            B = B + grp
+    if len(B) == 0 or cost(B) * 4 < cost(A):
+        return None
+    return [A, B]
 
 
 def plan_units(d: OdeDerivatives, outs) -> List[list]:
