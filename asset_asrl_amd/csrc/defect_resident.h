@@ -117,7 +117,8 @@ struct ResDims {
   static constexpr int x_WL = x_CL + CS * n;       // [CS][n]  sum_i D_ij lam_(i,r)
   static constexpr int x_Z4 = x_WL + CS * n;       // four zeros (a weight row of the lanes without a defect row)
   static constexpr int x_T = x_Z4 + 4;             // (T_XTRA) [K][16][n] the J^ buffers of the ride + 16 dummy cells
-  static constexpr int XTRA = x_T + (T_XTRA ? K * TB + 16 : 0);
+  static constexpr int x_FLAG = x_T + (T_XTRA ? K * TB + 16 : 0);   // (EARLYC) the group whose cardinal second derivatives wave A has finished
+  static constexpr int XTRA = x_FLAG + 2;
   // waves per SIMD the kernel is built for (registers: 512 / WPS per lane; LDS: 160 KiB / 4 WPS per wave).  Shapes with two
   // row tiles of defect rows keep two more accumulators and a third column tile's fragments: at 256 registers they spill
   // 650 bytes per lane (TwoBody-LGL7 x 10 000: 149.5 us), with the SIMD to themselves they do not (89.1 us; round 2's kernel 102.7)
@@ -143,6 +144,13 @@ struct ResDims {
 #define ASSET_RES_LOOP_PAIR 1
 #endif
   static constexpr bool LOOP_PAIR = ASSET_RES_LOOP_PAIR && ROWDPP;   // the looped level-2 kernel in two-wave workgroups too
+  // EARLYC (round 5): the cardinal value phase also leaves the Jacobians J_j in the slot (Ode::fj_save), so that the rows of [J ; g^T]
+  // -- the C passes of the row-wise dense part, 45 % of a segment's bytes -- are formed and stored by one wave of the pair WHILE the
+  // other runs the cardinal second-derivative phase: the stores start one phase earlier.
+#ifndef ASSET_RES_EARLYC
+#define ASSET_RES_EARLYC 1
+#endif
+  static constexpr bool EARLYC = ASSET_RES_EARLYC && ROWDPP && PAIR;
   static constexpr int GR_PASS = 64 / (CS * NWV);                   // one pass per phase covers the workgroup's group
   static constexpr int GR = GR_FIT < GR_PASS ? GR_FIT : GR_PASS;
   static constexpr int REGION = D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA;   // a wave's LDS (doubles)
@@ -222,17 +230,18 @@ struct GatherRun {   // y = X[first index of the segment + j q + i]: index rows 
 // P1: f_j and its transcendental sub-expressions at cardinal node j (reads the solver vector itself: its loads overlap P0's);
 // vi == nullptr: the segment's inputs are the run of X that starts at Xs
 // (LEVEL 1, the Jacobian kinds: f_j and J_j, nothing saved -- there is no second cardinal phase)
-template <class Ode, class D, int LEVEL = 2>
+// (WITHJ, level 2: f_j, J_j and the saved values -- Ode::fj_save, ResDims::EARLYC)
+template <class Ode, class D, int LEVEL = 2, bool WITHJ = false>
 __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_value(lds_double* S, int j, const double* Xs, const int* vi) {
   using R = ResDims<D>;
-  OdeOutRes<D> out{S + D::w_Cf + j * D::n, LEVEL == 1 ? S + D::w_CJ + j * D::NZJ : nullptr, nullptr, nullptr,
+  OdeOutRes<D> out{S + D::w_Cf + j * D::n, (LEVEL == 1 || WITHJ) ? S + D::w_CJ + j * D::NZJ : nullptr, nullptr, nullptr,
                    LEVEL == 1 ? nullptr : S + R::s_SV + j * R::SV_LD};
   if (vi) {
     GatherIn<D> in{Xs, vi, j};
-    if constexpr (LEVEL == 1) Ode::fj(in, out); else Ode::f_save(in, out);
+    if constexpr (LEVEL == 1) Ode::fj(in, out); else if constexpr (WITHJ) Ode::fj_save(in, out); else Ode::f_save(in, out);
   } else {
     GatherRun<D> in{Xs, j};
-    if constexpr (LEVEL == 1) Ode::fj(in, out); else Ode::f_save(in, out);
+    if constexpr (LEVEL == 1) Ode::fj(in, out); else if constexpr (WITHJ) Ode::fj_save(in, out); else Ode::f_save(in, out);
   }
 }
 
@@ -296,7 +305,8 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
 }
 
 // P3: cardinal node j: adjoint weights w_j (LGLDefects.h:369-374) ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f
-template <class Ode, class D, int HALF = -1>
+// (NOJ: J_j is in the slot already -- EARLYC -- and the partner wave is reading it: not stored again)
+template <class Ode, class D, int HALF = -1, bool NOJ = false>
 __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(lds_double* S, int j, const LglTab* tabp) {
   constexpr int K = D::K, n = D::n, N = D::N, T = D::T;
   using R = ResDims<D>;
@@ -324,7 +334,7 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(l
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   } else wave_lds_order();
   CardInRes<D> in{z, w, sv, j};
-  OdeOutRes<D> out{nullptr, S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
+  OdeOutRes<D> out{nullptr, NOJ ? nullptr : S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
   if constexpr (HALF >= 0) Ode::template fjgh_load_half<HALF>(in, out);
   else Ode::fjgh_load(in, out);
 }
@@ -790,6 +800,12 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     for (int r = ROWS / 4 * 4; r < ROWS; r++) lds_dma_row(dst + r * 256, src, lane * 4 + r * 256);
     if (TAIL > 0 && lane < TAIL) lds_dma_row(dst + ROWS * 256, src, lane * 4 + ROWS * 256);
   };
+  // (the one-group kernel only: in the looped pair form the waves meet at a barrier per group and wave B, with all the C passes of a group,
+  //  is the longer one every time -- TwoBody-LGL5-BlockConstant x 1 000 000: 2.53 ms with it, 2.07 ms without)
+  constexpr bool EARLYC = R::EARLYC && PAIR && !LOOP && LEVEL == 2 && !ASM && !GIVEN && !D::TRAP;
+  unsigned int rd_rec[R::ROWDPP ? RdDims<Ode, D>::NQH * 4 : 1];       // the row record of the row-wise dense part (defect_rowdpp.h)
+  const unsigned int* const rd_rectab = static_cast<const unsigned int*>(a.lane_consts_res) +
+                                        size_t(blockIdx.x % ASSET_LANE_REPLICAS) * size_t(res_table_words<Ode, D>()) + res_table_words_tile<Ode, D>();
   ResRecord<LCT> lrec;
   auto load_record = [&]() {
     typedef __attribute__((ext_vector_type(4))) unsigned int u4;
@@ -899,6 +915,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       }
       if (lane < GR) tb[D::TABSZ + lane * SLOT + R::s_Z0] = 0.0;
       if (lane < 4) xt[R::x_Z4 + lane] = 0.0;
+      if (grp == 0 && lane == 0) xt[R::x_FLAG] = 0.0;
     }
 #pragma unroll
     for (int t = 0; t < NZ; t++) {
@@ -927,8 +944,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   } else {
   if (roleA && pj < CS && pg < gall) { // P1 (reads X itself, writes f_j and the saved values: nothing of P0's)
     const int g = pg, j = pj;
-    if (a.affine && D::p == 0) res_cardinal_value<Ode, D, LEVEL>(pslot(g), j, a.X + (a.aff_v0 + pseg(g) * a.aff_vs), nullptr);
-    else res_cardinal_value<Ode, D, LEVEL>(pslot(g), j, a.X, a.vindex + size_t(pseg(g)) * IR);
+    if (a.affine && D::p == 0) res_cardinal_value<Ode, D, LEVEL, EARLYC>(pslot(g), j, a.X + (a.aff_v0 + pseg(g) * a.aff_vs), nullptr);
+    else res_cardinal_value<Ode, D, LEVEL, EARLYC>(pslot(g), j, a.X, a.vindex + size_t(pseg(g)) * IR);
   }
   pair_sync();
   RTS();
@@ -940,7 +957,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #ifndef ASSET_RES_HALVES
 #define ASSET_RES_HALVES 0
 #endif
-  constexpr bool HALVED = ASSET_RES_HALVES && PAIR && LEVEL >= 2 && Ode::HALVES == 2;
+  constexpr bool HALVED = ASSET_RES_HALVES && PAIR && LEVEL >= 2 && Ode::HALVES == 2 && !EARLYC;
   if constexpr (!D::TRAP) {
     if constexpr (HALVED) {
       if (pj < K && pg < gall) {          // P2, both waves
@@ -960,6 +977,21 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         if (roleA) res_cardinal_second<Ode, D, 0>(pslot(pg), pj, &tab);
         else res_cardinal_second<Ode, D, 1>(pslot(pg), pj, &tab);
       }
+    } else if constexpr (EARLYC) {
+      // P3 by wave A -- and meanwhile wave B forms and stores the rows of [J ; g^T] of the whole group (defect_rowdpp.h, MODE 1)
+      if (roleA) {
+        if (pj < CS && pg < gall) res_cardinal_second<Ode, D, -1, true>(pslot(pg), pj, &tab);
+        // ... and says so -- a flag in wave 0's region, not a barrier: wave A goes on to its H passes, wave B looks at the flag when
+        // its C passes are done (LDS instructions of a wave execute in issue order: whoever sees the flag sees the phase's results)
+        wave_lds_sync();
+        if (lane == 0) *reinterpret_cast<volatile lds_double*>(region0 + D::TABSZ + GR * SLOT + R::x_FLAG) = double(grp + 1);
+      } else {
+        int slo = 0x7fffffff, shi = 0;
+        if (gc0 > 0) { slo = min(slo, sg0); shi = max(shi, sg0 + gc0); }
+        if (gc1 > 0) { slo = min(slo, sg1); shi = max(shi, sg1 + gc1); }
+        rowdpp_dense<Ode, D, R::s_Z0, R::s_FB, LEVEL, 1>(a, (const lds_double*)tabL, rd_rectab, gall, slo, shi, wv, NWV, lane,
+                                                      [&](int g) -> const lds_double* { return pslot(g); }, pseg, rd_rec);
+      }
     } else if (roleA && pj < CS && pg < gall) {  // P3
       const int g = pg, j = pj;
       res_cardinal_second<Ode, D>(pslot(g), j, &tab);
@@ -974,19 +1006,35 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   if constexpr (R::ROWDPP && LEVEL >= 1 && !ASM && !GIVEN) {
     // ------------------------------------------------------------------ dense part by output rows (defect_rowdpp.h): the workgroup's
     // (segment, row group) tasks in passes of four, dealt to the two waves alternately
-    pair_sync();                       // (the last ODE phase's results, for both waves)
+    if constexpr (EARLYC) {
+      if (!roleA) {                    // wave B: the cardinal second derivatives of the group are in the slots?
+        volatile lds_double* const flag = reinterpret_cast<volatile lds_double*>(region0 + D::TABSZ + GR * SLOT + R::x_FLAG);
+        while (*flag != double(grp + 1)) __builtin_amdgcn_s_sleep(2);
+      }
+    } else pair_sync();                // (the last ODE phase's results, for both waves)
     RTS();
     int seg_lo = 0x7fffffff, seg_hi = 0;
     if (gc0 > 0) { seg_lo = min(seg_lo, sg0); seg_hi = max(seg_hi, sg0 + gc0); }
     if (gc1 > 0) { seg_lo = min(seg_lo, sg1); seg_hi = max(seg_hi, sg1 + gc1); }
-    const unsigned int* const rectab = static_cast<const unsigned int*>(a.lane_consts_res) +
-                                       size_t(blockIdx.x % ASSET_LANE_REPLICAS) * size_t(res_table_words<Ode, D>()) + res_table_words_tile<Ode, D>();
-    rowdpp_dense<Ode, D, R::s_Z0, R::s_FB, LEVEL>(a, (const lds_double*)tabL, rectab, gall, seg_lo, seg_hi, wv, NWV, lane,
-                                           [&](int g) -> const lds_double* { return pslot(g); }, pseg
+    if constexpr (EARLYC) {
+      // (wave B has stored the C passes -- nCP x 540 instructions -- while wave A ran the cardinal second-derivative phase, ~ 550)
+      const int nCP = (gall + (4 / (RdDims<Ode, D>::CRG > 0 ? RdDims<Ode, D>::CRG : 1) > 0 ? 4 / RdDims<Ode, D>::CRG : 1) - 1) /
+                      (4 / RdDims<Ode, D>::CRG > 0 ? 4 / RdDims<Ode, D>::CRG : 1);
+      const int lB = nCP * 540, lA = 550;   // (weights 900 / 370 -- wave A four H passes of five instead of three -- measured the same at 10 000 Reentry segments and slower at 5 000)
+      rowdpp_dense<Ode, D, R::s_Z0, R::s_FB, LEVEL, 2>(a, (const lds_double*)tabL, rd_rectab, gall, seg_lo, seg_hi, wv, NWV, lane,
+                                                    [&](int g) -> const lds_double* { return pslot(g); }, pseg, rd_rec, /*have_rec=*/!roleA,
+                                                    wa == 0 ? lA : lB, wa == 0 ? lB : lA
 #if defined(ASSET_TIMING)
-                                           , tstamp, &nts
+                                                    , tstamp, &nts
 #endif
-                                           );
+                                                    );
+    } else
+    rowdpp_dense<Ode, D, R::s_Z0, R::s_FB, LEVEL>(a, (const lds_double*)tabL, rd_rectab, gall, seg_lo, seg_hi, wv, NWV, lane,
+                                                  [&](int g) -> const lds_double* { return pslot(g); }, pseg, rd_rec, false, 0, 0
+#if defined(ASSET_TIMING)
+                                                  , tstamp, &nts
+#endif
+                                                  );
     RTS();
     seg0 += gcount;
     o_seg0 += o_gcount;

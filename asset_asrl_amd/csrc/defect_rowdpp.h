@@ -151,9 +151,16 @@ __device__ void rd_lane_setup(unsigned int* out, int rec) {
 // ---------------------------------------------------------------------------------------------------------------- the passes
 // Ctx: what the kernel hands over -- the workgroup's segments (slot pointer and mesh segment of group member g), the LDS copy of
 // the weight tables, the outputs.
-template <class Ode, class D, int SLOTZERO, int S_FB, int LEVEL, class PSlot, class PSeg>
+// MODE 0: every pass of the workgroup's group, dealt between its waves.  MODE 1 / 2 (ResDims::EARLYC, pair workgroups): the C passes
+// alone -- ALL of them, by the calling wave, while its partner is still in the cardinal second-derivative phase, which the rows of
+// [J ; g^T] need nothing of -- and later the H passes alone, dealt with what each wave has done by then counted in (load0 / load1).
+// `recw`: the calling wave's row record; MODE 1 loads it ahead of its first store for the H passes that follow, MODE 2 loads it when
+// `have_rec` is false.
+template <class Ode, class D, int SLOTZERO, int S_FB, int LEVEL, int MODE = 0, class PSlot, class PSeg>
 __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double* tabL, const unsigned int* rectab, int gall, int seg_lo,
-                                            int seg_hi, int wv, int nwv, int lane, PSlot pslot, PSeg pseg, long long* tsp = nullptr, int* ntsp = nullptr) {
+                                            int seg_hi, int wv, int nwv, int lane, PSlot pslot, PSeg pseg,
+                                            unsigned int (&recw)[RdDims<Ode, D>::NQH * 4], bool have_rec = false, int load0 = 0, int load1 = 0,
+                                            long long* tsp = nullptr, int* ntsp = nullptr) {
 #define RDTS() do { if (tsp && *ntsp < 24) tsp[(*ntsp)++] = clock64(); } while (0)
   using X = RdDims<Ode, D>;
   constexpr int K = X::K, CS = X::CS, n = X::n, q = X::q, N = X::N, T = X::T, TF = X::TF, IR = X::IR, OR = X::OR, P0 = X::P0, p = X::p;
@@ -195,17 +202,16 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
   // that the partially written lines of its block columns meet in the L2 instead of going to memory half filled.
   constexpr int SPP = 4 / RG > 0 ? 4 / RG : 1, SPC = 4 / CRG > 0 ? 4 / CRG : 1;
   static_assert(RG <= 4 && CRG <= 4, "a segment's row groups fit one pass");
-  union RecH { typename X::LaneH h; unsigned int w[X::NQH * 4]; __device__ RecH() {} };
   const int hsub = rs / RG, rg = rs - hsub * RG;
-  RecH rec;
-  if constexpr (LEVEL >= 2) {
+  if (LEVEL >= 2 && !(MODE == 2 && have_rec)) {
     const u4* src = reinterpret_cast<const u4*>(rectab) + (16 * rg + lr);
 #pragma unroll
     for (int k = 0; k < X::NQH; k++) {
       const u4 v = src[k * X::NRECH];
-      rec.w[4 * k] = v.x, rec.w[4 * k + 1] = v.y, rec.w[4 * k + 2] = v.z, rec.w[4 * k + 3] = v.w;
+      recw[4 * k] = v.x, recw[4 * k + 1] = v.y, recw[4 * k + 2] = v.z, recw[4 * k + 3] = v.w;
     }
   }
+  const typename X::LaneH& recL = *reinterpret_cast<const typename X::LaneH*>(recw);
   auto hpass = [&](const int pl) __attribute__((always_inline)) {
     const int g0 = SPP * pl + hsub;
     const bool tv = hsub < SPP && g0 < gall;
@@ -224,7 +230,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       });
       return;
     }
-    const typename X::LaneH& L = rec.h;
+    const typename X::LaneH& L = recL;
     const double h = S[S_FB + K * n];                  // (t_f - t_0, left there by the interior phase)
     const double rh = 1.0 / h;
 
@@ -505,6 +511,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
     const double w_t0 = (tms - tm1) - fb, w_tf = tm1 + fb;
     RdOps<D::w_CJ, D::w_CJ + CS * NZJ> cj;
     cj.load(Sl);
+    const unsigned gbd = isG ? unsigned(srel * (IR * 8)) : INVALID;
     lds_double* const agx_z = const_cast<lds_double*>(S) + D::w_z;
     lds_double* const agx_dummy = const_cast<lds_double*>(S) + D::w_lam + (lr < OR ? lr : 0);
     auto col_init = [&](auto CC) -> double {
@@ -553,11 +560,12 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
         bst(rs_kkt, kb, 8 * (X::colstart(c) - c), acc[decltype(Bx)::value]);
         // the gradient row's entry: into the segment's z section (dead: this pass has read it), the other lanes into lam cells of
         // their own (dead as well) -- one coalesced store per sixteen entries below instead of a store of four lanes per column
-        *(isG ? agx_z + c : agx_dummy) = acc[decltype(Bx)::value];
+        if constexpr (MODE == 1) bst(rs_agx, gbd, 8 * c, acc[decltype(Bx)::value]);   // (the partner's phase still reads z and lam: no staging there)
+        else *(isG ? agx_z + c : agx_dummy) = acc[decltype(Bx)::value];
       });
     });
     wave_lds_order();
-    {
+    if constexpr (MODE != 1) {
       // (the row slot that holds the segment's gradient row -- crg of row OR -- stores it; with CRG > 1 the other slots of the segment sit out)
       const bool gslot = tv && (OR / 16) == crg;
       const unsigned gb2 = gslot ? unsigned(srel * (IR * 8) + 8 * lr) : INVALID;
@@ -567,19 +575,34 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
     }
   };
 
-  // the workgroup's passes in segment order -- the H passes of four segments, then their C pass(es) -- each to the wave with less to do
-  // so far (cost: the instructions of a pass, tools/isa_count.py); both waves walk the same list
-  int load0 = 0, load1 = 0, hp = 0, cp = 0;
   const int nHP = (LEVEL < 2 && (a.flags & 1)) ? 0 : (gall + SPP - 1) / SPP, nCP = (gall + SPC - 1) / SPC;
-  while (hp < nHP || cp < nCP) {
-    const bool isH = hp < nHP && (cp >= nCP || SPP * hp < SPC * (cp + 1));     // H passes up to the segments of the next C pass first
-    const int w = (nwv > 1 && load1 < load0) ? 1 : 0;
-    (w ? load1 : load0) += isH ? (LEVEL >= 2 ? 640 : 40) : 540;
-    if (w == wv) {
+  if constexpr (MODE == 1) {
+    for (int cp = 0; cp < nCP; cp++) {
       RDTS();
-      if (isH) hpass(hp); else cpass(cp);
+      cpass(cp);
     }
-    if (isH) hp++; else cp++;
+  } else if constexpr (MODE == 2) {
+    for (int hp = 0; hp < nHP; hp++) {
+      const int w = (nwv > 1 && load1 < load0) ? 1 : 0;
+      (w ? load1 : load0) += 640;
+      if (w != wv) continue;
+      RDTS();
+      hpass(hp);
+    }
+  } else {
+    // the workgroup's passes in segment order -- the H passes of four segments, then their C pass(es) -- each to the wave with less to do
+    // so far (cost: the instructions of a pass, tools/isa_count.py); both waves walk the same list
+    int hp = 0, cp = 0;
+    while (hp < nHP || cp < nCP) {
+      const bool isH = hp < nHP && (cp >= nCP || SPP * hp < SPC * (cp + 1));     // H passes up to the segments of the next C pass first
+      const int w = (nwv > 1 && load1 < load0) ? 1 : 0;
+      (w ? load1 : load0) += isH ? (LEVEL >= 2 ? 640 : 40) : 540;
+      if (w == wv) {
+        RDTS();
+        if (isH) hpass(hp); else cpass(cp);
+      }
+      if (isH) hp++; else cp++;
+    }
   }
   RDTS();
 #undef RDTS

@@ -500,6 +500,9 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     # ---- f_save / fjgh_load: the value pass stores every transcendental sub-expression of f; the second-derivative
     #      pass at the SAME point (cardinal nodes: LGLDefects.h:336 then :383-384) loads them instead of recomputing
     body("f_save", outputs(0), extra_roots=saved, extra_stmt="out.save({}, {});")
+    # (round 5) ... and the Jacobian with it: the cardinal value phase of the resident kernel then leaves J_j in the slot, and the rows
+    # of [J ; g^T] -- which need nothing of the cardinal second-derivative phase -- can be formed and stored while that phase runs
+    body("fj_save", outputs(1), extra_roots=saved, extra_stmt="out.save({}, {});")
     if split:
         two_parts("fjgh_load", True)
     else:
