@@ -477,7 +477,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("lgl_defect_kernel (ODE stage) + lgl_rows_kernel (dense stage by output rows; LGL3: lgl_wide_dense_kernel)" if IR >= 64 else
-                                    "lgl_resident_kernel (one launch, ODE results resident in LDS) for the narrow LGL shapes; otherwise "
+                                    "lgl_resident_kernel (one launch, ODE results resident in LDS; dense part as matrix-instruction tiles, or by "
+                                    "output rows with DPP-broadcast operands for the shapes the tiles would pad: defect_rowdpp.h) for the narrow LGL shapes; otherwise "
                                     "lgl_defect_kernel (fused launch, or ODE-stage + dense-stage launches; ODE stage in units for heavy ODEs)")
                                    + "; rank 0's share, all launches of one evaluation timed",
                          "launch_ms": ms_roof, "launch_ms_source": ("HIP events around the K timed steps / K" if ms_roof is ms_timed_region
