@@ -26,7 +26,7 @@
 // ASSET_WALLCLOCK, ASSET_FUNC_TIMING) and elimination experiments that compute WRONG results on purpose (ASSET_EXP_*).  A
 // production build that defines one of them -- through ASSET_HIP_JIT flags or a build environment -- is refused.
 #if (defined(ASSET_TIMING) || defined(ASSET_WALLCLOCK) || defined(ASSET_FUNC_TIMING) || defined(ASSET_EXP_NOWS) ||       \
-     defined(ASSET_EXP_NULL) || defined(ASSET_EXP_ODEREP) || defined(ASSET_EXP_ONEUNIT) || defined(ASSET_EXP_UNITREP) || defined(ASSET_EXP_ROWS)) && \
+     defined(ASSET_EXP_NULL) || defined(ASSET_EXP_ODEREP) || defined(ASSET_EXP_ONEUNIT) || defined(ASSET_EXP_UNITREP) || defined(ASSET_EXP_ROWS) || defined(ASSET_EXP_RDALIGN)) && \
     !defined(ASSET_TUNING_BUILD)
 #error "ASSET_TIMING / ASSET_WALLCLOCK / ASSET_EXP_* change what the kernels write: measurement builds only (-DASSET_TUNING_BUILD)"
 #endif

@@ -43,10 +43,18 @@ struct ResDims {
   static constexpr int s_Z0 = D::WSLOTD;
   static constexpr int s_SV = SV_ALIAS ? D::w_Cg : D::WSLOTD + 1;
   static constexpr int SV_LD = SV_ALIAS ? N : Ode::NSAVE;
+  // (round 5) shapes that take the row-wise dense part (RD_SHAPE, below) are built for two waves per SIMD whatever their number of row
+  // tiles: that part needs ~ 250 registers at any width.  Their ASSEMBLED kinds, which keep the tile form, would spill at 256 registers
+  // (650 bytes per lane, TwoBody-LGL7) and go to the fused / two-launch kernels instead (ASM_OK, MF_RES_ASM).
+#ifndef ASSET_RES_ROWDPP
+#define ASSET_RES_ROWDPP 1
+#endif
+  static constexpr bool RD_SHAPE = ASSET_RES_ROWDPP == 2 || (ASSET_RES_ROWDPP == 1 && !((q % 4 == 0) && D::p == 0));
 #ifndef ASSET_RES_WPS
-#define ASSET_RES_WPS ((D::TJ > 1 || Ode::NUNITS > 1) ? 1 : 2)
+#define ASSET_RES_WPS ((Ode::NUNITS > 1 || (D::TJ > 1 && !(RD_SHAPE && !D::TRAP))) ? 1 : 2)
 #endif
   static constexpr int WPS = ASSET_RES_WPS;
+  static constexpr bool ASM_OK = !(D::TJ > 1 && RD_SHAPE && !D::TRAP && Ode::NUNITS == 1);
 #ifndef ASSET_RES_PAIR
 #define ASSET_RES_PAIR 1
 #endif
@@ -60,10 +68,6 @@ struct ResDims {
   // multiple of four and that have no parameter columns (ResLane::QFAST) fill their 16-column tiles without padding and keep their row
   // weights in registers; there the tile form issues 500 instructions and 33 matrix instructions per segment against ~ 800 vector
   // instructions of the row-wise form, and both end at the drain of the block stores.  ASSET_RES_ROWDPP: 0 never, 1 by that rule, 2 always.
-#ifndef ASSET_RES_ROWDPP
-#define ASSET_RES_ROWDPP 1
-#endif
-  static constexpr bool RD_SHAPE = ASSET_RES_ROWDPP == 2 || (ASSET_RES_ROWDPP == 1 && !((q % 4 == 0) && D::p == 0));
   static constexpr bool ROWDPP = RD_SHAPE && ASSET_RES_PAIR && !D::TRAP && WPS == 2 && Ode::NUNITS == 1;
   static constexpr int s_FB = D::WSLOTD + 1 + (SV_ALIAS ? 0 : CS * Ode::NSAVE);
   static constexpr int SLOT = (s_FB + (ROWDPP ? K * n + 1 : 0)) | 1;   // odd: conflict-free across segments
@@ -1528,7 +1532,7 @@ void lgl_resident_kernel(EvalArgs a) {
   using R = ResDims<Dims<Ode, SCH, BLOCKED>>;
   if constexpr (LPAIR) {
     if constexpr (R::OK && R::LOOP_PAIR) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN, true>(a);
-  } else if constexpr (GIVEN ? R::GIVEN_OK : R::OK) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN>(a);
+  } else if constexpr ((GIVEN ? R::GIVEN_OK : R::OK) && (!ASM || GIVEN || R::ASM_OK)) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN>(a);
 }
 
 }  // namespace asset_hip

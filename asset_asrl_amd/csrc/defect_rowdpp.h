@@ -404,7 +404,15 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
           });
           rd_for<nb>([&](auto Bx) {
             constexpr int c = b0 + decltype(Bx)::value;
+#if defined(ASSET_EXP_RDALIGN)   // (experiment, WRONG results: the entries in 32-byte sectors shared with the Jacobian part are not stored)
+            {
+              constexpr int s0c = X::colstart(c), bc = s0c + IR - c, lo = (s0c + 3) / 4 * 4, hi = bc / 4 * 4;
+              const int slot = s0c + r - c;
+              bst(rs_kkt, (c <= r && slot >= lo && slot < hi) ? kb : INVALID, 8 * (X::colstart(c) - c), acc[decltype(Bx)::value]);
+            }
+#else
             bst(rs_kkt, (c <= r) ? kb : INVALID, 8 * (X::colstart(c) - c), acc[decltype(Bx)::value]);
+#endif
           });
         });
       }
@@ -557,7 +565,15 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       });
       rd_for<nb>([&](auto Bx) {
         constexpr int c = b0 + decltype(Bx)::value;
+#if defined(ASSET_EXP_RDALIGN)
+        {
+          constexpr int bc = X::colstart(c) + IR - c, ec = bc + OR, lo = (bc + 3) / 4 * 4, hi = ec / 4 * 4;
+          const int slot = bc + jr;
+          bst(rs_kkt, (slot >= lo && slot < hi) ? kb : INVALID, 8 * (X::colstart(c) - c), acc[decltype(Bx)::value]);
+        }
+#else
         bst(rs_kkt, kb, 8 * (X::colstart(c) - c), acc[decltype(Bx)::value]);
+#endif
         // the gradient row's entry: into the segment's z section (dead: this pass has read it), the other lanes into lam cells of
         // their own (dead as well) -- one coalesced store per sixteen entries below instead of a store of four lanes per column
         if constexpr (MODE == 1) bst(rs_agx, gbd, 8 * c, acc[decltype(Bx)::value]);   // (the partner's phase still reads z and lam: no staging there)

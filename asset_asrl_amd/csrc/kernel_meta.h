@@ -36,6 +36,7 @@ enum MetaField {
   MF_ROWS_LDS_BYTES,                                // wide shapes, dense stage by output rows (defect_rows.h): its LDS (0: none)
   MF_RES_NWV,                                       // resident kernel: waves per workgroup (2: the pair form, ResDims::PAIR)
   MF_RES_LOOP_NWV,                                  // ... of its looped level-2 block kernel (2 with the row-wise dense part)
+  MF_RES_ASM,                                       // ... 1: its assembled kinds exist (0: shapes of two row tiles with the row-wise dense part)
   MF_COUNT
 };
 
@@ -67,7 +68,7 @@ struct LglMeta {
       AdjDims<D>::GP, (long long)AdjDims<D>::lds_bytes(),
       ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>(),
       ResDims<D>::WPS, ResDims<D>::GIVEN_OK ? ResDims<D>::GR : 0,
-      RowsDims<D>::OK ? (long long)RowsDims<D>::lds_bytes() : 0, ResDims<D>::NWV, ResDims<D>::LOOP_PAIR ? 2 : 1};
+      RowsDims<D>::OK ? (long long)RowsDims<D>::lds_bytes() : 0, ResDims<D>::NWV, ResDims<D>::LOOP_PAIR ? 2 : 1, ResDims<D>::ASM_OK ? 1 : 0};
 };
 
 template <class F>

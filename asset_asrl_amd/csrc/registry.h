@@ -262,7 +262,7 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
     case 0: return ode_stage(0);
     case 1: {
       static const bool no_res1 = tuning_env("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
-      if (m[MF_RES_GR] > 0 && !no_res1 && !skip_dense && a.lane_consts_res && t.k[K_RES1(a.kmap != nullptr)]) {
+      if (m[MF_RES_GR] > 0 && !no_res1 && !skip_dense && a.lane_consts_res && t.k[K_RES1(a.kmap != nullptr)] && (!a.kmap || m[MF_RES_ASM])) {
         const int waves = cus * 4 * int(m[MF_RES_WPS]);   // resident kernel, Jacobian kinds (defect_resident.h, LEVEL 1)
         const bool one = (a.nseg + waves - 1) / waves <= int(m[MF_RES_GR]);
         const KRef& kr = one ? t.k[K_RES1(a.kmap != nullptr)] : t.k[K_RESL(1, a.kmap != nullptr)];
@@ -294,7 +294,7 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
     case 2: {
       // resident kernel (defect_resident.h): the ODE results stay in LDS; meshes of at most GR segments per wave
       static const bool no_res = tuning_env("ASSET_HIP_NO_RESIDENT") != nullptr;                              // tuning only
-      if (m[MF_RES_GR] > 0 && !no_res && !skip_dense && a.lane_consts_res && t.k[K_RES(a.kmap != nullptr)]) {
+      if (m[MF_RES_GR] > 0 && !no_res && !skip_dense && a.lane_consts_res && t.k[K_RES(a.kmap != nullptr)] && (!a.kmap || m[MF_RES_ASM])) {
         int waves = cus * 4 * int(m[MF_RES_WPS]);   // one group per wave up to GR segments per wave, the looped instantiation beyond
         static const int env_max = tuning_env("ASSET_HIP_RESIDENT_MAX_GROUPS") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_MAX_GROUPS")) : 0;   // tuning only
         static const int env_grid = tuning_env("ASSET_HIP_RESIDENT_GRID") ? std::atoi(std::getenv("ASSET_HIP_RESIDENT_GRID")) : 0;   // tuning only
