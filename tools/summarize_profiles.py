@@ -19,6 +19,8 @@ def stage_of(kernel_name):
     """lgl_defect_kernel<Ode, CS, BLOCKED, G, LEVEL, STAGE[, ASM]>: STAGE is the sixth template argument."""
     if "lgl_resident_kernel" in kernel_name:              # resident single launch (defect_resident.h): <Ode, CS, BLOCKED, LEVEL, ASM, LOOP>
         rargs = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
+        if len(rargs) >= 5 and rargs[4] == "true":        # ASM (on-device assembly): bench.py's host_visible_assembled leg only
+            return "secondary"
         return "resident" if len(rargs) < 4 or rargs[3] == "2" else "secondary"
     if "lgl_wide_dense_kernel" in kernel_name or "lgl_rows_kernel" in kernel_name:   # dense stage of the wide shapes (defect_wide.h / defect_rows.h)
         return "dense_stage"
@@ -27,6 +29,8 @@ def stage_of(kernel_name):
         return "ode_units" + (uargs[3] if len(uargs) >= 4 else "")     # two launches per evaluation
     args = [x.strip() for x in kernel_name.split("<", 1)[1].rsplit(">", 1)[0].split(",")]
     if len(args) >= 6 and args[4] != "2":                 # derivative level 0 / 1: the secondary kinds bench.py also times
+        return "secondary"
+    if len(args) >= 7 and args[6] == "true":              # ASM: on-device assembly, bench.py's host_visible_assembled leg only
         return "secondary"
     if len(args) >= 6 and args[5] == "3":                 # fused single launch (defect_kernels.h, STAGE 3)
         return "fused"
