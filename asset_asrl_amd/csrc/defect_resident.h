@@ -548,7 +548,7 @@ constexpr long long res_table_words_tile() {
 }
 template <class Ode, class D>
 constexpr long long res_table_words() {
-  if constexpr (ResDims<D>::DENSE_OK && ResDims<D>::ROWDPP) return res_table_words_tile<Ode, D>() + RdDims<Ode, D>::table_bytes() / 4;
+  if constexpr ((ResDims<D>::DENSE_OK && ResDims<D>::ROWDPP) || UResDims<Ode, D>::OK) return res_table_words_tile<Ode, D>() + RdDims<Ode, D>::table_bytes() / 4;
   else return res_table_words_tile<Ode, D>();
 }
 
@@ -565,6 +565,10 @@ __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
       for (int rec = threadIdx.x; rec < RdDims<Ode, D>::NRECH; rec += 64)
         rd_lane_setup<Ode, D, ResDims<D>::s_Z0>(out + res_table_words_tile<Ode, D>(), rec);
     }
+  }
+  if constexpr (UResDims<Ode, D>::OK) {   // (heavy right-hand sides, defect_ures.h: the row records for its slot layout)
+    for (int rec = threadIdx.x; rec < RdDims<Ode, D>::NRECH; rec += 64)
+      rd_lane_setup<Ode, D, UResDims<Ode, D>::s_Z0>(out + res_table_words_tile<Ode, D>(), rec);
   }
 }
 
