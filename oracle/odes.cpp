@@ -68,6 +68,8 @@ AD2_ODE(integrand_quad2, 1, 0, 0)
 AD2_ODE(pairprod, 1, 2, 0)
 AD2_ODE(integrand_powp, 1, 2, 0)
 AD2_ODE(reentry_heating, 1, 1, 0)
+AD2_ODE(cartpole, 4, 1, 0)
+AD2_ODE(integrand_usq, 1, 0, 0)
 
 }  // namespace
 
@@ -102,6 +104,8 @@ GEN_DECL(integrand_quad2)
 GEN_DECL(pairprod)
 GEN_DECL(integrand_powp)
 GEN_DECL(reentry_heating)
+GEN_DECL(cartpole)
+GEN_DECL(integrand_usq)
 
 extern "C" {
 
@@ -145,6 +149,8 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(pairprod)
   TRY4(integrand_powp)
   TRY4(reentry_heating)
+  TRY4(cartpole)
+  TRY4(integrand_usq)
   return -1;
 }
 
@@ -166,6 +172,8 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(pairprod, 1, 2, 0, nullptr)
   TRY(integrand_powp, 1, 2, 0, nullptr)
   TRY(reentry_heating, 1, 1, 0, nullptr)
+  TRY(cartpole, 4, 1, 0, nullptr)
+  TRY(integrand_usq, 1, 0, 0, nullptr)
   return -1;
 }
 }

@@ -106,6 +106,22 @@ void reentry_heating(const S* y, S* f, const void*) {
   f[0] = (qa * qr - Qlimit) * (1.0 / Qlimit);
 }
 
+// ------------------------------------------------------------------ cart-pole swing-up (4,1,0)
+// The dynamics of the reference's second full-problem test with a known answer (asset_asrl/test/test_FullProblems/
+// test_CartPole.py:11-32; l = 0.5, m1 = 1, m2 = 0.3, g = 9.81 as in :43-46): y = [q1, q2, q1', q2', t, u].
+// tests/kkt_harness.py defines the same right-hand side in the product's expression DSL.
+template <class S>
+void cartpole(const S* y, S* f, const void*) {
+  const double l = 0.5, m1 = 1.0, m2 = 0.3, g = 9.81;
+  const S &q2 = y[1], &q1d = y[2], &q2d = y[3], &u = y[5];
+  const S s2 = sin(q2), c2 = cos(q2);
+  const S den = m1 + m2 * (1.0 - c2 * c2);
+  f[0] = q1d;
+  f[1] = q2d;
+  f[2] = (l * m2 * s2 * (q2d * q2d) + u + m2 * g * c2 * s2) / den;
+  f[3] = -1.0 * (l * m2 * c2 * s2 * (q2d * q2d) + u * c2 + (m1 * g + m2 * g) * s2) / (l * den);
+}
+
 // ------------------------------------------------------------------ integrands (one output) for the segment quadrature
 // quad2: I(x0, x1) = x1^2 + x0 (the integrand of tests/test_gpu_function.py);  record (xv, uv, pv) = (1, 0, 0): 2 inputs.
 // powp: I(x0, x1, x2, p) = p x0^2 + sin(x1) x2 + exp(-x0 x2) / (1 + p^2): three node values and a phase parameter;
@@ -115,6 +131,10 @@ template <class S>
 void pairprod(const S* y, S* f, const void*) { f[0] = y[0] * y[2] - y[1] * y[3] - 0.5; }
 template <class S>
 void integrand_quad2(const S* y, S* f, const void*) { f[0] = y[1] * y[1] + y[0]; }
+// usq: I(x0, x1) = x1^2 -- the control effort u^2 of the cart-pole problem (test_CartPole.py:69), taken over the node values
+// (q1, u): record (1, 0, 0), 2 inputs, the first unused
+template <class S>
+void integrand_usq(const S* y, S* f, const void*) { f[0] = y[1] * y[1]; }
 template <class S>
 void integrand_powp(const S* y, S* f, const void*) {
   f[0] = y[3] * y[0] * y[0] + sin(y[1]) * y[2] + exp(-(y[0] * y[2])) / (1.0 + y[3] * y[3]);

@@ -9,7 +9,12 @@ The linear parts of the problem (boundary values, variable bounds, the upper bou
 -(theta_f - theta_0)) are handled here as fixed variables, bounds and a constant cost vector; every NONLINEAR function the
 phase registers -- defects, mesh spacing, control splines -- comes from the assembly under test: constraint values, the
 Jacobian (off-diagonal block of the upper-triangular KKT CSR) and the Lagrangian Hessian sum_k lam_k grad^2 c_k (its
-primal block)."""
+primal block).
+
+A second problem of the same kind (round 5): the cart-pole swing-up of test_FullProblems/test_CartPole.py:11-95, objective
+58.83219229674185 +- 0.1 -- there the cost is NONLINEAR (the integral of u^2: an LGLIntegral objective the assembly evaluates), so
+the loop also takes the objective's value and gradient from the provider (`objective`, `objective_gradient`); its Hessian is in the
+primal block already (ObjScale = 1)."""
 from __future__ import annotations
 
 import numpy as np
@@ -78,6 +83,57 @@ def reentry_problem(mode: str, control: str, nseg: int = 64, heating: bool = Fal
                 slack_rows=slack_rows)
 
 
+def cartpole_ode():
+    """The reference test's dynamics (test_CartPole.py:11-32; l, m1, m2, g of :43-46) in the product's DSL; the oracle holds the
+    same right-hand side as `cartpole` (oracle/odes.h), differentiated independently by AD2."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+    l, m1, m2, g = 0.5, 1.0, 0.3, 9.81
+
+    class CartPole(ODEBase):
+        def __init__(self):
+            a = ODEArguments(4, 1)
+            q1, q2, q1d, q2d = a.XVec().tolist()
+            u = a.UVar(0)
+            s2, c2 = vf.sin(q2), vf.cos(q2)
+            den = m1 + m2 * (1.0 - c2 * c2)
+            q1dd = (l * m2 * s2 * (q2d * q2d) + u + m2 * g * c2 * s2) / den
+            q2dd = -1.0 * (l * m2 * c2 * s2 * (q2d * q2d) + u * c2 + (m1 * g + m2 * g) * s2) / (l * den)
+            super().__init__(vf.stack([q1d, q2d, q1dd, q2dd]), 4, 1, 0, name="cartpole")
+
+    return CartPole()
+
+
+def cartpole_problem(mode: str, control: str, nseg: int):
+    """test_CartPole.py:41-70: swing the pole up in tf = 2 while the cart moves d = 1, |u| <= 20, |q1| <= 2, minimise int u^2 dt.
+    The integrand is taken over the node values (q1, u) -- u^2 with an unused first input: the oracle's function records have at
+    least two inputs -- which is the same objective."""
+    from asset_asrl_amd import vf
+    umax, dmax, tf, d = 20.0, 2.0, 2.0, 1.0
+    ts = np.linspace(0, tf, 100)
+    traj = np.array([[d * t / tf, np.pi * t / tf, 0.0, 0.0, t, 0.0] for t in ts])
+    ph = cartpole_ode().phase(mode, traj, nseg)
+    ph.setControlMode(control)
+    a = vf.Arguments(2)
+    ph.addIntegralObjective(a.coeff(1) * a.coeff(1), [0, 5])     # addIntegralObjective(Args(1)[0]**2, [5])
+    ix, (V, Cx), entries, n_equal, _ = ph.layout()
+    x0 = ix.makeSolverInput(ph.ActiveTraj)
+    n, S, D = x0.size, ix.numStates, ix.numDefects
+    lb, ub, cost = np.full(n, -np.inf), np.full(n, np.inf), np.zeros(n)
+    for k in range(S):                                           # addLUVarBound("Path", 0, -dmax, dmax)
+        lb[ix.getXTUVarLoc(0, k)], ub[ix.getXTUVarLoc(0, k)] = -dmax, dmax
+    for k, dd in ([(0, dd) for dd in range(D)] if ix.BlockedControls else [(k, None) for k in range(S)]):
+        lu = ix.getXTUVarLoc(5, k, dd)                           # addLUVarBound("Path", 5, -umax, umax)
+        lb[lu], ub[lu] = -umax, umax
+    for v, val in enumerate([0.0, 0.0, 0.0, 0.0, 0.0]):          # addBoundaryValue("Front", range(0, 5), ...)
+        lb[ix.getXTUVarLoc(v, 0)] = ub[ix.getXTUVarLoc(v, 0)] = val
+    for v, val in enumerate([d, np.pi, 0.0, 0.0, tf]):           # addBoundaryValue("Back", range(0, 5), ...)
+        lb[ix.getXTUVarLoc(v, S - 1)] = ub[ix.getXTUVarLoc(v, S - 1)] = val
+    return dict(phase=ph, ix=ix, x0=x0, lb=lb, ub=ub, cost=cost, V=V, Cx=Cx, entries=entries, n_equal=n_equal,
+                slack_rows=np.zeros(0, dtype=np.int32), ode_name="cartpole", integrands={"obj0": ("integrand_usq", 2)},
+                usize=1)
+
+
 class SlackRows:
     """Turns rows of an equality-only assembly into inequalities g(x) <= 0: variables [x ; s], rows g(x) + s = 0, s >= 0."""
 
@@ -121,7 +177,8 @@ class OracleProvider:
         ph, ix = prob["phase"], prob["ix"]
         n, m = prob["x0"].size, prob["n_equal"]
         nlp = ob.FullNlp(n, m, 0)
-        nlp.add(1, ob.get_ode("reentry", 0), ob.MODES[ph.TranscriptionMode], ix.BlockedControls, prob["V"], prob["Cx"])
+        nlp.add(1, ob.get_ode(prob.get("ode_name", "reentry"), 0), ob.MODES[ph.TranscriptionMode], ix.BlockedControls, prob["V"],
+                prob["Cx"])
         cs = synth.MODE_CS[ph.TranscriptionMode]
         for kind, tag, F, name, V, Cx, consts in prob["entries"]:
             if tag == "mesh_spacing":
@@ -129,9 +186,13 @@ class OracleProvider:
             elif tag == "nodal_spacing":
                 nlp.add_single_mesh_spacing(1, consts.ravel(), V, Cx)
             elif tag == "control_spline":
-                nlp.add_control_spline(1, cs, 2, V, Cx)
+                nlp.add_control_spline(1, cs, prob.get("usize", 2), V, Cx)
             elif tag == "eq0":                                   # the heating-rate bound (reentry_problem(heating=True))
                 nlp.add(1, ob.get_ode("reentry_heating", 0), ob.MODES["Function"], False, V, Cx)
+            elif kind == "objective":                            # an integral objective: the segment quadrature of an integrand
+                name, nx = prob["integrands"][tag]
+                nlp.add_integral(0, ob.get_ode(name, 0), cs, nx, 0, V, Cx)
+                self.has_objective = True
             else:
                 raise ValueError(tag)
         nlp.analyze()
@@ -140,14 +201,23 @@ class OracleProvider:
         self.csr = CsrKkt(*nlp.csr(), n, m)
         self.calls = 0
 
+    has_objective, pgx = False, None
+
     def kkt(self, x, lam):
         self.calls += 1
-        _, _, agx, fxe, _, vals = self.nlp.eval(4, 1.0, x, lam, np.zeros(1))
+        _, self.pgx, agx, fxe, _, vals = self.nlp.eval(4, 1.0, x, lam, np.zeros(1))
         W, J = self.csr.split(vals)
         return fxe, agx, W, J
 
     def con(self, x):
         return self.nlp.eval(0, 1.0, x, np.zeros(self.m), np.zeros(1))[3]
+
+    def objective(self, x):
+        return float(self.nlp.eval(0, 1.0, x, np.zeros(self.m), np.zeros(1))[0]) if self.has_objective else 0.0
+
+    def objective_gradient(self):
+        """of the last kkt() call"""
+        return self.pgx if self.has_objective else 0.0
 
 
 # ---------------------------------------------------------------------------------------------- the loop
@@ -174,10 +244,15 @@ def solve_ip(provider, x0, lb, ub, cost, tol=1e-7, maxit=400, mu=0.1, verbose=Fa
     su = lambda v: np.where(hasu, ub - v, 1.0)
     zl, zu = np.where(hasl, mu / sl(x), 0.0), np.where(hasu, mu / su(x), 0.0)
     dw, filt = 0.0, []
-    phi = lambda xx: cost @ xx - mu * (np.log(sl(xx))[hasl].sum() + np.log(su(xx))[hasu].sum())
+    # a nonlinear part of the cost (an integral objective the assembly evaluates): value and gradient from the provider
+    nonlin = (not feasibility) and getattr(provider, "has_objective", False)
+    fobj = (lambda xx: provider.objective(xx)) if nonlin else (lambda xx: 0.0)
+    pgrad = (lambda: provider.objective_gradient()) if nonlin else (lambda: 0.0)
+    phi = lambda xx: cost @ xx + fobj(xx) - mu * (np.log(sl(xx))[hasl].sum() + np.log(su(xx))[hasu].sum())
     info = dict(iters=maxit, converged=False)
     for it in range(maxit):
         c, agx, W, J = provider.kkt(x, lam)
+        pg = pgrad()
         Jf = J[:, free]
         if feasibility:
             if np.abs(c).max() < tol:
@@ -185,11 +260,12 @@ def solve_ip(provider, x0, lb, ub, cost, tol=1e-7, maxit=400, mu=0.1, verbose=Fa
                 break
             lam, agx, W = 0.0 * lam, 0.0 * agx, sp.identity(x.size, format="csr")
         elif it == 0:                                            # least-squares multiplier estimate at the start
-            g0 = (cost - np.where(hasl, mu / sl(x), 0.0) + np.where(hasu, mu / su(x), 0.0))[free]
+            g0 = (cost + pg - np.where(hasl, mu / sl(x), 0.0) + np.where(hasu, mu / su(x), 0.0))[free]
             K0 = sp.bmat([[sp.identity(nf), Jf.T], [Jf, -1e-9 * sp.identity(m)]], format="csc")
             lam = spla.splu(K0).solve(np.concatenate([-g0, np.zeros(m)]))[nf:]
             c, agx, W, J = provider.kkt(x, lam)
-        gl = cost + agx - zl + zu
+            pg = pgrad()
+        gl = cost + pg + agx - zl + zu
         err = lambda mu_: max(np.abs(gl[free]).max(), np.abs(c).max(), np.abs(sl(x) * zl - mu_)[hasl].max(initial=0.0),
                               np.abs(su(x) * zu - mu_)[hasu].max(initial=0.0))
         if not feasibility and err(0.0) < tol:
@@ -198,7 +274,7 @@ def solve_ip(provider, x0, lb, ub, cost, tol=1e-7, maxit=400, mu=0.1, verbose=Fa
         while err(mu) < 10.0 * mu and mu > tol / 10:
             mu, filt = max(tol / 10, min(0.2 * mu, mu ** 1.5)), []
         sig = zl / sl(x) + zu / su(x)
-        gphi = cost - np.where(hasl, mu / sl(x), 0.0) + np.where(hasu, mu / su(x), 0.0)
+        gphi = cost + pg - np.where(hasl, mu / sl(x), 0.0) + np.where(hasu, mu / su(x), 0.0)
         Wf = W[free][:, free]
         rhs = -np.concatenate([(gphi + agx)[free], c])
         tau = max(0.99, 1.0 - mu)
@@ -250,7 +326,7 @@ def solve_ip(provider, x0, lb, ub, cost, tol=1e-7, maxit=400, mu=0.1, verbose=Fa
         if verbose:
             print(f"{it:4d} obj {cost @ x:+.8f} |c| {np.abs(c).max():.2e} |gl| {np.abs(gl[free]).max():.2e} mu {mu:.1e} "
                   f"a {a:.2e} dw {dw:.1e} |dx| {np.abs(dx).max():.2e} tries {_try} ls {_ls} filt {len(filt)}")
-    info["objective"] = float(cost @ x)
+    info["objective"] = float(cost @ x + fobj(x))
     return x, lam, info
 
 
@@ -271,6 +347,13 @@ def solve_reentry(provider, prob, verbose=False, x0=None):
     return x[:prob["x0"].size], lam, info
 
 
+def solve_optimize_only(provider, prob, verbose=False, **kw):
+    """phase.optimize() from the initial guess, as test_CartPole.py:71 does (no feasibility stage).  -> (x, lam, info)."""
+    x, lam, info = solve_ip(provider, prob["x0"], prob["lb"], prob["ub"], prob["cost"], verbose=verbose, **kw)
+    info["feasible"] = bool(np.abs(provider.con(x)).max() < 1e-6)
+    return x, lam, info
+
+
 class DeviceProvider:
     """The product: every function evaluated on the GPU through the C ABI and assembled by the C++ host shim's
     KktAssembly (asset_asrl_amd/host/kkt_assembly.h) -- `shim` is tests/host_shim_driver.cpp compiled by the test."""
@@ -288,13 +371,16 @@ class DeviceProvider:
         mode_id = {"LGL3": _lib.LGL3, "LGL5": _lib.LGL5, "LGL7": _lib.LGL7, "Trapezoidal": _lib.TRAPEZOIDAL}[ph.TranscriptionMode]
         fns = [(jit.ensure_kernel(ph.ode, ph.TranscriptionMode, ix.BlockedControls), mode_id, int(ix.BlockedControls),
                 prob["V"], prob["Cx"], None)]
-        fns += [(jit.ensure_function(F, name), _lib.FUNCTION, 0, V, Cx, consts) for _, _, F, name, V, Cx, consts in prob["entries"]]
+        fns = [f + (1,) for f in fns]                            # (kind 1: equality; 0: objective -- host/kkt_assembly.h)
+        fns += [(jit.ensure_function(F, name), _lib.FUNCTION, 0, V, Cx, consts, 0 if kind == "objective" else 1)
+                for kind, _, F, name, V, Cx, consts in prob["entries"]]
+        self.has_objective = any(f[6] == 0 for f in fns)
         self._keep, descs = [], (FnDesc * len(fns))()
-        for k, (name, mode, blocked, V, Cx, consts) in enumerate(fns):
+        for k, (name, mode, blocked, V, Cx, consts, fkind) in enumerate(fns):
             v, c = np.ascontiguousarray(V, dtype=np.int32), np.ascontiguousarray(Cx, dtype=np.int32)
             cc = None if consts is None else np.ascontiguousarray(consts, dtype=float)
             self._keep += [v, c, cc]
-            descs[k] = FnDesc(1, name.encode(), mode, blocked, v.shape[1], c.shape[1], v.shape[0], v.ctypes.data_as(ip),
+            descs[k] = FnDesc(fkind, name.encode(), mode, blocked, v.shape[1], c.shape[1], v.shape[0], v.ctypes.data_as(ip),
                               c.ctypes.data_as(ip), None if cc is None else cc.ctypes.data_as(dp), 0 if cc is None else cc.shape[1])
         err = C.create_string_buffer(512)
         shim.fullnlp_create.restype = C.c_void_p
@@ -317,15 +403,25 @@ class DeviceProvider:
         rc = self.shim.fullnlp_eval(self._h, level, C.c_double(1.0), p(x), p(lam), p(fxi), C.byref(val), p(pgx), p(agx), p(fxe),
                                     p(fxi), p(vals), err, 512)
         assert rc == 0, err.value
+        self._val, self._pgx = float(val.value), pgx
         return fxe, agx, vals
 
     def kkt(self, x, lam):
         self.calls += 1
         fxe, agx, vals = self._eval(4, x, lam)
+        self.pgx = self._pgx
         return (fxe, agx) + self.csr.split(vals)
 
     def con(self, x):
         return self._eval(0, x, np.zeros(self.m))[0]
+
+    def objective(self, x):
+        self._eval(0, x, np.zeros(self.m))
+        return self._val if self.has_objective else 0.0
+
+    def objective_gradient(self):
+        """of the last kkt() call"""
+        return self.pgx if self.has_objective else 0.0
 
     def close(self):
         if self._h:
