@@ -261,10 +261,10 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
 #pragma unroll
           for (int b = 0; b < N; b++) out.gacc_[b] = 0.0;
           run_unit_j<Ode>(unit, in, out);
-          const unsigned own = Ode::UNIT_COLS[unit];
+          const unsigned long long own = Ode::UNIT_COLS[unit];
 #pragma unroll
           for (int b = 0; b < N; b++)
-            if ((own >> b) & 1u) S[D::w_Ig + i * N + b] = out.gacc_[b];
+            if ((own >> b) & 1ull) S[D::w_Ig + i * N + b] = out.gacc_[b];
         } else {
         OdeOutUnit<D, false, true> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH,
                                        nullptr};

@@ -471,7 +471,10 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
         for u in range(len(units)):
             o.append(f"    {'if' if u == 0 else 'else if'} constexpr (U == {u}) fj_u{u}_(in, out);")
         o.append("  }")
-        o.append(f"  static constexpr unsigned UNIT_COLS[{len(units)}] = {{" + ", ".join(str(sum(1 << c for c in m)) + "u" for m in masks) + "};")
+        # (64-bit masks: a plain function with more than 32 inputs -- the LGL7 control spline of four controls has 36 -- is cut into
+        #  units too; the unit kernels of defect_units.h are for ODEs, whose N = XV + 1 + UV + PV stays below 64)
+        o.append(f"  static constexpr unsigned long long UNIT_COLS[{len(units)}] = {{" +
+                 ", ".join(str(sum(1 << c for c in m if c < 64)) + "ull" for m in masks) + "};")
         o.append(f"  static constexpr int F_UNIT = {f_unit};")
         # the state components of g = J^T lam alone (a vector-Jacobian product: about three value bodies).  The cardinal adjoint
         # weights w_j (LGLDefects.h:369-374) need g^_i[0:n] of the interior points and nothing else of them, so a workgroup that

@@ -70,6 +70,8 @@ AD2_ODE(integrand_powp, 1, 2, 0)
 AD2_ODE(reentry_heating, 1, 1, 0)
 AD2_ODE(cartpole, 4, 1, 0)
 AD2_ODE(integrand_usq, 1, 0, 0)
+AD2_ODE(freeflyingrobot, 6, 4, 0)
+AD2_ODE(integrand_sum4, 1, 2, 0)
 
 }  // namespace
 
@@ -106,6 +108,8 @@ GEN_DECL(integrand_powp)
 GEN_DECL(reentry_heating)
 GEN_DECL(cartpole)
 GEN_DECL(integrand_usq)
+GEN_DECL(freeflyingrobot)
+GEN_DECL(integrand_sum4)
 
 extern "C" {
 
@@ -151,6 +155,8 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(reentry_heating)
   TRY4(cartpole)
   TRY4(integrand_usq)
+  TRY4(freeflyingrobot)
+  TRY4(integrand_sum4)
   return -1;
 }
 
@@ -174,6 +180,8 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(reentry_heating, 1, 1, 0, nullptr)
   TRY(cartpole, 4, 1, 0, nullptr)
   TRY(integrand_usq, 1, 0, 0, nullptr)
+  TRY(freeflyingrobot, 6, 4, 0, nullptr)
+  TRY(integrand_sum4, 1, 2, 0, nullptr)
   return -1;
 }
 }

@@ -122,6 +122,24 @@ void cartpole(const S* y, S* f, const void*) {
   f[3] = -1.0 * (l * m2 * c2 * s2 * (q2d * q2d) + u * c2 + (m1 * g + m2 * g) * s2) / (l * den);
 }
 
+// ------------------------------------------------------------------ free-flying robot (6,4,0)
+// The dynamics of the reference's third full-problem test with a known answer (asset_asrl/test/test_FullProblems/
+// test_FreeFlyingRobot.py:14-35; alpha = beta = 0.2 as in :52): y = [x, y, vx, vy, theta, omega, t, u0..u3].
+// tests/kkt_harness.py defines the same right-hand side in the product's expression DSL.
+template <class S>
+void freeflyingrobot(const S* y, S* f, const void*) {
+  const double alpha = 0.2, beta = 0.2;
+  const S &theta = y[4], &omega = y[5];
+  const S* u = y + 7;
+  const S vscale = u[0] - u[1] + u[2] - u[3];
+  f[0] = y[2];
+  f[1] = y[3];
+  f[2] = cos(theta) * vscale;
+  f[3] = sin(theta) * vscale;
+  f[4] = omega;
+  f[5] = alpha * u[0] - alpha * u[1] - beta * u[2] + beta * u[3];
+}
+
 // ------------------------------------------------------------------ integrands (one output) for the segment quadrature
 // quad2: I(x0, x1) = x1^2 + x0 (the integrand of tests/test_gpu_function.py);  record (xv, uv, pv) = (1, 0, 0): 2 inputs.
 // powp: I(x0, x1, x2, p) = p x0^2 + sin(x1) x2 + exp(-x0 x2) / (1 + p^2): three node values and a phase parameter;
@@ -135,6 +153,10 @@ void integrand_quad2(const S* y, S* f, const void*) { f[0] = y[1] * y[1] + y[0];
 // (q1, u): record (1, 0, 0), 2 inputs, the first unused
 template <class S>
 void integrand_usq(const S* y, S* f, const void*) { f[0] = y[1] * y[1]; }
+// sum4: I(u0..u3) = u0 + u1 + u2 + u3 -- the thruster effort of the free-flying robot (test_FreeFlyingRobot.py:37-41,75);
+// record (1, 2, 0): 4 inputs
+template <class S>
+void integrand_sum4(const S* y, S* f, const void*) { f[0] = y[0] + y[1] + y[2] + y[3]; }
 template <class S>
 void integrand_powp(const S* y, S* f, const void*) {
   f[0] = y[3] * y[0] * y[0] + sin(y[1]) * y[2] + exp(-(y[0] * y[2])) / (1.0 + y[3] * y[3]);

@@ -134,6 +134,53 @@ def cartpole_problem(mode: str, control: str, nseg: int):
                 usize=1)
 
 
+def freeflyingrobot_ode():
+    """test_FreeFlyingRobot.py:14-35 (alpha = beta = 0.2) in the product's DSL; the oracle holds it as `freeflyingrobot`."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+    alpha, beta = 0.2, 0.2
+
+    class FreeFlyingRobot(ODEBase):
+        def __init__(self):
+            a = ODEArguments(6, 4)
+            x, y, vx, vy, theta, omega = a.XVec().tolist()
+            u = [a.UVar(k) for k in range(4)]
+            vscale = u[0] - u[1] + u[2] - u[3]
+            rates = [vx, vy, vf.cos(theta) * vscale, vf.sin(theta) * vscale, omega,
+                     alpha * u[0] - alpha * u[1] - beta * u[2] + beta * u[3]]
+            super().__init__(vf.stack(rates), 6, 4, 0, name="freeflyingrobot")
+
+    return FreeFlyingRobot()
+
+
+def freeflyingrobot_problem(mode: str, control: str, nseg: int = 256):
+    """test_FreeFlyingRobot.py:50-76: from (-10, -10) at rest, heading pi/2, to the origin at rest, heading 0, in tf = 12; four
+    thrusters in [0, 1]; minimise the integral of their sum (bang-bang)."""
+    from asset_asrl_amd import vf
+    tf = 12.0
+    X0, XF = np.array([-10, -10, 0, 0, np.pi / 2, 0, 0.0]), np.array([0, 0, 0, 0, 0, 0, tf])
+    ts = np.linspace(0, tf, 100)
+    traj = np.array([np.concatenate([X0 + (t / tf) * (XF - X0), 0.5 * np.ones(4)]) for t in ts])
+    ph = freeflyingrobot_ode().phase(mode, traj, nseg)
+    ph.setControlMode(control)
+    a = vf.Arguments(4)
+    ph.addIntegralObjective(a.coeff(0) + a.coeff(1) + a.coeff(2) + a.coeff(3), [7, 8, 9, 10])
+    ix, (V, Cx), entries, n_equal, _ = ph.layout()
+    x0 = ix.makeSolverInput(ph.ActiveTraj)
+    n, S, D = x0.size, ix.numStates, ix.numDefects
+    lb, ub, cost = np.full(n, -np.inf), np.full(n, np.inf), np.zeros(n)
+    for k, dd in ([(0, dd) for dd in range(D)] if ix.BlockedControls else [(k, None) for k in range(S)]):
+        for v in range(7, 11):                                   # addLUVarBounds("Path", range(7, 11), 0.0, 1.0)
+            lu = ix.getXTUVarLoc(v, k, dd)
+            lb[lu], ub[lu] = 0.0, 1.0
+    for v in range(7):                                           # addBoundaryValue("Front" / "Back", range(0, 7), ...)
+        lb[ix.getXTUVarLoc(v, 0)] = ub[ix.getXTUVarLoc(v, 0)] = X0[v]
+        lb[ix.getXTUVarLoc(v, S - 1)] = ub[ix.getXTUVarLoc(v, S - 1)] = XF[v]
+    return dict(phase=ph, ix=ix, x0=x0, lb=lb, ub=ub, cost=cost, V=V, Cx=Cx, entries=entries, n_equal=n_equal,
+                slack_rows=np.zeros(0, dtype=np.int32), ode_name="freeflyingrobot", integrands={"obj0": ("integrand_sum4", 4)},
+                usize=4)
+
+
 class SlackRows:
     """Turns rows of an equality-only assembly into inequalities g(x) <= 0: variables [x ; s], rows g(x) + s = 0, s >= 0."""
 
