@@ -72,6 +72,8 @@ AD2_ODE(cartpole, 4, 1, 0)
 AD2_ODE(integrand_usq, 1, 0, 0)
 AD2_ODE(freeflyingrobot, 6, 4, 0)
 AD2_ODE(integrand_sum4, 1, 2, 0)
+AD2_ODE(cannon, 4, 0, 1)
+AD2_ODE(cannon_energy, 1, 0, 0)
 
 }  // namespace
 
@@ -110,6 +112,8 @@ GEN_DECL(cartpole)
 GEN_DECL(integrand_usq)
 GEN_DECL(freeflyingrobot)
 GEN_DECL(integrand_sum4)
+GEN_DECL(cannon)
+GEN_DECL(cannon_energy)
 
 extern "C" {
 
@@ -157,6 +161,8 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(integrand_usq)
   TRY4(freeflyingrobot)
   TRY4(integrand_sum4)
+  TRY4(cannon)
+  TRY4(cannon_energy)
   return -1;
 }
 
@@ -182,6 +188,8 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(integrand_usq, 1, 0, 0, nullptr)
   TRY(freeflyingrobot, 6, 4, 0, nullptr)
   TRY(integrand_sum4, 1, 2, 0, nullptr)
+  TRY(cannon, 4, 0, 1, nullptr)
+  TRY(cannon_energy, 1, 0, 0, nullptr)
   return -1;
 }
 }

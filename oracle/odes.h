@@ -140,6 +140,38 @@ void freeflyingrobot(const S* y, S* f, const void*) {
   f[5] = alpha * u[0] - alpha * u[1] - beta * u[2] + beta * u[3];
 }
 
+// ------------------------------------------------------------------ cannon ball with drag (4,0,1): an ODE PARAMETER (the ball's radius)
+// The dynamics of the reference's two-phase full-problem test (asset_asrl/test/test_FullProblems/test_MultiPhaseCannon.py:16-72,
+// non-dimensional units of :16-34): y = [v, gamma, h, r, t, rad].  cannon_energy: (E(v, rad) - E0) / 100, the muzzle-energy bound of
+// :75-79,131 -- record (1, 0, 0): one output of the two inputs (v, rad).  tests/kkt_harness.py defines both in the product's DSL.
+namespace cannon_units {
+constexpr double g0 = 9.81, Lstar = 1000.0, Tstar = 60.0, Mstar = 10.0;
+constexpr double Astar = Lstar / (Tstar * Tstar), Vstar = Lstar / Tstar, Rhostar = Mstar / (Lstar * Lstar * Lstar);
+constexpr double Estar = Mstar * (Vstar * Vstar);
+constexpr double CD = 0.5, RhoAir = 1.225 / Rhostar, RhoIron = 7870.0 / Rhostar, h_scale = 8.44e3 / Lstar, E0 = 400000.0 / Estar;
+constexpr double g = g0 / Astar;
+}  // namespace cannon_units
+template <class S>
+void cannon(const S* y, S* f, const void*) {
+  using namespace cannon_units;
+  const S &v = y[0], &gamma = y[1], &h = y[2], &rad = y[5];
+  const S Sref = M_PI * (rad * rad);
+  const S M = (4.0 / 3.0) * (M_PI * RhoIron) * (rad * rad * rad);
+  const S rho = RhoAir * exp(-1.0 * h / h_scale);
+  const S D = (0.5 * CD) * rho * (v * v) * Sref;
+  f[0] = -1.0 * D / M - g * sin(gamma);
+  f[1] = -1.0 * g * cos(gamma) / v;
+  f[2] = v * sin(gamma);
+  f[3] = v * cos(gamma);
+}
+template <class S>
+void cannon_energy(const S* y, S* f, const void*) {
+  using namespace cannon_units;
+  const S &v = y[0], &rad = y[1];
+  const S M = (4.0 / 3.0) * (M_PI * RhoIron) * (rad * rad * rad);
+  f[0] = (0.5 * M * (v * v) - E0) * 0.01;
+}
+
 // ------------------------------------------------------------------ integrands (one output) for the segment quadrature
 // quad2: I(x0, x1) = x1^2 + x0 (the integrand of tests/test_gpu_function.py);  record (xv, uv, pv) = (1, 0, 0): 2 inputs.
 // powp: I(x0, x1, x2, p) = p x0^2 + sin(x1) x2 + exp(-x0 x2) / (1 + p^2): three node values and a phase parameter;

@@ -181,6 +181,142 @@ def freeflyingrobot_problem(mode: str, control: str, nseg: int = 256):
                 usize=4)
 
 
+def cannon_constants():
+    """test_MultiPhaseCannon.py:16-34"""
+    g0, Lstar, Tstar, Mstar = 9.81, 1000.0, 60.0, 10.0
+    Astar, Vstar, Rhostar = Lstar / Tstar ** 2, Lstar / Tstar, Mstar / Lstar ** 3
+    Estar = Mstar * Vstar ** 2
+    return dict(Lstar=Lstar, Tstar=Tstar, CD=0.5, RhoAir=1.225 / Rhostar, RhoIron=7870.0 / Rhostar, h_scale=8.44e3 / Lstar,
+                E0=400000.0 / Estar, g=g0 / Astar)
+
+
+def cannon_ode():
+    """test_MultiPhaseCannon.py:43-72 in the product's DSL -- an ODE with a PARAMETER (the ball's radius); the oracle holds it as
+    `cannon` (oracle/odes.h)."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+    k = cannon_constants()
+
+    class Cannon(ODEBase):
+        def __init__(self):
+            a = ODEArguments(4, 0, 1)
+            v, gamma, h, r = a.XVec().tolist()
+            rad = a.PVar(0)
+            S = np.pi * (rad * rad)
+            M = (4.0 / 3.0) * (np.pi * k["RhoIron"]) * (rad * rad * rad)
+            rho = k["RhoAir"] * vf.exp(-1.0 * h / k["h_scale"])
+            D = (0.5 * k["CD"]) * rho * (v * v) * S
+            rates = [-1.0 * D / M - k["g"] * vf.sin(gamma), -1.0 * k["g"] * vf.cos(gamma) / v, v * vf.sin(gamma), v * vf.cos(gamma)]
+            super().__init__(vf.stack(rates), 4, 0, 1, name="cannon")
+
+    return Cannon()
+
+
+def cannon_energy():
+    """(E(v, rad) - E0) / 100 <= 0 at the muzzle (EFunc() * .01, test_MultiPhaseCannon.py:75-79,131); the oracle's `cannon_energy`."""
+    from asset_asrl_amd import vf
+    k = cannon_constants()
+    v, rad = vf.Arguments(2).tolist()
+    M = (4.0 / 3.0) * (np.pi * k["RhoIron"]) * (rad * rad * rad)
+    return vf.stack([(0.5 * M * (v * v) - k["E0"]) * 0.01])
+
+
+def _cannon_rhs(y):
+    k = cannon_constants()
+    v, gamma, h, r, t, rad = y
+    M = (4.0 / 3.0) * np.pi * k["RhoIron"] * rad ** 3
+    D = 0.5 * k["CD"] * k["RhoAir"] * np.exp(-h / k["h_scale"]) * v * v * np.pi * rad * rad
+    return np.array([-D / M - k["g"] * np.sin(gamma), -k["g"] * np.cos(gamma) / v, v * np.sin(gamma), v * np.cos(gamma), 1.0, 0.0])
+
+
+def _rk4_until(y0, tmax, stop, dt=1e-3):
+    """the initial guess only (the reference integrates it with its adaptive integrator, :107-116): classical RK4 until `stop`"""
+    out, y = [np.array(y0, dtype=float)], np.array(y0, dtype=float)
+    while y[4] - y0[4] < tmax:
+        k1 = _cannon_rhs(y); k2 = _cannon_rhs(y + 0.5 * dt * k1); k3 = _cannon_rhs(y + 0.5 * dt * k2); k4 = _cannon_rhs(y + dt * k3)
+        y = y + (dt / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+        out.append(y.copy())
+        if stop(y):
+            break
+    return np.array(out)
+
+
+def cannon_problem(mode: str, nseg: int):
+    """test_MultiPhaseCannon.py:89-150: TWO phases (ascent to the apex, descent to the ground) of the same ODE, linked -- the ball's
+    radius is an ODE parameter of each phase, the two tied by a direct link; maximise the range for a bounded muzzle energy.
+    -> a problem of two `parts` in one solver vector: the second phase's variables and equality rows start behind the first's
+    (Phase.layout(Vstart, Estart): transcribe_phase(Vstart, Estart, ...), OptimalControlProblem.cpp:131-146).  The links
+    (addForwardLinkEqualCon / addDirectLinkEqualCon: linear) live in the harness as `linear_rows`; the muzzle-energy bound is a
+    user function of the assembly (slack row)."""
+    k = cannon_constants()
+    Lstar, Tstar = k["Lstar"], k["Tstar"]
+    rad0, h0, r0, gamma0 = 0.1 / Lstar, 100.0 / Lstar, 0.0, np.deg2rad(45.0)
+    m0 = (4.0 / 3.0) * np.pi * k["RhoIron"] * rad0 ** 3
+    v0 = np.sqrt(2 * k["E0"] / m0) * 0.99
+    asc = _rk4_until([v0, gamma0, h0, r0, 0.0, rad0], 60.0 / Tstar, lambda y: y[0] * np.sin(y[1]) < 0)
+    des = _rk4_until(asc[-1], 30.0 / Tstar, lambda y: y[2] < 0)
+    ode = cannon_ode()
+    pa = ode.phase(mode, asc, nseg)
+    pa.addEqualCon("Front", cannon_energy(), [0], [0])          # addInequalCon("Front", EFunc() * .01, [0], [0], []): a slack row
+    pd = ode.phase(mode, des, nseg)
+    ia, (Va, Ca), ea, na_eq, _ = pa.layout()
+    xa = ia.makeSolverInput(pa.ActiveTraj)
+    idd, (Vd, Cd), ed, nd_eq, _ = pd.layout(Vstart=xa.size, Estart=na_eq)
+    xd = idd.makeSolverInput(pd.ActiveTraj)
+    x0 = np.concatenate([xa, xd])
+    n = x0.size
+    lb, ub, cost = np.full(n, -np.inf), np.full(n, np.inf), np.zeros(n)
+    Sa, Sd = ia.numStates, idd.numStates
+    rad_a, rad_d = ia.var_offset + ia.ODEParamLoc0, idd.var_offset + idd.ODEParamLoc0
+    lb[rad_a] = 0.01 / Lstar                                    # aphase.addLowerVarBound("ODEParams", 0, 0.01 / Lstar)
+    lb[ia.getXTUVarLoc(1, 0)] = 0.0                             # aphase.addLowerVarBound("Front", 1, 0.0)
+    for v, val in ((2, h0), (3, r0), (4, 0.0)):                 # aphase.addBoundaryValue("Front", [2, 3, 4], [h0, r0, 0])
+        lb[ia.getXTUVarLoc(v, 0)] = ub[ia.getXTUVarLoc(v, 0)] = val
+    lb[ia.getXTUVarLoc(1, Sa - 1)] = ub[ia.getXTUVarLoc(1, Sa - 1)] = 0.0      # aphase.addBoundaryValue("Back", [1], [0.0])
+    lb[idd.getXTUVarLoc(2, Sd - 1)] = ub[idd.getXTUVarLoc(2, Sd - 1)] = 0.0    # dphase.addBoundaryValue("Back", [2], [0.0])
+    cost[idd.getXTUVarLoc(3, Sd - 1)] = -1.0                    # dphase.addValueObjective("Back", 3, -1.0)
+    rows = [(ia.getXTUVarLoc(v, Sa - 1), idd.getXTUVarLoc(v, 0)) for v in range(5)] + [(rad_a, rad_d)]   # the two links
+    A = sp.csr_matrix((np.tile([1.0, -1.0], len(rows)), (np.repeat(np.arange(len(rows)), 2), np.ravel(rows))), shape=(len(rows), n))
+    slack_rows = np.concatenate([e[5].ravel() for e in ea if e[0] == "equality"])
+    parts = [dict(phase=pa, ix=ia, V=Va, Cx=Ca, entries=ea, ode_name="cannon", functions={"eq0": "cannon_energy"}),
+             dict(phase=pd, ix=idd, V=Vd, Cx=Cd, entries=ed, ode_name="cannon", functions={})]
+    var_scale = np.ones(n)
+    var_scale[[rad_a, rad_d]] = rad0
+    return dict(parts=parts, x0=x0, lb=lb, ub=ub, cost=cost, n_equal=na_eq + nd_eq, slack_rows=slack_rows,
+                linear_rows=(A, np.zeros(len(rows))), objective_scale=Lstar, var_scale=var_scale)
+
+
+class LinearRows:
+    """Appends linear equality rows A x = b (the links between phases) to an assembly: multipliers behind the inner ones."""
+
+    def __init__(self, inner, A, b):
+        self.inner, self.A, self.b, self.n, self.mi = inner, sp.csr_matrix(A), np.asarray(b, dtype=float), inner.n, inner.m
+        self.m = inner.m + self.A.shape[0]
+
+    def kkt(self, x, lam):
+        c, agx, W, J = self.inner.kkt(x, lam[:self.mi])
+        return (np.concatenate([c, self.A @ x - self.b]), agx + self.A.T @ lam[self.mi:], W, sp.vstack([J, self.A], format="csr"))
+
+    def con(self, x):
+        return np.concatenate([self.inner.con(x), self.A @ x - self.b])
+
+
+class ScaledVars:
+    """The assembly in scaled variables x = s * xs (a harness-level diagonal scaling: the cannon ball's radius is 1e-4 in the
+    problem's units, the other variables O(1) -- PSIOPT's own scaling is not part of this loop)."""
+
+    def __init__(self, inner, scale):
+        self.inner, self.s, self.n, self.m = inner, np.asarray(scale, dtype=float), inner.n, inner.m
+        self.D = sp.diags(self.s)
+
+    def kkt(self, xs, lam):
+        c, agx, W, J = self.inner.kkt(self.s * xs, lam)
+        return c, self.s * agx, (self.D @ W @ self.D).tocsr(), (J @ self.D).tocsr()
+
+    def con(self, xs):
+        return self.inner.con(self.s * xs)
+
+
 class SlackRows:
     """Turns rows of an equality-only assembly into inequalities g(x) <= 0: variables [x ; s], rows g(x) + s = 0, s >= 0."""
 
@@ -217,31 +353,33 @@ class CsrKkt:
 
 
 class OracleProvider:
-    """The oracle's restatement of NonLinearProgram (oracle/fullnlp.cpp) as the assembly: the CPU path."""
+    """The oracle's restatement of NonLinearProgram (oracle/fullnlp.cpp) as the assembly: the CPU path.  A problem is one phase
+    (the dict itself) or several `parts` sharing the solver vector."""
 
     def __init__(self, ob, prob):
         from asset_asrl_amd import synth
-        ph, ix = prob["phase"], prob["ix"]
         n, m = prob["x0"].size, prob["n_equal"]
         nlp = ob.FullNlp(n, m, 0)
-        nlp.add(1, ob.get_ode(prob.get("ode_name", "reentry"), 0), ob.MODES[ph.TranscriptionMode], ix.BlockedControls, prob["V"],
-                prob["Cx"])
-        cs = synth.MODE_CS[ph.TranscriptionMode]
-        for kind, tag, F, name, V, Cx, consts in prob["entries"]:
-            if tag == "mesh_spacing":
-                nlp.add_mesh_spacing(1, cs, V, Cx)
-            elif tag == "nodal_spacing":
-                nlp.add_single_mesh_spacing(1, consts.ravel(), V, Cx)
-            elif tag == "control_spline":
-                nlp.add_control_spline(1, cs, prob.get("usize", 2), V, Cx)
-            elif tag == "eq0":                                   # the heating-rate bound (reentry_problem(heating=True))
-                nlp.add(1, ob.get_ode("reentry_heating", 0), ob.MODES["Function"], False, V, Cx)
-            elif kind == "objective":                            # an integral objective: the segment quadrature of an integrand
-                name, nx = prob["integrands"][tag]
-                nlp.add_integral(0, ob.get_ode(name, 0), cs, nx, 0, V, Cx)
-                self.has_objective = True
-            else:
-                raise ValueError(tag)
+        for part in prob.get("parts", [prob]):
+            ph, ix = part["phase"], part["ix"]
+            nlp.add(1, ob.get_ode(part.get("ode_name", "reentry"), 0), ob.MODES[ph.TranscriptionMode], ix.BlockedControls, part["V"],
+                    part["Cx"])
+            cs = synth.MODE_CS[ph.TranscriptionMode]
+            for kind, tag, F, name, V, Cx, consts in part["entries"]:
+                if tag == "mesh_spacing":
+                    nlp.add_mesh_spacing(1, cs, V, Cx)
+                elif tag == "nodal_spacing":
+                    nlp.add_single_mesh_spacing(1, consts.ravel(), V, Cx)
+                elif tag == "control_spline":
+                    nlp.add_control_spline(1, cs, part.get("usize", 2), V, Cx)
+                elif kind == "objective":                        # an integral objective: the segment quadrature of an integrand
+                    name, nx = part["integrands"][tag]
+                    nlp.add_integral(0, ob.get_ode(name, 0), cs, nx, 0, V, Cx)
+                    self.has_objective = True
+                elif kind == "equality":                         # a user function (the heating-rate bound, the muzzle-energy bound)
+                    nlp.add(1, ob.get_ode(part.get("functions", {"eq0": "reentry_heating"})[tag], 0), ob.MODES["Function"], False, V, Cx)
+                else:
+                    raise ValueError(tag)
         nlp.analyze()
         nlp.set_solver_coeffs(np.zeros(nlp.num_solver_kkt))
         self.nlp, self.n, self.m = nlp, n, m
@@ -268,7 +406,8 @@ class OracleProvider:
 
 
 # ---------------------------------------------------------------------------------------------- the loop
-def solve_ip(provider, x0, lb, ub, cost, tol=1e-7, maxit=400, mu=0.1, verbose=False, feasibility=False, step_cap=1.0):
+def solve_ip(provider, x0, lb, ub, cost, tol=1e-7, maxit=400, mu=0.1, verbose=False, feasibility=False, step_cap=1.0,
+             relative_push=False):
     """min cost.x  s.t. c(x) = 0, lb <= x <= ub (lb == ub: fixed).  -> (x, lam, info).  Primal-dual barrier Newton
     steps on the KKT system [W + Sigma + dw I, J^T; J, 0]: dw is raised until the step has positive curvature (the
     inertia-free test) and is no longer than step_cap; the step length is found by backtracking against a filter on
@@ -283,8 +422,12 @@ def solve_ip(provider, x0, lb, ub, cost, tol=1e-7, maxit=400, mu=0.1, verbose=Fa
     free = np.flatnonzero(~fixed)
     hasl, hasu = np.isfinite(lb) & ~fixed, np.isfinite(ub) & ~fixed
     gap = np.where(np.isfinite(ub - lb), 1e-2 * (ub - lb), 1e-2)   # push the start into the interior
-    x = np.where(hasl, np.maximum(x, lb + gap), x)
-    x = np.where(hasu, np.minimum(x, ub - gap), x)
+    if relative_push:   # a variable much smaller than 1e-2 that sits inside its bound stays where it is (the cannon ball's radius)
+        gl_, gu_ = np.where(x > lb, np.minimum(gap, 0.5 * (x - lb)), gap), np.where(x < ub, np.minimum(gap, 0.5 * (ub - x)), gap)
+    else:
+        gl_, gu_ = gap, gap
+    x = np.where(hasl, np.maximum(x, lb + gl_), x)
+    x = np.where(hasu, np.minimum(x, ub - gu_), x)
     m, nf = provider.m, free.size
     lam = np.zeros(m)
     sl = lambda v: np.where(hasl, v - lb, 1.0)
@@ -394,6 +537,30 @@ def solve_reentry(provider, prob, verbose=False, x0=None):
     return x[:prob["x0"].size], lam, info
 
 
+def solve_linked(provider, prob, verbose=False, feasibility_first=False, **kw):
+    """ocp.optimize() of a problem with slack rows and linear link rows (the two-phase cannon).  -> (x, lam, info)."""
+    rows, (A, b) = prob["slack_rows"], prob["linear_rows"]
+    lb, ub, cost, xs = prob["lb"], prob["ub"], prob["cost"], prob["x0"]
+    n = xs.size
+    sc = prob.get("var_scale")
+    if sc is not None:
+        provider = ScaledVars(provider, sc)
+        lb, ub, cost, xs, A = lb / sc, ub / sc, cost * sc, xs / sc, sp.csr_matrix(A) @ sp.diags(sc)
+    if len(rows):
+        g = provider.con(xs)[rows]
+        provider = SlackRows(provider, rows)
+        xs = np.concatenate([xs, np.maximum(-g, 1e-2)])
+        lb, ub = np.concatenate([lb, np.zeros(len(rows))]), np.concatenate([ub, np.full(len(rows), np.inf)])
+        cost = np.concatenate([cost, np.zeros(len(rows))])
+        A = sp.hstack([A, sp.csr_matrix((A.shape[0], len(rows)))], format="csr")
+    provider = LinearRows(provider, A, b)
+    if feasibility_first:
+        xs, _, _ = solve_ip(provider, xs, lb, ub, cost, feasibility=True, mu=1e-6, verbose=verbose, relative_push=kw.get("relative_push", False))
+    x, lam, info = solve_ip(provider, xs, lb, ub, cost, verbose=verbose, **kw)
+    info["feasible"] = bool(np.abs(provider.con(x)).max() < 1e-6)
+    return (x[:n] if sc is None else sc * x[:n]), lam, info
+
+
 def solve_optimize_only(provider, prob, verbose=False, **kw):
     """phase.optimize() from the initial guess, as test_CartPole.py:71 does (no feasibility stage).  -> (x, lam, info)."""
     x, lam, info = solve_ip(provider, prob["x0"], prob["lb"], prob["ub"], prob["cost"], verbose=verbose, **kw)
@@ -408,19 +575,20 @@ class DeviceProvider:
     def __init__(self, shim, prob):
         import ctypes as C
         from asset_asrl_amd import _lib, jit
-        ph, ix = prob["phase"], prob["ix"]
         n, m = prob["x0"].size, prob["n_equal"]
         ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
 
         class FnDesc(C.Structure):
             _fields_ = [("kind", C.c_int), ("name", C.c_char_p), ("mode", C.c_int), ("blocked", C.c_int), ("ir", C.c_int),
                         ("orr", C.c_int), ("nappl", C.c_int), ("vindex", ip), ("cindex", ip), ("consts", dp), ("nconst", C.c_int)]
-        mode_id = {"LGL3": _lib.LGL3, "LGL5": _lib.LGL5, "LGL7": _lib.LGL7, "Trapezoidal": _lib.TRAPEZOIDAL}[ph.TranscriptionMode]
-        fns = [(jit.ensure_kernel(ph.ode, ph.TranscriptionMode, ix.BlockedControls), mode_id, int(ix.BlockedControls),
-                prob["V"], prob["Cx"], None)]
-        fns = [f + (1,) for f in fns]                            # (kind 1: equality; 0: objective -- host/kkt_assembly.h)
-        fns += [(jit.ensure_function(F, name), _lib.FUNCTION, 0, V, Cx, consts, 0 if kind == "objective" else 1)
-                for kind, _, F, name, V, Cx, consts in prob["entries"]]
+        mode_ids = {"LGL3": _lib.LGL3, "LGL5": _lib.LGL5, "LGL7": _lib.LGL7, "Trapezoidal": _lib.TRAPEZOIDAL}
+        fns = []                                                 # (kind 1: equality; 0: objective -- host/kkt_assembly.h)
+        for part in prob.get("parts", [prob]):
+            ph, ix = part["phase"], part["ix"]
+            fns.append((jit.ensure_kernel(ph.ode, ph.TranscriptionMode, ix.BlockedControls), mode_ids[ph.TranscriptionMode],
+                        int(ix.BlockedControls), part["V"], part["Cx"], None, 1))
+            fns += [(jit.ensure_function(F, name), _lib.FUNCTION, 0, V, Cx, consts, 0 if kind == "objective" else 1)
+                    for kind, _, F, name, V, Cx, consts in part["entries"]]
         self.has_objective = any(f[6] == 0 for f in fns)
         self._keep, descs = [], (FnDesc * len(fns))()
         for k, (name, mode, blocked, V, Cx, consts, fkind) in enumerate(fns):
