@@ -74,6 +74,16 @@ AD2_ODE(freeflyingrobot, 6, 4, 0)
 AD2_ODE(integrand_sum4, 1, 2, 0)
 AD2_ODE(cannon, 4, 0, 1)
 AD2_ODE(cannon_energy, 1, 0, 0)
+AD2_ODE(shape_1_0_0, 1, 0, 0)
+AD2_ODE(shape_1_1_0, 1, 1, 0)
+AD2_ODE(shape_2_1_0, 2, 1, 0)
+AD2_ODE(shape_3_0_1, 3, 0, 1)
+AD2_ODE(shape_4_4_0, 4, 4, 0)
+AD2_ODE(shape_5_3_2, 5, 3, 2)
+AD2_ODE(shape_6_0_0, 6, 0, 0)
+AD2_ODE(shape_8_3_1, 8, 3, 1)
+AD2_ODE(shape_10_4_0, 10, 4, 0)
+AD2_ODE(shape_11_4_0, 11, 4, 0)
 
 }  // namespace
 
@@ -114,6 +124,16 @@ GEN_DECL(freeflyingrobot)
 GEN_DECL(integrand_sum4)
 GEN_DECL(cannon)
 GEN_DECL(cannon_energy)
+GEN_DECL(shape_1_0_0)
+GEN_DECL(shape_1_1_0)
+GEN_DECL(shape_2_1_0)
+GEN_DECL(shape_3_0_1)
+GEN_DECL(shape_4_4_0)
+GEN_DECL(shape_5_3_2)
+GEN_DECL(shape_6_0_0)
+GEN_DECL(shape_8_3_1)
+GEN_DECL(shape_10_4_0)
+GEN_DECL(shape_11_4_0)
 
 extern "C" {
 
@@ -163,6 +183,16 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(integrand_sum4)
   TRY4(cannon)
   TRY4(cannon_energy)
+  TRY4(shape_1_0_0)
+  TRY4(shape_1_1_0)
+  TRY4(shape_2_1_0)
+  TRY4(shape_3_0_1)
+  TRY4(shape_4_4_0)
+  TRY4(shape_5_3_2)
+  TRY4(shape_6_0_0)
+  TRY4(shape_8_3_1)
+  TRY4(shape_10_4_0)
+  TRY4(shape_11_4_0)
   return -1;
 }
 
@@ -190,6 +220,16 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(integrand_sum4, 1, 2, 0, nullptr)
   TRY(cannon, 4, 0, 1, nullptr)
   TRY(cannon_energy, 1, 0, 0, nullptr)
+  TRY(shape_1_0_0, 1, 0, 0, nullptr)
+  TRY(shape_1_1_0, 1, 1, 0, nullptr)
+  TRY(shape_2_1_0, 2, 1, 0, nullptr)
+  TRY(shape_3_0_1, 3, 0, 1, nullptr)
+  TRY(shape_4_4_0, 4, 4, 0, nullptr)
+  TRY(shape_5_3_2, 5, 3, 2, nullptr)
+  TRY(shape_6_0_0, 6, 0, 0, nullptr)
+  TRY(shape_8_3_1, 8, 3, 1, nullptr)
+  TRY(shape_10_4_0, 10, 4, 0, nullptr)
+  TRY(shape_11_4_0, 11, 4, 0, nullptr)
   return -1;
 }
 }

@@ -76,6 +76,40 @@ void driven14(const S* y, S* f, const void*) { driven_n<14>(y, f); }
 template <class S>
 void driven20(const S* y, S* f, const void*) { driven_n<20>(y, f); }
 
+// ------------------------------------------------------------------ a family of shapes (n, m, p) for the narrow kernels
+// Not BASELINE configs: one smooth right-hand side for ANY (states, controls, parameters), so that run-time compiled ODEs of
+// unusual dimensions -- one state, no controls, node strides that are / are not multiples of four, N + 1 = 16 and 17, two row
+// groups of defect rows -- reach every narrow dense-part form (csrc/defect_resident.h tile form, csrc/defect_rowdpp.h row form,
+// the fallback of csrc/defect_kernels.h).  tests/helpers.py: make_shape(n, m, p) defines the same right-hand side in the DSL.
+//   x_k' = -x_k/2 + sin(x_{k+1}) x_{k+2} [u_{k mod m}] + 0.3 cos(t) x_{k+3} [+ 0.1 u_{(k+1) mod m}^2] [+ p_0 x_k x_{k+1} + p_{p-1} cos t]
+template <int n, int m, int p, class S>
+void shape_nmp(const S* y, S* f) {
+  const S& t = y[n];
+  const S* u = y + n + 1;
+  const S* par = y + n + 1 + m;
+  for (int k = 0; k < n; k++) {
+    S v = sin(y[(k + 1) % n]) * y[(k + 2) % n];
+    if (m > 0) v = v * u[k % (m > 0 ? m : 1)];
+    v = v - 0.5 * y[k] + 0.3 * cos(t) * y[(k + 3) % n];
+    if (m > 0) v = v + 0.1 * u[(k + 1) % (m > 0 ? m : 1)] * u[(k + 1) % (m > 0 ? m : 1)];
+    if (p > 0) v = v + par[0] * y[k] * y[(k + 1) % n] + par[p > 0 ? p - 1 : 0] * cos(t);
+    f[k] = v;
+  }
+}
+#define ORACLE_SHAPE_ODE(n, m, p) \
+  template <class S>              \
+  void shape_##n##_##m##_##p(const S* y, S* f, const void*) { shape_nmp<n, m, p>(y, f); }
+ORACLE_SHAPE_ODE(1, 0, 0)
+ORACLE_SHAPE_ODE(1, 1, 0)
+ORACLE_SHAPE_ODE(2, 1, 0)
+ORACLE_SHAPE_ODE(3, 0, 1)
+ORACLE_SHAPE_ODE(4, 4, 0)
+ORACLE_SHAPE_ODE(5, 3, 2)
+ORACLE_SHAPE_ODE(6, 0, 0)
+ORACLE_SHAPE_ODE(8, 3, 1)
+ORACLE_SHAPE_ODE(10, 4, 0)
+ORACLE_SHAPE_ODE(11, 4, 0)
+
 // ------------------------------------------------------------------ a nonlinear path constraint, 2 outputs of 6 inputs
 // Not an ODE: the independent check for plain functions batched over applications (mode FUNCTION);
 // tests/test_gpu_function.py defines the same function in the product's expression DSL.

@@ -105,6 +105,39 @@ def make_driven(n: int = 14):
     return Driven()
 
 
+SHAPES = [(1, 0, 0), (1, 1, 0), (2, 1, 0), (3, 0, 1), (4, 4, 0), (5, 3, 2), (6, 0, 0), (8, 3, 1), (10, 4, 0), (11, 4, 0)]
+
+
+def make_shape(n: int, m: int, p: int):
+    """One smooth right-hand side for any (states, controls, parameters) -- the oracle holds the members of SHAPES as
+    ``shape_n_m_p`` (oracle/odes.h: shape_nmp):
+      x_k' = -x_k/2 + sin(x_{k+1}) x_{k+2} [u_{k mod m}] + 0.3 cos(t) x_{k+3} [+ 0.1 u_{(k+1) mod m}^2] [+ p_0 x_k x_{k+1} + p_{p-1} cos t]"""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+
+    class Shape(ODEBase):
+        def __init__(self):
+            a = ODEArguments(n, m, p)
+            x = a.XVec().tolist() if n > 1 else [a.XVar(0)]
+            t = a.TVar()
+            u = [a.UVar(k) for k in range(m)]
+            par = [a.PVar(k) for k in range(p)]
+            rhs = []
+            for k in range(n):
+                v = vf.sin(x[(k + 1) % n]) * x[(k + 2) % n]
+                if m > 0:
+                    v = v * u[k % m]
+                v = v - 0.5 * x[k] + 0.3 * vf.cos(t) * x[(k + 3) % n]
+                if m > 0:
+                    v = v + 0.1 * u[(k + 1) % m] * u[(k + 1) % m]
+                if p > 0:
+                    v = v + par[0] * x[k] * x[(k + 1) % n] + par[p - 1] * vf.cos(t)
+                rhs.append(v)
+            super().__init__(vf.stack(rhs), n, m, p, name=f"shape_{n}_{m}_{p}")
+
+    return Shape()
+
+
 class FullProblem:
     """One Reentry LGL5 phase with everything a phase can hand the solver: the defect equality, a path equality at every
     state, the mesh-spacing equality of every segment, a pair-wise path inequality between neighbouring states and an
