@@ -74,6 +74,12 @@ AD2_ODE(freeflyingrobot, 6, 4, 0)
 AD2_ODE(integrand_sum4, 1, 2, 0)
 AD2_ODE(cannon, 4, 0, 1)
 AD2_ODE(cannon_energy, 1, 0, 0)
+AD2_ODE(delta3_1, 7, 3, 0)
+AD2_ODE(delta3_2, 7, 3, 0)
+AD2_ODE(delta3_3, 7, 3, 0)
+AD2_ODE(delta3_4, 7, 3, 0)
+AD2_ODE(norm3, 1, 1, 0)
+AD2_ODE(delta3_orbit, 5, 0, 0)
 AD2_ODE(shape_1_0_0, 1, 0, 0)
 AD2_ODE(shape_1_1_0, 1, 1, 0)
 AD2_ODE(shape_2_1_0, 2, 1, 0)
@@ -124,6 +130,12 @@ GEN_DECL(freeflyingrobot)
 GEN_DECL(integrand_sum4)
 GEN_DECL(cannon)
 GEN_DECL(cannon_energy)
+GEN_DECL(delta3_1)
+GEN_DECL(delta3_2)
+GEN_DECL(delta3_3)
+GEN_DECL(delta3_4)
+GEN_DECL(norm3)
+GEN_DECL(delta3_orbit)
 GEN_DECL(shape_1_0_0)
 GEN_DECL(shape_1_1_0)
 GEN_DECL(shape_2_1_0)
@@ -183,6 +195,12 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(integrand_sum4)
   TRY4(cannon)
   TRY4(cannon_energy)
+  TRY4(delta3_1)
+  TRY4(delta3_2)
+  TRY4(delta3_3)
+  TRY4(delta3_4)
+  TRY4(norm3)
+  TRY4(delta3_orbit)
   TRY4(shape_1_0_0)
   TRY4(shape_1_1_0)
   TRY4(shape_2_1_0)
@@ -220,6 +238,12 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(integrand_sum4, 1, 2, 0, nullptr)
   TRY(cannon, 4, 0, 1, nullptr)
   TRY(cannon_energy, 1, 0, 0, nullptr)
+  TRY(delta3_1, 7, 3, 0, nullptr)
+  TRY(delta3_2, 7, 3, 0, nullptr)
+  TRY(delta3_3, 7, 3, 0, nullptr)
+  TRY(delta3_4, 7, 3, 0, nullptr)
+  TRY(norm3, 1, 1, 0, nullptr)
+  TRY(delta3_orbit, 5, 0, 0, nullptr)
   TRY(shape_1_0_0, 1, 0, 0, nullptr)
   TRY(shape_1_1_0, 1, 1, 0, nullptr)
   TRY(shape_2_1_0, 2, 1, 0, nullptr)

@@ -76,6 +76,74 @@ void driven14(const S* y, S* f, const void*) { driven_n<14>(y, f); }
 template <class S>
 void driven20(const S* y, S* f, const void*) { driven_n<20>(y, f); }
 
+// ------------------------------------------------------------------ Delta III ascent (7,3,0), four stages
+// The dynamics of the reference's four-phase full-problem test (asset_asrl/test/test_FullProblems/test_Delta3Launch.py:14-131;
+// units and stage constants :16-99): y = [r(3), v(3), m, t, u(3)], thrust along u / |u|, drag in an exponential atmosphere that
+// rotates with the Earth.  delta3_<k>: stage k's thrust and mass flow.  norm3: |a| of three inputs (the control-norm and radius
+// bounds, :216-243) -- record (1, 1, 0).  delta3_orbit: the five insertion conditions on (r, v) at the end of the last phase,
+// record (5, 0, 0): semi-major axis, eccentricity, inclination, node and perigee directions.  The reference writes the last three
+// with arccos and branches (:133-157); here they are the smooth conditions with the same zero set near the solution --
+// cos i, the node line's direction, the cosine of the argument of perigee -- so that no branch has to be differentiated.
+// tests/kkt_harness.py defines all of them in the product's expression DSL.
+namespace delta3_units {
+constexpr double g0 = 9.80665, Lstar = 6378145.0, Tstar = 961.0, Mstar = 301454.0;
+constexpr double Astar = Lstar / (Tstar * Tstar), Rhostar = Mstar / (Lstar * Lstar * Lstar);
+constexpr double Mustar = (Lstar * Lstar * Lstar) / (Tstar * Tstar), Fstar = Astar * Mstar;
+constexpr double mu = 3.986012e14 / Mustar, Re = 1.0, We = 7.29211585e-5 * Tstar;
+constexpr double RhoAir = 1.225 / Rhostar, h_scale = 7200.0 / Lstar, g = g0 / Astar;
+constexpr double CD = 0.5, Sref = 4.0 * M_PI / (Lstar * Lstar);
+constexpr double TS = 628500.0 / Fstar, T1 = 1083100.0 / Fstar, T2 = 110094.0 / Fstar;
+constexpr double IS = 283.33364 / Tstar, I1 = 301.68 / Tstar, I2 = 467.21 / Tstar;
+constexpr double thrust[4] = {6 * TS + T1, 3 * TS + T1, T1, T2};
+constexpr double mdot[4] = {(6 * TS / IS + T1 / I1) / g, (3 * TS / IS + T1 / I1) / g, T1 / (g * I1), T2 / (g * I2)};
+}  // namespace delta3_units
+template <int PH, class S>
+void delta3_stage(const S* y, S* f) {
+  using namespace delta3_units;
+  const S *r = y, *v = y + 3, *u = y + 8;
+  const S& m = y[6];
+  const S rn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const S un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+  const S rho = RhoAir * exp(-1.0 * (rn - Re) / h_scale);
+  // vr = v + r x [0, 0, We]
+  const S vr[3] = {v[0] + r[1] * We, v[1] - r[0] * We, v[2]};
+  const S vrn = sqrt(vr[0] * vr[0] + vr[1] * vr[1] + vr[2] * vr[2]);
+  const S r3 = rn * rn * rn;
+  for (int k = 0; k < 3; k++) {
+    f[k] = v[k];
+    const S D = (-0.5 * CD * Sref) * rho * (vr[k] * vrn);
+    f[3 + k] = (-1.0 * mu) * r[k] / r3 + (thrust[PH] * (u[k] / un) + D) / m;
+  }
+  f[6] = 0.0 * m - mdot[PH];
+}
+template <class S> void delta3_1(const S* y, S* f, const void*) { delta3_stage<0>(y, f); }
+template <class S> void delta3_2(const S* y, S* f, const void*) { delta3_stage<1>(y, f); }
+template <class S> void delta3_3(const S* y, S* f, const void*) { delta3_stage<2>(y, f); }
+template <class S> void delta3_4(const S* y, S* f, const void*) { delta3_stage<3>(y, f); }
+template <class S>
+void norm3(const S* y, S* f, const void*) { f[0] = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]); }
+template <class S>
+void delta3_orbit(const S* y, S* f, const void*) {
+  using namespace delta3_units;
+  const double at = 24361140.0 / Lstar, et = 0.7308, it = 28.5 * M_PI / 180.0, Ot = 269.8 * M_PI / 180.0, Wt = 130.5 * M_PI / 180.0;
+  const S *r = y, *v = y + 3;
+  const S h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
+  const S rn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const S v2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  const S hn = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+  // evec = v x h / mu - r / |r|
+  const S e[3] = {(v[1] * h[2] - v[2] * h[1]) / mu - r[0] / rn, (v[2] * h[0] - v[0] * h[2]) / mu - r[1] / rn,
+                  (v[0] * h[1] - v[1] * h[0]) / mu - r[2] / rn};
+  const S en = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  const S nx = -1.0 * h[1], ny = h[0];                      // node line z x h
+  const S nn = sqrt(nx * nx + ny * ny);
+  f[0] = -0.5 * mu / (0.5 * v2 - mu / rn) - at;
+  f[1] = en - et;
+  f[2] = h[2] / hn - std::cos(it);
+  f[3] = (nx * std::sin(Ot) - ny * std::cos(Ot)) / nn;
+  f[4] = (nx * e[0] + ny * e[1]) / (nn * en) - std::cos(Wt);
+}
+
 // ------------------------------------------------------------------ a family of shapes (n, m, p) for the narrow kernels
 // Not BASELINE configs: one smooth right-hand side for ANY (states, controls, parameters), so that run-time compiled ODEs of
 // unusual dimensions -- one state, no controls, node strides that are / are not multiples of four, N + 1 = 16 and 17, two row

@@ -301,6 +301,166 @@ class LinearRows:
         return np.concatenate([self.inner.con(x), self.A @ x - self.b])
 
 
+def delta3_constants():
+    """test_Delta3Launch.py:16-99 (non-dimensional: Earth radius, first-stage burn time, lift-off mass)"""
+    g0, Lstar, Tstar, Mstar = 9.80665, 6378145.0, 961.0, 301454.0
+    Astar, Rhostar = Lstar / Tstar ** 2, Mstar / Lstar ** 3
+    Mustar, Fstar = Lstar ** 3 / Tstar ** 2, Lstar / Tstar ** 2 * Mstar
+    k = dict(Lstar=Lstar, Tstar=Tstar, Mstar=Mstar, Vstar=Lstar / Tstar, mu=3.986012e14 / Mustar, Re=1.0, We=7.29211585e-5 * Tstar,
+             RhoAir=1.225 / Rhostar, h_scale=7200.0 / Lstar, g=g0 / Astar, CD=0.5, S=4 * np.pi / Lstar ** 2)
+    TS, T1, T2 = 628500.0 / Fstar, 1083100.0 / Fstar, 110094.0 / Fstar
+    IS, I1, I2 = 283.33364 / Tstar, 301.68 / Tstar, 467.21 / Tstar
+    tS, t1, t2 = 75.2 / Tstar, 261.0 / Tstar, 700.0 / Tstar
+    TMS, TM1, TM2, TMPay = 19290.0 / Mstar, 104380.0 / Mstar, 19300.0 / Mstar, 4164.0 / Mstar
+    PMS, PM1, PM2 = 17010.0 / Mstar, 95550.0 / Mstar, 16820.0 / Mstar
+    SMS, SM1 = TMS - PMS, TM1 - PM1
+    k["thrust"] = [6 * TS + T1, 3 * TS + T1, T1, T2]
+    k["mdot"] = [(6 * TS / IS + T1 / I1) / k["g"], (3 * TS / IS + T1 / I1) / k["g"], T1 / (k["g"] * I1), T2 / (k["g"] * I2)]
+    k["tf"] = [tS, 2 * tS, t1, t1 + t2]
+    m01 = 9 * TMS + TM1 + TM2 + TMPay
+    mf1 = m01 - 6 * PMS - (tS / t1) * PM1
+    m02 = mf1 - 6 * SMS
+    mf2 = m02 - 3 * PMS - (tS / t1) * PM1
+    m03 = mf2 - 3 * SMS
+    mf3 = m03 - (1 - 2 * tS / t1) * PM1
+    m04 = mf3 - SM1
+    k["m0"], k["mf"] = [m01, m02, m03, m04], [mf1, mf2, mf3, m04 - PM2]
+    return k
+
+
+def delta3_ode(stage: int):
+    """test_Delta3Launch.py:104-131 in the product's DSL: stage `stage`'s thrust and mass flow; the oracle's `delta3_<stage + 1>`."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+    k = delta3_constants()
+    T, mdot = k["thrust"][stage], k["mdot"][stage]
+
+    class Delta3(ODEBase):
+        def __init__(self):
+            a = ODEArguments(7, 3)
+            X = a.XVec()
+            r, v, m = X.head3(), X.segment3(3), a.XVar(6)
+            u = a.UVec().normalized()
+            rho = k["RhoAir"] * vf.exp(-1.0 * (r.norm() - k["Re"]) / k["h_scale"])
+            vr = v + r.cross(np.array([0.0, 0.0, k["We"]]))
+            D = (-0.5 * k["CD"] * k["S"]) * rho * (vr * vr.norm())
+            vdot = (-k["mu"]) * r.normalized_power3() + (T * u + D) / m
+            super().__init__(vf.stack(v, vdot, 0.0 * m - mdot), 7, 3, 0, name=f"delta3_{stage + 1}")
+
+    return Delta3()
+
+
+def delta3_orbit():
+    """The five insertion conditions of test_Delta3Launch.py:133-157 as smooth functions with the same zero set near the solution (no
+    arccos, no branch): a - at, |e| - et, cos i - cos it, the node line's direction, the cosine of the argument of perigee; the
+    oracle's `delta3_orbit`."""
+    from asset_asrl_amd import vf
+    k = delta3_constants()
+    at, et, it, Ot, Wt = 24361140.0 / k["Lstar"], 0.7308, np.deg2rad(28.5), np.deg2rad(269.8), np.deg2rad(130.5)
+    a = vf.Arguments(6)
+    r, v = a.head3(), a.tail3()
+    h = r.cross(v)
+    e = v.cross(h) / k["mu"] - r.normalized()
+    nx, ny = -1.0 * h[1], h[0]
+    nn = (nx * nx + ny * ny).sqrt()
+    eps = 0.5 * v.squared_norm() - k["mu"] / r.norm()
+    return vf.stack([-0.5 * k["mu"] / eps - at, e.norm() - et, h[2] / h.norm() - np.cos(it),
+                     (nx * np.sin(Ot) - ny * np.cos(Ot)) / nn, (nx * e[0] + ny * e[1]) / (nn * e.norm()) - np.cos(Wt)])
+
+
+def _classic_to_cartesian(oe, mu):
+    """(a, e, i, Omega, omega, M) -> [r, v] (the initial guess only: Astro.classic_to_cartesian, test_Delta3Launch.py:179)"""
+    a, e, i, Om, w, M = oe
+    E = M
+    for _ in range(50):
+        E -= (E - e * np.sin(E) - M) / (1 - e * np.cos(E))
+    nu = 2 * np.arctan2(np.sqrt(1 + e) * np.sin(E / 2), np.sqrt(1 - e) * np.cos(E / 2))
+    p = a * (1 - e * e)
+    rp = p / (1 + e * np.cos(nu)) * np.array([np.cos(nu), np.sin(nu), 0.0])
+    vp = np.sqrt(mu / p) * np.array([-np.sin(nu), e + np.cos(nu), 0.0])
+    R3 = lambda t: np.array([[np.cos(t), -np.sin(t), 0], [np.sin(t), np.cos(t), 0], [0, 0, 1.0]])
+    R1 = lambda t: np.array([[1.0, 0, 0], [0, np.cos(t), -np.sin(t)], [0, np.sin(t), np.cos(t)]])
+    Q = R3(Om) @ R1(i) @ R3(w)
+    return np.concatenate([Q @ rp, Q @ vp])
+
+
+def delta3_problem(mode: str, control: str, npts: int, warm=None):
+    """test_Delta3Launch.py:164-262: FOUR phases (the burns between the jettison events), each its own ODE object, linked in
+    position, velocity, time and thrust direction; stage masses fixed at the front of each phase; maximise the mass at the end of
+    the last; the target orbit's five conditions at its end; |u| in [0.5, 1.5] and |r| >= 0.999999 Re at every state."""
+    from asset_asrl_amd import vf
+    k = delta3_constants()
+    at, et, Ot, Wt, istart = 24361140.0 / k["Lstar"], 0.7308, np.deg2rad(269.8), np.deg2rad(130.5), np.deg2rad(28.5)
+    y0 = np.zeros(6)
+    y0[:3] = np.array([np.cos(istart), 0.0, np.sin(istart)]) * k["Re"]
+    y0[3:] = -np.cross(y0[:3], [0.0, 0.0, k["We"]])
+    y0[3] += 0.0001 / k["Vstar"]
+    yf = _classic_to_cartesian([at, et, istart, Ot, Wt, -0.05], k["mu"])
+    tf, m0, mf = k["tf"], k["m0"], k["mf"]
+    igs = [[], [], [], []]
+    for t in np.linspace(0, tf[3], npts):
+        ph = next((j for j in range(4) if t < tf[j]), None)
+        if ph is None:
+            continue
+        X = np.zeros(11)
+        X[:6] = y0 + (yf - y0) * (t / tf[3])
+        t_lo = 0.0 if ph == 0 else tf[ph - 1]
+        X[6] = m0[ph] + (mf[ph] - m0[ph]) * ((t - t_lo) / (tf[ph] - t_lo))
+        X[7], X[8] = t, 1.0
+        igs[ph].append(X)
+    if warm is not None:       # (a converged solution of another transcription on the same mesh, per phase: (problem, x))
+        wp, wx = warm
+        igs = [part["ix"].collectSolverOutput(wx[part["ix"].var_offset:part["ix"].var_offset + part["ix"].numPhaseVars])[0]
+               for part in wp["parts"]]
+    a3 = vf.Arguments(3)
+    nsegs = [len(g) - 1 for g in igs] if warm is None else [part["ix"].numDefects for part in warm[0]["parts"]]
+    first = [np.array(g[0]) for g in igs]
+    parts, xs, nvar, nrow = [], [], 0, 0
+    for j in range(4):
+        ph = delta3_ode(j).phase(mode, np.array(igs[j]), nsegs[j])
+        ph.setControlMode(control)
+        ph.addEqualCon("Path", vf.stack([a3.norm()]), [8, 9, 10])       # addLUNormBound("Path", [8, 9, 10], .5, 1.5): slack rows
+        ph.addEqualCon("Path", vf.stack([a3.norm()]), [0, 1, 2])        # addLowerNormBound("Path", [0, 1, 2], Re * .999999)
+        fmap = {"eq0": "norm3", "eq1": "norm3"}
+        if j == 3:
+            ph.addEqualCon("Back", delta3_orbit(), range(6))            # addEqualCon("Back", TargetOrbit(...), range(0, 6))
+            fmap["eq2"] = "delta3_orbit"
+        ix, (V, Cx), entries, neq, _ = ph.layout(Vstart=nvar, Estart=nrow)
+        x = ix.makeSolverInput(ph.ActiveTraj)
+        parts.append(dict(phase=ph, ix=ix, V=V, Cx=Cx, entries=entries, ode_name=f"delta3_{j + 1}", functions=fmap, usize=3))
+        xs.append(x)
+        nvar, nrow = nvar + x.size, nrow + neq
+    x0 = np.concatenate(xs)
+    n = x0.size
+    lb, ub, cost = np.full(n, -np.inf), np.full(n, np.inf), np.zeros(n)
+    fix = lambda loc, val: (lb.__setitem__(loc, val), ub.__setitem__(loc, val))
+    ix1, ix4 = parts[0]["ix"], parts[3]["ix"]
+    for v in range(8):                                                  # phase1.addBoundaryValue("Front", range(0, 8), IG1[0][0:8])
+        fix(ix1.getXTUVarLoc(v, 0), first[0][v])
+    for j in range(3):                                                  # addBoundaryValue("Back", [7], [tf_phase])
+        fix(parts[j]["ix"].getXTUVarLoc(7, parts[j]["ix"].numStates - 1), tf[j])
+    for j in range(1, 4):                                               # addBoundaryValue("Front", [6], [m0_phase])
+        fix(parts[j]["ix"].getXTUVarLoc(6, 0), m0[j])
+    ub[ix4.getXTUVarLoc(7, ix4.numStates - 1)] = tf[3]                  # phase4.addUpperVarBound("Back", 7, tf_phase4)
+    cost[ix4.getXTUVarLoc(6, ix4.numStates - 1)] = -1.0                 # phase4.addValueObjective("Back", 6, -1.0)
+    links = []                                                          # ocp.addForwardLinkEqualCon(phase1, phase4, [0..5, 7, 8, 9, 10])
+    for j in range(3):
+        ia, ib = parts[j]["ix"], parts[j + 1]["ix"]
+        links += [(ia.getXTUVarLoc(v, ia.numStates - 1), ib.getXTUVarLoc(v, 0)) for v in (0, 1, 2, 3, 4, 5, 7, 8, 9, 10)]
+    A = sp.csr_matrix((np.tile([1.0, -1.0], len(links)), (np.repeat(np.arange(len(links)), 2), np.ravel(links))), shape=(len(links), n))
+    srows, slo, shi = [], [], []
+    for part in parts:                                                  # g(x) + s = 0:  s in [-1.5, -0.5] / s <= -0.999999 Re
+        for e in part["entries"]:
+            if e[1] in ("eq0", "eq1"):
+                r = e[5].ravel()
+                srows.append(r)
+                slo.append(np.full(r.size, -1.5 if e[1] == "eq0" else -np.inf))
+                shi.append(np.full(r.size, -0.5 if e[1] == "eq0" else -0.999999 * k["Re"]))
+    return dict(parts=parts, x0=x0, lb=lb, ub=ub, cost=cost, n_equal=nrow, slack_rows=np.concatenate(srows),
+                slack_bounds=(np.concatenate(slo), np.concatenate(shi)), linear_rows=(A, np.zeros(len(links))),
+                objective_scale=k["Mstar"])
+
+
 class ScaledVars:
     """The assembly in scaled variables x = s * xs (a harness-level diagonal scaling: the cannon ball's radius is 1e-4 in the
     problem's units, the other variables O(1) -- PSIOPT's own scaling is not part of this loop)."""
@@ -549,8 +709,10 @@ def solve_linked(provider, prob, verbose=False, feasibility_first=False, **kw):
     if len(rows):
         g = provider.con(xs)[rows]
         provider = SlackRows(provider, rows)
-        xs = np.concatenate([xs, np.maximum(-g, 1e-2)])
-        lb, ub = np.concatenate([lb, np.zeros(len(rows))]), np.concatenate([ub, np.full(len(rows), np.inf)])
+        slo, shi = prob.get("slack_bounds", (np.zeros(len(rows)), np.full(len(rows), np.inf)))
+        s0 = np.maximum(-g, 1e-2) if "slack_bounds" not in prob else np.clip(-g, np.where(np.isfinite(slo), slo, -np.inf), shi)
+        xs = np.concatenate([xs, s0])
+        lb, ub = np.concatenate([lb, slo]), np.concatenate([ub, shi])
         cost = np.concatenate([cost, np.zeros(len(rows))])
         A = sp.hstack([A, sp.csr_matrix((A.shape[0], len(rows)))], format="csr")
     provider = LinearRows(provider, A, b)
