@@ -74,6 +74,9 @@ AD2_ODE(freeflyingrobot, 6, 4, 0)
 AD2_ODE(integrand_sum4, 1, 2, 0)
 AD2_ODE(cannon, 4, 0, 1)
 AD2_ODE(cannon_energy, 1, 0, 0)
+AD2_ODE(integrand_lq, 1, 0, 0)
+AD2_ODE(integrand_lq_pi, 1, 0, 0)
+AD2_ODE(lq1, 1, 1, 0)
 AD2_ODE(delta3_1, 7, 3, 0)
 AD2_ODE(delta3_2, 7, 3, 0)
 AD2_ODE(delta3_3, 7, 3, 0)
@@ -130,6 +133,9 @@ GEN_DECL(freeflyingrobot)
 GEN_DECL(integrand_sum4)
 GEN_DECL(cannon)
 GEN_DECL(cannon_energy)
+GEN_DECL(integrand_lq)
+GEN_DECL(integrand_lq_pi)
+GEN_DECL(lq1)
 GEN_DECL(delta3_1)
 GEN_DECL(delta3_2)
 GEN_DECL(delta3_3)
@@ -195,6 +201,9 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(integrand_sum4)
   TRY4(cannon)
   TRY4(cannon_energy)
+  TRY4(integrand_lq)
+  TRY4(integrand_lq_pi)
+  TRY4(lq1)
   TRY4(delta3_1)
   TRY4(delta3_2)
   TRY4(delta3_3)
@@ -238,6 +247,9 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(integrand_sum4, 1, 2, 0, nullptr)
   TRY(cannon, 4, 0, 1, nullptr)
   TRY(cannon_energy, 1, 0, 0, nullptr)
+  TRY(integrand_lq, 1, 0, 0, nullptr)
+  TRY(integrand_lq_pi, 1, 0, 0, nullptr)
+  TRY(lq1, 1, 1, 0, nullptr)
   TRY(delta3_1, 7, 3, 0, nullptr)
   TRY(delta3_2, 7, 3, 0, nullptr)
   TRY(delta3_3, 7, 3, 0, nullptr)

@@ -291,6 +291,14 @@ void integrand_usq(const S* y, S* f, const void*) { f[0] = y[1] * y[1]; }
 // record (1, 2, 0): 4 inputs
 template <class S>
 void integrand_sum4(const S* y, S* f, const void*) { f[0] = y[0] + y[1] + y[2] + y[3]; }
+// lq: I(x, u) = u^2 + x u + 1.25 x^2, the running cost of the reference's scaling test (asset_asrl/test/test_AutoScaling/
+// test_ObjScaling.py:23-27); lq_pi: the same times pi (ODE.obj() * iscale, :77).  Records (1, 0, 0).  lq1: its ODE x' = x / 2 + u (:11-21).
+template <class S>
+void integrand_lq(const S* y, S* f, const void*) { f[0] = y[1] * y[1] + y[0] * y[1] + 1.25 * (y[0] * y[0]); }
+template <class S>
+void integrand_lq_pi(const S* y, S* f, const void*) { f[0] = M_PI * (y[1] * y[1] + y[0] * y[1] + 1.25 * (y[0] * y[0])); }
+template <class S>
+void lq1(const S* y, S* f, const void*) { f[0] = 0.5 * y[0] + y[2]; }
 template <class S>
 void integrand_powp(const S* y, S* f, const void*) {
   f[0] = y[3] * y[0] * y[0] + sin(y[1]) * y[2] + exp(-(y[0] * y[2])) / (1.0 + y[3] * y[3]);

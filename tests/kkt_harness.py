@@ -461,6 +461,50 @@ def delta3_problem(mode: str, control: str, npts: int, warm=None):
                 objective_scale=k["Mstar"])
 
 
+def lq_ode():
+    """x' = x / 2 + u (test_ObjScaling.py:11-21); the oracle's `lq1`."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+
+    class LQ(ODEBase):
+        def __init__(self):
+            a = ODEArguments(1, 1)
+            super().__init__(vf.stack([0.5 * a.XVar(0) + a.UVar(0)]), 1, 1, 0, name="lq1")
+
+    return LQ()
+
+
+def lq_problem(mode: str, control: str, nseg: int, integral_param: bool = False):
+    """test_ObjScaling.py:44-141 on a fixed mesh: x(0) = 1, t in [0, 1], minimise pi * int (u^2 + x u + 1.25 x^2) dt + e * x(1).
+    integral_param = False: the running cost as an integral objective (:77).  True: as an INTEGRAL PARAMETER FUNCTION (:126-128) --
+    the static parameter p is made to equal the integral by one constraint row that the accumulation -p and the segment quadratures
+    share (Phase.addIntegralParamFunction; ODEPhaseBase.cpp:835-889), and the cost is e * x(1) + pi * p, linear."""
+    from asset_asrl_amd import vf
+    traj = np.array([[1.0, t, 0.4] for t in np.linspace(0.0, 1.0, 100)])
+    ph = lq_ode().phase(mode, traj, nseg)
+    ph.setControlMode(control)
+    a = vf.Arguments(2)
+    run = a.coeff(1) * a.coeff(1) + a.coeff(0) * a.coeff(1) + 1.25 * (a.coeff(0) * a.coeff(0))
+    if integral_param:
+        ph.setStaticParams([0.0])
+        ph.addIntegralParamFunction(run, [0, 2], accum_param=0, scale=1.0)
+    else:
+        ph.addIntegralObjective(run * np.pi, [0, 2])
+    ix, (V, Cx), entries, n_equal, _ = ph.layout()
+    x0 = ix.makeSolverInput(ph.ActiveTraj, ph.ActiveStaticParams)
+    n, S = x0.size, ix.numStates
+    lb, ub, cost = np.full(n, -np.inf), np.full(n, np.inf), np.zeros(n)
+    lb[ix.getXTUVarLoc(0, 0)] = ub[ix.getXTUVarLoc(0, 0)] = 1.0          # addBoundaryValue("Front", [0, 1], [x0, t0])
+    lb[ix.getXTUVarLoc(1, 0)] = ub[ix.getXTUVarLoc(1, 0)] = 0.0
+    lb[ix.getXTUVarLoc(1, S - 1)] = ub[ix.getXTUVarLoc(1, S - 1)] = 1.0  # addBoundaryValue("Back", [1], [tf])
+    cost[ix.getXTUVarLoc(0, S - 1)] = np.e                               # addValueObjective("Back", 0, vscale)
+    if integral_param:
+        cost[ix.var_offset + ix.StaticParamLoc0] = np.pi                 # addValueObjective("StaticParams", 0, iscale)
+    return dict(phase=ph, ix=ix, x0=x0, lb=lb, ub=ub, cost=cost, V=V, Cx=Cx, entries=entries, n_equal=n_equal,
+                slack_rows=np.zeros(0, dtype=np.int32), ode_name="lq1", integrands={"obj0": ("integrand_lq_pi", 2), "ipf0_int": ("integrand_lq", 2)},
+                usize=1, final_state=ix.getXTUVarLoc(0, S - 1))
+
+
 class ScaledVars:
     """The assembly in scaled variables x = s * xs (a harness-level diagonal scaling: the cannon ball's radius is 1e-4 in the
     problem's units, the other variables O(1) -- PSIOPT's own scaling is not part of this loop)."""
@@ -520,6 +564,7 @@ class OracleProvider:
         from asset_asrl_amd import synth
         n, m = prob["x0"].size, prob["n_equal"]
         nlp = ob.FullNlp(n, m, 0)
+        affine = []
         for part in prob.get("parts", [prob]):
             ph, ix = part["phase"], part["ix"]
             nlp.add(1, ob.get_ode(part.get("ode_name", "reentry"), 0), ob.MODES[ph.TranscriptionMode], ix.BlockedControls, part["V"],
@@ -536,6 +581,11 @@ class OracleProvider:
                     name, nx = part["integrands"][tag]
                     nlp.add_integral(0, ob.get_ode(name, 0), cs, nx, 0, V, Cx)
                     self.has_objective = True
+                elif kind == "equality" and tag.endswith("_int"):    # an integral parameter function's quadratures: ONE shared row
+                    name, nx = part["integrands"][tag]
+                    nlp.add_integral(1, ob.get_ode(name, 0), cs, nx, 0, V, Cx)
+                elif kind == "equality" and tag.endswith("_acc"):    # ... and its accumulation -scale * p on that row: linear, added to the
+                    affine.append((int(Cx[0, 0]), int(V[0, 0]), float(F.compute(np.ones(1))[0])))   # oracle's values here (its function records have two inputs at least)
                 elif kind == "equality":                         # a user function (the heating-rate bound, the muzzle-energy bound)
                     nlp.add(1, ob.get_ode(part.get("functions", {"eq0": "reentry_heating"})[tag], 0), ob.MODES["Function"], False, V, Cx)
                 else:
@@ -545,6 +595,7 @@ class OracleProvider:
         self.nlp, self.n, self.m = nlp, n, m
         self.csr = CsrKkt(*nlp.csr(), n, m)
         self.calls = 0
+        self.B = sp.csr_matrix(([a[2] for a in affine], ([a[0] for a in affine], [a[1] for a in affine])), shape=(m, n)) if affine else None
 
     has_objective, pgx = False, None
 
@@ -552,10 +603,13 @@ class OracleProvider:
         self.calls += 1
         _, self.pgx, agx, fxe, _, vals = self.nlp.eval(4, 1.0, x, lam, np.zeros(1))
         W, J = self.csr.split(vals)
+        if self.B is not None:
+            fxe, agx, J = fxe + self.B @ x, agx + self.B.T @ lam, (J + self.B).tocsr()
         return fxe, agx, W, J
 
     def con(self, x):
-        return self.nlp.eval(0, 1.0, x, np.zeros(self.m), np.zeros(1))[3]
+        c = self.nlp.eval(0, 1.0, x, np.zeros(self.m), np.zeros(1))[3]
+        return c if self.B is None else c + self.B @ x
 
     def objective(self, x):
         return float(self.nlp.eval(0, 1.0, x, np.zeros(self.m), np.zeros(1))[0]) if self.has_objective else 0.0
