@@ -53,3 +53,23 @@ def mesh_info(ode_name: str, mode: str, traj, n: int, blocked: bool = False, dev
     """(tsnd, bins, error) -- ODEPhaseBase::getMeshInfo(False, n)."""
     tsnd, _, _, error, dist = mesh_error_deboor(ode_name, mode, traj, blocked, device)
     return bins_from_density(tsnd, error, dist, n)
+
+
+class MeshIterateInfo:
+    """One iterate of the adaptive mesh loop (MeshIterateInfo.h:6-86): the estimate on the current mesh, its summary numbers and the
+    cumulative error-density integral the next mesh's edges are read from."""
+
+    def __init__(self, numsegs: int, tol: float, times, error, distribution):
+        self.numsegs = self.up_numsegs = int(numsegs)
+        self.tol, self.converged, self.global_error = float(tol), False, -1.0
+        self.times, self.error, self.distribution = (np.asarray(v, dtype=float).copy() for v in (times, error, distribution))
+        hs = np.diff(self.times)
+        self.max_error = float(self.error.max())
+        self.avg_error = float((self.error[:-1] * hs).sum())
+        self.gmean_error = float(np.exp((np.log(self.max_error) + np.log(self.avg_error)) / 2.0))
+        self.distintegral = np.zeros_like(self.times)
+        self.distintegral[1:] = np.cumsum(self.distribution[:-1] * hs)
+        self.distintegral /= self.distintegral[-1]
+
+    def calc_bins(self, nbins: int):
+        return bins_from_density(self.times, self.error, self.distribution, int(nbins))[1]

@@ -100,6 +100,10 @@ class Phase:
         self._ev_kept = None      # (key, evaluator): survives re-meshing, see transcribe()
         self._indexer = None
         self.AutoScaling = False
+        # adaptive mesh (ODEPhaseBase.h:96-118): the loop around the de Boor estimate -- checkMesh / updateMesh below
+        self.AdaptiveMesh, self.MeshConverged, self.MeshIters = False, False, []
+        self.MeshTol, self.MaxMeshIters, self.MaxSegments, self.MinSegments, self.NumExtraSegs = 1.0e-6, 10, 10000, 4, 4
+        self.MeshRedFactor, self.MeshIncFactor, self.MeshErrFactor, self.MeshErrorCriteria = 0.5, 5.0, 10.0, "max"
         self.XtUPUnits = np.ones(ode.XtUPVars())
         self._ode_scaled = None
         self._eq_funcs = []       # (region, func, xtuv, opv, spv) -- addEqualCon
@@ -552,6 +556,45 @@ class Phase:
         from . import mesh
         tsnd, err, dist = self.get_meshinfo_deboor()
         return mesh.bins_from_density(tsnd, np.abs(err).max(axis=0), np.abs(dist).max(axis=0), n)
+
+    # ---- the adaptive mesh loop's two steps (ODEPhaseBase.cpp:1443-1494 checkMesh, :1496-1542 updateMesh).  The solver between
+    #      them is the caller's: solve, checkMesh(); while not converged: updateMesh(), solve again, checkMesh()
+    def setAdaptiveMesh(self, flag: bool = True):
+        self.AdaptiveMesh = bool(flag)
+
+    def setMeshTol(self, tol: float):
+        self.MeshTol = abs(float(tol))
+
+    def checkMesh(self, meshinfo=None) -> bool:
+        """Estimate the error of the active trajectory (the device de Boor estimator; `meshinfo`: another source of
+        (tsnd, mesh_errors[XV, nb+1], mesh_dist[XV, nb+1]) -- a test's oracle), record the iterate and compare the criterion
+        ("max", "avg", "geometric": MeshIterateInfo.h:42-47) with MeshTol."""
+        from .mesh import MeshIterateInfo
+        tsnd, err, dist = meshinfo() if meshinfo is not None else self.get_meshinfo_deboor()
+        it = MeshIterateInfo(self.numDefects, self.MeshTol, tsnd, np.abs(err).max(axis=0), np.abs(dist).max(axis=0))
+        if self.MeshErrorCriteria not in ("max", "avg", "geometric"):
+            raise ValueError("Unknown mesh error criteria")      # ("endtoend" needs the integrator, which stays on the host)
+        crit = {"max": it.max_error, "avg": it.avg_error, "geometric": it.gmean_error}[self.MeshErrorCriteria]
+        it.converged = self.MeshConverged = bool(crit < self.MeshTol)
+        self.MeshIters.append(it)
+        return self.MeshConverged
+
+    def updateMesh(self):
+        """The next mesh from the last iterate: per segment (err * MeshErrFactor / MeshTol)^(1 / (Order + 1)) new segments (at least
+        MeshRedFactor), summed, plus NumExtraSegs, kept between MeshRedFactor and MeshIncFactor times the current number and
+        between MinSegments and MaxSegments; their edges equidistribute the error density; the trajectory is re-distributed
+        (control-switch detection, :1511-1536, is not built)."""
+        if not self.MeshIters:
+            raise RuntimeError("checkMesh first")
+        it = self.MeshIters[-1]
+        order = {"Trapezoidal": 2.0, "LGL3": 3.0, "LGL5": 5.0, "LGL7": 7.0}[self.TranscriptionMode]
+        per = np.maximum(self.MeshRedFactor, (it.error[:-1] * self.MeshErrFactor / self.MeshTol) ** (1.0 / (order + 1.0)))
+        n = int(np.ceil(per.sum())) + self.NumExtraSegs
+        n = min(max(n, int(self.numDefects * self.MeshRedFactor)), int(self.numDefects * self.MeshIncFactor))
+        n = min(max(n, self.MinSegments), self.MaxSegments)
+        bins = it.calc_bins(n)
+        it.up_numsegs = bins.size - 1
+        return self.refineTrajManual(bins, np.ones(bins.size - 1, dtype=int))
 
     def get_defect(self) -> DefectFunction:
         name = jit.ensure_kernel(self._active_ode(), self.TranscriptionMode, self._blocked())

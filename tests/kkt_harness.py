@@ -104,7 +104,7 @@ def cartpole_ode():
     return CartPole()
 
 
-def cartpole_problem(mode: str, control: str, nseg: int):
+def cartpole_problem(mode: str, control: str, nseg: int, phase=None):
     """test_CartPole.py:41-70: swing the pole up in tf = 2 while the cart moves d = 1, |u| <= 20, |q1| <= 2, minimise int u^2 dt.
     The integrand is taken over the node values (q1, u) -- u^2 with an unused first input: the oracle's function records have at
     least two inputs -- which is the same objective."""
@@ -112,10 +112,12 @@ def cartpole_problem(mode: str, control: str, nseg: int):
     umax, dmax, tf, d = 20.0, 2.0, 2.0, 1.0
     ts = np.linspace(0, tf, 100)
     traj = np.array([[d * t / tf, np.pi * t / tf, 0.0, 0.0, t, 0.0] for t in ts])
-    ph = cartpole_ode().phase(mode, traj, nseg)
-    ph.setControlMode(control)
-    a = vf.Arguments(2)
-    ph.addIntegralObjective(a.coeff(1) * a.coeff(1), [0, 5])     # addIntegralObjective(Args(1)[0]**2, [5])
+    ph = phase                                                   # (the adaptive mesh loop: the same phase on its new mesh)
+    if ph is None:
+        ph = cartpole_ode().phase(mode, traj, nseg)
+        ph.setControlMode(control)
+        a = vf.Arguments(2)
+        ph.addIntegralObjective(a.coeff(1) * a.coeff(1), [0, 5])     # addIntegralObjective(Args(1)[0]**2, [5])
     ix, (V, Cx), entries, n_equal, _ = ph.layout()
     x0 = ix.makeSolverInput(ph.ActiveTraj)
     n, S, D = x0.size, ix.numStates, ix.numDefects
@@ -782,6 +784,32 @@ def solve_optimize_only(provider, prob, verbose=False, **kw):
     x, lam, info = solve_ip(provider, prob["x0"], prob["lb"], prob["ub"], prob["cost"], verbose=verbose, **kw)
     info["feasible"] = bool(np.abs(provider.con(x)).max() < 1e-6)
     return x, lam, info
+
+
+def solve_adaptive(make_provider, rebuild, prob, meshinfo, verbose=False, **kw):
+    """The reference's adaptive mesh loop (ODEPhaseBase.cpp:1639-1673 around checkMesh / updateMesh, :1443-1542) with this harness
+    as the solver: optimise, estimate the error of the solution (`meshinfo(phase)` -> (tsnd, errors, dist): the device estimator or
+    the oracle's), stop when it is below the phase's MeshTol, otherwise re-mesh by the error density and optimise again from the
+    re-distributed solution.  `rebuild(phase)` -> the problem on the phase's new mesh.  -> (problem, x, lam, info)."""
+    ph = prob["phase"]
+    for it in range(ph.MaxMeshIters + 1):
+        prov = make_provider(prob)
+        try:
+            x, lam, info = solve_optimize_only(prov, prob, verbose=verbose, **kw)
+        finally:
+            if hasattr(prov, "close"):
+                prov.close()
+        ph.ActiveTraj = prob["ix"].collectSolverOutput(x)[0]
+        done = ph.checkMesh(meshinfo=lambda: meshinfo(ph))
+        if verbose:
+            m = ph.MeshIters[-1]
+            print(f"mesh iteration {it}: {m.numsegs} segments, max error {m.max_error:.3e}, objective {info['objective']:.8f}")
+        if done or not info["converged"] or it == ph.MaxMeshIters:
+            break
+        ph.updateMesh()
+        prob = rebuild(ph)
+    info["mesh_iterations"], info["mesh_converged"], info["segments"] = len(ph.MeshIters), ph.MeshConverged, ph.numDefects
+    return prob, x, lam, info
 
 
 class DeviceProvider:
