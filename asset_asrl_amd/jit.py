@@ -25,6 +25,16 @@ from .vf.codegen import emit_hip_functor, saved_nodes
 JIT_DIR = os.path.join(build.GEN, "jit")
 _MODE_CS = {"LGL3": 2, "LGL5": 3, "LGL7": 4}
 _loaded: set = set()
+_PARTITION = None      # (worker, workers): compile-only builds spread over processes -- a module is compiled by the worker its key names
+
+
+def set_partition(worker=None, workers=None):
+    """compile_only_mode builds only: this process compiles the cache misses whose content key is `worker` modulo `workers` and
+    skips the others (None: all) -- __graft_entry__.build() runs its pre-build once per worker, then once more serially."""
+    global _PARTITION
+    _PARTITION = None if worker is None else (int(worker), int(workers))
+
+
 _TOUCHED: set = set()     # cache files this process compiled or found (prune_unused drops the rest)
 _FUNCTORS: dict = {}        # device name of a plain function -> (functor struct name, its derivatives)
 # The build step (__graft_entry__.build) runs where there is no device: it compiles and caches the modules the test suite
@@ -140,6 +150,8 @@ def _build_and_load(name, hdr_name, hdr, tag, reg_line, mode_id, blocked, what, 
         args = (src.encode(), functor.encode(), kind, cs_id, int(blocked), G, copts, len(opts), mod.encode())
         if compile_only:                    # (the build step, which has no device: compile and cache)
             if not os.path.exists(mod):
+                if _PARTITION is not None and int(key_of(src, opts), 16) % _PARTITION[1] != _PARTITION[0]:
+                    return name             # (another worker of a parallel pre-build compiles this one)
                 _lib.check(_lib.lib().asset_hip_jit_compile(*args), f"asset_hip_jit_compile ({what})")
                 drop_older(f"module_{tag}_", ".rtc", mod)
             return name
