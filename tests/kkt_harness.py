@@ -40,7 +40,52 @@ def heating_bound():
     return vf.stack([(qa * qr - Qlimit) * (1.0 / Qlimit)])
 
 
-def reentry_problem(mode: str, control: str, nseg: int = 64, heating: bool = False):
+def reentry_dimensional_ode():
+    """The shuttle re-entry dynamics in ENGLISH UNITS (feet, seconds, slugs), as the reference's AutoScaling test states them
+    (asset_asrl/test/test_AutoScaling/test_Reentry.py:14-103) -- with Phase.setUnits(h = 1e5 ft, v = 1e5 ft / min, t = 1 min) and
+    AutoScaling the phase evaluates IOScaled(this), which is mathematically the non-dimensional `reentry` of the library and of
+    the oracle."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+    g0, W, Re, S, mu, rho0, h_ref = 32.2, 203000.0, 20902900.0, 2690.0, 0.140765e17, 0.002378, 23800.0
+    m = W / g0
+    a0, a1, b0, b1, b2 = -0.20704, 0.029244, 0.07854, -0.61592e-2, 0.621408e-3
+
+    class ShuttleReentryFeet(ODEBase):
+        def __init__(self):
+            a = ODEArguments(5, 2)
+            h, theta, v, gamma, psi = a.XVec().tolist()
+            alpha, beta = a.UVar(0), a.UVar(1)
+            alphadeg = (180.0 / np.pi) * alpha
+            CL = a0 + a1 * alphadeg
+            CD = b0 + b1 * alphadeg + b2 * (alphadeg * alphadeg)
+            rho = rho0 * vf.exp(-1.0 * h / h_ref)
+            r = h + Re
+            L = 0.5 * CL * S * rho * (v * v)
+            D = 0.5 * CD * S * rho * (v * v)
+            g = mu / (r * r)
+            sgam, cgam = vf.sin(gamma), vf.cos(gamma)
+            rates = [v * sgam, (v / r) * cgam * vf.cos(psi), -1.0 * D / m - g * sgam,
+                     (L / (m * v)) * vf.cos(beta) + cgam * (v / r - g / v),
+                     L * vf.sin(beta) / (m * v * cgam) + (v / r) * cgam * vf.sin(psi) * vf.tan(theta)]
+            super().__init__(vf.stack(rates), 5, 2, 0, name="reentry_feet")
+
+    return ShuttleReentryFeet()
+
+
+def heating_bound_dimensional():
+    """(q(h [ft], v [ft/s], alpha) - Qlimit) / Qlimit: QFunc of test_AutoScaling/test_Reentry.py:105-114 with the bound's scale."""
+    from asset_asrl_amd import vf
+    rho0, h_ref = 0.002378, 23800.0
+    c0, c1, c2, c3, Qlimit = 1.0672181, -0.19213774e-1, 0.21286289e-3, -0.10117e-5, 70.0
+    h, v, alpha = vf.Arguments(3).tolist()
+    alphadeg = (180.0 / np.pi) * alpha
+    qr = 17700.0 * vf.sqrt(rho0 * vf.exp(-1.0 * h / h_ref)) * ((0.0001 * v) ** 3.07)
+    qa = c0 + c1 * alphadeg + c2 * (alphadeg * alphadeg) + c3 * (alphadeg * alphadeg * alphadeg)
+    return vf.stack([(qa * qr - Qlimit) * (1.0 / Qlimit)])
+
+
+def reentry_problem(mode: str, control: str, nseg: int = 64, heating: bool = False, autoscaled: bool = False):
     """-> dict(phase, ix, x0, lb, ub, cost, V, Cx, entries, n_equal); constants of test_Reentry.py:14-47,130-175.  heating: the
     heating-rate bound at every state; registered with the assembly as an EQUALITY whose rows (`slack_rows`) the harness turns
     into  g(x) + s = 0, s >= 0  (SlackRows below)."""
@@ -56,12 +101,18 @@ def reentry_problem(mode: str, control: str, nseg: int = 64, heating: bool = Fal
     s = ts / tf
     traj = np.column_stack([ht0 * (1 - s) + htf * s, thetaf * s, vt0 * (1 - s) + vtf * s, g0 * (1 - s) + gf * s,
                             np.full_like(s, psi0), ts, 0 * s, 0 * s])
-    ph = ShuttleReentry().phase(mode, traj, nseg)
+    if autoscaled:     # test_AutoScaling/test_Reentry.py:166-175: the problem in feet and seconds, the phase scales it (the solver's
+        units = np.array([Lstar, 1.0, Vstar, 1.0, 1.0, Tstar, 1.0, 1.0])   # variables, bounds and cost below are in scaled units)
+        ph = reentry_dimensional_ode().phase(mode, traj * units, nseg)
+        ph.setUnits(units)
+        ph.setAutoScaling(True)
+    else:
+        ph = ShuttleReentry().phase(mode, traj, nseg)
     ph.setControlMode(control)
     if heating:
-        ph.addEqualCon("Path", heating_bound(), [0, 2, 6])
+        ph.addEqualCon("Path", heating_bound_dimensional() if autoscaled else heating_bound(), [0, 2, 6])
     ix, (V, Cx), entries, n_equal, _ = ph.layout()
-    x0 = ix.makeSolverInput(ph.ActiveTraj)
+    x0 = ix.makeSolverInput(ph.ActiveTraj / ph.XtUPUnits if autoscaled else ph.ActiveTraj)
     n, S, D = x0.size, ix.numStates, ix.numDefects
     lb, ub, cost = np.full(n, -np.inf), np.full(n, np.inf), np.zeros(n)
     d89, d90, d1 = np.deg2rad(89.0), np.deg2rad(90.0), np.deg2rad(1.0)
@@ -829,7 +880,7 @@ class DeviceProvider:
         fns = []                                                 # (kind 1: equality; 0: objective -- host/kkt_assembly.h)
         for part in prob.get("parts", [prob]):
             ph, ix = part["phase"], part["ix"]
-            fns.append((jit.ensure_kernel(ph.ode, ph.TranscriptionMode, ix.BlockedControls), mode_ids[ph.TranscriptionMode],
+            fns.append((jit.ensure_kernel(ph._active_ode(), ph.TranscriptionMode, ix.BlockedControls), mode_ids[ph.TranscriptionMode],
                         int(ix.BlockedControls), part["V"], part["Cx"], None, 1))
             fns += [(jit.ensure_function(F, name), _lib.FUNCTION, 0, V, Cx, consts, 0 if kind == "objective" else 1)
                     for kind, _, F, name, V, Cx, consts in part["entries"]]
