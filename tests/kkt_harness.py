@@ -85,7 +85,7 @@ def heating_bound_dimensional():
     return vf.stack([(qa * qr - Qlimit) * (1.0 / Qlimit)])
 
 
-def reentry_problem(mode: str, control: str, nseg: int = 64, heating: bool = False, autoscaled: bool = False):
+def reentry_problem(mode: str, control: str, nseg: int = 64, heating: bool = False, autoscaled: bool = False, phase=None):
     """-> dict(phase, ix, x0, lb, ub, cost, V, Cx, entries, n_equal); constants of test_Reentry.py:14-47,130-175.  heating: the
     heating-rate bound at every state; registered with the assembly as an EQUALITY whose rows (`slack_rows`) the harness turns
     into  g(x) + s = 0, s >= 0  (SlackRows below)."""
@@ -101,16 +101,19 @@ def reentry_problem(mode: str, control: str, nseg: int = 64, heating: bool = Fal
     s = ts / tf
     traj = np.column_stack([ht0 * (1 - s) + htf * s, thetaf * s, vt0 * (1 - s) + vtf * s, g0 * (1 - s) + gf * s,
                             np.full_like(s, psi0), ts, 0 * s, 0 * s])
-    if autoscaled:     # test_AutoScaling/test_Reentry.py:166-175: the problem in feet and seconds, the phase scales it (the solver's
+    if phase is not None:                                        # (the adaptive mesh loop: the same phase on its new mesh)
+        ph = phase
+    elif autoscaled:   # test_AutoScaling/test_Reentry.py:166-175: the problem in feet and seconds, the phase scales it (the solver's
         units = np.array([Lstar, 1.0, Vstar, 1.0, 1.0, Tstar, 1.0, 1.0])   # variables, bounds and cost below are in scaled units)
         ph = reentry_dimensional_ode().phase(mode, traj * units, nseg)
         ph.setUnits(units)
         ph.setAutoScaling(True)
     else:
         ph = ShuttleReentry().phase(mode, traj, nseg)
-    ph.setControlMode(control)
-    if heating:
-        ph.addEqualCon("Path", heating_bound_dimensional() if autoscaled else heating_bound(), [0, 2, 6])
+    if phase is None:
+        ph.setControlMode(control)
+        if heating:
+            ph.addEqualCon("Path", heating_bound_dimensional() if autoscaled else heating_bound(), [0, 2, 6])
     ix, (V, Cx), entries, n_equal, _ = ph.layout()
     x0 = ix.makeSolverInput(ph.ActiveTraj / ph.XtUPUnits if autoscaled else ph.ActiveTraj)
     n, S, D = x0.size, ix.numStates, ix.numDefects
@@ -837,7 +840,7 @@ def solve_optimize_only(provider, prob, verbose=False, **kw):
     return x, lam, info
 
 
-def solve_adaptive(make_provider, rebuild, prob, meshinfo, verbose=False, **kw):
+def solve_adaptive(make_provider, rebuild, prob, meshinfo, verbose=False, solver=None, **kw):
     """The reference's adaptive mesh loop (ODEPhaseBase.cpp:1639-1673 around checkMesh / updateMesh, :1443-1542) with this harness
     as the solver: optimise, estimate the error of the solution (`meshinfo(phase)` -> (tsnd, errors, dist): the device estimator or
     the oracle's), stop when it is below the phase's MeshTol, otherwise re-mesh by the error density and optimise again from the
@@ -846,7 +849,7 @@ def solve_adaptive(make_provider, rebuild, prob, meshinfo, verbose=False, **kw):
     for it in range(ph.MaxMeshIters + 1):
         prov = make_provider(prob)
         try:
-            x, lam, info = solve_optimize_only(prov, prob, verbose=verbose, **kw)
+            x, lam, info = (solver or solve_optimize_only)(prov, prob, verbose=verbose, **kw)
         finally:
             if hasattr(prov, "close"):
                 prov.close()

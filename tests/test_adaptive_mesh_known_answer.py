@@ -8,7 +8,11 @@ Solve (tests/kkt_harness.py), estimate the error of the solution, re-mesh by the
 solution -- until the estimate is below the tolerance:
 * on the CPU with the oracle's assembly AND the oracle's estimator (oracle/mesh.cpp);
 * on the GPU (-m gpu) with the device kernels through the C ABI / KktAssembly and the DEVICE estimator (csrc/mesh_kernels.h), every
-  mesh a new handle."""
+  mesh a new handle.
+
+And on the re-entry problem (test_AdaptiveMesh/test_Reentry.py): from 40 / 20 / 15 segments at MeshTol = 1e-7 the loop ends on 446 / 78 /
+31 segments with the cross-range -0.59588007165 / -0.59588007419 / -0.59588003641 -- the reference's recorded -0.5958800738629952 to
+2e-9 / 3e-10 / 4e-8: its number is a mesh-converged one, and the converged meshes of this build land on it."""
 import ctypes as C
 import os
 import subprocess
@@ -53,6 +57,37 @@ def test_oracle_loop_converges_to_the_reference_objective(oracle, mode):
     assert h.max() / h.min() > 1.5
 
 
+# ---- the same loop on the re-entry problem: test_AdaptiveMesh/test_Reentry.py:112-250 -- from 40 / 20 / 15 segments, MeshTol = 1e-7,
+#      MeshIncFactor = 5, 'solve' then 'optimize'; mesh converged and the cross-range -0.5958800738629952 +- 1e-2
+RE_START = {"LGL3": 40, "LGL5": 20, "LGL7": 15}
+RE_OWN = {"LGL3": ([40, 200, 446], -0.59588007165), "LGL5": ([20, 72, 78], -0.59588007419), "LGL7": ([15, 31], -0.59588003641)}
+RE_REFERENCE = -0.5958800738629952
+
+
+def _run_reentry(mode, make_provider, meshinfo):
+    prob = kh.reentry_problem(mode, "HighestOrderSpline", RE_START[mode])
+    ph = prob["phase"]
+    ph.setAdaptiveMesh(True)
+    ph.setMeshTol(1.0e-7)
+    ph.MeshIncFactor = 5
+    prob, x, lam, info = kh.solve_adaptive(make_provider, lambda p: kh.reentry_problem(mode, "HighestOrderSpline", None, phase=p), prob,
+                                           meshinfo, solver=kh.solve_reentry)
+    assert info["converged"] and info["feasible"] and ph.MeshConverged, info
+    assert abs(info["objective"] - RE_REFERENCE) < 1e-2                                       # the reference's own assertion
+    assert [m.numsegs for m in ph.MeshIters] == RE_OWN[mode][0] and ph.MeshIters[-1].max_error < 1e-7
+    assert abs(info["objective"] - RE_OWN[mode][1]) < 2e-9, info["objective"]
+    # on the converged mesh the objective IS the reference's recorded value (its own meshes were converged to the same tolerance)
+    assert abs(info["objective"] - RE_REFERENCE) < (5e-9 if mode != "LGL7" else 5e-8)
+    return ph
+
+
+@pytest.mark.parametrize("mode", list(RE_START))
+def test_oracle_loop_on_the_reentry_problem(oracle, mode):
+    ode = oracle.get_ode("reentry", 0)
+    _run_reentry(mode, lambda pr: kh.OracleProvider(oracle, pr),
+                 lambda p: oracle.mesh_error_deboor(ode, oracle.MODES[mode], np.asarray(p.ActiveTraj), False))
+
+
 @pytest.fixture(scope="module")
 def shim(tmp_path_factory):
     pk = os.path.join(ROOT, "asset_asrl_amd")
@@ -71,3 +106,8 @@ def test_device_loop_converges_to_the_reference_objective(oracle, shim, mode):
     t_o, e_o, d_o = oracle.mesh_error_deboor(ode, oracle.MODES[mode], np.asarray(ph.ActiveTraj), False)
     t_d, e_d, d_d = ph.get_meshinfo_deboor()
     assert np.abs(t_d - t_o).max() < 1e-14 and np.abs(e_d - e_o).max() < 1e-9 * max(1.0, np.abs(e_o).max()) + 1e-12
+
+
+@pytest.mark.gpu
+def test_device_loop_on_the_reentry_problem(oracle, shim):
+    _run_reentry("LGL5", lambda pr: kh.DeviceProvider(shim, pr), lambda p: p.get_meshinfo_deboor())
