@@ -64,3 +64,34 @@ def test_phase_modes_and_errors():
     bad[3, 2] = np.nan
     with pytest.raises(ValueError):
         ph.setTraj(bad, 10)
+
+
+RECIPE_CASES = [("brachistochrone", "LGL3", False), ("reentry", "LGL7", False), ("reentry", "Trapezoidal", False),
+                ("twobody_lt", "LGL5", True), ("betts_lowthrust", "LGL5", False), ("betts_lowthrust", "LGL3", True),
+                ("synthetic32", "LGL7", False)]
+
+
+@pytest.mark.parametrize("ode,mode,blocked", RECIPE_CASES)
+def test_reference_self_consistency_recipe_on_the_device(ode, mode, blocked):
+    """The reference's own derivative test (asset_asrl/test/test_VectorFunctions/__init__.py:40-67: ``jx^T L == gx`` to 1e-12,
+    analytic Jacobian against central differences of ``compute`` to 1e-4, analytic Hessian against the symmetrised differences of
+    ``adjointgradient`` to 1e-4) -- which its suite never applies to the defects -- applied to the DEVICE's defect function
+    (``phase.get_defect()``: the resident, unit and row kernels behind one segment) for every kernel family.  No oracle involved."""
+    from asset_asrl_amd.phase import DefectFunction
+    from helpers import Workload
+    w = Workload(ode, mode, 6, blocked)
+    F = DefectFunction(ode, mode, w.blocked)
+    x = w.X[w.vindex[3]]
+    lam = w.L[w.cindex[3]] / 100.0
+    fx, jx, gx, hx = F.computeall(x, lam)
+    assert np.abs(jx.T @ lam - gx).max() < 1e-12 * max(1.0, np.abs(gx).max())     # "Adjoint gradients do not match"
+    assert np.abs(hx - hx.T).max() < 1e-13 * max(1.0, np.abs(hx).max())
+    eps = 1e-6
+    jfd, hfd = np.zeros_like(jx), np.zeros_like(hx)
+    for i in range(x.size):
+        e = np.zeros(x.size)
+        e[i] = eps
+        jfd[:, i] = (F.compute(x + e) - F.compute(x - e)) / (2 * eps)
+        hfd[:, i] = (F.adjointgradient(x + e, lam) - F.adjointgradient(x - e, lam)) / (2 * eps)
+    assert np.abs(jx - jfd).max() < 1e-4 * max(1.0, np.abs(jx).max())
+    assert np.abs(hx - 0.5 * (hfd + hfd.T)).max() < 1e-4 * max(1.0, np.abs(hx).max())
