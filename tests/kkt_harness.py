@@ -137,6 +137,37 @@ def reentry_problem(mode: str, control: str, nseg: int = 64, heating: bool = Fal
                 slack_rows=slack_rows)
 
 
+def brachistochrone_exact(x=10.0, drop=5.0, g=9.81):
+    """The cycloid through the start: x = R (phi - sin phi), drop = R (1 - cos phi); descent time phi sqrt(R / g)."""
+    from scipy.optimize import brentq
+    phi = brentq(lambda p: (p - np.sin(p)) / (1 - np.cos(p)) - x / drop, 0.1, 2 * np.pi - 0.1, xtol=1e-15)
+    return float(phi * np.sqrt(drop / (1 - np.cos(phi)) / g))
+
+
+def brachistochrone_problem(mode: str, control: str, nseg: int = 32):
+    """examples/Brachistochrone.py:36-67 (BASELINE.json configs[0], the reference's own CPU-runnable case): a bead from (0, 10) at rest
+    to (10, 5) under g = 9.81, theta in [-0.1, 2], minimum time.  The library ODE `brachistochrone`; linear cost t_f."""
+    from asset_asrl_amd.ode import Brachistochrone
+    g, theta0, tf = 9.81, 1.0, 1.0
+    traj = np.array([[10 * t / tf, 10 - 5 * t / tf, g * t * np.cos(theta0), t, theta0] for t in np.linspace(0, tf, 100)])
+    ph = Brachistochrone(g).phase(mode, traj, nseg)
+    ph.setControlMode(control)
+    ix, (V, Cx), entries, n_equal, _ = ph.layout()
+    x0 = ix.makeSolverInput(ph.ActiveTraj)
+    n, S, D = x0.size, ix.numStates, ix.numDefects
+    lb, ub, cost = np.full(n, -np.inf), np.full(n, np.inf), np.zeros(n)
+    for k, dd in ([(0, dd) for dd in range(D)] if ix.BlockedControls else [(k, None) for k in range(S)]):
+        lu = ix.getXTUVarLoc(4, k, dd)                           # addLUVarBound("Path", 4, -0.1, 2.00)
+        lb[lu], ub[lu] = -0.1, 2.0
+    for v, val in enumerate([0.0, 10.0, 0.0, 0.0]):              # addBoundaryValue("Front", range(0, 4), [x0, y0, v0, 0])
+        lb[ix.getXTUVarLoc(v, 0)] = ub[ix.getXTUVarLoc(v, 0)] = val
+    for v, val in ((0, 10.0), (1, 5.0)):                         # addBoundaryValue("Back", [0, 1], [xf, yf])
+        lb[ix.getXTUVarLoc(v, S - 1)] = ub[ix.getXTUVarLoc(v, S - 1)] = val
+    cost[ix.getXTUVarLoc(3, S - 1)] = 1.0                        # addDeltaTimeObjective(1.0); t_0 is fixed at 0
+    return dict(phase=ph, ix=ix, x0=x0, lb=lb, ub=ub, cost=cost, V=V, Cx=Cx, entries=entries, n_equal=n_equal,
+                slack_rows=np.zeros(0, dtype=np.int32), ode_name="brachistochrone", usize=1)
+
+
 def cartpole_ode():
     """The reference test's dynamics (test_CartPole.py:11-32; l, m1, m2, g of :43-46) in the product's DSL; the oracle holds the
     same right-hand side as `cartpole` (oracle/odes.h), differentiated independently by AD2."""
