@@ -3,7 +3,9 @@ results of a sparse assembly (the oracle's FullNlp here, the product's KktAssemb
 re-entry problem of the reference's own full-problem test, so that the path can be checked against a number the REFERENCE
 holds: /root/reference/asset_asrl/test/test_FullProblems/test_Reentry.py:116-127 (objective -0.5958800738629952 +- 1e-2 for
 LGL3/5/7/Trapezoidal x {HighestOrderSpline, BlockConstant}; the problem set-up is :130-175).  PSIOPT itself stays out of
-scope; this loop is deliberately minimal (l1 merit, inertia-free curvature test, monotone barrier) and must not grow.
+scope; the loop is deliberately minimal (filter line search, inertia-free curvature test, monotone barrier) -- what has grown since
+round 3 is the list of PROBLEMS stated for it (every full-problem test of the reference with a known answer, below) and the thin
+wrappers they need (slack rows, link rows, variable scaling), not the solver.
 
 The linear parts of the problem (boundary values, variable bounds, the upper bound on the final time, the objective
 -(theta_f - theta_0)) are handled here as fixed variables, bounds and a constant cost vector; every NONLINEAR function the
