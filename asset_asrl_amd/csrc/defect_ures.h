@@ -1,8 +1,13 @@
 // Heavy right-hand sides in ONE launch (round 5): eight-wave workgroups, a group of G segments resident in LDS.
 //
+// STATUS: built, parity-exact (7e-16 / 9e-16 against the oracle at every size tried) and SLOWER than the shipped unit kernels + dense part --
+// 31.6 against 20.1 us (Betts-LGL5 x 1 000), 93.5 against 90.0 us (Betts-LGL7 x 5 000); the dense part alone in this form
+// (lgl_ures_dense_kernel) 28.2 against 20.2 us.  Compiled only with -DASSET_URES=1 / -DASSET_URES_DENSE=1 (defect_rowdpp.h: UResDims); the
+// launcher takes what the kernel table holds.  Timeline and reasons: profiles/r5_ures_timeline.txt, DESIGN.md section 4.5.
+//
 // The unit kernels of defect_units.h spread an ODE whose derivative bodies do not fit a lane's registers over one single-wave
 // workgroup per OUTPUT UNIT and group of segments; the results travel through the workspace in HBM to a second launch, the dense part
-// (defect_resident.h, GIVEN form): for 1 000 Betts low-thrust LGL5 segments 9.7 us + 10.9 us, two launch latencies and 3.7 x the
+// (defect_resident.h, GIVEN form): for 1 000 Betts low-thrust LGL5 segments 9.7 us + 10.9 us, two launch latencies and 2.8 x the
 // algorithmic bytes in memory traffic.  Here the units of a group are the WAVES of one workgroup:
 //
 //   P0  all waves     z, lam of the group's G segments and the weight tables -> LDS slots
