@@ -34,6 +34,9 @@ SYMBOLS = {
     "asset_hip_defect_destroy": (None, [C.c_void_p]),
     "asset_hip_defect_rebind": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int]),
     "asset_hip_defect_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "asset_hip_defect_kkt_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "asset_hip_kkt_layout": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32)]),
     "asset_hip_defect_eval": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "asset_hip_defect_eval_device": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6),
     "asset_hip_jit_compile": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
@@ -111,6 +114,20 @@ def ode_sizes(name: str):
     xv, uv, pv = C.c_int(), C.c_int(), C.c_int()
     check(lib().asset_hip_ode_sizes(name.encode(), C.byref(xv), C.byref(uv), C.byref(pv)), "asset_hip_ode_sizes")
     return xv.value, uv.value, pv.value
+
+
+def kkt_layout(name: str, mode: int, blocked: bool):
+    """(layout id, NKKT, stride, rows, cols) of the KKT blocks of a compiled (ode, mode, blocked): asset_hip_kkt_layout -- no
+    handle, no device."""
+    nk, st = C.c_int(), C.c_int()
+    kl = lib().asset_hip_kkt_layout(name.encode(), mode, int(blocked), C.byref(nk), C.byref(st), None, None)
+    if kl < 0:
+        check(kl, "asset_hip_kkt_layout")
+    rows, cols = np.empty(st.value, dtype=np.int32), np.empty(st.value, dtype=np.int32)
+    kl = lib().asset_hip_kkt_layout(name.encode(), mode, int(blocked), None, None, rows.ctypes.data_as(_ip), cols.ctypes.data_as(_ip))
+    if kl < 0:
+        check(kl, "asset_hip_kkt_layout")
+    return kl, nk.value, st.value, rows, cols
 
 
 def has_kernel(name: str, mode: int, blocked: bool) -> bool:

@@ -56,7 +56,10 @@ def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None, trap=False):
     WSLOT = WSLOTD + cs * nsave
     LDM = K * NP + 1
     SCRATCH = max(K * n * IRP, IRP * LDM) + K * (NP - n) * IRP + ORP * (IRP + 4) + 4 * IRP + 2
-    if (70 + WSLOTD + SCRATCH) * 8 > LDS_BUDGET or (IR >= 64 and not trap):     # Dims::WIDE (csrc/defect_wide.h): DI resident, M in registers, no DC tile
+    wide = (70 + WSLOTD + SCRATCH) * 8 > LDS_BUDGET or (IR >= 64 and not trap)
+    # KKT block layout (Dims::KL): wide shapes keep the reference's order, the others write J | H with padded regions
+    KSTRIDE = NKKT if wide else (OR * IR + 15) // 16 * 16 + (IR * (IR + 1) // 2 + 15) // 16 * 16
+    if wide:     # Dims::WIDE (csrc/defect_wide.h): DI resident, M in registers, no DC tile
         SCRATCH = K * n * IRP + K * (N - n) * IRP + (ORP + cs * n + 2) + 4 * IRP + 2 \
             + (n * N + 3) // 4 + (NH + 3) // 4
     DENSE = WSLOTD + SCRATCH
@@ -68,7 +71,7 @@ def dims(xv, uv, pv, cs, blocked, nsave=0, nzj=None, nzh=None, trap=False):
 
     def lds_bytes(G=0):
         return (70 + BODY) * 8
-    return dict(n=n, m=m, p=p, q=q, N=N, IR=IR, OR=OR, NKKT=NKKT, SLOT=WSLOT, LC=LC, lds_bytes=lds_bytes,
+    return dict(n=n, m=m, p=p, q=q, N=N, IR=IR, OR=OR, NKKT=NKKT, KSTRIDE=KSTRIDE, KL=0 if wide else 1, SLOT=WSLOT, LC=LC, lds_bytes=lds_bytes,
                 lds_bytes_ode=(70 + (LC * STG_LD if staged else 0)) * 8, lds_bytes_dense=(70 + DENSE) * 8)
 
 

@@ -575,6 +575,32 @@ int asset_hip_defect_sizes(asset_hip_defect_t h, int* irows, int* orows, int* nk
   return 0;
 }
 
+// The order of a block's slots (defect_dims.h: Dims::KL, hcol / jcol -- the same arithmetic, on the host)
+static int entry_kkt_layout(const asset_hip::KernelEntry* ke, int* stride, int32_t* rows, int32_t* cols) {
+  const int IR = ke->ir, OR = ke->orr, KS = ke->kstride, kl = ke->kl;
+  if (stride) *stride = KS;
+  if (!rows && !cols) return kl;
+  if (!rows || !cols) return fail(ASSET_HIP_EINVAL, "rows and cols go together");
+  for (int k = 0; k < KS; k++) rows[k] = cols[k] = -1;
+  const int hoff = kl ? (OR * IR + 15) / 16 * 16 : 0, hca = kl ? IR - 1 : IR + OR - 1;
+  for (int c = 0; c < IR; c++) {
+    const int hc = hoff + c * hca - c * (c - 1) / 2, jc = kl ? c * OR : hc + IR;
+    for (int r = c; r < IR; r++) rows[hc + r] = r, cols[hc + r] = c;
+    for (int j = 0; j < OR; j++) rows[jc + j] = IR + j, cols[jc + j] = c;
+  }
+  return kl;
+}
+int asset_hip_defect_kkt_layout(asset_hip_defect_t h, int* stride, int32_t* rows, int32_t* cols) {
+  if (!h) return fail(ASSET_HIP_EINVAL, "null handle");
+  return entry_kkt_layout(h->ke, stride, rows, cols);
+}
+int asset_hip_kkt_layout(const char* ode, int mode, int blocked, int* nkkt, int* stride, int32_t* rows, int32_t* cols) {
+  const asset_hip::KernelEntry* ke = ode ? find_entry(ode, mode, blocked) : nullptr;
+  if (!ke) return fail(ASSET_HIP_ENOODE, "no device code compiled for this (ode, mode, blocked)");
+  if (nkkt) *nkkt = ke->nkkt;
+  return entry_kkt_layout(ke, stride, rows, cols);
+}
+
 // the kernel arguments of one evaluation of a handle (block kinds)
 static int fill_args(asset_hip_defect_t h, int what, const double* dX, const double* dL, double* dfx, double* dagx,
                      double* dkkt, asset_hip::EvalArgs& a) {
@@ -587,7 +613,7 @@ static int fill_args(asset_hip_defect_t h, int what, const double* dX, const dou
     return fail(ASSET_HIP_EINVAL, "ASSET_HIP_KEEP_HESSIAN_SLOTS goes with ASSET_HIP_JAC / ASSET_HIP_JAC_ADJGRAD only");
   // (honoured while the phase's blocks stay in the Infinity Cache; see include/asset_hip.h)
   // (wide shapes -- IR >= 64 -- skip whole lines: it pays at every size there)
-  const bool keep_pays = h->ke->ir >= 64 || size_t(h->nseg) * size_t(h->ke->nkkt) * sizeof(double) <= (size_t(192) << 20);
+  const bool keep_pays = h->ke->ir >= 64 || size_t(h->nseg) * size_t(h->ke->kstride) * sizeof(double) <= (size_t(192) << 20);
   a.flags = ((opts & ASSET_HIP_KEEP_HESSIAN_SLOTS) && keep_pays) ? 1 : 0;
   if (!dX) return fail(ASSET_HIP_EINVAL, "X is null");
   const bool needs_l = (what == ASSET_HIP_CON_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD || what == ASSET_HIP_JAC_ADJGRAD_HESS);
@@ -732,12 +758,12 @@ int asset_hip_defect_eval(asset_hip_defect_t h, int what, const double* X, const
   if (!X) return fail(ASSET_HIP_EINVAL, "X is null");
   HIP_TRY(hipSetDevice(h->device));
   const size_t nfx = size_t(h->nseg) * h->ke->orr, nagx = size_t(h->nseg) * h->ke->ir,
-               nkkt = size_t(h->nseg) * h->ke->nkkt;
+               nkkt = size_t(h->nseg) * h->ke->kstride;   // (blocks in the handle's layout: asset_hip_defect_kkt_layout)
   if (!h->d_X) HIP_TRY(hipMalloc(&h->d_X, sizeof(double) * h->cap_primal));
   if (!h->d_L) HIP_TRY(hipMalloc(&h->d_L, sizeof(double) * h->cap_equal));
   if (fx && !h->d_fx) HIP_TRY(hipMalloc(&h->d_fx, sizeof(double) * size_t(h->cap_seg) * h->ke->orr));   // (sized for the handle's capacity: asset_hip_defect_rebind)
   if (agx && !h->d_agx) HIP_TRY(hipMalloc(&h->d_agx, sizeof(double) * size_t(h->cap_seg) * h->ke->ir));
-  if (kkt && !h->d_kkt) HIP_TRY(hipMalloc(&h->d_kkt, sizeof(double) * size_t(h->cap_seg) * h->ke->nkkt));
+  if (kkt && !h->d_kkt) HIP_TRY(hipMalloc(&h->d_kkt, sizeof(double) * size_t(h->cap_seg) * h->ke->kstride));
   HIP_TRY(hipMemcpyAsync(h->d_X, X, sizeof(double) * h->n_primal, hipMemcpyHostToDevice, h->stream));
   if (L) HIP_TRY(hipMemcpyAsync(h->d_L, L, sizeof(double) * h->n_equal, hipMemcpyHostToDevice, h->stream));
   int rc = launch(h, what, h->d_X, L ? h->d_L : nullptr, fx ? h->d_fx : nullptr, agx ? h->d_agx : nullptr,

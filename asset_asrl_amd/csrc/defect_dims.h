@@ -149,6 +149,26 @@ struct Dims {
   static constexpr bool WIDE =
       size_t(TABSZ + WSLOTD + XM_ALL + K * (NP - n) * IRP + ORP * LDC + 4 * IRP + 2) * 8 > 160 * 1024 ||
       (!TRAP && IR >= ASSET_WIDE_MIN_IR);
+  // ---- layout of a KKT block in memory (round 6).  The order of a block's slots is private to the function: the solver sees
+  // (row, col) per slot through getKKTSpace -- a method the function itself implements (SolverInterfaceSpecs.h:41-92) -- and maps
+  // each to its location in the matrix whatever the order (NonLinearProgram.cpp:282-330).  KL 0: the order of the reference's
+  // dense functions, `for c: { H(r, c), r >= c ; J(j, c) }` (DenseFunctionBase.h:1112-1123), stride NKKT.  KL 1 (narrow shapes):
+  // the Jacobian, column-major, then the packed lower triangle of H, column-major, each region a whole number of 128-byte lines:
+  //     J(j, c) at  c OR + j ,       H(r, c), r >= c, at  HOFF + c IR - c (c - 1) / 2 + (r - c) ,      stride KSTRIDE
+  // A dense part that writes the rows of [J ; g^T] and the rows of H in different passes (defect_rowdpp.h) then never writes a
+  // 32-byte sector from two passes -- in the reference's order a block column's H part and J part share sectors, which reached
+  // memory once per pass (WRITE_SIZE 1.29-1.38 x the block bytes, profiles/r5_*_pmc.json).  The handle exports the order
+  // (asset_hip_defect_kkt_layout); padding slots are never written and never read.
+#ifndef ASSET_KKT_LAYOUT
+#define ASSET_KKT_LAYOUT 1
+#endif
+  static constexpr int KL = WIDE ? 0 : ASSET_KKT_LAYOUT;
+  static constexpr int JREG = (OR * IR + 15) / 16 * 16, HREG = (IR * (IR + 1) / 2 + 15) / 16 * 16;
+  static constexpr int KSTRIDE = KL ? JREG + HREG : NKKT;
+  static constexpr int HOFF = KL ? JREG : 0;
+  static constexpr int HCA = KL ? IR - 1 : IR + OR - 1;                  // hcol(c) = HOFF + c HCA - c (c - 1) / 2
+  static constexpr int hcol(int c) { return HOFF + c * HCA - c * (c - 1) / 2; }          // H(r, c) sits at hcol(c) + r
+  static constexpr int jcol(int c) { return KL ? c * OR : hcol(c) + IR; }                // J(j, c) sits at jcol(c) + j
   static constexpr int WNW = 4;                        // waves of the wide dense kernel
   static constexpr int NCR = WIDE ? N - n : NP - n;    // constant rows per interior (wide: the k-padding rows read a zero row)
   static constexpr int s_DIx = 0;                      // [K][n][IRP]

@@ -696,17 +696,16 @@ struct LaneConsts {
   #pragma unroll
         for (int v = 0; v < 4; v++) {
           const int c = 16 * ct + lk + 4 * v;
-          const int cst = c * (IR + OR) - c * (c - 1) / 2;   // first slot of block column c
   #pragma unroll
           for (int jt = 0; jt < D::TJ; jt++) {
             const int jr = 16 * jt + lr;
-            jst[ct * D::TJ + jt][v] = (c < IR && jr < OR) ? cst + (IR - c) + jr : -1;
+            jst[ct * D::TJ + jt][v] = (c < IR && jr < OR) ? D::jcol(c) + jr : -1;      // (block layout: defect_dims.h, Dims::KL)
           }
   #pragma unroll
           for (int rt = ct; rt < D::TI; rt++) {
             const int r = 16 * rt + lr, tix = rt * (rt + 1) / 2 + ct;
             const bool ok = (c < IR && r < IR && r >= c);
-            hst[tix][v] = ok ? cst + (r - c) : -1;
+            hst[tix][v] = ok ? D::hcol(c) + r : -1;
             if constexpr (LEVEL >= 2) {
               int ch = ZERO, cp = -1;
               if (ok) {
@@ -1227,7 +1226,7 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
       // first -- so a lane reads its own locations with coalesced loads and needs no slot arithmetic; -1 marks an
       // accumulator entry that is no KKT slot (upper triangle of a diagonal tile, padding).
       constexpr int NFRAG = (D::NTH + D::TI * D::TJ) * 4;
-      double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr);
+      double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::KSTRIDE) : nullptr);
       const int* const kmap_seg = ASM ? a.kmap + seg * size_t(NFRAG) * 64 + lane : nullptr;
       int hmap[ASM ? D::NTH : 1][4], jmap[ASM ? D::TI * D::TJ : 1][4];
       auto load_hmap = [&](int tix) {

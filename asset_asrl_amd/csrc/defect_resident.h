@@ -1074,7 +1074,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   lds_double* const WL = xtra + R::x_WL;
   constexpr int NFRAG = (D::NTH + TI * TJ) * 4;
 
-  const int nb_kkt = (!ASM && a.KKT) ? int(D::NKKT * 8) : 0, nb_fx = a.FX ? OR * 8 : 0, nb_agx = (a.AGX && a.L) ? IR * 8 : 0;
+  const int nb_kkt = (!ASM && a.KKT) ? int(D::KSTRIDE * 8) : 0, nb_fx = a.FX ? OR * 8 : 0, nb_agx = (a.AGX && a.L) ? IR * 8 : 0;
   const int nb_h = (LEVEL >= 2 || !(a.flags & 1)) ? nb_kkt : 0;   // (Jacobian kinds: zeros, unless the caller never reads them)
 #ifndef ASSET_RES_LDS_ORDER
 #define ASSET_RES_LDS_ORDER 1
@@ -1099,13 +1099,13 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #define ASSET_RES_FASTHT 1
 #endif
     const double rh = ASSET_RES_FASTHT ? 1.0 / h : 0.0;   // (one division per segment, off the tile columns' critical chain)
-    double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::NKKT) : nullptr);
+    double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::KSTRIDE) : nullptr);
     // lane-masked block stores as raw buffer stores whose masked lanes carry an out-of-range offset (dropped by the bounds check):
     // no exec-mask region, no basic-block boundary per store group; an output the caller did not ask for is a resource of zero
     // records (sizes nb_* formed once, ahead of the loop) -- no branch on the pointers inside the segment either
     struct SegOut { __amdgpu_buffer_rsrc_t rs; double* p; int nb; };
     auto seg_out = [&](double* seg_base, int bytes) { return SegOut{__builtin_amdgcn_make_buffer_rsrc(seg_base, 0, bytes, 0x00020000), seg_base, bytes}; };
-    const SegOut o_kkt = seg_out(a.KKT + seg * size_t(D::NKKT), nb_kkt), o_h = seg_out(a.KKT + seg * size_t(D::NKKT), nb_h);
+    const SegOut o_kkt = seg_out(a.KKT + seg * size_t(D::KSTRIDE), nb_kkt), o_h = seg_out(a.KKT + seg * size_t(D::KSTRIDE), nb_h);
     const SegOut o_fx = seg_out(a.FX + seg * size_t(OR), nb_fx), o_agx = seg_out(a.AGX + seg * size_t(IR), nb_agx);
     auto bst = [&](const SegOut& o, unsigned idx, bool ok, double v) {
       if constexpr (R::BSTORE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(res_u2, v), o.rs, ok ? idx * 8u : 0xFFFFFFF0u, 0, 0);
@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       const double lamr = S[D::w_lam + (jr < OR ? jr : 0)];      // (read, then select: a load under a lane condition is an exec-mask
       lsd += ((jr < OR) ? lamr : 0.0) * sdv;                       //  region of its own, and a basic-block boundary for the scheduler)
     }
-    int lkv = lk, lkb = lk * (IR + OR - 1) - ((lk * (lk - 1)) >> 1);   // (opaque per iteration: what is derived from them is
+    int lkv = lk, lkb = lk * D::HCA - ((lk * (lk - 1)) >> 1);          // (opaque per iteration: what is derived from them is
     asm volatile("" : "+v"(lkv), "+v"(lkb));                              //  recomputed, not kept in registers across the loop)
     const double sls = row16_sum(lsd);                // sum_(i,r) lam_(i,r) sd_(i,r), in every lane
     {                                                 // CL[j][r] = sum_i C_ij lam_(i,r), WL[j][r] = sum_i D_ij lam_(i,r)
@@ -1238,11 +1238,15 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     // data): J^T first, then one tile column rt of H at a time -- M_i[:, tile rt] is the B operand of the tiles (ct <= rt, rt)
     // only, the rank-2 time rows of those tiles need HT on the tiles up to rt.
     // Entry v of a tile: block column c = 16ct + lk + 4v, row (H) r = 16rt + lr or (J) jr = lr; 16 consecutive lanes cover
-    // 128 contiguous bytes of the reference's slot order (DenseFunctionBase.h:1112-1123); first slot of block column c,
-    // minus c: H(r, c) sits at cbv + r, J(jr, c) at cbv + IR + jr.
-    auto cbv = [&](int ct, int v) {                  // c = c0 + lk:  cb(c) = cb(c0) + [lk (IR+OR-1) - lk (lk-1) / 2] - c0 lk
+    // 128 contiguous bytes of the block in either layout (defect_dims.h, Dims::KL; the reference's order:
+    // DenseFunctionBase.h:1112-1123): H(r, c) sits at hcb + r, J(jr, c) at jcb + jr.
+    auto hcb = [&](int ct, int v) {                  // c = c0 + lk:  hcol(c) = hcol(c0) + [lk HCA - lk (lk-1) / 2] - c0 lk
       const int c0 = 16 * ct + 4 * v;
-      return c0 * (IR + OR - 1) - ((c0 * (c0 - 1)) >> 1) + lkb - c0 * lkv;
+      return D::HOFF + c0 * D::HCA - ((c0 * (c0 - 1)) >> 1) + lkb - c0 * lkv;
+    };
+    auto jcb = [&](int ct, int v) {
+      if constexpr (D::KL != 0) return (16 * ct + 4 * v) * OR + lkv * OR;
+      else return hcb(ct, v) + IR;
     };
     double ah[K][KS];                                  // A operand of the M products: [h E_i H^_i ; E_i g^_i]
 #pragma unroll
@@ -1324,7 +1328,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       } else {
 #pragma unroll
         for (int v = 0; v < 4; v++)
-          bst(o_kkt, unsigned(cbv(ct, v) + IR + 16 * jt + lr), 16 * jt + lr < OR && (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR), acc[v]);
+          bst(o_kkt, unsigned(jcb(ct, v) + 16 * jt + lr), 16 * jt + lr < OR && (CFULL || ct + 1 < TI || 16 * ct + lk + 4 * v < IR), acc[v]);
       }
     };
     if constexpr (!R::JRIDE) {
@@ -1496,10 +1500,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #pragma unroll
         for (int ct = 0; ct < rt; ct++)                 // tiles left of the diagonal: every column < IR
 #pragma unroll
-          for (int v = 0; v < 4; v++) bst(o_h, unsigned(cbv(ct, v) + 16 * rt + lr), CFULL || 16 * rt + lr < IR, accH[ct][v]);
+          for (int v = 0; v < 4; v++) bst(o_h, unsigned(hcb(ct, v) + 16 * rt + lr), CFULL || 16 * rt + lr < IR, accH[ct][v]);
 #pragma unroll
         for (int v = 0; v < 4; v++)                     // diagonal tile: r >= c
-          bst(o_h, unsigned(cbv(rt, v) + 16 * rt + lr), lr >= lk + 4 * v && (CFULL || rt + 1 < TI || 16 * rt + lr < IR), accH[rt][v]);
+          bst(o_h, unsigned(hcb(rt, v) + 16 * rt + lr), lr >= lk + 4 * v && (CFULL || rt + 1 < TI || 16 * rt + lr < IR), accH[rt][v]);
       }
     }
     __builtin_amdgcn_s_setprio(0);

@@ -96,7 +96,6 @@ struct RdDims {
   static constexpr int NWH = int((sizeof(LaneH) + 3) / 4), NQH = (NWH + 3) / 4;
   static constexpr int NRECH = RG * 16;
   static constexpr long long table_bytes() { return (long long)NQH * 16 * NRECH; }
-  static constexpr int colstart(int c) { return c * (IR + OR) - (c * (c - 1)) / 2; }   // first slot of block column c (DenseFunctionBase.h:1112-1123)
 };
 
 template <class Ode, class D, int ZERO>
@@ -197,7 +196,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
 #define RDTS() do { if (tsp && *ntsp < 24) tsp[(*ntsp)++] = clock64(); } while (0)
   using X = RdDims<Ode, D>;
   constexpr int K = X::K, CS = X::CS, n = X::n, q = X::q, N = X::N, T = X::T, TF = X::TF, IR = X::IR, OR = X::OR, P0 = X::P0, p = X::p;
-  constexpr int NZJ = X::NZJ, NZH = X::NZH, RG = X::RG, CRG = X::CRG, NKKT = D::NKKT;
+  constexpr int NZJ = X::NZJ, NZH = X::NZH, RG = X::RG, CRG = X::CRG, KSTRIDE = D::KSTRIDE;   // (block layout: defect_dims.h, Dims::KL)
   constexpr int oS = __builtin_offsetof(LglTab, s) / 8, oA = __builtin_offsetof(LglTab, A) / 8, oB = __builtin_offsetof(LglTab, B) / 8;
   constexpr int oU = __builtin_offsetof(LglTab, U) / 8, oC = __builtin_offsetof(LglTab, C) / 8, oD = __builtin_offsetof(LglTab, D) / 8;
   constexpr int oE = __builtin_offsetof(LglTab, E) / 8;
@@ -215,7 +214,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
   // did not ask for: zero records, every store dropped)
   const int nsegs = seg_hi > seg_lo ? seg_hi - seg_lo : 0;
   const size_t s0 = size_t(seg_lo);
-  const __amdgpu_buffer_rsrc_t rs_kkt = __builtin_amdgcn_make_buffer_rsrc(a.KKT + s0 * size_t(NKKT), 0, a.KKT ? nsegs * NKKT * 8 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_kkt = __builtin_amdgcn_make_buffer_rsrc(a.KKT + s0 * size_t(KSTRIDE), 0, a.KKT ? nsegs * KSTRIDE * 8 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_fx = __builtin_amdgcn_make_buffer_rsrc(a.FX + s0 * size_t(OR), 0, a.FX ? nsegs * OR * 8 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_agx = __builtin_amdgcn_make_buffer_rsrc(a.AGX + s0 * size_t(IR), 0, (a.AGX && a.L) ? nsegs * IR * 8 : 0, 0x00020000);
   auto bst = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff, double v) {
@@ -253,13 +252,13 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
     const bool rv = tv && r < IR;
     const lds_double* const S = pslot(g);
     const lds_double* const Sl = S + lr;
-    const unsigned kb = rv ? unsigned((pseg(g) - seg_lo) * (NKKT * 8) + 8 * r) : INVALID;   // slot (r, c) at kb + 8 (colstart(c) - c)
+    const unsigned kb = rv ? unsigned((pseg(g) - seg_lo) * (KSTRIDE * 8) + 8 * r) : INVALID;   // slot (r, c) at kb + 8 hcol(c)
     if constexpr (LEVEL < 2) {
       // the Jacobian kinds (evalSOE / evalAUG): the Hessian slots hold zeros -- unless the caller never reads them
       // (ASSET_HIP_KEEP_HESSIAN_SLOTS: the pass is not run at all, below)
       rd_for<IR>([&](auto CC) {
         constexpr int c = decltype(CC)::value;
-        bst(rs_kkt, (c <= r) ? kb : INVALID, 8 * (X::colstart(c) - c), 0.0);
+        bst(rs_kkt, (c <= r) ? kb : INVALID, 8 * D::hcol(c), 0.0);
       });
       return;
     }
@@ -437,15 +436,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
           });
           rd_for<nb>([&](auto Bx) {
             constexpr int c = b0 + decltype(Bx)::value;
-#if defined(ASSET_EXP_RDALIGN)   // (experiment, WRONG results: the entries in 32-byte sectors shared with the Jacobian part are not stored)
-            {
-              constexpr int s0c = X::colstart(c), bc = s0c + IR - c, lo = (s0c + 3) / 4 * 4, hi = bc / 4 * 4;
-              const int slot = s0c + r - c;
-              bst(rs_kkt, (c <= r && slot >= lo && slot < hi) ? kb : INVALID, 8 * (X::colstart(c) - c), acc[decltype(Bx)::value]);
-            }
-#else
-            bst(rs_kkt, (c <= r) ? kb : INVALID, 8 * (X::colstart(c) - c), acc[decltype(Bx)::value]);
-#endif
+            bst(rs_kkt, (c <= r) ? kb : INVALID, 8 * D::hcol(c), acc[decltype(Bx)::value]);
           });
         });
       }
@@ -464,7 +455,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
     const lds_double* const S = pslot(g);
     const lds_double* const Sl = S + lr;
     const int srel = pseg(g) - seg_lo;
-    const unsigned kb = isJ ? unsigned(srel * (NKKT * 8) + 8 * (IR + jr)) : INVALID;
+    const unsigned kb = isJ ? unsigned(srel * (KSTRIDE * 8) + 8 * jr) : INVALID;            // slot (jr, c) at kb + 8 jcol(c)
     const double h = S[S_FB + K * n];                  // (t_f - t_0, left there by the interior phase)
     const double rh = 1.0 / h;
     // the defect value of the row: sum_j C_ij z_j[r] + h (sum_j D_ij f_j[r] + E_i f^_i[r])    (LGLDefects.h:460-500)
@@ -598,15 +589,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       });
       rd_for<nb>([&](auto Bx) {
         constexpr int c = b0 + decltype(Bx)::value;
-#if defined(ASSET_EXP_RDALIGN)
-        {
-          constexpr int bc = X::colstart(c) + IR - c, ec = bc + OR, lo = (bc + 3) / 4 * 4, hi = ec / 4 * 4;
-          const int slot = bc + jr;
-          bst(rs_kkt, (slot >= lo && slot < hi) ? kb : INVALID, 8 * (X::colstart(c) - c), acc[decltype(Bx)::value]);
-        }
-#else
-        bst(rs_kkt, kb, 8 * (X::colstart(c) - c), acc[decltype(Bx)::value]);
-#endif
+        bst(rs_kkt, kb, 8 * D::jcol(c), acc[decltype(Bx)::value]);
         // the gradient row's entry: into the segment's z section (dead: this pass has read it), the other lanes into lam cells of
         // their own (dead as well) -- one coalesced store per sixteen entries below instead of a store of four lanes per column
         if constexpr (MODE == 1) bst(rs_agx, gbd, 8 * c, acc[decltype(Bx)::value]);   // (the partner's phase still reads z and lam: no staging there)

@@ -143,6 +143,7 @@ struct KernelEntry {
   int mode;     // ASSET_HIP_* transcription mode
   int blocked;
   int ir, orr, nkkt;
+  int kl, kstride;        // layout of the KKT blocks the kernels write (defect_dims.h: Dims::KL) and the block stride in doubles
   int seg_per_group;      // segments whose ODE results one workgroup keeps in its workspace at a time
   size_t lds_bytes;
   size_t work_doubles;    // workspace doubles per segment (ODE result slot)
@@ -154,6 +155,7 @@ inline void entry_from_table(KernelEntry& e, const char* name, const KernelTable
   const long long* m = t->meta;
   e.ode = name, e.xv = int(m[MF_XV]), e.uv = int(m[MF_UV]), e.pv = int(m[MF_PV]), e.mode = int(m[MF_MODE]);
   e.blocked = int(m[MF_BLOCKED]), e.ir = int(m[MF_IR]), e.orr = int(m[MF_OR]), e.nkkt = int(m[MF_NKKT]);
+  e.kl = int(m[MF_KL]), e.kstride = m[MF_KSTRIDE] > 0 ? int(m[MF_KSTRIDE]) : e.nkkt;   // (plain functions, bundles: the reference's order)
   e.seg_per_group = int(m[MF_G]), e.lds_bytes = size_t(m[MF_LDS_BYTES]), e.work_doubles = size_t(m[MF_WORK_DOUBLES]);
   e.naconst = int(m[MF_NACONST]), e.table = t, e.next = nullptr;
 }

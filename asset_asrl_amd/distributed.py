@@ -39,10 +39,18 @@ _ADJ = (1, 3, 4)     # evaluation kinds that produce an adjoint gradient (CON_AD
 
 
 def _sizes(ode, mode, blocked):
+    """(IR, OR, NKKT, KSTRIDE) of a rank that owns no segment (it still takes part in the exchange): from the library's tables."""
     from . import _lib, synth
     from .build import dims
     d = dims(*_lib.ode_sizes(ode), synth.MODE_CS[mode] if isinstance(mode, str) else max(mode, 2), blocked)
-    return d["IR"], d["OR"], d["NKKT"]
+    mode_id = _lib.MODES[mode] if isinstance(mode, str) else int(mode)
+    _, nk, stride, _, _ = _lib.kkt_layout(ode, mode_id, bool(blocked))
+    assert nk == d["NKKT"]
+    return d["IR"], d["OR"], nk, stride
+
+
+def _al16(n: int) -> int:
+    return (n + 15) // 16 * 16          # (a block array starts on a 128-byte line)
 
 
 class HostSharedBlocks:
@@ -191,9 +199,17 @@ class ShardedDefectEvaluator(_StreamOrder):
             self.ev = evaluator_factory(ode, mode, blocked, vindex[self.start:self.start + self.count],
                                         cindex[self.start:self.start + self.count], n_primal, n_equal, device)
             self.IR, self.OR, self.NKKT = self.ev.IR, self.ev.OR, self.ev.NKKT
+            self.KSTRIDE = getattr(self.ev, "KSTRIDE", self.NKKT)      # blocks travel in the handle's layout (DefectEvaluator.kkt_rows / kkt_cols)
         else:
-            self.IR, self.OR, self.NKKT = _sizes(ode, mode, blocked)
+            self.IR, self.OR, self.NKKT, self.KSTRIDE = _sizes(ode, mode, blocked)
         self._local = self._recv = None
+
+    def kkt_to_reference(self, kkt):
+        """KKT blocks as the ranks write and exchange them ([n, KSTRIDE]) -> [n, NKKT] in the canonical (reference) order
+        (host-side; needs a rank that owns segments -- DefectEvaluator.kkt_to_reference)."""
+        if self.ev is not None and hasattr(self.ev, "kkt_to_reference"):
+            return self.ev.kkt_to_reference(kkt)
+        return kkt
 
     # ---- local evaluation (host arrays) -----------------------------------------------------
     def eval_local(self, what: int, X, L=None):
@@ -206,12 +222,12 @@ class ShardedDefectEvaluator(_StreamOrder):
     @property
     def slot_doubles(self) -> int:
         """Length of a rank's flat output buffer: [fx | agx | kkt] for max_count segments."""
-        return self.max_count * (self.OR + self.IR + self.NKKT)
+        return _al16(self.max_count * (self.OR + self.IR)) + self.max_count * self.KSTRIDE
 
     def _views(self, flat, count=None):
         m = self.max_count
-        o1, o2 = m * self.OR, m * (self.OR + self.IR)
-        fx, agx, kkt = flat[:o1].view(m, self.OR), flat[o1:o2].view(m, self.IR), flat[o2:].view(m, self.NKKT)
+        o1, o2, o3 = m * self.OR, m * (self.OR + self.IR), _al16(m * (self.OR + self.IR))
+        fx, agx, kkt = flat[:o1].view(m, self.OR), flat[o1:o2].view(m, self.IR), flat[o3:].view(m, self.KSTRIDE)
         if count is not None:
             fx, agx, kkt = fx[:count], agx[:count], kkt[:count]
         return fx, agx, kkt
@@ -275,7 +291,7 @@ class ShardedDefectEvaluator(_StreamOrder):
         return [self._views(self._recv[r], c) for r, (_, c) in enumerate(self.shards)]
 
     def blocks_on_root(self):
-        """(fx[nseg_total, OR], agx[nseg_total, IR], kkt[nseg_total, NKKT]) on the root (None elsewhere): the shards
+        """(fx[nseg_total, OR], agx[nseg_total, IR], kkt[nseg_total, KSTRIDE], handle layout) on the root (None elsewhere): the shards
         of `shard_blocks_on_root` concatenated per kind (one device copy; the scatter can as well walk the shards)."""
         import torch
         per = self.shard_blocks_on_root()
@@ -461,10 +477,19 @@ class PhaseShardedEvaluator(_StreamOrder):
             cix = np.concatenate([np.asarray(phases[k][1]) for k in self.mine], axis=0)
             self.ev = evaluator_factory(ode, mode, blocked, vix, cix, n_primal, n_equal, device)
             self.IR, self.OR, self.NKKT = self.ev.IR, self.ev.OR, self.ev.NKKT
+            self.KSTRIDE = getattr(self.ev, "KSTRIDE", self.NKKT)
         else:
-            self.IR, self.OR, self.NKKT = _sizes(ode, mode, blocked)
-        self.width = self.OR + self.IR + self.NKKT
+            self.IR, self.OR, self.NKKT, self.KSTRIDE = _sizes(ode, mode, blocked)
         self._local = self._recv = None
+
+    def kkt_to_reference(self, kkt):
+        if self.ev is not None and hasattr(self.ev, "kkt_to_reference"):
+            return self.ev.kkt_to_reference(kkt)
+        return kkt
+
+    def _flat_doubles(self, nlocal: int) -> int:
+        m = nlocal * self.nseg
+        return _al16(m * (self.OR + self.IR)) + m * self.KSTRIDE
 
     def _nlocal(self, rank: int) -> int:
         return len(range(rank, self.nphases, self.world))
@@ -472,8 +497,8 @@ class PhaseShardedEvaluator(_StreamOrder):
     def _views(self, flat, nlocal: int):
         """(fx, agx, kkt) of a rank's flat buffer: [fx | agx | kkt], each over that rank's nlocal * nseg applications."""
         m = nlocal * self.nseg
-        o1, o2, o3 = m * self.OR, m * (self.OR + self.IR), m * self.width
-        return flat[:o1].view(m, self.OR), flat[o1:o2].view(m, self.IR), flat[o2:o3].view(m, self.NKKT)
+        o1, o2, o3 = m * self.OR, m * (self.OR + self.IR), _al16(m * (self.OR + self.IR))
+        return flat[:o1].view(m, self.OR), flat[o1:o2].view(m, self.IR), flat[o3:o3 + m * self.KSTRIDE].view(m, self.KSTRIDE)
 
     def _phase_views(self, flat, nlocal: int, slot: int):
         lo, hi = slot * self.nseg, (slot + 1) * self.nseg
@@ -482,10 +507,9 @@ class PhaseShardedEvaluator(_StreamOrder):
     def alloc_device(self, device, dst: int = 0, always_exchange: bool = False):
         import torch
         self._dst = dst
-        self._local = torch.zeros(self.per_rank * self.nseg * self.width, dtype=torch.float64, device=device)
+        self._local = torch.zeros(self._flat_doubles(self.per_rank), dtype=torch.float64, device=device)
         if self.rank == dst and (self.world > 1 or always_exchange):
-            self._recv = torch.empty((self.world, self.per_rank * self.nseg * self.width), dtype=torch.float64,
-                                     device=device)
+            self._recv = torch.empty((self.world, self._flat_doubles(self.per_rank)), dtype=torch.float64, device=device)
         self._ordered = self.world > 1 or always_exchange
         return self
 

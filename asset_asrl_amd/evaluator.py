@@ -13,6 +13,72 @@ def _dptr(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def reference_slot_order(IR: int, OR: int):
+    """(rows, cols) of the canonical numbering of a block's entries -- the reference's order,
+    ``for i: {H(j,i), j>=i ; J(j,i)}`` (DenseFunctionBase.h:1112-1123); Jacobian rows are IR + j."""
+    rows, cols = [], []
+    for i in range(IR):
+        rows += list(range(i, IR)) + [IR + j for j in range(OR)]
+        cols += [i] * (IR - i + OR)
+    return np.asarray(rows, dtype=np.int32), np.asarray(cols, dtype=np.int32)
+
+
+def kkt_layout_table(IR: int, OR: int, kl: int):
+    """Host mirror of the block layouts the kernels write (csrc/defect_dims.h: Dims::KL, hcol / jcol): (stride, rows, cols),
+    rows / cols as asset_hip_defect_kkt_layout returns them.  kl 0: the reference's order; kl 1: J column-major, then the packed
+    lower triangle of H column-major, each region padded to a multiple of 16 doubles."""
+    if not kl:
+        r, c = reference_slot_order(IR, OR)
+        return r.size, r, c
+    jreg, hreg = (OR * IR + 15) // 16 * 16, (IR * (IR + 1) // 2 + 15) // 16 * 16
+    rows = np.full(jreg + hreg, -1, dtype=np.int32)
+    cols = np.full(jreg + hreg, -1, dtype=np.int32)
+    for c in range(IR):
+        rows[c * OR:(c + 1) * OR], cols[c * OR:(c + 1) * OR] = np.arange(IR, IR + OR), c
+        h0 = jreg + c * IR - c * (c - 1) // 2
+        rows[h0:h0 + IR - c], cols[h0:h0 + IR - c] = np.arange(c, IR), c
+    return jreg + hreg, rows, cols
+
+
+class _KktLayout:
+    """The order of a handle's KKT blocks (asset_hip_defect_kkt_layout): ``KSTRIDE`` doubles per block, ``kkt_rows`` /
+    ``kkt_cols`` per slot (-1: padding), ``kkt_perm[k]`` = offset in the block of canonical entry k."""
+
+    def _read_layout(self, handle):
+        L = _lib.lib()
+        st = C.c_int()
+        kl = L.asset_hip_defect_kkt_layout(handle, C.byref(st), None, None)
+        if kl < 0:
+            _lib.check(kl, "asset_hip_defect_kkt_layout")
+        self.KSTRIDE, self.kkt_layout = st.value, kl
+        self.kkt_rows = np.empty(self.KSTRIDE, dtype=np.int32)
+        self.kkt_cols = np.empty(self.KSTRIDE, dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        kl = L.asset_hip_defect_kkt_layout(handle, None, self.kkt_rows.ctypes.data_as(ip), self.kkt_cols.ctypes.data_as(ip))
+        if kl < 0:
+            _lib.check(kl, "asset_hip_defect_kkt_layout")
+        self._set_layout(kl, self.KSTRIDE, self.kkt_rows, self.kkt_cols)
+
+    def _set_layout(self, kl, stride, rows, cols):
+        """(needs self.IR / OR / NKKT)"""
+        self.kkt_layout, self.KSTRIDE, self.kkt_rows, self.kkt_cols = int(kl), int(stride), rows, cols
+        where = {(int(r), int(c)): k for k, (r, c) in enumerate(zip(self.kkt_rows, self.kkt_cols)) if r >= 0}
+        rr, cc = reference_slot_order(self.IR, self.OR)
+        if len(where) != self.NKKT or any((int(r), int(c)) not in where for r, c in zip(rr, cc)):
+            raise _lib.AssetHipError("asset_hip_defect_kkt_layout does not enumerate every entry of the block exactly once")
+        self.kkt_perm = np.asarray([where[(int(r), int(c))] for r, c in zip(rr, cc)], dtype=np.int64)
+        self._perm_identity = self.KSTRIDE == self.NKKT and bool(np.all(self.kkt_perm == np.arange(self.NKKT)))
+
+    def kkt_to_reference(self, kkt):
+        """Blocks as the handle writes them ([nseg, KSTRIDE] or flat; numpy or a torch tensor) -> [nseg, NKKT] in the canonical
+        (reference) order.  A host-side convenience of tests and scripts: a solver-side consumer walks ``kkt_rows`` /
+        ``kkt_cols`` instead (host/batched_defect_constraint.cpp)."""
+        if hasattr(kkt, "detach"):
+            kkt = kkt.detach().cpu().numpy()
+        a = np.asarray(kkt).reshape(-1, self.KSTRIDE)
+        return a if self._perm_identity else a[:, self.kkt_perm]
+
+
 _STREAM_LEGACY = 1      # include/asset_hip.h: ASSET_HIP_STREAM_LEGACY = hipStreamLegacy, the null stream named explicitly
 
 
@@ -27,11 +93,13 @@ def _stream_arg(stream):
     return C.c_void_p(h if h else _STREAM_LEGACY)
 
 
-class DefectEvaluator:
+class DefectEvaluator(_KktLayout):
     """Evaluates the defect constraint of ``nseg`` mesh segments on a HIP device.
 
     ``vindex[nseg, IR]`` / ``cindex[nseg, OR]`` are the application-major index tables
-    (see indexing.PhaseIndexer.make_defect_Vindex_Cindex).
+    (see indexing.PhaseIndexer.make_defect_Vindex_Cindex).  KKT blocks: the device-pointer entry points (``eval_device``,
+    ``bind_device``, ``time_device``) and the pinned outputs take / return them in the HANDLE'S layout -- ``nseg * KSTRIDE``
+    doubles, order ``kkt_rows`` / ``kkt_cols`` --; ``eval`` converts to the canonical order unless told ``native=True``.
     """
 
     def __init__(self, ode: str, mode, blocked: bool, vindex, cindex, n_primal: int, n_equal: int,
@@ -56,6 +124,7 @@ class DefectEvaluator:
         ir, orr, nk = C.c_int(), C.c_int(), C.c_int()
         _lib.check(L.asset_hip_defect_sizes(self._h, C.byref(ir), C.byref(orr), C.byref(nk)))
         self.IR, self.OR, self.NKKT = ir.value, orr.value, nk.value
+        self._read_layout(self._h)
         if self.vindex.shape[1] != self.IR or self.cindex.shape[1] != self.OR:
             self.close()
             raise ValueError(f"index tables are [{self.vindex.shape[1]}],[{self.cindex.shape[1]}] wide, "
@@ -100,8 +169,10 @@ class DefectEvaluator:
         return (self.IR * (self.IR + 1) // 2 if dohess else 0) + (self.OR * self.IR if dojac else 0)
 
     # ---- host-pointer evaluation -----------------------------------------------------------
-    def eval(self, what: int, X, L=None):
-        """Returns (fx[nseg,OR], agx[nseg,IR] or None, kkt[nseg,NKKT] or None)."""
+    def eval(self, what: int, X, L=None, native: bool = False):
+        """Returns (fx[nseg,OR], agx[nseg,IR] or None, kkt or None).  kkt: [nseg, NKKT] in the canonical (reference) order --
+        a host-side re-ordering of what the C ABI returned -- or, with ``native=True`` and always with pinned outputs
+        (``pin_outputs``), the blocks as the C ABI returns them: [nseg, KSTRIDE] in the handle's layout."""
         X = np.ascontiguousarray(X, dtype=np.float64)
         if X.size != self.n_primal:
             raise ValueError(f"X has {X.size} entries, expected {self.n_primal}")
@@ -117,9 +188,13 @@ class DefectEvaluator:
         else:
             fx = np.empty((self.nseg, self.OR))
             agx = np.empty((self.nseg, self.IR)) if kind in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
-            kkt = np.empty((self.nseg, self.NKKT)) if kind >= JAC else None
+            kkt = np.empty((self.nseg, self.KSTRIDE)) if kind >= JAC else None
+            if kkt is not None and self.KSTRIDE != self.NKKT:
+                kkt.fill(np.nan)           # (padding slots are never written: make a consumer that reads them stand out)
         _lib.check(_lib.lib().asset_hip_defect_eval(self._h, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx),
                                                     _dptr(kkt)), "asset_hip_defect_eval")
+        if kkt is not None and not native and self._pinned is None:
+            kkt = self.kkt_to_reference(kkt)
         return fx, agx, kkt
 
     def set_appl_consts(self, consts):
@@ -131,7 +206,7 @@ class DefectEvaluator:
         """Allocate the block arrays once and page-lock them (asset_hip_host_register): ``eval`` then returns these
         arrays, overwritten by every call, and the copies out run at PCIe rate instead of through pageable staging."""
         if self._pinned is None:
-            bufs = (np.empty((self.nseg, self.OR)), np.empty((self.nseg, self.IR)), np.empty((self.nseg, self.NKKT)))
+            bufs = (np.empty((self.nseg, self.OR)), np.empty((self.nseg, self.IR)), np.empty((self.nseg, self.KSTRIDE)))
             for b in bufs:
                 _lib.check(_lib.lib().asset_hip_host_register(b.ctypes.data, b.nbytes), "asset_hip_host_register")
             self._pinned = bufs
@@ -139,7 +214,8 @@ class DefectEvaluator:
 
     # ---- on-device KKT assembly -----------------------------------
     def set_kkt_map(self, slot_locations, nvalues: int, accumulate: bool = False):
-        """slot_locations[V, k] = KKTLocations[InnerKKTStarts[V] + k]: where block slot k of application V lives in the
+        """slot_locations[V, k] = KKTLocations[InnerKKTStarts[V] + k]: where entry k (canonical numbering: the reference's
+        order, whatever the layout of the handle's blocks) of application V lives in the
         solver's CSR value array of length ``nvalues`` (uploaded once per sparsity analysis).  ``accumulate``: the
         device-pointer evaluation adds into whatever the value array holds (all atomics) instead of expecting zeros
         at this constraint's locations."""
@@ -220,7 +296,7 @@ class DefectEvaluator:
 
 
 def unpack_kkt_block(blk: np.ndarray, IR: int, OR: int):
-    """Block slot order -> (H lower-triangular filled symmetric [IR,IR], J [OR,IR])."""
+    """A block in the canonical (reference) order -> (H lower-triangular filled symmetric [IR,IR], J [OR,IR])."""
     H = np.zeros((IR, IR))
     J = np.zeros((OR, IR))
     k = 0
@@ -233,11 +309,14 @@ def unpack_kkt_block(blk: np.ndarray, IR: int, OR: int):
     return H, J
 
 
-class ShardedDefectEvaluator:
+class ShardedDefectEvaluator(_KktLayout):
     """One constraint as several device handles in ONE process (include/asset_hip.h: asset_hip_defect_create_sharded): the
     reference's ``ConstraintFunction.thread_split`` (ConstraintFunction.h:55-62, IndexingData.h:117-146) with a device per
     chunk instead of a CPU thread.  ``devices``: one HIP ordinal per shard; naming a device several times gives several
-    handles on it.  Host-pointer evaluation only: every shard's blocks land in the caller's arrays over its own PCIe link."""
+    handles on it.  Host-pointer evaluation only: every shard's blocks land in the caller's arrays over its own PCIe link.
+    ``pin_outputs()`` keeps ONE set of page-locked output arrays across calls (``eval`` then returns views of them, overwritten by
+    the next call, the KKT blocks in the handles' layout) -- what a solver does with its RHS and KKT arrays; without it the
+    outputs are fresh pageable arrays and the library drives every shard from a host thread of its own."""
 
     def __init__(self, ode: str, mode, blocked: bool, vindex, cindex, n_primal: int, n_equal: int, devices):
         L = _lib.lib()
@@ -255,7 +334,17 @@ class ShardedDefectEvaluator:
         ir, orr, nk = C.c_int(), C.c_int(), C.c_int()
         _lib.check(L.asset_hip_defect_sizes(C.c_void_p(L.asset_hip_sharded_handle(self._s, 0)), C.byref(ir), C.byref(orr), C.byref(nk)))
         self.IR, self.OR, self.NKKT = ir.value, orr.value, nk.value
+        self._read_layout(C.c_void_p(L.asset_hip_sharded_handle(self._s, 0)))
         self._nvalues = -1
+        self._pinned = None
+
+    def pin_outputs(self):
+        if self._pinned is None:
+            bufs = (np.empty((self.nseg, self.OR)), np.empty((self.nseg, self.IR)), np.empty((self.nseg, self.KSTRIDE)))
+            for b in bufs:
+                _lib.check(_lib.lib().asset_hip_host_register(b.ctypes.data, b.nbytes), "asset_hip_host_register")
+            self._pinned = bufs
+        return self
 
     @property
     def ranges(self):
@@ -267,15 +356,23 @@ class ShardedDefectEvaluator:
             out.append((f.value, c.value, d.value))
         return out
 
-    def eval(self, what: int, X, L=None):
+    def eval(self, what: int, X, L=None, native: bool = False):
+        """As DefectEvaluator.eval: kkt in the canonical order unless ``native`` (or pinned outputs)."""
         X = np.ascontiguousarray(X, dtype=np.float64)
         L = None if L is None else np.ascontiguousarray(L, dtype=np.float64)
         kind = what & 0xFF
-        fx = np.empty((self.nseg, self.OR))
-        agx = np.empty((self.nseg, self.IR)) if kind in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
-        kkt = np.empty((self.nseg, self.NKKT)) if kind >= JAC else None
+        if self._pinned is not None:
+            fx, agx, kkt = self._pinned
+            agx = agx if kind in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+            kkt = kkt if kind >= JAC else None
+        else:
+            fx = np.empty((self.nseg, self.OR))
+            agx = np.empty((self.nseg, self.IR)) if kind in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+            kkt = np.empty((self.nseg, self.KSTRIDE)) if kind >= JAC else None
         _lib.check(_lib.lib().asset_hip_sharded_eval(self._s, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx), _dptr(kkt)),
                    "asset_hip_sharded_eval")
+        if kkt is not None and not native and self._pinned is None:
+            kkt = self.kkt_to_reference(kkt)
         return fx, agx, kkt
 
     def set_kkt_map(self, slot_locations, nvalues: int):
@@ -292,8 +389,11 @@ class ShardedDefectEvaluator:
         if values.dtype != np.float64 or not values.flags.c_contiguous or values.size != self._nvalues:
             raise ValueError("values must be a contiguous float64 array of the map's length")
         kind = what & 0xFF
-        fx = np.empty((self.nseg, self.OR))
-        agx = np.empty((self.nseg, self.IR)) if kind in (JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
+        if self._pinned is not None:
+            fx, agx = self._pinned[0], (self._pinned[1] if kind in (JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
+        else:
+            fx = np.empty((self.nseg, self.OR))
+            agx = np.empty((self.nseg, self.IR)) if kind in (JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None
         _lib.check(_lib.lib().asset_hip_sharded_eval_assembled(self._s, what, _dptr(X), _dptr(L), _dptr(fx), _dptr(agx), _dptr(values)),
                    "asset_hip_sharded_eval_assembled")
         return fx, agx
@@ -301,6 +401,9 @@ class ShardedDefectEvaluator:
     def close(self):
         s, self._s = getattr(self, "_s", None), None
         if s and _lib is not None and getattr(_lib, "lib", None) is not None:
+            for b in (getattr(self, "_pinned", None) or ()):
+                _lib.lib().asset_hip_host_unregister(b.ctypes.data)
+            self._pinned = None
             _lib.lib().asset_hip_sharded_destroy(s)
 
     __del__ = close

@@ -84,6 +84,9 @@ void BatchedDefectConstraint::create(const SolverIndexingData& data) {
     throw std::invalid_argument(std::string("BatchedDefectConstraint: ") + asset_hip_last_error());
   check(rc, devices_.empty() ? "asset_hip_defect_create" : "asset_hip_defect_create_sharded");
   check(asset_hip_defect_sizes(h_, &ir_, &or_, &nkkt_), "asset_hip_defect_sizes");
+  if (asset_hip_defect_kkt_layout(h_, &kstride_, nullptr, nullptr) < 0) check(ASSET_HIP_EINVAL, "asset_hip_defect_kkt_layout");
+  lrows_.resize(kstride_), lcols_.resize(kstride_);
+  if (asset_hip_defect_kkt_layout(h_, nullptr, lrows_.data(), lcols_.data()) < 0) check(ASSET_HIP_EINVAL, "asset_hip_defect_kkt_layout");
   if (ir_ != data.input_size || or_ != data.output_size) {
     if (hs_) asset_hip_sharded_destroy(hs_); else asset_hip_defect_destroy(h_);
     h_ = nullptr, hs_ = nullptr;
@@ -91,7 +94,7 @@ void BatchedDefectConstraint::create(const SolverIndexingData& data) {
   }
   fx_.resize(size_t(nappl_) * or_);
   agx_.resize(size_t(nappl_) * ir_);
-  kkt_.resize(size_t(nappl_) * nkkt_);
+  kkt_.resize(size_t(nappl_) * kstride_);
   // the staging arrays live as long as the constraint: page-lock them so the block copies run at PCIe rate
   pinned_ = asset_hip_host_register(fx_.data(), fx_.size() * sizeof(double)) == 0 &&
             asset_hip_host_register(agx_.data(), agx_.size() * sizeof(double)) == 0 &&
@@ -136,7 +139,7 @@ void BatchedDefectConstraint::rebind(const SolverIndexingData& data, int primal_
   nappl_ = data.NumAppl(), n_primal_ = primal_vars, n_equal_ = equal_cons;
   fx_.resize(size_t(nappl_) * or_);
   agx_.resize(size_t(nappl_) * ir_);
-  kkt_.resize(size_t(nappl_) * nkkt_);
+  kkt_.resize(size_t(nappl_) * kstride_);
   pinned_ = asset_hip_host_register(fx_.data(), fx_.size() * sizeof(double)) == 0 &&
             asset_hip_host_register(agx_.data(), agx_.size() * sizeof(double)) == 0 &&
             asset_hip_host_register(kkt_.data(), kkt_.size() * sizeof(double)) == 0;
@@ -205,47 +208,41 @@ int BatchedDefectConstraint::numKKTEles(bool dojac, bool dohess) const {   // De
 
 void BatchedDefectConstraint::getKKTSpace(int* KKTrows, int* KKTcols, int& freeloc, int conoffset, bool dojac,
                                           bool dohess, SolverIndexingData& data) const {
+  // (row, col) of an application's slots in the order of the device's blocks (see the header): DenseFunctionBase.h:1097-1129 with
+  // its two loops replaced by one walk over the layout
   data.InnerKKTStarts.resize(data.NumAppl());
   for (int V = 0; V < data.NumAppl(); V++) {
     data.InnerKKTStarts[V] = freeloc;
-    for (int i = 0; i < ir_; i++) {
-      if (dohess)
-        for (int j = i; j < ir_; j++) {
-          if (!HessianElemIsNonZero(j, i)) continue;
-          KKTrows[freeloc] = data.VLoc(j, V);
-          KKTcols[freeloc] = data.VLoc(i, V);
-          freeloc++;
-        }
-      if (dojac)
-        for (int j = 0; j < or_; j++) {
-          KKTrows[freeloc] = data.CLoc(j, V) + conoffset;
-          KKTcols[freeloc] = data.VLoc(i, V);
-          freeloc++;
-        }
+    for (int k = 0; k < kstride_; k++) {
+      const int r = lrows_[k], i = lcols_[k];
+      if (r < 0) continue;                                       // padding
+      if (r < ir_) {
+        if (!dohess || !HessianElemIsNonZero(r, i)) continue;
+        KKTrows[freeloc] = data.VLoc(r, V);
+      } else {
+        if (!dojac) continue;
+        KKTrows[freeloc] = data.CLoc(r - ir_, V) + conoffset;
+      }
+      KKTcols[freeloc] = data.VLoc(i, V);
+      freeloc++;
     }
   }
 }
 
-void BatchedDefectConstraint::scatter_kkt(const double* blocks, int nkkt, int ir, int orr, bool dohess,
-                                          double* KKTvals, const int* lpt, const SolverIndexingData& data, bool dojac,
-                                          const char* hess_nz) {
+void BatchedDefectConstraint::scatter_kkt(const double* blocks, bool dohess, double* KKTvals, const int* lpt,
+                                          const SolverIndexingData& data, bool dojac) const {
   for (int V = 0; V < data.NumAppl(); V++) {
-    const double* blk = blocks + size_t(V) * nkkt;
+    const double* blk = blocks + size_t(V) * kstride_;
     int freeloc = data.InnerKKTStarts[V];
-    int k = 0;
-    for (int i = 0; i < ir; i++) {
-      if (dohess) {
-        if (!hess_nz) for (int j = i; j < ir; j++) KKTvals[lpt[freeloc++]] += blk[k++];
-        else for (int j = i; j < ir; j++, k++) { if (hess_nz[size_t(j) + size_t(ir) * i]) KKTvals[lpt[freeloc++]] += blk[k]; }   // AddHessianElem
-      } else {  // KKTFillJac: the Hessian slots exist in the layout but are skipped
-        if (!hess_nz) freeloc += ir - i;
-        else for (int j = i; j < ir; j++) freeloc += hess_nz[size_t(j) + size_t(ir) * i] ? 1 : 0;
-        k += ir - i;
-      }
-      if (dojac) {
-        for (int j = 0; j < orr; j++) KKTvals[lpt[freeloc++]] += blk[k++];
-      } else {  // KKTFillHess: the block carries the Jacobian entries, the objective's KKT space has no slot for them
-        k += orr;
+    for (int k = 0; k < kstride_; k++) {
+      const int r = lrows_[k];
+      if (r < 0) continue;
+      if (r < ir_) {
+        if (!HessianElemIsNonZero(r, lcols_[k])) continue;         // claims no slot (AddHessianElem)
+        if (dohess) KKTvals[lpt[freeloc]] += blk[k];               // KKTFillJac: the slot exists in the space and is stepped over
+        freeloc++;
+      } else if (dojac) {                                          // KKTFillHess: an objective's space has no Jacobian slots
+        KKTvals[lpt[freeloc++]] += blk[k];
       }
     }
   }
@@ -277,8 +274,7 @@ void BatchedDefectConstraint::eval(int what, const double* X, const double* L, d
     if (want_agx) std::memcpy(AGX + data.InnerGradientStarts[V], agx_.data() + size_t(V) * ir_, sizeof(double) * ir_);
   }
   if (want_kkt && !assembled)
-    scatter_kkt(kkt_.data(), nkkt_, ir_, or_, what == ASSET_HIP_JAC_ADJGRAD_HESS, KKTvals, KKTLocations, data, !hess_only,
-                hess_nz_.empty() ? nullptr : hess_nz_.data());
+    scatter_kkt(kkt_.data(), what == ASSET_HIP_JAC_ADJGRAD_HESS, KKTvals, KKTLocations, data, !hess_only);
 }
 
 // ---- objective: the function's single output weighted by ObjScale (DenseScalarFunctionBase.h:14-80)
@@ -325,48 +321,43 @@ void BatchedDefectConstraint::enable_device_assembly(long long nvalues) {
 void BatchedDefectConstraint::ensure_kkt_map(const int* lpt, const SolverIndexingData& data, bool hess_only) {
   if (!lpt) throw std::invalid_argument("KKTLocations is null");
   if (int(data.InnerKKTStarts.size()) != nappl_) throw std::invalid_argument("InnerKKTStarts not filled: call getKKTSpace first");
-  // where block slot k of application V lives in the caller's KKT space: slot order `for i: {H(j>=i,i); J(:,i)}`; with
-  // hess_only the space holds the Hessian slots alone (an objective) and the block's Jacobian slots are dropped (-1)
-  // (with a Hessian mask -- EnableHessianSparsity -- the claimed slots of a block column are fewer: hoff[i] = claimed Hessian slots
-  //  ahead of column i, hidx(j, i) = position of (j, i) among column i's claimed slots, -1 when it claims none)
-  std::vector<int> hoff(ir_ + 1, 0);
-  for (int i = 0; i < ir_; i++) {
-    int c = 0;
-    for (int j = i; j < ir_; j++) c += HessianElemIsNonZero(j, i) ? 1 : 0;
-    hoff[i + 1] = hoff[i] + c;
-  }
-  auto hidx = [&](int j, int i) -> int {
-    if (hess_nz_.empty()) return j - i;
-    if (!HessianElemIsNonZero(j, i)) return -1;
-    int c = 0;
-    for (int jj = i; jj < j; jj++) c += HessianElemIsNonZero(jj, i) ? 1 : 0;
-    return c;
-  };
-  auto space_slot = [&](int V, int i, int j_h, int j_j) -> int {   // exactly one of j_h / j_j is >= 0
-    int off = data.InnerKKTStarts[V];
-    if (!hess_only) {
-      off += hoff[i] + i * or_;                                   // first slot of block column i
-      if (j_h >= 0) { const int k = hidx(j_h, i); return k < 0 ? -1 : lpt[off + k]; }
-      return lpt[off + (hoff[i + 1] - hoff[i]) + j_j];
+  // The library takes the map in the CANONICAL numbering of a block's entries (the reference's order `for i: {H(j>=i,i); J(:,i)}`,
+  // include/asset_hip.h); the caller's KKT space was claimed by getKKTSpace above, i.e. in the order of the handle's layout, without
+  // the entries that claim no slot (a Hessian mask -- EnableHessianSparsity; the Jacobian slots of an objective, hess_only).
+  // space_of[k] = position of block slot k among the claimed slots of an application, or -1.
+  std::vector<int> space_of(kstride_, -1);
+  {
+    int pos = 0;
+    for (int k = 0; k < kstride_; k++) {
+      const int r = lrows_[k];
+      if (r < 0) continue;
+      if (r < ir_) { if (HessianElemIsNonZero(r, lcols_[k])) space_of[k] = pos++; }
+      else if (!hess_only) space_of[k] = pos++;
     }
-    if (j_h < 0) return -1;
-    const int k = hidx(j_h, i);
-    return k < 0 ? -1 : lpt[off + hoff[i] + k];
-  };
+  }
+  // canonical entry -> block slot
+  std::vector<int> slot_h(size_t(ir_) * ir_, -1), slot_j(size_t(or_) * ir_, -1);
+  for (int k = 0; k < kstride_; k++) {
+    const int r = lrows_[k], i = lcols_[k];
+    if (r < 0) continue;
+    if (r < ir_) slot_h[size_t(r) + size_t(ir_) * i] = k; else slot_j[size_t(r - ir_) + size_t(or_) * i] = k;
+  }
+  auto space_slot = [&](int V, int k) -> int { return space_of[k] < 0 ? -1 : lpt[data.InnerKKTStarts[V] + space_of[k]]; };
+  const int k_first = slot_h[0], k_last = slot_h[size_t(ir_ - 1) + size_t(ir_) * (ir_ - 1)];
   bool fresh = (lpt == map_source_) && map_.size() == size_t(nappl_) * nkkt_ && map_hess_only_ == hess_only;
   if (fresh) {  // same array: make sure the solver did not re-fill it in place (cheap sample)
     for (int V = 0; V < nappl_ && fresh; V += nappl_ / 16 + 1)
-      fresh = (map_[size_t(V) * nkkt_] == space_slot(V, 0, 0, -1)) &&
-              (map_[size_t(V) * nkkt_ + nkkt_ - or_ - 1] == space_slot(V, ir_ - 1, ir_ - 1, -1));
+      fresh = (map_[size_t(V) * nkkt_] == space_slot(V, k_first)) &&
+              (map_[size_t(V) * nkkt_ + nkkt_ - or_ - 1] == space_slot(V, k_last));
   }
   if (fresh) return;
   map_.resize(size_t(nappl_) * nkkt_);
   for (int V = 0; V < nappl_; V++) {
     int* m = map_.data() + size_t(V) * nkkt_;
-    int k = 0;
+    int c = 0;
     for (int i = 0; i < ir_; i++) {
-      for (int j = i; j < ir_; j++) m[k++] = space_slot(V, i, j, -1);
-      for (int j = 0; j < or_; j++) m[k++] = space_slot(V, i, -1, j);
+      for (int j = i; j < ir_; j++) m[c++] = space_slot(V, slot_h[size_t(j) + size_t(ir_) * i]);
+      for (int j = 0; j < or_; j++) m[c++] = space_slot(V, slot_j[size_t(j) + size_t(or_) * i]);
     }
   }
   if (hs_) check(asset_hip_sharded_set_kkt_map(hs_, map_.data(), nvalues_), "asset_hip_sharded_set_kkt_map");

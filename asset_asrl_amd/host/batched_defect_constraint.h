@@ -75,7 +75,12 @@ class BatchedDefectConstraint {
   int ORows() const { return or_; }
   bool thread_safe() const { return false; }  // one evaluation at a time per handle
 
-  // DenseFunctionBase.h:1070-1088 / 1097-1129 (every Jacobian and lower-triangle Hessian entry is structural)
+  // DenseFunctionBase.h:1070-1088 / 1097-1129 (every Jacobian and lower-triangle Hessian entry is structural).  The ORDER in which
+  // getKKTSpace tells the solver the (row, col) of an application's slots is this function's own business -- the solver maps every
+  // pair to a matrix location whatever the order (NonLinearProgram.cpp:282-330) -- and here it is the order the device writes its
+  // blocks in (asset_hip_defect_kkt_layout: for the narrow transcriptions the Jacobian column-major, then the packed lower
+  // triangle; the reference's `for i: {H(j>=i, i); J(:, i)}` for plain functions and wide shapes), so that the fill walks block
+  // and space side by side.
   int numKKTEles(bool dojac, bool dohess) const;
   void getKKTSpace(int* KKTrows, int* KKTcols, int& freeloc, int conoffset, bool dojac, bool dohess,
                    SolverIndexingData& data) const;
@@ -101,12 +106,15 @@ class BatchedDefectConstraint {
   void disable_device_assembly() { nvalues_ = 0; }
   bool device_assembly() const { return nvalues_ > 0; }
 
-  // block scatter (public so it can be checked on its own): KKTFillAll / KKTFillJac, DenseFunctionBase.h:1413-1523;
-  // dojac = false: KKTFillHess of a scalar objective (DenseScalarFunctionBase.h:82-126), whose space holds no
-  // Jacobian slots
-  static void scatter_kkt(const double* kkt_blocks, int nkkt, int ir, int orr, bool dohess, double* KKTvals,
-                          const int* KKTLocations, const SolverIndexingData& data, bool dojac = true,
-                          const char* hess_nz = nullptr /* [row + ir * col] or null: every entry */);
+  // block scatter (public so it can be checked on its own): KKTFillAll / KKTFillJac, DenseFunctionBase.h:1413-1523, over blocks in
+  // the handle's layout ([NumAppl][kkt_stride()]); dojac = false: KKTFillHess of a scalar objective
+  // (DenseScalarFunctionBase.h:82-126), whose space holds no Jacobian slots
+  void scatter_kkt(const double* kkt_blocks, bool dohess, double* KKTvals, const int* KKTLocations, const SolverIndexingData& data,
+                   bool dojac = true) const;
+  int kkt_stride() const { return kstride_; }
+  // slot k of a block: (row, col) as asset_hip_defect_kkt_layout gives them (row >= IRows(): Jacobian row row - IRows(); -1: padding)
+  const std::vector<int32_t>& kkt_rows() const { return lrows_; }
+  const std::vector<int32_t>& kkt_cols() const { return lcols_; }
 
   // ---- the same function used as an OBJECTIVE (one output): SolverObjectiveSpec::Concept, SolverInterfaceSpecs.h:252-281;
   //      bodies DenseScalarFunctionBase.h:14-80.  Val is accumulated (+= ObjScale * f over the applications), the GX
@@ -130,6 +138,8 @@ class BatchedDefectConstraint {
   std::vector<char> hess_nz_;          // empty: every Hessian entry claims a slot
   std::string ode_;
   int mode_, ir_ = 0, or_ = 0, nkkt_ = 0, nappl_ = 0, n_equal_ = 0;
+  int kstride_ = 0;                    // doubles per block, and (row, col) of every slot of a block: the handle's layout
+  std::vector<int32_t> lrows_, lcols_;
   bool blocked_ = false;
   int n_primal_ = 0, device_ = 0;
   std::vector<double> fx_, agx_, kkt_;
@@ -139,7 +149,7 @@ class BatchedDefectConstraint {
   bool map_hess_only_ = false;
   long long nvalues_ = 0;
   const int* map_source_ = nullptr;
-  std::vector<int> map_;          // [nappl][nkkt] value location of every block slot
+  std::vector<int> map_;          // [nappl][nkkt] value location of every block entry, canonical numbering (asset_hip_defect_set_kkt_map)
 };
 
 }  // namespace asset_hip_host

@@ -257,7 +257,7 @@ class Phase:
         inequality space (PhaseIndexer.cpp:78-92)."""
         return self._add_func(self._iq_funcs, region, func, XtUVars, OPVars, SPVars)
 
-    def addIntegralObjective(self, integrand, XtUVars=(), OPVars=(), SPVars=()) -> int:
+    def addIntegralObjective(self, integrand, XtUVars=(), OPVars=(), SPVars=(), output_scale: float = 1.0) -> int:
         """Minimise ``int integrand(x, t, u, p) dt`` over the phase (ODEPhaseBase.cpp:743-889): the segment quadrature
         ``LGLIntegral`` (LGLIntegrals.h:9-52; Trapezoidal phases use the two-node rule) of ``integrand`` over every defect,
         summed.  ``integrand`` takes the chosen variables of one state and the chosen parameters; it is evaluated, with
@@ -268,7 +268,9 @@ class Phase:
         # (the time variable may be among the integrand's inputs: the quadrature appends it again for the node times,
         #  xtrap.head(xp) = XtUVars; xtrap[xp] = TVar, ODEPhaseBase.cpp:786-790 -- the Vindex row then names it twice and the
         #  duplicate-location Hessian entries are summed by the assembly like any other shared location)
-        self._integral_objs.append((integrand, xtuv, opv, spv))
+        # (output_scale: the reference's OutputScales of the integrand -- with AutoScaling the objective handed to the solver is
+        #  output_scale * integrand in the scaled variables, ODEPhaseBase.cpp:796-803; without AutoScaling it is not applied)
+        self._integral_objs.append((integrand, xtuv, opv, spv, float(output_scale)))
         self._ev = None
         return len(self._integral_objs) - 1
 
@@ -281,26 +283,49 @@ class Phase:
         from .indexing import trapezoidal_hessian_mask
         return trapezoidal_hessian_mask(self.ode.XVars(), self.ode.UVars(), self.ode.PVars(), self._blocked())
 
-    def setStaticParams(self, params):
+    def setStaticParams(self, params, units=None):
         """Static parameters of the phase: solver variables behind the trajectory and the ODE parameters that user functions may
-        name in their ``SPVars`` (ODEPhaseBase.h setStaticParams; PhaseIndexer.cpp: StaticParamLoc)."""
+        name in their ``SPVars`` (ODEPhaseBase.h setStaticParams; PhaseIndexer.cpp: StaticParamLoc).  ``units``: their units under
+        AutoScaling (the reference's ``SPUnits``; ones when omitted)."""
         self.ActiveStaticParams = np.asarray(params, dtype=float).ravel().copy()
+        self.SPUnits = np.ones(self.ActiveStaticParams.size) if units is None else np.asarray(units, dtype=float).ravel().copy()
+        if self.SPUnits.size != self.ActiveStaticParams.size or np.any(self.SPUnits <= 0):
+            raise ValueError("one positive unit per static parameter")
         self._ev = None
 
-    def addIntegralParamFunction(self, integrand, XtUVars=(), OPVars=(), SPVars=(), accum_param: int = 0, scale: float = 1.0) -> int:
+    def _input_scales(self, xtuv, opv, spv):
+        """Units of a user function's inputs, in its argument order (the reference's get_input_scale: the chosen state variables,
+        the chosen ODE parameters, the chosen static parameters)."""
+        xtu = self.ode.XtUVars()
+        sp = getattr(self, "SPUnits", np.ones(len(self.ActiveStaticParams)))
+        return [self.XtUPUnits[v] for v in xtuv] + [self.XtUPUnits[xtu + v] for v in opv] + [sp[v] for v in spv]
+
+    def _scaled_integrand(self, integrand, xtuv, opv, spv, output_scale):
+        """An integrand as the solver's scaled variables see it (ODEPhaseBase.cpp:796-803, 848-855): IOScaled over the input units with
+        the integrand's output scale.  Without AutoScaling the integrand itself."""
+        if not self.AutoScaling:
+            return integrand
+        from .vf import IOScaled
+        return IOScaled(integrand, self._input_scales(xtuv, opv, spv), [output_scale])
+
+    def addIntegralParamFunction(self, integrand, XtUVars=(), OPVars=(), SPVars=(), accum_param: int = 0, scale: float = 1.0,
+                                 output_scale: float = 1.0) -> int:
         """``int integrand(x, t, u, p) dt - scale * StaticParams[accum_param] = 0`` (ODEPhaseBase.cpp:835-889 with
         PhaseIndexer::addAccumulation, PhaseIndexer.cpp:41-76): the static parameter is made to equal the integral.  TWO equality
         functions share ONE constraint row -- the linear accumulation ``-scale * p`` over the Params region, and the segment
         quadrature of the integrand (the one ``addIntegralObjective`` uses) over every defect, all of whose applications carry
         the accumulation's row: their values, multiplier and Jacobian entries add up in the solver's row.  Returns the index of
         the pair among the phase's integral parameter functions; the two evaluators are
-        ``integral_param_evaluators[index] = (accumulation, quadrature)``."""
+        ``integral_param_evaluators[index] = (accumulation, quadrature)``.  With AutoScaling the solver's variables are in scaled units:
+        the integrand is wrapped in IOScaled over its input units with ``output_scale`` and the accumulation becomes
+        ``-scale * AccScale * p_scaled``, ``AccScale = SPUnits[accum_param] * output_scale / XtUPUnits[t]`` (ODEPhaseBase.cpp:846-861) --
+        the row is then ``(output_scale / t_unit) * (int integrand dt - scale * p)`` of the unscaled problem."""
         xtuv, opv, spv = [int(v) for v in XtUVars], [int(v) for v in OPVars], [int(v) for v in SPVars]
         if integrand.ORows() != 1 or integrand.IRows() != len(xtuv) + len(opv) + len(spv):
             raise ValueError("an integrand has one output and takes the listed state variables and parameters")
         if not 0 <= int(accum_param) < len(self.ActiveStaticParams):
             raise ValueError("accum_param names no static parameter of the phase (setStaticParams first)")
-        self._integral_params.append((integrand, xtuv, opv, spv, int(accum_param), float(scale)))
+        self._integral_params.append((integrand, xtuv, opv, spv, int(accum_param), float(scale), float(output_scale)))
         self._ev = None
         return len(self._integral_params) - 1
 
@@ -357,18 +382,21 @@ class Phase:
                 V, Cx, next_eq = ix.make_Vindex_Cindex("DefectPairWisePath", tu, (), (), F.ORows(), next_eq)
                 out.append(("auto", "control_spline", F, f"lglcontrolspline{cs}_{self.ode.UVars()}_{order}", V, Cx, None))
         # integral objectives: LGLIntegral over every defect (ODEPhaseBase.cpp:743-889)
-        for k, (integrand, xtuv, opv, spv) in enumerate(self._integral_objs):
-            f = LGLIntegral(integrand, cs, len(xtuv), len(opv) + len(spv))
+        for k, (integrand, xtuv, opv, spv, oscale) in enumerate(self._integral_objs):
+            f = LGLIntegral(self._scaled_integrand(integrand, xtuv, opv, spv, oscale), cs, len(xtuv), len(opv) + len(spv))
             V, _, _ = ix.make_Vindex_Cindex("DefectPath", xtuv + tv, opv, spv, 0, 0)
             Cx = np.zeros((V.shape[0], 1), dtype=np.int32)           # every application reads multiplier 0 = ObjScale
             out.append(("objective", f"obj{k}", f, f"obj{k}_integral{cs}", V, Cx, None))
         # integral parameter functions (ODEPhaseBase.cpp:835-889; addAccumulation, PhaseIndexer.cpp:41-76): the accumulation
         # -scale * p over Params claims the row, every application of the quadrature carries that same row
-        for k, (integrand, xtuv, opv, spv, acc, scale) in enumerate(self._integral_params):
+        for k, (integrand, xtuv, opv, spv, acc, scale, oscale) in enumerate(self._integral_params):
             from .vf import Arguments
+            acc_scale = 1.0
+            if self.AutoScaling:      # AccScale = pscale * output_scale / t_unit (ODEPhaseBase.cpp:857-859)
+                acc_scale = getattr(self, "SPUnits", np.ones(len(self.ActiveStaticParams)))[acc] * oscale / self.XtUPUnits[self.ode.TVar()]
             Va, Ca, next_eq = ix.make_Vindex_Cindex("Params", (), (), [acc], 1, next_eq)
-            out.append(("equality", f"ipf{k}_acc", Arguments(1) * (-scale), f"ipf{k}_accumulate", Va, Ca, None))
-            f = LGLIntegral(integrand, cs, len(xtuv), len(opv) + len(spv))
+            out.append(("equality", f"ipf{k}_acc", Arguments(1) * (-scale * acc_scale), f"ipf{k}_accumulate", Va, Ca, None))
+            f = LGLIntegral(self._scaled_integrand(integrand, xtuv, opv, spv, oscale), cs, len(xtuv), len(opv) + len(spv))
             V, _, _ = ix.make_Vindex_Cindex("DefectPath", xtuv + tv, opv, spv, 0, 0)
             Cx = np.full((V.shape[0], 1), int(Ca[0, 0]), dtype=np.int32)
             out.append(("equality", f"ipf{k}_int", f, f"ipf{k}_integral{cs}", V, Cx, None))
@@ -524,7 +552,10 @@ class Phase:
         if self._indexer is None:
             self.transcribe()
         traj = self.ActiveTraj / self.XtUPUnits if self.AutoScaling else self.ActiveTraj   # variables in scaled units
-        return self._indexer.makeSolverInput(traj, self.ActiveStaticParams if len(self.ActiveStaticParams) else None)
+        sp = self.ActiveStaticParams
+        if self.AutoScaling and len(sp):
+            sp = sp / getattr(self, "SPUnits", np.ones(len(sp)))
+        return self._indexer.makeSolverInput(traj, sp if len(sp) else None)
 
     @property
     def evaluator(self) -> DefectEvaluator:

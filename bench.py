@@ -157,16 +157,40 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="reentry_lgl7_10k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inprocess-shards", type=int, default=0,
+                    help="N >= 1: also time the constraint as N device handles in THIS process (the C ABI's asset_hip_defect_create_sharded, "
+                         "shard k on device k mod the visible devices): host-visible rates of the blocks and of the assembled values")
     a = ap.parse_args()
-
-    import numpy as np
-    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started plainly with --gpus N: launch the ranks ourselves -- fresh child processes of a parent that has not touched the
+        # GPU (nothing above imports torch or the HIP library) -- and relay rank 0's JSON line.  Never an exec.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        js = [ln for ln in lines if ln.lstrip().startswith("{")]
+        for ln in lines:
+            if not js or ln is not js[-1]:
+                print(ln, file=sys.stderr)
+        if js:
+            print(js[-1], flush=True)              # the JSON line last
+        raise SystemExit(r.returncode if (r.returncode or js) else 1)
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs a torch.distributed launch with WORLD_SIZE={a.gpus} (got {world})")
+        raise SystemExit(f"--gpus {a.gpus} under a torch.distributed launch needs WORLD_SIZE={a.gpus} (got {world})")
+
+    import numpy as np
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     backend = os.environ.get("ASSET_BENCH_BACKEND", "nccl")     # "gloo": functional runs of N ranks that share devices
@@ -246,7 +270,7 @@ def main():
             local_segments = len(sh.mine) * nseg
             evs = [sh.ev] if sh.ev is not None else []
         sh.alloc_device(dev, always_exchange=use_dist)
-        IR, OR, NKKT = sh.IR, sh.OR, sh.NKKT
+        IR, OR, NKKT, KSTRIDE = sh.IR, sh.OR, sh.NKKT, sh.KSTRIDE
 
         def evaluate():
             sh.eval_device(JAC_ADJGRAD_HESS, X, L, stream)
@@ -260,10 +284,10 @@ def main():
     else:
         ev = DefectEvaluator(ode, mode, blocked, w.vindex, w.cindex, n_primal, n_equal, device=local_rank)
         evs, local_segments = [ev], nseg
-        IR, OR, NKKT = ev.IR, ev.OR, ev.NKKT
+        IR, OR, NKKT, KSTRIDE = ev.IR, ev.OR, ev.NKKT, ev.KSTRIDE    # (KSTRIDE: doubles per block in the handle's layout, >= NKKT)
         fx = torch.empty(nseg * OR, dtype=torch.float64, device=dev)
         agx = torch.empty(nseg * IR, dtype=torch.float64, device=dev)
-        kkt = torch.empty(nseg * NKKT, dtype=torch.float64, device=dev)
+        kkt = torch.empty(nseg * KSTRIDE, dtype=torch.float64, device=dev)
         step = evaluate = ev.bind_device(JAC_ADJGRAD_HESS, X, L, fx, agx, kkt, stream)   # (arguments converted once)
 
     def fence():
@@ -304,7 +328,7 @@ def main():
         n0 = e0.nseg
         kfx = torch.empty(n0 * OR, dtype=torch.float64, device=dev)
         kagx = torch.empty(n0 * IR, dtype=torch.float64, device=dev)
-        kkkt = torch.empty(n0 * NKKT, dtype=torch.float64, device=dev)
+        kkkt = torch.empty(n0 * KSTRIDE, dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
         iters = 200 if n0 * (OR + IR + NKKT) * 8 < (1 << 30) else 20
         for _ in range(8):
@@ -330,7 +354,7 @@ def main():
         extra["ms_per_step_without_exchange"] = timed(evaluate, k2, 5) / k2 * 1e3
         extra["value_without_exchange"] = total_segments / (extra["ms_per_step_without_exchange"] * 1e-3)
         extra["exchange_ms"] = timed(exchange, k2, 5) / k2 * 1e3
-        extra["exchange_bytes_into_root"] = 8 * max(world - 1, 1) * (sh.slot_doubles if nphases == 1 else sh.per_rank * nseg * sh.width)
+        extra["exchange_bytes_into_root"] = 8 * max(world - 1, 1) * (sh.slot_doubles if nphases == 1 else sh._flat_doubles(sh.per_rank))
 
     # host-visible rate (NOT `value`): the blocks in host memory, where the reference's solver keeps its KKT system.  Every
     # rank copies its shard over its own PCIe link into its range of one page-locked host buffer all ranks map
@@ -411,6 +435,46 @@ def main():
         if use_dist:
             sh._hostv.close()
 
+    # the constraint as N device handles in ONE process, through the C ABI alone (asset_hip_defect_create_sharded: the reference's
+    # thread_split with a device per chunk; no RCCL, no second process): host-visible rates, outputs page-locked once (what a solver's
+    # RHS / KKT arrays are) and -- for contrast -- fresh pageable outputs every call (one host thread per shard inside the library)
+    inprocess = None
+    if a.inprocess_shards > 0 and world == 1 and nphases == 1 and nseg * (OR + IR + KSTRIDE) * 8 <= 4 << 30:
+        from asset_asrl_amd.evaluator import ShardedDefectEvaluator as InProcessShards
+        from asset_asrl_amd.indexing import kkt_slot_locations
+        ndev = torch.cuda.device_count()
+        devices = [k % ndev for k in range(a.inprocess_shards)]
+        k4 = max(5, min(a.steps, 30))
+
+        def wall(fn, n=k4):
+            fn(); fn()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            return (time.perf_counter() - t0) / n
+        inprocess = {"shards": a.inprocess_shards, "devices": devices,
+                     "path": "asset_hip_sharded_eval / _eval_assembled: X, L to every shard's device, all shards enqueued, every shard's slice of the "
+                             "blocks (or its range of the assembled values) over its device's PCIe link into the caller's host arrays; wall clock per call"}
+        for nsh in sorted({1, a.inprocess_shards}):
+            se = InProcessShards(ode, mode, blocked, w.vindex, w.cindex, n_primal, n_equal, devices[:nsh])
+            t_pageable = wall(lambda: se.eval(JAC_ADJGRAD_HESS, Xh, Lh, native=True), max(3, k4 // 3))
+            se.pin_outputs()
+            t_pinned = wall(lambda: se.eval(JAC_ADJGRAD_HESS, Xh, Lh))
+            entry = {"blocks_pinned_ms": t_pinned * 1e3, "blocks_pinned_segments_per_s": nseg / t_pinned,
+                     "blocks_pageable_ms": t_pageable * 1e3, "bytes": nseg * (OR + IR + KSTRIDE) * 8}
+            if nseg * NKKT <= 60_000_000:
+                locs_s, nnz_s = kkt_slot_locations(w.vindex, w.cindex, n_primal)
+                se.set_kkt_map(locs_s, nnz_s)
+                hv = torch.zeros(nnz_s, dtype=torch.float64, pin_memory=True).numpy()
+
+                def asm():
+                    hv.fill(0.0)
+                    se.eval_assembled(JAC_ADJGRAD_HESS, Xh, Lh, hv)
+                t_asm = wall(asm)
+                entry.update({"assembled_ms": t_asm * 1e3, "assembled_segments_per_s": nseg / t_asm, "kkt_values": nnz_s})
+            inprocess[f"{nsh}_shard{'s' if nsh > 1 else ''}"] = entry
+            se.close()
+
     bseg = algorithmic_bytes_per_segment(IR, OR)
     # roofline: the launch duration over the TIMED REGION (HIP events around the K steps, N = 1: one evaluation per step,
     # nothing else on the stream); with an exchange in the step (N > 1) the kernel's own settled HIP-event figure
@@ -427,7 +491,7 @@ def main():
     per_rank_frac = [(n * bseg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0 for n, ms in zip(per_rank_segments, per_rank_ms)]
 
     traffic, traffic_src = None, None
-    prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_{a.workload}_pmc.json") for r in (5, 4, 3, 2)) if os.path.exists(q)), "")
+    prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_{a.workload}_pmc.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), "")
     if world == 1 and prof:   # NOT measured by this run: HBM bytes per evaluation from the committed rocprofv3 --pmc passes
         try:
             traffic = json.load(open(prof))["hbm"]["bytes_per_launch"]
@@ -461,7 +525,7 @@ def main():
             "config": {"workload": f"{ode} ODE, {mode}, {phases_note}"
                                    f"{', BlockConstant control' if blocked else ''}; evalKKT-equivalent "
                                    "(value + adjoint gradient + Jacobian + adjoint-Hessian blocks), inputs resident in HBM",
-                       "name": a.workload, "IR": IR, "OR": OR, "kkt_slots_per_segment": NKKT,
+                       "name": a.workload, "IR": IR, "OR": OR, "kkt_slots_per_segment": NKKT, "kkt_block_stride": KSTRIDE,
                        "total_segments": total_segments, "sharding": sharding,
                        # which of the line's rates the strong-scaling target of BASELINE.json (>= 6x at 8 GPUs) is claimed on
                        "scaling_claim": ("none at this size: a 10 000-segment phase leaves 1 250 segments per GPU, one latency-bound "
@@ -502,6 +566,8 @@ def main():
             out["host_visible"] = host_visible
         if host_visible_assembled is not None:
             out["host_visible_assembled"] = host_visible_assembled
+        if inprocess is not None:
+            out["inprocess_shards"] = inprocess
         if world == 1 and not a.no_cpu_baseline:
             # bounded sample: the oracle's CSR scatter needs 12 B per KKT slot on the host -- cap it at 2e8 slots
             cap = max(1, int(2e8) // NKKT)

@@ -23,8 +23,17 @@
  * Block layouts (what the reference's scatter consumes, so a host shim can do its indexed += unchanged):
  *   FX  [nseg][OR]     rows of application V   = InnerConstraintStarts[V] + 0..OR   (ComputableBase.h:256-259)
  *   AGX [nseg][IR]     rows of application V   = InnerGradientStarts[V] + 0..IR     (ComputableBase.h:327-331)
- *   KKT [nseg][NKKT]   for i in 0..IR-1: { H(j,i), j=i..IR-1 ; J(j,i), j=0..OR-1 }  (DenseFunctionBase.h:1112-1123)
- *                      NKKT = IR(IR+1)/2 + OR*IR.  For JAC / JAC_ADJGRAD the H slots are written as 0.
+ *   KKT [nseg][STRIDE] NKKT = IR(IR+1)/2 + OR*IR entries per application -- J(j,i) and the lower triangle H(j,i), j >= i -- in an
+ *                      order that is the HANDLE'S OWN and that it exports: asset_hip_defect_kkt_layout (below).  In the reference
+ *                      that order is private to the function too -- getKKTSpace is a method of the plug-in
+ *                      (SolverInterfaceSpecs.h:41-92), the solver maps every (row, col) it is told to a matrix location whatever
+ *                      the order (NonLinearProgram.cpp:282-330).  Two orders exist: the one of the reference's dense functions,
+ *                      for i in 0..IR-1: { H(j,i), j=i..IR-1 ; J(j,i), j=0..OR-1 } with STRIDE = NKKT (DenseFunctionBase.h:1112-1123;
+ *                      plain functions and shapes of 64 inputs or more), and -- every other transcription of an ODE -- the
+ *                      Jacobian column-major, then the packed lower triangle of H column-major, each region padded to a whole
+ *                      number of 128-byte lines.  For JAC / JAC_ADJGRAD the H slots are written as 0; padding is never written.
+ *                      The CANONICAL numbering of a block's entries -- slot k of the reference's order above -- is what
+ *                      asset_hip_defect_set_kkt_map and the sharded map take, whatever the layout of the blocks.
  *
  * Conventions: every function returns 0 on success or a negative ASSET_HIP_E* / positive hipError_t code and
  * never throws; asset_hip_last_error() gives text for the calling thread.  A handle is thread-compatible
@@ -108,7 +117,10 @@ int asset_hip_defect_rebind(asset_hip_defect_t h, int nseg, const int32_t* vinde
  * 519-526: shard i is a handle of its own on HIP device devices[i] (a device may be named more than once) with its own stream.
  * An evaluation copies X / L to every shard's device over that device's PCIe link, enqueues ALL shards, and lets every shard
  * copy its slice of the blocks (rows [first, first + count) of the arrays a single handle would fill) straight into the
- * caller's arrays; it returns when every shard has finished.  Page-lock the arrays (asset_hip_host_register) for DMA rate.
+ * caller's arrays; it returns when every shard has finished.  Page-lock the arrays (asset_hip_host_register) for DMA rate: the
+ * calling thread then enqueues every shard before any copy has run.  With pageable arrays -- where a copy blocks the thread that
+ * issues it -- every shard is driven by a host thread of its own for the call, as the reference drives its thread-split
+ * functions (NonLinearProgram.cpp:519-526), so that the shards still overlap.  The calling thread's current device is preserved.
  * No collective library and no second process are involved.  The blocks are bitwise those of a single handle. */
 typedef struct asset_hip_sharded* asset_hip_sharded_t;
 int asset_hip_defect_create_sharded(const asset_hip_defect_desc* desc, int nshards, const int* devices, asset_hip_sharded_t* out);   /* desc->device is ignored */
@@ -118,7 +130,8 @@ int asset_hip_sharded_range(asset_hip_sharded_t s, int shard, int* first, int* c
 asset_hip_defect_t asset_hip_sharded_handle(asset_hip_sharded_t s, int shard);   /* the shard's own handle (owned by s) */
 int asset_hip_sharded_eval(asset_hip_sharded_t s, int what, const double* X, const double* L, double* fx_blocks,
                            double* agx_blocks, double* kkt_blocks);
-/* On-device assembly per shard (see asset_hip_defect_set_kkt_map below): slot_locations[nseg * NKKT] as for a single handle.
+/* On-device assembly per shard (see asset_hip_defect_set_kkt_map below): slot_locations[nseg * NKKT] as for a single handle
+ * (canonical numbering).  Failure-atomic: after an error no map is in effect (asset_hip_sharded_eval_assembled refuses) until a call succeeds.
  * Every shard assembles its entries into its own range [lowest, highest location] of the value array on its device; the range
  * crosses PCIe into page-locked staging and is ADDED into kkt_values[nvalues] in shard order (kkt_values is accumulated into,
  * as asset_hip_defect_eval_assembled does).  Entries two neighbouring shards share are a + b as with a single handle (bitwise
@@ -127,8 +140,21 @@ int asset_hip_sharded_set_kkt_map(asset_hip_sharded_t s, const int32_t* slot_loc
 int asset_hip_sharded_eval_assembled(asset_hip_sharded_t s, int what, const double* X, const double* L, double* fx_blocks,
                                      double* agx_blocks, double* kkt_values);
 
-/* IRows, ORows, per-application KKT slots */
+/* IRows, ORows, per-application KKT slots (numKKTEles(true, true), DenseFunctionBase.h:1070-1088) */
 int asset_hip_defect_sizes(asset_hip_defect_t h, int* irows, int* orows, int* nkkt);
+
+/* The layout of this handle's KKT blocks: what the plug-in's getKKTSpace (DenseFunctionBase.h:1097-1129) walks to tell the solver
+ * (row, col) of every slot, and what its fill (KKTFillAll / KKTFillJac, :1413-1523) walks to add the values.  *stride = doubles from
+ * one application's block to the next (the block arrays of every entry point hold nseg * stride doubles; block arrays handed to
+ * the device-pointer entry points should start on a 128-byte boundary); for k in [0, stride): rows[k] = j and cols[k] = i of an
+ * entry H(j, i), j >= i, of the adjoint Hessian, or rows[k] = IR + j, cols[k] = i of an entry J(j, i) of the Jacobian, or -1 / -1
+ * for padding (never written, never to be read).  rows / cols may both be NULL (stride only).  Returns the layout id (0: the
+ * reference's order, 1: J | H) or a negative ASSET_HIP_E* code. */
+int asset_hip_defect_kkt_layout(asset_hip_defect_t h, int* stride, int32_t* rows, int32_t* cols);
+/* The same for a compiled (ode, mode, blocked) without a handle or a device -- what a host needs to size its arrays before it
+ * creates anything (and what a rank of a sharded job that owns no segment needs to take part in the exchange).  *nkkt: entries
+ * per block (may be NULL). */
+int asset_hip_kkt_layout(const char* ode, int mode, int blocked, int* nkkt, int* stride, int32_t* rows, int32_t* cols);
 
 /* Host-pointer evaluation: X[n_primal], L[n_equal] (may be NULL for CON/JAC) are copied in, the requested
  * block arrays (any may be NULL) are copied out.  Synchronous. */
@@ -175,8 +201,10 @@ int asset_hip_host_unregister(void* ptr);
  * every application (VectorFunctions/DenseFunctionBase.h:1413-1466 KKTFillAll, :1468-1523 KKTFillJac; locations
  * from Solvers/NonLinearProgram.cpp:316-330), and its column mutexes (KKTClashes / KKTLocks).
  *
- * asset_hip_defect_set_kkt_map: slot_locations[V*NKKT + k] = index in the solver's value array of block slot k of
- * application V, i.e. KKTLocations[InnerKKTStarts[V] + k] (block slot order as documented above); nvalues = length of
+ * asset_hip_defect_set_kkt_map: slot_locations[V*NKKT + k] = index in the solver's value array of entry k of
+ * application V in the CANONICAL numbering (the reference's order, see "Block layouts" above -- NOT the handle's block
+ * layout: the assembled kinds write no blocks), i.e. what KKTLocations[InnerKKTStarts[V] + k] holds when getKKTSpace walks the
+ * entries in the reference's order; nvalues = length of
  * that value array, or -1 for a slot whose entry is to be dropped (an objective keeps only the Hessian slots of its
  * blocks: DenseScalarFunctionBase.h:48-80, getKKTSpace with dojac = false).  Uploaded once per sparsity analysis.  accumulate = 0: locations used by a single slot are found
  * here and written with plain stores, the shared ones (boundary nodes of adjacent segments, phase parameters) with

@@ -35,6 +35,21 @@ class Workload:
                       self.n_primal, self.n_equal, threads, hessian_sparsity=hessian_sparsity)
 
 
+def csr_locations(rows, cols, outer, inner):
+    """KKTLocations of slots (rows, cols) in an upper-triangular row-major CSR matrix (outer, inner): what
+    NonLinearProgram::analyzeSparsity computes (NonLinearProgram.cpp:282-330) -- every slot is kept as (larger, smaller) index
+    and filed in CSR row `smaller`; the order of the slots does not enter."""
+    rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+    lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+    outer, inner = np.asarray(outer, dtype=np.int64), np.asarray(inner, dtype=np.int64)
+    dim = outer.size - 1
+    key_of = np.repeat(np.arange(dim, dtype=np.int64), np.diff(outer)) * (dim + 1) + inner        # sorted: rows ascending, columns sorted
+    want = lo * (dim + 1) + hi
+    pos = np.searchsorted(key_of, want)
+    assert np.array_equal(key_of[pos], want), "a slot names an entry the matrix does not hold"
+    return pos.astype(np.int32)
+
+
 def rel_err(a, b, floor=1.0):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.max(np.abs(a - b)) / max(floor, float(np.max(np.abs(b)))))

@@ -20,6 +20,27 @@ static std::unique_ptr<BatchedDefectConstraint> make_con(const char* ode, int mo
   return std::make_unique<BatchedDefectConstraint>(ode, mode, blocked, d, primal, equal, 0);
 }
 
+// The KKT space the constraint claims -- (row, col) of every slot in ITS order (the order of the device's blocks); the caller turns
+// them into KKTLocations the way NonLinearProgram::analyzeSparsity does (NonLinearProgram.cpp:282-330), whatever the order.
+extern "C" int shim_space(const char* ode, int mode, int blocked, int ir, int orr, int nappl, const int* vindex, const int* cindex,
+                          int primal, int equal, int* kkt_rows_out, int* kkt_cols_out, char* err, int errcap) {
+  try {
+    SolverIndexingData data;
+    data.input_size = ir, data.output_size = orr, data.num_funcappl = nappl;
+    data.Vindex.assign(vindex, vindex + size_t(ir) * nappl);
+    data.Cindex.assign(cindex, cindex + size_t(orr) * nappl);
+    auto conp = make_con(ode, mode, blocked != 0, data, primal, equal);
+    conp->EnableHessianSparsity(g_hess_sparsity != 0);
+    int kfree = 0;
+    conp->getKKTSpace(kkt_rows_out, kkt_cols_out, kfree, primal, true, true, data);
+    return kfree;
+  } catch (const std::exception& e) {
+    std::strncpy(err, e.what(), errcap - 1);
+    err[errcap - 1] = 0;
+    return -1;
+  }
+}
+
 extern "C" int shim_run(const char* ode, int mode, int blocked, int ir, int orr, int nappl, const int* vindex,
                         const int* cindex, int primal, int equal, int what, const double* X, const double* L,
                         const int* kkt_locations, int* kkt_rows_out, int* kkt_cols_out, double* kkt_vals,

@@ -38,6 +38,39 @@ def test_introspection_matches_survey_sizes():
     assert not _lib.has_kernel("nonexistent", _lib.LGL3, False)
 
 
+def test_kkt_block_layouts_without_a_device():
+    """asset_hip_kkt_layout (no handle, no device): every compiled (ode, transcription, control mode) exports the order of its KKT
+    blocks -- every entry of the block exactly once, padding marked -1 -- equal to the host mirror of the kernels' arithmetic
+    (evaluator.kkt_layout_table) and to the sizes build.dims() plans with.  The order is the function's own business
+    (DenseFunctionBase.h:1097-1129 against NonLinearProgram.cpp:282-330): narrow shapes J | H with 128-byte-aligned regions,
+    wide shapes the reference's order."""
+    from asset_asrl_amd.evaluator import kkt_layout_table, reference_slot_order
+    seen = set()
+    for ode in _lib.ode_names():
+        xv, uv, pv = _lib.ode_sizes(ode)
+        for mode, mid in _lib.MODES.items():
+            for blocked in (False, True):
+                if mode == "Function" or not _lib.has_kernel(ode, mid, blocked):
+                    continue
+                kl, nk, stride, rows, cols = _lib.kkt_layout(ode, mid, blocked)
+                d = dims(xv, uv, pv, synth.MODE_CS[mode], blocked, trap=(mode == "Trapezoidal"))
+                IR, OR = d["IR"], d["OR"]
+                assert (nk, kl, stride) == (d["NKKT"], d["KL"], d["KSTRIDE"])
+                st2, r2, c2 = kkt_layout_table(IR, OR, kl)
+                assert st2 == stride and np.array_equal(rows, r2) and np.array_equal(cols, c2)
+                real = rows >= 0
+                rr, cc = reference_slot_order(IR, OR)
+                assert sorted(zip(rows[real].tolist(), cols[real].tolist())) == sorted(zip(rr.tolist(), cc.tolist()))
+                if kl == 1:
+                    assert stride % 16 == 0 and np.all(rows[:IR * OR] >= IR)      # the Jacobian first, on a line of its own
+                else:
+                    assert stride == nk and np.array_equal(rows, rr) and np.array_equal(cols, cc)
+                seen.add(kl)
+    assert seen == {0, 1}
+    with pytest.raises(_lib.AssetHipError):
+        _lib.kkt_layout("nonexistent", _lib.LGL3, False)
+
+
 def test_lgl_tables_bitwise_equal_to_oracle(oracle):
     for cs in (2, 3, 4):
         for which in ("tc", "s", "A", "B", "U", "C", "D", "E"):

@@ -12,15 +12,23 @@ import pytest
 from helpers import Workload
 
 
-class _OracleShard:
-    """Stands in for DefectEvaluator on CPU: same constructor / eval / eval_device signatures, blocks from the oracle."""
+from asset_asrl_amd.evaluator import _KktLayout
+
+
+class _OracleShard(_KktLayout):
+    """Stands in for DefectEvaluator on CPU: same constructor / eval / eval_device signatures, blocks from the oracle -- written into
+    the device-side arrays in the layout the library's kernels for this shape use (asset_hip_kkt_layout: no device needed)."""
 
     def __init__(self, ode, mode, blocked, vindex, cindex, n_primal, n_equal, device=0):
         from oracle import bindings as ob
+        from asset_asrl_amd import _lib
         self.ob = ob
         self.nlp = ob.Nlp(ob.get_ode(ode, 0), ob.MODES[mode], blocked, vindex, cindex, n_primal, n_equal, 1)
         self.IR, self.OR, self.NKKT = self.nlp.ir, self.nlp.orr, self.nlp.nkkt
         self.nseg = self.nlp.nappl
+        kl, nk, stride, rows, cols = _lib.kkt_layout(ode, _lib.MODES[mode], blocked)
+        assert nk == self.NKKT
+        self._set_layout(kl, stride, rows, cols)
 
     def eval(self, what, X, L=None):
         return self.nlp.eval_blocks(what, X, L)
@@ -33,7 +41,9 @@ class _OracleShard:
         if agx is not None:
             agx[: self.nseg].copy_(torch.from_numpy(ragx))
         if kkt is not None and rkkt is not None:
-            kkt[: self.nseg].copy_(torch.from_numpy(rkkt))
+            native = np.zeros((self.nseg, self.KSTRIDE))
+            native[:, self.kkt_perm] = rkkt
+            kkt[: self.nseg].copy_(torch.from_numpy(native))
 
 
     # on-device assembly, stand-in: the oracle's blocks added into the (compact) value array through the map the sharded
@@ -85,8 +95,8 @@ def _worker(rank, world, port, nseg, q):
     for _ in range(2):                                    # twice: the buffers are reused every solver iteration
         lfx, lagx, lkkt = sh.eval_device(4, X, L)
         sh.gather_device()
-    assert lfx.shape[0] == sh.count and lkkt.shape == (sh.count, sh.NKKT)
-    assert sh._local.numel() == sh.max_count * (sh.OR + sh.IR + sh.NKKT)
+    assert lfx.shape[0] == sh.count and lkkt.shape == (sh.count, sh.KSTRIDE)
+    assert sh._local.numel() == (sh.max_count * (sh.OR + sh.IR) + 15) // 16 * 16 + sh.max_count * sh.KSTRIDE
     shards = sh.shard_blocks_on_root()
     full = sh.blocks_on_root()
     # host-visible exchange: every rank copies its flat buffer into its range of one shared host buffer, then a barrier
@@ -100,12 +110,13 @@ def _worker(rank, world, port, nseg, q):
     for got_h, loc in zip(hs[rank], (lfx, lagx, lkkt)):
         np.testing.assert_array_equal(got_h, loc.numpy())
     if rank == 0:
+        host_full[2] = sh.kkt_to_reference(host_full[2])                  # (the blocks travel in the kernels' layout)
         q.put(("host", host_full))
     sh._host.close()
     if rank == 0:
         assert len(shards) == world and all(s[2].shape[0] == c for s, (_, c) in zip(shards, sh.shards))
         assert shards[0][0].data_ptr() == sh._recv[0].data_ptr()          # views of the receive buffer, no copy
-        q.put([g.numpy() for g in got] + [sh.shards] + [t.numpy() for t in full])
+        q.put([g.numpy() for g in got] + [sh.shards] + [full[0].numpy(), full[1].numpy(), sh.kkt_to_reference(full[2])])
     else:
         assert shards is None and full is None
     dist.barrier()
@@ -175,8 +186,8 @@ def _phase_worker(rank, world, port, nphases, nseg, q):
         for k, wk in enumerate(ws):
             ref = ob.Nlp(ob.get_ode("twobody_lt", 0), ob.MODES["LGL5"], True, wk.vindex, wk.cindex, n_primal, n_equal,
                          1).eval_blocks(4, X, L)
-            for got, r in zip(blocks[k], ref):
-                np.testing.assert_array_equal(got.numpy(), r)
+            for got, r in zip((blocks[k][0].numpy(), blocks[k][1].numpy(), sh.kkt_to_reference(blocks[k][2])), ref):
+                np.testing.assert_array_equal(got, r)
         q.put("ok")
     else:
         assert blocks is None

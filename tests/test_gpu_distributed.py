@@ -62,7 +62,7 @@ hfx, hagx, hkkt = sh.host_shard_blocks()[0]
 host_same = bool(np.array_equal(hfx, fx) and np.array_equal(hagx, agx) and np.array_equal(hkkt, kkt))
 sh._host.close()
 print(json.dumps({{"fx": float(np.abs(fx - rfx).max() / max(1.0, np.abs(w.X).max())), "agx": rel_err(agx, ragx),
-                  "kkt": rel_err(kkt, rkkt), "shape": list(kkt.shape), "host_same": host_same, "cross_stream": cross,
+                  "kkt": rel_err(sh.kkt_to_reference(kkt), rkkt), "shape": list(kkt.shape), "stride": sh.KSTRIDE, "host_same": host_same, "cross_stream": cross,
                   "default_stream": default_stream}}))
 dist.destroy_process_group()
 """
@@ -73,7 +73,7 @@ def test_sharded_device_path_with_rccl_gather_matches_the_oracle(oracle):
     r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["shape"] == [333, 1008]
+    assert out["shape"] == [333, out["stride"]] and out["stride"] >= 1008     # (the blocks travel in the kernels' layout)
     assert out["fx"] < 1e-10 and out["agx"] < 1e-8 and out["kkt"] < 1e-8, out
     assert out["host_same"]                  # the host-shared exchange delivers the same bits
     assert out["cross_stream"]               # evaluation on one stream, gather on another: ordered by the evaluator

@@ -65,7 +65,11 @@ def test_full_kkt_layout_matches_the_oracle(oracle, shim, nseg):
         assert nnz == ref.nnz, err.value
         np.testing.assert_array_equal(outer, r_outer)
         np.testing.assert_array_equal(inner[:nnz], r_inner)
-        np.testing.assert_array_equal(locs[: r_locs.size], r_locs)
+        # KKTLocations: the same multiset of user locations (each function lists its slots in the order of its own blocks), the
+        # solver's own slots behind them unchanged
+        nu = ref.num_user_kkt
+        np.testing.assert_array_equal(np.sort(locs[:nu]), np.sort(r_locs[:nu]))
+        np.testing.assert_array_equal(locs[nu: r_locs.size], r_locs[nu:])
         rval, rPGX, rAGX, rFXE, rFXI, rvals = ref.eval(level, p.obj_scale, p.X, p.LE, p.LI)
         scale = max(1.0, np.abs(p.X).max())
         assert np.abs(FXE - rFXE).max() / scale < 1e-10 and np.abs(FXI - rFXI).max() / scale < 1e-10

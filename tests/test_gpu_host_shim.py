@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import Workload, rel_err
+from helpers import Workload, csr_locations, rel_err
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +22,30 @@ def shim(tmp_path_factory):
     return C.CDLL(so)
 
 
+def shim_locations(shim, oracle, w, nlp, mode):
+    """The constraint's own KKT space -- (row, col) per slot in the order of ITS blocks (BatchedDefectConstraint::getKKTSpace) --
+    checked against the oracle's space as a multiset per application (the order is the function's private business:
+    SolverInterfaceSpecs.h:41-92, NonLinearProgram.cpp:282-330), and turned into KKTLocations of the oracle's CSR matrix."""
+    ip = C.POINTER(C.c_int)
+    rows = np.zeros(nlp.num_user_kkt, dtype=np.int32)
+    cols = np.zeros(nlp.num_user_kkt, dtype=np.int32)
+    err = C.create_string_buffer(512)
+    n = shim.shim_space(w.ode.encode(), oracle.MODES[mode], int(w.blocked), w.IR, w.OR, w.nseg, w.vindex.ctypes.data_as(ip),
+                        w.cindex.ctypes.data_as(ip), w.n_primal, w.n_equal, rows.ctypes.data_as(ip), cols.ctypes.data_as(ip), err, 512)
+    assert n == nlp.num_user_kkt, err.value
+    rows_ref, cols_ref = nlp.kkt_coords()
+    # analyzeSparsity keeps every slot as (row >= col) and files it in CSR row `col` (NonLinearProgram.cpp:282-307)
+    lo, hi = np.minimum(rows, cols).astype(np.int64), np.maximum(rows, cols).astype(np.int64)
+    per = nlp.num_user_kkt // w.nseg
+    got = np.sort((hi * (1 << 31) + lo).reshape(w.nseg, per), axis=1)
+    ref = np.sort((rows_ref[: nlp.num_user_kkt].astype(np.int64) * (1 << 31) + cols_ref[: nlp.num_user_kkt]).reshape(w.nseg, per), axis=1)
+    np.testing.assert_array_equal(got, ref)
+    outer, inner = nlp.csr()
+    locs = nlp.kkt_locations().copy()                     # (the solver's own slots behind the user slots stay)
+    locs[: nlp.num_user_kkt] = csr_locations(rows, cols, outer, inner)
+    return locs, rows, cols
+
+
 @pytest.mark.parametrize("ode,mode,blocked,nseg", [("reentry", "LGL7", False, 37), ("twobody_lt", "LGL5", True, 20),
                                                    ("betts_lowthrust", "LGL3", False, 9), ("reentry", "Trapezoidal", False, 11)])
 @pytest.mark.parametrize("device_assembly", [False, True])
@@ -32,8 +56,7 @@ def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg, device_
     shim.shim_set_shards(shards)
     w = Workload(ode, mode, nseg, blocked, var_offset=2, con_offset=1, extra_vars=3)
     nlp = w.oracle_nlp(oracle, threads=1)
-    locs = nlp.kkt_locations()
-    rows_ref, cols_ref = nlp.kkt_coords()
+    locs, rows_sp, cols_sp = shim_locations(shim, oracle, w, nlp, mode)
     ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
     for what in (oracle.JAC_ADJGRAD_HESS, oracle.CON, oracle.CON_ADJGRAD, oracle.JAC, oracle.JAC_ADJGRAD):
         FXE, AGX, vals = np.zeros(w.n_equal), np.zeros(w.n_primal), np.zeros(nlp.nnz)
@@ -47,10 +70,8 @@ def test_shim_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg, device_
                            FXE.ctypes.data_as(dp), AGX.ctypes.data_as(dp), err, 512,
                            C.c_longlong(nlp.nnz if device_assembly else 0))
         assert rc == 0, err.value
-        # analyzeSparsity keeps every slot as (row >= col) and files it in CSR row `col` (NonLinearProgram.cpp:282-307)
-        lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
-        np.testing.assert_array_equal(hi, rows_ref[: nlp.num_user_kkt])
-        np.testing.assert_array_equal(lo, cols_ref[: nlp.num_user_kkt])
+        np.testing.assert_array_equal(rows, rows_sp)      # (the same space every time it is asked for)
+        np.testing.assert_array_equal(cols, cols_sp)
         rFXE, rAGX, rvals = nlp.eval(what, w.X, w.L)
         assert np.abs(FXE - rFXE).max() / max(1.0, np.abs(w.X).max()) < 1e-10
         if what in (oracle.CON_ADJGRAD, oracle.JAC_ADJGRAD, oracle.JAC_ADJGRAD_HESS):
@@ -67,7 +88,7 @@ def test_shim_rebind_and_deep_copy(oracle, shim, device_assembly, shards):
     shim.shim_set_shards(shards)
     w = Workload("reentry", "LGL5", 29, var_offset=2, con_offset=1, extra_vars=3)
     nlp = w.oracle_nlp(oracle, threads=1)
-    locs = nlp.kkt_locations()
+    locs, _, _ = shim_locations(shim, oracle, w, nlp, "LGL5")
     ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
     FXE, AGX, vals = np.zeros(w.n_equal), np.zeros(w.n_primal), np.zeros(nlp.nnz)
     err = C.create_string_buffer(512)
@@ -107,7 +128,10 @@ def test_kkt_assembly_matches_oracle_nlp(oracle, shim, ode, mode, blocked, nseg)
         assert nnz == nlp.nnz, err.value
         np.testing.assert_array_equal(outer, r_outer)
         np.testing.assert_array_equal(inner[:nnz], r_inner)
-        np.testing.assert_array_equal(locs, r_locs)
+        # KKTLocations: the same locations per application, in the order of the function's own space (the device's block layout)
+        nu = nlp.num_user_kkt
+        np.testing.assert_array_equal(np.sort(locs[:nu].reshape(w.nseg, -1), axis=1), np.sort(r_locs[:nu].reshape(w.nseg, -1), axis=1))
+        np.testing.assert_array_equal(locs[nu:], r_locs[nu:])
         rFXE, rAGX, rvals = nlp.eval(okind, w.X, w.L)
         assert np.abs(FXE - rFXE).max() / max(1.0, np.abs(w.X).max()) < 1e-10
         if what in (1, 3, 4):
@@ -129,8 +153,7 @@ def test_trapezoidal_hessian_sparsity_mask(oracle, shim, ode, blocked, nseg, dev
         nlp = w.oracle_nlp(oracle, threads=1, hessian_sparsity=True)
         dense = w.oracle_nlp(oracle, threads=1)
         assert nlp.num_user_kkt < dense.num_user_kkt
-        locs = nlp.kkt_locations()
-        rows_ref, cols_ref = nlp.kkt_coords()
+        locs, rows_sp, cols_sp = shim_locations(shim, oracle, w, nlp, "Trapezoidal")
         ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
         for what in (oracle.JAC_ADJGRAD_HESS, oracle.JAC_ADJGRAD):
             FXE, AGX, vals = np.zeros(w.n_equal), np.zeros(w.n_primal), np.zeros(nlp.nnz)
@@ -144,9 +167,8 @@ def test_trapezoidal_hessian_sparsity_mask(oracle, shim, ode, blocked, nseg, dev
                                FXE.ctypes.data_as(dp), AGX.ctypes.data_as(dp), err, 512,
                                C.c_longlong(nlp.nnz if device_assembly else 0))
             assert rc == 0, err.value
-            lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
-            np.testing.assert_array_equal(hi, rows_ref[: nlp.num_user_kkt])
-            np.testing.assert_array_equal(lo, cols_ref[: nlp.num_user_kkt])
+            np.testing.assert_array_equal(rows, rows_sp)
+            np.testing.assert_array_equal(cols, cols_sp)
             rFXE, rAGX, rvals = nlp.eval(what, w.X, w.L)
             assert np.abs(FXE - rFXE).max() / max(1.0, np.abs(w.X).max()) < 1e-10
             assert rel_err(AGX, rAGX) < 1e-8 and rel_err(vals, rvals) < 1e-8

@@ -297,7 +297,8 @@ def test_gpu_full_size_wide_shape_properties(oracle):
     X, L = torch.from_numpy(w.X).to(dev), torch.from_numpy(w.L).to(dev)
     fx = torch.zeros(nseg, w.OR, dtype=torch.float64, device=dev)
     agx = torch.zeros(nseg, w.IR, dtype=torch.float64, device=dev)
-    kkt = torch.zeros(nseg, w.NKKT, dtype=torch.float64, device=dev)
+    kkt = torch.zeros(nseg, ev.KSTRIDE, dtype=torch.float64, device=dev)
+    assert ev.kkt_layout == 0 and ev.KSTRIDE == w.NKKT            # (a wide shape: the reference's slot order, which the J^T lam check below walks)
     torch.cuda.synchronize()                              # (torch fills on its stream, the evaluator runs on its own)
     ev.eval_device(JAC_ADJGRAD_HESS, X, L, fx, agx, kkt)
     torch.cuda.synchronize()
@@ -359,7 +360,8 @@ def test_pinned_outputs_give_the_same_blocks(oracle):
     ref = [None if a is None else a.copy() for a in ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)]
     ev.pin_outputs()
     got = ev.eval(JAC_ADJGRAD_HESS, w.X, w.L)
-    for a, b in zip(got, ref):
+    assert got[2].shape == (w.nseg, ev.KSTRIDE)         # pinned outputs: the blocks as the C ABI returns them, in the handle's layout
+    for a, b in zip((got[0], got[1], ev.kkt_to_reference(got[2])), ref):
         np.testing.assert_array_equal(a, b)
     assert ev.eval(CON, w.X)[0] is got[0]               # the same page-locked arrays are returned every time
     ev.close()

@@ -130,7 +130,7 @@ def test_function_bundle_gives_the_blocks_of_the_separate_launches():
     def outs():
         return ([torch.full((e.nseg * e.OR,), np.nan, dtype=torch.float64, device=dev) for _, e in members],
                 [torch.full((e.nseg * e.IR,), np.nan, dtype=torch.float64, device=dev) for _, e in members],
-                [torch.full((e.nseg * e.NKKT,), np.nan, dtype=torch.float64, device=dev) for _, e in members])
+                [torch.full((e.nseg * e.KSTRIDE,), np.nan, dtype=torch.float64, device=dev) for _, e in members])
     for what in (JAC_ADJGRAD_HESS, JAC_ADJGRAD, CON):
         fb, gb, kb = outs()
         bundle.eval_device(what, X, Ls, fb, gb if what != CON else [None] * len(members), kb if what != CON else [None] * len(members))

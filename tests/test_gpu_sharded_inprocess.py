@@ -28,8 +28,42 @@ def test_sharded_blocks_are_bitwise_the_single_handle(ode, mode, blocked, nseg, 
             assert (x is None) == (y is None)
             if x is not None:
                 np.testing.assert_array_equal(x, y)
+    # page-locked outputs kept across calls (the calling thread enqueues every shard before any copy has run) give the same bits as the
+    # pageable ones above (a host thread per shard inside the library); the blocks arrive in the handles' layout
+    sh.pin_outputs()
+    ref = one.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    got = sh.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    assert got[2].shape == (nseg, sh.KSTRIDE) and sh.eval(CON, w.X)[0] is got[0]
+    got = sh.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+    for x, y in zip(ref, (got[0], got[1], sh.kkt_to_reference(got[2]))):
+        np.testing.assert_array_equal(x, y)
     sh.close()
     one.close()
+
+
+def test_sharded_calls_leave_the_current_device_alone_and_do_not_serialise():
+    """The asset_hip_sharded_* entry points walk the shards' devices (hipSetDevice is per thread) and put the caller's current device
+    back; and N handles on ONE device take about the time of one handle for the same phase -- the work and the bytes are the same --
+    not N times it (page-locked outputs: every shard is enqueued before any is waited for)."""
+    import ctypes as C
+    import time
+    hip = C.CDLL("libamdhip64.so")
+    dev = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(dev)) == 0
+    before = dev.value
+    w = Workload("reentry", "LGL7", 4000)
+    times = {}
+    for nsh in (1, 4):
+        sh = ShardedDefectEvaluator("reentry", "LGL7", False, w.vindex, w.cindex, w.n_primal, w.n_equal, [0] * nsh).pin_outputs()
+        for _ in range(3):
+            sh.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            sh.eval(JAC_ADJGRAD_HESS, w.X, w.L)
+        times[nsh] = (time.perf_counter() - t0) / 10
+        sh.close()
+        assert hip.hipGetDevice(C.byref(dev)) == 0 and dev.value == before
+    assert times[4] < 2.0 * times[1] + 1e-3, times
 
 
 @pytest.mark.parametrize("ode,mode,blocked,exact", [("reentry", "LGL5", False, True), ("twobody_lt", "LGL5", True, False)])

@@ -94,3 +94,45 @@ def test_integral_param_function_tables_share_the_accumulation_row():
     assert entries[tags.index("eq0")][5][0, 0] == Ca[0, 0] + 1
     X = ph.solver_input() if False else ix.makeSolverInput(ph.ActiveTraj, ph.ActiveStaticParams)
     assert X.size == ix.numPhaseVars and np.array_equal(X[ix.StaticParamLoc0:], [1.0, 2.0, 3.0])
+
+
+def test_integral_functions_under_autoscaling_constrain_the_same_integral():
+    """AutoScaling and the integral functions (ODEPhaseBase.cpp:796-803, 846-861): with the solver's variables in scaled units the
+    integrand is IOScaled over its input units with its output scale, and the accumulation of an integral parameter function is
+    ``-AccScale * p_scaled``, AccScale = SPUnits[p] * output_scale / t_unit -- so the row the solver sees is
+    ``(output_scale / t_unit) * (int f dt - scale * p)`` of the unscaled problem, and an integral objective ``(output_scale / t_unit) *
+    int f dt``.  Host-only: the phase's function tables evaluated with the expression graph (no device)."""
+    import numpy as np
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ShuttleReentry
+    from helpers import Workload
+    nseg = 5
+    w = Workload("reentry", "LGL7", nseg)
+    units = np.array([2.0, 0.5, 3.0, 1.5, 0.8, 4.0, 1.25, 2.5])
+    sp, spu = np.array([0.3, -1.2]), np.array([4.0, 0.5])
+    oscale_p, oscale_o, scale = 3.0, 0.7, 2.0
+
+    def build(auto):
+        ph = ShuttleReentry().phase("LGL7", w.traj, nseg)
+        ph.setStaticParams(sp, units=spu)
+        g = vf.Arguments(3)                                    # (state variables 2 and 0, static parameter 1)
+        ph.addIntegralParamFunction(g[1] * g[1] + g[0] * g[2], [2, 0], SPVars=[1], accum_param=0, scale=scale, output_scale=oscale_p)
+        g2 = vf.Arguments(3)
+        ph.addIntegralObjective(vf.sin(g2[0]) * g2[1] + g2[2] * g2[2], [2, 0], SPVars=[1], output_scale=oscale_o)
+        if auto:
+            ph.setUnits(units)
+            ph.setAutoScaling(True)
+        ix, _, entries, _, _ = ph.layout()
+        X = ix.makeSolverInput(ph.ActiveTraj / units if auto else ph.ActiveTraj, sp / spu if auto else sp)
+        val = {}
+        for kind, tag, F, name, V, Cx, consts in entries:
+            if tag.startswith(("ipf", "obj")):
+                val[tag] = sum(float(F.compute(X[V[a]])[0]) for a in range(V.shape[0]))
+        return val
+    plain, scaled = build(False), build(True)
+    t_unit = units[5]
+    row_plain = plain["ipf0_acc"] + plain["ipf0_int"]
+    row_scaled = scaled["ipf0_acc"] + scaled["ipf0_int"]
+    assert abs(plain["ipf0_acc"] + scale * sp[0]) < 1e-15 and abs(plain["ipf0_int"]) > 1e-3
+    assert abs(row_scaled - oscale_p / t_unit * row_plain) <= 1e-13 * max(1.0, abs(row_plain))
+    assert abs(scaled["obj0"] - oscale_o / t_unit * plain["obj0"]) <= 1e-13 * max(1.0, abs(plain["obj0"]))

@@ -16,7 +16,7 @@ ev.set_kkt_map(locs,nlp.nnz)
 dev=torch.device("cuda:0")
 X=torch.from_numpy(w.X).to(dev); L=torch.from_numpy(w.L).to(dev)
 fx=torch.zeros(nseg*ev.OR,dtype=torch.float64,device=dev); agx=torch.zeros(nseg*ev.IR,dtype=torch.float64,device=dev)
-kkt=torch.zeros(nseg*ev.NKKT,dtype=torch.float64,device=dev); vals=torch.zeros(nlp.nnz,dtype=torch.float64,device=dev)
+kkt=torch.zeros(nseg*ev.KSTRIDE,dtype=torch.float64,device=dev); vals=torch.zeros(nlp.nnz,dtype=torch.float64,device=dev)
 st=torch.cuda.Stream()   # a real stream: a null handle would select the evaluator's own
 def timeit(fn,n=100):
     for _ in range(10): fn()

@@ -10,7 +10,7 @@ nseg=int(sys.argv[3]) if len(sys.argv)>3 else 10000; blocked=bool(int(sys.argv[4
 what=int(sys.argv[5]) if len(sys.argv)>5 else 4
 w=Workload(ode,mode,nseg,blocked)
 ev=DefectEvaluator(ode,mode,blocked,w.vindex,w.cindex,w.n_primal,w.n_equal)
-IR,OR,NK=ev.IR,ev.OR,ev.NKKT
+IR,OR,NK=ev.IR,ev.OR,ev.KSTRIDE   # (blocks in the handle's layout)
 dev=torch.device("cuda:0")
 X=torch.from_numpy(w.X).to(dev); L=torch.from_numpy(w.L).to(dev)
 fx=torch.zeros(nseg*OR,dtype=torch.float64,device=dev); agx=torch.zeros(nseg*IR,dtype=torch.float64,device=dev)

@@ -30,9 +30,10 @@ hs = sh.host_shard_blocks()
 if rank == 0:
     rfx, ragx, rkkt = w.oracle_nlp(ob, threads=4).eval_blocks(4, w.X, w.L)
     hk = np.concatenate([h[2] for h in hs]); hf=np.concatenate([h[0] for h in hs]); ha=np.concatenate([h[1] for h in hs])
+    hk = sh.kkt_to_reference(hk)                      # (the blocks travel in the kernels' layout)
     out={"host_kkt": rel_err(hk, rkkt), "host_agx": rel_err(ha, ragx), "host_fx": float(np.abs(hf-rfx).max()), "shards": sh.shards, "how": how}
     if blocks is not None:
-        out["gather_kkt"]=rel_err(blocks[2].cpu().numpy(), rkkt)
+        out["gather_kkt"]=rel_err(sh.kkt_to_reference(blocks[2].cpu().numpy()), rkkt)
 sh._host.close()
 # sharded on-device assembly: every rank's compact value array pushed into the shared value array, against ONE device's
 # asset_hip_defect_eval_assembled_zeroed, bit for bit

@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 X, L = torch.from_numpy(w.X).to(dev), torch.from_numpy(w.L).to(dev)
 fx = torch.empty(n * ev.OR, dtype=torch.float64, device=dev)
 agx = torch.empty(n * ev.IR, dtype=torch.float64, device=dev)
-kkt = torch.empty(n * ev.NKKT, dtype=torch.float64, device=dev)
+kkt = torch.empty(n * ev.KSTRIDE, dtype=torch.float64, device=dev)
 for name, k in (("with block stores", kkt), ("no block stores", None)):
     ts = [ev.time_device(4, X, L, fx, agx, k, warmup=5, iters=200) for _ in range(5)]
     print(name, " ".join(f"{1e3*t:.2f}" for t in ts))

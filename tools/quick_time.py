@@ -19,7 +19,7 @@ dev = torch.device("cuda:0")
 X, L = torch.from_numpy(w.X).to(dev), torch.from_numpy(w.L).to(dev)
 fx = torch.empty(nseg * ev.OR, dtype=torch.float64, device=dev)
 agx = torch.empty(nseg * ev.IR, dtype=torch.float64, device=dev)
-kkt = torch.empty(nseg * ev.NKKT, dtype=torch.float64, device=dev)
+kkt = torch.empty(nseg * ev.KSTRIDE, dtype=torch.float64, device=dev)
 ts = []
 for rep in range(int(os.environ.get('QT_REPS', '6'))):
     k = kind & 0xFF

@@ -42,7 +42,7 @@ def main():
     for name, ev, lam in evs:
         fx = torch.empty(ev.nseg * ev.OR, dtype=torch.float64, device=dev)
         agx = torch.empty(ev.nseg * ev.IR, dtype=torch.float64, device=dev)
-        kkt = torch.empty(ev.nseg * ev.NKKT, dtype=torch.float64, device=dev)
+        kkt = torch.empty(ev.nseg * ev.KSTRIDE, dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
         ms = ev.time_device(JAC_ADJGRAD_HESS, X, lam, fx, agx, kkt, warmup=5, iters=100)
         out[name] = {"applications": ev.nseg, "IR": ev.IR, "OR": ev.OR, "us": round(ms * 1e3, 2),
@@ -52,7 +52,7 @@ def main():
     Ls = [Lo if kind == "objective" else L for kind, _ in members]
     fxs = [torch.empty(e.nseg * e.OR, dtype=torch.float64, device=dev) for _, e in members]
     agxs = [torch.empty(e.nseg * e.IR, dtype=torch.float64, device=dev) for _, e in members]
-    kkts = [torch.empty(e.nseg * e.NKKT, dtype=torch.float64, device=dev) for _, e in members]
+    kkts = [torch.empty(e.nseg * e.KSTRIDE, dtype=torch.float64, device=dev) for _, e in members]
     st = torch.cuda.Stream()
     call = bundle.bind_device(JAC_ADJGRAD_HESS, X, Ls, fxs, agxs, kkts, st)
     with torch.cuda.stream(st):
