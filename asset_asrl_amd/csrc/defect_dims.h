@@ -11,16 +11,10 @@
 
 #include "lgl_tables.h"
 
-#ifndef ASSET_ODE_WAVES_PER_SIMD
 #define ASSET_ODE_WAVES_PER_SIMD 1    // register budget of the ODE-stage kernel
-#endif
-#ifndef ASSET_DENSE_WAVES_PER_SIMD
 #define ASSET_DENSE_WAVES_PER_SIMD 2  // register budget of the dense-phase kernel: 512 / 2 = 256 per lane
-#endif
 
-#ifndef ASSET_LANE_REPLICAS
 #define ASSET_LANE_REPLICAS 64        // copies of the dense stage's per-lane constant table (capi.hip)
-#endif
 
 // Measurement builds (tools/build_one.py with -DASSET_TUNING_BUILD): clock stamps written over FX / AGX (ASSET_TIMING,
 // ASSET_WALLCLOCK, ASSET_FUNC_TIMING) and elimination experiments that compute WRONG results on purpose (ASSET_EXP_*).  A
@@ -143,9 +137,7 @@ struct Dims {
   // Shapes from IR = 64 on take the same kernel even though they fit: holding their accumulators, fragments and lane
   // constants in one wave spills (32 states in LGL5, 10 000 segments: 6.7 ms single-wave, 1.2 ms four-wave; LGL3:
   // 0.64 -> 0.38 ms), while at IR = 40 (TwoBody-LGL7) the single-wave layout is still twice as fast.
-#ifndef ASSET_WIDE_MIN_IR
 #define ASSET_WIDE_MIN_IR 64
-#endif
   static constexpr bool WIDE =
       size_t(TABSZ + WSLOTD + XM_ALL + K * (NP - n) * IRP + ORP * LDC + 4 * IRP + 2) * 8 > 160 * 1024 ||
       (!TRAP && IR >= ASSET_WIDE_MIN_IR);
@@ -191,9 +183,7 @@ struct Dims {
   static constexpr int STG_LD = NSTG | 1;
   static constexpr int DENSE = WSLOTD + SCRATCH;         // slot buffer + dense scratch (staging aliases both)
   // lanes per ODE pass: as many as fit in the LDS the dense phase needs anyway (occupancy is LDS-bound)
-#ifndef ASSET_LC_BUDGET
 #define ASSET_LC_BUDGET (64 * 1024)
-#endif
   // very wide ODEs: no LDS row fits -> the evaluating lanes write J/H straight to the workspace (uncoalesced, correct)
   static constexpr bool STAGED = (16 * STG_LD * 8 <= ASSET_LC_BUDGET);
   static constexpr int LC = !STAGED ? 64
@@ -347,9 +337,7 @@ __device__ inline void wave_loads_landed() { __builtin_amdgcn_s_waitcnt(0x0F70);
 // runs no faster (two launches 53.3 vs 53.4 us, fused 43.1 vs 42.9 us) and large meshes run 6-7 % slower (100 000
 // segments 537 vs 506 us, 1 000 000 segments 5.01 vs 4.66 ms): a wave's time in the store phase is the issue of its
 // own stores (about 2.4 bytes per cycle and wave, tools/ubench_store.hip), not the wait the compiler places.
-#ifndef ASSET_STORE_FENCE
 #define ASSET_STORE_FENCE 0
-#endif
 __device__ inline void wave_store_fence() { if constexpr (ASSET_STORE_FENCE != 0) wave_loads_landed(); }
 // Hand-offs through the global workspace (same wave writes, then reads): wait for the stores as well.
 __device__ inline void wave_mem_sync() { __syncthreads(); }

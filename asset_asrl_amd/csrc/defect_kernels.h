@@ -515,9 +515,7 @@ __device__ inline void pipe_ode_group2(const EvalArgs& a, int tid, int seg0, int
                                        lds_double* mirror, const LglTab* tabp, Pub&& publish_tables) {
   constexpr int CS = D::CS, K = D::K, n = D::n, N = D::N, IR = D::IR, OR = D::OR, STG_LD = D::STG_LD;
   static_assert(GP2 * CS <= 64, "one pass per phase");
-#ifndef ASSET_ROLE_SHIFT
 #define ASSET_ROLE_SHIFT 8
-#endif
   // which wave of the pair takes the cardinal phases alternates from one workgroup of a CU to the next (workgroups are
   // dealt to the 8 XCDs x 32 CUs breadth first: workgroup b is the (b >> 8)-th of its CU), so that the cardinal waves of
   // the workgroups sharing a CU do not pile up on the same SIMDs
@@ -784,9 +782,7 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
   static_assert(STAGE != 3 || (D::FUSED && LEVEL >= 1), "no fused kernel for this shape / level");
   static_assert(STAGE != 4 || (D::FUSED2 && LEVEL == 2), "no two-wave fused kernel for this shape / level");
   constexpr bool MIR = D::MIRROR && LEVEL >= 1 && STAGE == 1;
-#ifndef ASSET_ODE_PIPE
 #define ASSET_ODE_PIPE 1
-#endif
   constexpr bool PIPE = ASSET_ODE_PIPE && MIR && LEVEL == 2 && D::STAGED && LC == 64 && G * CS <= 64;
   lds_double* const mirror = (lds_double*)(body + (STAGE == 3 ? D::GF * CS : LC) * STG_LD);   // [G][MSLOT] (ODE stage, MIR)
   static_assert(!MIR || G <= D::GM, "the LDS mirror holds one slot per segment of a group");
@@ -839,9 +835,7 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
 #define ASSET_PTS_NONE
 #endif
 // sub-phase stamps of the dense stage, taken for the second segment of the workgroup (-DASSET_TIMING, tools/dbg_time.py)
-#ifndef ASSET_TSG_SEG
 #define ASSET_TSG_SEG 1
-#endif
 #define TSG() do { if (g == ASSET_TSG_SEG) TS(); } while (0)
   if constexpr (STAGE >= 3) TS();   // (timing builds: kernel start)
 #if defined(ASSET_WALLCLOCK)
@@ -1211,9 +1205,7 @@ __device__ __forceinline__ void lgl_defect_body(const EvalArgs& a) {
 
       // Small shapes keep every accumulator tile until D6 (the stores then share a handful of lane-condition
       // branches); wide ones store each tile as it completes -- holding them all would spill.
-#ifndef ASSET_HOLD_TILES
 #define ASSET_HOLD_TILES 6
-#endif
       constexpr bool HOLD = (D::NTH + D::TI * D::TJ) <= ASSET_HOLD_TILES;
       constexpr bool CFULL = (IR == IRP);
       d4 accH[(LEVEL >= 2 && HOLD) ? D::NTH : 1];

@@ -50,9 +50,7 @@ struct ResDims {
 #define ASSET_RES_ROWDPP 1
 #endif
   static constexpr bool RD_SHAPE = ASSET_RES_ROWDPP == 2 || (ASSET_RES_ROWDPP == 1 && !((q % 4 == 0) && D::p == 0));
-#ifndef ASSET_RES_WPS
 #define ASSET_RES_WPS ((Ode::NUNITS > 1 || (D::TJ > 1 && !(RD_SHAPE && !D::TRAP))) ? 1 : 2)
-#endif
   static constexpr int WPS = ASSET_RES_WPS;
   static constexpr bool ASM_OK = !(D::TJ > 1 && RD_SHAPE && !D::TRAP && Ode::NUNITS == 1);
 #ifndef ASSET_RES_PAIR
@@ -88,16 +86,12 @@ struct ResDims {
     }
     return -1;
   }
-#ifndef ASSET_RES_JRIDE
 #define ASSET_RES_JRIDE 1
-#endif
   // GROW: row N of the A operand carries E_i g^_i, so that sum_i E_i g^_i . DI_i falls out of the M product too.  Shapes where the
   // H^ rows, that row and the J^ rows do not fit 16 rows together but the first and the last do (TwoBody: N = 10, n = 6) give the
   // g^ row up -- the sum is then K KS vector FMAs and two cross-lane adds per column tile -- and keep the ride: 12 of 45 matrix
   // instructions per TwoBody-LGL5 segment gone.
-#ifndef ASSET_RES_GROWLESS
 #define ASSET_RES_GROWLESS 1
-#endif
   // (only where the wave has a SIMD's registers to itself: at two waves per SIMD the TwoBody-LGL5-BlockConstant kernel, which
   //  then keeps its J^T accumulators through the H tile columns, spills 48 values into the segment loop and runs 71.5 us
   //  instead of 35.6 -- every scratch reload there waits for the block stores in flight; TwoBody-LGL7: 81.4 -> 79.6 us)
@@ -139,9 +133,7 @@ struct ResDims {
   // masked stores of the segment loop as raw buffer stores (out-of-range offsets for the masked lanes) and the column role computed by
   // every lane: the loop is one basic block.  Not the two-row-tile shapes at one wave per SIMD: at 500 of 512 registers the freer
   // schedule spills (TwoBody-LGL7: 13 registers into the loop, 78.3 -> 81.4 us)
-#ifndef ASSET_RES_BSTORE
 #define ASSET_RES_BSTORE (!(WPS == 1 && D::TJ > 1 && Ode::NUNITS == 1))
-#endif
   static constexpr bool BSTORE = ASSET_RES_BSTORE;
   static constexpr int NWV = PAIR ? 2 : 1;                          // waves per workgroup
 #ifndef ASSET_RES_LOOP_PAIR
@@ -161,9 +153,7 @@ struct ResDims {
   static constexpr size_t lds_bytes() { return size_t(NWV * REGION) * 8; }
   // (two row tiles of defect rows -- TwoBody-LGL7, K n = 18: with three column tiles beside them a wave needs ~420 registers; such
   //  shapes are built for one wave per SIMD, WPS above: 78 us for 10 000 segments against 149.5 us spilling at two)
-#ifndef ASSET_RES_MAX_TJ
 #define ASSET_RES_MAX_TJ 2
-#endif
   static constexpr bool DENSE_OK = !D::WIDE && D::TJ <= ASSET_RES_MAX_TJ && N + 1 <= 16 && GR >= 2 && D::STAGED;
   static constexpr bool OK = DENSE_OK && Ode::NUNITS == 1;
   // heavy right-hand sides (one workgroup per output unit, defect_units.h): the ODE results are in the workspace when the
@@ -250,10 +240,7 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_value(ld
 }
 
 // P2: interior point i: x^, tau, u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
-// HALF >= 0 (round 5, pair workgroups, LEVEL 2): this wave emits only one of the two halves of the outputs (Ode::fjgh_half<HALF>: the
-// generated bodies partition {J[:, k], g[k], H[i >= k, k]} by input direction in two sets of about equal cost) -- the pair's other wave
-// evaluates the same points for the other half at the same time, on another SIMD: the phase is 700 instructions deep instead of 930
-template <class Ode, class D, int LEVEL = 2, int HALF = -1>
+template <class Ode, class D, int LEVEL = 2>
 __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_double* S, int i, const LglTab* tabp, bool have_lam) {
   constexpr int n = D::n, m = D::m, q = D::q, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
@@ -282,7 +269,7 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
   for (int k = 0; k < D::p; k++) y[q + k] = z[D::P0 + k];
 #pragma unroll
   for (int k = 0; k < n; k++) li[k] = have_lam ? lam[i * n + k] : 0.0;
-  if constexpr (ResDims<D>::ROWDPP && LEVEL >= 1 && HALF <= 0) {   // FB_i[k] = sum_j B_ij f_j[k]: the time rows of the row-wise dense part (defect_rowdpp.h)
+  if constexpr (ResDims<D>::ROWDPP && LEVEL >= 1) {   // FB_i[k] = sum_j B_ij f_j[k]: the time rows of the row-wise dense part (defect_rowdpp.h)
 #pragma unroll
     for (int k = 0; k < n; k++) {
       double acc = 0.0;
@@ -303,14 +290,13 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
     for (int b = 0; b < N; b++) S[D::w_Ig + i * N + b] = out.gacc_[b];
   } else {
     OdeOutRes<D> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH, nullptr};
-    if constexpr (HALF >= 0) Ode::template fjgh_half<HALF>(in, out);
-    else Ode::fjgh(in, out);
+    Ode::fjgh(in, out);
   }
 }
 
 // P3: cardinal node j: adjoint weights w_j (LGLDefects.h:369-374) ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f
 // (NOJ: J_j is in the slot already -- EARLYC -- and the partner wave is reading it: not stored again)
-template <class Ode, class D, int HALF = -1, bool NOJ = false>
+template <class Ode, class D, bool NOJ = false>
 __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(lds_double* S, int j, const LglTab* tabp) {
   constexpr int K = D::K, n = D::n, N = D::N, T = D::T;
   using R = ResDims<D>;
@@ -331,16 +317,10 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(l
   double sv[Ode::NSAVE > 0 ? Ode::NSAVE : 1];      // (read before g_j is written: the two may share their cells)
 #pragma unroll
   for (int k = 0; k < Ode::NSAVE; k++) sv[k] = S[R::s_SV + j * R::SV_LD + k];
-  if constexpr (HALF >= 0) {
-    // both waves of the pair are in this phase, for the same points: the saved values may share their cells with g_j (SV_ALIAS), which
-    // the OTHER wave writes too -- every read of them, in both waves, comes first (both waves have the same lanes active here, so
-    // both reach the barrier)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  } else wave_lds_order();
+  wave_lds_order();
   CardInRes<D> in{z, w, sv, j};
   OdeOutRes<D> out{nullptr, NOJ ? nullptr : S + D::w_CJ + j * D::NZJ, S + D::w_Cg + j * N, S + D::w_CH + j * D::NZH, nullptr};
-  if constexpr (HALF >= 0) Ode::template fjgh_load_half<HALF>(in, out);
-  else Ode::fjgh_load(in, out);
+  Ode::fjgh_load(in, out);
 }
 
 // Trapezoidal, all derivatives (TrapezoidalDefects.h:263-435): there is no interior point, so the adjoint weights of the
@@ -548,7 +528,7 @@ constexpr long long res_table_words_tile() {
 }
 template <class Ode, class D>
 constexpr long long res_table_words() {
-  if constexpr ((ResDims<D>::DENSE_OK && ResDims<D>::ROWDPP) || UResDims<Ode, D>::OK) return res_table_words_tile<Ode, D>() + RdDims<Ode, D>::table_bytes() / 4;
+  if constexpr (ResDims<D>::DENSE_OK && ResDims<D>::ROWDPP) return res_table_words_tile<Ode, D>() + RdDims<Ode, D>::table_bytes() / 4;
   else return res_table_words_tile<Ode, D>();
 }
 
@@ -565,10 +545,6 @@ __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
       for (int rec = threadIdx.x; rec < RdDims<Ode, D>::NRECH; rec += 64)
         rd_lane_setup<Ode, D, ResDims<D>::s_Z0>(out + res_table_words_tile<Ode, D>(), rec);
     }
-  }
-  if constexpr (UResDims<Ode, D>::OK) {   // (heavy right-hand sides, defect_ures.h: the row records for its slot layout)
-    for (int rec = threadIdx.x; rec < RdDims<Ode, D>::NRECH; rec += 64)
-      rd_lane_setup<Ode, D, UResDims<Ode, D>::s_Z0>(out + res_table_words_tile<Ode, D>(), rec);
   }
 }
 
@@ -592,9 +568,6 @@ __device__ inline void lds_dma_row(unsigned lds_addr, const void* gbase, unsigne
 // Exchanges between the four rows of a wave (row = 16 lanes) in the vector ALU: gfx950's v_permlane16_swap_b32 (old, src) returns
 // { [old.r0, src.r0, old.r2, src.r2], [old.r1, src.r1, old.r3, src.r3] } and v_permlane32_swap_b32
 // { [old.lo, src.lo], [old.hi, src.hi] } (tools/ubench_permlane.hip) -- no LDS round trip as with ds_bpermute (__shfl).
-#ifndef ASSET_RES_PERMLANE
-#define ASSET_RES_PERMLANE 1
-#endif
 template <int W>   // W = 16: rows 2k, 2k+1 exchanged;  W = 32: the halves
 __device__ inline void rows_split(double x, double& even, double& odd) {
   res_u2 lo, hi;
@@ -610,24 +583,17 @@ __device__ inline void rows_split(double x, double& even, double& odd) {
 }
 // x summed over the four rows (the lanes with the same lr), every lane gets the total; bitwise what the two __shfl_xor steps give
 __device__ inline double rows4_sum(double x) {
-  if constexpr (ASSET_RES_PERMLANE) {
-    double e, o;
-    rows_split<16>(x, e, o); x = e + o;
-    rows_split<32>(x, e, o); return e + o;
-  } else {
-    x += __shfl_xor(x, 16);
-    return x + __shfl_xor(x, 32);
-  }
+  double e, o;
+  rows_split<16>(x, e, o); x = e + o;
+  rows_split<32>(x, e, o); return e + o;
 }
 // the value row ROW's lane lr holds, in rows 0 and 1 (the other rows: unspecified)
 template <int ROW>
 __device__ inline double row_to_rows01(double x, int lr) {
-  if constexpr (ASSET_RES_PERMLANE) {
-    double e, o;
-    if constexpr (ROW >= 2) { rows_split<32>(x, e, o); x = o; }   // [r2, r3, r2, r3]
-    rows_split<16>(x, e, o);
-    return (ROW & 1) ? o : e;
-  } else return __shfl(x, 16 * ROW + lr);
+  double e, o;
+  if constexpr (ROW >= 2) { rows_split<32>(x, e, o); x = o; }   // [r2, r3, r2, r3]
+  rows_split<16>(x, e, o);
+  return (ROW & 1) ? o : e;
 }
 
 // sum over the 16 lanes of a row (lanes with the same lk): butterfly in DPP, every lane gets the total
@@ -688,9 +654,6 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   // of one workgroup and wave 0 of another (tools/ubench_place.hip), so the longer shares are spread one to a SIMD instead of two
   // to the SIMDs of the first rem / 2 workgroups: at 5 000 Reentry-LGL7 segments (shares of 3 and 2) the busiest SIMD has 5
   // segments instead of 6.
-#ifndef ASSET_RES_PAIR_W0FIRST
-#define ASSET_RES_PAIR_W0FIRST 1
-#endif
   auto pair_range = [&](int s, int& first, int& count) {
     const int b = s >> 1, w = s & 1, nwg = int(gridDim.x);
     const int rem0 = min(rem, nwg), rem1 = max(rem - nwg, 0);      // extras of the waves 0 / of the waves 1, workgroups in order
@@ -700,7 +663,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   // (measured, Reentry-LGL7: 3 000 segments 18.8 -> 18.2 us, 5 000: 23.5 -> 22.8, 7 000: 27.6 -> 26.7, 9 000: 31.7 -> 30.7; with more
   //  extras than workgroups -- 10 000: 1 808 for 1 024 -- the busiest SIMD has two long shares either way and the plain rule is
   //  0.15 us faster)
-  const bool w0first = ASSET_RES_PAIR_W0FIRST && rem <= int(gridDim.x);
+  const bool w0first = rem <= int(gridDim.x);
   if constexpr (PAIR) { if (w0first) pair_range(share, wg_first, wg_count); }
   if constexpr (GIVEN) {
     // Behind the one-launch unit stage (registry.h): group g of units_gp segments was evaluated on XCD g % 8, and this workgroup runs
@@ -733,11 +696,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   // 256-register waves per SIMD the dispatcher puts wave 1 of workgroup b and wave 0 of workgroup b + gridDim/4 on one SIMD
   // (tools/ubench_place.hip: 1 002 of 1 024 SIMDs host one wave 0 and one wave 1), so with the roles fixed by the wave index a
   // SIMD runs one ODE phase at a time -- one workgroup's P1, the other's P2, the first one's P3 -- at a lone wave's issue rate.
-  // (ASSET_RES_PAIR_FLIP: roles swapped in the upper half of the grid; measured slower, 33.1 against 32.6 us.)
-#ifndef ASSET_RES_PAIR_FLIP
-#define ASSET_RES_PAIR_FLIP 0
-#endif
-  const int wa = (ASSET_RES_PAIR_FLIP && 2 * int(blockIdx.x) >= int(gridDim.x)) ? 1 : 0;
+  // (roles swapped in the upper half of the grid: measured slower, 33.1 against 32.6 us)
+  constexpr int wa = 0;
   const bool roleA = !PAIR || wv == wa, roleB = !PAIR || wv != wa;
   auto pair_sync = [&]() {   // LDS hand-over between the pair's waves (no wait for stores in flight)
     if constexpr (PAIR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -745,12 +705,9 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   };
   // (shifting segments from the younger wave of every SIMD to the older one -- 52 / 54 / 56 % to the first half of the grid --
   //  changes nothing: 35.1-35.2 us each)
-#ifndef ASSET_RES_PAIR_YOUNG
-#define ASSET_RES_PAIR_YOUNG 1
-#endif
   // the second wave of its SIMD (workgroups are dealt breadth first: b and b + gridDim/2 share a SIMD; in the pair form b's wave 1
   // and (b + gridDim/4)'s wave 0 do)
-  const bool young = (PAIR && ASSET_RES_PAIR_YOUNG) ? (((4 * int(blockIdx.x)) / max(int(gridDim.x), 1)) & 1) != 0
+  const bool young = PAIR ? (((4 * int(blockIdx.x)) / max(int(gridDim.x), 1)) & 1) != 0
                                                     : 2 * int(blockIdx.x) >= int(gridDim.x);
   lds_double* const region0 = (lds_double*)lds;                     // (PAIR) wave 0's region; wave 1's follows
 
@@ -776,9 +733,6 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   // for slot g + 1 (the last segment of a group: for slot 0 of the next group), and the wait at the top of the next segment is for
   // loads issued a segment's worth of stores ago.  Before: all of a group's slots copied through registers ahead of its first
   // segment, 8 loads per lane in flight -- 22 k cycles per group of four Betts-LGL7 slots at one wave per SIMD, nothing to run under them.
-#ifndef ASSET_RES_SLOT_DMA
-#define ASSET_RES_SLOT_DMA 1
-#endif
   bool slot0_ahead = false;
   for (int grp = 0, seg0 = wg_first, o_seg0 = o_first; grp < ngroups; grp++) {
   const int gcount = gbase + (grp < gextra ? 1 : 0);
@@ -828,34 +782,16 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   if constexpr (GIVEN) {
     // ------------------------------------------------------------------ slots from the workspace (defect_units.h wrote them)
     // (the record first: there is no ODE body here that needs the registers, and its round trip to memory runs under the slots')
-    if constexpr (ASSET_RES_SLOT_DMA) {
-      if (!slot0_ahead) slot_dma(0, seg0);              // (later groups: the last segment of the group before has asked for it)
-    }
+    if (!slot0_ahead) slot_dma(0, seg0);                // (later groups: the last segment of the group before has asked for it)
     load_record();
     // (eight requests in flight per lane; 32 -- the slots of two Betts-LGL5 segments in one round trip instead of four -- changes
     //  nothing: 30.6 against 30.1 us for 1 000 segments, 106.1 / 106.7 for 5 000: the 11.8 k cycles of this copy are the slots arriving
     //  from where the unit kernels of seven other workgroups, on other XCDs, have just written them)
-    constexpr int NTAB = (D::TABSZ + 63) / 64, CH = 8;
+    constexpr int NTAB = (D::TABSZ + 63) / 64;
     double tabv[NTAB];
 #pragma unroll
     for (int t = 0; t < NTAB; t++)
       tabv[t] = (lane + 64 * t < D::TABSZ) ? reinterpret_cast<const double*>(&d_lgl_tab[D::TAB])[lane + 64 * t] : 0.0;
-    if constexpr (!ASSET_RES_SLOT_DMA) {
-      const int total = gcount * D::WSLOTD;
-      for (int e0 = 0; e0 < total; e0 += 64 * CH) {       // CH requests in flight per lane
-        double v[CH];
-#pragma unroll
-        for (int t = 0; t < CH; t++) {
-          const int e = e0 + lane + 64 * t, g = e / D::WSLOTD, r = e - g * D::WSLOTD;
-          v[t] = (e < total) ? a.work[size_t(seg0 + g) * D::WSLOT + r] : 0.0;
-        }
-#pragma unroll
-        for (int t = 0; t < CH; t++) {
-          const int e = e0 + lane + 64 * t, g = e / D::WSLOTD, r = e - g * D::WSLOTD;
-          if (e < total) slots[g * SLOT + r] = v[t];
-        }
-      }
-    }
 #pragma unroll
     for (int t = 0; t < NTAB; t++)
       if (lane + 64 * t < D::TABSZ) tabL[lane + 64 * t] = tabv[t];
@@ -957,22 +893,11 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   }
   pair_sync();
   RTS();
-  // HALVED (round 5, OFF): in a pair BOTH waves run the interior phase and the cardinal second-derivative phase, each for one half of the
-  // outputs (res_interior / res_cardinal_second, HALF) -- instead of one wave running the phase while its partner waits at the barrier.
-  // Built, parity-green, and slower: Reentry-LGL7 x 10 000 29.9-30.2 against 28.8-28.9 us, x 5 000 21.9 / 20.6.  The halves recompute what
-  // they share (2 x 700 instructions for 930), and the wave that used to wait shared its SIMD with ANOTHER workgroup's phase: the
-  // ODE stage is bound by what a SIMD issues, which the pair form had already halved, not by the depth of one wave's chain.
-#ifndef ASSET_RES_HALVES
-#define ASSET_RES_HALVES 0
-#endif
-  constexpr bool HALVED = ASSET_RES_HALVES && PAIR && LEVEL >= 2 && Ode::HALVES == 2 && !EARLYC;
+  // (Round 5 also ran the interior phase and the cardinal second-derivative phase in HALVES -- both waves of a pair, each one half of
+  //  the outputs, generated bodies fjgh_half<H>: parity-green and slower, Reentry-LGL7 x 10 000 29.9-30.2 against 28.8-28.9 us: the
+  //  halves recompute what they share, and the wave that used to wait shared its SIMD with ANOTHER workgroup's phase.  Removed.)
   if constexpr (!D::TRAP) {
-    if constexpr (HALVED) {
-      if (pj < K && pg < gall) {          // P2, both waves
-        if (roleB) res_interior<Ode, D, LEVEL, 0>(pslot(pg), pj, &tab, a.L != nullptr);
-        else res_interior<Ode, D, LEVEL, 1>(pslot(pg), pj, &tab, a.L != nullptr);
-      }
-    } else if (roleB && pj < K && pg < gall) {   // P2
+    if (roleB && pj < K && pg < gall) {   // P2
       const int g = pg, i = pj;
       res_interior<Ode, D, LEVEL>(pslot(g), i, &tab, a.L != nullptr);
     }
@@ -980,15 +905,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   }
   RTS();
   if constexpr (LEVEL >= 2) {
-    if constexpr (HALVED) {
-      if (pj < CS && pg < gall) {         // P3, both waves
-        if (roleA) res_cardinal_second<Ode, D, 0>(pslot(pg), pj, &tab);
-        else res_cardinal_second<Ode, D, 1>(pslot(pg), pj, &tab);
-      }
-    } else if constexpr (EARLYC) {
+    if constexpr (EARLYC) {
       // P3 by wave A -- and meanwhile wave B forms and stores the rows of [J ; g^T] of the whole group (defect_rowdpp.h, MODE 1)
       if (roleA) {
-        if (pj < CS && pg < gall) res_cardinal_second<Ode, D, -1, true>(pslot(pg), pj, &tab);
+        if (pj < CS && pg < gall) res_cardinal_second<Ode, D, true>(pslot(pg), pj, &tab);
         // ... and says so -- a flag in wave 0's region, not a barrier: wave A goes on to its H passes, wave B looks at the flag when
         // its C passes are done (LDS instructions of a wave execute in issue order: whoever sees the flag sees the phase's results)
         wave_lds_sync();
@@ -1069,21 +989,17 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   // -1 on column T, +1 on column TF of the lane's column 16t + lr: the direction d = e_TF - e_T of the rank-2 update and the
   // sign of the time-column terms
   auto tsA = [&](int t) -> double { return (16 * t + lr == T) ? -1.0 : ((16 * t + lr == TF) ? 1.0 : 0.0); };
-  lds_double* const HT = xtra + R::x_HT;
   lds_double* const CL = xtra + R::x_CL;
   lds_double* const WL = xtra + R::x_WL;
   constexpr int NFRAG = (D::NTH + TI * TJ) * 4;
 
   const int nb_kkt = (!ASM && a.KKT) ? int(D::KSTRIDE * 8) : 0, nb_fx = a.FX ? OR * 8 : 0, nb_agx = (a.AGX && a.L) ? IR * 8 : 0;
   const int nb_h = (LEVEL >= 2 || !(a.flags & 1)) ? nb_kkt : 0;   // (Jacobian kinds: zeros, unless the caller never reads them)
-#ifndef ASSET_RES_LDS_ORDER
-#define ASSET_RES_LDS_ORDER 1
-#endif
-  auto seg_lds_sync = [&]() { if constexpr (ASSET_RES_LDS_ORDER) wave_lds_order(); else wave_lds_sync(); };   // (hand-offs inside a segment: one wave)
+  auto seg_lds_sync = [&]() { wave_lds_order(); };   // (hand-offs inside a segment, one wave: an ordering, not a wait -- defect_dims.h)
   auto segment = [&](const int g) __attribute__((always_inline)) {
     const lds_double* S = slots + g * SLOT;
     const size_t seg = size_t(__builtin_amdgcn_readfirstlane(seg0 + g));   // (wave-uniform, and the compiler must know: buffer resources)
-    if constexpr (GIVEN && ASSET_RES_SLOT_DMA) {
+    if constexpr (GIVEN) {
       // this segment's slot: asked for at the top of the segment before -- every store of that segment was issued behind it, and
       // memory operations complete in the order of issue -- or, the first one, just now.  NST store instructions per segment,
       // none under a branch (BSTORE): vmcnt(NST) is "the slot has landed" without a wait for the stores themselves.
@@ -1095,10 +1011,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       else if (LOOP && grp + 1 < ngroups && g >= 1) { slot_dma(0, seg0 + gcount); slot0_ahead = true; }
     }
     const double h = S[D::w_z + TF] - S[D::w_z + T];
-#ifndef ASSET_RES_FASTHT
-#define ASSET_RES_FASTHT 1
-#endif
-    const double rh = ASSET_RES_FASTHT ? 1.0 / h : 0.0;   // (one division per segment, off the tile columns' critical chain)
+    const double rh = 1.0 / h;   // (one division per segment, off the tile columns' critical chain)
     double* const kkt_dst = ASM ? a.values : (a.KKT ? a.KKT + seg * size_t(D::KSTRIDE) : nullptr);
     // lane-masked block stores as raw buffer stores whose masked lanes carry an out-of-range offset (dropped by the bounds check):
     // no exec-mask region, no basic-block boundary per store group; an output the caller did not ask for is a resource of zero
@@ -1157,7 +1070,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         cl += tab.C[i][j] * l;
         wl += tab.D[i][j] * l;
       }
-      if constexpr (ASSET_RES_FASTHT && R::BSTORE) {
+      if constexpr (R::BSTORE) {
         xtra[own ? R::x_CL + lane : R::x_HT + (lane & 15)] = cl;      // (sixteen dead cells, one per lane of a write's 16-lane group:
         xtra[own ? R::x_WL + lane : R::x_HT + (lane & 15)] = wl;      //  forty lanes on ONE cell were forty bank-conflict cycles per write)
       } else if (own) {
@@ -1256,9 +1169,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       for (int kk = 0; kk < KS; kk++)           // (LEVEL 1: no H^ -- its section of the slot holds nothing)
         ah[i][kk] = (LEVEL >= 2 || lr >= N) ? sc * S[lc.ao[kk] + i * lc.ast[kk]] : 0.0;
     }
-#ifndef ASSET_RES_PRIO
 #define ASSET_RES_PRIO (PAIR ? 0 : 1)
-#endif
     // The two waves of a SIMD are workgroups b and b + gridDim/2; left alone the older one wins every arbitration and ends
     // ~5 us before the younger one (36.8 against 31.5 us), i.e. the kernel ends 2.5 us later than it would with both ending
     // together.  ASSET_RES_PRIO 1: the younger wave runs its products at a higher priority than the older one -- the looped
@@ -1443,8 +1354,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           d4 acc = accJ[rt][jt];
 #pragma unroll
           for (int v = 0; v < 4; v++) {
-            if constexpr (ASSET_RES_FASTHT) acc[v] += Tr[4 * v * n];   // (a lane without a defect row has il = rl = 0: a valid address, and
-            else acc[v] += (16 * jt + lr < OR) ? Tr[4 * v * n] : 0.0;    //  what it adds up is never stored -- no load under an exec mask, no select)
+            acc[v] += Tr[4 * v * n];   // (a lane without a defect row has il = rl = 0: a valid address, and what it adds up is never
+                                       //  stored -- no load under an exec mask, no select)
           }
           store_J_tile(rt, jt, acc);
         }
@@ -1467,19 +1378,14 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
           }
         }
         if constexpr (LEVEL >= 2) {
-          if constexpr (ASSET_RES_FASTHT) htv = fma(gs, rh, hi);
-          else if (lk == R::lkN) HT[c] = hi + gs / h;                     // (padding columns: 0 + 0)
+          htv = fma(gs, rh, hi);
         }
         bst(o_agx, unsigned(c), lk == R::lkN && (CFULL || c < IR), fma(h, hi + agJ[rt], fma(tsA(rt), sls, tabL[lc.clo[rt]])));
       }
       if constexpr (LEVEL >= 2) {
-        double ht;
-        if constexpr (ASSET_RES_FASTHT) {               // the column's value from its lk == lkN lane: one cross-lane read instead of an
-          ht = row_to_rows01<R::lkN>(htv, lr);          //  LDS write, a wait and a read (only lanes lk = 0, 1 use it)
-        } else {
-          wave_lds_sync();
-          ht = HT[16 * rt + lr];
-        }
+        // the column's value from its lk == lkN lane: one cross-lane read instead of an LDS write, a wait and a read (only lanes
+        // lk = 0, 1 use it)
+        const double ht = row_to_rows01<R::lkN>(htv, lr);
         // k-step of the rank-2 product: lanes lk == 0 carry (d, HT), lanes lk == 1 (HT, d), the others zeros -- as arithmetic with
         // the lane's 0 / 1 weights (nested selects on doubles came out of the compiler as branches)
         const double w0 = lk == 0 ? 1.0 : 0.0, w1 = lk == 1 ? 1.0 : 0.0, ts = tsA(rt);

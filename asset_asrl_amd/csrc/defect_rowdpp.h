@@ -147,38 +147,10 @@ __device__ void rd_lane_setup(unsigned int* out, int rec) {
   for (int k = 0; k < X::NQH * 4; k++) out[(k >> 2) * (X::NRECH * 4) + rec * 4 + (k & 3)] = u.w[k];
 }
 
-// Shapes of the one-launch kernel of heavy right-hand sides (defect_ures.h): its slot is the ODE results, a zero cell, FB and h
-// (measured, round 5 -- profiles/r5_ures_timeline.txt: 1 000 Betts-LGL5 segments 31.6 us against 20.1 us of the unit kernels + dense part,
-//  5 000 Betts-LGL7 segments 93.5 against 90.0: a workgroup's waves run the chain values -> interior unit -> cardinal unit -> pass two to a
-//  SIMD at 11-13 cycles per instruction with 8-12 lanes in use, the unit kernels one wave per SIMD of the whole device at 5 with 42.  Built
-//  only with -DASSET_URES=1; the launcher takes it whenever the table holds it.)
-#ifndef ASSET_URES
-#define ASSET_URES 0
-#endif
-
-template <class Ode, class D>
-struct UResDims {
-  static constexpr int CS = D::CS, K = D::K, n = D::n;
-  using X = RdDims<Ode, D>;
-  static constexpr int NWV = 8;                                  // waves per workgroup: two per SIMD, 256 registers each
-  static constexpr int s_Z0 = D::WSLOTD;                         // a cell that holds zero (structural zeros of the records)
-  static constexpr int s_FB = D::WSLOTD + 1;                     // FB_i[a] = sum_j B_ij f_j[a], then h = t_f - t_0
-  static constexpr int SLOT = (s_FB + K * n + 1) | 1;            // odd: conflict-free across segments
-  static constexpr int G_FIT = (160 * 1024 / 8 - D::TABSZ - 8) / SLOT;
-  static constexpr int GMAX = (64 / CS) < G_FIT ? (64 / CS) : G_FIT;   // lane <-> (cardinal point, segment)
-// (the dense part alone in this form, behind the unit kernels -- lgl_ures_dense_kernel: Betts-LGL5 x 1 000 / 2 000 / 5 000 segments 28.2 / 40.2 /
-//  69.6 us against 20.2 / 33.9 / 62.4 with the tile form of defect_resident.h, Betts-LGL7 x 1 000 / 5 000 43.5 / 112.8 against 26.7 / 89.9: a pass of
-//  this shape -- N = 12, three row groups of which a quarter of the lanes idle, 34-45 block columns -- is ~ 1 300-1 500 instructions per
-//  segment where the matrix form spends ~ 600 and 50 matrix instructions.  Built only with -DASSET_URES_DENSE=1.)
-#ifndef ASSET_URES_DENSE
-#define ASSET_URES_DENSE 0
-#endif
-  static constexpr bool SHAPE_OK = Ode::NUNITS > 1 && !D::TRAP && !D::WIDE && X::RG <= 4 && X::CRG <= 4 && GMAX >= 1 && D::STAGED;
-  static constexpr bool ONE_LAUNCH = ASSET_URES && SHAPE_OK && Ode::NUNITS <= NWV;      // units and dense part in one launch
-  static constexpr bool OK = SHAPE_OK && (ASSET_URES_DENSE || ONE_LAUNCH);                 // the row records and the dense-part kernel exist
-  static constexpr long long base_bytes() { return (long long)D::TABSZ * 8; }
-  static constexpr long long slot_bytes() { return (long long)SLOT * 8; }
-};
+// (Round 5 built this dense part into a one-launch kernel of heavy right-hand sides as well -- eight-wave workgroups, units and
+//  passes in one launch, no workspace: bit-for-bit as good and slower (1 000 Betts-LGL5 segments 31.6 us against 20.1 us of the unit
+//  kernels + the tile form's dense part, 5 000 Betts-LGL7 segments 93.5 against 90.0: profiles/r5_ures_timeline.txt).  It is kept, unbuilt,
+//  in tools/attic/defect_ures.h.)
 
 // ---------------------------------------------------------------------------------------------------------------- the passes
 // Ctx: what the kernel hands over -- the workgroup's segments (slot pointer and mesh segment of group member g), the LDS copy of
@@ -205,9 +177,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
   const LglTab& ctab = d_lgl_tab[D::TAB];                           // compile-time indices: scalar loads
   const int lr = lane & 15, rs = lane >> 4;
   constexpr unsigned INVALID = 0xF0000000u;
-#ifndef ASSET_RD_NB
 #define ASSET_RD_NB 8
-#endif
   constexpr int NB = ASSET_RD_NB;                                    // block columns evaluated side by side
 
   // outputs of the workgroup's segments [seg_lo, seg_hi): one buffer resource each, offsets relative to seg_lo (an output the caller
@@ -624,11 +594,10 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
   } else {
     // the workgroup's passes in segment order -- the H passes of four segments, then their C pass(es) -- each to the wave with less to do
     // so far (cost: the instructions of a pass, tools/isa_count.py); both waves walk the same list
-    // (workgroups of more than two waves -- defect_ures.h: round robin)
     int hp = 0, cp = 0;
     while (hp < nHP || cp < nCP) {
       const bool isH = hp < nHP && (cp >= nCP || SPP * hp < SPC * (cp + 1));     // H passes up to the segments of the next C pass first
-      const int w = nwv > 2 ? (hp + cp) % nwv : ((nwv > 1 && load1 < load0) ? 1 : 0);
+      const int w = (nwv > 1 && load1 < load0) ? 1 : 0;
       (w ? load1 : load0) += isH ? (LEVEL >= 2 ? 640 : 40) : 540;
       if (w == wv) {
         RDTS();

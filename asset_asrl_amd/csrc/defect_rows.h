@@ -33,9 +33,7 @@
 
 namespace asset_hip {
 
-#ifndef ASSET_EXP_ROWS
 #define ASSET_EXP_ROWS 0             // (experiments: bit 0 -- no H columns, bit 1 -- no defect-row columns, bit 2 -- no row preparation)
-#endif
 
 template <class D>
 struct RowsDims {
@@ -421,9 +419,7 @@ __device__ __forceinline__ void lgl_rows_body(const EvalArgs& a, const double* _
       // of its dfdy column instead of K (and K more to combine them) -- K n FMAs per node bought, ~ 2 K nnz(dfdy_j) saved
       // -- OFF: its n doubles are the registers the kernel does not have (512 of 512 and 340 bytes of scratch per lane instead of 482
       // and none; a scratch reload behind block stores waits for them all: 12 500 32-state segments 1.78 ms against 1.08 ms)
-#ifndef ASSET_ROWS_NODE_BM
 #define ASSET_ROWS_NODE_BM 0
-#endif
       double BMn[ASSET_ROWS_NODE_BM ? n : 1];
       static_for<IR>([&](auto Ct) {
         constexpr int c = decltype(Ct)::value;

@@ -138,9 +138,7 @@ __device__ __forceinline__ void lgl_ode_units_body(const EvalArgs& a, int gp) {
 #if defined(ASSET_WALLCLOCK)   // (tuning builds, with ASSET_HIP_SKIP_DENSE: 100 MHz stamps of every workgroup, left in AGX)
   double* const wstamp = a.AGX + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * 8;
   int wn = 0;
-#ifndef ASSET_WALLCLOCK_PHASE
 #define ASSET_WALLCLOCK_PHASE 0      // (two launches write the same cells: which one is kept)
-#endif
 #define UTS() do { if (lane == 0 && a.AGX && PHASE == ASSET_WALLCLOCK_PHASE) wstamp[wn] = double(wall_clock64()); wn++; } while (0)
 #else
 #define UTS() do {} while (0)

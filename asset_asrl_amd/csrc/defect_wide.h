@@ -111,9 +111,7 @@ struct WideSparsity {
   static constexpr HTable HT{};
 };
 
-#ifndef ASSET_WIDE_WGS
 #define ASSET_WIDE_WGS 2              // workgroups per CU when two working sets fit its LDS (halves the register budget)
-#endif
 template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM>
 __device__ __forceinline__ void lgl_wide_dense_body(const EvalArgs& a) {
   using D = Dims<Ode, SCH, BLOCKED>;

@@ -60,15 +60,9 @@ struct FuncIn {
 // are one contiguous range of the output -- with coalesced stores.  One thread per application storing straight to its
 // block puts the 64 lanes of every store instruction on 64 different cache lines (a control-spline block is 2.5 KB:
 // 10 000 of them took 21 us).  As many applications (a power of two, at least 4) as fit 40 KiB of LDS: four such workgroups per CU.
-#ifndef ASSET_FUNC_LDS_BUDGET
 #define ASSET_FUNC_LDS_BUDGET (40 * 1024 - 64)   // four such workgroups per CU (one per SIMD)
-#endif
-#ifndef ASSET_FUNC_COPY_UNROLL
 #define ASSET_FUNC_COPY_UNROLL 8
-#endif
-#ifndef ASSET_FUNC_WAVES
 #define ASSET_FUNC_WAVES 1
-#endif
 template <class F>
 struct FuncStage {
   using D = FuncDims<F>;

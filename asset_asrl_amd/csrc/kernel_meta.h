@@ -9,7 +9,6 @@
 #include "defect_resident.h"
 #include "defect_rows.h"
 #include "defect_units.h"
-#include "defect_ures.h"
 #include "defect_wide.h"
 #include "func_kernels.h"
 
@@ -38,8 +37,6 @@ enum MetaField {
   MF_RES_NWV,                                       // resident kernel: waves per workgroup (2: the pair form, ResDims::PAIR)
   MF_RES_LOOP_NWV,                                  // ... of its looped level-2 block kernel (2 with the row-wise dense part)
   MF_RES_ASM,                                       // ... 1: its assembled kinds exist (0: shapes of two row tiles with the row-wise dense part)
-  MF_URES_GMAX, MF_URES_BASE_BYTES, MF_URES_SLOT_BYTES,   // heavy right-hand sides, eight-wave workgroups (defect_ures.h): segments per group at most (0: none), LDS
-  MF_URES_ONE,                                      // ... 1: units and dense part in one launch is built too (ASSET_URES)
   MF_KL, MF_KSTRIDE,                                // layout of the KKT blocks the kernels write (defect_dims.h: Dims::KL) and their stride in doubles (0: NKKT)
   MF_COUNT
 };
@@ -73,8 +70,7 @@ struct LglMeta {
       ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>(),
       ResDims<D>::WPS, ResDims<D>::GIVEN_OK ? ResDims<D>::GR : 0,
       RowsDims<D>::OK ? (long long)RowsDims<D>::lds_bytes() : 0, ResDims<D>::NWV, ResDims<D>::LOOP_PAIR ? 2 : 1, ResDims<D>::ASM_OK ? 1 : 0,
-      UResDims<Ode, D>::OK ? UResDims<Ode, D>::GMAX : 0, UResDims<Ode, D>::base_bytes(), UResDims<Ode, D>::slot_bytes(),
-      UResDims<Ode, D>::ONE_LAUNCH ? 1 : 0, D::KL, D::KSTRIDE};
+      D::KL, D::KSTRIDE};
 };
 
 template <class F>

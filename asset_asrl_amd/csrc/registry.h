@@ -128,9 +128,7 @@ constexpr int K_ROWS = 58;     // wide shapes: dense stage by output rows, no ma
 constexpr int K_ROWS1 = 59;    // ... the Jacobian kinds
 constexpr int K_UNITS4 = 60;   // heavy right-hand sides: interior and cardinal units in one launch (defect_units.h, PHASE 4)
 constexpr int K_RESLP = 61;   // resident kernel, looped, level 2, blocks, as two-wave workgroups (row-wise dense part: defect_rowdpp.h)
-constexpr int K_URES = 62;    // heavy right-hand sides, level 2, blocks: units and dense part in one launch (defect_ures.h)
-constexpr int K_URESD = 63;   // ... its dense part alone, behind the unit kernels
-constexpr int K_COUNT = 64;
+constexpr int K_COUNT = 62;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -192,10 +190,8 @@ struct Registrar {
 #endif
 
 // ---- the launcher ---------------------------------------------------------------------------------------------------
-#ifndef ASSET_UNITS_ONE_LAUNCH_ROUNDS
 #define ASSET_UNITS_ONE_LAUNCH_ROUNDS 1000   // heavy ODEs: the one-launch unit stage ALWAYS (the limit, in rounds of the SIMDs, is beyond every mesh) -- measured faster at every size
                                             // tried (Betts-LGL5 x 1 000: 30.3 against 41.5 us, x 10 000: 191.7 / 200.0; Betts-LGL7 x 5 000: 145.1 / 151.1)
-#endif
 // Dispatch knobs of the measurement scripts (tools/): read ONLY when the process opts in with ASSET_HIP_TUNING=1, so that a
 // stray variable in a production environment cannot change which kernels run.  With the opt-in, every knob that takes effect is
 // reported once on stderr.
@@ -336,19 +332,6 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
           return klaunch(t.k[K_LGL(2, 3, a.kmap != nullptr)], dim3(grid_b), dim3(64), bytes_dense, st, kargs);
       }
       static const bool no_units = tuning_env("ASSET_HIP_NO_UNITS") != nullptr;                               // tuning only
-      static const bool no_ures = tuning_env("ASSET_HIP_NO_URES") != nullptr;                                 // tuning only
-      if (m[MF_URES_GMAX] > 0 && m[MF_URES_ONE] && !no_units && !no_ures && !skip_dense && !a.kmap && a.lane_consts_res && t.k[K_URES]) {
-        // heavy right-hand side, blocks: units and dense part in ONE launch, a group of G segments per eight-wave workgroup
-        // (defect_ures.h).  G: the fewest rounds of the device's CUs, then the groups as even as that allows
-        const int gmax = int(m[MF_URES_GMAX]);
-        const int rounds = (a.nseg + cus * gmax - 1) / (cus * gmax);
-        int G = (a.nseg + cus * rounds - 1) / (cus * rounds);
-        G = G < 1 ? 1 : (G > gmax ? gmax : G);
-        const int ngrp = (a.nseg + G - 1) / G;
-        const size_t bytes = size_t(m[MF_URES_BASE_BYTES]) + size_t(G) * size_t(m[MF_URES_SLOT_BYTES]);
-        void* uargs[] = {&args, &G};
-        return klaunch(t.k[K_URES], dim3(ngrp < cus ? ngrp : cus), dim3(512), bytes, st, uargs);
-      }
       if (m[MF_NUNITS] > 1 && !no_units) {
         // heavy right-hand side: the ODE stage runs one wave per output unit (defect_units.h)
         const int nunits = int(m[MF_NUNITS]), gpmax = 64 / int(m[MF_CS]);
@@ -388,19 +371,6 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         return e;
       }
       if (skip_dense) return hipSuccess;
-      static const bool no_uresd = tuning_env("ASSET_HIP_NO_URES_DENSE") != nullptr;                          // tuning only
-      if (m[MF_NUNITS] > 1 && m[MF_URES_GMAX] > 0 && !no_units && !no_uresd && !a.kmap && a.lane_consts_res && t.k[K_URESD]) {
-        // the dense part by output rows over the slots the units wrote: eight-wave workgroups, a group of G segments each
-        // (defect_ures.h) -- the fewest rounds of the device's CUs, then the groups as even as that allows
-        const int gmax = int(m[MF_URES_GMAX]);
-        const int rounds = (a.nseg + cus * gmax - 1) / (cus * gmax);
-        int G = (a.nseg + cus * rounds - 1) / (cus * rounds);
-        G = G < 1 ? 1 : (G > gmax ? gmax : G);
-        const int ngrp = (a.nseg + G - 1) / G;
-        const size_t bytes = size_t(m[MF_URES_BASE_BYTES]) + size_t(G) * size_t(m[MF_URES_SLOT_BYTES]);
-        void* uargs[] = {&args, &G};
-        return klaunch(t.k[K_URESD], dim3(ngrp < cus ? ngrp : cus), dim3(512), bytes, st, uargs);
-      }
       static const bool no_resd = tuning_env("ASSET_HIP_NO_RESIDENT") != nullptr;                             // tuning only
       if (m[MF_RESD_GR] > 0 && !no_resd && a.lane_consts_res && t.k[K_RESD(a.kmap != nullptr)]) {
         const int waves = cus * 4 * int(m[MF_RES_WPS]);   // dense part of the resident kernel over the slots the units wrote
@@ -518,11 +488,6 @@ const KernelTable* lgl_static_table() {
       r.k[K_UNITS1].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 1>);
       r.k[K_UNITSJ].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 3>);
       r.k[K_UNITS4].host = ASSET_KPTR(lgl_ode_units_kernel<Ode, SCH, BLOCKED, 4>);
-      if constexpr (UResDims<Ode, D>::OK) {
-        if constexpr (UResDims<Ode, D>::ONE_LAUNCH) r.k[K_URES].host = ASSET_KPTR(lgl_ures_kernel<Ode, SCH, BLOCKED>);
-        r.k[K_URESD].host = ASSET_KPTR(lgl_ures_dense_kernel<Ode, SCH, BLOCKED>);
-        r.k[K_RES_SETUP].host = ASSET_KPTR(res_lane_setup_kernel<Ode, SCH, BLOCKED>);
-      }
     }
     r.k[K_ADJGRAD].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED, true>);
     r.k[K_VALUE].host = ASSET_KPTR(lgl_adjgrad_kernel<Ode, SCH, BLOCKED, false>);
@@ -615,8 +580,6 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
   if (slot == K_UNITS1) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 1>";
   if (slot == K_UNITSJ) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 3>";
   if (slot == K_UNITS4) return "asset_hip::lgl_ode_units_kernel<" + lgl + ", 4>";
-  if (slot == K_URES) return "asset_hip::lgl_ures_kernel<" + lgl + ">";
-  if (slot == K_URESD) return "asset_hip::lgl_ures_dense_kernel<" + lgl + ">";
   if (slot == K_ADJGRAD) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ", true>";
   if (slot == K_VALUE) return "asset_hip::lgl_adjgrad_kernel<" + lgl + ", false>";
   if (slot == K_MESH_YVEC) return "asset_hip::mesh_yvec_kernel<" + lgl + ">";

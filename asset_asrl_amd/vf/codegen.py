@@ -40,6 +40,7 @@ class OdeDerivatives:
     J: List[List[Node]]      # [n][N]
     g: List[Node]            # [N]
     H: List[List[Node]]      # [N][N], only j<=i filled (lower), mirrored on request
+    chain_rule = None        # how the derivatives were formed: {"form": "flat" | "block", "ops_flat": ..., "ops_block": ...}
 
     @property
     def nin(self) -> int:
@@ -66,7 +67,297 @@ def differentiate_function(name: str, func: VectorFunction) -> OdeDerivatives:
     return differentiate(name, func, func.ORows(), func.IRows() - func.ORows() - 1, 0)
 
 
+def _count_ops(roots) -> int:
+    return sum(1 for n in topo_order(roots) if n.args)
+
+
+def _differentiate_flat(f, ys, lams):
+    """Every input direction through the whole (flattened) expression: forward derivatives for J, one reverse sweep of lam . f
+    for g, forward derivatives of g for H."""
+    N = len(ys)
+    J = [[G.d(fk, y) for y in ys] for fk in f]
+    g = G.grad(G.dot(lams, f), ys)
+    H = [[G.zero] * N for _ in range(N)]
+    for i in range(N):
+        for j in range(i + 1):
+            H[i][j] = G.d(g[i], ys[j])
+    return J, g, H
+
+
+def _differentiate_block(f, ys, lams):
+    """The chain rule BLOCK-wise across the cuts of the expression (ir.Graph.cut: the outputs of the inner function of a
+    composition, or what a definition marks with ``.cut()``) -- what the reference's NestedFunction does with the Jacobians and
+    adjoint Hessians of its two functions (CommonFunctions/NestedFunction.h:140-270), here on the expression graph, any depth:
+
+        J   = f_y + f_c T                                   T = dc/dy (total), f_y / f_c partials with the cuts held as variables
+        g   = s_y + T^T s_c                                 s = lam . f
+        H   = s_yy + s_yc T + (s_yc T)^T + T^T s_cc T + Hess_y( sum_m w_m c_m(y) ) |_(w = s_c held constant)
+
+    the last term by recursion on the cuts' own expressions.  The partials with respect to the cut variables are formed once and
+    shared by every input direction: with a cut of m variables under N inputs the outer expression is differentiated in m + (its
+    direct inputs) directions instead of N, and in (m + ...)^2 / 2 second-order pairs instead of N^2 / 2."""
+    from .ir import frontier
+    N = len(ys)
+    zero = G.zero
+    yidx = {y.id: i for i, y in enumerate(ys)}
+    cuts = [n for n in topo_order(f) if n.op == "cut"]            # inner ones first
+    T: Dict[int, List[Node]] = {}
+
+    def total_first(e: Node) -> List[Node]:
+        _, cs = frontier([e])
+        row = []
+        for y in ys:
+            acc = G.d(e, y)
+            for c in cs:
+                t = T[c.id][yidx[y.id]]
+                if t is zero:
+                    continue
+                pc = G.d(e, c)
+                if pc is not zero:
+                    acc = G.add(acc, G.mul(pc, t))
+            row.append(acc)
+        return row
+    for c in cuts:
+        T[c.id] = total_first(c.args[0])
+    J = [total_first(fk) for fk in f]
+
+    def low(i, j):
+        return (i, j) if i >= j else (j, i)
+
+    def grad_hess(S: Node):
+        vs, cs = frontier([S])
+        Z = vs + cs
+        ny = len(vs)
+        gb = G.grad(S, Z)                                         # partial gradient, cuts as variables
+        iy = [yidx[v.id] for v in vs]
+        g = [zero] * N
+        for a in range(ny):
+            g[iy[a]] = gb[a]
+        for b, c in enumerate(cs):
+            if gb[ny + b] is zero:
+                continue
+            for i in range(N):
+                t = T[c.id][i]
+                if t is not zero:
+                    g[i] = G.add(g[i], G.mul(gb[ny + b], t))
+        P = [[G.d(gb[a], Z[b]) if b <= a else None for b in range(len(Z))] for a in range(len(Z))]   # second partials, lower
+        H = [[zero] * N for _ in range(N)]
+        for a in range(ny):                                       # s_yy
+            for b in range(a + 1):
+                i, j = low(iy[a], iy[b])
+                H[i][j] = G.add(H[i][j], P[a][b])
+        for m, c in enumerate(cs):                                # s_yc T + (s_yc T)^T
+            Tc = T[c.id]
+            for b in range(ny):
+                pcy = P[ny + m][b]
+                if pcy is zero:
+                    continue
+                ib = iy[b]
+                for j in range(N):
+                    if Tc[j] is zero:
+                        continue
+                    term = G.mul(pcy, Tc[j])
+                    if j == ib:
+                        term = G.add(term, term)
+                    i2, j2 = low(ib, j)
+                    H[i2][j2] = G.add(H[i2][j2], term)
+        if cs:                                                    # T^T s_cc T
+            U = []
+            for m in range(len(cs)):
+                row = [zero] * N
+                for m2, c2 in enumerate(cs):
+                    pcc = P[ny + max(m, m2)][ny + min(m, m2)]
+                    if pcc is zero:
+                        continue
+                    for j in range(N):
+                        t = T[c2.id][j]
+                        if t is not zero:
+                            row[j] = G.add(row[j], G.mul(pcc, t))
+                U.append(row)
+            for i in range(N):
+                for j in range(i + 1):
+                    acc = H[i][j]
+                    for m, c in enumerate(cs):
+                        if T[c.id][i] is not zero and U[m][j] is not zero:
+                            acc = G.add(acc, G.mul(T[c.id][i], U[m][j]))
+                    H[i][j] = acc
+            # sum_m (ds/dc_m) Hess_y(c_m): the adjoint weights held constant, the cuts' own expressions one level down
+            live = [(m, c) for m, c in enumerate(cs) if gb[ny + m] is not zero]
+            if live:
+                ws = [G.frozen() for _ in live]
+                sigma = G.sum(G.mul(w, c.args[0]) for w, (_, c) in zip(ws, live))
+                _, H2 = grad_hess(sigma)
+                flat = [H2[i][j] for i in range(N) for j in range(i + 1)]
+                flat = G.replace(flat, {w.id: gb[ny + m] for w, (m, _) in zip(ws, live)})
+                k = 0
+                for i in range(N):
+                    for j in range(i + 1):
+                        H[i][j] = G.add(H[i][j], flat[k])
+                        k += 1
+        return g, H
+    g, H = grad_hess(G.dot(lams, f))
+    return J, g, H
+
+
+def _differentiate_block_local(f, ys, lams):
+    """Block-wise chain rule with LOCAL Jacobians: the cut variables are eliminated group by group from the outermost inwards, the
+    second-order terms carried in the coordinates of the variables still alive (inputs and deeper cuts) -- for a group of cuts
+    c = e(z) with local Jacobian L = de/dz (barrier partials), weights w_c and the rows / columns A_c. of the running matrix:
+        A_uv += sum_m L_mu (A_{c_m v} + sum_m' A_{c_m c_m'} L_m'v) + sum_m A_{u c_m} L_mv + Hess_z(sum_m w_m e_m)_uv ,   w_u += sum_m w_m L_mu
+    (the reference's NestedFunction rule, CommonFunctions/NestedFunction.h:140-270, applied at every level of the nest)."""
+    from .ir import frontier
+    N = len(ys)
+    zero = G.zero
+    yidx = {y.id: i for i, y in enumerate(ys)}
+    cuts = [n for n in topo_order(f) if n.op == "cut"]            # inner ones first
+    depth: Dict[int, int] = {}
+    for c in cuts:
+        _, cs = frontier([c.args[0]])
+        depth[c.id] = 1 + max([depth[x.id] for x in cs], default=0)
+    # ---- first derivatives (J): total derivatives of the cuts by local composition, then of the outputs
+    T: Dict[int, List[Node]] = {}
+
+    def total_first(e: Node) -> List[Node]:
+        _, cs = frontier([e])
+        row = []
+        for y in ys:
+            acc = G.d(e, y)
+            for c in cs:
+                t = T[c.id][yidx[y.id]]
+                if t is zero:
+                    continue
+                pc = G.d(e, c)
+                if pc is not zero:
+                    acc = G.add(acc, G.mul(pc, t))
+            row.append(acc)
+        return row
+    for c in cuts:
+        T[c.id] = total_first(c.args[0])
+    J = [total_first(fk) for fk in f]
+    # ---- second order: eliminate the cuts, outermost group first
+    S = G.dot(lams, f)
+    vs, cs = frontier([S])
+    Z = vs + cs
+    gb = G.grad(S, Z)
+    w: Dict[int, Node] = {}
+    A: Dict[int, Dict[int, Node]] = {}
+    node_of: Dict[int, Node] = {}
+
+    def addA(u: Node, v: Node, val: Node):
+        if val is zero:
+            return
+        node_of[u.id], node_of[v.id] = u, v
+        row = A.setdefault(u.id, {})
+        row[v.id] = G.add(row.get(v.id, zero), val)
+        if u.id != v.id:
+            row2 = A.setdefault(v.id, {})
+            row2[u.id] = row[v.id]
+
+    def addw(u: Node, val: Node):
+        if val is zero:
+            return
+        node_of[u.id] = u
+        w[u.id] = G.add(w.get(u.id, zero), val)
+    for a, z in enumerate(Z):
+        addw(z, gb[a])
+        for b in range(a + 1):
+            addA(z, Z[b], G.d(gb[a], Z[b]))
+    by_depth: Dict[int, List[Node]] = {}
+    for c in cuts:
+        by_depth.setdefault(depth[c.id], []).append(c)
+    for dep in sorted(by_depth, reverse=True):
+        grp = [c for c in by_depth[dep] if c.id in w or c.id in A]
+        if not grp:
+            continue
+        gids = {c.id for c in grp}
+        es = [c.args[0] for c in grp]
+        zv, zc = frontier(es)
+        Zg = zv + zc
+        L = [[G.d(e, z) for z in Zg] for e in es]                # local Jacobian (barrier partials)
+        # Hess_z( sum_m w_m e_m ), the weights frozen
+        live = [m for m, c in enumerate(grp) if w.get(c.id, zero) is not zero]
+        Hs = {}
+        if live:
+            fr = [G.frozen() for _ in live]
+            sigma = G.sum(G.mul(x, es[m]) for x, m in zip(fr, live))
+            gs = G.grad(sigma, Zg)
+            flat = [G.d(gs[a], Zg[b]) for a in range(len(Zg)) for b in range(a + 1)]
+            flat = G.replace(flat, {x.id: w[grp[m].id] for x, m in zip(fr, live)})
+            k = 0
+            for a in range(len(Zg)):
+                for b in range(a + 1):
+                    Hs[(a, b)] = flat[k]
+                    k += 1
+        # rows of A that belong to the group
+        Arow = {c.id: dict(A.get(c.id, {})) for c in grp}
+        # C[m][b] = sum_m' A_{c_m c_m'} L[m'][b]
+        Cm = []
+        for m, c in enumerate(grp):
+            row = [zero] * len(Zg)
+            for m2, c2 in enumerate(grp):
+                acc = Arow[c.id].get(c2.id, zero)
+                if acc is zero:
+                    continue
+                for b in range(len(Zg)):
+                    if L[m2][b] is not zero:
+                        row[b] = G.add(row[b], G.mul(acc, L[m2][b]))
+            Cm.append(row)
+        # drop the group from A and w
+        wg = {c.id: w.pop(c.id, zero) for c in grp}
+        for c in grp:
+            A.pop(c.id, None)
+        for r in A.values():
+            for cid in gids:
+                r.pop(cid, None)
+        # gradient
+        for m, c in enumerate(grp):
+            if wg[c.id] is zero:
+                continue
+            for b, z in enumerate(Zg):
+                if L[m][b] is not zero:
+                    addw(z, G.mul(wg[c.id], L[m][b]))
+        # second order: pairs inside Zg
+        for a in range(len(Zg)):
+            for b in range(a + 1):
+                acc = Hs.get((a, b), zero)
+                for m, c in enumerate(grp):
+                    # L[m][a] * (A[c_m][z_b] + C[m][b]) + A[z_a][c_m] * L[m][b]
+                    d1 = G.add(Arow[c.id].get(Zg[b].id, zero), Cm[m][b])
+                    if L[m][a] is not zero and d1 is not zero:
+                        acc = G.add(acc, G.mul(L[m][a], d1))
+                    d2 = Arow[c.id].get(Zg[a].id, zero)
+                    if d2 is not zero and L[m][b] is not zero:
+                        acc = G.add(acc, G.mul(d2, L[m][b]))
+                addA(Zg[a], Zg[b], acc)
+        # ... and pairs (z in Zg, x alive outside Zg and outside the group)
+        zg_ids = {z.id for z in Zg}
+        others = set()
+        for c in grp:
+            others |= {xid for xid in Arow[c.id] if xid not in gids and xid not in zg_ids}
+        for xid in others:
+            x = node_of[xid]
+            for a, z in enumerate(Zg):
+                acc = zero
+                for m, c in enumerate(grp):
+                    v = Arow[c.id].get(xid, zero)
+                    if v is not zero and L[m][a] is not zero:
+                        acc = G.add(acc, G.mul(L[m][a], v))
+                addA(z, x, acc)
+    g = [w.get(y.id, zero) for y in ys]
+    H = [[zero] * N for _ in range(N)]
+    for i in range(N):
+        for j in range(i + 1):
+            H[i][j] = A.get(ys[i].id, {}).get(ys[j].id, zero)
+    return J, g, H
+
+
+BLOCK_CHAIN_RULE = os.environ.get("ASSET_BLOCK_CHAIN_RULE", "1") == "1"
+
+
 def differentiate(name: str, ode: VectorFunction, xv: int, uv: int, pv: int) -> OdeDerivatives:
+    """f, J, g, H of an ODE right-hand side (or a plain function).  An expression with cuts (ir.Graph.cut -- compositions
+    ``F(G)``, ``.cut()``) is differentiated twice, flattened and block-wise across its cuts, and the form with fewer operations in the
+    value + Jacobian + adjoint-gradient + adjoint-Hessian body is kept; what is returned holds no cuts."""
     N = xv + 1 + uv + pv
     if ode.IRows() != N:
         raise ValueError(f"ODE input size {ode.IRows()} != XV+1+UV+PV = {N}")
@@ -74,15 +365,40 @@ def differentiate(name: str, ode: VectorFunction, xv: int, uv: int, pv: int) -> 
         raise ValueError(f"ODE output size {ode.ORows()} != XV = {xv}")
     ys = [G.var(i) for i in range(N)]
     lams = [G.lam(k) for k in range(xv)]
-    f = list(ode.outs)
-    J = [[G.d(fk, y) for y in ys] for fk in f]
-    s = G.dot(lams, f)
-    g = G.grad(s, ys)
-    H = [[G.zero] * N for _ in range(N)]
-    for i in range(N):
-        for j in range(i + 1):
-            H[i][j] = G.d(g[i], ys[j])
-    return OdeDerivatives(name, xv, uv, pv, f, J, g, H)
+    f_cut = list(ode.outs)
+    f = G.strip_cuts(f_cut)
+
+    def pack(J, g, H):
+        return f + [e for r in J for e in r] + list(g) + [H[i][j] for i in range(N) for j in range(i + 1)]
+
+    def unpack(flat):
+        k = len(f)
+        J = [flat[k + r * N:k + (r + 1) * N] for r in range(xv)]
+        k += xv * N
+        g = flat[k:k + N]
+        k += N
+        H = [[G.zero] * N for _ in range(N)]
+        for i in range(N):
+            for j in range(i + 1):
+                H[i][j] = flat[k]
+                k += 1
+        return J, g, H
+    J, g, H = _differentiate_flat(f, ys, lams)
+    d = OdeDerivatives(name, xv, uv, pv, f, J, g, H)
+    d.chain_rule = {"form": "flat", "ops_flat": _count_ops(pack(J, g, H))}
+    if BLOCK_CHAIN_RULE and any(n.op == "cut" for n in topo_order(f_cut)):
+        best = ("flat", d.chain_rule["ops_flat"], (J, g, H))
+        for form, fn in (("block", _differentiate_block), ("block_local", _differentiate_block_local)):
+            Jb, gb, Hb = unpack(G.strip_cuts(f_cut + pack(*fn(f_cut, ys, lams))[len(f):]))
+            ops = _count_ops(pack(Jb, gb, Hb))
+            d.chain_rule["ops_" + form] = ops
+            if ops < best[1]:
+                best = (form, ops, (Jb, gb, Hb))
+        if best[0] != "flat":
+            cr = dict(d.chain_rule, form=best[0])
+            d = OdeDerivatives(name, xv, uv, pv, f, *best[2])
+            d.chain_rule = cr
+    return d
 
 
 # --------------------------------------------------------------------------- printing
@@ -481,25 +797,12 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
         # evaluates a cardinal unit forms it itself instead of waiting for the interior units of a launch before
         # (csrc/defect_units.h, PHASE 4)
         body("gx", [(f"out.g({i}, {{}});", d.g[i]) for i in range(n)], q=UNIT_QUAL, level_order=UNIT_LEVEL_ORDER)
-    # ---- halves (round 5): the level-2 outputs of a body that is NOT split into units, in two sets of about equal cost -- by input
-    #      direction, like the units: {J[:, k], g[k], H[i >= k, k]}, the value outputs with the first set; each half recomputes the
-    #      forward values it needs.  The two waves of a pair workgroup run the halves of an ODE phase side by side (csrc/
-    #      defect_resident.h): the interior phase of the resident kernel is a lone wave's chain of ~ 930 instructions otherwise, the
-    #      cardinal second-derivative phase one of ~ 510, and nothing can be stored before they end.
-    halves = None if units else plan_halves(d, outputs(2))
-    o.append(f"  static constexpr int HALVES = {2 if halves else 1};   // bodies fjgh_half<H> / fjgh_load_half<H> (1: none)")
+    # (round 5 also emitted the level-2 body in two HALVES for the pair workgroups of the resident kernel; measured slower and
+    #  removed in round 6 -- DESIGN.md 4.0b)
     if split:
         two_parts("fjgh", False)
     else:
         body("fjgh", outputs(2))
-    if halves:
-        for hx, outs_h in enumerate(halves):
-            body(f"fjgh_half{hx}_", outs_h)
-            body(f"fjgh_load_half{hx}_", outs_h, use_saved=True)
-        for nm in ("fjgh_half", "fjgh_load_half"):
-            o.append(f"  template <int H, class In, class Out> __host__ __device__ static inline void {nm}(const In& in, Out& out) {{")
-            o.append(f"    if constexpr (H == 0) {nm}0_(in, out); else {nm}1_(in, out);")
-            o.append("  }")
     # ---- f_save / fjgh_load: the value pass stores every transcendental sub-expression of f; the second-derivative
     #      pass at the SAME point (cardinal nodes: LGLDefects.h:336 then :383-384) loads them instead of recomputing
     body("f_save", outputs(0), extra_roots=saved, extra_stmt="out.save({}, {});")
@@ -515,40 +818,6 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
 
 
 MAX_UNITS = 8
-
-
-def plan_halves(d: OdeDerivatives, outs):
-    """The level-2 outputs ([(statement format, root)] in outputs(2) order) in two sets of about equal operation count: columns
-    {J[:, k], g[k], H[i >= k, k]} dealt, heaviest first, to the set whose cost grows less; f goes with the first set.  None when a
-    set would come out empty (tiny bodies)."""
-    N, n = d.nin, d.xv
-    f_outs = outs[:n]
-    j_outs = outs[n:n + n * N]
-    g_outs = outs[n + n * N:n + n * N + N]
-    h_outs = outs[n + n * N + N:]
-    hpos, e = {}, 0
-    for i in range(N):
-        for j in range(i + 1):
-            hpos[(i, j)] = e
-            e += 1
-
-    def cost(group):
-        return sum(1 for x in topo_order(lower_reciprocals([r for _, r in group])) if x.args)
-
-    cols = []
-    for k in range(N):
-        grp = [j_outs[r * N + k] for r in range(n)] + [g_outs[k]] + [h_outs[hpos[(i, k)]] for i in range(k, N)]
-        cols.append((cost(grp), k, grp))
-    A, B = list(f_outs), []
-    for c, k, grp in sorted(cols, key=lambda t: (-t[0], t[1])):
-        ca, cb = cost(A + grp), cost(B + grp)
-        if (ca, len(A)) <= (cb, len(B)):
-            A = A + grp
-        else:
-            B = B + grp
-    if len(B) == 0 or cost(B) * 4 < cost(A):
-        return None
-    return [A, B]
 
 
 def plan_units(d: OdeDerivatives, outs) -> List[list]:

@@ -119,8 +119,17 @@ class VectorFunction:
         """self(inner(x)) -- the reference's ``F.eval(G)`` / ``F(G)``."""
         if inner.ORows() != self._irows:
             raise ValueError("Inner function output size does not match outer input size")
-        outs = G.substitute(self.outs, {i: n for i, n in enumerate(inner.outs)})
+        # (the inner function's outputs become cut variables of the expression: codegen.py differentiates across them block-wise,
+        #  the reference's NestedFunction chain rule -- numerically a cut is the identity)
+        outs = G.substitute(self.outs, {i: G.cut(n) for i, n in enumerate(inner.outs)})
         return VectorFunction(inner._irows, outs)
+
+    def cut(self) -> "VectorFunction":
+        """This function's outputs as cut variables (``ir.Graph.cut``): whatever is built on top of them is differentiated
+        block-wise across them.  For an intermediate vector with FEWER components than the inputs it depends on -- a position, a
+        perturbing acceleration -- that is cheaper than differentiating the flattened expression; the derivative builder counts
+        both and keeps the cheaper form."""
+        return self._like([G.cut(n) for n in self.outs])      # (explicit: no size rule)
 
     def __call__(self, arg):
         if isinstance(arg, VectorFunction):
@@ -203,34 +212,52 @@ class VectorFunction:
         return self._map("tanh")
 
     # ---- vector algebra ------------------------------------------------------------
+    # (Measured, round 6: cutting the OPERANDS of these vector operations -- the reference's norm / normalized / cross / dot are
+    #  functions of their own, nested over whatever produced their arguments -- makes the block-wise derivative builder of
+    #  codegen.py WORSE:
+    #  the Cartesian-detour low-thrust model of round 4 is 7 792 operations flat, 6 093 with cuts at its F(G) compositions
+    #  only, 10 763 with the operands cut as well -- and 9 635 with the level-local elimination (_differentiate_block_local), still
+    #  above the flat form: on a hash-consed graph the flat derivative already shares what a fine-grained nest would share, and
+    #  every extra cut adds the products that join its two sides.  Cuts are therefore made at compositions and where a definition
+    #  says ``.cut()``.)
+    @staticmethod
+    def _operands(nodes):
+        return list(nodes)
+
     def sum(self):
         return self._like([G.sum(self.outs)])
 
     def dot(self, other):
         b = self._coerce(other, self.ORows())
-        return self._like([G.dot(self.outs, b)])
+        return self._like([G.dot(self._operands(self.outs), self._operands(b))])
 
     def squared_norm(self):
-        return self._like([G.dot(self.outs, self.outs)])
+        a = self._operands(self.outs)
+        return self._like([G.dot(a, a)])
 
     def norm(self):
-        return self._like([G.unary("sqrt", G.dot(self.outs, self.outs))])
+        a = self._operands(self.outs)
+        return self._like([G.unary("sqrt", G.dot(a, a))])
 
     def inverse_norm(self):
-        return self._like([G.div(G.one, G.unary("sqrt", G.dot(self.outs, self.outs)))])
+        a = self._operands(self.outs)
+        return self._like([G.div(G.one, G.unary("sqrt", G.dot(a, a)))])
 
     def cubed_norm(self):
-        n = G.unary("sqrt", G.dot(self.outs, self.outs))
+        a = self._operands(self.outs)
+        n = G.unary("sqrt", G.dot(a, a))
         return self._like([G.powi(n, 3)])
 
     def normalized(self):
-        n = G.unary("sqrt", G.dot(self.outs, self.outs))
-        return self._like([G.div(x, n) for x in self.outs])
+        a = self._operands(self.outs)
+        n = G.unary("sqrt", G.dot(a, a))
+        return self._like([G.div(x, n) for x in a])
 
     def _normalized_power(self, k: int):
-        n = G.unary("sqrt", G.dot(self.outs, self.outs))
+        a = self._operands(self.outs)
+        n = G.unary("sqrt", G.dot(a, a))
         nk = G.powi(n, k)
-        return self._like([G.div(x, nk) for x in self.outs])
+        return self._like([G.div(x, nk) for x in a])
 
     def normalized_power2(self):
         return self._normalized_power(2)
@@ -247,8 +274,8 @@ class VectorFunction:
     def cross(self, other):
         if self.ORows() != 3:
             raise ValueError("cross requires 3-vectors")
-        a = self.outs
-        b = self._coerce(other, 3)
+        a = self._operands(self.outs)
+        b = self._operands(self._coerce(other, 3))
         return self._like([
             G.sub(G.mul(a[1], b[2]), G.mul(a[2], b[1])),
             G.sub(G.mul(a[2], b[0]), G.mul(a[0], b[2])),

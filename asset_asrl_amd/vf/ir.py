@@ -82,6 +82,26 @@ class Graph:
         """Adjoint (multiplier) input; a second family of leaves."""
         return self._mk("lam", (), int(k))
 
+    def cut(self, a: Node) -> Node:
+        """A CUT through the expression: numerically the identity, for differentiation a variable of its own.  Where a function is
+        composed, ``f(g(x))``, the outputs of ``g`` are wrapped in cuts, and the derivative builders of codegen.py apply the chain
+        rule BLOCK-wise across them -- partials of the outer expression with respect to the cut variables, formed once, times the
+        total derivatives of the cuts -- the way the reference's NestedFunction combines the Jacobians and adjoint Hessians of its
+        two functions (CommonFunctions/NestedFunction.h:140-270), instead of pushing every input direction through the whole
+        flattened expression.  ``d`` and ``grad`` below treat a cut as a LEAF (a barrier): they return partial derivatives.
+        Trivial arguments (leaves, a leaf times / plus a constant) are not cut."""
+        if not a.args or a.op == "cut":
+            return a
+        if a.op in ("mul", "add", "sub", "neg", "div") and all((not x.args) for x in a.args):
+            return a
+        return self._mk("cut", (a,))
+
+    def frozen(self) -> Node:
+        """A fresh leaf that stands for an expression held CONSTANT in a differentiation (an adjoint weight of the block-wise
+        second-order chain rule); replaced by that expression afterwards (``replace``)."""
+        self._nfrozen = getattr(self, "_nfrozen", 0) + 1
+        return self._mk("frozen", (), self._nfrozen)
+
     def aconst(self, k: int) -> Node:
         """Constant of the function APPLICATION (a third family of leaves): a number the caller supplies per application
         beside the solver variables -- e.g. the nodal spacing of the reference's SingleMeshSpacing objects, one object per
@@ -225,7 +245,9 @@ class Graph:
             return self.zero
         if op in ("var", "lam"):
             return self.one if n is w else self.zero
-        if op == "aconst":
+        if op == "cut":                        # a barrier: the partial derivative (the total one is the builder's business)
+            return self.one if n is w else self.zero
+        if op in ("aconst", "frozen"):
             return self.zero
         a = n.args[0]
         da = self.d(a, w)
@@ -303,6 +325,8 @@ class Graph:
             if bar is None or bar is self.zero or not n.args:
                 continue
             op = n.op
+            if op == "cut":                    # a barrier: its adjoint is read off by the caller, nothing flows into its argument
+                continue
             if op in _UNARY or op in ("powi", "powr"):
                 a = n.args[0]
                 self._acc(adj, a, self.mul(bar, self._dunary(n, a)))
@@ -352,8 +376,34 @@ class Graph:
                 memo[n.id] = self.rebuild(n, [memo[a.id] for a in n.args])
         return [memo[r.id] for r in roots]
 
+    def replace(self, roots: Sequence[Node], mapping: Dict[int, Node]) -> List[Node]:
+        """Rebuild roots with every node whose id is a key of `mapping` replaced by the mapped node (cuts are kept)."""
+        memo: Dict[int, Node] = {}
+        for n in topo_order(roots):
+            if n.id in mapping:
+                memo[n.id] = mapping[n.id]
+            elif not n.args:
+                memo[n.id] = n
+            else:
+                memo[n.id] = self.rebuild(n, [memo[a.id] for a in n.args])
+        return [memo[r.id] for r in roots]
+
+    def strip_cuts(self, roots: Sequence[Node]) -> List[Node]:
+        """The same expressions without their cuts (what is printed: a cut is the identity)."""
+        memo: Dict[int, Node] = {}
+        for n in topo_order(roots):
+            if not n.args:
+                memo[n.id] = n
+            elif n.op == "cut":
+                memo[n.id] = memo[n.args[0].id]
+            else:
+                memo[n.id] = self.rebuild(n, [memo[a.id] for a in n.args])
+        return [memo[r.id] for r in roots]
+
     def rebuild(self, n: Node, args: Sequence[Node]) -> Node:
         op = n.op
+        if op == "cut":
+            return self.cut(args[0])
         if op == "add":
             return self.add(*args)
         if op == "sub":
@@ -403,6 +453,25 @@ def topo_order(roots: Sequence[Node]) -> List[Node]:
     return out
 
 
+def frontier(roots: Sequence[Node]):
+    """(var leaves, cut nodes) reachable from roots WITHOUT crossing a cut: what the expressions depend on directly when cuts are
+    variables.  Both in a deterministic order (var index / first visit)."""
+    seen, vs, cs = set(), {}, []
+    stack = list(reversed(list(roots)))
+    while stack:
+        n = stack.pop()
+        if n.id in seen:
+            continue
+        seen.add(n.id)
+        if n.op == "var":
+            vs[n.value] = n
+        elif n.op == "cut":
+            cs.append(n)
+        else:
+            stack.extend(reversed(n.args))
+    return [vs[k] for k in sorted(vs)], cs
+
+
 def evaluate(roots: Sequence[Node], y: Sequence[float], lam: Sequence[float] = (), aconst: Sequence[float] = ()) -> List[float]:
     """Host-side numeric walk of the DAG (set-up time checks only, never the hot path)."""
     val: Dict[int, float] = {}
@@ -432,6 +501,8 @@ def evaluate(roots: Sequence[Node], y: Sequence[float], lam: Sequence[float] = (
             v = val[n.args[0].id] ** n.value
         elif op == "atan2":
             v = math.atan2(val[n.args[0].id], val[n.args[1].id])
+        elif op == "cut":
+            v = val[n.args[0].id]
         else:
             v = _EVAL_UNARY[op](val[n.args[0].id])
         val[n.id] = v

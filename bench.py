@@ -49,6 +49,7 @@ WORKLOADS = {
 }
 MULTI_PHASE = {"multispacecraft_8x1250": 8}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+FP64_PEAK_GFLOPS = 78600.0  # MI355X FP64 vector = FP64 matrix: 16 FMA lanes per cycle and SIMD (half the 157.3 TFLOP/s FP32 vector rate of MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes_per_segment(IR, OR):
@@ -490,12 +491,36 @@ def main():
     # every rank's own kernel against ITS roofline: algorithmic bytes of its share / its settled HIP-event kernel time
     per_rank_frac = [(n * bseg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0 for n, ms in zip(per_rank_segments, per_rank_ms)]
 
+    # FP64 side of the roofline (SURVEY section 8d "MFMA/FP64-vector bound only checked for config 5"): useful flops of the node-wise
+    # sparse form (asset_asrl_amd/flopcount.py) against the FP64 vector peak, the arithmetic intensity against the ridge, and -- from the
+    # committed counter profile -- the flops the kernels ISSUE if every vector instruction were a 64-lane FMA (an upper bound)
+    fp64 = None
+    if mode != "Trapezoidal":
+        from asset_asrl_amd import synth
+        from asset_asrl_amd.flopcount import sparse_useful_flops
+        from asset_asrl_amd.ode import ODE_LIBRARY
+        fl = sparse_useful_flops(ODE_LIBRARY[ode]().derivatives(), synth.MODE_CS[mode], blocked)
+        ach = local_segments * fl["total"] / (ms_roof * 1e-3) / 1e9 if ms_roof > 0 else 0.0
+        fp64 = {"bound": "fp64_valu", "peak": FP64_PEAK_GFLOPS, "unit": "GFLOP/s", "achieved": ach, "frac": ach / FP64_PEAK_GFLOPS,
+                "useful_flops_per_segment": fl["total"], "useful_flops_algebra": fl["algebra"], "useful_flops_ode": fl["ode"],
+                "flop_per_algorithmic_byte": fl["total"] / bseg, "ridge_flop_per_byte": FP64_PEAK_GFLOPS / HBM_PEAK_GBS,
+                "dense_reference_flops_per_segment": fl["dense_survey"],
+                "note": "useful = FMAs (x 2) of the node-wise sparse form of LGLDefects.h:414-512 for the entries a block holds, with the ODE's "
+                        "structural sparsity, + (CS + K) ODE bodies; dense_reference = SURVEY 8(d)'s formula for the reference's dense products"}
+
     traffic, traffic_src = None, None
     prof = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_{a.workload}_pmc.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), "")
     if world == 1 and prof:   # NOT measured by this run: HBM bytes per evaluation from the committed rocprofv3 --pmc passes
         try:
-            traffic = json.load(open(prof))["hbm"]["bytes_per_launch"]
+            pj = json.load(open(prof))
+            traffic = pj["hbm"]["bytes_per_launch"]
             traffic_src = f"committed profile profiles/{os.path.basename(prof)} (separate rocprofv3 --pmc passes of this command)"
+            if fp64 is not None:
+                valu = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in pj.get("sq_counters_per_dispatch", {}).items() if k != "secondary")
+                if valu > 0:
+                    fp64["issued_flops_per_segment_upper_bound"] = valu * 128.0 / nseg
+                    fp64["issued_source"] = (f"SQ_INSTS_VALU of the evaluation's kernels x 64 lanes x 2 (profiles/{os.path.basename(prof)}): what the "
+                                             "vector ALU would do if every instruction were a full-wave FMA")
         except Exception:
             traffic = None
 
@@ -548,7 +573,7 @@ def main():
                          "launch_ms": ms_roof, "launch_ms_source": ("HIP events around the K timed steps / K" if ms_roof is ms_timed_region
                                                                      else "settled HIP-event rounds (the step also holds the exchange)"),
                          "kernel_ms": ms_kernel, "kernel_ms_rounds": kernel_rounds, "segments_in_kernel": local_segments,
-                         "algorithmic_bytes_per_segment": bseg},
+                         "algorithmic_bytes_per_segment": bseg, "fp64": fp64},
             "per_rank_kernel_ms": per_rank_ms, "per_rank_segments": per_rank_segments, "per_rank_roofline_frac": per_rank_frac,
             "secondary": {"evalOCC (CON: defect values only), rank 0's share, kernel": {
                 "ms": ms_con, "segments_per_s": local_segments / (ms_con * 1e-3) if ms_con > 0 else 0.0,

@@ -221,3 +221,40 @@ class FullProblem:
                 "meshspacing": (LGLMeshSpacing(3), "lglmeshspacing3"),
                 "pairprod": (vf.stack([b[0] * b[2] - b[1] * b[3] - 0.5]), "iq0_pairwisepath"),
                 "integral": (LGLIntegral(g.coeff(1) * g.coeff(1) + g.coeff(0), 3, 2), "lglintegral3_quad2")}
+
+
+def make_nested_orbit(flat: bool = False):
+    """A user ODE written the way the reference's users compose functions, ``outer(inner(y))``: the inner function maps two polar
+    states and a scaled third one to a position vector, the outer one is a point-mass pull with an oblateness term in that vector
+    -- (4, 1, 1): states (rho, phi, z, w), control u, parameter p.  The composition leaves CUTS in the expression graph
+    (asset_asrl_amd/vf/ir.py: Graph.cut) and the derivative builder applies the chain rule block-wise across them
+    (vf/codegen.py; the reference: CommonFunctions/NestedFunction.h:140-270).  ``flat``: differentiated as one flattened expression."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+
+    class NestedOrbit(ODEBase):
+        def __init__(self):
+            a = ODEArguments(4, 1, 1)
+            rho, phi, z, w = a.XVec().tolist()
+            t, u, p = a.TVar(), a.UVar(0), a.PVar(0)
+            inner = vf.stack([rho * vf.cos(phi), rho * vf.sin(phi), z * (1.0 + 0.1 * p)])       # R^7 -> R^3
+            R = vf.Arguments(3)
+            r2 = R.squared_norm()
+            r = vf.sqrt(r2)
+            s = R[2] / r
+            pull = R.normalized_power3() * (-1.0)
+            obl = vf.stack([R[0] * (5.0 * s * s - 1.0), R[1] * (5.0 * s * s - 1.0), R[2] * (5.0 * s * s - 3.0)]) * (0.01 / (r2 * r2 * r))
+            acc = (pull + obl)(inner)                                                             # the composition
+            rhs = [w * vf.cos(phi) + acc[0] * 0.5, acc[1] / rho + u * 0.1, w * 0.3 + acc[2] * vf.cos(0.2 * t), acc[0] * acc[2] - 0.05 * w + u]
+            super().__init__(vf.stack(rhs), 4, 1, 1, name="nested_orbit")
+
+    ode = NestedOrbit()
+    if flat:          # the same function differentiated as ONE flattened expression (the form of rounds 1-5): another device module
+        from asset_asrl_amd.vf import codegen
+        old = codegen.BLOCK_CHAIN_RULE
+        codegen.BLOCK_CHAIN_RULE = False
+        try:
+            ode.derivatives()
+        finally:
+            codegen.BLOCK_CHAIN_RULE = old
+    return ode

@@ -78,3 +78,62 @@ def test_dsl_surface_and_errors():
     args = odelib.ODEArguments(3, 2, 1)
     assert args.IRows() == 7 and args.UVec().ORows() == 2 and args.PVar(0).ORows() == 1
     np.testing.assert_allclose(args.TVar().compute(np.arange(7.0)), [3.0])
+
+
+def test_block_chain_rule_across_compositions():
+    """Expressions that are COMPOSED, ``outer(inner(y))``, keep cuts at the inner function's outputs (vf/ir.py: Graph.cut) and are
+    differentiated block-wise across them (vf/codegen.py: _differentiate_block -- the reference's NestedFunction chain rule,
+    CommonFunctions/NestedFunction.h:140-270): the same J, g, H as the flattened expression to rounding, in fewer operations; the
+    builder keeps the cheaper of the two forms and what it returns holds no cuts."""
+    from asset_asrl_amd.vf import codegen
+    from asset_asrl_amd.vf.ir import topo_order
+    from helpers import make_nested_orbit
+    ode = make_nested_orbit()
+    assert any(n.op == "cut" for n in topo_order(ode.func.outs))
+    d = ode.derivatives()
+    assert d.chain_rule["form"] in ("block", "block_local")        # (total Jacobians of the cuts / local elimination: the cheaper)
+    assert min(d.chain_rule["ops_block"], d.chain_rule["ops_block_local"]) < 0.92 * d.chain_rule["ops_flat"]
+    assert d.stats()["ops_fjgh"] == d.chain_rule["ops_" + d.chain_rule["form"]]
+    N, n = d.nin, d.xv
+    roots = d.f + [e for r in d.J for e in r] + d.g + [d.H[i][j] for i in range(N) for j in range(i + 1)]
+    assert not any(x.op in ("cut", "frozen") for x in topo_order(roots))
+    old = codegen.BLOCK_CHAIN_RULE
+    codegen.BLOCK_CHAIN_RULE = False
+    try:
+        d0 = codegen.differentiate("flat", ode.func, 4, 1, 1)
+    finally:
+        codegen.BLOCK_CHAIN_RULE = old
+    assert d0.chain_rule["form"] == "flat" and d0.stats()["ops_fjgh"] == d.chain_rule["ops_flat"]
+    roots0 = d0.f + [e for r in d0.J for e in r] + d0.g + [d0.H[i][j] for i in range(N) for j in range(i + 1)]
+    rng = np.random.default_rng(7)
+    for _ in range(5):
+        y = np.concatenate([rng.uniform(0.6, 1.4, 1), rng.uniform(-1, 1, N - 1)])
+        y[2] = rng.uniform(0.2, 0.9)
+        lam = rng.uniform(-1, 1, n)
+        a, b = np.array(evaluate(roots, y, lam)), np.array(evaluate(roots0, y, lam))
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-13
+    # the structure is the same whichever way it was formed
+    assert d.stats()["nnz_J"] == d0.stats()["nnz_J"] and d.stats()["nnz_H_lower"] == d0.stats()["nnz_H_lower"]
+    # ... and finite differences of the composed function agree with its Jacobian
+    y = np.array([1.1, 0.4, 0.5, -0.3, 0.7, 0.2, 1.5])
+    J = np.array(evaluate([e for r in d.J for e in r], y)).reshape(n, N)
+    for i in range(N):
+        e = np.zeros(N); e[i] = 1e-6
+        fd = (ode.func.compute(y + e) - ode.func.compute(y - e)) / 2e-6
+        assert np.max(np.abs(fd - J[:, i])) < 1e-7
+
+
+def test_an_explicit_cut_is_the_identity_and_a_barrier():
+    """``.cut()``: numerically the identity; for ir.Graph.d / grad a variable of its own (partial derivatives)."""
+    from asset_asrl_amd.vf.ir import GRAPH as G
+    a = vf.Arguments(3)
+    inner = (a[0] * a[1] + vf.sin(a[2])).cut()
+    f = inner * inner + a[0]
+    y = np.array([0.3, -1.2, 0.8])
+    assert abs(f.compute(y)[0] - ((y[0] * y[1] + np.sin(y[2])) ** 2 + y[0])) < 1e-15
+    c = inner.outs[0]
+    assert c.op == "cut"
+    assert G.d(f.outs[0], G.var(1)) is G.zero                       # nothing flows through the cut
+    assert abs(evaluate([G.d(f.outs[0], c)], y)[0] - 2 * (y[0] * y[1] + np.sin(y[2]))) < 1e-15
+    assert G.d(f.outs[0], G.var(0)) is G.one                        # the direct dependence only
+    assert vf.Arguments(2)[0].cut().outs[0].op == "var"             # plain arguments are never cut
