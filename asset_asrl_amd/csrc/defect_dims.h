@@ -20,7 +20,7 @@
 // ASSET_WALLCLOCK, ASSET_FUNC_TIMING) and elimination experiments that compute WRONG results on purpose (ASSET_EXP_*).  A
 // production build that defines one of them -- through ASSET_HIP_JIT flags or a build environment -- is refused.
 #if (defined(ASSET_TIMING) || defined(ASSET_WALLCLOCK) || defined(ASSET_FUNC_TIMING) || defined(ASSET_EXP_NOWS) ||       \
-     defined(ASSET_EXP_NULL) || defined(ASSET_EXP_ODEREP) || defined(ASSET_EXP_ONEUNIT) || defined(ASSET_EXP_UNITREP) || defined(ASSET_EXP_ROWS) || defined(ASSET_EXP_RDALIGN)) && \
+     defined(ASSET_EXP_NULL) || defined(ASSET_EXP_ODEREP) || defined(ASSET_EXP_ONEUNIT) || defined(ASSET_EXP_UNITREP) || defined(ASSET_EXP_ROWS)) && \
     !defined(ASSET_TUNING_BUILD)
 #error "ASSET_TIMING / ASSET_WALLCLOCK / ASSET_EXP_* change what the kernels write: measurement builds only (-DASSET_TUNING_BUILD)"
 #endif
@@ -37,7 +37,7 @@ struct EvalArgs {
   const int* cindex;   // [OR x nseg] column-major (device)
   double* FX;          // [nseg x OR] blocks or null
   double* AGX;         // [nseg x IR] blocks or null
-  double* KKT;         // [nseg x NKKT] blocks or null
+  double* KKT;         // [nseg x KSTRIDE] blocks (layout: Dims::KL below) or null
   double* work;        // [grid][G][SLOT] per-workgroup ODE result slots (L2-resident scratch in HBM)
   // On-device assembly (dense stage, ASM kernels): KKT entries go into the solver's value array instead of being
   // stored as blocks (DenseFunctionBase.h:1413-1523 KKTFillAll / KKTFillJac; locations NonLinearProgram.cpp:316-330;
@@ -161,6 +161,10 @@ struct Dims {
   static constexpr int HCA = KL ? IR - 1 : IR + OR - 1;                  // hcol(c) = HOFF + c HCA - c (c - 1) / 2
   static constexpr int hcol(int c) { return HOFF + c * HCA - c * (c - 1) / 2; }          // H(r, c) sits at hcol(c) + r
   static constexpr int jcol(int c) { return KL ? c * OR : hcol(c) + IR; }                // J(j, c) sits at jcol(c) + j
+  // (Measured and rejected, round 6 -- profiles/r6_aligned.txt: every block column on 128-byte lines of its own, the triangles'
+  //  columns starting on 32-byte sectors, i.e. whole-line stores from every 16-lane group.  The store path likes it -- TwoBody-LGL5-
+  //  BlockConstant x 10 000 21.0 -> 20.1 us although WRITE_SIZE grows 49.9 -> 60.5 MB -- but the padding is bytes: Reentry-LGL7 x 10 000
+  //  27.5 -> 29.8 us (84.8 -> 101.7 MB), x 100 000 280 -> 360 us, TwoBody x 100 000 200 -> 260 us.  The packed regions stay.)
   static constexpr int WNW = 4;                        // waves of the wide dense kernel
   static constexpr int NCR = WIDE ? N - n : NP - n;    // constant rows per interior (wide: the k-padding rows read a zero row)
   static constexpr int s_DIx = 0;                      // [K][n][IRP]

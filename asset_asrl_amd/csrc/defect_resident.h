@@ -66,9 +66,17 @@ struct ResDims {
   // multiple of four and that have no parameter columns (ResLane::QFAST) fill their 16-column tiles without padding and keep their row
   // weights in registers; there the tile form issues 500 instructions and 33 matrix instructions per segment against ~ 800 vector
   // instructions of the row-wise form, and both end at the drain of the block stores.  ASSET_RES_ROWDPP: 0 never, 1 by that rule, 2 always.
-  static constexpr bool ROWDPP = RD_SHAPE && ASSET_RES_PAIR && !D::TRAP && WPS == 2 && Ode::NUNITS == 1;
+  static constexpr bool RD_CAP = ASSET_RES_PAIR && !D::TRAP && WPS == 2 && Ode::NUNITS == 1;   // the shape CAN run the row-wise part
+  static constexpr bool ROWDPP = RD_SHAPE && RD_CAP;                  // ... and it is its default form
+  // (round 6) BOTH forms for the shapes that default to tiles (Reentry without segment parameters): with the J | H block layout the
+  // row-wise part wins where a workgroup has enough segments to fill its passes and on the large meshes -- Reentry-LGL7 x 7 500 22.8
+  // against 24.8 us, x 10 000 27.5 / 28.5, x 1 000 000 2.80 / 2.89 ms; LGL5 x 100 000 205 / 224 us -- and loses on small meshes (LGL3 x 1 000
+  // 9.75 / 9.12, LGL7 x 5 000 21.0 / 20.6) and where a wave walks two or three groups (LGL7 x 30 000 96 / 88): profiles/r6_forms.txt.
+  // The launcher picks by mesh size (registry.h: K_RES_ALT, K_RESLP).
+  static constexpr bool RD_ALT = !RD_SHAPE && RD_CAP && ASSET_RES_ROWDPP == 1;
+  static constexpr bool RD_ANY = ROWDPP || RD_ALT;
   static constexpr int s_FB = D::WSLOTD + 1 + (SV_ALIAS ? 0 : CS * Ode::NSAVE);
-  static constexpr int SLOT = (s_FB + (ROWDPP ? K * n + 1 : 0)) | 1;   // odd: conflict-free across segments
+  static constexpr int SLOT = (s_FB + (RD_ANY ? K * n + 1 : 0)) | 1;   // odd: conflict-free across segments
   // JRIDE: the rows behind the H^ rows of the A operand of the M product carry h E_i J^_i, so the interior part of J comes out of
   // the same matrix instructions (as J_i[r][c] in the lanes of column c: transposed with respect to the store order).  It is
   // turned through LDS, one 16-column tile and interior at a time, in buffers T_i [16][n] laid over sections of the segment's
@@ -139,14 +147,14 @@ struct ResDims {
 #ifndef ASSET_RES_LOOP_PAIR
 #define ASSET_RES_LOOP_PAIR 1
 #endif
-  static constexpr bool LOOP_PAIR = ASSET_RES_LOOP_PAIR && ROWDPP;   // the looped level-2 kernel in two-wave workgroups too
+  static constexpr bool LOOP_PAIR = ASSET_RES_LOOP_PAIR && RD_ANY;   // the looped level-2 kernel in two-wave workgroups too (row-wise part)
   // EARLYC (round 5): the cardinal value phase also leaves the Jacobians J_j in the slot (Ode::fj_save), so that the rows of [J ; g^T]
   // -- the C passes of the row-wise dense part, 45 % of a segment's bytes -- are formed and stored by one wave of the pair WHILE the
   // other runs the cardinal second-derivative phase: the stores start one phase earlier.
 #ifndef ASSET_RES_EARLYC
 #define ASSET_RES_EARLYC 1
 #endif
-  static constexpr bool EARLYC = ASSET_RES_EARLYC && ROWDPP && PAIR;
+  static constexpr bool EARLYC = ASSET_RES_EARLYC && RD_ANY && PAIR;   // (of the kernels that run the row-wise part)
   static constexpr int GR_PASS = 64 / (CS * NWV);                   // one pass per phase covers the workgroup's group
   static constexpr int GR = GR_FIT < GR_PASS ? GR_FIT : GR_PASS;
   static constexpr int REGION = D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA;   // a wave's LDS (doubles)
@@ -240,7 +248,7 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_value(ld
 }
 
 // P2: interior point i: x^, tau, u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
-template <class Ode, class D, int LEVEL = 2>
+template <class Ode, class D, int LEVEL = 2, bool RDF = ResDims<D>::ROWDPP>
 __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_double* S, int i, const LglTab* tabp, bool have_lam) {
   constexpr int n = D::n, m = D::m, q = D::q, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
@@ -269,7 +277,7 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
   for (int k = 0; k < D::p; k++) y[q + k] = z[D::P0 + k];
 #pragma unroll
   for (int k = 0; k < n; k++) li[k] = have_lam ? lam[i * n + k] : 0.0;
-  if constexpr (ResDims<D>::ROWDPP && LEVEL >= 1) {   // FB_i[k] = sum_j B_ij f_j[k]: the time rows of the row-wise dense part (defect_rowdpp.h)
+  if constexpr (RDF && LEVEL >= 1) {   // FB_i[k] = sum_j B_ij f_j[k]: the time rows of the row-wise dense part (defect_rowdpp.h)
 #pragma unroll
     for (int k = 0; k < n; k++) {
       double acc = 0.0;
@@ -528,7 +536,7 @@ constexpr long long res_table_words_tile() {
 }
 template <class Ode, class D>
 constexpr long long res_table_words() {
-  if constexpr (ResDims<D>::DENSE_OK && ResDims<D>::ROWDPP) return res_table_words_tile<Ode, D>() + RdDims<Ode, D>::table_bytes() / 4;
+  if constexpr (ResDims<D>::DENSE_OK && ResDims<D>::RD_ANY) return res_table_words_tile<Ode, D>() + RdDims<Ode, D>::table_bytes() / 4;
   else return res_table_words_tile<Ode, D>();
 }
 
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
     for (int k = 0; k < ResRecord<LC>::NQ * 4; k++) r.w[k] = 0u;
     r.lc.compute(threadIdx.x);
     for (int k = 0; k < ResRecord<LC>::NQ * 4; k++) out[(k >> 2) * 256 + threadIdx.x * 4 + (k & 3)] = r.w[k];
-    if constexpr (ResDims<D>::ROWDPP) {
+    if constexpr (ResDims<D>::RD_ANY) {
       for (int rec = threadIdx.x; rec < RdDims<Ode, D>::NRECH; rec += 64)
         rd_lane_setup<Ode, D, ResDims<D>::s_Z0>(out + res_table_words_tile<Ode, D>(), rec);
     }
@@ -617,10 +625,13 @@ __device__ inline double row16_sum(double x) {
 // the blocks are written as zeros unless the caller says it never reads them (ASSET_HIP_KEEP_HESSIAN_SLOTS).
 // LOOP: meshes of more than GR segments per wave (a second instantiation: the one-group form is the north-star case and
 // loses 1 us to the loop's bookkeeping).
-template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM, bool LOOP, bool GIVEN = false, bool LPAIR = false>
+template <class Ode, int SCH, bool BLOCKED, int LEVEL, bool ASM, bool LOOP, bool GIVEN = false, bool LPAIR = false,
+          bool RDF = ResDims<Dims<Ode, SCH, BLOCKED>>::ROWDPP>       // RDF: the dense part by output rows (defect_rowdpp.h) instead of tiles
 __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   using D = Dims<Ode, SCH, BLOCKED>;
   using R = ResDims<D>;
+  constexpr bool ROWDPP = RDF;
+  static_assert(!RDF || R::RD_ANY, "the row-wise dense part: shapes built for it");
   using LCT = ResLane<Ode, D>;
   constexpr int CS = D::CS, K = D::K, KE = R::KE, n = D::n, q = D::q, N = D::N, T = D::T, TF = D::TF;
   constexpr int IR = D::IR, OR = D::OR, IRP = D::IRP, KS = D::KS, TI = D::TI, TJ = D::TJ, GR = R::GR, SLOT = R::SLOT;
@@ -764,8 +775,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   };
   // (the one-group kernel only: in the looped pair form the waves meet at a barrier per group and wave B, with all the C passes of a group,
   //  is the longer one every time -- TwoBody-LGL5-BlockConstant x 1 000 000: 2.53 ms with it, 2.07 ms without)
-  constexpr bool EARLYC = R::EARLYC && PAIR && !LOOP && LEVEL == 2 && !ASM && !GIVEN && !D::TRAP;
-  unsigned int rd_rec[R::ROWDPP ? RdDims<Ode, D>::NQH * 4 : 1];       // the row record of the row-wise dense part (defect_rowdpp.h)
+  constexpr bool EARLYC = R::EARLYC && ROWDPP && PAIR && !LOOP && LEVEL == 2 && !ASM && !GIVEN && !D::TRAP;
+  unsigned int rd_rec[R::RD_ANY ? RdDims<Ode, D>::NQH * 4 : 1];       // the row record of the row-wise dense part (defect_rowdpp.h)
   const unsigned int* const rd_rectab = static_cast<const unsigned int*>(a.lane_consts_res) +
                                         size_t(blockIdx.x % ASSET_LANE_REPLICAS) * size_t(res_table_words<Ode, D>()) + res_table_words_tile<Ode, D>();
   ResRecord<LCT> lrec;
@@ -899,7 +910,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   if constexpr (!D::TRAP) {
     if (roleB && pj < K && pg < gall) {   // P2
       const int g = pg, i = pj;
-      res_interior<Ode, D, LEVEL>(pslot(g), i, &tab, a.L != nullptr);
+      res_interior<Ode, D, LEVEL, ROWDPP>(pslot(g), i, &tab, a.L != nullptr);
     }
     if constexpr (LEVEL >= 2) pair_sync();
   }
@@ -931,7 +942,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #endif
   }   // (!GIVEN)
   RTS();
-  if constexpr (R::ROWDPP && LEVEL >= 1 && !ASM && !GIVEN) {
+  if constexpr (ROWDPP && LEVEL >= 1 && !ASM && !GIVEN) {
     // ------------------------------------------------------------------ dense part by output rows (defect_rowdpp.h): the workgroup's
     // (segment, row group) tasks in passes of four, dealt to the two waves alternately
     if constexpr (EARLYC) {
@@ -1437,15 +1448,18 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
 #undef RTSG
 }
 
-template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false, bool LOOP = false, bool GIVEN = false, bool LPAIR = false>
+// FORM 1: the row-wise dense part for a shape whose default form is tiles (ResDims::RD_ALT; one-group kernel, level 2, blocks)
+template <class Ode, int SCH, bool BLOCKED, int LEVEL = 2, bool ASM = false, bool LOOP = false, bool GIVEN = false, bool LPAIR = false, int FORM = -1>
 __global__ __launch_bounds__((!GIVEN && ResDims<Dims<Ode, SCH, BLOCKED>>::PAIR && (!LOOP || LPAIR)) ? 128 : 64, (ResDims<Dims<Ode, SCH, BLOCKED>>::WPS))
 void lgl_resident_kernel(EvalArgs a) {
 #if defined(ASSET_EXP_NULL)   // (experiment: the cost of the launch itself)
   if (a.nseg > 0) return;
 #endif
   using R = ResDims<Dims<Ode, SCH, BLOCKED>>;
-  if constexpr (LPAIR) {
-    if constexpr (R::OK && R::LOOP_PAIR) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN, true>(a);
+  if constexpr (FORM == 1) {
+    if constexpr (R::OK && R::RD_ALT && LEVEL == 2 && !ASM && !LOOP && !GIVEN && !LPAIR) lgl_resident_body<Ode, SCH, BLOCKED, 2, false, false, false, false, true>(a);
+  } else if constexpr (LPAIR) {
+    if constexpr (R::OK && R::LOOP_PAIR) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN, true, true>(a);
   } else if constexpr ((GIVEN ? R::GIVEN_OK : R::OK) && (!ASM || GIVEN || R::ASM_OK)) lgl_resident_body<Ode, SCH, BLOCKED, LEVEL, ASM, LOOP, GIVEN>(a);
 }
 

@@ -20,8 +20,10 @@
 // The time terms fold into the same sums: with FB = sum_j f_j . BM_j (+ E f^ . l) the columns t_0 / t_f get -/+ FB, and the rank-2
 // update of H (LGLDefects.h:508-511) is  M_i -/+= E_i g^_i  in the lanes of rows t_0 / t_f (the row part) and -/+ HT[r] on the two
 // time columns (the column part), HT[r] = (g_j[cc] + sum_i g^_i . hE_i d_i) / h from the lane's own d_i.
-// For a fixed block column the lanes' rows are contiguous in the reference's slot order (DenseFunctionBase.h:1112-1123): a row
-// group stores 128 contiguous bytes per column.  Lanes above the diagonal carry an out-of-range buffer offset.
+// For a fixed block column the lanes' rows are contiguous in the block (either layout of defect_dims.h, Dims::KL -- the reference's slot
+// order, DenseFunctionBase.h:1112-1123, or J | H): a row group stores 128 contiguous bytes per column.  Lanes above the diagonal carry an
+// out-of-range buffer offset.  With the J | H layout (round 6) the rows of [J ; g^T] and the rows of H -- different passes -- never write one
+// 32-byte sector twice: WRITE_SIZE 1.29-1.38 x the block bytes in the reference's order, 1.00 x now (profiles/r6_layout_ab.txt).
 //
 // Counted on the ISA of Reentry-LGL7 (tools/isa_count.py): an H pass (the lower triangles of two segments) is ~ 1 000 vector
 // instructions, 473 of them v_fmac_f64_dpp; a C pass (the Jacobian and gradient rows of four segments) ~ 1 000 with 456: ~ 800 per

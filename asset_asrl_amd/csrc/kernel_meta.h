@@ -37,6 +37,7 @@ enum MetaField {
   MF_RES_NWV,                                       // resident kernel: waves per workgroup (2: the pair form, ResDims::PAIR)
   MF_RES_LOOP_NWV,                                  // ... of its looped level-2 block kernel (2 with the row-wise dense part)
   MF_RES_ASM,                                       // ... 1: its assembled kinds exist (0: shapes of two row tiles with the row-wise dense part)
+  MF_RES_ALT,                                       // resident kernel: 1 when the row-wise form exists beside a default tile form (ResDims::RD_ALT)
   MF_KL, MF_KSTRIDE,                                // layout of the KKT blocks the kernels write (defect_dims.h: Dims::KL) and their stride in doubles (0: NKKT)
   MF_COUNT
 };
@@ -70,7 +71,7 @@ struct LglMeta {
       ResDims<D>::OK ? ResDims<D>::GR : 0, (long long)ResDims<D>::lds_bytes(), res_lane_table_bytes<Ode, SCH, BLOCKED>(),
       ResDims<D>::WPS, ResDims<D>::GIVEN_OK ? ResDims<D>::GR : 0,
       RowsDims<D>::OK ? (long long)RowsDims<D>::lds_bytes() : 0, ResDims<D>::NWV, ResDims<D>::LOOP_PAIR ? 2 : 1, ResDims<D>::ASM_OK ? 1 : 0,
-      D::KL, D::KSTRIDE};
+      ResDims<D>::RD_ALT ? 1 : 0, D::KL, D::KSTRIDE};
 };
 
 template <class F>

@@ -128,7 +128,8 @@ constexpr int K_ROWS = 58;     // wide shapes: dense stage by output rows, no ma
 constexpr int K_ROWS1 = 59;    // ... the Jacobian kinds
 constexpr int K_UNITS4 = 60;   // heavy right-hand sides: interior and cardinal units in one launch (defect_units.h, PHASE 4)
 constexpr int K_RESLP = 61;   // resident kernel, looped, level 2, blocks, as two-wave workgroups (row-wise dense part: defect_rowdpp.h)
-constexpr int K_COUNT = 62;
+constexpr int K_RES_ALT = 62;   // resident kernel, one group, level 2, blocks: the row-wise dense part of a shape that defaults to tiles
+constexpr int K_COUNT = 63;
 
 struct KernelTable {
   long long meta[MF_COUNT] = {};
@@ -306,11 +307,17 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
           // two-wave workgroups: the one-group kernel of a pair shape -- and, on meshes of four or more groups per wave, the looped block
           // kernel of the shapes with the row-wise dense part (TwoBody-LGL5-BlockConstant: 100 000 segments 244 -> 220 us as pairs, but
           // 30 000 -- two groups per wave -- 65 -> 76 us: the pair's barriers cost what the shared ODE stage saves until the waves drift)
-          const bool lpair = !one && !a.kmap && m[MF_RES_LOOP_NWV] > 1 && t.k[K_RESLP] &&
+          static const bool no_alt = tuning_env("ASSET_HIP_NO_ALT_FORM") != nullptr;                           // tuning only
+          const bool lpair = !one && !a.kmap && m[MF_RES_LOOP_NWV] > 1 && t.k[K_RESLP] && !(no_alt && m[MF_RES_ALT]) &&
                              (a.nseg + waves - 1) / waves >= 4 * int(m[MF_RES_GR]);
           const int nwv = ((one && m[MF_RES_NWV] > 1) || lpair) ? 2 : 1, nw = a.nseg < waves ? a.nseg : waves;
           const size_t lds = size_t(m[MF_RES_LDS_BYTES]) / size_t(m[MF_RES_NWV] > 1 ? 2 : 1) * size_t(nwv);
-          return klaunch(lpair ? t.k[K_RESLP] : kr, dim3((nw + nwv - 1) / nwv), dim3(64 * nwv), lds, st, kargs);
+          // shapes with both forms of the dense part (ResDims::RD_ALT): rows in the one-group kernel from six segments per workgroup
+          // on (its passes take four / two segments: below that they run half empty), tiles otherwise; looped meshes: tiles for two or
+          // three groups per wave, the looped pair kernel (rows) beyond -- the rule above (profiles/r6_forms.txt)
+          const int nwg = (nw + nwv - 1) / nwv;
+          const bool alt = one && nwv == 2 && !a.kmap && !no_alt && m[MF_RES_ALT] && t.k[K_RES_ALT] && a.nseg >= 6 * nwg;
+          return klaunch(lpair ? t.k[K_RESLP] : (alt ? t.k[K_RES_ALT] : kr), dim3(nwg), dim3(64 * nwv), lds, st, kargs);
         }
       }
       if (m[MF_FUSED]) {
@@ -476,6 +483,7 @@ const KernelTable* lgl_static_table() {
         r.k[K_RESL(1, true)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 1, true, true>);
         r.k[K_RES_SETUP].host = ASSET_KPTR(res_lane_setup_kernel<Ode, SCH, BLOCKED>);
         if constexpr (ResDims<D>::LOOP_PAIR) r.k[K_RESLP].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, false, true, false, true>);
+        if constexpr (ResDims<D>::RD_ALT) r.k[K_RES_ALT].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, false, false, false, false, 1>);
       }
       if constexpr (ResDims<D>::GIVEN_OK) {
         r.k[K_RESD(false)].host = ASSET_KPTR(lgl_resident_kernel<Ode, SCH, BLOCKED, 2, false, true, true>);
@@ -571,6 +579,7 @@ inline std::string rtc_kernel_expr(int slot, int kind, const std::string& type, 
     for (int as = 0; as <= 1; as++)
       if (slot == K_RESL(lv, as != 0)) return "asset_hip::lgl_resident_kernel<" + lgl + ", " + std::to_string(lv) + ", " + tf(as != 0) + ", true>";
   if (slot == K_RESLP) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, false, true, false, true>";
+  if (slot == K_RES_ALT) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, false, false, false, false, 1>";
   if (slot == K_RESD(false)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, false, true, true>";
   if (slot == K_RESD(true)) return "asset_hip::lgl_resident_kernel<" + lgl + ", 2, true, true, true>";
   if (slot == K_RES_SETUP) return "asset_hip::res_lane_setup_kernel<" + lgl + ">";

@@ -22,5 +22,5 @@
 // (an array cannot be initialised from another array: spell the elements out)
 #define ASSET_RTC_META_LIST(V)                                                                                     \
   V[0], V[1], V[2], V[3], V[4], V[5], V[6], V[7], V[8], V[9], V[10], V[11], V[12], V[13], V[14], V[15], V[16], V[17],  \
-      V[18], V[19], V[20], V[21], V[22], V[23], V[24], V[25], V[26], V[27], V[28], V[29], V[30], V[31], V[32], V[33], V[34], V[35], V[36], V[37], V[38], V[39], V[40]
-static_assert(::asset_hip::MF_COUNT == 41, "ASSET_RTC_META_LIST spells out MF_COUNT elements");
+      V[18], V[19], V[20], V[21], V[22], V[23], V[24], V[25], V[26], V[27], V[28], V[29], V[30], V[31], V[32], V[33], V[34], V[35], V[36], V[37], V[38], V[39], V[40], V[41]
+static_assert(::asset_hip::MF_COUNT == 42, "ASSET_RTC_META_LIST spells out MF_COUNT elements");
