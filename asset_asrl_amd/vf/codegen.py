@@ -26,8 +26,11 @@ from dataclasses import dataclass
 from typing import Dict, List, Sequence, Tuple
 
 from .functions import VectorFunction
+from .ir import COND_OPS
 from .ir import GRAPH as G
 from .ir import Node, topo_order
+
+_COND_C = {"lt": "<", "le": "<=", "gt": ">", "ge": ">=", "and": "&&", "or": "||"}
 
 
 @dataclass
@@ -529,6 +532,8 @@ class _Printer:
                 continue
             if not n.args or n.id in self.names:
                 continue
+            if n.op in COND_OPS:             # a condition is printed where it is used (inside its select): no temporary of its own
+                continue
             if n.id in partner:
                 other = partner[n.id]
                 k = len(self.lines)
@@ -552,6 +557,9 @@ class _Printer:
             return self.lname.format(n.value)
         if n.op == "aconst":
             return f"c{n.value}"
+        if n.op in COND_OPS:
+            a, b = (self.ref(x) for x in n.args)
+            return f"({a} {_COND_C[n.op]} {b})"
         return self.names[n.id]
 
     def _expr(self, n: Node) -> str:
@@ -573,6 +581,8 @@ class _Printer:
             return f"pow({a[0]}, {_cnum(n.value)})"
         if op == "atan2":
             return f"atan2({a[0]}, {a[1]})"
+        if op == "select":
+            return f"{a[0]} ? {a[1]} : {a[2]}"
         if op == "abs":
             return f"fabs({a[0]})"
         if op == "sign":

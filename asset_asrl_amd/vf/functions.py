@@ -114,6 +114,24 @@ class VectorFunction:
             return [self.coeff(i) for i in range(self.ORows())]
         return [self.segment(s, n) for (s, n) in spec]
 
+    # ---- comparisons (scalar functions): conditions for ``ifelse`` (ConditionalStatement, CommonFunctions/Conditional.h:19-150) ----
+    def _cmp(self, other, op):
+        if self.ORows() != 1:
+            raise ValueError("LHS and RHS of conditional statement must be scalar functions")
+        return Condition(self._irows, G.compare(op, self.outs[0], self._coerce(other, 1)[0]))
+
+    def __lt__(self, other):
+        return self._cmp(other, "lt")
+
+    def __le__(self, other):
+        return self._cmp(other, "le")
+
+    def __gt__(self, other):
+        return self._cmp(other, "gt")
+
+    def __ge__(self, other):
+        return self._cmp(other, "ge")
+
     # ---- composition ---------------------------------------------------------------
     def eval(self, inner: "VectorFunction") -> "VectorFunction":
         """self(inner(x)) -- the reference's ``F.eval(G)`` / ``F(G)``."""
@@ -289,6 +307,47 @@ class VectorFunction:
         return self / other
 
 
+class Condition:
+    """A test on the inputs: a comparison of two scalar functions, or two conditions joined by ``&`` / ``|`` (the reference's
+    ConditionalStatement with ANDFlag / ORFlag).  Consumed by :func:`ifelse`."""
+
+    def __init__(self, irows: int, node: Node):
+        self._irows, self.node = int(irows), node
+
+    def IRows(self) -> int:
+        return self._irows
+
+    def _join(self, other, op):
+        if not isinstance(other, Condition) or other._irows != self._irows:
+            raise ValueError("conditions over the same inputs can be joined")
+        return Condition(self._irows, G.logic(op, self.node, other.node))
+
+    def __and__(self, other):
+        return self._join(other, "and")
+
+    def __or__(self, other):
+        return self._join(other, "or")
+
+    def compute(self, x) -> bool:
+        return bool(evaluate([self.node], np.asarray(x, dtype=float).ravel())[0])
+
+
+def ifelse(test: Condition, true_func, false_func) -> VectorFunction:
+    """``true_func(x)`` where ``test(x)`` holds, ``false_func(x)`` elsewhere (the reference's ``vf.ifelse``, IfElseFunction,
+    CommonFunctions/Conditional.h:151-260): value, Jacobian and adjoint Hessian are those of the branch the test picks -- on the device
+    a select per emitted quantity, both branches evaluated (the lanes of a wave take different branches)."""
+    if not isinstance(test, Condition):
+        raise ValueError("ifelse: the test is a comparison of two scalar functions (f > g, f <= 0.0, (a > b) & (c < d))")
+    fs = [f for f in (true_func, false_func) if isinstance(f, VectorFunction)]
+    if not fs:
+        raise ValueError("ifelse: at least one branch is a function")
+    n = fs[0].ORows()
+    a, b = fs[0]._coerce(true_func, n), fs[0]._coerce(false_func, n)
+    if any(f._irows != test._irows for f in fs):
+        raise ValueError("Test,True,and False functions in conditional statement must have same number of inputrows.")
+    return VectorFunction(test._irows, [G.select(test.node, x, y) for x, y in zip(a, b)])
+
+
 class MatrixFunction:
     """Row/Col-major matrix view of a VectorFunction (``vf.RowMatrix`` / ``vf.ColMatrix``)."""
 
@@ -376,6 +435,7 @@ sin, cos, tan, exp, log, sqrt, tanh = (_u(o) for o in ("sin", "cos", "tan", "exp
 sinh, cosh = _u("sinh"), _u("cosh")
 arcsin, arccos, arctan = _u("asin"), _u("acos"), _u("atan")
 abs = _u("abs")  # noqa: A001
+sign = _u("sign")       # -1 / 0 / +1 (the reference's SignFunction.h): piecewise constant, no derivative
 
 
 def arctan2(y: VectorFunction, x: VectorFunction) -> VectorFunction:

@@ -24,6 +24,12 @@ from typing import Dict, Iterable, List, Sequence, Tuple
 _UNARY = ("neg", "sin", "cos", "tan", "exp", "log", "sqrt", "tanh", "asin", "acos", "atan",
           "sinh", "cosh", "abs", "sign")
 _BINARY = ("add", "sub", "mul", "div", "atan2")
+# conditions (values 1.0 / 0.0, never differentiated) and the selection between two expressions: the reference's
+# ConditionalStatement / IfElseFunction (CommonFunctions/Conditional.h:19-150, 151-260) -- value, Jacobian and adjoint Hessian of an
+# ifelse are those of the branch the test picks
+_COMPARE = ("lt", "le", "gt", "ge")
+_LOGIC = ("and", "or")
+COND_OPS = _COMPARE + _LOGIC
 
 
 class Node:
@@ -213,6 +219,30 @@ class Graph:
             return self.const(_EVAL_UNARY[op](a.value))
         return self._mk(op, (a,))
 
+    def compare(self, op: str, a: Node, b: Node) -> Node:
+        assert op in _COMPARE
+        if a.is_const() and b.is_const():
+            return self.const(float(_EVAL_COND[op](a.value, b.value)))
+        return self._mk(op, (a, b))
+
+    def logic(self, op: str, a: Node, b: Node) -> Node:
+        assert op in _LOGIC
+        for x, y in ((a, b), (b, a)):
+            if x.is_const():
+                t = x.value != 0.0
+                return (y if t else self.zero) if op == "and" else (self.one if t else y)
+        return self._mk(op, (a, b))
+
+    def select(self, c: Node, a: Node, b: Node) -> Node:
+        """a where the condition c holds, b elsewhere."""
+        if c.is_const():
+            return a if c.value != 0.0 else b
+        if a is b:
+            return a
+        if c.op not in COND_OPS:
+            raise ValueError("select: the first argument is a condition (a comparison of two scalar expressions)")
+        return self._mk("select", (c, a, b))
+
     def atan2(self, a: Node, b: Node) -> Node:
         if a.is_const() and b.is_const():
             return self.const(math.atan2(a.value, b.value))
@@ -247,8 +277,10 @@ class Graph:
             return self.one if n is w else self.zero
         if op == "cut":                        # a barrier: the partial derivative (the total one is the builder's business)
             return self.one if n is w else self.zero
-        if op in ("aconst", "frozen"):
+        if op in ("aconst", "frozen") or op in COND_OPS:
             return self.zero
+        if op == "select":                     # the derivative of the branch the test picks (Conditional.h:215-250); the test itself has none
+            return self.select(n.args[0], self.d(n.args[1], w), self.d(n.args[2], w))
         a = n.args[0]
         da = self.d(a, w)
         if op in _UNARY or op in ("powi", "powr"):
@@ -327,6 +359,13 @@ class Graph:
             op = n.op
             if op == "cut":                    # a barrier: its adjoint is read off by the caller, nothing flows into its argument
                 continue
+            if op in COND_OPS:
+                continue
+            if op == "select":
+                c, a, b = n.args
+                self._acc(adj, a, self.select(c, bar, self.zero))
+                self._acc(adj, b, self.select(c, self.zero, bar))
+                continue
             if op in _UNARY or op in ("powi", "powr"):
                 a = n.args[0]
                 self._acc(adj, a, self.mul(bar, self._dunary(n, a)))
@@ -404,6 +443,12 @@ class Graph:
         op = n.op
         if op == "cut":
             return self.cut(args[0])
+        if op in _COMPARE:
+            return self.compare(op, *args)
+        if op in _LOGIC:
+            return self.logic(op, *args)
+        if op == "select":
+            return self.select(*args)
         if op == "add":
             return self.add(*args)
         if op == "sub":
@@ -420,6 +465,8 @@ class Graph:
             return self.powr(args[0], n.value)
         return self.unary(op, args[0])
 
+
+_EVAL_COND = {"lt": lambda a, b: a < b, "le": lambda a, b: a <= b, "gt": lambda a, b: a > b, "ge": lambda a, b: a >= b}
 
 _EVAL_UNARY = {
     "sin": math.sin, "cos": math.cos, "tan": math.tan, "exp": math.exp, "log": math.log,
@@ -503,6 +550,14 @@ def evaluate(roots: Sequence[Node], y: Sequence[float], lam: Sequence[float] = (
             v = math.atan2(val[n.args[0].id], val[n.args[1].id])
         elif op == "cut":
             v = val[n.args[0].id]
+        elif op in _COMPARE:
+            v = float(_EVAL_COND[op](val[n.args[0].id], val[n.args[1].id]))
+        elif op == "and":
+            v = float(val[n.args[0].id] != 0.0 and val[n.args[1].id] != 0.0)
+        elif op == "or":
+            v = float(val[n.args[0].id] != 0.0 or val[n.args[1].id] != 0.0)
+        elif op == "select":
+            v = val[n.args[1].id] if val[n.args[0].id] != 0.0 else val[n.args[2].id]
         else:
             v = _EVAL_UNARY[op](val[n.args[0].id])
         val[n.id] = v

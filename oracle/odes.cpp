@@ -59,6 +59,7 @@ AD2_ODE(twobody_lt, 6, 3, 0)
 AD2_ODE(betts_lowthrust, 7, 3, 1)
 AD2_ODE(synthetic32, 32, 0, 0)
 AD2_ODE(vanderpol, 2, 1, 1)
+AD2_ODE(switched, 2, 1, 0)
 AD2_ODE(coupled12, 12, 3, 2)
 AD2_ODE(coupled16, 16, 3, 2)
 AD2_ODE(driven14, 14, 3, 0)
@@ -118,6 +119,7 @@ GEN_DECL(twobody_lt)
 GEN_DECL(betts_lowthrust)
 GEN_DECL(synthetic32)
 GEN_DECL(vanderpol)
+GEN_DECL(switched)
 GEN_DECL(coupled12)
 GEN_DECL(coupled16)
 GEN_DECL(driven14)
@@ -186,6 +188,7 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(betts_lowthrust)
   TRY4(synthetic32)
   TRY4(vanderpol)
+  TRY4(switched)
   TRY4(coupled12)
   TRY4(coupled16)
   TRY4(driven14)
@@ -232,6 +235,7 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(betts_lowthrust, 7, 3, 1, nullptr)
   TRY(synthetic32, 32, 0, 0, g_synth32)
   TRY(vanderpol, 2, 1, 1, nullptr)
+  TRY(switched, 2, 1, 0, nullptr)
   TRY(coupled12, 12, 3, 2, nullptr)
   TRY(coupled16, 16, 3, 2, nullptr)
   TRY(driven14, 14, 3, 0, nullptr)

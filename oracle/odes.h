@@ -43,6 +43,24 @@ void vanderpol(const S* y, S* f, const void*) {
   f[1] = mu * (1.0 - x0 * x0) * x1 - x0 + u * exp(-0.1 * t);
 }
 
+// ------------------------------------------------------------------ a switched oscillator (2,1,0): conditionals, |.| and sign
+// Not a BASELINE config: the independent check for the DSL's ifelse / abs / sign nodes on the device (round 6; the reference's
+// IfElseFunction and ConditionalStatement, CommonFunctions/Conditional.h:19-260 -- value and derivatives of the branch the test picks).
+// tests/helpers.py: make_switched defines the same right-hand side in the product's expression DSL.
+static inline double valof(double a) { return a; }
+template <int N> static inline double valof(const AD2<N>& a) { return a.v; }
+static inline double absv(double a) { return std::fabs(a); }
+template <int N> static inline AD2<N> absv(const AD2<N>& a) { return ad2_unary(a, std::fabs(a.v), (a.v > 0.0) - (a.v < 0.0), 0.0); }
+template <class S>
+void switched(const S* y, S* f, const void*) {
+  const S &x0 = y[0], &x1 = y[1], &t = y[2], &u = y[3];
+  const bool stiff = valof(x0) > 0.25 && valof(x1) >= 0.0;
+  const S spring = stiff ? S(3.0 * x0 + 0.5 * x0 * x0) : S(x0 * 1.0);
+  const double dir = (valof(x1) > 0.0) - (valof(x1) < 0.0);          // sign(x1): piecewise constant, no derivative
+  f[0] = x1 + (valof(t) < 5.0 ? S(0.1 * sin(x0)) : S(0.0 * x0));
+  f[1] = -1.0 * spring - 0.3 * absv(x1) * x1 - 0.05 * dir + u * cos(t);
+}
+
 // ------------------------------------------------------------------ coupled oscillators (12,3,2): wide shapes with u and p
 // Not a BASELINE config: in LGL7 its segment has IR = 66 inputs, which puts a run-time compiled ODE with controls and
 // parameters through the four-wave dense kernel (tests/test_gpu_jit.py defines the same right-hand side in the DSL).

@@ -258,3 +258,23 @@ def make_nested_orbit(flat: bool = False):
         finally:
             codegen.BLOCK_CHAIN_RULE = old
     return ode
+
+
+def make_switched():
+    """A user ODE with conditionals (2, 1, 0): ``vf.ifelse`` on a joined test, on a test of the time, ``vf.abs`` and ``vf.sign`` --
+    the reference's IfElseFunction / ConditionalStatement / SignFunction (CommonFunctions/Conditional.h:19-260).  The oracle holds the
+    same right-hand side as ``switched`` (oracle/odes.h), differentiated independently by AD2."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+
+    class Switched(ODEBase):
+        def __init__(self):
+            a = ODEArguments(2, 1, 0)
+            x0, x1 = a.XVec().tolist()
+            t, u = a.TVar(), a.UVar(0)
+            spring = vf.ifelse((x0 > 0.25) & (x1 >= 0.0), 3.0 * x0 + 0.5 * x0 * x0, x0)
+            f0 = x1 + vf.ifelse(t < 5.0, 0.1 * vf.sin(x0), 0.0)
+            f1 = -1.0 * spring - 0.3 * vf.abs(x1) * x1 - 0.05 * vf.sign(x1) + u * vf.cos(t)
+            super().__init__(vf.stack([f0, f1]), 2, 1, 0, name="switched")
+
+    return Switched()

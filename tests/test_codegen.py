@@ -137,3 +137,35 @@ def test_an_explicit_cut_is_the_identity_and_a_barrier():
     assert abs(evaluate([G.d(f.outs[0], c)], y)[0] - 2 * (y[0] * y[1] + np.sin(y[2]))) < 1e-15
     assert G.d(f.outs[0], G.var(0)) is G.one                        # the direct dependence only
     assert vf.Arguments(2)[0].cut().outs[0].op == "var"             # plain arguments are never cut
+
+
+def test_conditionals_abs_and_sign_match_oracle_ad2(oracle):
+    """``vf.ifelse`` (tests joined by ``&``, a test of the time), ``vf.abs``, ``vf.sign`` -- the reference's IfElseFunction,
+    ConditionalStatement and SignFunction (CommonFunctions/Conditional.h:19-260): value, Jacobian, adjoint gradient and adjoint Hessian
+    are those of the branch the test picks.  Against the oracle's AD2 derivatives of the same right-hand side written with plain C++
+    branches (oracle/odes.h: switched), at points on every side of every test."""
+    from helpers import make_switched
+    ode = make_switched()
+    d = ode.derivatives()
+    o = oracle.get_ode("switched", 0)
+    N, n = d.nin, d.xv
+    rng = np.random.default_rng(0)
+    sides = set()
+    fn = C.CFUNCTYPE(None, *([C.c_void_p] * 7))(o.fjgh)
+    for _ in range(300):
+        y = rng.uniform(-1, 1, N)
+        y[2] = rng.uniform(0, 10)
+        lam = rng.uniform(-1, 1, n)
+        sides.add((y[0] > 0.25 and y[1] >= 0.0, y[2] < 5.0, y[1] > 0))
+        f, J, g, H = np.zeros(n), np.zeros((n, N)), np.zeros(N), np.zeros((N, N))
+        fn(y.ctypes.data, lam.ctypes.data, f.ctypes.data, J.ctypes.data, g.ctypes.data, H.ctypes.data, o.ctx)
+        assert rel_err(evaluate(d.f, y), f) < 1e-14
+        assert rel_err(np.array(evaluate([e for r in d.J for e in r], y)).reshape(n, N), J) < 1e-13
+        assert rel_err(evaluate(d.g, y, lam), g) < 1e-13
+        Hs = np.array(evaluate([d.H[max(i, j)][min(i, j)] for i in range(N) for j in range(N)], y, lam)).reshape(N, N)
+        assert rel_err(Hs, H) < 1e-13
+    assert len(sides) == 6                     # (every reachable combination: the stiff branch needs x1 >= 0)
+    # the printers: a condition is printed inside its select, in C and in the device functor
+    assert "? " in emit_c(d, "ode_switched") and "&&" in emit_hip_functor(d, "OdeSwitched")
+    with pytest.raises(ValueError):
+        vf.ifelse(vf.Arguments(2)[0], 1.0, 2.0)                       # the test must be a comparison

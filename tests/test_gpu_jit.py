@@ -252,3 +252,20 @@ def test_composed_user_ode_block_form_against_flat_form(mode, blocked):
         assert rel_err(J.T @ w.L[w.cindex[V]], agx[V]) < 1e-12 and rel_err(H, H.T) == 0.0
     eb.close()
     ef.close()
+
+
+@pytest.mark.parametrize("mode,blocked", [("LGL5", False), ("LGL7", True), ("Trapezoidal", False)])
+def test_user_ode_with_conditionals_matches_oracle(oracle, mode, blocked):
+    """``vf.ifelse`` / ``vf.abs`` / ``vf.sign`` on the device (round 6; the reference's IfElseFunction, ConditionalStatement,
+    SignFunction: CommonFunctions/Conditional.h:19-260): a switched oscillator whose lanes take different branches, run-time
+    compiled, against the oracle's AD2 derivatives of the same right-hand side written with C++ branches (oracle/odes.h: switched)."""
+    from helpers import make_switched
+    name = jit.ensure_kernel(make_switched(), mode, blocked)
+    w = Workload("switched", mode, 83, blocked, sizes=(2, 1, 0), var_offset=1, con_offset=2, extra_vars=2)
+    nlp = oracle.Nlp(oracle.get_ode("switched", 0), oracle.MODES[mode], w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal, 2)
+    ev = DefectEvaluator(name, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    for what in (JAC_ADJGRAD_HESS, CON, CON_ADJGRAD, JAC, JAC_ADJGRAD):
+        ref = nlp.eval_blocks(what, w.X, w.L)
+        got = ev.eval(what, w.X, w.L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
+        _check_blocks(got, ref, w, what)
+    ev.close()
