@@ -17,3 +17,7 @@ for l in open("gpurun_out/r6_bench_all.jsonl"):
     r = d["roofline"]
     print(d["config"]["name"], "ms/step %.4f" % d["ms_per_step"], "frac %.3f" % r["frac"], "fp64 %.3f" % ((r.get("fp64") or {}).get("frac", float("nan"))))
 PY
+# compute-only time of the north-star launch (no block stores: a null KKT pointer), both forms
+python3 tools/attic/dbg_nostore.py reentry LGL7 10000 > gpurun_out/r6_nostore.txt 2>&1
+ASSET_HIP_TUNING=1 ASSET_HIP_NO_ALT_FORM=1 python3 tools/attic/dbg_nostore.py reentry LGL7 10000 >> gpurun_out/r6_nostore.txt 2>&1
+cat gpurun_out/r6_nostore.txt
