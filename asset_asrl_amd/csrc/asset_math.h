@@ -46,3 +46,22 @@ ASSET_MATH_FN void asset_sincos(double x, double* sp, double* cp) {
 ASSET_MATH_FN double asset_sin(double x) { double s, c; asset_sincos(x, &s, &c); return s; }
 ASSET_MATH_FN double asset_cos(double x) { double s, c; asset_sincos(x, &s, &c); return c; }
 ASSET_MATH_FN double asset_tan(double x) { double s, c; asset_sincos(x, &s, &c); return s / c; }
+
+// Tabulated data in a generated body (vf.InterpTable1D; the reference's InterpTable1D::get_telem, CommonFunctions/InterpTable1D.h:181-197):
+// the element of the abscissae t falls into, clamped to [0, n-2] -- by division where they are evenly spaced, by bisection elsewhere.
+// Returned as a double: the generated bodies hold doubles only, and the conversions fold into the address arithmetic.
+ASSET_MATH_FN double asset_tab_even(double t, double t0, double step, int n) {
+  int e = static_cast<int>((t - t0) / step);
+  e = e < n - 2 ? e : n - 2;
+  return static_cast<double>(e > 0 ? e : 0);
+}
+ASSET_MATH_FN double asset_tab_find(const double* ts, int n, double t) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ts[mid] <= t) lo = mid + 1; else hi = mid;
+  }
+  int e = lo - 1;
+  e = e < n - 2 ? e : n - 2;
+  return static_cast<double>(e > 0 ? e : 0);
+}

@@ -26,7 +26,9 @@ from dataclasses import dataclass
 from typing import Dict, List, Sequence, Tuple
 
 from .functions import VectorFunction
-from .ir import COND_OPS
+import numpy as np
+
+from .ir import COND_OPS, TABLES
 from .ir import GRAPH as G
 from .ir import Node, topo_order
 
@@ -489,7 +491,8 @@ class _Printer:
     unless needed elsewhere).  ``pair_sincos``: emit one ``sincos`` for a sin/cos pair on the same argument (device)."""
 
     def __init__(self, roots: Sequence[Node], yname="y{}", lname="l{}", loaded=None, pair_sincos=False,
-                 level_order=False):
+                 level_order=False, tabprefix=""):
+        self.tabprefix = tabprefix           # plain C: the table arrays and look-ups are file-scope names of this function's own
         self.names: Dict[int, str] = {}
         self.lines: List[str] = []
         self.used_y = set()
@@ -583,6 +586,14 @@ class _Printer:
             return f"atan2({a[0]}, {a[1]})"
         if op == "select":
             return f"{a[0]} ? {a[1]} : {a[2]}"
+        if op == "tabloc":                  # InterpTable1D.h:181-197 (get_telem): evenly spaced abscissae by division, others by bisection
+            tab = TABLES[n.value]
+            if tab.teven:
+                return f"{self.tabprefix or 'asset_'}tab_even({a[0]}, {_cnum(tab.ts[0])}, {_cnum(tab.ts[1] - tab.ts[0])}, {tab.tsize})"
+            return f"{self.tabprefix or 'asset_'}tab_find({self.tabprefix}TAB_{n.value}_t, {tab.tsize}, {a[0]})"
+        if op == "tabget":
+            dg, arr, row, off = n.value
+            return f"{self.tabprefix}TAB_{dg}_{arr}[{row * TABLES[dg].tsize + off} + (int){a[0]}]"
         if op == "abs":
             return f"fabs({a[0]})"
         if op == "sign":
@@ -590,6 +601,38 @@ class _Printer:
         if self.device_math and op in ("sin", "cos", "tan"):
             return f"asset_{op}({a[0]})"
         return f"{op}({a[0]})"
+
+
+def table_arrays(roots: Sequence[Node]) -> List[Tuple[str, List[float]]]:
+    """[(array name, numbers)] of every table array the expressions read (sorted: the same function prints the same code)."""
+    need = set()
+    for n in topo_order(roots):
+        if n.op == "tabget":
+            need.add((n.value[0], n.value[1]))
+        elif n.op == "tabloc" and not TABLES[n.value].teven:
+            need.add((n.value, "t"))
+    out = []
+    for dg, arr in sorted(need):
+        tab = TABLES[dg]
+        data = tab.ts if arr == "t" else (tab.vs if arr == "v" else tab.dvs_dts)
+        out.append((f"TAB_{dg}_{arr}", [float(v) for v in np.asarray(data, dtype=float).ravel()]))
+    return out
+
+
+# the two look-ups as plain C (the device has them in csrc/asset_math.h)
+TABLE_HELPERS_C = """static inline double asset_tab_even(double t, double t0, double step, int n) {
+  int e = (int)((t - t0) / step);
+  e = e < n - 2 ? e : n - 2;
+  return (double)(e > 0 ? e : 0);
+}
+static inline double asset_tab_find(const double* ts, int n, double t) {
+  int lo = 0, hi = n;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (ts[mid] <= t) lo = mid + 1; else hi = mid; }
+  int e = lo - 1;
+  e = e < n - 2 ? e : n - 2;
+  return (double)(e > 0 ? e : 0);
+}
+"""
 
 
 def _powi_expr(x: str, n: int) -> str:
@@ -654,6 +697,8 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     o.append(arr("HPOS", [hpos.get(e, -1) for e in range(N * (N + 1) // 2)]))
     o.append(arr("JIDX", jnz))
     o.append(arr("HIDX", hnz))
+    for nm, vals in table_arrays(_level_roots(d, 2)):       # tabulated data (vf.InterpTable1D): constant arrays of the module
+        o.append(f"  static constexpr double {nm}[{len(vals)}] = {{{', '.join(_cnum(v) for v in vals)}}};")
     saved = saved_nodes(d)
     o.insert(-1, f"  static constexpr int NSAVE = {len(saved)};   // transcendental values f_save() hands to fjgh_load()")
     # Large bodies (Betts low-thrust: 7 800 operations for value + J + g + H, ~780 values live at the peak) are emitted
@@ -873,6 +918,11 @@ def emit_c(d: OdeDerivatives, prefix: str) -> str:
     N, n = d.nin, d.xv
     o: List[str] = ["#include <math.h>",
                     f"/* generated by asset_asrl_amd/vf/codegen.py -- ODE '{d.name}' */"]
+    tabs = table_arrays(_level_roots(d, 2))
+    if tabs:
+        o.append(TABLE_HELPERS_C.replace("asset_tab_", f"{prefix}_tab_"))
+        for nm, vals in tabs:
+            o.append(f"static const double {prefix}_{nm}[{len(vals)}] = {{{', '.join(_cnum(v) for v in vals)}}};")
     sigs = [
         f"void {prefix}_f(const double* y, double* f)",
         f"void {prefix}_fj(const double* y, double* f, double* J)",
@@ -880,7 +930,7 @@ def emit_c(d: OdeDerivatives, prefix: str) -> str:
     ]
     for level, sig in enumerate(sigs):
         low = lower_reciprocals(_level_roots(d, level))
-        p = _Printer(low, yname="y[{}]", lname="lam[{}]")
+        p = _Printer(low, yname="y[{}]", lname="lam[{}]", tabprefix=f"{prefix}_" if tabs else "")
         it = iter(low)
         o.append(sig + " {")
         o += ["  " + ln for ln in p.lines]

@@ -19,6 +19,7 @@ from .ir import GRAPH as G
 from .ir import Node, evaluate
 
 Number = Union[int, float, np.floating, np.integer]
+builtins_abs = abs      # (the module defines ``abs`` as a function of expressions further down)
 
 
 def _is_num(x) -> bool:
@@ -485,3 +486,201 @@ def ConstantVector(irows: int, v) -> VectorFunction:
 
 def ConstantScalar(irows: int, v: float) -> VectorFunction:
     return VectorFunction(irows, [G.const(v)])
+
+
+class InterpTable1D:
+    """Tabulated data ``v(t)`` interpolated along one axis, cubic (Hermite, nodal slopes from five-point differences) or linear,
+    usable as a number-in / number-out interpolant on the host and as a node of an ODE or function expression -- the reference's
+    ``InterpTable1D`` and ``InterpFunction1D`` (/root/reference/src/VectorFunctions/CommonFunctions/InterpTable1D.h:9-320, 322-401).
+
+    Constructors as the reference binds them (:409-424): ``(ts, Vs, axis=0, kind="cubic")`` with ``Vs`` a vector or a matrix whose
+    `axis` runs along ``ts`` (0: rows are samples), or ``(Vts, tvar=-1, kind="cubic")`` with a list of value-time vectors.
+
+    In an expression (``tab(tfunc)``, ``tab.sf()``, ``tab.vf()``) the table becomes CONSTANT ARRAYS of the compiled module and two
+    piecewise-constant nodes -- the element ``t`` falls into, and entries of the arrays at that element (vf/ir.py: tabloc / tabget);
+    the Hermite polynomial on top of them is an ordinary expression, so value, Jacobian and adjoint Hessian of anything built on a
+    table come from the same symbolic rules as every other node (the reference hand-writes them: :219-256, :337-400)."""
+
+    def __init__(self, *args, **kw):
+        names = ("ts", "Vs", "axis", "kind")
+        if args and isinstance(args[0], (list, tuple)) and len(args[0]) and np.ndim(args[0][0]) == 1 and (len(args) < 2 or _is_num(args[1]) or isinstance(args[1], str)) \
+                and "Vs" not in kw:
+            # (Vts, tvar=-1, kind="cubic"): InterpTable1D.h:43-79
+            Vts = [np.asarray(v, dtype=float).ravel() for v in args[0]]
+            rest = list(args[1:])
+            tvar = kw.get("tvar", rest.pop(0) if rest and _is_num(rest[0]) else -1)
+            kind = kw.get("kind", rest.pop(0) if rest else "cubic")
+            if len(Vts) == 0:
+                raise ValueError("Input is empty")
+            m = Vts[0].size
+            if m < 2:
+                raise ValueError("Invalid sized value-time data.")
+            if tvar < 0:
+                tvar += m
+            if tvar > m - 1 or tvar < 0:
+                raise ValueError("Invalid time variable index")
+            if any(v.size != m for v in Vts):
+                raise ValueError("All value-time vectors must have same size")
+            A = np.stack(Vts, axis=1)                         # [m, samples]
+            self._set_data(A[tvar], np.delete(A, tvar, axis=0), 1, kind)
+            return
+        a = dict(zip(names, args))
+        a.update(kw)
+        Vs = np.asarray(a["Vs"], dtype=float)
+        if Vs.ndim == 1:                                        # a vector of values: one output (:39-42)
+            self._set_data(a["ts"], Vs[None, :], 1, a.get("kind", "cubic"))
+        else:
+            self._set_data(a["ts"], Vs, a.get("axis", 0), a.get("kind", "cubic"))
+
+    # ---- InterpTable1D.h:80-131
+    def _set_data(self, ts, Vs, axis, kind):
+        self.ts = np.asarray(ts, dtype=float).ravel().copy()
+        if axis == 1:
+            self.vs = np.array(Vs, dtype=float)
+        elif axis == 0:
+            self.vs = np.array(Vs, dtype=float).T.copy()
+        else:
+            raise ValueError("Interpolation axis must be 0 or 1")
+        self.axis = int(axis)
+        if kind in ("cubic", "Cubic"):
+            self.kind = "cubic"
+        elif kind in ("linear", "Linear"):
+            self.kind = "linear"
+        else:
+            raise ValueError("Unrecognized interpolation type")
+        self.tsize = int(self.ts.size)
+        self.vlen = int(self.vs.shape[0])
+        if self.tsize < 5:
+            raise ValueError("t coordinates must be larger than 4")
+        if self.tsize != self.vs.shape[1]:
+            raise ValueError("Length of t coordinates must match length of interpolation axis")
+        if np.any(np.diff(self.ts) < 0):
+            raise ValueError("t Coordinates must be in ascending order")
+        self.ttotal = float(self.ts[-1] - self.ts[0])
+        even = np.linspace(self.ts[0], self.ts[-1], self.tsize)
+        self.teven = bool(np.max(np.abs(self.ts - even)) <= builtins_abs(self.ttotal) * 1.0e-12)
+        self.WarnOutOfBounds, self.ThrowOutOfBounds = True, False
+        self.dvs_dts = self._nodal_slopes() if self.kind == "cubic" else np.zeros_like(self.vs)
+        import hashlib
+        h = hashlib.blake2b(digest_size=8)
+        for part in (self.kind.encode(), self.ts.tobytes(), np.ascontiguousarray(self.vs).tobytes(), str(self.vs.shape).encode()):
+            h.update(part)
+        self.digest = h.hexdigest()
+        from .ir import TABLES
+        TABLES[self.digest] = self
+
+    def _nodal_slopes(self):
+        """dv/dt at every abscissa from the five-point difference formula exact for quartics on the points around it (centred inside,
+        one-sided at the two ends on either side): the weights solve the 5 x 5 moment system in the scaled offsets
+        (InterpTable1D.h:134-179)."""
+        n = self.tsize
+        d = np.empty_like(self.vs)
+        rhs = np.array([0.0, 1.0, 0.0, 0.0, 0.0])
+        for i in range(n):
+            if 2 <= i <= n - 3:
+                start = i - 2
+            elif i < n - 1 - i:
+                start = 0
+            else:
+                start = n - 5
+            step = builtins_abs(self.ts[i + (1 if i < n - 1 else -1)] - self.ts[i])
+            off = (self.ts[start:start + 5] - self.ts[i]) / step
+            w = np.linalg.solve(np.vander(off, 5, increasing=True).T, rhs)
+            d[:, i] = self.vs[:, start:start + 5] @ (w / step)
+        return d
+
+    # ---- InterpTable1D.h:181-197
+    def locate(self, t: float) -> int:
+        if self.teven:
+            e = int((t - self.ts[0]) / (self.ts[1] - self.ts[0]))
+        else:
+            e = int(np.searchsorted(self.ts, t, side="right")) - 1
+        return max(min(e, self.tsize - 2), 0)
+
+    def _check_bounds(self, t):
+        if self.WarnOutOfBounds or self.ThrowOutOfBounds:
+            eps = np.finfo(float).eps * self.ttotal
+            if t < self.ts[0] - eps or t > self.ts[-1] + eps:
+                msg = f"WARNING: t= {t} falls outside of InterpTable1D time range. Data is being extrapolated!!"
+                if self.ThrowOutOfBounds:
+                    raise ValueError(msg)
+                import warnings
+                warnings.warn(msg)
+
+    def _interp(self, t: float, deriv: int):
+        """(v, dv/dt, d2v/dt2) up to `deriv`: InterpTable1D.h:199-267."""
+        t = float(t)
+        self._check_bounds(t)
+        e = self.locate(t)
+        step = self.ts[e + 1] - self.ts[e]
+        x = (t - self.ts[e]) / step
+        v0, v1, d0, d1 = self.vs[:, e], self.vs[:, e + 1], self.dvs_dts[:, e], self.dvs_dts[:, e + 1]
+        out = []
+        if self.kind == "cubic":
+            x2, x3 = x * x, x * x * x
+            out.append(v0 * (2 * x3 - 3 * x2 + 1) + v1 * (-2 * x3 + 3 * x2) + d0 * ((x3 - 2 * x2 + x) * step) + d1 * ((x3 - x2) * step))
+            if deriv > 0:
+                out.append(v0 * ((6 * x2 - 6 * x) / step) + v1 * ((-6 * x2 + 6 * x) / step) + d0 * (3 * x2 - 4 * x + 1) + d1 * (3 * x2 - 2 * x))
+            if deriv > 1:
+                out.append(v0 * ((12 * x - 6) / step ** 2) + v1 * ((-12 * x + 6) / step ** 2) + d0 * ((6 * x - 4) / step) + d1 * ((6 * x - 2) / step))
+        else:
+            out.append(v0 * (1 - x) + v1 * x)
+            if deriv > 0:
+                out.append((v1 - v0) / step)
+            if deriv > 1:
+                out.append(np.zeros(self.vlen))
+        return out
+
+    def interp(self, t):
+        if np.ndim(t) == 0:
+            return self._interp(t, 0)[0]
+        return np.stack([self._interp(x, 0)[0] for x in np.asarray(t, dtype=float).ravel()], axis=1)
+
+    def interp_deriv1(self, t):
+        return tuple(self._interp(t, 1))
+
+    def interp_deriv2(self, t):
+        return tuple(self._interp(t, 2))
+
+    # ---- as an expression: InterpFunction1D (InterpTable1D.h:322-401) and the binds at :434-479
+    def _nodes(self, t: Node) -> List[Node]:
+        dg = self.digest
+        loc = G.tabloc(dg, t)
+        t0 = G.tabget(dg, "t", 0, 0, loc)
+        if self.teven:
+            step = G.const(self.ts[1] - self.ts[0])
+        else:
+            step = G.sub(G.tabget(dg, "t", 0, 1, loc), t0)
+        x = G.div(G.sub(t, t0), step)
+        outs = []
+        if self.kind == "cubic":
+            x2 = G.mul(x, x)
+            x3 = G.mul(x2, x)
+            c = G.const
+            p0 = G.add(G.sub(G.mul(c(2.0), x3), G.mul(c(3.0), x2)), G.one)
+            p1 = G.sub(G.mul(c(3.0), x2), G.mul(c(2.0), x3))
+            m0 = G.mul(G.add(G.sub(x3, G.mul(c(2.0), x2)), x), step)
+            m1 = G.mul(G.sub(x3, x2), step)
+        for k in range(self.vlen):
+            v0, v1 = G.tabget(dg, "v", k, 0, loc), G.tabget(dg, "v", k, 1, loc)
+            if self.kind == "cubic":
+                d0, d1 = G.tabget(dg, "d", k, 0, loc), G.tabget(dg, "d", k, 1, loc)
+                outs.append(G.sum([G.mul(v0, p0), G.mul(v1, p1), G.mul(d0, m0), G.mul(d1, m1)]))
+            else:
+                outs.append(G.add(G.mul(v0, G.sub(G.one, x)), G.mul(v1, x)))
+        return outs
+
+    def __call__(self, t):
+        if isinstance(t, VectorFunction):
+            if t.ORows() != 1:
+                raise ValueError("InterpTable1D: the argument is a scalar function")
+            return VectorFunction(t._irows, self._nodes(t.outs[0]))
+        return self.interp(t)
+
+    def sf(self) -> "VectorFunction":
+        if self.vlen != 1:
+            raise ValueError("InterpTable1D storing Vector data cannot be converted to Scalar Function.")
+        return self(Arguments(1))
+
+    def vf(self) -> "VectorFunction":
+        return self(Arguments(1))

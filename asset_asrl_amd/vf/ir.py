@@ -30,6 +30,12 @@ _BINARY = ("add", "sub", "mul", "div", "atan2")
 _COMPARE = ("lt", "le", "gt", "ge")
 _LOGIC = ("and", "or")
 COND_OPS = _COMPARE + _LOGIC
+# tabulated data (the reference's InterpTable1D, CommonFunctions/InterpTable1D.h): "tabloc" = the element of a table's abscissae its
+# argument falls into (get_telem, :181-197), "tabget" = an entry of one of the table's arrays at that element or the next.  Both are
+# piecewise constant in the argument -- no derivative -- and the interpolant itself is an ordinary expression built on them
+# (functions.py: InterpTable1D), so its first and second derivatives come from the rules of this file
+TABLE_OPS = ("tabloc", "tabget")
+TABLES: Dict[str, object] = {}      # digest -> table (anything with .ts, .vs, .dvs_dts, .teven, .locate): registered by InterpTable1D
 
 
 class Node:
@@ -248,6 +254,18 @@ class Graph:
             return self.const(math.atan2(a.value, b.value))
         return self._mk("atan2", (a, b))
 
+    def tabloc(self, digest: str, t: Node) -> Node:
+        """The element of table `digest` that t falls into, as a number (0 .. tsize-2)."""
+        if t.is_const():
+            return self.const(float(TABLES[digest].locate(t.value)))
+        return self._mk("tabloc", (t,), digest)
+
+    def tabget(self, digest: str, arr: str, row: int, off: int, loc: Node) -> Node:
+        """Entry ``[row, loc + off]`` of the table's array `arr` ('t': abscissae, 'v': values, 'd': nodal derivatives)."""
+        if loc.is_const():
+            return self.const(float(_tab_entry(TABLES[digest], arr, row, int(loc.value) + off)))
+        return self._mk("tabget", (loc,), (digest, arr, int(row), int(off)))
+
     # ---- n-ary helpers -------------------------------------------------------------
     def sum(self, xs: Iterable[Node]) -> Node:
         acc = self.zero
@@ -277,7 +295,7 @@ class Graph:
             return self.one if n is w else self.zero
         if op == "cut":                        # a barrier: the partial derivative (the total one is the builder's business)
             return self.one if n is w else self.zero
-        if op in ("aconst", "frozen") or op in COND_OPS:
+        if op in ("aconst", "frozen") or op in COND_OPS or op in TABLE_OPS:
             return self.zero
         if op == "select":                     # the derivative of the branch the test picks (Conditional.h:215-250); the test itself has none
             return self.select(n.args[0], self.d(n.args[1], w), self.d(n.args[2], w))
@@ -359,7 +377,7 @@ class Graph:
             op = n.op
             if op == "cut":                    # a barrier: its adjoint is read off by the caller, nothing flows into its argument
                 continue
-            if op in COND_OPS:
+            if op in COND_OPS or op in TABLE_OPS:
                 continue
             if op == "select":
                 c, a, b = n.args
@@ -449,6 +467,10 @@ class Graph:
             return self.logic(op, *args)
         if op == "select":
             return self.select(*args)
+        if op == "tabloc":
+            return self.tabloc(n.value, args[0])
+        if op == "tabget":
+            return self.tabget(*n.value, args[0])
         if op == "add":
             return self.add(*args)
         if op == "sub":
@@ -464,6 +486,12 @@ class Graph:
         if op == "powr":
             return self.powr(args[0], n.value)
         return self.unary(op, args[0])
+
+
+def _tab_entry(tab, arr: str, row: int, col: int) -> float:
+    if arr == "t":
+        return tab.ts[col]
+    return (tab.vs if arr == "v" else tab.dvs_dts)[row, col]
 
 
 _EVAL_COND = {"lt": lambda a, b: a < b, "le": lambda a, b: a <= b, "gt": lambda a, b: a > b, "ge": lambda a, b: a >= b}
@@ -558,6 +586,11 @@ def evaluate(roots: Sequence[Node], y: Sequence[float], lam: Sequence[float] = (
             v = float(val[n.args[0].id] != 0.0 or val[n.args[1].id] != 0.0)
         elif op == "select":
             v = val[n.args[1].id] if val[n.args[0].id] != 0.0 else val[n.args[2].id]
+        elif op == "tabloc":
+            v = float(TABLES[n.value].locate(val[n.args[0].id]))
+        elif op == "tabget":
+            dg, arr, row, off = n.value
+            v = float(_tab_entry(TABLES[dg], arr, row, int(val[n.args[0].id]) + off))
         else:
             v = _EVAL_UNARY[op](val[n.args[0].id])
         val[n.id] = v

@@ -58,7 +58,7 @@ def build_native() -> str:
     srcs = [os.path.join(_HERE, f) for f in ("defect.cpp", "nlp.cpp", "mesh.cpp", "pathfuncs.cpp", "fullnlp.cpp", "odes.cpp")]
     gen = os.path.join(_HERE, "gen", "odes_gen.c")
     gen4 = os.path.join(_HERE, "gen", "odes_gen4.c")          # the same bodies over four segments at once (batch4.h)
-    deps = srcs + [gen, gen4] + [os.path.join(_HERE, f) for f in ("odes.h", "ad2.h", "lgl_coeffs.h", "oracle.h", "batch4.h")]
+    deps = srcs + [gen, gen4] + [os.path.join(_HERE, f) for f in ("odes.h", "interp_table.h", "ad2.h", "lgl_coeffs.h", "oracle.h", "batch4.h")]
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
         return so
     flags = ["-O2", "-march=native", "-ffast-math", "-fPIC"]
@@ -93,6 +93,9 @@ def lib(path=None):
         L = C.CDLL(path or build())
         L.oracle_get_ode.argtypes = [C.c_char_p, C.c_int, C.POINTER(OdeStruct)]
         L.oracle_set_synthetic32.argtypes = [_dp]
+        L.oracle_table_sizes.argtypes = [C.c_int, _ip, _ip, _ip, _ip]
+        L.oracle_table_data.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.oracle_table_interp.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp]
         L.oracle_defect_sizes.argtypes = [C.c_int] * 5 + [_ip, _ip]
         L.oracle_defect_compute.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, _dp, _dp]
         L.oracle_defect_jacobian.argtypes = [C.POINTER(OdeStruct), C.c_int, C.c_int, _dp, _dp, _dp]
@@ -164,6 +167,25 @@ def get_ode(name: str, provider: int = 0) -> OdeStruct:
     if rc:
         raise KeyError(f"oracle ODE {name!r} provider {provider}: rc={rc}")
     return o
+
+
+def table(which: int):
+    """(ts, vs[vlen, n], dvs_dts[vlen, n], even, cubic) of table `which` of the `tabulated` ODE (interp_table.h)."""
+    sz = [C.c_int() for _ in range(4)]
+    if lib().oracle_table_sizes(which, *[C.byref(x) for x in sz]):
+        raise KeyError(which)
+    n, vlen, even, cubic = (x.value for x in sz)
+    ts, vs, ds = np.empty(n), np.empty((vlen, n)), np.empty((vlen, n))
+    lib().oracle_table_data(which, _d(ts), _d(vs), _d(ds))
+    return ts, vs, ds, bool(even), bool(cubic)
+
+
+def table_interp(which: int, t: float):
+    """(v, dv/dt, d2v/dt2) of table `which` at t."""
+    vlen = table(which)[1].shape[0]
+    out = [np.empty(vlen) for _ in range(3)]
+    lib().oracle_table_interp(which, float(t), *[_d(x) for x in out])
+    return out
 
 
 def lgl_table(cs: int, which: str) -> np.ndarray:

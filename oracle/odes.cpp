@@ -60,6 +60,7 @@ AD2_ODE(betts_lowthrust, 7, 3, 1)
 AD2_ODE(synthetic32, 32, 0, 0)
 AD2_ODE(vanderpol, 2, 1, 1)
 AD2_ODE(switched, 2, 1, 0)
+AD2_ODE(tabulated, 2, 1, 0)
 AD2_ODE(coupled12, 12, 3, 2)
 AD2_ODE(coupled16, 16, 3, 2)
 AD2_ODE(driven14, 14, 3, 0)
@@ -120,6 +121,7 @@ GEN_DECL(betts_lowthrust)
 GEN_DECL(synthetic32)
 GEN_DECL(vanderpol)
 GEN_DECL(switched)
+GEN_DECL(tabulated)
 GEN_DECL(coupled12)
 GEN_DECL(coupled16)
 GEN_DECL(driven14)
@@ -159,6 +161,28 @@ extern "C" {
 
 void oracle_set_synthetic32(const double* abc) { std::memcpy(g_synth32, abc, sizeof g_synth32); }
 
+// the restated InterpTable1D on the tables of the `tabulated` ODE (interp_table.h): sizes, arrays, and one evaluation
+int oracle_table_sizes(int which, int* n, int* vlen, int* even, int* cubic) {
+  if (which < 0 || which > 2) return -1;
+  const oracle_odes::OTable& T = oracle_odes::tabulated_table(which);
+  *n = T.n, *vlen = T.vlen, *even = T.even, *cubic = T.cubic;
+  return 0;
+}
+int oracle_table_data(int which, double* ts, double* vs, double* ds) {
+  if (which < 0 || which > 2) return -1;
+  const oracle_odes::OTable& T = oracle_odes::tabulated_table(which);
+  std::memcpy(ts, T.ts.data(), sizeof(double) * T.n);
+  std::memcpy(vs, T.vs.data(), sizeof(double) * T.n * T.vlen);
+  std::memcpy(ds, T.ds.data(), sizeof(double) * T.n * T.vlen);
+  return 0;
+}
+int oracle_table_interp(int which, double t, double* v, double* dv, double* d2v) {
+  if (which < 0 || which > 2) return -1;
+  const oracle_odes::OTable& T = oracle_odes::tabulated_table(which);
+  for (int q = 0; q < T.vlen; q++) T.interp(q, t, v[q], dv[q], d2v[q]);
+  return 0;
+}
+
 #define TRY(NAME, XV, UV, PV, CTX)                                                  \
   if (!std::strcmp(name, #NAME)) {                                                  \
     out->xv = XV, out->uv = UV, out->pv = PV, out->ctx = CTX;                       \
@@ -189,6 +213,7 @@ int oracle_get_ode4(const oracle_ode* ode, oracle_ode4* out) {
   TRY4(synthetic32)
   TRY4(vanderpol)
   TRY4(switched)
+  TRY4(tabulated)
   TRY4(coupled12)
   TRY4(coupled16)
   TRY4(driven14)
@@ -236,6 +261,7 @@ int oracle_get_ode(const char* name, int provider, oracle_ode* out) {
   TRY(synthetic32, 32, 0, 0, g_synth32)
   TRY(vanderpol, 2, 1, 1, nullptr)
   TRY(switched, 2, 1, 0, nullptr)
+  TRY(tabulated, 2, 1, 0, nullptr)
   TRY(coupled12, 12, 3, 2, nullptr)
   TRY(coupled16, 16, 3, 2, nullptr)
   TRY(driven14, 14, 3, 0, nullptr)

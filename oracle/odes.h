@@ -13,6 +13,7 @@
 #include <cstdint>
 
 #include "ad2.h"
+#include "interp_table.h"
 
 namespace oracle_odes {
 
@@ -59,6 +60,20 @@ void switched(const S* y, S* f, const void*) {
   const double dir = (valof(x1) > 0.0) - (valof(x1) < 0.0);          // sign(x1): piecewise constant, no derivative
   f[0] = x1 + (valof(t) < 5.0 ? S(0.1 * sin(x0)) : S(0.0 * x0));
   f[1] = -1.0 * spring - 0.3 * absv(x1) * x1 - 0.05 * dir + u * cos(t);
+}
+
+// ------------------------------------------------------------------ a sounding rocket on tabulated data (2,1,0): InterpTable1D
+// Not a BASELINE config: the independent check for tables in a device body (round 6; the reference's InterpTable1D / InterpFunction1D,
+// CommonFunctions/InterpTable1D.h).  Density over the altitude from a cubic table with UNEVEN abscissae, thrust over time from a linear
+// one, a two-valued cubic table over the speed.  tests/helpers.py: make_tabulated defines the same right-hand side with vf.InterpTable1D.
+template <class S>
+void tabulated(const S* y, S* f, const void*) {
+  const S &x0 = y[0], &x1 = y[1], &t = y[2], &u = y[3];
+  const S rho = tab_eval(tabulated_table(0), 0, x0);
+  const S thr = tab_eval(tabulated_table(1), 0, t);
+  const S w0 = tab_eval(tabulated_table(2), 0, x1), w1 = tab_eval(tabulated_table(2), 1, x1);
+  f[0] = x1 + 0.1 * w0 * w1;
+  f[1] = u * thr - 0.05 * rho * x1 * x1 - 1.0;
 }
 
 // ------------------------------------------------------------------ coupled oscillators (12,3,2): wide shapes with u and p

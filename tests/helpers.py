@@ -278,3 +278,39 @@ def make_switched():
             super().__init__(vf.stack([f0, f1]), 2, 1, 0, name="switched")
 
     return Switched()
+
+
+def tabulated_tables():
+    """The three tables of the oracle's `tabulated` ODE (oracle/interp_table.h: tabulated_table), built here from the same
+    arithmetic as ``vf.InterpTable1D`` objects through three of the reference's constructors (InterpTable1D.h:409-424)."""
+    from asset_asrl_amd import vf
+    i = np.arange(25, dtype=float)
+    h = -1.5 + 0.1 * i + 0.004 * i * i
+    density = vf.InterpTable1D(h, 1.2 / (1.0 + 0.5 * (h + 1.0) * (h + 1.0)), kind="cubic")              # (ts, vector)
+    i = np.arange(21, dtype=float)
+    thrust = vf.InterpTable1D([np.array([1.0 + 0.05 * k - 0.004 * k * k, -0.25 + 0.537 * k]) for k in i], -1, "linear")   # value-time vectors
+    s = -2.0 + 0.25 * np.arange(17, dtype=float)
+    wind = vf.InterpTable1D(s, np.column_stack([0.3 * s * s - 0.1 * s, 1.0 / (2.5 + s)]), axis=0, kind="cubic")   # (ts, matrix, axis)
+    return density, thrust, wind
+
+
+def make_tabulated():
+    """A user ODE on tabulated data (2, 1, 0): a cubic table with uneven abscissae over a state, a linear one over the time, a
+    two-valued cubic one over the other state -- the reference's InterpTable1D in an ODE (CommonFunctions/InterpTable1D.h:9-401).
+    The oracle holds the same right-hand side as ``tabulated`` (oracle/odes.h) over its own restatement of the table
+    (oracle/interp_table.h), differentiated by AD2 with the reference's hand-written dv/dt and d2v/dt2."""
+    from asset_asrl_amd import vf
+    from asset_asrl_amd.ode import ODEArguments, ODEBase
+    density, thrust, wind = tabulated_tables()
+
+    class Tabulated(ODEBase):
+        def __init__(self):
+            a = ODEArguments(2, 1, 0)
+            x0, x1 = a.XVec().tolist()
+            t, u = a.TVar(), a.UVar(0)
+            w = wind(x1)
+            f0 = x1 + 0.1 * w[0] * w[1]
+            f1 = u * thrust(t) - 0.05 * density(x0) * x1 * x1 - 1.0
+            super().__init__(vf.stack([f0, f1]), 2, 1, 0, name="tabulated")
+
+    return Tabulated()

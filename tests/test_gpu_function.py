@@ -55,6 +55,28 @@ def test_path_constraint_matches_oracle_nlp(oracle):
     ev.close()
 
 
+def test_function_on_tabulated_data_matches_oracle_nlp(oracle):
+    """A plain function built on three ``vf.InterpTable1D`` tables, batched over applications that share variables (the reference's
+    InterpFunction1D inside a path function, CommonFunctions/InterpTable1D.h:322-401) -- against the oracle's NLP restatement over
+    the same right-hand side (oracle/odes.h: tabulated)."""
+    from helpers import make_tabulated
+    napp, ir, orr = 300, 4, 2
+    n_primal, n_equal = 2 * napp + 20, 2 * napp + 5
+    vindex, cindex, X, L = _tables(napp, ir, orr, n_primal, n_equal, 12)
+    X *= 2.4                                                               # past both ends of every table
+    ev = FunctionEvaluator(make_tabulated().vf(), "tabulated_fn", vindex, cindex, n_primal, n_equal)
+    nlp = oracle.Nlp(oracle.get_ode("tabulated", 0), oracle.MODES["Function"], False, vindex, cindex, n_primal, n_equal, 2)
+    for what in (JAC_ADJGRAD_HESS, CON, CON_ADJGRAD, JAC, JAC_ADJGRAD):
+        rfx, ragx, rkkt = nlp.eval_blocks(what, X, L)
+        fx, agx, kkt = ev.eval(what, X, L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
+        assert np.abs(fx - rfx).max() < 1e-10
+        if agx is not None:
+            assert rel_err(agx, ragx) < 1e-8
+        if kkt is not None:
+            assert rel_err(kkt, rkkt) < 1e-8
+    ev.close()
+
+
 def test_lgl_mesh_spacing_closed_form():
     cs, napp = 4, 100
     rng = np.random.default_rng(2)

@@ -269,3 +269,27 @@ def test_user_ode_with_conditionals_matches_oracle(oracle, mode, blocked):
         got = ev.eval(what, w.X, w.L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
         _check_blocks(got, ref, w, what)
     ev.close()
+
+
+@pytest.mark.parametrize("mode,blocked", [("LGL5", False), ("LGL7", True), ("Trapezoidal", False), ("LGL3", False)])
+def test_user_ode_on_tabulated_data_matches_oracle(oracle, mode, blocked):
+    """``vf.InterpTable1D`` on the device (round 6; the reference's InterpTable1D / InterpFunction1D, CommonFunctions/InterpTable1D.h):
+    a cubic table with uneven abscissae over a state (bisection per lane), a linear one over the time, a two-valued cubic one over the
+    other state -- constant arrays of the run-time compiled module -- against the oracle's AD2 derivatives of the same right-hand side
+    over its restatement of the reference's table formulas (oracle/odes.h: tabulated, oracle/interp_table.h).  The synthetic states
+    reach past both ends of the tables: the clamped element extrapolates, as in the reference."""
+    from helpers import make_tabulated
+    name = jit.ensure_kernel(make_tabulated(), mode, blocked)
+    w = Workload("tabulated", mode, 83, blocked, sizes=(2, 1, 0), var_offset=1, con_offset=2, extra_vars=2)
+    ix = w.indexer
+    S, xtu = ix.numStates, (ix.XtVars() if w.blocked else ix.XtUVars())    # (BlockConstant: the controls follow the states as a block)
+    st = w.X[1:1 + S * xtu].reshape(S, xtu)
+    st[:, 0] = np.random.default_rng(4).uniform(-1.8, 2.6, S)              # altitude: across (and beyond) the uneven table
+    st[:, 1] *= 2.2                                                        # speed: beyond the two-valued table at both ends
+    nlp = oracle.Nlp(oracle.get_ode("tabulated", 0), oracle.MODES[mode], w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal, 2)
+    ev = DefectEvaluator(name, mode, w.blocked, w.vindex, w.cindex, w.n_primal, w.n_equal)
+    for what in (JAC_ADJGRAD_HESS, CON, CON_ADJGRAD, JAC, JAC_ADJGRAD):
+        ref = nlp.eval_blocks(what, w.X, w.L)
+        got = ev.eval(what, w.X, w.L if what in (CON_ADJGRAD, JAC_ADJGRAD, JAC_ADJGRAD_HESS) else None)
+        _check_blocks(got, ref, w, what)
+    ev.close()
