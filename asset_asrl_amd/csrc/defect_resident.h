@@ -125,6 +125,11 @@ struct ResDims {
   static constexpr int x_T = x_Z4 + 4;             // (T_XTRA) [K][16][n] the J^ buffers of the ride + 16 dummy cells
   static constexpr int x_FLAG = x_T + (T_XTRA ? K * TB + 16 : 0);   // (EARLYC) the group whose cardinal second derivatives wave A has finished
   static constexpr int XTRA = x_FLAG + 2;
+  // (round 6, row-wise dense part at level 2: the rows of J as what they are -- adjoint gradients for UNIT multiplier vectors -- and the
+  //  adjoint gradient itself from the H passes, defect_rowdpp.h: UNITC.)  The time rows of the gradient need the segment's
+  //  FB = sum_j f_j . BM_j + sum_i E_i f^_i . lam_i: the ODE phases leave its CS + K terms -- a lane per node / interior point -- in eight
+  //  cells per slot laid over x_HT / x_CL / x_WL, which only the tile form uses.
+  static constexpr int x_FBL = x_HT, FBL_LD = 8;
   // waves per SIMD the kernel is built for (registers: 512 / WPS per lane; LDS: 160 KiB / 4 WPS per wave).  Shapes with two
   // row tiles of defect rows keep two more accumulators and a third column tile's fragments: at 256 registers they spill
   // 650 bytes per lane (TwoBody-LGL7 x 10 000: 149.5 us), with the SIMD to themselves they do not (89.1 us; round 2's kernel 102.7)
@@ -147,7 +152,13 @@ struct ResDims {
 #ifndef ASSET_RES_LOOP_PAIR
 #define ASSET_RES_LOOP_PAIR 1
 #endif
-  static constexpr bool LOOP_PAIR = ASSET_RES_LOOP_PAIR && RD_ANY;   // the looped level-2 kernel in two-wave workgroups too (row-wise part)
+  // the looped level-2 kernel in two-wave workgroups too (row-wise part) -- for right-hand sides heavy enough that sharing the ODE stage
+  // pays for the pair's barriers (measured after UNITC, profiles/r6_forms2.txt: Reentry, 411 operations, every shape and every looped mesh
+  // size 5-15 % faster as pairs -- LGL7 x 30 000 74 against 88 us, LGL5-BlockConstant x 1 000 000 1.79 / 1.94 ms; TwoBody, 186, every shape
+  // 10-25 % SLOWER -- LGL5-BlockConstant x 100 000 195 against 169 us, LGL3 x 1 000 000 1.29 / 1.01 ms; Brachistochrone, 35, within 3 %
+  // either way).  Light right-hand sides keep single-wave workgroups, whose waves drift apart and run one's ODE stage under another's stores.
+  static constexpr int LOOP_PAIR_MIN_OPS = 300;
+  static constexpr bool LOOP_PAIR = ASSET_RES_LOOP_PAIR && RD_ANY && Ode::OPS_FJGH >= LOOP_PAIR_MIN_OPS;
   // EARLYC (round 5): the cardinal value phase also leaves the Jacobians J_j in the slot (Ode::fj_save), so that the rows of [J ; g^T]
   // -- the C passes of the row-wise dense part, 45 % of a segment's bytes -- are formed and stored by one wave of the pair WHILE the
   // other runs the cardinal second-derivative phase: the stores start one phase earlier.
@@ -157,6 +168,10 @@ struct ResDims {
   static constexpr bool EARLYC = ASSET_RES_EARLYC && RD_ANY && PAIR;   // (of the kernels that run the row-wise part)
   static constexpr int GR_PASS = 64 / (CS * NWV);                   // one pass per phase covers the workgroup's group
   static constexpr int GR = GR_FIT < GR_PASS ? GR_FIT : GR_PASS;
+#ifndef ASSET_RD_UNITC
+#define ASSET_RD_UNITC 1
+#endif
+  static constexpr bool UNITC = ASSET_RD_UNITC && RD_ANY && CS + K <= FBL_LD && FBL_LD * (GR > 0 ? GR : 0) <= IRP + 2 * CS * n;
   static constexpr int REGION = D::TABSZ + (GR > 0 ? GR : 0) * SLOT + XTRA;   // a wave's LDS (doubles)
   static constexpr size_t lds_bytes() { return size_t(NWV * REGION) * 8; }
   // (two row tiles of defect rows -- TwoBody-LGL7, K n = 18: with three column tiles beside them a wave needs ~420 registers; such
@@ -249,7 +264,8 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_value(ld
 
 // P2: interior point i: x^, tau, u^ ; f^, J^, g^ = J^^T lam_i, H^ = lam_i^T d2f
 template <class Ode, class D, int LEVEL = 2, bool RDF = ResDims<D>::ROWDPP>
-__device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_double* S, int i, const LglTab* tabp, bool have_lam) {
+__device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_double* S, int i, const LglTab* tabp, bool have_lam,
+                                                                       lds_double* fbl = nullptr) {
   constexpr int n = D::n, m = D::m, q = D::q, N = D::N, T = D::T, CS = D::CS;
   const LglTab& tab = *tabp;
   const lds_double* z = S + D::w_z;
@@ -299,13 +315,19 @@ __device__ __attribute__((noinline, not_tail_called)) void res_interior(lds_doub
   } else {
     OdeOutRes<D> out{S + D::w_If + i * n, S + D::w_IJ + i * D::NZJ, S + D::w_Ig + i * N, S + D::w_IH + i * D::NZH, nullptr};
     Ode::fjgh(in, out);
+    if constexpr (RDF && ResDims<D>::UNITC) {   // E_i f^_i . lam_i: this point's term of the gradient's time rows (ResDims::x_FBL)
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < n; k++) acc = fma(have_lam ? lam[i * n + k] : 0.0, S[D::w_If + i * n + k], acc);
+      fbl[CS + i] = tab.E[i] * acc;
+    }
   }
 }
 
 // P3: cardinal node j: adjoint weights w_j (LGLDefects.h:369-374) ; J_j, g_j = J_j^T w_j, H_j = w_j^T d2f
 // (NOJ: J_j is in the slot already -- EARLYC -- and the partner wave is reading it: not stored again)
-template <class Ode, class D, bool NOJ = false>
-__device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(lds_double* S, int j, const LglTab* tabp) {
+template <class Ode, class D, bool NOJ = false, bool RDF = false>
+__device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(lds_double* S, int j, const LglTab* tabp, lds_double* fbl = nullptr) {
   constexpr int K = D::K, n = D::n, N = D::N, T = D::T;
   using R = ResDims<D>;
   const LglTab& tab = *tabp;
@@ -321,6 +343,12 @@ __device__ __attribute__((noinline, not_tail_called)) void res_cardinal_second(l
       acc += S[D::w_lam + i * n + k] * (tab.D[i][j] * h);
     }
     w[k] = acc;
+  }
+  if constexpr (RDF && ResDims<D>::UNITC) {        // f_j . w_j = h f_j . BM_j: this node's term of the gradient's time rows (ResDims::x_FBL)
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < n; k++) acc = fma(S[D::w_Cf + j * n + k], w[k], acc);
+    fbl[j] = acc;
   }
   double sv[Ode::NSAVE > 0 ? Ode::NSAVE : 1];      // (read before g_j is written: the two may share their cells)
 #pragma unroll
@@ -552,6 +580,8 @@ __global__ __launch_bounds__(64) void res_lane_setup_kernel(unsigned int* out) {
     if constexpr (ResDims<D>::RD_ANY) {
       for (int rec = threadIdx.x; rec < RdDims<Ode, D>::NRECH; rec += 64)
         rd_lane_setup<Ode, D, ResDims<D>::s_Z0>(out + res_table_words_tile<Ode, D>(), rec);
+      for (int rec = threadIdx.x; rec < RdDims<Ode, D>::NRECC; rec += 64)
+        rd_lane_setup_c<Ode, D, ResDims<D>::s_Z0>(out + res_table_words_tile<Ode, D>(), rec);
     }
   }
 }
@@ -756,6 +786,11 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     else return slots + g * SLOT;
   };
   auto pseg = [&](int g) -> int { if constexpr (PAIR) return g < gc0 ? sg0 + g : sg1 + (g - gc0); else return seg0 + g; };
+  auto pfbl = [&](int g) -> lds_double* {        // the eight cells of group member g for the terms of its FB (ResDims::x_FBL)
+    constexpr int o = D::TABSZ + GR * SLOT + R::x_FBL;
+    if constexpr (PAIR) return region0 + o + (g < gc0 ? g * R::FBL_LD : R::REGION + (g - gc0) * R::FBL_LD);
+    else return tabL + o + g * R::FBL_LD;
+  };
   const int gall = PAIR ? gc0 + gc1 : gcount;
   // (the lane index is made opaque per group: what derives from it is then recomputed in every group instead of being
   //  computed once before the loop and kept -- in scratch, there being no registers to keep it in across the ODE bodies)
@@ -910,7 +945,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
   if constexpr (!D::TRAP) {
     if (roleB && pj < K && pg < gall) {   // P2
       const int g = pg, i = pj;
-      res_interior<Ode, D, LEVEL, ROWDPP>(pslot(g), i, &tab, a.L != nullptr);
+      res_interior<Ode, D, LEVEL, ROWDPP>(pslot(g), i, &tab, a.L != nullptr, pfbl(g));
     }
     if constexpr (LEVEL >= 2) pair_sync();
   }
@@ -919,7 +954,7 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     if constexpr (EARLYC) {
       // P3 by wave A -- and meanwhile wave B forms and stores the rows of [J ; g^T] of the whole group (defect_rowdpp.h, MODE 1)
       if (roleA) {
-        if (pj < CS && pg < gall) res_cardinal_second<Ode, D, true>(pslot(pg), pj, &tab);
+        if (pj < CS && pg < gall) res_cardinal_second<Ode, D, true, ROWDPP>(pslot(pg), pj, &tab, pfbl(pg));
         // ... and says so -- a flag in wave 0's region, not a barrier: wave A goes on to its H passes, wave B looks at the flag when
         // its C passes are done (LDS instructions of a wave execute in issue order: whoever sees the flag sees the phase's results)
         wave_lds_sync();
@@ -929,11 +964,12 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
         if (gc0 > 0) { slo = min(slo, sg0); shi = max(shi, sg0 + gc0); }
         if (gc1 > 0) { slo = min(slo, sg1); shi = max(shi, sg1 + gc1); }
         rowdpp_dense<Ode, D, R::s_Z0, R::s_FB, LEVEL, 1>(a, (const lds_double*)tabL, rd_rectab, gall, slo, shi, wv, NWV, lane,
-                                                      [&](int g) -> const lds_double* { return pslot(g); }, pseg, rd_rec);
+                                                      [&](int g) -> const lds_double* { return pslot(g); }, pseg,
+                                                      [&](int g) -> const lds_double* { return pfbl(g); }, rd_rec);
       }
     } else if (roleA && pj < CS && pg < gall) {  // P3
       const int g = pg, j = pj;
-      res_cardinal_second<Ode, D>(pslot(g), j, &tab);
+      res_cardinal_second<Ode, D, false, ROWDPP>(pslot(g), j, &tab, pfbl(g));
     }
   }
   }
@@ -959,9 +995,10 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
       // (wave B has stored the C passes -- nCP x 540 instructions -- while wave A ran the cardinal second-derivative phase, ~ 550)
       const int nCP = (gall + (4 / (RdDims<Ode, D>::CRG > 0 ? RdDims<Ode, D>::CRG : 1) > 0 ? 4 / RdDims<Ode, D>::CRG : 1) - 1) /
                       (4 / RdDims<Ode, D>::CRG > 0 ? 4 / RdDims<Ode, D>::CRG : 1);
-      const int lB = nCP * 540, lA = 550;   // (weights 900 / 370 -- wave A four H passes of five instead of three -- measured the same at 10 000 Reentry segments and slower at 5 000)
+      const int lB = nCP * (R::UNITC ? ASSET_RD_CCOST_UNIT : 540), lA = 550;   // (weights 900 / 370 -- wave A four H passes of five instead of three -- measured the same at 10 000 Reentry segments and slower at 5 000)
       rowdpp_dense<Ode, D, R::s_Z0, R::s_FB, LEVEL, 2>(a, (const lds_double*)tabL, rd_rectab, gall, seg_lo, seg_hi, wv, NWV, lane,
-                                                    [&](int g) -> const lds_double* { return pslot(g); }, pseg, rd_rec, /*have_rec=*/!roleA,
+                                                    [&](int g) -> const lds_double* { return pslot(g); }, pseg,
+                                                    [&](int g) -> const lds_double* { return pfbl(g); }, rd_rec, /*have_rec=*/!roleA,
                                                     wa == 0 ? lA : lB, wa == 0 ? lB : lA
 #if defined(ASSET_TIMING)
                                                     , tstamp, &nts
@@ -969,7 +1006,8 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
                                                     );
     } else
     rowdpp_dense<Ode, D, R::s_Z0, R::s_FB, LEVEL>(a, (const lds_double*)tabL, rd_rectab, gall, seg_lo, seg_hi, wv, NWV, lane,
-                                                  [&](int g) -> const lds_double* { return pslot(g); }, pseg, rd_rec, false, 0, 0
+                                                  [&](int g) -> const lds_double* { return pslot(g); }, pseg,
+                                                  [&](int g) -> const lds_double* { return pfbl(g); }, rd_rec, false, 0, 0
 #if defined(ASSET_TIMING)
                                                   , tstamp, &nts
 #endif

@@ -97,7 +97,13 @@ struct RdDims {
   };
   static constexpr int NWH = int((sizeof(LaneH) + 3) / 4), NQH = (NWH + 3) / 4;
   static constexpr int NRECH = RG * 16;
-  static constexpr long long table_bytes() { return (long long)NQH * 16 * NRECH; }
+  // what a row of J needs as the adjoint gradient of a UNIT multiplier vector (UNITC, below): where row r0 of J^_i0 sits in the slot
+  struct LaneC {
+    unsigned short jo[N];          // J^_i0[r0][aa] (zero cell: a structural zero, or a lane without a defect row)
+  };
+  static constexpr int NWC = int((sizeof(LaneC) + 3) / 4), NQC = (NWC + 3) / 4;
+  static constexpr int NRECC = CRG * 16;
+  static constexpr long long table_bytes() { return (long long)NQH * 16 * NRECH + (long long)NQC * 16 * NRECC; }
 };
 
 template <class Ode, class D, int ZERO>
@@ -148,6 +154,19 @@ __device__ void rd_lane_setup(unsigned int* out, int rec) {
   }
   for (int k = 0; k < X::NQH * 4; k++) out[(k >> 2) * (X::NRECH * 4) + rec * 4 + (k & 3)] = u.w[k];
 }
+template <class Ode, class D, int ZERO>
+__device__ void rd_lane_setup_c(unsigned int* out, int rec) {      // (the C records follow the H records of the table)
+  using X = RdDims<Ode, D>;
+  union { typename X::LaneC c; unsigned int w[X::NQC * 4]; } u;
+  for (int k = 0; k < X::NQC * 4; k++) u.w[k] = 0u;
+  const int jr = rec, i0 = jr < X::OR ? jr / X::n : 0, r0 = jr < X::OR ? jr - i0 * X::n : 0;
+  for (int aa = 0; aa < X::N; aa++) {
+    const int jp = jr < X::OR ? Ode::JPOS[r0 * X::N + aa] : -1;
+    u.c.jo[aa] = (unsigned short)(jp >= 0 ? D::w_IJ + i0 * D::NZJ + jp : ZERO);
+  }
+  unsigned int* const base = out + X::NQH * 4 * X::NRECH;
+  for (int k = 0; k < X::NQC * 4; k++) base[(k >> 2) * (X::NRECC * 4) + rec * 4 + (k & 3)] = u.w[k];
+}
 
 // (Round 5 built this dense part into a one-launch kernel of heavy right-hand sides as well -- eight-wave workgroups, units and
 //  passes in one launch, no workspace: bit-for-bit as good and slower (1 000 Betts-LGL5 segments 31.6 us against 20.1 us of the unit
@@ -162,9 +181,9 @@ __device__ void rd_lane_setup(unsigned int* out, int rec) {
 // [J ; g^T] need nothing of -- and later the H passes alone, dealt with what each wave has done by then counted in (load0 / load1).
 // `recw`: the calling wave's row record; MODE 1 loads it ahead of its first store for the H passes that follow, MODE 2 loads it when
 // `have_rec` is false.
-template <class Ode, class D, int SLOTZERO, int S_FB, int LEVEL, int MODE = 0, class PSlot, class PSeg>
+template <class Ode, class D, int SLOTZERO, int S_FB, int LEVEL, int MODE = 0, class PSlot, class PSeg, class PFbl>
 __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double* tabL, const unsigned int* rectab, int gall, int seg_lo,
-                                            int seg_hi, int wv, int nwv, int lane, PSlot pslot, PSeg pseg,
+                                            int seg_hi, int wv, int nwv, int lane, PSlot pslot, PSeg pseg, PFbl pfbl,
                                             unsigned int (&recw)[RdDims<Ode, D>::NQH * 4], bool have_rec = false, int load0 = 0, int load1 = 0,
                                             long long* tsp = nullptr, int* ntsp = nullptr) {
 #define RDTS() do { if (tsp && *ntsp < 24) tsp[(*ntsp)++] = clock64(); } while (0)
@@ -174,12 +193,20 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
   constexpr int oS = __builtin_offsetof(LglTab, s) / 8, oA = __builtin_offsetof(LglTab, A) / 8, oB = __builtin_offsetof(LglTab, B) / 8;
   constexpr int oU = __builtin_offsetof(LglTab, U) / 8, oC = __builtin_offsetof(LglTab, C) / 8, oD = __builtin_offsetof(LglTab, D) / 8;
   constexpr int oE = __builtin_offsetof(LglTab, E) / 8;
+  // UNITC (round 6; level 2): every row of J is the adjoint gradient for a UNIT multiplier vector e_(i0, r0) -- M_i = 0 off i0 and
+  // M_i0 = hE_i0 (row r0 of J^_i0), BM_j = B_i0j M_i0 + D_i0j e_r0 -- so the C pass carries ONE interior's row through lane-own weights
+  // instead of K through the general path (a third of its instructions), and the adjoint gradient itself -- the one row with a full
+  // multiplier vector -- comes out of the H passes, whose lane of row r already holds most of entry r:
+  //     agx[r] = sum_i hE_i w_i(r) g^_i[a(r)] + sum_j g_j[cc(r)] + sum_i C_ij(r) lam_i[cc(r)] -/+ FB on the rows t_0 / t_f
+  // (g_j = J_j^T w_j carries the B and D parts: LGLDefects.h:369-374, :512), FB from the terms the ODE phases left (ResDims::x_FBL).
+  constexpr bool UNITC = ResDims<D>::UNITC && LEVEL >= 2;
   typedef __attribute__((ext_vector_type(2))) unsigned int u2;
   typedef __attribute__((ext_vector_type(4))) unsigned int u4;
   const LglTab& ctab = d_lgl_tab[D::TAB];                           // compile-time indices: scalar loads
   const int lr = lane & 15, rs = lane >> 4;
   constexpr unsigned INVALID = 0xF0000000u;
 #define ASSET_RD_NB 8
+#define ASSET_RD_CCOST_UNIT 300      // a UNITC C pass in the units of the dealing below (instructions of a pass / 1.6; 540 in the general form; 200 / 400 measure the same: profiles/r6_unitc.txt)
   constexpr int NB = ASSET_RD_NB;                                    // block columns evaluated side by side
 
   // outputs of the workgroup's segments [seg_lo, seg_hi): one buffer resource each, offsets relative to seg_lo (an output the caller
@@ -216,6 +243,16 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
     }
   }
   const typename X::LaneH& recL = *reinterpret_cast<const typename X::LaneH*>(recw);
+  unsigned int reccw[X::NQC * 4];                                    // (UNITC) the lane's C record: its row of [J ; g^T] never changes either
+  if constexpr (UNITC && MODE != 2) {
+    const u4* src = reinterpret_cast<const u4*>(rectab) + X::NQH * X::NRECH + (16 * ((lane >> 4) % CRG) + lr);
+#pragma unroll
+    for (int k = 0; k < X::NQC; k++) {
+      const u4 v = src[k * X::NRECC];
+      reccw[4 * k] = v.x, reccw[4 * k + 1] = v.y, reccw[4 * k + 2] = v.z, reccw[4 * k + 3] = v.w;
+    }
+  }
+  const typename X::LaneC& recC = *reinterpret_cast<const typename X::LaneC*>(reccw);
   auto hpass = [&](const int pl) __attribute__((always_inline)) {
     const int g0 = SPP * pl + hsub;
     const bool tv = hsub < SPP && g0 < gall;
@@ -316,6 +353,23 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
             });
         }
       });
+      if constexpr (UNITC) {
+        const int jn = r < P0 ? r / q : CS - 1;                      // (rows without a state entry read lam's zero cell: any weight will do)
+        const int lo = L.ar < n ? D::w_lam + L.ar : SLOTZERO, lst = L.ar < n ? n : 0;
+        double ag = gsum;
+#pragma unroll
+        for (int i = 0; i < K; i++) ag = fma(h * L.wE[i], S[D::w_Ig + i * N + L.ar], ag);
+#pragma unroll
+        for (int i = 0; i < K; i++) ag = fma(tabL[oC + 4 * i + jn], S[lo + i * lst], ag);
+        const lds_double* const F = pfbl(g);
+        double fc = 0.0, fi2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < CS; j++) fc += F[j];
+#pragma unroll
+        for (int i = 0; i < K; i++) fi2 += F[CS + i];
+        ag = fma(L.tsg, fma(rh, fc, fi2), ag);
+        bst(rs_agx, rv ? unsigned((pseg(g) - seg_lo) * (IR * 8) + 8 * r) : INVALID, 0, ag);
+      }
 #pragma unroll
       for (int i = 0; i < K; i++) gsum += hsp[i];
       hto = rh * gsum;
@@ -431,6 +485,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
     const double h = S[S_FB + K * n];                  // (t_f - t_0, left there by the interior phase)
     const double rh = 1.0 / h;
     // the defect value of the row: sum_j C_ij z_j[r] + h (sum_j D_ij f_j[r] + E_i f^_i[r])    (LGLDefects.h:460-500)
+    double sdv;
     {
       double cz = 0.0, sd = tabL[oE + i0] * S[D::w_If + jrr];
 #pragma unroll
@@ -439,6 +494,77 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
         sd = fma(tabL[oD + 4 * i0 + j], S[D::w_Cf + j * n + r0], sd);
       }
       bst(rs_fx, isJ ? unsigned(srel * (OR * 8) + 8 * jr) : INVALID, 0, fma(h, sd, cz));
+      sdv = sd;
+    }
+    if constexpr (UNITC) {
+      // ---- the rows of J alone, each for its unit multiplier vector e_(i0, r0) (the gradient row: hpass)
+      const lds_double* const tw = tabL + 4 * i0;                    // the lane's rows of the weight tables
+      double wA[CS], wB[CS], wC[CS], wD[CS], wU[CS];
+#pragma unroll
+      for (int j = 0; j < CS; j++) wA[j] = tw[oA + j], wB[j] = tw[oB + j], wC[j] = tw[oC + j], wD[j] = tw[oD + j], wU[j] = tw[oU + j];
+      const double hE = h * tabL[oE + i0];
+      double M[N];
+#pragma unroll
+      for (int aa = 0; aa < N; aa++) M[aa] = hE * S[recC.jo[aa]];
+      // FB = E f^ . l + sum_j f_j . BM_j = (sum_j D_i0j f_j[r0] + E_i0 f^_i0[r0]) + sum_a FB_i0[a] M[a]
+      double fb = sdv;
+#pragma unroll
+      for (int aa = 0; aa < n; aa++) fb = fma(S[S_FB + i0 * n + aa], M[aa], fb);
+      double dsel[n], hB[CS], hD[CS];
+#pragma unroll
+      for (int aa = 0; aa < n; aa++) dsel[aa] = rd_sel01(isJ && r0 == aa);
+#pragma unroll
+      for (int j = 0; j < CS; j++) hB[j] = h * wB[j], hD[j] = h * wD[j];
+      double BM[CS][n];
+#pragma unroll
+      for (int j = 0; j < CS; j++)
+#pragma unroll
+        for (int aa = 0; aa < n; aa++) BM[j][aa] = fma(hB[j], M[aa], hD[j] * dsel[aa]);
+      const double tm1 = tabL[oS + i0] * M[T];
+      const double w_t0 = (M[T] - tm1) - fb, w_tf = tm1 + fb;
+      RdOps<D::w_CJ, D::w_CJ + CS * NZJ> cj;
+      cj.load(Sl);
+      auto col_init = [&](auto CC) -> double {
+        constexpr int c = decltype(CC)::value;
+        if constexpr (c < P0) {
+          constexpr int j = c / q, cc = c - j * q;
+          if constexpr (cc == T) return (j == 0) ? w_t0 : ((j == CS - 1) ? w_tf : 0.0);
+          else if constexpr (cc < n) return wC[j] * dsel[cc];
+          else return 0.0;
+        } else return M[q + (c - P0)];
+      };
+      auto col_term = [&](auto CC, auto SS, double& acc) {
+        constexpr int c = decltype(CC)::value, s = decltype(SS)::value;
+        if constexpr (c < P0) {
+          constexpr int j = c / q, cc = c - j * q;
+          if constexpr (s == 0) {
+            if constexpr (cc != T) acc = fma(cc < n ? wA[j] : wU[j], M[cc], acc);
+          } else if constexpr (s <= n) {
+            constexpr int aa = s - 1, jp = Ode::JPOS[aa * N + cc];
+            if constexpr (jp >= 0) cj.template fm<D::w_CJ + j * NZJ + jp>(acc, BM[j][aa]);
+          }
+        } else {
+          constexpr int pc = c - P0;
+          if constexpr (s < CS * n) {
+            constexpr int j = s / n, aa = s - j * n, jp = Ode::JPOS[aa * N + q + pc];
+            if constexpr (jp >= 0) cj.template fm<D::w_CJ + j * NZJ + jp>(acc, BM[j][aa]);
+          }
+        }
+      };
+      constexpr int NT = (p > 0 && CS * n > n + 1) ? CS * n : n + 1;
+      rd_for<(IR + NB - 1) / NB>([&](auto BB) {
+        constexpr int b0 = NB * decltype(BB)::value, nb = b0 + NB <= IR ? NB : IR - b0;
+        double acc[NB];
+        rd_for<nb>([&](auto Bx) { acc[decltype(Bx)::value] = col_init(std::integral_constant<int, b0 + decltype(Bx)::value>{}); });
+        rd_for<NT>([&](auto SS) {
+          rd_for<nb>([&](auto Bx) { col_term(std::integral_constant<int, b0 + decltype(Bx)::value>{}, SS, acc[decltype(Bx)::value]); });
+        });
+        rd_for<nb>([&](auto Bx) {
+          constexpr int c = b0 + decltype(Bx)::value;
+          bst(rs_kkt, kb, 8 * D::jcol(c), acc[decltype(Bx)::value]);
+        });
+      });
+      return;
     }
     // the row's multiplier vector l (unit vector of the defect row, lam for the gradient row), and hE_i l_i
     double lw[K][n], ls[K][n];
@@ -600,7 +726,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
     while (hp < nHP || cp < nCP) {
       const bool isH = hp < nHP && (cp >= nCP || SPP * hp < SPC * (cp + 1));     // H passes up to the segments of the next C pass first
       const int w = (nwv > 1 && load1 < load0) ? 1 : 0;
-      (w ? load1 : load0) += isH ? (LEVEL >= 2 ? 640 : 40) : 540;
+      (w ? load1 : load0) += isH ? (LEVEL >= 2 ? 640 : 40) : (UNITC ? ASSET_RD_CCOST_UNIT : 540);
       if (w == wv) {
         RDTS();
         if (isH) hpass(hp); else cpass(cp);

@@ -304,19 +304,22 @@ inline hipError_t launch_lgl_table(const KernelTable& t, int level, const EvalAr
         const KRef& kr = one ? t.k[K_RES(a.kmap != nullptr)] : t.k[K_RESL(2, a.kmap != nullptr)];
         if (kr && (one || env_max <= 0 || (a.nseg + waves - 1) / waves <= env_max * int(m[MF_RES_GR])))
         {
-          // two-wave workgroups: the one-group kernel of a pair shape -- and, on meshes of four or more groups per wave, the looped block
-          // kernel of the shapes with the row-wise dense part (TwoBody-LGL5-BlockConstant: 100 000 segments 244 -> 220 us as pairs, but
-          // 30 000 -- two groups per wave -- 65 -> 76 us: the pair's barriers cost what the shared ODE stage saves until the waves drift)
+          // two-wave workgroups: the one-group kernel of a pair shape -- and, on every looped mesh, the looped block kernel of the shapes
+          // that are built with one (ResDims::LOOP_PAIR: row-wise dense part, a right-hand side heavy enough for the shared ODE stage to
+          // pay for the pair's barriers -- profiles/r6_forms2.txt)
           static const bool no_alt = tuning_env("ASSET_HIP_NO_ALT_FORM") != nullptr;                           // tuning only
+          static const int lpair_min = tuning_env("ASSET_HIP_LPAIR_MIN") ? std::atoi(std::getenv("ASSET_HIP_LPAIR_MIN")) : 1;   // tuning only (groups per wave from which the pair form is taken)
+          static const int alt_min = tuning_env("ASSET_HIP_ALT_MIN") ? std::atoi(std::getenv("ASSET_HIP_ALT_MIN")) : 5;         // tuning only (HALF segments per workgroup)
           const bool lpair = !one && !a.kmap && m[MF_RES_LOOP_NWV] > 1 && t.k[K_RESLP] && !(no_alt && m[MF_RES_ALT]) &&
-                             (a.nseg + waves - 1) / waves >= 4 * int(m[MF_RES_GR]);
+                             (a.nseg + waves - 1) / waves >= lpair_min * int(m[MF_RES_GR]);
           const int nwv = ((one && m[MF_RES_NWV] > 1) || lpair) ? 2 : 1, nw = a.nseg < waves ? a.nseg : waves;
           const size_t lds = size_t(m[MF_RES_LDS_BYTES]) / size_t(m[MF_RES_NWV] > 1 ? 2 : 1) * size_t(nwv);
-          // shapes with both forms of the dense part (ResDims::RD_ALT): rows in the one-group kernel from six segments per workgroup
-          // on (its passes take four / two segments: below that they run half empty), tiles otherwise; looped meshes: tiles for two or
-          // three groups per wave, the looped pair kernel (rows) beyond -- the rule above (profiles/r6_forms.txt)
+          // shapes with both forms of the dense part (ResDims::RD_ALT): rows in the one-group kernel from two and a half segments per
+          // workgroup on (with UNITC the row-wise part is the cheaper one wherever its passes -- four / two segments -- are not mostly
+          // empty: Reentry-LGL7 x 2 500 15.8 against 16.1 us, x 5 000 20.5 / 20.9, x 10 000 26.4 / 28.4; x 1 000 13.8 / 13.2), tiles below;
+          // looped meshes: the looped pair kernel (rows) -- profiles/r6_forms2.txt
           const int nwg = (nw + nwv - 1) / nwv;
-          const bool alt = one && nwv == 2 && !a.kmap && !no_alt && m[MF_RES_ALT] && t.k[K_RES_ALT] && a.nseg >= 6 * nwg;
+          const bool alt = one && nwv == 2 && !a.kmap && !no_alt && m[MF_RES_ALT] && t.k[K_RES_ALT] && 2 * a.nseg >= alt_min * nwg;
           return klaunch(lpair ? t.k[K_RESLP] : (alt ? t.k[K_RES_ALT] : kr), dim3(nwg), dim3(64 * nwv), lds, st, kargs);
         }
       }

@@ -165,17 +165,19 @@ def _build_and_load(name, hdr_name, hdr, tag, reg_line, mode_id, blocked, what, 
         so = os.path.join(wd, f"plugin_{tag}_{key_of(src, build.FLAGS)}.so")
         _TOUCHED.add(so)
         if not os.path.exists(so):
+            if compile_only and _PARTITION is not None and int(key_of(src, build.FLAGS), 16) % _PARTITION[1] != _PARTITION[0]:
+                return name                 # (another worker of a parallel pre-build compiles this one)
             build._write_if_changed(os.path.join(wd, hdr_name), hdr)
             tu = os.path.join(wd, f"tu_{tag}.hip")
             build._write_if_changed(tu, src)
             if not os.path.exists(build.HIPCC):
                 raise _lib.AssetHipError(f"{build.HIPCC} not found: {what} needs the HIP compiler driver (ASSET_HIP_JIT=hipcc)")
             cmd = [build.HIPCC] + build.FLAGS + ["-DASSET_PLUGIN", "-shared", "-I", os.path.join(build.HERE, "..", "include"),
-                                                 tu, "-o", so + ".tmp"]
-            r = subprocess.run(cmd, capture_output=True, text=True)
+                                                 tu, "-o", f"{so}.{os.getpid()}.tmp"]     # (a name of this process's own: two
+            r = subprocess.run(cmd, capture_output=True, text=True)                                          #  builders never share a half-written file)
             if r.returncode != 0:
                 raise _lib.AssetHipError(f"hipcc failed for {what}:\n{r.stderr[-3000:]}")
-            os.replace(so + ".tmp", so)
+            os.replace(f"{so}.{os.getpid()}.tmp", so)
             drop_older(f"plugin_{tag}_", ".so", so)
         if compile_only:
             return name
@@ -235,10 +237,12 @@ def ensure_bundle(dev_names, compile_only=None) -> str:
                            rtc=(flist, 3, 0, 0, f"ASSET_RTC_BUNDLE({flist})"), compile_only=compile_only)
 
 
-def prune_unused(verbose: bool = False) -> int:
-    """Remove every entry of the in-tree module cache that this process has neither compiled nor found: the cache is keyed by
-    content, so code objects of older sources are never loaded again, but they travel with every snapshot of the tree.  Called by
-    ``__graft_entry__.build()`` after it has asked for everything the GPU tests use.  Returns the number of files removed."""
+def prune_unused(verbose: bool = False, everything: bool = False) -> int:
+    """Remove stale code objects from the in-tree module cache: the cache is keyed by content, so builds against older sources
+    are never loaded again, but they travel with every snapshot of the tree.  By default only inside the directories of units THIS
+    process asked for (older ``module_*`` / ``plugin_*`` builds of the same unit); ``everything=True`` also removes the directories of
+    units this process never asked for -- cached modules of ODEs some other script compiled.  ``__graft_entry__.build()`` passes it,
+    after asking for everything the GPU tests use.  Returns the number of files removed."""
     import shutil
     removed = 0
     if not os.path.isdir(JIT_DIR):
@@ -250,8 +254,9 @@ def prune_unused(verbose: bool = False) -> int:
         files = [os.path.join(wd, f) for f in os.listdir(wd)]
         keep = [f for f in files if f in _TOUCHED]
         if not keep:
-            removed += len(files)
-            shutil.rmtree(wd, ignore_errors=True)
+            if everything:
+                removed += len(files)
+                shutil.rmtree(wd, ignore_errors=True)
             continue
         for f in files:
             if f not in _TOUCHED and (f.endswith(".rtc") or (f.endswith(".so") and os.path.basename(f).startswith("plugin_"))):

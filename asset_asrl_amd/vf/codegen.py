@@ -676,6 +676,7 @@ def emit_hip_functor(d: OdeDerivatives, struct_name: str) -> str:
     o.append(f"struct {struct_name} {{")
     o.append(f"  static constexpr int XV = {d.xv}, UV = {d.uv}, PV = {d.pv}, NIN = {N};")
     o.append(f"  static constexpr int NNZ_J = {st['nnz_J']}, NNZ_H = {st['nnz_H_lower']};")
+    o.append(f"  static constexpr int OPS_FJGH = {st['ops_fjgh']};   // operations of the value + J + g + H body (csrc/defect_resident.h: which looped form pays)")
     nac = 1 + max([nd.value for nd in topo_order(_level_roots(d, 2)) if nd.op == "aconst"], default=-1)
     o.append(f"  static constexpr int NACONST = {nac};   // constants of the application the function reads (vf.ApplConst)")
     o.append(f"  static constexpr const char* name() {{ return \"{d.name}\"; }}")

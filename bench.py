@@ -36,6 +36,7 @@ WORKLOADS = {
     "reentry_lgl7_5k": ("reentry", "LGL7", 5000, False),                  # BASELINE.json configs[2] (initial mesh)
     "betts_lgl5_1k": ("betts_lowthrust", "LGL5", 1000, False),            # BASELINE.json configs[1]
     "twobody_lgl5_blocked_10k": ("twobody_lt", "LGL5", 10000, True),      # configs[3] dynamics as one phase
+    "twobody_lgl5_blocked_100k": ("twobody_lt", "LGL5", 100000, True),    # ... on a looped mesh (a light right-hand side: single-wave workgroups)
     "brachistochrone_lgl3_40": ("brachistochrone", "LGL3", 40, False),    # configs[0]
     "twobody_lgl7_10k": ("twobody_lt", "LGL7", 10000, False),            # mid-width shapes (32 < IR < 64): IR = 40
     "betts_lgl7_5k": ("betts_lowthrust", "LGL7", 5000, False),            #                                   IR = 45

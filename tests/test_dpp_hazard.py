@@ -25,6 +25,22 @@ def test_no_dpp_hazard_in_the_built_objects():
     assert total > 1000          # the row-wise kernels are in there
 
 
+def test_no_dpp_hazard_in_the_run_time_compiled_modules():
+    """The same inline assembly is instantiated in every module compiled at run time for a user ODE -- another register allocation
+    each time: the cached modules of the in-tree cache (what build() compiled for the GPU tests) are scanned like the static objects."""
+    import isa_dpp_hazard as H
+    mods = [f for f in H.default_files() if f.endswith((".rtc", ".so"))]
+    if not mods or not os.path.exists(os.path.join(H.LLVM, "llvm-objdump")):
+        pytest.skip("no cached run-time modules here (build() writes them)")
+    total, bad = 0, []
+    for o in mods:
+        f, n = H.check(H.disassemble(o), os.path.relpath(o, ROOT))
+        bad += f
+        total += n
+    assert not bad, "\n".join(bad[:20])
+    assert total > 1000          # user ODEs of narrow shapes take the row-wise part too
+
+
 def test_the_checker_sees_a_planted_hazard():
     import isa_dpp_hazard as H
     text = """0000 <k>:

@@ -147,10 +147,13 @@ def test_ragged_segment_counts(oracle, nseg):
     # 3 + 2 (slot 0 of the second group asked for by the last segment of the first), three groups
     ("betts_lowthrust", "LGL7", False, 1000), ("betts_lowthrust", "LGL7", False, 1031), ("betts_lowthrust", "LGL7", False, 4500),
     ("betts_lowthrust", "LGL7", False, 9001),
-    # (round 6) shapes with BOTH forms of the dense part (ResDims::RD_ALT): tiles below six segments per workgroup, rows from there to the
-    # end of the one-group kernel, tiles for two or three groups per wave, the looped pair kernel (rows) from four groups on
-    ("reentry", "LGL7", False, 6143), ("reentry", "LGL7", False, 6144), ("reentry", "LGL7", False, 10240), ("reentry", "LGL7", False, 10241),
-    ("reentry", "LGL7", False, 30720), ("reentry", "LGL7", False, 30721), ("reentry", "LGL3", False, 6200), ("reentry", "LGL5", False, 43100)])
+    # (round 6) shapes with both forms of the dense part (registry.h: alt, lpair): tiles below two and a half segments per workgroup, rows from there to the
+    # end of the one-group kernel, the looped pair kernel (rows) on every looped mesh
+    ("reentry", "LGL7", False, 2559), ("reentry", "LGL7", False, 2560), ("reentry", "LGL7", False, 6143), ("reentry", "LGL7", False, 6144),
+    ("reentry", "LGL7", False, 10240), ("reentry", "LGL7", False, 10241), ("reentry", "LGL7", False, 15000),
+    ("reentry", "LGL7", False, 30720), ("reentry", "LGL7", False, 30721), ("reentry", "LGL3", False, 6200), ("reentry", "LGL5", False, 43100),
+    # light right-hand sides keep single-wave workgroups on looped meshes (ResDims::LOOP_PAIR)
+    ("twobody_lt", "LGL5", True, 60003), ("brachistochrone", "LGL7", False, 40001)])
 def test_launch_form_boundaries(oracle, ode, mode, blocked, nseg):
     """Mesh sizes on either side of every switch of the launcher (csrc/registry.h: launch_lgl_table): one-wave fused,
     two-wave fused, ODE stage + dense stage, units -- every block against the oracle."""

@@ -3,7 +3,7 @@ every switch that stays, one -m gpu test that builds the non-default setting and
 translation unit each -- are built by tools/build_variants.py (run by __graft_entry__.build(), they travel with the snapshot); each
 is loaded in a child process (ASSET_HIP_LIB) and run through every evaluation kind at mesh sizes that take the one-group kernel,
 the looped kernel and the looped pair kernel (tools/quick_check.py).  Switches: ASSET_KKT_LAYOUT, ASSET_RES_ROWDPP, ASSET_RES_PAIR,
-ASSET_RES_EARLYC, ASSET_RES_LOOP_PAIR."""
+ASSET_RES_EARLYC, ASSET_RES_LOOP_PAIR, ASSET_RD_UNITC."""
 import os
 import subprocess
 import sys

@@ -18,7 +18,9 @@ VARIANTS = {
     "rowdpp0_twobody": ("tu_twobody_lt_lgl3_1", ["-DASSET_RES_ROWDPP=0"], ("twobody_lt", "LGL5", 1), "tile form on a shape that defaults to rows"),
     "pair0_reentry": ("tu_reentry_lgl4_0", ["-DASSET_RES_PAIR=0"], ("reentry", "LGL7", 0), "single-wave workgroups (round 3's form)"),
     "earlyc0_twobody": ("tu_twobody_lt_lgl3_1", ["-DASSET_RES_EARLYC=0"], ("twobody_lt", "LGL5", 1), "C passes behind the cardinal second-derivative phase"),
-    "looppair0_twobody": ("tu_twobody_lt_lgl3_1", ["-DASSET_RES_LOOP_PAIR=0"], ("twobody_lt", "LGL5", 1), "looped block kernel as single waves"),
+    "unitc0_reentry": ("tu_reentry_lgl4_0", ["-DASSET_RD_UNITC=0"], ("reentry", "LGL7", 0), "the general C pass (J rows and the gradient row through one path) on a two-form shape"),
+    "unitc0_twobody": ("tu_twobody_lt_lgl3_1", ["-DASSET_RD_UNITC=0"], ("twobody_lt", "LGL5", 1), "the general C pass on a shape with segment parameters"),
+    "looppair0_reentry": ("tu_reentry_lgl3_1", ["-DASSET_RES_LOOP_PAIR=0"], ("reentry", "LGL5", 1), "looped block kernel as single waves on a shape that is built with the pair form"),
 }
 
 

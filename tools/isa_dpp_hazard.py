@@ -8,8 +8,12 @@
 (The operand registers of the row-wise dense part come straight from ds_read_b64, so neither should ever occur; this is the
 check that it stays so when the compiler's register allocation changes.)
 
-    python tools/isa_dpp_hazard.py [object files ...]        default: asset_asrl_amd/csrc/obj/tu_*.o
-Exit code 1 and one line per finding when a hazard is found.
+    python tools/isa_dpp_hazard.py [files ...]        default: asset_asrl_amd/csrc/obj/tu_*.o AND the run-time compiled modules
+                                                      of the in-tree cache (csrc/gen/jit/*/module_*.rtc, plugin_*.so)
+Files: host objects / shared objects with a .hip_fatbin section, raw code objects, the cache files of asset_hip_jit_compile
+(a text header, then the code object: capi.hip, rtc_write).  Exit code 1 and one line per finding when a hazard is found.
+The scan is linear in address order; the history is NOT carried across a taken branch (the fall-through path is what is checked: a
+taken branch re-fetches, which is more than the five wait states of the longest hazard).
 """
 import glob
 import os
@@ -23,9 +27,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
 
+RTC_MAGIC = b"ASSET-HIP-RTC-1\n"
+
+
 def disassemble(obj):
     with tempfile.TemporaryDirectory() as td:
         fat, co = os.path.join(td, "fat"), os.path.join(td, "co")
+        head = open(obj, "rb").read(len(RTC_MAGIC))
+        if head == RTC_MAGIC:                       # a cache file of the in-process compiler: header lines, then the code object
+            data = open(obj, "rb").read()
+            pos = len(RTC_MAGIC)
+            nl = data.index(b"\n", pos)
+            for _ in range(int(data[pos:nl]) + 1):   # the kernel-name lines, then the line with the size
+                pos = nl + 1
+                nl = data.index(b"\n", pos)
+            size = int(data[pos:nl])
+            open(co, "wb").write(data[nl + 1:nl + 1 + size])
+            return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], text=True)
+        sections = subprocess.run([f"{LLVM}/llvm-objdump", "-h", obj], capture_output=True, text=True).stdout
+        if ".hip_fatbin" not in sections:           # a raw code object
+            return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", obj], text=True)
         subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj], stderr=subprocess.DEVNULL)
         subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", f"--targets={TARGET}",
                                f"--output={co}"], stderr=subprocess.DEVNULL)
@@ -74,8 +95,14 @@ def check(text, name):
     return findings, ndpp
 
 
+def default_files():
+    jit = os.path.join(ROOT, "asset_asrl_amd", "csrc", "gen", "jit")
+    return (sorted(glob.glob(os.path.join(ROOT, "asset_asrl_amd", "csrc", "obj", "tu_*.o")))
+            + sorted(glob.glob(os.path.join(jit, "*", "module_*.rtc"))) + sorted(glob.glob(os.path.join(jit, "*", "plugin_*.so"))))
+
+
 def main(argv):
-    objs = argv or sorted(glob.glob(os.path.join(ROOT, "asset_asrl_amd", "csrc", "obj", "tu_*.o")))
+    objs = argv or default_files()
     bad, total = [], 0
     for o in objs:
         f, n = check(disassemble(o), os.path.basename(o))

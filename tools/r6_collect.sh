@@ -7,7 +7,7 @@ python3 -m pytest tests -m gpu -q > gpurun_out/r6_gputest3.log 2>&1; tail -8 gpu
 RND=r6 bash tools/bench_all.sh > gpurun_out/r6_bench_all.log 2>&1
 python3 bench.py --no-cpu-baseline --inprocess-shards 4 --steps 200 2>/dev/null | tail -1 > gpurun_out/r6_bench_inprocess.json
 ASSET_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r6_bench_selflaunch.json 2> gpurun_out/r6_bench_selflaunch.err
-bash tools/collect_all_profiles.sh r6 ${PROF_WLS:-reentry_lgl7_10k reentry_lgl7_5k reentry_lgl7_100k reentry_lgl7_1m twobody_lgl5_blocked_10k multispacecraft_8x1250 betts_lgl5_1k betts_lgl7_5k synthetic32_lgl7_100k twobody_lgl7_10k reentry_trap_10k} > gpurun_out/r6_profiles.log 2>&1
+bash tools/collect_all_profiles.sh r6 ${PROF_WLS:-reentry_lgl7_10k reentry_lgl7_5k reentry_lgl7_100k reentry_lgl7_1m twobody_lgl5_blocked_10k twobody_lgl5_blocked_100k multispacecraft_8x1250 betts_lgl5_1k betts_lgl7_5k synthetic32_lgl7_100k twobody_lgl7_10k reentry_trap_10k} > gpurun_out/r6_profiles.log 2>&1
 tail -3 gpurun_out/r6_profiles.log
 python3 - <<'PY'
 import json
