@@ -155,7 +155,7 @@ struct ResDims {
   // the looped level-2 kernel in two-wave workgroups too (row-wise part) -- for right-hand sides heavy enough that sharing the ODE stage
   // pays for the pair's barriers (measured after UNITC, profiles/r6_forms2.txt: Reentry, 411 operations, every shape and every looped mesh
   // size 5-15 % faster as pairs -- LGL7 x 30 000 74 against 88 us, LGL5-BlockConstant x 1 000 000 1.79 / 1.94 ms; TwoBody, 186, every shape
-  // 10-25 % SLOWER -- LGL5-BlockConstant x 100 000 195 against 169 us, LGL3 x 1 000 000 1.29 / 1.01 ms; Brachistochrone, 35, within 3 %
+  // 10-25 % SLOWER -- LGL5-BlockConstant x 100 000 195 against 169 us, LGL3 x 1 000 000 1.29 / 1.01 ms; Brachistochrone, 26, within 3 %
   // either way).  Light right-hand sides keep single-wave workgroups, whose waves drift apart and run one's ODE stage under another's stores.
   static constexpr int LOOP_PAIR_MIN_OPS = 300;
   static constexpr bool LOOP_PAIR = ASSET_RES_LOOP_PAIR && RD_ANY && Ode::OPS_FJGH >= LOOP_PAIR_MIN_OPS;
@@ -808,9 +808,12 @@ __device__ __forceinline__ void lgl_resident_body(const EvalArgs& a) {
     for (int r = ROWS / 4 * 4; r < ROWS; r++) lds_dma_row(dst + r * 256, src, lane * 4 + r * 256);
     if (TAIL > 0 && lane < TAIL) lds_dma_row(dst + ROWS * 256, src, lane * 4 + ROWS * 256);
   };
-  // (the one-group kernel only: in the looped pair form the waves meet at a barrier per group and wave B, with all the C passes of a group,
-  //  is the longer one every time -- TwoBody-LGL5-BlockConstant x 1 000 000: 2.53 ms with it, 2.07 ms without)
-  constexpr bool EARLYC = R::EARLYC && ROWDPP && PAIR && !LOOP && LEVEL == 2 && !ASM && !GIVEN && !D::TRAP;
+  // (round 5 kept this to the one-group kernel: in the looped pair form the waves meet at a barrier per group and wave B, with all the C passes
+  //  of a group in their general form, was the longer one every time -- TwoBody-LGL5-BlockConstant x 1 000 000: 2.53 ms with it, 2.07 ms
+  //  without.  Round 6: a unit-multiplier C pass is half the instructions, and the looped pair kernel is built for heavy right-hand sides only
+  //  (ResDims::LOOP_PAIR), whose cardinal second-derivative phase is long: wave B's C passes now fit under it -- Reentry-LGL7 x 100 000
+  //  264 -> 254 us, x 1 000 000 2.55 -> 2.45 ms; LGL5-BlockConstant x 1 000 000 1.88 -> 1.76 ms; LGL3 x 100 000 83.5 -> 77.8 us: profiles/r6_ecl.txt)
+  constexpr bool EARLYC = R::EARLYC && ROWDPP && PAIR && (!LOOP || LPAIR) && LEVEL == 2 && !ASM && !GIVEN && !D::TRAP;
   unsigned int rd_rec[R::RD_ANY ? RdDims<Ode, D>::NQH * 4 : 1];       // the row record of the row-wise dense part (defect_rowdpp.h)
   const unsigned int* const rd_rectab = static_cast<const unsigned int*>(a.lane_consts_res) +
                                         size_t(blockIdx.x % ASSET_LANE_REPLICAS) * size_t(res_table_words<Ode, D>()) + res_table_words_tile<Ode, D>();

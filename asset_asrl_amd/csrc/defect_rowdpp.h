@@ -94,6 +94,7 @@ struct RdDims {
     unsigned short jc[NJC];        // slot offsets of the row's column of dfdy: p == 0: dfdy_j(r)[a][cc(r)]; p > 0: per node (zero cell off the row's node; parameter rows: every node)
     unsigned short gs[CS];         // g_j[cc(r)] (zero cell off the row's node; parameter rows: every node)
     unsigned short hr[CS][N];      // row cc(r) of the cardinal Hessian of node jj (zero cell off the row's node; parameter rows: every node)
+    unsigned short hc[K][N];       // column a(r) of the interior Hessian H^_i: what the UNIT entry of DI_i[:, r] picks out of it (zero cell: a structural zero)
   };
   static constexpr int NWH = int((sizeof(LaneH) + 3) / 4), NQH = (NWH + 3) / 4;
   static constexpr int NRECH = RG * 16;
@@ -121,6 +122,8 @@ __device__ void rd_lane_setup(unsigned int* out, int rec) {
   };
   typename X::LaneH& L = u.h;
   for (int k = 0; k < X::NJC; k++) L.jc[k] = (unsigned short)ZERO;
+  for (int i = 0; i < K; i++)
+    for (int c = 0; c < N; c++) L.hc[i][c] = (unsigned short)ZERO;
   for (int jj = 0; jj < CS; jj++) {
     L.gs[jj] = (unsigned short)ZERO;
     for (int c = 0; c < N; c++) L.hr[jj][c] = (unsigned short)ZERO;
@@ -130,6 +133,11 @@ __device__ void rd_lane_setup(unsigned int* out, int rec) {
     const int j = node ? r / q : 0, cc = node ? r - j * q : 0, pr = node ? 0 : r - P0;
     L.ar = node ? cc : q + pr;
     L.tsg = (r == T) ? -1.0 : ((r == TF) ? 1.0 : 0.0);
+    for (int i = 0; i < K; i++)
+      for (int c = 0; c < N; c++) {
+        const int hp = Ode::HPOS[(c >= L.ar) ? c * (c + 1) / 2 + L.ar : L.ar * (L.ar + 1) / 2 + c];
+        if (hp >= 0) L.hc[i][c] = (unsigned short)(D::w_IH + i * D::NZH + hp);
+      }
     for (int i = 0; i < K; i++) {
       double w = 0.0;
       if (!node) w = 1.0;
@@ -277,15 +285,17 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
 
     // (every chain of dependent FMAs below is interleaved with others by hand: the compiler does not know the latency of an inline
     //  assembly statement and leaves them in source order -- a dependent v_fmac_f64 issues every 9 cycles, an independent one every 5)
-    // ---- d'_i = hE_i DI_i[:, r]
-    double d[K][N];
+    // ---- d'_i = hE_i DI_i[:, r] WITHOUT its unit entry hw_i e_a(r): what that entry contributes to M_i is hw_i times column a(r) of H^_i,
+    //      N values a lane reads by its own offsets (LaneH::hc) -- LDS reads, which do not take the f64 pipe -- instead of N selects per
+    //      interior to place it and an FMA for every structural entry of H^_i it meets.  The rest of d'_i lives on the state rows alone.
+    double d[K][n], hw[K];
     {
       RdOps<S_FB, S_FB + K * n> fbv;                                 // FB_i[a] = sum_j B_ij f_j[a]  (written by the interior phase)
       fbv.load(Sl);
       double jcv[X::NJC];
 #pragma unroll
       for (int k = 0; k < X::NJC; k++) jcv[k] = S[L.jc[k]];
-      double hw[K], tsh[K], hhb[K];
+      double tsh[K], hhb[K];
 #pragma unroll
       for (int i = 0; i < K; i++) hw[i] = h * L.wE[i], tsh[i] = L.tsg * (h * ctab.E[i]), hhb[i] = h * h * (p == 0 ? L.bE[i] : ctab.E[i]);
       double sj[p > 0 ? K : 1][p > 0 ? n : 1];
@@ -301,11 +311,9 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       }
       rd_for<K>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        rd_for<N>([&](auto A) {
+        rd_for<n>([&](auto A) {
           constexpr int aa = decltype(A)::value;
-          double v = rd_keep(L.ar == aa, hw[i]);
-          if constexpr (aa < n) v = fma(hhb[i], p == 0 ? jcv[aa] : sj[p > 0 ? i : 0][p > 0 ? aa : 0], v);
-          d[i][aa] = v;
+          d[i][aa] = hhb[i] * (p == 0 ? jcv[aa] : sj[p > 0 ? i : 0][p > 0 ? aa : 0]);
         });
       });
       rd_for<n>([&](auto A) {
@@ -327,13 +335,16 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       double hsp[K], tse[K];
 #pragma unroll
       for (int i = 0; i < K; i++) hsp[i] = 0.0, tse[i] = L.tsg * ctab.E[i];
+      double gu[K];                                                  // hw_i g^_i[a(r)]: the unit entry's share of g^_i . d'_i -- and of the adjoint gradient's entry r
+#pragma unroll
+      for (int i = 0; i < K; i++) gu[i] = hw[i] * S[D::w_Ig + i * N + L.ar];
       rd_for<N>([&](auto A) {
         constexpr int aa = decltype(A)::value;
         rd_for<K>([&](auto I) {
           constexpr int i = decltype(I)::value;
-          M[i][aa] = 0.0;
+          M[i][aa] = hw[i] * S[L.hc[i][aa]];
           ig.template fm<D::w_Ig + i * N + aa>(M[i][aa], tse[i]);
-          ig.template fm<D::w_Ig + i * N + aa>(hsp[i], d[i][aa]);
+          if constexpr (aa < n) ig.template fm<D::w_Ig + i * N + aa>(hsp[i], d[i][aa]);
         });
       });
       rd_for<N*(N + 1) / 2>([&](auto E) {
@@ -342,23 +353,26 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
         if constexpr (hp >= 0) {
           constexpr int ra = rd_tri_row(e);
           constexpr int cb = e - ra * (ra + 1) / 2;
-          rd_for<K>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            ih.template fm<D::w_IH + i * NZH + hp>(M[i][ra], d[i][cb]);
-          });
-          if constexpr (ra != cb)
+          if constexpr (cb < n)
+            rd_for<K>([&](auto I) {
+              constexpr int i = decltype(I)::value;
+              ih.template fm<D::w_IH + i * NZH + hp>(M[i][ra], d[i][cb]);
+            });
+          if constexpr (ra != cb && ra < n)
             rd_for<K>([&](auto I) {
               constexpr int i = decltype(I)::value;
               ih.template fm<D::w_IH + i * NZH + hp>(M[i][cb], d[i][ra]);
             });
         }
       });
+#pragma unroll
+      for (int i = 0; i < K; i++) hsp[i] += gu[i];
       if constexpr (UNITC) {
         const int jn = r < P0 ? r / q : CS - 1;                      // (rows without a state entry read lam's zero cell: any weight will do)
         const int lo = L.ar < n ? D::w_lam + L.ar : SLOTZERO, lst = L.ar < n ? n : 0;
         double ag = gsum;
 #pragma unroll
-        for (int i = 0; i < K; i++) ag = fma(h * L.wE[i], S[D::w_Ig + i * N + L.ar], ag);
+        for (int i = 0; i < K; i++) ag += gu[i];
 #pragma unroll
         for (int i = 0; i < K; i++) ag = fma(tabL[oC + 4 * i + jn], S[lo + i * lst], ag);
         const lds_double* const F = pfbl(g);
@@ -421,7 +435,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       if constexpr (c < P0) {
         constexpr int j = c / q, cc = c - j * q;
         if constexpr (cc == T) return (j == 0) ? w_t0 : ((j == CS - 1) ? w_tf : 0.0);
-        else return 0.0;
+        else return S[L.hr[j][cc]];                    // (the cardinal Hessian entry: the sum starts from it -- a read, not a read and an add)
       } else {
         double acc = 0.0;
 #pragma unroll
@@ -438,7 +452,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
         } else if constexpr (s < K + n) {
           constexpr int aa = s - K, jp = Ode::JPOS[aa * N + cc];
           if constexpr (jp >= 0) cj.template fm<D::w_CJ + j * NZJ + jp>(acc, BM[j][aa]);
-        } else if constexpr (s == K + n) acc += S[L.hr[j][cc]];
+        } else if constexpr (s == K + n) { if constexpr (cc == T) acc += S[L.hr[j][cc]]; }
         else if constexpr (s == K + n + 1) cg.template fm<D::w_Cg + j * N + cc>(acc, tg);
       } else {
         constexpr int pc = c - P0;

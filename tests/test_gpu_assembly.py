@@ -65,6 +65,7 @@ def test_assembled_device_pointers(oracle, mode):
     fx = torch.zeros(w.nseg * ev.OR, dtype=torch.float64, device=dev)
     agx = torch.zeros(w.nseg * ev.IR, dtype=torch.float64, device=dev)
     vals = torch.zeros(nlp.nnz, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()                                   # (torch fills on its stream, the evaluator runs on its own)
     ev.eval_assembled_device(JAC_ADJGRAD_HESS, X, L, fx, agx, vals)
     torch.cuda.synchronize()
     _, _, ref = nlp.eval(JAC_ADJGRAD_HESS, w.X, w.L)
@@ -80,6 +81,7 @@ def test_assembled_device_pointers_accumulate(oracle, ode, nseg):
     fx = torch.zeros(w.nseg * ev.OR, dtype=torch.float64, device=dev)
     agx = torch.zeros(w.nseg * ev.IR, dtype=torch.float64, device=dev)
     vals = torch.zeros(nlp.nnz, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()                                   # (torch fills on its stream, the evaluator runs on its own)
     for _ in range(2):                                         # two evaluations into the same array: it accumulates
         ev.eval_assembled_device(JAC_ADJGRAD_HESS, X, L, fx, agx, vals)
     torch.cuda.synchronize()
@@ -134,7 +136,8 @@ def test_full_size_assembly_and_rhs_on_the_device_are_exact_and_repeatable(oracl
     assert rel_err(AGX, rAGX) < 1e-8 and rel_err(vals, rvals) < 1e-8
     # value-only and gradient kinds through the same entry point
     FXE = torch.zeros(w.n_equal, dtype=torch.float64, device=dev)
-    ev.eval_kkt_device(0, X, None, FXE, None, None)
+    torch.cuda.synchronize()                                   # (the fill runs on torch's stream, the evaluation on the handle's: without
+    ev.eval_kkt_device(0, X, None, FXE, None, None)            #  this the fill can land AFTER the kernel's result -- seen once, round 6)
     torch.cuda.synchronize()
     assert np.abs(FXE.cpu().numpy() - rFXE).max() < 1e-10 * max(1.0, np.abs(w.X).max())
     ev.close()

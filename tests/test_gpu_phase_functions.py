@@ -133,8 +133,9 @@ def test_function_bundle_gives_the_blocks_of_the_separate_launches():
                 [torch.full((e.nseg * e.KSTRIDE,), np.nan, dtype=torch.float64, device=dev) for _, e in members])
     for what in (JAC_ADJGRAD_HESS, JAC_ADJGRAD, CON):
         fb, gb, kb = outs()
-        bundle.eval_device(what, X, Ls, fb, gb if what != CON else [None] * len(members), kb if what != CON else [None] * len(members))
         fs, gs, ks = outs()
+        torch.cuda.synchronize()                               # (torch fills on its stream, the evaluators run on their own)
+        bundle.eval_device(what, X, Ls, fb, gb if what != CON else [None] * len(members), kb if what != CON else [None] * len(members))
         for (_, e), l, f, g_, k in zip(members, Ls, fs, gs, ks):
             e.eval_device(what, X, l if what != CON else None, f, g_ if what != CON else None, k if what != CON else None)
         torch.cuda.synchronize()
