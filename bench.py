@@ -554,7 +554,7 @@ def main():
                        "total_segments": total_segments, "sharding": sharding,
                        # which of the line's rates the strong-scaling target of BASELINE.json (>= 6x at 8 GPUs) is claimed on
                        "scaling_claim": ("none at this size: a 10 000-segment phase leaves 1 250 segments per GPU, one latency-bound "
-                                         "launch (~17 us floor against 28.5 us on one GPU) -- `value_without_exchange` can reach ~2.4x, and "
+                                         "launch (~17 us floor against 26 us on one GPU) -- `value_without_exchange` can reach ~2.4x, and "
                                          "`value` carries the gather of 84 MB of blocks into one GPU on top; the >= 6x target is claimed on "
                                          "`value_without_exchange` (and `host_visible_assembled`, every rank over its own PCIe link) of the "
                                          "large meshes: --workload reentry_lgl7_1m / synthetic32_lgl7_100k (tools/bench_scale.sh)"
