@@ -57,7 +57,12 @@ def test_emitted_c_compiles_and_matches_dag(tmp_path):
     assert rel_err(f, evaluate(d.f, y)) < 1e-14
     assert rel_err(g, evaluate(d.g, y, lam)) < 1e-13
     assert np.abs(H - H.T).max() == 0.0
-    assert "struct OdeR" in emit_hip_functor(d, "OdeR")
+    hip = emit_hip_functor(d, "OdeR")
+    assert "struct OdeR" in hip
+    # the functor carries the operation count of its second-derivative body: csrc/defect_resident.h decides by it whether the looped
+    # kernel of the shape is also built as two-wave workgroups (ResDims::LOOP_PAIR: heavy right-hand sides only)
+    assert f"static constexpr int OPS_FJGH = {d.stats()['ops_fjgh']};" in hip and d.stats()["ops_fjgh"] >= 300
+    assert odelib.TwoBody().derivatives().stats()["ops_fjgh"] < 300
 
 
 def test_dsl_surface_and_errors():
