@@ -132,8 +132,12 @@ def _build_and_load(name, hdr_name, hdr, tag, reg_line, mode_id, blocked, what, 
     os.makedirs(wd, exist_ok=True)
 
     def key_of(src, flags):
-        return hashlib.sha256((hdr + src + " ".join(flags)).encode()
-                              + b"".join(open(p, "rb").read() for p in deps)).hexdigest()[:16]
+        # (the key names WHAT is compiled, not WHERE the tree lies: the generated text carries absolute include paths, and the GPU box
+        #  runs a snapshot of this tree under another root -- with the paths in the key every module pre-built here was compiled again
+        #  there, round after round)
+        root = os.path.dirname(build.HERE)
+        text = (hdr + src + " ".join(flags)).replace(root, "$ROOT")
+        return hashlib.sha256(text.encode() + b"".join(open(p, "rb").read() for p in deps)).hexdigest()[:16]
 
     def drop_older(prefix, suffix, keep):
         for f in os.listdir(wd):            # builds of this unit against older sources

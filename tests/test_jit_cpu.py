@@ -31,6 +31,32 @@ def test_user_ode_is_compiled_in_process_and_cached(monkeypatch):
             jit.ensure_kernel(ode, "LGL5", False)
 
 
+def test_module_cache_key_does_not_depend_on_where_the_tree_lies(monkeypatch, tmp_path):
+    """The GPU box runs a snapshot of this tree under another root.  The generated translation units carry absolute include paths; with
+    them in the cache key every module build() had compiled here was compiled again there (round 6 found it).  The same tree seen through
+    a symbolic link elsewhere must find the cached module: no new file, nothing rebuilt."""
+    import subprocess
+    import sys
+    monkeypatch.delenv("ASSET_HIP_JIT", raising=False)
+    ode = make_vanderpol()
+    name = jit.ensure_kernel(ode, "LGL3", False, compile_only=True)
+    mods = sorted(glob.glob(os.path.join(jit.JIT_DIR, name, "module_lgl3_0_*.rtc")))
+    assert len(mods) == 1
+    stamp = os.path.getmtime(mods[0])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    link = tmp_path / "elsewhere"
+    os.symlink(root, link)
+    code = (f"import os, sys; L = {str(link)!r}; sys.path.insert(0, L); sys.path.insert(0, os.path.join(L, 'tests'));"
+            "from asset_asrl_amd import jit, build; from helpers import make_vanderpol;"
+            "assert build.CSRC.startswith(L), build.CSRC;"                       # (abspath keeps the link: another root, as on the GPU box)
+            "print(jit.ensure_kernel(make_vanderpol(), 'LGL3', False, compile_only=True))")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(link), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == name
+    assert sorted(glob.glob(os.path.join(jit.JIT_DIR, name, "module_lgl3_0_*.rtc"))) == mods and os.path.getmtime(mods[0]) == stamp
+
+
 def test_compile_errors_come_back_with_the_compilers_log(monkeypatch, tmp_path):
     import ctypes as C
     opts = jit.rtc_options()
