@@ -296,7 +296,7 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     last_event_ms = [0.0]
@@ -311,6 +311,8 @@ def main():
             for _ in range(steps):
                 fn()
             ev_b.record(stream)
+            while not ev_b.query():          # (poll for the last step: a blocking wait adds the scheduler's wake-up to the host clock -- 40-140 us,
+                pass                         #  2-7 us per step of the driver's 20-step run; the fence below then returns at once)
             fence()
             dt = time.perf_counter() - t0
             last_event_ms[0] = ev_a.elapsed_time(ev_b)
