@@ -61,6 +61,13 @@ constexpr int rd_tri_row(int e) { int x = 0; while ((x + 1) * (x + 2) / 2 <= e) 
 __device__ __forceinline__ double rd_sel01(bool c) { return __hiloint2double(c ? 0x3FF00000 : 0, 0); }
 __device__ __forceinline__ double rd_keep(bool c, double v) { return __hiloint2double(c ? __double2hiint(v) : 0, c ? __double2loint(v) : 0); }
 
+// A slot entry by a BYTE offset out of a lane record (LaneH / LaneC hold byte offsets in 16 bits: the address is ONE add with a word
+// select -- v_add_u32_sdwa -- instead of an unpack, a shift and an add)
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ double rd_at(const lds_double* S, unsigned short byte_off) {
+  return *reinterpret_cast<const lds_double*>(reinterpret_cast<const lds_char*>(S) + byte_off);
+}
+
 // Operand registers over entries [LO, HI) of an LDS array: register k holds base[16 (R0 + k) + lr] in lane lr of every row
 // (base differs from row to row: each row's own segment)
 template <int LO, int HI>
@@ -160,6 +167,14 @@ __device__ void rd_lane_setup(unsigned int* out, int rec) {
       for (int c = 0; c < N; c++) L.hr[jj][c] = (unsigned short)(mine ? hofs(jj, row, c) : ZERO);
     }
   }
+  // (byte offsets: rd_at)
+  for (int k = 0; k < X::NJC; k++) L.jc[k] = (unsigned short)(8 * L.jc[k]);
+  for (int jj = 0; jj < CS; jj++) {
+    L.gs[jj] = (unsigned short)(8 * L.gs[jj]);
+    for (int c = 0; c < N; c++) L.hr[jj][c] = (unsigned short)(8 * L.hr[jj][c]);
+  }
+  for (int i = 0; i < K; i++)
+    for (int c = 0; c < N; c++) L.hc[i][c] = (unsigned short)(8 * L.hc[i][c]);
   for (int k = 0; k < X::NQH * 4; k++) out[(k >> 2) * (X::NRECH * 4) + rec * 4 + (k & 3)] = u.w[k];
 }
 template <class Ode, class D, int ZERO>
@@ -170,7 +185,7 @@ __device__ void rd_lane_setup_c(unsigned int* out, int rec) {      // (the C rec
   const int jr = rec, i0 = jr < X::OR ? jr / X::n : 0, r0 = jr < X::OR ? jr - i0 * X::n : 0;
   for (int aa = 0; aa < X::N; aa++) {
     const int jp = jr < X::OR ? Ode::JPOS[r0 * X::N + aa] : -1;
-    u.c.jo[aa] = (unsigned short)(jp >= 0 ? D::w_IJ + i0 * D::NZJ + jp : ZERO);
+    u.c.jo[aa] = (unsigned short)(8 * (jp >= 0 ? D::w_IJ + i0 * D::NZJ + jp : ZERO));   // (byte offset: rd_at)
   }
   unsigned int* const base = out + X::NQH * 4 * X::NRECH;
   for (int k = 0; k < X::NQC * 4; k++) base[(k >> 2) * (X::NRECC * 4) + rec * 4 + (k & 3)] = u.w[k];
@@ -208,6 +223,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
   //     agx[r] = sum_i hE_i w_i(r) g^_i[a(r)] + sum_j g_j[cc(r)] + sum_i C_ij(r) lam_i[cc(r)] -/+ FB on the rows t_0 / t_f
   // (g_j = J_j^T w_j carries the B and D parts: LGLDefects.h:369-374, :512), FB from the terms the ODE phases left (ResDims::x_FBL).
   constexpr bool UNITC = ResDims<D>::UNITC && LEVEL >= 2;
+  static_assert(ResDims<D>::SLOT * 8 < 65536, "the lane records hold byte offsets into a slot in 16 bits (rd_at)");
   typedef __attribute__((ext_vector_type(2))) unsigned int u2;
   typedef __attribute__((ext_vector_type(4))) unsigned int u4;
   const LglTab& ctab = d_lgl_tab[D::TAB];                           // compile-time indices: scalar loads
@@ -294,7 +310,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       fbv.load(Sl);
       double jcv[X::NJC];
 #pragma unroll
-      for (int k = 0; k < X::NJC; k++) jcv[k] = S[L.jc[k]];
+      for (int k = 0; k < X::NJC; k++) jcv[k] = rd_at(S, L.jc[k]);
       double tsh[K], hhb[K];
 #pragma unroll
       for (int i = 0; i < K; i++) hw[i] = h * L.wE[i], tsh[i] = L.tsg * (h * ctab.E[i]), hhb[i] = h * h * (p == 0 ? L.bE[i] : ctab.E[i]);
@@ -331,7 +347,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       ih.load(Sl);
       double gsum = 0.0;
 #pragma unroll
-      for (int jj = 0; jj < CS; jj++) gsum += S[L.gs[jj]];
+      for (int jj = 0; jj < CS; jj++) gsum += rd_at(S, L.gs[jj]);
       double hsp[K], tse[K];
 #pragma unroll
       for (int i = 0; i < K; i++) hsp[i] = 0.0, tse[i] = L.tsg * ctab.E[i];
@@ -342,7 +358,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
         constexpr int aa = decltype(A)::value;
         rd_for<K>([&](auto I) {
           constexpr int i = decltype(I)::value;
-          M[i][aa] = hw[i] * S[L.hc[i][aa]];
+          M[i][aa] = hw[i] * rd_at(S, L.hc[i][aa]);
           ig.template fm<D::w_Ig + i * N + aa>(M[i][aa], tse[i]);
           if constexpr (aa < n) ig.template fm<D::w_Ig + i * N + aa>(hsp[i], d[i][aa]);
         });
@@ -435,7 +451,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       if constexpr (c < P0) {
         constexpr int j = c / q, cc = c - j * q;
         if constexpr (cc == T) return (j == 0) ? w_t0 : ((j == CS - 1) ? w_tf : 0.0);
-        else return S[L.hr[j][cc]];                    // (the cardinal Hessian entry: the sum starts from it -- a read, not a read and an add)
+        else return rd_at(S, L.hr[j][cc]);                    // (the cardinal Hessian entry: the sum starts from it -- a read, not a read and an add)
       } else {
         double acc = 0.0;
 #pragma unroll
@@ -452,14 +468,14 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
         } else if constexpr (s < K + n) {
           constexpr int aa = s - K, jp = Ode::JPOS[aa * N + cc];
           if constexpr (jp >= 0) cj.template fm<D::w_CJ + j * NZJ + jp>(acc, BM[j][aa]);
-        } else if constexpr (s == K + n) { if constexpr (cc == T) acc += S[L.hr[j][cc]]; }
+        } else if constexpr (s == K + n) { if constexpr (cc == T) acc += rd_at(S, L.hr[j][cc]); }
         else if constexpr (s == K + n + 1) cg.template fm<D::w_Cg + j * N + cc>(acc, tg);
       } else {
         constexpr int pc = c - P0;
         if constexpr (s < CS * n) {
           constexpr int j = s / n, aa = s - j * n, jp = Ode::JPOS[aa * N + q + pc];
           if constexpr (jp >= 0) cj.template fm<D::w_CJ + j * NZJ + jp>(acc, BM[j][aa]);
-        } else if constexpr (s < CS * n + CS) acc += S[L.hr[s - CS * n][q + pc]];
+        } else if constexpr (s < CS * n + CS) acc += rd_at(S, L.hr[s - CS * n][q + pc]);
         else if constexpr (s < CS * n + 2 * CS) cg.template fm<D::w_Cg + (s - CS * n - CS) * N + q + pc>(acc, tg);
       }
     };
@@ -519,7 +535,7 @@ __device__ __forceinline__ void rowdpp_dense(const EvalArgs& a, const lds_double
       const double hE = h * tabL[oE + i0];
       double M[N];
 #pragma unroll
-      for (int aa = 0; aa < N; aa++) M[aa] = hE * S[recC.jo[aa]];
+      for (int aa = 0; aa < N; aa++) M[aa] = hE * rd_at(S, recC.jo[aa]);
       // FB = E f^ . l + sum_j f_j . BM_j = (sum_j D_i0j f_j[r0] + E_i0 f^_i0[r0]) + sum_a FB_i0[a] M[a]
       double fb = sdv;
 #pragma unroll
